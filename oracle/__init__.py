@@ -1,0 +1,27 @@
+"""CPU oracle for the ERC conversation-graph training step.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it, and there only as the checker / the timed CPU baseline.
+The product path (``erc_amd`` + ``libercgraft.so``) never imports this package
+and raises if the HIP library is missing.
+
+What it is: a plain PyTorch-CPU fp32 restatement of the reference's hot path
+(sailist/emotion-recognition-in-conversation, ``track_mm/{cogmen,dagerc,mmgcn,
+dgcn}.py`` and their ``*_models.py`` / ``*_utils.py``), structurally faithful
+to the reference including its host-side per-edge Python graph construction,
+so that it doubles as the "reference CPU path" timed next to the GPU number.
+Every function cites the reference file:line it follows.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * graph construction (window edges / relation ids / DAG adjacency / speaker
+    mask), ERCCollate batch layout, DAG-ERC end-to-end logits+grads, MMGCN
+    graph model, DialogueGCN EdgeAtt / vendored RGCNConv / classifier, the
+    vendored encoder layer: PINNED by golden vectors produced by importing the
+    reference's own modules in the build container
+    (``tests/golden/make_golden.py``, fixtures committed as ``.npz``).
+  * torch_geometric ``RGCNConv`` (mean), ``TransformerConv`` (heads=1) and
+    ``GraphConv`` are third-party, unpinned (``requirements.txt:12``) and not
+    installed: restated here from their published formulae ->
+    "parity unpinned" for those three operators.
+"""

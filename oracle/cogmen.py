@@ -1,0 +1,77 @@
+"""Oracle: COGMEN forward / loss on CPU, fp32 (track_mm/cogmen.py:61-160).
+
+Structure-faithful: per-edge python graph construction, the
+computed-and-discarded 2-layer Transformer encoder (cogmen.py:145-147 applies
+every module of ``self.rnn`` to the RAW input, so only ``rnn.1`` -- the
+Linear(D,100) -- reaches the logits), per-relation RGCN loop.
+``state_dict`` keys mirror the reference module.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .graph import window_graph_loop
+from .pyg import RGCNConvMean, TransformerConv1
+
+
+def pick_heads(input_size, num_head=17):
+    """First h in [6, num_head) dividing input_size (cogmen.py:86-92)."""
+    for h in range(6, num_head):
+        if input_size % h == 0:
+            return h
+    raise AssertionError(input_size)
+
+
+class GNN(nn.Module):
+    """cogmen.py:61-74.  num_relations is 2*2**2 = 8 whatever the dataset
+    (COGMENModule never forwards its n_speakers, cogmen.py:114)."""
+
+    def __init__(self, g_dim, h1_dim, h2_dim, n_speakers=2):
+        super().__init__()
+        self.conv1 = RGCNConvMean(g_dim, h1_dim, 2 * n_speakers ** 2)
+        self.conv2 = TransformerConv1(h1_dim, h2_dim)
+        self.bn = nn.BatchNorm1d(h2_dim)
+        self.relu = nn.LeakyReLU()
+
+    def forward(self, x, edge_index, edge_type):
+        x = self.conv1(x, edge_index, edge_type)
+        return self.relu(self.bn(self.conv2(x, edge_index)))
+
+
+class COGMENOracle(nn.Module):
+    def __init__(self, input_size, hidden_size=100, num_head=17, n_speakers=2,
+                 n_classes=6, dead_encoder=True):
+        super().__init__()
+        self.n_speakers = n_speakers
+        self.dead_encoder = dead_encoder
+        layer = nn.TransformerEncoderLayer(d_model=input_size, nhead=pick_heads(input_size, num_head),
+                                           dropout=0.5, batch_first=True)
+        encoder = nn.TransformerEncoder(layer, num_layers=2, enable_nested_tensor=False)
+        self.rnn = nn.ModuleList([encoder, nn.Linear(input_size, hidden_size)])
+        self.gcn = GNN(hidden_size, hidden_size, hidden_size)
+        self.cls = nn.Sequential(nn.Linear(100, 100), nn.ReLU(), nn.Dropout(p=0.5),
+                                 nn.Linear(100, n_classes))
+
+    def forward(self, input_tensor, speaker_tensor, text_length, *args, **kwargs):
+        node_features = input_tensor
+        for mod in self.rnn:  # each module sees the raw input (cogmen.py:146-147)
+            if mod is self.rnn[0] and not self.dead_encoder:
+                continue
+            node_features = mod(input_tensor)
+        x, edge_index, edge_type, _ = window_graph_loop(
+            node_features, text_length, speaker_tensor, 5, 5, self.n_speakers)
+        self.last_graph = (edge_index, edge_type)
+        out = self.gcn(x, edge_index, edge_type)
+        return self.cls(out), x
+
+
+def cogmen_train_step(model, optim, batch):
+    """track_mm/cogmen.py:179-195 without the lumo plumbing."""
+    ys = batch["label"]
+    logits, _ = model(**batch)
+    loss = F.cross_entropy(logits, ys)
+    optim.zero_grad()
+    loss.backward()
+    optim.step()
+    acc = torch.eq(logits.argmax(dim=-1), ys).float().mean()
+    return loss.detach(), acc

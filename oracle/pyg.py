@@ -1,0 +1,102 @@
+"""Oracle: restatement of the three torch_geometric operators on the path.
+
+torch_geometric is a third-party dependency of the reference, NOT vendored,
+NOT version-pinned (requirements.txt:12 is a bare ``torch_geometric``) and not
+installed here.  These are restated from the published operator definitions
+(PyG 2.x docs) and structurally cross-checked against the vendored 1.4.2
+``MessagePassing.propagate`` in models/rgcn.py:188-221 (gather
+x[edge_index[0]] -> message -> scatter at edge_index[1] -> update).
+PARITY UNPINNED for these three operators: the reference holds no test or
+golden vector at this boundary.
+
+Call sites: track_mm/cogmen.py:65-66,71-72 (RGCNConv, TransformerConv);
+track_mm/dgcn_models.py:42,46 (GraphConv).
+"""
+import math
+
+import torch
+from torch import nn
+
+
+def scatter_sum(src, index, n):
+    out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+    return out.index_add(0, index, src)
+
+
+class RGCNConvMean(nn.Module):
+    """x'_i = sum_r mean_{j in N_r(i)} x_j @ W_r + x_i @ root + bias.
+
+    PyG RGCNConv(in, out, num_relations) defaults: aggr='mean', no bases /
+    blocks, root_weight, bias.  Parameters ``weight [R,in,out]``, ``root
+    [in,out]``, ``bias [out]`` (Appendix A of SURVEY.md).  Edge types >=
+    num_relations are ignored (PyG loops ``for i in range(num_relations)``).
+    Init: glorot(weight), glorot(root), zeros(bias).
+    """
+
+    def __init__(self, in_channels, out_channels, num_relations):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_relations = num_relations
+        self.weight = nn.Parameter(torch.empty(num_relations, in_channels, out_channels))
+        self.root = nn.Parameter(torch.empty(in_channels, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        for w in (self.weight, self.root):
+            a = math.sqrt(6.0 / (w.size(-2) + w.size(-1)))
+            nn.init.uniform_(w, -a, a)
+
+    def forward(self, x, edge_index, edge_type):
+        n = x.size(0)
+        out = torch.zeros(n, self.out_channels, dtype=x.dtype)
+        src, dst = edge_index[0], edge_index[1]
+        for r in range(self.num_relations):  # per-relation loop, as PyG does
+            sel = edge_type == r
+            if not bool(sel.any()):
+                continue
+            s, d = src[sel], dst[sel]
+            summed = scatter_sum(x[s], d, n)
+            cnt = scatter_sum(torch.ones(s.numel(), dtype=x.dtype), d, n).clamp(min=1)
+            out = out + (summed / cnt[:, None]) @ self.weight[r]
+        return out + x @ self.root + self.bias
+
+
+class TransformerConv1(nn.Module):
+    """PyG TransformerConv(in, out, heads=1, concat=True, beta=False,
+    dropout=0, edge_dim=None, root_weight=True):
+    alpha_ij = softmax_{j in N(i)} (W_q x_i + b_q).(W_k x_j + b_k) / sqrt(out),
+    out_i = sum_j alpha_ij (W_v x_j + b_v) + W_skip x_i + b_skip; the softmax
+    groups by TARGET node edge_index[1]."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.out_channels = out_channels
+        self.lin_key = nn.Linear(in_channels, out_channels)
+        self.lin_query = nn.Linear(in_channels, out_channels)
+        self.lin_value = nn.Linear(in_channels, out_channels)
+        self.lin_skip = nn.Linear(in_channels, out_channels)
+
+    def forward(self, x, edge_index):
+        n = x.size(0)
+        src, dst = edge_index[0], edge_index[1]
+        q, k, v = self.lin_query(x), self.lin_key(x), self.lin_value(x)
+        score = (q[dst] * k[src]).sum(-1) / math.sqrt(self.out_channels)
+        mx = torch.full((n,), -float("inf"), dtype=x.dtype).scatter_reduce(
+            0, dst, score.detach(), reduce="amax", include_self=True)
+        ex = torch.exp(score - mx[dst])
+        den = scatter_sum(ex, dst, n)
+        alpha = ex / (den[dst] + 1e-16)
+        out = scatter_sum(alpha[:, None] * v[src], dst, n)
+        return out + self.lin_skip(x)
+
+
+class GraphConvAdd(nn.Module):
+    """PyG GraphConv(in, out, aggr='add'): x'_i = W_rel sum_{j->i} x_j + b +
+    W_root x_i (lin_rel has the bias, lin_root has none)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin_rel = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_root = nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x, edge_index):
+        agg = scatter_sum(x[edge_index[0]], edge_index[1], x.size(0))
+        return self.lin_rel(agg) + self.lin_root(x)

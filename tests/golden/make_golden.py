@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE's own importable leaf
+modules on CPU fp32 in the build container.
+
+Run once, here (never on the GPU box: /root/reference does not exist there):
+
+    python tests/golden/make_golden.py [--ref /root/reference]
+
+Outputs small ``.npz`` fixtures next to this file.  Fixtures are DATA (inputs,
+parameters, expected outputs); no reference source text is stored.  The stub
+modules below are this repo's own code: they stand in for third-party /
+framework packages the reference imports at module scope but that the hot-path
+``nn.Module``s never touch (lumo, fire-based params, dbrecord, dataset
+registry) and for two absent third-party numeric packages, for which only a
+minimal shim is provided:
+  * ``torch_scatter.scatter_add`` -> ``index_add_`` (needed by the vendored
+    models/rgcn.py:12,37);
+  * ``torch_geometric.nn`` -> placeholder classes (module construction only;
+    their forward is never called here - those operators stay "parity
+    unpinned", see oracle/pyg.py).
+torch-1.11 -> torch-2.10 drift handled here, not in the reference:
+  * contrib/nn.py layers are called one after another by this script instead
+    of through nn.TransformerEncoder (which now passes ``is_causal``);
+  * mmgcn_models.py:634 ``adj[idx] = dia_sim`` relied on legacy
+    sequence-as-tuple indexing; the module is loaded with that one statement
+    read as ``adj[tuple(idx)] = dia_sim`` (in memory only).
+"""
+import argparse
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+
+# ----------------------------------------------------------------------------
+# stubs
+# ----------------------------------------------------------------------------
+class _Anything:
+    """Attribute sink: any attribute / call / subclassing works."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+
+def _stub_module(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []  # behave as a package
+
+    def _getattr(attr, _m=m):
+        if attr.startswith("__"):
+            raise AttributeError(attr)
+        cls = type(attr, (_Anything,), {})
+        setattr(_m, attr, cls)
+        return cls
+
+    m.__getattr__ = _getattr
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs(ref):
+    class CollateBase:
+        def __init__(self, params=None):
+            self.params = params
+
+    def _base():
+        class _Base:
+            def __init__(self, *a, **k):
+                pass
+
+            def iparams(self):
+                pass
+        return _Base
+
+    cb = _stub_module("lumo.callbacks")
+    _stub_module("lumo", CollateBase=CollateBase, Trainer=_base(), TrainerParams=_base(), callbacks=cb)
+    _stub_module("lumo.data")
+    _stub_module("lumo.core")
+    _stub_module("lumo.contrib")
+    _stub_module("lumo.contrib.torch")
+    spec = importlib.util.spec_from_file_location(
+        "lumo.contrib.torch.tensor", os.path.join(ref, "lumo/contrib/torch/tensor.py"))
+    real = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(real)  # the real onehot (mmbase.py:15)
+    sys.modules["lumo.contrib.torch.tensor"] = real
+    _stub_module("dbrecord")
+    _stub_module("mmdatasets")
+    _stub_module("mmdatasets.erc_dataset")
+    _stub_module("mmdatasets.dataset_utils", DataParams=_base())
+    _stub_module("models.module_utils", ModelParams=_base())
+    _stub_module("contrib.make_optim")
+
+    def scatter_add(src, index, dim=0, out=None, dim_size=None):
+        assert dim == 0
+        res = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype)
+        return res.index_add_(0, index, src)
+
+    _stub_module("torch_scatter", scatter_add=scatter_add)
+
+    class _Placeholder(torch.nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    _stub_module("torch_geometric")
+    _stub_module("torch_geometric.nn", RGCNConv=_Placeholder, TransformerConv=_Placeholder,
+                 GraphConv=_Placeholder)
+
+
+def load_with_patch(ref, modname, relpath, old, new):
+    """Load a reference module from its source text with one statement
+    rewritten in memory (torch-1.11 indexing semantics, see module docstring)."""
+    path = os.path.join(ref, relpath)
+    with open(path) as fh:
+        text = fh.read()
+    assert text.count(old) == 1, (relpath, old)
+    text = text.replace(old, new)
+    mod = types.ModuleType(modname)
+    mod.__file__ = path
+    mod.__package__ = modname.rpartition(".")[0]
+    sys.modules[modname] = mod
+    exec(compile(text, path, "exec"), mod.__dict__)
+    return mod
+
+
+# ----------------------------------------------------------------------------
+# synthetic inputs (our generator; shapes of SURVEY.md 8d)
+# ----------------------------------------------------------------------------
+def t2n(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-34s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def gen_collate(ref):
+    from erc_amd.synthetic import make_dialogues
+    mmbase = importlib.import_module("track_mm.mmbase")
+    for tag, S, dims in (("s2", 2, dict(a=3, t=5, v=4)), ("s9", 9, dict(a=2, t=3, v=6))):
+        dialogs = make_dialogues(5, dims, n_speakers=S, n_classes=6, min_len=2, max_len=9, seed=11)
+        samples = [[d] for d in dialogs]  # lumo DatasetBuilder yields 1-lists (builder.py:100-101)
+        for modality in ("atv", "tv", "a"):
+            for batch_first in (True, False):
+                for onehot in (False, True):
+                    p = types.SimpleNamespace(batch_first=batch_first, speaker_onehot=onehot, n_classes=6,
+                                              n_speakers=S, modality=modality)
+                    out = mmbase.ERCCollate(p)(samples)
+                    arrs = {k: v for k, v in t2n({k: v for k, v in out.items() if torch.is_tensor(v)}).items()}
+                    save("collate_%s_%s_bf%d_oh%d" % (tag, modality, batch_first, onehot),
+                         seed=11, **{"out_" + k: v for k, v in arrs.items()})
+
+
+def gen_window_graph(ref):
+    """cogmen_utils.batch_graphify (wp=wf=5, S=2) and dgcn-style window 10 with S=9."""
+    cu = importlib.import_module("track_mm.cogmen_utils")
+    from oracle.graph import relation_table, canonical_edges
+    g = torch.Generator().manual_seed(5)
+    for tag, S, wp, wf, lens in (
+            ("cogmen_s2_w5", 2, 5, 5, [1, 2, 3, 6, 11, 12, 17, 30]),
+            ("dgcn_s9_w10", 9, 10, 10, [1, 4, 10, 11, 21, 22, 33]),
+            ("asym_s3_w2_4", 3, 2, 4, [1, 2, 5, 9, 14])):
+        B, T = len(lens), max(lens)
+        lengths = torch.tensor(lens)
+        spk = torch.randint(0, S, (B, T), generator=g)
+        for b, L in enumerate(lens):
+            spk[b, L:] = 0
+        feats = torch.randn(B, T, 4, generator=g)
+        x, ei, et, cnt = cu.batch_graphify(feats, lengths, spk, wp, wf, relation_table(S))
+        ei_s, et_s = canonical_edges(ei.numpy(), et.numpy())
+        save("graph_" + tag, lengths=lengths.numpy(), speakers=spk.numpy(), wp=wp, wf=wf, n_speakers=S,
+             features=feats.numpy(), x=x.numpy(), edge_index=ei_s, edge_type=et_s, edge_count=cnt.numpy())
+
+
+GENERATORS = {"collate": gen_collate, "window_graph": gen_window_graph}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(4)
+    install_stubs(args.ref)
+    # the repo has its own ``track_mm`` plugin package: bind the reference's
+    # packages explicitly so that ``track_mm.*`` / ``contrib.*`` / ``models.*``
+    # resolve to /root/reference inside THIS process only.
+    for pkg in ("track_mm", "contrib", "models"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(args.ref, pkg)]
+        sys.modules[pkg] = m
+    for name, fn in GENERATORS.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        print("==", name)
+        fn(args.ref)
+
+
+if __name__ == "__main__":
+    main()
