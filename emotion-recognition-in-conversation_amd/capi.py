@@ -1,0 +1,188 @@
+"""ctypes binding of libercgraft.so (include/ercgraft.h).
+
+PyTorch is plumbing here: tensors own device memory, ``data_ptr()`` and the
+current stream handle are passed straight through the C-ABI.  There is NO
+fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libercgraft.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+_SIGS = {
+    "erc_abi_version": (C.c_int, []),
+    "erc_last_error": (C.c_char_p, []),
+    "erc_window_graph_build": (C.c_int, [_vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _i] + [_vp] * 13 + [_vp]),
+    "erc_gemm_f32": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp, _i64,
+                               _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
+    "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
+                                 _i64, _vp]),
+    "erc_slab_reduce": (C.c_int, [_vp, _i, _i64, _vp, _i, _i, _vp, _i64, _vp]),
+    "erc_slab_reduce_batched": (C.c_int, [_vp, _vp, _vp, _i, _i64, _vp]),
+    "erc_rgcn_mean_fwd": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "erc_rgcn_mean_bwd": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "erc_tconv_attn_fwd": (C.c_int, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp]),
+    "erc_tconv_attn_bwd_target": (C.c_int, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "erc_tconv_attn_bwd_source": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "erc_bn_ws_floats": (C.c_int64, [_i]),
+    "erc_bn_lrelu_fwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _vp, _vp, _i, _vp, _vp]),
+    "erc_bn_lrelu_bwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "erc_cross_entropy": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp]),
+    "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp]),
+    "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class ErcGraftError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into lib/libercgraft.so (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise ErcGraftError("building libercgraft.so failed")
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ErcGraftError(
+                "libercgraft.so not found at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU / PyTorch fallback for the hot path)" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError = symbol missing: fail loudly
+            fn.restype, fn.argtypes = res, args
+        if handle.erc_abi_version() != 1:
+            raise ErcGraftError("libercgraft ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def _check(code, name):
+    if code != 0:
+        raise ErcGraftError("%s failed (%d): %s" % (name, code, lib().erc_last_error().decode()))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ErcGraftError("libercgraft operands must live on the GPU (got a %s tensor)" % t.device)
+
+
+# --------------------------------------------------------------------------- wrappers
+def window_graph_build(lengths, speakers, spk_sb, spk_st, B, T, wp, wf, S, n_cap, e_cap, g, edge_index=None,
+                       edge_type=None):
+    _dev(lengths, speakers)
+    _check(lib().erc_window_graph_build(
+        ptr(lengths), ptr(speakers), spk_sb, spk_st, B, T, wp, wf, S, n_cap, e_cap,
+        ptr(g["node_off"]), ptr(g["node_row"]), ptr(g["node_spk"]), ptr(g["in_ptr"]), ptr(g["in_src"]),
+        ptr(g["in_typ"]), ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]), ptr(g["out_eid"]),
+        ptr(edge_index), ptr(edge_type), ptr(g["counts"]), stream()), "erc_window_graph_build")
+
+
+def gemm_f32(A, lda, a_kmajor, a_gather, B, ldb, b_kmajor, b_gather, Cmat, ldc, M, N, K, split_k=1, c_slab=0,
+             ones_col=0, bias_out=None, bias_slab=0, bias=None, act=0, aux=None, ldaux=0, act_scale=1.0,
+             drop_p=0.0, rng_state=None, accumulate=0):
+    _dev(A, B, Cmat)
+    _check(lib().erc_gemm_f32(ptr(A), lda, a_kmajor, ptr(a_gather), ptr(B), ldb, b_kmajor, ptr(b_gather),
+                              ptr(Cmat), ldc, M, N, K, split_k, c_slab, ones_col, ptr(bias_out), bias_slab,
+                              ptr(bias), act, ptr(aux), ldaux, act_scale, drop_p, ptr(rng_state), accumulate,
+                              stream()), "erc_gemm_f32")
+
+
+def gemm_bf16x(A, lda, a_kmajor, a_gather, B, ldb, b_kmajor, b_gather, x_is_a, Cmat, ldc, M, N, K, split_k=1,
+               c_slab=0, ones_col=0, bias_out=None, bias_slab=0):
+    _dev(A, B, Cmat)
+    _check(lib().erc_gemm_bf16x(ptr(A), lda, a_kmajor, ptr(a_gather), ptr(B), ldb, b_kmajor, ptr(b_gather), x_is_a,
+                                ptr(Cmat), ldc, M, N, K, split_k, c_slab, ones_col, ptr(bias_out), bias_slab,
+                                stream()), "erc_gemm_bf16x")
+
+
+def slab_reduce(slabs, S, stride, bias, n_cols, act, out, numel):
+    _check(lib().erc_slab_reduce(ptr(slabs), S, stride, ptr(bias), n_cols, act, ptr(out), numel, stream()),
+           "erc_slab_reduce")
+
+
+def slab_reduce_batched(ws, dst, jobs, n_jobs, max_numel):
+    _check(lib().erc_slab_reduce_batched(ptr(ws), ptr(dst), ptr(jobs), n_jobs, max_numel, stream()),
+           "erc_slab_reduce_batched")
+
+
+def rgcn_mean_fwd(x, ldx, F, R, N, g, Mout, ldm, inv_cnt):
+    _check(lib().erc_rgcn_mean_fwd(ptr(x), ldx, F, R, N, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
+                                   ptr(Mout), ldm, ptr(inv_cnt), stream()), "erc_rgcn_mean_fwd")
+
+
+def rgcn_mean_bwd(dM, ldm, F, R, N, g, inv_cnt, dx, lddx):
+    _check(lib().erc_rgcn_mean_bwd(ptr(dM), ldm, F, R, N, ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]),
+                                   ptr(inv_cnt), ptr(dx), lddx, stream()), "erc_rgcn_mean_bwd")
+
+
+def tconv_attn_fwd(qkvs, ld, F, N, scale, g, out, ldo, alpha):
+    _check(lib().erc_tconv_attn_fwd(ptr(qkvs), ld, F, N, scale, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(out), ldo,
+                                    ptr(alpha), stream()), "erc_tconv_attn_fwd")
+
+
+def tconv_attn_bwd(qkvs, ld, F, N, scale, g, alpha, dout, lddo, dqkvs, dscore):
+    _check(lib().erc_tconv_attn_bwd_target(ptr(qkvs), ld, F, N, scale, ptr(g["in_ptr"]), ptr(g["in_src"]),
+                                           ptr(alpha), ptr(dout), lddo, ptr(dqkvs), ptr(dscore), stream()),
+           "erc_tconv_attn_bwd_target")
+    _check(lib().erc_tconv_attn_bwd_source(ptr(qkvs), ld, F, N, ptr(g["out_ptr"]), ptr(g["out_dst"]),
+                                           ptr(g["out_eid"]), ptr(alpha), ptr(dscore), ptr(dout), lddo, ptr(dqkvs),
+                                           stream()), "erc_tconv_attn_bwd_source")
+
+
+def bn_ws_floats(F):
+    return int(lib().erc_bn_ws_floats(F))
+
+
+def bn_lrelu_fwd(x, ldx, N, F, gamma, beta, rmean, rvar, momentum, eps, slope, training, saved, y, ldy, ws):
+    _check(lib().erc_bn_lrelu_fwd(ptr(x), ldx, N, F, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
+                                  slope, int(training), ptr(saved), ptr(y), ldy, ptr(ws), stream()),
+           "erc_bn_lrelu_fwd")
+
+
+def bn_lrelu_bwd(x, ldx, N, F, gamma, beta, saved, slope, dy, lddy, dx, lddx, dgamma, dbeta, ws):
+    _check(lib().erc_bn_lrelu_bwd(ptr(x), ldx, N, F, ptr(gamma), ptr(beta), ptr(saved), slope, ptr(dy), lddy,
+                                  ptr(dx), lddx, ptr(dgamma), ptr(dbeta), ptr(ws), stream()), "erc_bn_lrelu_bwd")
+
+
+def cross_entropy(logits, ld, Cn, n_rows, row_map, labels, weight, grad_scale, dlogits, lddl, stats):
+    _check(lib().erc_cross_entropy(ptr(logits), ld, Cn, n_rows, ptr(row_map), ptr(labels), ptr(weight), grad_scale,
+                                   ptr(dlogits), lddl, ptr(stats), stream()), "erc_cross_entropy")
+
+
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_norm, gnorm, state):
+    _check(lib().erc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale,
+                               clip_norm, ptr(gnorm), ptr(state), stream()), "erc_adam_step")
+
+
+def grad_norm(g, n, grad_scale, gnorm, ws):
+    _check(lib().erc_grad_norm(ptr(g), n, grad_scale, ptr(gnorm), ptr(ws), stream()), "erc_grad_norm")

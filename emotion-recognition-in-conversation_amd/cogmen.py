@@ -1,0 +1,297 @@
+"""COGMEN on the MI355X hot path (drop-in for track_mm/cogmen.py:61-195).
+
+``COGMENModule`` keeps the reference's constructor signature, ``state_dict``
+keys and ``forward(**batch) -> (logits [N,C],
+features [N,100])`` contract; every numeric step runs in libercgraft.so
+(capi.py) -- there is no PyTorch fallback.
+
+The 2-layer Transformer encoder ``rnn.0`` is dead in the reference's forward
+(cogmen.py:145-147 feeds the RAW input to each module of ``self.rnn`` in turn
+and keeps only the last result): its parameters are carried in the state dict
+and never touched, exactly as in the reference where their grad stays None.
+
+Forward chain (N valid utterances, F = 100, R = 8 relations):
+  K1 graph  -> H0 = X[node_row] W1^T + b1 -> M = relation means | self  [N,9F]
+  -> H1 = M [W_0..W_7;W_root] + b -> QKVS = H1 [Wq;Wk;Wv;Ws]^T + b
+  -> H2 = segmented-softmax attention + skip -> H3 = LeakyReLU(BN(H2))
+  -> Z = dropout(relu(H3 Wc0^T + b)) -> logits = Z Wc3^T + b -> CE
+and the hand-written backward of each stage in reverse, weight gradients
+accumulated as split-K slabs that one batched kernel reduces into the flat
+gradient buffer (deterministic; no float atomics).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import capi
+from .engine import FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
+    matmul_wgrad_io
+
+F_HID = 100
+WP = WF = 5           # cogmen.py:153-154
+N_REL = 8             # GNN(n_speakers=2) always: cogmen.py:62-64,114
+
+
+def pick_heads(input_size, num_head):
+    for h in range(6, num_head):       # cogmen.py:86-92
+        if input_size % h == 0:
+            return h
+    raise AssertionError(input_size)
+
+
+class _RGCNParams(nn.Module):
+    """Parameter holder with torch_geometric RGCNConv's names / shapes / init (glorot, zeros)."""
+
+    def __init__(self, cin, cout, R):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(R, cin, cout))
+        self.root = nn.Parameter(torch.empty(cin, cout))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        for w in (self.weight, self.root):
+            a = math.sqrt(6.0 / (w.size(-2) + w.size(-1)))
+            nn.init.uniform_(w, -a, a)
+
+
+class _TConvParams(nn.Module):
+    """torch_geometric TransformerConv(heads=1) names: lin_key / lin_query / lin_value / lin_skip."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.lin_key = nn.Linear(cin, cout)
+        self.lin_query = nn.Linear(cin, cout)
+        self.lin_value = nn.Linear(cin, cout)
+        self.lin_skip = nn.Linear(cin, cout)
+
+
+class _GNNParams(nn.Module):
+    def __init__(self, g_dim, h1_dim, h2_dim, n_speakers=2):
+        super().__init__()
+        self.conv1 = _RGCNParams(g_dim, h1_dim, 2 * n_speakers ** 2)
+        self.conv2 = _TConvParams(h1_dim, h2_dim)
+        self.bn = nn.BatchNorm1d(h2_dim)
+
+
+class COGMENModule(nn.Module):
+    def __init__(self, input_size, hidden_size, num_head, n_speakers, n_classes, compute="f32", seed=1):
+        super().__init__()
+        assert hidden_size == F_HID, "the reference hard-codes 100 (cogmen.py:116-122)"
+        self.input_size, self.n_speakers, self.n_classes = input_size, n_speakers, n_classes
+        self.compute = compute
+        layer = nn.TransformerEncoderLayer(d_model=input_size, nhead=pick_heads(input_size, num_head),
+                                           dropout=0.5, batch_first=True)
+        encoder = nn.TransformerEncoder(layer, num_layers=2, enable_nested_tensor=False)  # dead (see module doc)
+        self.rnn = nn.ModuleList([encoder, nn.Linear(input_size, hidden_size)])
+        self.gcn = _GNNParams(hidden_size, hidden_size, hidden_size)
+        self.cls = nn.Sequential(nn.Linear(100, 100), nn.ReLU(), nn.Dropout(p=0.5), nn.Linear(100, n_classes))
+        self.drop_p = 0.5
+        self.flat = None
+        self._ws = {}
+        self._seed = seed
+
+    # ------------------------------------------------------------------ setup
+    def live_groups(self):
+        g, c = self.gcn, self.cls
+        named = lambda mod, pre, names: [(pre + n, getattr(mod, n)) for n in names]
+        return [
+            [("rnn.1.weight", self.rnn[1].weight)], [("rnn.1.bias", self.rnn[1].bias)],
+            named(g.conv1, "gcn.conv1.", ["weight", "root"]), [("gcn.conv1.bias", g.conv1.bias)],
+            [("gcn.conv2.lin_query.weight", g.conv2.lin_query.weight), ("gcn.conv2.lin_key.weight", g.conv2.lin_key.weight),
+             ("gcn.conv2.lin_value.weight", g.conv2.lin_value.weight), ("gcn.conv2.lin_skip.weight", g.conv2.lin_skip.weight)],
+            [("gcn.conv2.lin_query.bias", g.conv2.lin_query.bias), ("gcn.conv2.lin_key.bias", g.conv2.lin_key.bias),
+             ("gcn.conv2.lin_value.bias", g.conv2.lin_value.bias), ("gcn.conv2.lin_skip.bias", g.conv2.lin_skip.bias)],
+            [("gcn.bn.weight", g.bn.weight)], [("gcn.bn.bias", g.bn.bias)],
+            [("cls.0.weight", c[0].weight)], [("cls.0.bias", c[0].bias)],
+            [("cls.3.weight", c[3].weight)], [("cls.3.bias", c[3].bias)],
+        ]
+
+    def finalize(self, device):
+        """Move to ``device`` and pack the live parameters (call once, after loading a state dict)."""
+        self.to(device)
+        self.flat = FlatParams(self.live_groups(), device)
+        self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
+        return self
+
+    def _workspace(self, B, T, N, device):
+        key = (B, T, N)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        E = N * (WP + WF + 1)
+        C, F, D = self.n_classes, F_HID, self.input_size
+        g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E),
+                 in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
+        ws = dict(
+            g=g, E=E,
+            H0=f32(N, F), M=f32(N, 9 * F), inv_cnt=f32(N, N_REL), H1=f32(N, F), QKVS=f32(N, 4 * F),
+            alpha=f32(E), H2=f32(N, F), H3=f32(N, F), Z=f32(N, F), logits=f32(N, C),
+            bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=f32(4),
+            dlogits=f32(N, C), dZ=f32(N, F), dH3=f32(N, F), dH2=f32(N, F), dQKVS=f32(N, 4 * F), dscore=f32(E),
+            dH1=f32(N, F), dM=f32(N, 9 * F), dH0=f32(N, F),
+        )
+        # slab space: forward split-K of the input projection + every weight gradient, sized generously
+        slab = 16 * N * F + 8 * (F * D + 9 * F * F + 4 * F * F + 2 * F * F) + (1 << 20)
+        ws["planner"] = GemmPlanner(device, slab)
+        ws["jobs"] = None
+        self._ws[key] = ws
+        return ws
+
+    # ---------------------------------------------------------------- forward
+    def _shape(self, input_tensor, text_length, label):
+        B, T = input_tensor.shape[0], input_tensor.shape[1]
+        if label is not None:
+            N = int(label.shape[0])          # label is [N]: no device sync needed
+        else:
+            N = int(text_length.sum().item())
+        return B, T, N
+
+    def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training):
+        fp, dev = self.flat, x.device
+        ws = self._workspace(B, T, N, dev)
+        g, pl = ws["g"], ws["planner"]
+        pl.reset()
+        F, C, D = F_HID, self.n_classes, self.input_size
+        x_bf16 = x.dtype == torch.bfloat16
+        capi.window_graph_build(text_length, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
+                                B, T, WP, WF, self.n_speakers, N, ws["E"], g)
+        linear_fwd(pl, x, D, g["node_row"], fp.w("rnn.1.weight"), fp.w("rnn.1.bias"), ws["H0"], F, N, F, D,
+                   x_bf16=x_bf16)
+        capi.rgcn_mean_fwd(ws["H0"], F, F, N_REL, N, g, ws["M"], 9 * F, ws["inv_cnt"])
+        # H1 = M @ [W_r ; W_root] + bias : B operand is the [9F, F] k-major stack conv1.weight|conv1.root
+        Wcat = fp.w("gcn.conv1.weight")
+        S = pl.split_for(N, F, 9 * F)
+        if S == 1:
+            capi.gemm_f32(ws["M"], 9 * F, 0, None, Wcat, F, 1, None, ws["H1"], F, N, F, 9 * F,
+                          bias=fp.w("gcn.conv1.bias"))
+        else:
+            src = pl.take(S * N * F)
+            capi.gemm_f32(ws["M"], 9 * F, 0, None, Wcat, F, 1, None, pl.ws[src:], F, N, F, 9 * F, split_k=S,
+                          c_slab=N * F)
+            capi.slab_reduce(pl.ws[src:], S, N * F, fp.w("gcn.conv1.bias"), F, 0, ws["H1"], N * F)
+        linear_fwd(pl, ws["H1"], F, None, fp.w("gcn.conv2.lin_query.weight"), fp.w("gcn.conv2.lin_query.bias"),
+                   ws["QKVS"], 4 * F, N, 4 * F, F)
+        capi.tconv_attn_fwd(ws["QKVS"], 4 * F, F, N, 1.0 / math.sqrt(F), g, ws["H2"], F, ws["alpha"])
+        bn = self.gcn.bn
+        capi.bn_lrelu_fwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), bn.running_mean,
+                          bn.running_var, bn.momentum, bn.eps, 0.01, training, ws["bn_saved"], ws["H3"], F,
+                          ws["bn_ws"])
+        if training:
+            bn.num_batches_tracked += 1
+        p = self.drop_p if training else 0.0
+        linear_fwd(pl, ws["H3"], F, None, fp.w("cls.0.weight"), fp.w("cls.0.bias"), ws["Z"], F, N, F, F,
+                   act=3 if p > 0 else 1, drop_p=p, rng=self.rng_state)
+        linear_fwd(pl, ws["Z"], F, None, fp.w("cls.3.weight"), fp.w("cls.3.bias"), ws["logits"], C, N, C, F)
+        return ws
+
+    def forward(self, input_tensor, speaker_tensor, text_length, *args, label=None, **kwargs):
+        if self.flat is None:
+            raise capi.ErcGraftError("call COGMENModule.finalize(device) before forward")
+        B, T, N = self._shape(input_tensor, text_length, label)
+        ws = self._forward_impl(input_tensor, speaker_tensor, text_length, B, T, N, self.training)
+        return ws["logits"], ws["H0"]
+
+    # --------------------------------------------------------------- training
+    def loss_and_grads(self, batch, class_weight=None):
+        """Forward in the module's current mode, cross entropy, full backward into ``flat.grad``.
+        Returns the stats tensor {loss, #correct, weight sum} (device, no sync)."""
+        x, spk, lens, ys = batch["input_tensor"], batch["speaker_tensor"], batch["text_length"], batch["label"]
+        B, T, N = self._shape(x, lens, ys)
+        training = self.training
+        ws = self._forward_impl(x, spk, lens, B, T, N, training)
+        fp, g, pl = self.flat, ws["g"], ws["planner"]
+        F, C, D = F_HID, self.n_classes, self.input_size
+        x_bf16 = x.dtype == torch.bfloat16
+        capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
+        p = self.drop_p if training else 0.0
+        # head
+        capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
+                      act=2, aux=ws["Z"], ldaux=F, act_scale=1.0 / (1.0 - p))
+        linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
+                     fp.offsets["cls.3.bias"])
+        capi.gemm_f32(ws["dZ"], F, 0, None, fp.w("cls.0.weight"), F, 1, None, ws["dH3"], F, N, F, F)
+        linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
+                     fp.offsets["cls.0.bias"])
+        # BatchNorm + LeakyReLU
+        capi.bn_lrelu_bwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
+                          ws["dH3"], F, ws["dH2"], F, fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"), ws["bn_ws"])
+        # TransformerConv
+        capi.tconv_attn_bwd(ws["QKVS"], 4 * F, F, N, 1.0 / math.sqrt(F), g, ws["alpha"], ws["dH2"], F,
+                            ws["dQKVS"], ws["dscore"])
+        capi.gemm_f32(ws["dQKVS"], 4 * F, 0, None, fp.w("gcn.conv2.lin_query.weight"), F, 1, None, ws["dH1"], F,
+                      N, F, 4 * F)
+        linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1"], F, None, 4 * F, F, N,
+                     fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"])
+        # RGCN: dM = dH1 @ Wcat^T ; dWcat = M^T dH1 ; dbias = colsum(dH1)
+        capi.gemm_f32(ws["dH1"], F, 0, None, fp.w("gcn.conv1.weight"), F, 0, None, ws["dM"], 9 * F, N, 9 * F, F)
+        matmul_wgrad_io(pl, ws["M"], 9 * F, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
+                        fp.offsets["gcn.conv1.bias"])
+        capi.rgcn_mean_bwd(ws["dM"], 9 * F, F, N_REL, N, g, ws["inv_cnt"], ws["dH0"], F)
+        # input projection (no gradient into the features)
+        linear_wgrad(pl, ws["dH0"], F, x, D, g["node_row"], F, D, N, fp.offsets["rnn.1.weight"],
+                     fp.offsets["rnn.1.bias"], x_bf16=x_bf16)
+        if ws["jobs"] is None or ws["jobs"].shape[0] != len(pl.jobs):
+            ws["jobs"] = pl.job_table()
+        capi.slab_reduce_batched(pl.ws, fp.grad, ws["jobs"], len(pl.jobs), pl.max_numel)
+        return ws["stats"]
+
+    def last_graph(self, B, T, N):
+        return self._ws[(B, T, N)]["g"]
+
+
+def build_graph_tensors(text_length, speaker_tensor, wp, wf, n_speakers, n_nodes=None, explicit=True):
+    """Device graph builder as a standalone op: returns the CSR dict plus, when ``explicit``, the
+    reference-shaped ``edge_index [2,E]`` / ``edge_type [E]`` int64 tensors (cogmen_utils.py:139-142),
+    in canonical (target, source) order."""
+    dev = text_length.device
+    if speaker_tensor.dim() != 2:
+        raise capi.ErcGraftError("speaker_tensor must be [B,T] integer ids")
+    B, T = speaker_tensor.shape
+    N = int(n_nodes) if n_nodes is not None else int(text_length.sum().item())
+    w = (wp if wp >= 0 else T) + (wf if wf >= 0 else T) + 1
+    E = max(1, N * min(w, T))
+    i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+    g = dict(node_off=i32(B + 1), node_row=i32(max(N, 1)), node_spk=i32(max(N, 1)), in_ptr=i32(N + 1),
+             in_src=i32(E), in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E),
+             counts=i32(2))
+    ei = torch.zeros(2, E, dtype=torch.int64, device=dev) if explicit else None
+    et = torch.zeros(E, dtype=torch.int64, device=dev) if explicit else None
+    capi.window_graph_build(text_length, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
+                            B, T, wp, wf, n_speakers, N, E, g, ei, et)
+    g["e_cap"] = E
+    return g, ei, et
+
+
+class COGMENTrainer:
+    """train_step / to_logits of track_mm/cogmen.py:163-195 without lumo."""
+
+    def __init__(self, params, device):
+        self.params, self.device = params, torch.device(device)
+        torch.manual_seed(params.seed)
+        self.model = COGMENModule(input_size=params.hidden_all, hidden_size=100,
+                                  num_head=params.get("num_heads", 17), n_speakers=params.n_speakers,
+                                  n_classes=params.n_classes, compute=params.get("compute", "f32"),
+                                  seed=params.seed).finalize(self.device)
+        o = params.optim
+        self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.weight_decay,
+                               decoupled=(o.name == "AdamW"), seed=params.seed)
+        self.model.rng_state = self.optim.rng_state   # dropout offset advances with the optimizer step
+        self.class_weight = None
+
+    def to_logits(self, batch):
+        return self.model(**batch)[0]
+
+    def prepare_batch(self, batch):
+        out = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        if self.model.compute == "bf16":
+            out["input_tensor"] = out["input_tensor"].to(torch.bfloat16)
+        return out
+
+    def train_step(self, batch):
+        """forward + CE + backward + (DP all-reduce) + Adam.  Returns the device stats tensor."""
+        self.model.train()
+        stats = self.model.loss_and_grads(batch, self.class_weight)
+        scale = all_reduce_grads(self.model.flat)
+        self.optim.step(grad_scale=scale)
+        return stats

@@ -1,0 +1,130 @@
+// K1: device-side window-graph construction, one workgroup per dialogue.
+//
+// Replaces the reference's host-side python loops (one .item() per edge
+// endpoint): track_mm/cogmen_utils.py:109-172, track_mm/dgcn_models.py:51-118.
+// All offsets come from closed forms, so there is no
+// sort, no atomics and no second pass: each dialogue writes its own slice of
+// both CSRs and of the reference-shaped int64 edge list in canonical
+// (target-major, then source) order.
+#include "erc_common.h"
+
+namespace {
+
+// sum_{q<p} deg(q) with deg(q) = min(L-1, q+fwd) - max(0, q-back) + 1
+__device__ __forceinline__ int window_prefix(int p, int L, int back, int fwd) {
+    int a = min(p, max(0, L - fwd));  // #q<p whose upper end is not clipped
+    int c = max(0, p - back);         // #q<p whose lower end is not clipped
+    return a * (a - 1) / 2 + a * fwd + (p - a) * (L - 1) - c * (c - 1) / 2 + p;
+}
+
+__global__ __launch_bounds__(256) void window_graph_kernel(
+    const int64_t* __restrict__ lengths, const int64_t* __restrict__ speakers, int64_t spk_sb, int64_t spk_st,
+    int B, int T, int wp, int wf, int S, int n_cap, int e_cap,
+    int32_t* __restrict__ node_off, int32_t* __restrict__ node_row, int32_t* __restrict__ node_spk,
+    int32_t* __restrict__ in_ptr, int32_t* __restrict__ in_src, int32_t* __restrict__ in_typ,
+    int32_t* __restrict__ out_ptr, int32_t* __restrict__ out_dst, int32_t* __restrict__ out_typ,
+    int32_t* __restrict__ out_eid, int64_t* __restrict__ edge_index, int64_t* __restrict__ edge_type,
+    int32_t* __restrict__ counts) {
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ int red_n[256];
+    __shared__ int red_e[256];
+
+    // exclusive prefix of node / edge counts over the dialogues before b
+    int acc_n = 0, acc_e = 0;
+    for (int i = tid; i < b; i += 256) {
+        int Li = (int)lengths[i];
+        acc_n += Li;
+        acc_e += window_prefix(Li, Li, wf, wp);
+    }
+    red_n[tid] = acc_n;
+    red_e[tid] = acc_e;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            red_n[tid] += red_n[tid + o];
+            red_e[tid] += red_e[tid + o];
+        }
+        __syncthreads();
+    }
+    const int noff = red_n[0];
+    const int eoff = red_e[0];
+    const int L = (int)lengths[b];
+    const int E_b = window_prefix(L, L, wf, wp);
+
+    if (tid == 0) {
+        node_off[b] = noff;
+        if (b == B - 1) {
+            node_off[B] = noff + L;
+            counts[0] = noff + L;
+            counts[1] = eoff + E_b;
+            if (noff + L <= n_cap) {
+                in_ptr[noff + L] = eoff + E_b;
+                out_ptr[noff + L] = eoff + E_b;
+            }
+        }
+    }
+    if (noff + L > n_cap || eoff + E_b > e_cap) return;  // capacity guard (host checks counts)
+
+    const int64_t* spk = speakers + (int64_t)b * spk_sb;
+    for (int p = tid; p < L; p += 256) {
+        const int n = noff + p;
+        const int sp = (int)spk[(int64_t)p * spk_st];
+        node_row[n] = b * T + p;
+        node_spk[n] = sp;
+
+        // in-edges of target k = p: sources j in [p-wf, p+wp]
+        {
+            const int lo = max(0, p - wf), hi = min(L - 1, p + wp);
+            const int base = eoff + window_prefix(p, L, wf, wp);
+            in_ptr[n] = base;
+            for (int j = lo; j <= hi; ++j) {
+                const int e = base + (j - lo);
+                const int sj = (int)spk[(int64_t)j * spk_st];
+                const int ty = 2 * (sj * S + sp) + (j < p ? 0 : 1);
+                in_src[e] = noff + j;
+                in_typ[e] = ty;
+                if (edge_index) {
+                    edge_index[e] = noff + j;
+                    edge_index[(int64_t)e_cap + e] = n;
+                }
+                if (edge_type) edge_type[e] = ty;
+            }
+        }
+        // out-edges of source j = p: targets k in [p-wp, p+wf]
+        {
+            const int lo = max(0, p - wp), hi = min(L - 1, p + wf);
+            const int base = eoff + window_prefix(p, L, wp, wf);
+            out_ptr[n] = base;
+            for (int k = lo; k <= hi; ++k) {
+                const int e = base + (k - lo);
+                const int sk = (int)spk[(int64_t)k * spk_st];
+                out_dst[e] = noff + k;
+                out_typ[e] = 2 * (sp * S + sk) + (p < k ? 0 : 1);
+                out_eid[e] = eoff + window_prefix(k, L, wf, wp) + (p - max(0, k - wf));
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int erc_window_graph_build(const int64_t* lengths, const int64_t* speakers, int64_t spk_sb, int64_t spk_st,
+                                      int B, int T, int wp, int wf, int n_speakers, int n_cap, int e_cap,
+                                      int32_t* node_off, int32_t* node_row, int32_t* node_spk,
+                                      int32_t* in_ptr, int32_t* in_src, int32_t* in_typ,
+                                      int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ, int32_t* out_eid,
+                                      int64_t* edge_index, int64_t* edge_type, int32_t* counts, void* stream) {
+    ERC_REQUIRE(B > 0 && T > 0 && n_speakers > 0, "window_graph_build: bad sizes B=%d T=%d S=%d", B, T, n_speakers);
+    ERC_REQUIRE(lengths && speakers && node_off && node_row && node_spk && in_ptr && in_src && in_typ && out_ptr &&
+                    out_dst && out_typ && out_eid && counts,
+                "window_graph_build: null pointer");
+    ERC_REQUIRE(wp >= -1 && wf >= -1, "window_graph_build: window must be >= -1");
+    if (wp < 0) wp = T;  // -1 = unbounded past   (cogmen_utils.py:158-163)
+    if (wf < 0) wf = T;  // -1 = unbounded future
+    hipLaunchKernelGGL(window_graph_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, lengths, speakers, spk_sb,
+                       spk_st, B, T, wp, wf, n_speakers, n_cap, e_cap, node_off, node_row, node_spk, in_ptr, in_src,
+                       in_typ, out_ptr, out_dst, out_typ, out_eid, edge_index, edge_type, counts);
+    ERC_LAUNCH_CHECK("window_graph_build");
+    return ERC_OK;
+}

@@ -1,0 +1,112 @@
+// S4: fused optimizer over the flat live-parameter buffer, and the library's
+// error plumbing.
+#include <stdarg.h>
+
+#include "erc_common.h"
+
+static thread_local char g_err[512] = "";
+
+extern "C" void erc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* erc_last_error(void) { return g_err; }
+extern "C" int erc_abi_version(void) { return ERC_ABI_VERSION; }
+
+namespace {
+
+// torch.optim.Adam / AdamW update (torch/optim/adam.py single-tensor path):
+//   g += wd*p (Adam)  |  p *= 1 - lr*wd (AdamW)
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+//   p -= lr/(1-b1^t) * m / ( sqrt(v)/sqrt(1-b2^t) + eps )
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float wd, int decoupled,
+                                                   float grad_scale, float clip_norm,
+                                                   const float* __restrict__ gnorm, const int64_t* state) {
+    const int64_t step = state[0] + 1;  // state is bumped by adam_bump_kernel after this launch
+    const float bc1 = 1.0f - powf(b1, (float)step);
+    const float bc2 = 1.0f - powf(b2, (float)step);
+    const float step_size = lr / bc1;
+    const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    float gs = grad_scale;
+    if (clip_norm > 0.f) {
+        const float coef = clip_norm / (gnorm[0] + 1e-6f);
+        if (coef < 1.f) gs *= coef;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float pi = p[i], gi = g[i] * gs;
+        if (decoupled)
+            pi *= 1.0f - lr * wd;
+        else if (wd != 0.f)
+            gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+__global__ void adam_bump_kernel(int64_t* state) {
+    state[0] += 1;  // optimizer step
+    state[1] += 1;  // RNG offset: a fresh dropout mask next step
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float scale,
+                                                    double* __restrict__ partial) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = (double)(g[i] * scale);
+        acc += x * x;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void norm_final_kernel(const double* __restrict__ partial, int np,
+                                                         float* __restrict__ gnorm) {
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) gnorm[0] = (float)sqrt(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+}  // namespace
+
+extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                             float clip_norm, const float* gnorm, int64_t* state, void* stream) {
+    ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
+    ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       decoupled, grad_scale, clip_norm, gnorm, state);
+    ERC_LAUNCH_CHECK("adam_step");
+    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, state);
+    ERC_LAUNCH_CHECK("adam_bump");
+    return ERC_OK;
+}
+
+extern "C" int erc_grad_norm(const float* g, int64_t n, float grad_scale, float* gnorm, float* ws, void* stream) {
+    ERC_REQUIRE(g && gnorm && ws && n > 0, "grad_norm: bad arguments");
+    ERC_REQUIRE(((uintptr_t)ws & 7) == 0, "grad_norm: ws must be 8-byte aligned");
+    int grid = (int)((n + 255) / 256);
+    if (grid > 512) grid = 512;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, st, g, n, grad_scale, (double*)ws);
+    ERC_LAUNCH_CHECK("grad_norm.sumsq");
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, grid, gnorm);
+    ERC_LAUNCH_CHECK("grad_norm.final");
+    return ERC_OK;
+}

@@ -1,0 +1,192 @@
+"""Host-side plumbing shared by the four ERC plugins.
+
+* ``FlatParams``  : the LIVE parameters of a module packed into one fp32 device
+  buffer (plus flat grad / Adam moment buffers of the same layout).  The
+  ``nn.Parameter``s of the module become views into it, so ``state_dict`` keys
+  and shapes stay those of the reference while the optimizer and the RCCL
+  gradient all-reduce see one contiguous array.  Parameters that never receive
+  a gradient in the reference (dead encoder, unused heads) are
+  left out: torch.optim skips ``grad is None`` parameters, so they never change.
+* ``GemmPlanner`` : split-K policy + slab workspace + the batched slab-reduce
+  job table for weight gradients.
+* ``FusedAdam``   : one erc_adam_step over the flat buffer (optionally after a
+  gradient all-reduce over RCCL).
+"""
+import math
+
+import torch
+
+from . import capi
+
+ALIGN = 64  # floats: every group starts on a 256-byte boundary
+
+
+class FlatParams:
+    def __init__(self, groups, device):
+        """``groups``: list of lists of (name, nn.Parameter).  Members of a group are
+        laid out back to back (so e.g. q|k|v|skip weights form one [4F,F] matrix)."""
+        self.device = torch.device(device)
+        self.offsets, self.shapes = {}, {}
+        off = 0
+        for grp in groups:
+            off = (off + ALIGN - 1) // ALIGN * ALIGN
+            for name, p in grp:
+                self.offsets[name] = off
+                self.shapes[name] = tuple(p.shape)
+                off += p.numel()
+        self.numel = (off + ALIGN - 1) // ALIGN * ALIGN
+        self.data = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.data)
+        self.exp_avg = torch.zeros_like(self.data)
+        self.exp_avg_sq = torch.zeros_like(self.data)
+        self.params = {}
+        with torch.no_grad():
+            for grp in groups:
+                for name, p in grp:
+                    view = self.view(self.data, name)
+                    view.copy_(p.detach().to(self.device, torch.float32))
+                    p.data = view
+                    p.grad = self.view(self.grad, name)
+                    self.params[name] = p
+        self.live_numel = sum(p.numel() for p in self.params.values())
+
+    def view(self, flat, name):
+        off = self.offsets[name]
+        n = 1
+        for s in self.shapes[name]:
+            n *= s
+        return flat[off:off + n].view(self.shapes[name])
+
+    def w(self, name):
+        return self.view(self.data, name)
+
+    def g(self, name):
+        return self.view(self.grad, name)
+
+
+class GemmPlanner:
+    """Chooses split-K per GEMM and hands out slab space from one workspace."""
+
+    TARGET_WG = 512
+    MIN_CHUNKS = 8
+    BK = 32
+
+    def __init__(self, device, ws_floats):
+        self.device = device
+        self.ws = torch.empty(ws_floats, dtype=torch.float32, device=device)
+        self.reset()
+
+    def reset(self):
+        self.cursor = 0
+        self.jobs = []
+        self.max_numel = 0
+
+    def split_for(self, M, N, K, bk=None, min_chunks=None):
+        bk = bk or self.BK
+        min_chunks = self.MIN_CHUNKS if min_chunks is None else min_chunks
+        tiles = -(-N // 32) * -(-M // 64)
+        nchunk = -(-K // bk)
+        want = max(1, -(-self.TARGET_WG // tiles))
+        return max(1, min(want, nchunk // min_chunks if nchunk >= min_chunks else 1))
+
+    def take(self, n):
+        start = (self.cursor + ALIGN - 1) // ALIGN * ALIGN
+        if start + n > self.ws.numel():
+            raise capi.ErcGraftError("slab workspace too small (%d + %d > %d)" % (start, n, self.ws.numel()))
+        self.cursor = start + n
+        return start
+
+    def add_job(self, src, stride, S, numel, dst_off):
+        self.jobs.append((src, stride, S, numel, dst_off))
+        self.max_numel = max(self.max_numel, numel)
+
+    def job_table(self):
+        return torch.tensor(self.jobs, dtype=torch.int64, device=self.device)
+
+
+def linear_fwd(pl, x, ldx, gather, W, bias, out, ldo, M, N, K, act=0, drop_p=0.0, rng=None, x_bf16=False):
+    """out[M,N] = act(x[M,K] @ W[N,K]^T + bias): nn.Linear forward.  Split-K + slab reduce when K is long."""
+    if x_bf16:
+        S = pl.split_for(M, N, K, bk=64, min_chunks=4)
+        src = pl.take(S * M * N)
+        capi.gemm_bf16x(x, ldx, 0, gather, W, K, 0, None, 1, pl.ws[src:], N, M, N, K, split_k=S, c_slab=M * N)
+        capi.slab_reduce(pl.ws[src:], S, M * N, bias, N, act, out, M * N)
+        assert ldo == N
+        return
+    S = pl.split_for(M, N, K)
+    if S == 1:
+        capi.gemm_f32(x, ldx, 0, gather, W, K, 0, None, out, ldo, M, N, K, bias=bias, act=act,
+                      act_scale=(1.0 / (1.0 - drop_p) if act == 3 else 1.0), drop_p=drop_p, rng_state=rng)
+    else:
+        assert act in (0, 1) and ldo == N
+        src = pl.take(S * M * N)
+        capi.gemm_f32(x, ldx, 0, gather, W, K, 0, None, pl.ws[src:], N, M, N, K, split_k=S, c_slab=M * N)
+        capi.slab_reduce(pl.ws[src:], S, M * N, bias, N, act, out, M * N)
+
+
+def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off, x_bf16=False):
+    """dW[n_out,n_in] = dy^T x and db[n_out] = colsum(dy) into slabs; registers the reduce jobs.
+    (nn.Linear weight layout [out,in].)"""
+    if x_bf16:
+        S = pl.split_for(n_out, n_in + 1, n_rows, bk=64, min_chunks=2)
+    else:
+        S = pl.split_for(n_out, n_in + 1, n_rows, min_chunks=2)
+    src_w = pl.take(S * n_out * n_in)
+    src_b = pl.take(S * n_out)
+    if x_bf16:
+        capi.gemm_bf16x(dy, lddy, 1, None, x, ldx, 1, gather, 0, pl.ws[src_w:], n_in, n_out, n_in, n_rows,
+                        split_k=S, c_slab=n_out * n_in, ones_col=1, bias_out=pl.ws[src_b:], bias_slab=n_out)
+    else:
+        capi.gemm_f32(dy, lddy, 1, None, x, ldx, 1, gather, pl.ws[src_w:], n_in, n_out, n_in, n_rows,
+                      split_k=S, c_slab=n_out * n_in, ones_col=1, bias_out=pl.ws[src_b:], bias_slab=n_out)
+    pl.add_job(src_w, n_out * n_in, S, n_out * n_in, w_off)
+    if b_off is not None:
+        pl.add_job(src_b, n_out, S, n_out, b_off)
+
+
+def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off):
+    """dW[n_in,n_out] = x^T dy and db[n_out] = colsum(dy) for [in,out]-stored weights (PyG RGCNConv)."""
+    S = pl.split_for(n_in + 1, n_out, n_rows, min_chunks=2)
+    src_w = pl.take(S * n_in * n_out)
+    src_b = pl.take(S * n_out)
+    capi.gemm_f32(x, ldx, 1, None, dy, lddy, 1, None, pl.ws[src_w:], n_out, n_in, n_out, n_rows,
+                  split_k=S, c_slab=n_in * n_out, ones_col=2, bias_out=pl.ws[src_b:], bias_slab=n_out)
+    pl.add_job(src_w, n_in * n_out, S, n_in * n_out, w_off)
+    if b_off is not None:
+        pl.add_job(src_b, n_out, S, n_out, b_off)
+
+
+class FusedAdam:
+    """torch.optim.Adam / AdamW semantics on a FlatParams buffer, one launch."""
+
+    def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
+                 clip_norm=0.0, seed=1):
+        self.flat, self.lr, self.betas, self.eps = flat, lr, betas, eps
+        self.weight_decay, self.decoupled, self.clip_norm = weight_decay, decoupled, clip_norm
+        dev = flat.device
+        # {step, rng offset, rng seed}
+        self.state = torch.tensor([0, 0, seed], dtype=torch.int64, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.norm_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
+
+    @property
+    def rng_state(self):
+        return self.state[1:]
+
+    def step(self, grad_scale=1.0):
+        f = self.flat
+        if self.clip_norm > 0:
+            capi.grad_norm(f.grad, f.numel, grad_scale, self.gnorm, self.norm_ws)
+        capi.adam_step(f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, self.lr, self.betas[0], self.betas[1],
+                       self.eps, self.weight_decay, self.decoupled, grad_scale, self.clip_norm,
+                       self.gnorm if self.clip_norm > 0 else None, self.state)
+
+
+def all_reduce_grads(flat):
+    """DP exchange step: one sum all-reduce of the flat live-gradient buffer;
+    the 1/world scaling is folded into the optimizer's grad_scale."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat.grad)
+        return 1.0 / dist.get_world_size()
+    return 1.0

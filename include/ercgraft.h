@@ -1,0 +1,220 @@
+/*
+ * libercgraft -- C-ABI of the MI355X-native ERC conversation-graph hot path.
+ *
+ * The reference (sailist/emotion-recognition-in-conversation) is pure Python:
+ * it has no FFI / operator registry, its plugin boundary is the Python
+ * convention "XModule.forward(**batch) -> (logits, aux)" (SURVEY.md 8b).  This
+ * header is the boundary UNDERNEATH that convention: every entry point replaces
+ * a chain of PyTorch / torch_geometric calls of the reference, cited per
+ * function as file:line under /root/reference.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - the CALLER owns all memory (inputs, outputs, workspaces); no entry point
+ *     allocates, frees or synchronises; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*), so calls are HIP-graph capturable.
+ *   - return value: 0 on success, negative on error (ERC_E_*);
+ *     erc_last_error() returns a static description of the last failure of the
+ *     calling thread.  Nothing throws.
+ *   - matrices are dense row-major fp32 with an explicit leading dimension
+ *     unless stated otherwise; index arrays are int32; the drop-in edge lists
+ *     (edge_index / edge_type) are int64 like the reference's.
+ */
+#ifndef ERCGRAFT_H
+#define ERCGRAFT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ERC_ABI_VERSION 1
+
+#define ERC_OK 0
+#define ERC_E_ARG (-1)     /* bad shape / null pointer / unsupported size */
+#define ERC_E_LAUNCH (-2)  /* hipLaunch failed */
+
+int erc_abi_version(void);
+const char* erc_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * K1  window-graph builder.
+ * Replaces batch_graphify + edge_perms: track_mm/cogmen_utils.py:109-172
+ * (COGMEN, wp=wf=5) and track_mm/dgcn_models.py:51-118 (DialogueGCN,
+ * wp=wf=10); relation id rule track_mm/cogmen.py:124-129 /
+ * cogmen_utils.py:131-137:  type(j->k) = 2*(s_j*S + s_k) + (j<k ? 0 : 1).
+ * Edge j->k exists iff max(0,j-wp) <= k <= min(L-1,j+wf), j,k in one dialogue.
+ *
+ *   lengths   int64 [B]                 text_length
+ *   speakers  int64, element (b,t) at speakers[b*spk_sb + t*spk_st]
+ *             (so both [B,T] and [T,B] layouts are accepted)
+ * outputs (capacities: n_cap >= N = sum(lengths), e_cap >= E)
+ *   node_off  int32 [B+1]   exclusive prefix sum of lengths
+ *   node_row  int32 [n_cap] node -> row b*T+t of the padded [B,T,.] block
+ *   node_spk  int32 [n_cap]
+ *   in_ptr    int32 [n_cap+1], in_src / in_typ int32 [e_cap]:
+ *             CSR by TARGET; edges in canonical (target, then source) order --
+ *             edge e of this CSR is edge e of edge_index / edge_type below
+ *   out_ptr   int32 [n_cap+1], out_dst / out_typ / out_eid int32 [e_cap]:
+ *             CSR by SOURCE; out_eid = position of that edge in the in-CSR
+ *   edge_index int64 [2, e_cap] (row 0 = source j, row 1 = target k) and
+ *   edge_type  int64 [e_cap]: the reference's tensors; either may be NULL
+ *   counts    int32 [2] = {N, E}
+ * Entries beyond N / E are left untouched.
+ */
+int erc_window_graph_build(const int64_t* lengths, const int64_t* speakers, int64_t spk_sb, int64_t spk_st,
+                           int B, int T, int wp, int wf, int n_speakers, int n_cap, int e_cap,
+                           int32_t* node_off, int32_t* node_row, int32_t* node_spk,
+                           int32_t* in_ptr, int32_t* in_src, int32_t* in_typ,
+                           int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ, int32_t* out_eid,
+                           int64_t* edge_index, int64_t* edge_type, int32_t* counts, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K2  dense fp32 GEMM on the matrix cores (v_mfma_f32_16x16x4_f32: exact
+ * fp32 fma chains), C[M,N] = opA(A)[M,K] * opB(B)[K,N].
+ * Replaces every nn.Linear / torch.matmul of the path and their autograd
+ * (e.g. track_mm/cogmen.py:103-105,116-122; dagerc.py:94,98-106).
+ *
+ *   a_kmajor = 0: A(m,k) = A[row(m)*lda + k], row(m) = a_gather ? a_gather[m] : m
+ *   a_kmajor = 1: A(m,k) = A[k*lda + m]
+ *   b_kmajor = 0: B(k,n) = B[n*ldb + k]            ("NT": nn.Linear weight [out,in])
+ *   b_kmajor = 1: B(k,n) = B[row(k)*ldb + n], row(k) = b_gather ? b_gather[k] : k
+ *   a_gather / b_gather (int32) implement the fused gather of the valid rows of
+ *   the padded [B,T,D] feature block (node_row of K1); NULL = identity.
+ *   ones_col = 1: B gets a virtual extra column N of ones; its result
+ *   (sum_k opA(A)[m,k], the bias gradient of an nn.Linear whose dY^T is A)
+ *   goes to bias_out[m].  ones_col = 2: A gets a virtual extra row M of ones;
+ *   its result (sum_k opB(B)[k,n], the bias gradient when dY is B, i.e. for
+ *   [in,out]-stored weights) goes to bias_out[n].
+ *   split_k = S > 1: the K range is cut in S pieces, piece z writes its partial
+ *   product to C + z*c_slab (and bias_out + z*bias_slab); the caller reduces
+ *   (erc_slab_reduce).  bias / act require S == 1.
+ *   epilogue (S == 1): v = acc (+ bias[n]); act 0 none, 1 relu,
+ *     2: v = aux[m*ldaux+n] > 0 ? v*act_scale : 0   (backward of relu+dropout)
+ *     3: relu then inverted dropout with keep-probability 1-drop_p, mask from
+ *        the counter RNG keyed by (rng_state[0] = per-step offset,
+ *        rng_state[1] = seed, element m*N+n); act_scale = 1/(1-drop_p)
+ *   accumulate != 0: C += v instead of C = v.
+ */
+int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t* a_gather,
+                 const float* B, int ldb, int b_kmajor, const int32_t* b_gather,
+                 float* C, int ldc, int M, int N, int K,
+                 int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
+                 const float* bias, int act, const float* aux, int ldaux, float act_scale,
+                 float drop_p, const uint64_t* rng_state, int accumulate, void* stream);
+
+/* Same contract with bf16 operands for the big streamed operand (the padded
+ * feature block): A or B given as bf16 (uint16 storage), the other operand is
+ * converted from fp32 while staging; v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+ *   x_is_a != 0: A is bf16 (forward input projection);  else B is bf16 (wgrad).
+ */
+int erc_gemm_bf16x(const void* A, int lda, int a_kmajor, const int32_t* a_gather,
+                   const void* B, int ldb, int b_kmajor, const int32_t* b_gather, int x_is_a,
+                   float* C, int ldc, int M, int N, int K,
+                   int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
+                   void* stream);
+
+/* out[i] = act( sum_{s<S} slabs[s*slab_stride + i] + (bias ? bias[i % n_cols] : 0) ), i < numel */
+int erc_slab_reduce(const float* slabs, int S, int64_t slab_stride, const float* bias, int n_cols, int act,
+                    float* out, int64_t numel, void* stream);
+
+/* Batched form for weight gradients: job j reduces S[j] slabs of numel[j]
+ * floats at ws + src[j] (stride = stride[j]) into dst + dst_off[j].
+ * `jobs` is a device int64 [n_jobs,5] = {src, stride, S, numel, dst_off}. */
+int erc_slab_reduce_batched(const float* ws, float* dst, const int64_t* jobs, int n_jobs, int64_t max_numel,
+                            void* stream);
+
+/* ------------------------------------------------------------------------
+ * K3  relation-segmented mean aggregation (torch_geometric RGCNConv,
+ * aggr='mean', call site track_mm/cogmen.py:65,71):
+ *   M[i, r*F:(r+1)*F] = mean_{j in N_r(i)} x_j   (0 when N_r(i) is empty)
+ *   M[i, R*F:(R+1)*F] = x_i                       (root term)
+ * so that RGCNConv(x) = M @ [W_0;..;W_{R-1};W_root] + bias is one GEMM.
+ * inv_cnt [N,R] receives 1/|N_r(i)| (0 if empty) for the backward.
+ * One wavefront per target node; edges of relation >= R are ignored (PyG).
+ * F <= 128, R <= 8.
+ */
+int erc_rgcn_mean_fwd(const float* x, int ldx, int F, int R, int N,
+                      const int32_t* in_ptr, const int32_t* in_src, const int32_t* in_typ,
+                      float* Mout, int ldm, float* inv_cnt, void* stream);
+/* dx[j] = sum_{e=(j->i)} dM[i, typ_e*F:..] * inv_cnt[i,typ_e] + dM[j, R*F:..]  (gather over out-edges) */
+int erc_rgcn_mean_bwd(const float* dM, int ldm, int F, int R, int N,
+                      const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_typ,
+                      const float* inv_cnt, float* dx, int lddx, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K4  per-target segmented softmax attention (torch_geometric
+ * TransformerConv(heads=1, root_weight=True), call site
+ * track_mm/cogmen.py:66,72).  qkvs [N, 4F] holds q | k | v | skip per node.
+ *   alpha_e = softmax_{e in in(i)} ( q_i . k_src(e) * scale ),
+ *   out_i   = sum_e alpha_e v_src(e) + skip_i
+ * alpha [E] is kept for the backward (in-CSR order).
+ */
+int erc_tconv_attn_fwd(const float* qkvs, int ld, int F, int N, float scale,
+                       const int32_t* in_ptr, const int32_t* in_src,
+                       float* out, int ldo, float* alpha, void* stream);
+/* backward, target side: dq_i, dskip_i and dscore_e (= dL/d(q.k), scale folded in) */
+int erc_tconv_attn_bwd_target(const float* qkvs, int ld, int F, int N, float scale,
+                              const int32_t* in_ptr, const int32_t* in_src, const float* alpha,
+                              const float* dout, int lddo, float* dqkvs, float* dscore, void* stream);
+/* backward, source side: dk_j = sum_{e out of j} dscore_e q_dst, dv_j = sum alpha_e dout_dst */
+int erc_tconv_attn_bwd_source(const float* qkvs, int ld, int F, int N,
+                              const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                              const float* alpha, const float* dscore, const float* dout, int lddo,
+                              float* dqkvs, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K5  BatchNorm1d (+ LeakyReLU) over the N nodes of this rank
+ * (track_mm/cogmen.py:67-68,72; nn.BatchNorm1d semantics: biased variance for
+ * the normalisation, unbiased for running_var, momentum 0.1, eps 1e-5).
+ *   training != 0: batch statistics; saved[0:F] = mean, saved[F:2F] = rstd;
+ *                  running_mean / running_var updated in place.
+ *   training == 0: running statistics.
+ *   y = leaky_relu(xhat*gamma + beta, slope)      (slope = 1 -> no activation)
+ * ws: >= erc_bn_ws_floats(F) floats of scratch.
+ */
+int64_t erc_bn_ws_floats(int F);
+int erc_bn_lrelu_fwd(const float* x, int ldx, int N, int F, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, float slope,
+                     int training, float* saved, float* y, int ldy, float* ws, void* stream);
+/* dx, dgamma, dbeta from dy (gradient wrt y) ; recomputes xhat and the activation sign from x */
+int erc_bn_lrelu_bwd(const float* x, int ldx, int N, int F, const float* gamma, const float* beta,
+                     const float* saved, float slope, const float* dy, int lddy,
+                     float* dx, int lddx, float* dgamma, float* dbeta, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------
+ * S3  cross entropy (F.cross_entropy: track_mm/cogmen.py:185, mmgcn.py:147,
+ * masked dagerc.py:225-226, class-weighted dgcn.py:124).
+ *   row_map (int32 [n_rows] or NULL): logits row of sample i is row_map[i]
+ *     (DAG-ERC keeps padded [B*T,C] logits; the mask becomes a row map)
+ *   weight (float [C] or NULL): loss = sum w_y nll / sum w_y
+ *   out: stats[0] = loss, stats[1] = #(argmax == y), stats[2] = sum of weights
+ *   dlogits (may be NULL): gradient, same row addressing as logits; rows that
+ *     no sample maps to are NOT written (caller zero-fills when row_map != NULL)
+ */
+int erc_cross_entropy(const float* logits, int ld, int C, int n_rows, const int32_t* row_map,
+                      const int64_t* labels, const float* weight, float grad_scale,
+                      float* dlogits, int lddl, float* stats, void* stream);
+
+/* ------------------------------------------------------------------------
+ * S4  optimizer over the flat live-parameter buffer (torch.optim.Adam /
+ * AdamW, track_mm/cogmen.py:50,187-189; dagerc.py:39,230-231).
+ *   state: device int64 [3] = {step count, RNG offset, RNG seed}; the call
+ *   increments state[0] and state[1] (so state+1 is a valid rng_state).
+ *   clip_norm > 0: grads are scaled by min(1, clip_norm/(gnorm+1e-6)) where
+ *   gnorm[0] was produced by erc_grad_norm (clip_grad_norm_ semantics).
+ *   decoupled != 0 -> AdamW (p *= 1 - lr*wd) else L2 (g += wd*p).
+ *   grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ */
+int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                  float grad_scale, float clip_norm, const float* gnorm, int64_t* state, void* stream);
+/* gnorm[0] = ||g * grad_scale||_2 ; ws >= 1024 floats */
+int erc_grad_norm(const float* g, int64_t n, float grad_scale, float* gnorm, float* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ERCGRAFT_H */

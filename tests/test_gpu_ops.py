@@ -1,0 +1,404 @@
+"""GPU parity tests of the individual libercgraft operators against the CPU oracle
+(oracle/*.py, plain torch fp32/fp64 on the host).  Every call goes through the C-ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from erc_amd import capi as c
+    c.lib()
+    return c
+
+
+def _close(got, want, atol, rtol=1e-5):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    assert bool((err <= tol).all()), "max err %.3e (tol %.1e) at %s" % (
+        float(err.max()), atol, np.unravel_index(int(err.argmax()), err.shape))
+
+
+# ------------------------------------------------------------------ K1 graph
+@pytest.mark.parametrize("name", ["graph_cogmen_s2_w5", "graph_dgcn_s9_w10", "graph_asym_s3_w2_4"])
+def test_window_graph_golden(capi, golden, name):
+    """bit-exact edges / relation ids vs the reference's batch_graphify (golden fixture)."""
+    from erc_amd.cogmen import build_graph_tensors
+    g = golden(name)
+    lengths = torch.from_numpy(g["lengths"]).to(DEV)
+    spk = torch.from_numpy(g["speakers"]).to(DEV)
+    wp, wf, S = int(g["wp"]), int(g["wf"]), int(g["n_speakers"])
+    gr, ei, et = build_graph_tensors(lengths, spk, wp, wf, S)
+    N, E = gr["counts"].cpu().tolist()
+    assert N == int(g["lengths"].sum()) and E == g["edge_index"].shape[1]
+    np.testing.assert_array_equal(ei[:, :E].cpu().numpy(), g["edge_index"])
+    np.testing.assert_array_equal(et[:E].cpu().numpy(), g["edge_type"])
+    _check_csr(gr, g["edge_index"], g["edge_type"], N, E, g["lengths"], spk.shape[1])
+
+
+def _check_csr(gr, ei, et, N, E, lengths, T):
+    in_ptr = gr["in_ptr"][:N + 1].cpu().numpy()
+    np.testing.assert_array_equal(gr["in_src"][:E].cpu().numpy(), ei[0])
+    np.testing.assert_array_equal(gr["in_typ"][:E].cpu().numpy(), et)
+    deg = np.bincount(ei[1], minlength=N)
+    np.testing.assert_array_equal(np.diff(in_ptr), deg)
+    # out-CSR: same edge set grouped by source, out_eid points back into the in-CSR
+    out_ptr = gr["out_ptr"][:N + 1].cpu().numpy()
+    out_dst = gr["out_dst"][:E].cpu().numpy()
+    out_typ = gr["out_typ"][:E].cpu().numpy()
+    out_eid = gr["out_eid"][:E].cpu().numpy()
+    np.testing.assert_array_equal(np.diff(out_ptr), np.bincount(ei[0], minlength=N))
+    src_of = np.repeat(np.arange(N), np.diff(out_ptr))
+    np.testing.assert_array_equal(ei[0][out_eid], src_of)
+    np.testing.assert_array_equal(ei[1][out_eid], out_dst)
+    np.testing.assert_array_equal(et[out_eid], out_typ)
+    assert len(np.unique(out_eid)) == E
+    # node tables
+    off = np.concatenate([[0], np.cumsum(lengths)])
+    np.testing.assert_array_equal(gr["node_off"].cpu().numpy(), off)
+    rows = np.concatenate([b * T + np.arange(L) for b, L in enumerate(lengths)]) if N else np.zeros(0)
+    np.testing.assert_array_equal(gr["node_row"][:N].cpu().numpy(), rows)
+
+
+@pytest.mark.parametrize("B,T,S,wp,wf", [(32, 110, 2, 5, 5), (64, 33, 9, 10, 10), (7, 40, 3, -1, 2), (5, 12, 2, 3, -1),
+                                         (512, 110, 2, 5, 5)])
+def test_window_graph_full_size(capi, B, T, S, wp, wf):
+    """BASELINE-size batches: bit-exact vs the oracle's closed form (itself pinned to the reference)."""
+    from erc_amd.cogmen import build_graph_tensors
+    from oracle.graph import window_graph_closed_form
+    rng = np.random.RandomState(B + T)
+    lengths = rng.randint(1, T + 1, size=B)
+    lengths[0] = T
+    spk = rng.randint(0, S, size=(B, T))
+    gr, ei, et = build_graph_tensors(torch.from_numpy(lengths).to(DEV), torch.from_numpy(spk).to(DEV), wp, wf, S)
+    N, E = gr["counts"].cpu().tolist()
+    ei_c, et_c = window_graph_closed_form(lengths, spk, wp, wf, S)
+    assert N == lengths.sum() and E == ei_c.shape[1]
+    np.testing.assert_array_equal(ei[:, :E].cpu().numpy(), ei_c)
+    np.testing.assert_array_equal(et[:E].cpu().numpy(), et_c)
+    _check_csr(gr, ei_c, et_c, N, E, lengths, T)
+
+
+def test_window_graph_time_major_speakers(capi):
+    """[T,B] speaker layout (MMGCN batch_first=False) through the stride arguments."""
+    from erc_amd.cogmen import build_graph_tensors
+    from oracle.graph import window_graph_closed_form
+    rng = np.random.RandomState(0)
+    lengths = np.array([4, 9, 1, 7])
+    spk = rng.randint(0, 2, size=(4, 9))
+    spk_tb = torch.from_numpy(spk).to(DEV).t().contiguous().t()  # [B,T] view over [T,B] storage
+    assert spk_tb.stride() == (1, 4)
+    gr, ei, et = build_graph_tensors(torch.from_numpy(lengths).to(DEV), spk_tb, 5, 5, 2)
+    N, E = gr["counts"].cpu().tolist()
+    ei_c, et_c = window_graph_closed_form(lengths, spk, 5, 5, 2)
+    np.testing.assert_array_equal(ei[:, :E].cpu().numpy(), ei_c)
+    np.testing.assert_array_equal(et[:E].cpu().numpy(), et_c)
+
+
+# ------------------------------------------------------------------- K2 GEMM
+def _gemm_ref(A, B):
+    return (A.double() @ B.double()).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(70, 100, 1380), (2080, 100, 100), (33, 6, 100), (257, 400, 100), (1, 1, 1),
+                                   (64, 32, 32), (130, 900, 100), (2080, 100, 900)])
+@pytest.mark.parametrize("split", [1, 3])
+def test_gemm_nt_nn(capi, M, N, K, split):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)  # nn.Linear layout
+    bias = torch.randn(N, generator=g)
+    want = _gemm_ref(A, W.t())
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    nchunk = -(-K // 32)
+    S = min(split, nchunk)
+    # NT
+    slabs = torch.zeros(S, M, N, device=DEV)
+    capi.gemm_f32(Ad, K, 0, None, Wd, K, 0, None, slabs, N, M, N, K, split_k=S, c_slab=M * N)
+    _close(slabs.sum(0), want, 2e-4 * math.sqrt(K / 100))
+    # NN with bias + relu epilogue (S == 1)
+    Wk = W.t().contiguous().to(DEV)  # [K,N]
+    out = torch.zeros(M, N, device=DEV)
+    capi.gemm_f32(Ad, K, 0, None, Wk, N, 1, None, out, N, M, N, K, bias=bias.to(DEV), act=1)
+    _close(out, torch.relu(want + bias), 2e-4 * math.sqrt(K / 100))
+    # accumulate
+    capi.gemm_f32(Ad, K, 0, None, Wk, N, 1, None, out, N, M, N, K, accumulate=1)
+    _close(out, torch.relu(want + bias) + want, 4e-4 * math.sqrt(K / 100))
+
+
+@pytest.mark.parametrize("rows,n_out,n_in", [(2080, 100, 1380), (61, 6, 100), (300, 400, 100), (5, 3, 7), (2080, 100, 100)])
+def test_gemm_wgrad_tn(capi, rows, n_out, n_in):
+    """dW = dY^T X (+ bias grad through the ones column), split-K slabs reduced by erc_slab_reduce."""
+    g = torch.Generator().manual_seed(rows + n_out)
+    dY = torch.randn(rows, n_out, generator=g)
+    X = torch.randn(rows, n_in, generator=g)
+    S = min(5, -(-rows // 32))
+    slabs = torch.zeros(S, n_out, n_in, device=DEV)
+    bslabs = torch.zeros(S, n_out, device=DEV)
+    capi.gemm_f32(dY.to(DEV), n_out, 1, None, X.to(DEV), n_in, 1, None, slabs, n_in, n_out, n_in, rows,
+                  split_k=S, c_slab=n_out * n_in, ones_col=1, bias_out=bslabs, bias_slab=n_out)
+    out = torch.zeros(n_out, n_in, device=DEV)
+    capi.slab_reduce(slabs, S, n_out * n_in, None, 0, 0, out, n_out * n_in)
+    tol = 3e-4 * math.sqrt(rows / 100)
+    _close(out, _gemm_ref(dY.t(), X), tol)
+    _close(bslabs.sum(0), dY.double().sum(0).float(), tol)
+    # [in,out]-stored weight (PyG): dW = X^T dY, bias grad through the ones ROW
+    slabs2 = torch.zeros(S, n_in, n_out, device=DEV)
+    bslabs2 = torch.zeros(S, n_out, device=DEV)
+    capi.gemm_f32(X.to(DEV), n_in, 1, None, dY.to(DEV), n_out, 1, None, slabs2, n_out, n_in, n_out, rows,
+                  split_k=S, c_slab=n_out * n_in, ones_col=2, bias_out=bslabs2, bias_slab=n_out)
+    _close(slabs2.sum(0), _gemm_ref(X.t(), dY), tol)
+    _close(bslabs2.sum(0), dY.double().sum(0).float(), tol)
+
+
+def test_gemm_gather_and_unaligned(capi):
+    """fused gather of valid rows of the padded block; leading dimension not a multiple of 4 (MELD D=1242)."""
+    g = torch.Generator().manual_seed(9)
+    for D in (1242, 1380, 37):
+        Xpad = torch.randn(5 * 11, D, generator=g)
+        rows = torch.tensor([0, 1, 2, 11, 12, 22, 23, 24, 25, 33, 44, 45, 54], dtype=torch.int32)
+        W = torch.randn(100, D, generator=g)
+        want = _gemm_ref(Xpad[rows.long()], W.t())
+        out = torch.zeros(len(rows), 100, device=DEV)
+        capi.gemm_f32(Xpad.to(DEV), D, 0, rows.to(DEV), W.to(DEV), D, 0, None, out, 100, len(rows), 100, D)
+        _close(out, want, 2e-4 * math.sqrt(D / 100))
+        dY = torch.randn(len(rows), 100, generator=g)
+        dW = torch.zeros(100, D, device=DEV)
+        capi.gemm_f32(dY.to(DEV), 100, 1, None, Xpad.to(DEV), D, 1, rows.to(DEV), dW, D, 100, D, len(rows))
+        _close(dW, _gemm_ref(dY.t(), Xpad[rows.long()]), 2e-4)
+
+
+def test_gemm_relu_dropout_epilogues(capi):
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 300, 100, 100
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    rng = torch.tensor([7, 123], dtype=torch.int64, device=DEV)
+    Z = torch.zeros(M, N, device=DEV)
+    capi.gemm_f32(A.to(DEV), K, 0, None, W.to(DEV), K, 0, None, Z, N, M, N, K, act=3, act_scale=2.0, drop_p=0.5,
+                  rng_state=rng)
+    Z2 = torch.zeros(M, N, device=DEV)
+    capi.gemm_f32(A.to(DEV), K, 0, None, W.to(DEV), K, 0, None, Z2, N, M, N, K, act=3, act_scale=2.0, drop_p=0.5,
+                  rng_state=rng)
+    assert torch.equal(Z, Z2)  # same (offset, seed) -> same mask
+    relu = torch.relu(_gemm_ref(A, W.t()))
+    kept = Z.cpu() != 0
+    _close(Z.cpu()[kept], 2.0 * relu[kept], 5e-4)
+    frac = float(kept.float().sum() / (relu > 0).float().sum())
+    assert 0.45 < frac < 0.55, frac
+    rng2 = torch.tensor([8, 123], dtype=torch.int64, device=DEV)
+    capi.gemm_f32(A.to(DEV), K, 0, None, W.to(DEV), K, 0, None, Z2, N, M, N, K, act=3, act_scale=2.0, drop_p=0.5,
+                  rng_state=rng2)
+    assert not torch.equal(Z, Z2)  # next step -> fresh mask
+    # act 2: backward of relu+dropout
+    dY = torch.randn(M, 6, generator=g)
+    W3 = torch.randn(6, N, generator=g)
+    dZ = torch.zeros(M, N, device=DEV)
+    capi.gemm_f32(dY.to(DEV), 6, 0, None, W3.to(DEV), N, 1, None, dZ, N, M, N, 6, act=2, aux=Z, ldaux=N, act_scale=2.0)
+    want = torch.where(Z.cpu() > 0, 2.0 * _gemm_ref(dY, W3), torch.zeros(()))
+    _close(dZ, want, 1e-4)
+
+
+@pytest.mark.parametrize("rows,D", [(2080, 1380), (77, 1242), (130, 712), (9, 40)])
+def test_gemm_bf16_feature_operand(capi, rows, D):
+    """bf16 feature block: forward projection and weight gradient vs fp32 math on the SAME bf16-rounded operands."""
+    g = torch.Generator().manual_seed(rows)
+    T = 7
+    Xpad = torch.randn(rows + 20, D, generator=g).to(torch.bfloat16)
+    idx = torch.sort(torch.randperm(rows + 20, generator=g)[:rows]).values.to(torch.int32)
+    W = torch.randn(100, D, generator=g)
+    Wb = W.to(torch.bfloat16).float()
+    Xg = Xpad.float()[idx.long()]
+    S = min(3, -(-D // 64))
+    slabs = torch.zeros(S, rows, 100, device=DEV)
+    capi.gemm_bf16x(Xpad.to(DEV), D, 0, idx.to(DEV), W.to(DEV), D, 0, None, 1, slabs, 100, rows, 100, D, split_k=S,
+                    c_slab=rows * 100)
+    _close(slabs.sum(0), _gemm_ref(Xg, Wb.t()), 3e-4 * math.sqrt(D / 100))
+    dY = torch.randn(rows, 100, generator=g)
+    dYb = dY.to(torch.bfloat16).float()
+    S2 = min(4, -(-rows // 64))
+    wsl = torch.zeros(S2, 100, D, device=DEV)
+    bsl = torch.zeros(S2, 100, device=DEV)
+    capi.gemm_bf16x(dY.to(DEV), 100, 1, None, Xpad.to(DEV), D, 1, idx.to(DEV), 0, wsl, D, 100, D, rows, split_k=S2,
+                    c_slab=100 * D, ones_col=1, bias_out=bsl, bias_slab=100)
+    _close(wsl.sum(0), _gemm_ref(dYb.t(), Xg), 3e-4 * math.sqrt(rows / 100))
+    _close(bsl.sum(0), dYb.double().sum(0).float(), 3e-4 * math.sqrt(rows / 100))
+
+
+# ------------------------------------------------------------- K3 / K4 graph ops
+def _graph_case(seed, B=6, T=17, S=2, wp=5, wf=5):
+    from erc_amd.cogmen import build_graph_tensors
+    rng = np.random.RandomState(seed)
+    lengths = rng.randint(1, T + 1, size=B)
+    lengths[0] = T
+    spk = rng.randint(0, S, size=(B, T))
+    gr, ei, et = build_graph_tensors(torch.from_numpy(lengths).to(DEV), torch.from_numpy(spk).to(DEV), wp, wf, S)
+    N, E = gr["counts"].cpu().tolist()
+    return gr, ei[:, :E].cpu(), et[:E].cpu(), N, E
+
+
+@pytest.mark.parametrize("S", [2, 3])
+def test_rgcn_mean_fwd_bwd(capi, S):
+    """relation-mean aggregation + GEMM == RGCNConv(mean) restatement; S=3 makes relation ids >= 8 that must be ignored."""
+    from oracle.pyg import RGCNConvMean
+    F, R = 100, 8
+    gr, ei, et, N, E = _graph_case(11 + S, S=S)
+    torch.manual_seed(0)
+    conv = RGCNConvMean(F, F, R)
+    with torch.no_grad():
+        conv.bias.uniform_(-0.2, 0.2)
+    x = torch.randn(N, F, requires_grad=True)
+    want = conv(x, ei, et)
+    gout = torch.randn(N, F)
+    want.backward(gout)
+    xd = x.detach().to(DEV)
+    M = torch.zeros(N, (R + 1) * F, device=DEV)
+    inv = torch.zeros(N, R, device=DEV)
+    capi.rgcn_mean_fwd(xd, F, F, R, N, gr, M, (R + 1) * F, inv)
+    Wcat = torch.cat([conv.weight.detach().reshape(R * F, F), conv.root.detach()], 0).to(DEV)
+    out = torch.zeros(N, F, device=DEV)
+    capi.gemm_f32(M, (R + 1) * F, 0, None, Wcat, F, 1, None, out, F, N, F, (R + 1) * F, bias=conv.bias.detach().to(DEV))
+    _close(out, want, 1e-4)
+    # backward: dM = gout Wcat^T ; dx = gather over out-edges
+    dM = torch.zeros(N, (R + 1) * F, device=DEV)
+    capi.gemm_f32(gout.to(DEV), F, 0, None, Wcat, F, 0, None, dM, (R + 1) * F, N, (R + 1) * F, F)
+    dx = torch.zeros(N, F, device=DEV)
+    capi.rgcn_mean_bwd(dM, (R + 1) * F, F, R, N, gr, inv, dx, F)
+    _close(dx, x.grad, 1e-4)
+    dW = torch.zeros((R + 1) * F, F, device=DEV)
+    db = torch.zeros(F, device=DEV)
+    capi.gemm_f32(M, (R + 1) * F, 1, None, gout.to(DEV), F, 1, None, dW, F, (R + 1) * F, F, N, ones_col=2, bias_out=db)
+    _close(dW[:R * F].reshape(R, F, F), conv.weight.grad, 1e-4)
+    _close(dW[R * F:], conv.root.grad, 1e-4)
+    _close(db, conv.bias.grad, 1e-4)
+
+
+def test_tconv_attention_fwd_bwd(capi):
+    from oracle.pyg import TransformerConv1
+    F = 100
+    gr, ei, et, N, E = _graph_case(5)
+    torch.manual_seed(1)
+    conv = TransformerConv1(F, F)
+    x = torch.randn(N, F, requires_grad=True)
+    want = conv(x, ei)
+    gout = torch.randn(N, F)
+    want.backward(gout)
+    Wq = torch.cat([conv.lin_query.weight, conv.lin_key.weight, conv.lin_value.weight, conv.lin_skip.weight], 0).detach()
+    bq = torch.cat([conv.lin_query.bias, conv.lin_key.bias, conv.lin_value.bias, conv.lin_skip.bias], 0).detach()
+    xd = x.detach().to(DEV)
+    qkvs = torch.zeros(N, 4 * F, device=DEV)
+    capi.gemm_f32(xd, F, 0, None, Wq.to(DEV), F, 0, None, qkvs, 4 * F, N, 4 * F, F, bias=bq.to(DEV))
+    out = torch.zeros(N, F, device=DEV)
+    alpha = torch.zeros(E, device=DEV)
+    capi.tconv_attn_fwd(qkvs, 4 * F, F, N, 0.1, gr, out, F, alpha)
+    _close(out, want, 1e-4)
+    # alpha sums to one per target
+    sums = torch.zeros(N).index_add_(0, ei[1], alpha.cpu())
+    _close(sums, torch.ones(N), 1e-5)
+    dqkvs = torch.zeros(N, 4 * F, device=DEV)
+    dscore = torch.zeros(E, device=DEV)
+    capi.tconv_attn_bwd(qkvs, 4 * F, F, N, 0.1, gr, alpha, gout.to(DEV), F, dqkvs, dscore)
+    dx = torch.zeros(N, F, device=DEV)
+    capi.gemm_f32(dqkvs, 4 * F, 0, None, Wq.to(DEV), F, 1, None, dx, F, N, F, 4 * F)
+    _close(dx, x.grad, 2e-4)
+    dW = torch.zeros(4 * F, F, device=DEV)
+    db = torch.zeros(4 * F, device=DEV)
+    capi.gemm_f32(dqkvs, 4 * F, 1, None, xd, F, 1, None, dW, F, 4 * F, F, N, ones_col=1, bias_out=db)
+    want_dW = torch.cat([conv.lin_query.weight.grad, conv.lin_key.weight.grad, conv.lin_value.weight.grad,
+                         conv.lin_skip.weight.grad], 0)
+    want_db = torch.cat([conv.lin_query.bias.grad, conv.lin_key.bias.grad, conv.lin_value.bias.grad,
+                         conv.lin_skip.bias.grad], 0)
+    _close(dW, want_dW, 2e-4)
+    _close(db, want_db, 2e-4)
+
+
+# ------------------------------------------------------------ K5 / S3 / S4
+@pytest.mark.parametrize("N", [1, 2, 37, 2080])
+def test_batchnorm_lrelu(capi, N):
+    F = 100
+    torch.manual_seed(N)
+    bn = torch.nn.BatchNorm1d(F)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5), bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-1, 1), bn.running_var.uniform_(0.5, 2)
+    act = torch.nn.LeakyReLU()
+    x = (torch.randn(N, F) * 2 + 0.7).requires_grad_()
+    rm, rv = bn.running_mean.clone().to(DEV), bn.running_var.clone().to(DEV)
+    ws = torch.zeros(capi.bn_ws_floats(F), device=DEV)
+    saved = torch.zeros(2 * F, device=DEV)
+    y = torch.zeros(N, F, device=DEV)
+    gam, bet = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    # eval
+    bn.eval()
+    capi.bn_lrelu_fwd(x.detach().to(DEV), F, N, F, gam, bet, rm, rv, 0.1, 1e-5, 0.01, False, saved, y, F, ws)
+    _close(y, act(bn(x)), 1e-5)
+    if N == 1:
+        return  # torch refuses batch statistics over a single row
+    bn.train()
+    want = act(bn(x))
+    gout = torch.randn(N, F)
+    want.backward(gout)
+    capi.bn_lrelu_fwd(x.detach().to(DEV), F, N, F, gam, bet, rm, rv, 0.1, 1e-5, 0.01, True, saved, y, F, ws)
+    _close(y, want, 2e-5)
+    _close(rm, bn.running_mean, 1e-5)
+    _close(rv, bn.running_var, 1e-5)
+    dx = torch.zeros(N, F, device=DEV)
+    dg, db = torch.zeros(F, device=DEV), torch.zeros(F, device=DEV)
+    capi.bn_lrelu_bwd(x.detach().to(DEV), F, N, F, gam, bet, saved, 0.01, gout.to(DEV), F, dx, F, dg, db, ws)
+    _close(dx, x.grad, 5e-5, 1e-4)
+    _close(dg, bn.weight.grad, 1e-4, 1e-4)
+    _close(db, bn.bias.grad, 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("weighted,mapped", [(False, False), (True, False), (False, True)])
+def test_cross_entropy(capi, weighted, mapped):
+    C, n = 6, 777
+    torch.manual_seed(2)
+    rows = n + 100 if mapped else n
+    logits = (torch.randn(rows, C) * 3).requires_grad_()
+    ys = torch.randint(0, C, (n,))
+    w = torch.tensor([1 / 0.086747, 1 / 0.144406, 1 / 0.227883, 1 / 0.160585, 1 / 0.127711, 1 / 0.252668]) if weighted else None
+    row_map = torch.sort(torch.randperm(rows)[:n]).values.to(torch.int32) if mapped else None
+    sel = logits[row_map.long()] if mapped else logits
+    loss = torch.nn.functional.cross_entropy(sel, ys, weight=w)
+    loss.backward()
+    dl = torch.zeros(rows, C, device=DEV)
+    stats = torch.zeros(4, device=DEV)
+    capi.cross_entropy(logits.detach().to(DEV), C, C, n, row_map.to(DEV) if mapped else None, ys.to(DEV),
+                       w.to(DEV) if weighted else None, 1.0, dl, C, stats)
+    s = stats.cpu()
+    assert abs(float(s[0]) - float(loss)) < 2e-6 * max(1.0, float(loss))
+    assert int(s[1]) == int((sel.argmax(-1) == ys).sum())
+    _close(dl, logits.grad, 1e-7, 1e-4)
+
+
+@pytest.mark.parametrize("decoupled,wd,clip", [(False, 1e-8, 0.0), (False, 3e-5, 0.0), (True, 1e-2, 5.0), (True, 1e-2, 0.05)])
+def test_fused_adam_matches_torch(capi, decoupled, wd, clip):
+    n = 10_007
+    torch.manual_seed(3)
+    p0 = torch.randn(n)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref], lr=1e-3, weight_decay=wd)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.tensor([0, 0, 1], dtype=torch.int64, device=DEV)
+    gnorm, ws = torch.zeros(1, device=DEV), torch.zeros(1024, device=DEV)
+    for it in range(4):
+        g = torch.randn(n) * (0.01 if it % 2 else 1.0)
+        ref.grad = g.clone()
+        if clip > 0:
+            torch.nn.utils.clip_grad_norm_([ref], clip)
+        opt.step()
+        gd = g.to(DEV)
+        if clip > 0:
+            capi.grad_norm(gd, n, 1.0, gnorm, ws)
+            assert abs(float(gnorm) - float(g.norm())) < 1e-4 * float(g.norm())
+        capi.adam_step(p, gd, m, v, n, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, 1.0, clip, gnorm if clip > 0 else None, state)
+        _close(p, ref.detach(), 2e-6, 1e-5)
+    assert state.cpu().tolist() == [4, 4, 1]

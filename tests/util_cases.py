@@ -1,0 +1,106 @@
+"""Shared builders for parity tests: synthetic batches, oracle <-> HIP model pairs."""
+import types
+
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+from erc_amd.collate import ERCCollate
+from erc_amd.synthetic import make_dialogues
+
+
+def make_batch(B, dims, n_speakers=2, n_classes=6, min_len=3, max_len=14, seed=1, modality="atv",
+               batch_first=True, speaker_onehot=False, force_max=False):
+    dialogs = make_dialogues(B, dims, n_speakers=n_speakers, n_classes=n_classes, min_len=min_len,
+                             max_len=max_len, seed=seed, force_max=force_max)
+    p = types.SimpleNamespace(batch_first=batch_first, speaker_onehot=speaker_onehot, n_classes=n_classes,
+                              n_speakers=n_speakers, modality=modality)
+    batch = ERCCollate(p)([[d] for d in dialogs])
+    batch.pop("utterance_texts", None)
+    return batch
+
+
+def cogmen_case(B=4, min_len=3, max_len=14, dims=None, seed=3, n_classes=6, n_speakers=2):
+    dims = dims or dict(a=12, t=20, v=16)
+    return dict(batch=make_batch(B, dims, n_speakers, n_classes, min_len, max_len, seed), D=sum(dims.values()),
+                n_classes=n_classes, n_speakers=n_speakers, seed=seed)
+
+
+def to_device(batch, device):
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+ZERO_GRAD = ("gcn.conv2.lin_key.bias", "gcn.conv2.lin_value.bias", "gcn.conv2.lin_skip.bias")
+
+
+def rel_err(a, b, floor=1e-5):
+    """max |a-b| relative to the scale of the reference tensor.  ``floor`` keeps gradients that are
+    mathematically zero (TransformerConv key bias: softmax is shift invariant) from dividing noise by noise."""
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + floor))
+
+
+def run_cogmen_parity(case, device="cuda:0", compute="f32"):
+    """eval-mode logits and train-mode (dropout p=0) loss/gradients: HIP path vs oracle."""
+    from oracle.cogmen import COGMENOracle
+    from erc_amd.cogmen import COGMENModule
+    torch.manual_seed(case["seed"])
+    D, C, S = case["D"], case["n_classes"], case["n_speakers"]
+    ref = COGMENOracle(D, 100, 17, S, C, dead_encoder=False)
+    with torch.no_grad():  # make BN affine / running stats non-trivial
+        ref.gcn.bn.weight.uniform_(0.5, 1.5)
+        ref.gcn.bn.bias.uniform_(-0.3, 0.3)
+        ref.gcn.bn.running_mean.uniform_(-0.2, 0.2)
+        ref.gcn.bn.running_var.uniform_(0.5, 1.5)
+        ref.gcn.conv1.bias.uniform_(-0.1, 0.1)
+    mine = COGMENModule(D, 100, 17, S, C, compute=compute)
+    mine.load_state_dict(ref.state_dict())
+    mine.finalize(device)
+    batch = case["batch"]
+    dbatch = to_device(batch, device)
+    if compute == "bf16":
+        # bf16 mode stores the feature block in bf16 and rounds rnn.1.weight to bf16 while staging it:
+        # give the oracle the SAME rounded operands so that the test isolates implementation error
+        # (fp32 accumulate) from the quantisation error of the mode itself.
+        dbatch["input_tensor"] = dbatch["input_tensor"].to(torch.bfloat16)
+        batch = dict(batch, input_tensor=batch["input_tensor"].to(torch.bfloat16).float())
+        with torch.no_grad():
+            ref.rnn[1].weight.copy_(ref.rnn[1].weight.to(torch.bfloat16).float())
+            mine.rnn[1].weight.copy_(ref.rnn[1].weight.to(device))
+    out = {}
+    # --- eval logits
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        want, want_feat = ref(**batch)
+    got, got_feat = mine(**dbatch)
+    out["logit_err"] = float((got.cpu() - want).abs().max())
+    out["feat_err"] = float((got_feat.cpu() - want_feat).abs().max())
+    # --- train mode, dropout off: loss + every live gradient + BN running stats
+    ref.train(), mine.train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    mine.drop_p = 0.0
+    logits, _ = ref(**batch)
+    loss = F.cross_entropy(logits, batch["label"])
+    ref.zero_grad()
+    loss.backward()
+    stats = mine.loss_and_grads(dbatch).cpu()
+    out["loss_err"] = abs(float(stats[0]) - float(loss))
+    out["acc_match"] = int(stats[1]) == int((logits.argmax(-1) == batch["label"]).sum())
+    worst, names = 0.0, {}
+    ref_params = dict(ref.named_parameters())
+    for name in mine.flat.params:
+        if name in ZERO_GRAD:
+            # mathematically zero: softmax shift invariance (key bias) / constant shift in front of BatchNorm
+            assert float(mine.flat.g(name).abs().max()) < 1e-5 and float(ref_params[name].grad.abs().max()) < 1e-5
+            continue
+        e = rel_err(mine.flat.g(name).cpu(), ref_params[name].grad)
+        names[name] = e
+        worst = max(worst, e)
+    out["grad_err"], out["grad_errs"] = worst, names
+    out["bn_mean_err"] = float((mine.gcn.bn.running_mean.cpu() - ref.gcn.bn.running_mean).abs().max())
+    out["bn_var_err"] = float((mine.gcn.bn.running_var.cpu() - ref.gcn.bn.running_var).abs().max())
+    dead = [n for n, p in ref.named_parameters() if p.grad is None]
+    out["dead_ok"] = all(n.startswith("rnn.0.") for n in dead) and len(dead) > 0
+    return out
