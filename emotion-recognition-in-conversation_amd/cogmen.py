@@ -239,6 +239,41 @@ class COGMENModule(nn.Module):
     def last_graph(self, B, T, N):
         return self._ws[(B, T, N)]["g"]
 
+    def dominant_kernel_probe(self, batch, reps=200):
+        """Time the HBM-dominant kernel of the step -- the input projection H0 = X[node_row] W1^T, the only
+        kernel that touches the [B,T,D] feature block in the forward -- with HIP events on the stream it is
+        launched on: ``reps`` back-to-back launches between one event pair (inter-launch gaps included, so
+        the figure is conservative w.r.t. rocprofv3's per-dispatch duration).
+        Algorithmic bytes per launch: N*D*sizeof(x) + F*D*4 + N*F*4 + N*4."""
+        x, lens, ys = batch["input_tensor"], batch["text_length"], batch["label"]
+        B, T, N = self._shape(x, lens, ys)
+        ws = self._workspace(B, T, N, x.device)
+        pl, g, fp = ws["planner"], ws["g"], self.flat
+        F, D = F_HID, self.input_size
+        x_bf16 = x.dtype == torch.bfloat16
+        if x_bf16:
+            S = pl.split_for(N, F, D, bk=64, min_chunks=4)
+            launch = lambda: capi.gemm_bf16x(x, D, 0, g["node_row"], fp.w("rnn.1.weight"), D, 0, None, 1,
+                                             pl.ws, F, N, F, D, split_k=S, c_slab=N * F)
+            name = "gemm_bf16x_kernel<0,0,1,2> (input projection, bf16 features)"
+        else:
+            S = pl.split_for(N, F, D)
+            launch = lambda: capi.gemm_f32(x, D, 0, g["node_row"], fp.w("rnn.1.weight"), D, 0, None,
+                                           pl.ws, F, N, F, D, split_k=S, c_slab=N * F)
+            name = "gemm_f32_kernel<0,0,2> (input projection, fp32 features)"
+        nbytes = N * D * x.element_size() + F * D * 4 + N * F * 4 + N * 4
+        for _ in range(10):
+            launch()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        return {"kernel": name, "us": us, "bytes": nbytes, "gbs": nbytes / us * 1e-3, "split_k": S}
+
 
 def build_graph_tensors(text_length, speaker_tensor, wp, wf, n_speakers, n_nodes=None, explicit=True):
     """Device graph builder as a standalone op: returns the CSR dict plus, when ``explicit``, the

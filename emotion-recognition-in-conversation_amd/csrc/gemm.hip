@@ -21,6 +21,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 struct GemmP {
     const void* A;
@@ -303,9 +304,10 @@ __global__ __launch_bounds__(256) void gemm_bf16x_kernel(GemmP p) {
         unsigned short* dst = is_a ? As : Bs;
         const bool kmajor = is_a ? (bool)A_KMAJOR : (bool)B_KMAJOR;
         const bool is_x = is_a ? (bool)X_IS_A : !(bool)X_IS_A;
-        const bool vec = is_a ? p.a_vec : p.b_vec;
+        const int vec = is_a ? p.a_vec : p.b_vec;
         if (!kmajor) {
-            // rows are K-contiguous in memory: 8 threads x 8 elements per row
+            // rows are K-contiguous in memory: 8 threads x 8 elements per row.
+            // vec: 2 = 16-byte loads, 1 = 8-byte loads (bf16 rows of 1380 elements are only 8-byte aligned)
             for (int row = tid >> 3; row < ROWS; row += 32) {
                 const int kk = 8 * (tid & 7);
                 const int rg = base_row + row;
@@ -315,7 +317,15 @@ __global__ __launch_bounds__(256) void gemm_bf16x_kernel(GemmP p) {
                     const int64_t src = (is_a && p.a_gather) ? (int64_t)p.a_gather[rg] : (int64_t)rg;
                     const int ld = is_a ? p.lda : p.ldb;
                     if (is_x) {
-                        v = *reinterpret_cast<const bf16x8*>((const unsigned short*)(is_a ? p.A : p.B) + src * ld + k0 + kk);
+                        const unsigned short* s = (const unsigned short*)(is_a ? p.A : p.B) + src * ld + k0 + kk;
+                        if (vec == 2) {
+                            v = *reinterpret_cast<const bf16x8*>(s);
+                        } else {
+                            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(s);
+                            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(s + 4);
+                            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+                            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+                        }
                     } else {
                         const float* s = (const float*)(is_a ? p.A : p.B) + src * ld + k0 + kk;
                         const float4 lo = *reinterpret_cast<const float4*>(s);
@@ -330,13 +340,33 @@ __global__ __launch_bounds__(256) void gemm_bf16x_kernel(GemmP p) {
                 *reinterpret_cast<bf16x8*>(dst + row * KH_STRIDE + kk) = v;
             }
         } else {
-            // memory is K-major (row index contiguous): read 4 consecutive rows of one k, transpose into LDS
+            // memory is K-major (row index contiguous): each thread reads 4 consecutive rows of one k
+            // (one 8-byte / 16-byte load) and scatters them into the K-contiguous LDS image
             const int RQ = ROWS / 4;  // row-quads
+            const int lim = is_a ? p.M : p.N;
             for (int idx = tid; idx < RQ * BKH; idx += 256) {
                 const int kq = idx / RQ, rq = idx % RQ;
                 const int k = k0 + kq, rg = base_row + 4 * rq;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dst[(4 * rq + j) * KH_STRIDE + kq] = fetch(is_a, rg + j, k);
+                unsigned short e0, e1, e2, e3;
+                if (k < p.K && rg + 4 <= lim && vec) {
+                    const int ld = is_a ? p.lda : p.ldb;
+                    const int64_t src = (!is_a && p.b_gather) ? (int64_t)p.b_gather[k] : (int64_t)k;
+                    if (is_x) {
+                        const bf16x4 q = *reinterpret_cast<const bf16x4*>(
+                            (const unsigned short*)(is_a ? p.A : p.B) + src * ld + rg);
+                        e0 = q[0]; e1 = q[1]; e2 = q[2]; e3 = q[3];
+                    } else {
+                        const float4 q = *reinterpret_cast<const float4*>((const float*)(is_a ? p.A : p.B) + src * ld + rg);
+                        e0 = f2bf(q.x); e1 = f2bf(q.y); e2 = f2bf(q.z); e3 = f2bf(q.w);
+                    }
+                } else {
+                    e0 = fetch(is_a, rg, k); e1 = fetch(is_a, rg + 1, k);
+                    e2 = fetch(is_a, rg + 2, k); e3 = fetch(is_a, rg + 3, k);
+                }
+                dst[(4 * rq + 0) * KH_STRIDE + kq] = e0;
+                dst[(4 * rq + 1) * KH_STRIDE + kq] = e1;
+                dst[(4 * rq + 2) * KH_STRIDE + kq] = e2;
+                dst[(4 * rq + 3) * KH_STRIDE + kq] = e3;
             }
         }
     };
@@ -476,9 +506,15 @@ extern "C" int erc_gemm_bf16x(const void* A, int lda, int a_kmajor, const int32_
     if (split_k > nchunk) split_k = nchunk;
     p.chunks_per_split = erc_cdiv(nchunk, split_k);
     p.ones_col = ones_col;
-    // vector path: 8 contiguous elements, 16-byte aligned for bf16 / fp32 rows alike
-    p.a_vec = aligned16(A) && (lda % 8 == 0);
-    p.b_vec = aligned16(B) && (ldb % 8 == 0);
+    // vector path: bf16 operand: 2 = 16-byte loads (ld % 8 == 0), 1 = 8-byte loads (ld % 4 == 0);
+    // fp32 operand: non-zero = float4 loads (ld % 4 == 0)
+    auto vec_of = [](const void* ptr, int ld, bool is_bf16) {
+        if (!aligned16(ptr)) return 0;
+        if (is_bf16) return ld % 8 == 0 ? 2 : (ld % 4 == 0 ? 1 : 0);
+        return ld % 4 == 0 ? 2 : 0;
+    };
+    p.a_vec = vec_of(A, lda, x_is_a != 0);
+    p.b_vec = vec_of(B, ldb, x_is_a == 0);
     ERC_REQUIRE(ones_col == 0 || ones_col == 1, "gemm_bf16x: ones mode %d", ones_col);
     const int Nlog = N + (ones_col ? 1 : 0);
     dim3 grid(erc_cdiv(Nlog, 32), erc_cdiv(M, BM), split_k);

@@ -190,3 +190,27 @@ def all_reduce_grads(flat):
         dist.all_reduce(flat.grad)
         return 1.0 / dist.get_world_size()
     return 1.0
+
+
+class GraphedStep:
+    """Capture ``fn()`` (a whole training step whose every launch goes to the current stream and which
+    performs no host synchronisation) into one HIP graph and replay it.  The inputs of ``fn`` must live in
+    fixed device buffers; shapes are static per captured graph (one graph per (B, T, N) bucket)."""
+
+    def __init__(self, fn, warmup=2):
+        self.fn = fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):      # allocates workspaces / job tables outside the capture
+                self.out = fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+        self.warmup_steps = warmup
+
+    def __call__(self):
+        self.graph.replay()
+        return self.out

@@ -1,0 +1,68 @@
+"""world_size-2 gloo test (CPU) of the data-parallel exchange step: one sum all-reduce of the flat
+live-gradient buffer, 1/world returned as the optimizer's grad_scale (DDP-mean semantics)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from erc_amd.engine import FlatParams, all_reduce_grads
+    torch.manual_seed(0)  # identical parameters on every rank
+    lin1, lin2 = torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)
+    flat = FlatParams([[("a.weight", lin1.weight)], [("a.bias", lin1.bias)],
+                       [("b.weight", lin2.weight), ("b.bias", lin2.bias)]], "cpu")
+    assert lin1.weight.data_ptr() == flat.w("a.weight").data_ptr()       # parameters are views of the flat buffer
+    assert lin2.bias.grad.data_ptr() == flat.g("b.bias").data_ptr()      # and so are their .grad
+    # each rank has its own gradient (its own shard of dialogues)
+    g = torch.Generator().manual_seed(100 + rank)
+    for name in flat.params:
+        flat.g(name).copy_(torch.randn(flat.shapes[name], generator=g))
+    mine = flat.grad.clone()
+    scale = all_reduce_grads(flat)
+    others = []
+    for r in range(world):
+        gg = torch.Generator().manual_seed(100 + r)
+        others.append(torch.cat([torch.randn(flat.shapes[n], generator=gg).flatten() for n in flat.params]))
+    want_sum = sum(others)
+    got = torch.cat([flat.g(n).flatten() for n in flat.params])
+    ok = torch.allclose(got, want_sum, atol=1e-6) and abs(scale - 1.0 / world) < 1e-12
+    # padding between groups stays zero (the optimizer sweeps the whole buffer)
+    live = torch.zeros(flat.numel, dtype=torch.bool)
+    for n in flat.params:
+        live[flat.offsets[n]:flat.offsets[n] + flat.params[n].numel()] = True
+    ok = ok and float(flat.grad[~live].abs().sum()) == 0.0
+    # an empty shard still has to enter the collective with zeros
+    flat.grad.zero_()
+    if rank == 0:
+        flat.grad.copy_(mine)
+    all_reduce_grads(flat)
+    r0 = others[0]
+    ok = ok and torch.allclose(torch.cat([flat.g(n).flatten() for n in flat.params]), r0, atol=1e-6)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

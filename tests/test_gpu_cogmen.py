@@ -1,5 +1,6 @@
 """End-to-end COGMEN parity on the GPU: eval logits within 1e-4 (fp32) of the CPU oracle, loss and every
 live gradient in train mode with dropout forced to 0, BatchNorm running statistics, one optimizer step."""
+import numpy as np
 import pytest
 import torch
 
@@ -92,3 +93,25 @@ def test_cogmen_dropout_train_mode_runs_and_is_reproducible():
         losses.append([float(tr.train_step(b).cpu()[0]) for _ in range(3)])
     assert losses[0] == losses[1]            # bit-reproducible run to run (no atomics, counter RNG)
     assert losses[0][2] < losses[0][0] + 1.0  # and training does not blow up
+
+
+def test_train_mm_cli_plugin_surface():
+    """``python train_mm.py --module=cogmen --dataset=iemocap-cogmen-4 --modality=atv`` (BASELINE configs[0] shape)
+    runs end to end on the GPU: dispatcher -> plugin main() -> collate -> train steps -> test metrics."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "train_mm.py", "--module=cogmen", "--dataset=iemocap-cogmen-4",
+                          "--modality=atv", "--epoch=2", "--n_train=12", "--n_test=5", "--train.batch_size=4",
+                          "--test.batch_size=4"], cwd=repo, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    steps = [l for l in lines if "Lall" in l]
+    epochs = [l for l in lines if "test" in l]
+    assert len(steps) == 6 and len(epochs) == 2
+    assert all(np.isfinite(l["Lall"]) for l in steps)
+    assert set(epochs[-1]["test"]) >= {"acc", "wa", "f1", "mif1", "maf1"}
+    bad = subprocess.run([sys.executable, "train_mm.py", "--module=nope"], cwd=repo, capture_output=True, text=True)
+    assert bad.returncode == 1 and "cogmen" in bad.stdout
