@@ -190,7 +190,68 @@ def gen_window_graph(ref):
              features=feats.numpy(), x=x.numpy(), edge_index=ei_s, edge_type=et_s, edge_count=cnt.numpy())
 
 
-GENERATORS = {"collate": gen_collate, "window_graph": gen_window_graph}
+def fill_params(model, seed):
+    """Deterministic parameter values shared by this script and the tests (tests/util_cases.py has the
+    same function): a fixture then only needs the seed, not 15 M parameters."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in sorted(model.named_parameters()):
+            bound = 1.0 / (p.shape[-1] ** 0.5) if p.dim() > 1 else 0.1
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+
+
+def grad_digest(named_grads, seed=0, keep=512):
+    """Small gradients verbatim; big ones as (norm, values at fixed pseudo-random positions)."""
+    out = {}
+    for name, gr in named_grads:
+        key = name.replace(".", "__")
+        if gr is None:
+            continue
+        flat = gr.detach().flatten()
+        if flat.numel() <= 20000:
+            out["grad__" + key] = flat.numpy()
+        else:
+            g = torch.Generator().manual_seed(seed + flat.numel())
+            idx = torch.randint(0, flat.numel(), (keep,), generator=g)
+            out["gsample__" + key] = flat[idx].numpy()
+            out["gnorm__" + key] = np.array(float(flat.double().norm()))
+    return out
+
+
+def gen_dagerc(ref):
+    """DAG-ERC end to end through the reference's own DAGERCModule (track_mm/dagerc.py:73-198):
+    adjacency, speaker mask, padded logits, masked CE loss, every gradient."""
+    from erc_amd.collate import ERCCollate
+    from erc_amd.synthetic import make_dialogues
+    import torch.nn.functional as F
+    dag = importlib.import_module("track_mm.dagerc")
+    for tag, B, dims, S, C, lens in (("small", 3, dict(a=6, t=8, v=6), 2, 6, (2, 9)),
+                                     ("s3", 4, dict(a=5, t=4, v=3), 3, 7, (1, 12))):
+        D = sum(dims.values())
+        dialogs = make_dialogues(B, dims, n_speakers=S, n_classes=C, min_len=lens[0], max_len=lens[1], seed=21,
+                                 force_max=True)
+        p = types.SimpleNamespace(batch_first=True, speaker_onehot=True, n_classes=C, n_speakers=S, modality="atv")
+        batch = ERCCollate(p)([[d] for d in dialogs])
+        batch.pop("utterance_texts", None)
+        model = dag.DAGERCModule(emb_dim=D, dropout=0.0, n_classes=C, gnn_layers=4)
+        fill_params(model, 77)
+        model.train()
+        logits, _ = model(**batch)
+        sel = logits[batch["attention_mask"].bool()]
+        loss = F.cross_entropy(sel, batch["label"])
+        loss.backward()
+        spk = batch["speaker_tensor"].tolist()
+        mx = int(batch["text_length"].max())
+        adj = model.get_adj_v1(spk, mx)
+        s_mask, _ = model.get_s_mask(spk, mx)
+        none = [n for n, q in model.named_parameters() if q.grad is None]
+        save("dagerc_" + tag, param_seed=77, n_classes=C, n_speakers=S, dims=np.array([dims["a"], dims["t"], dims["v"]]),
+             **{"in_" + k: v.numpy() for k, v in batch.items() if torch.is_tensor(v)},
+             logits=logits.detach().numpy(), loss=np.array(float(loss)), adj=adj.numpy(), s_mask=s_mask.numpy(),
+             grad_none=np.array(none), **grad_digest([(n, q.grad) for n, q in model.named_parameters()]))
+
+
+GENERATORS = {"collate": gen_collate, "window_graph": gen_window_graph, "dagerc": gen_dagerc}
 
 
 def main():

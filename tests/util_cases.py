@@ -104,3 +104,38 @@ def run_cogmen_parity(case, device="cuda:0", compute="f32"):
     dead = [n for n, p in ref.named_parameters() if p.grad is None]
     out["dead_ok"] = all(n.startswith("rnn.0.") for n in dead) and len(dead) > 0
     return out
+
+
+# ----------------------------------------------------------------------------- golden helpers
+def fill_params(model, seed):
+    """Same deterministic filler as tests/golden/make_golden.py: fixtures carry the seed, not the weights."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in sorted(model.named_parameters()):
+            bound = 1.0 / (p.shape[-1] ** 0.5) if p.dim() > 1 else 0.1
+            p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+
+
+def check_grad_digest(fix, named_grads, tol, seed=0, keep=512):
+    """Compare gradients with a fixture written by make_golden.grad_digest; returns the worst relative error."""
+    worst = 0.0
+    seen = 0
+    for name, gr in named_grads:
+        key = name.replace(".", "__")
+        flat = gr.detach().cpu().flatten()
+        if "grad__" + key in fix.files:
+            want = torch.from_numpy(fix["grad__" + key])
+            e = rel_err(flat, want)
+        elif "gsample__" + key in fix.files:
+            g = torch.Generator().manual_seed(seed + flat.numel())
+            idx = torch.randint(0, flat.numel(), (keep,), generator=g)
+            want = torch.from_numpy(fix["gsample__" + key])
+            e = max(rel_err(flat[idx], want),
+                    abs(float(flat.double().norm()) - float(fix["gnorm__" + key])) / (float(fix["gnorm__" + key]) + 1e-9))
+        else:
+            continue
+        seen += 1
+        assert e < tol, (name, e)
+        worst = max(worst, e)
+    assert seen > 0
+    return worst
