@@ -24,7 +24,7 @@ _SIGS = {
                                _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
                                  _i64, _vp]),
-    "erc_slab_reduce": (C.c_int, [_vp, _i, _i64, _vp, _i, _i, _vp, _i64, _vp]),
+    "erc_slab_reduce": (C.c_int, [_vp, _i, _i64, _vp, _i, _i, _vp, _i, _i64, _vp]),
     "erc_slab_reduce_batched": (C.c_int, [_vp, _vp, _vp, _i, _i64, _vp]),
     "erc_rgcn_mean_fwd": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_rgcn_mean_bwd": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
@@ -37,6 +37,11 @@ _SIGS = {
     "erc_cross_entropy": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp]),
     "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
+    "erc_dag_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "erc_dag_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
+                                   _vp, _vp, _vp, _vp]),
+    "erc_dag_scan_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                   _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -125,8 +130,8 @@ def gemm_bf16x(A, lda, a_kmajor, a_gather, B, ldb, b_kmajor, b_gather, x_is_a, C
                                 stream()), "erc_gemm_bf16x")
 
 
-def slab_reduce(slabs, S, stride, bias, n_cols, act, out, numel):
-    _check(lib().erc_slab_reduce(ptr(slabs), S, stride, ptr(bias), n_cols, act, ptr(out), numel, stream()),
+def slab_reduce(slabs, S, stride, bias, n_cols, act, out, numel, ld_out=0):
+    _check(lib().erc_slab_reduce(ptr(slabs), S, stride, ptr(bias), n_cols, act, ptr(out), ld_out, numel, stream()),
            "erc_slab_reduce")
 
 
@@ -186,3 +191,23 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_no
 
 def grad_norm(g, n, grad_scale, gnorm, ws):
     _check(lib().erc_grad_norm(ptr(g), n, grad_scale, ptr(gnorm), ptr(ws), stream()), "erc_grad_norm")
+
+
+def dag_meta(speaker_onehot, speaker_ids, sb, st, S, lengths, B, T, spk, pred, node_off, node_row):
+    _check(lib().erc_dag_meta(ptr(speaker_onehot), ptr(speaker_ids), sb, st, S, ptr(lengths), B, T, ptr(spk),
+                              ptr(pred), ptr(node_off), ptr(node_row), stream()), "erc_dag_meta")
+
+
+def dag_scan_fwd(Hl, ldh, GI, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_lin, pred, spk, B, T, H1, ldo, Mseq, GH, R, ks,
+                 alpha):
+    _check(lib().erc_dag_scan_fwd(ptr(Hl), ldh, ptr(GI), ptr(W_hh_c), ptr(b_hh_c), ptr(W_ih_p), ptr(b_ih_p), ptr(Wr),
+                                  ptr(w_lin), ptr(pred), ptr(spk), B, T, ptr(H1), ldo, ptr(Mseq), ptr(GH), ptr(R),
+                                  ptr(ks), ptr(alpha), stream()), "erc_dag_scan_fwd")
+
+
+def dag_scan_bwd(Hl, ldh, GI, GH, Mseq, R, alpha, H1, ldo, W_hh_c, W_ih_p, Wr, w_lin, pred, spk, B, T, dH1, ldd, dHl,
+                 lddl, DGI, DGH, dR, dks, dlin):
+    _check(lib().erc_dag_scan_bwd(ptr(Hl), ldh, ptr(GI), ptr(GH), ptr(Mseq), ptr(R), ptr(alpha), ptr(H1), ldo,
+                                  ptr(W_hh_c), ptr(W_ih_p), ptr(Wr), ptr(w_lin), ptr(pred), ptr(spk), B, T, ptr(dH1),
+                                  ldd, ptr(dHl), lddl, ptr(DGI), ptr(DGH), ptr(dR), ptr(dks), ptr(dlin), stream()),
+           "erc_dag_scan_bwd")

@@ -1,0 +1,443 @@
+// K6: DAG-ERC directed-acyclic recurrence (track_mm/dagerc.py:109-189,
+// track_mm/dagerc_models.py:312-365), one persistent workgroup per dialogue.
+//
+// The reference rebuilds, for every utterance i of every layer, the attention
+// over the whole prefix [:i] (Wr0/Wr1 of every earlier node recomputed, state
+// regrown with torch.cat).  Here each node's relation transforms R0_i = Wr0 h_i,
+// R1_i = Wr1 h_i and its key score w_k.h_i are computed ONCE when h_i is
+// produced; the adjacency is never materialised: row i of adj is the index range
+// [max(pred_i,0), i-1] with pred_i = last earlier utterance of the same speaker
+// (SURVEY.md Appendix C), and s_mask is a speaker-id compare.
+//
+// The two GRU cells share the work per step as
+//   hoisted (one GEMM over all B*T rows, outside this kernel):
+//       GI[:,   0: 900] = W_ih(grus_c) H_l + b_ih(grus_c)   (cell C, input side)
+//       GI[:, 900:1800] = W_hh(grus_p) H_l + b_hh(grus_p)   (cell P, hidden side)
+//   sequential (this kernel, depends on the attention result M_i):
+//       GH[:,   0: 900] = W_hh(grus_c) M_i + b_hh(grus_c)   (cell C, hidden side)
+//       GH[:, 900:1800] = W_ih(grus_p) M_i + b_ih(grus_p)   (cell P, input side)
+// The weight matrices (2.9 MB fp32 per layer) are streamed from L2 each step by
+// 16 wavefronts (coalesced 1200-byte rows, wave-level dot products); the
+// backward scan runs the same steps in reverse with the transposed products
+// and leaves every weight gradient to dense GEMMs over the saved per-step
+// gate gradients (DGI, DGH, dR), again outside the kernel.
+#include "erc_common.h"
+
+namespace {
+
+constexpr int HID = 300;
+constexpr int G3 = 900;       // 3 gates x HID
+constexpr int NT = 1024;      // threads per workgroup
+constexpr int NW = NT / 64;   // 16 wavefronts
+constexpr int MAX_T = 512;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// out[r] = W[r,:] . v (+ bias[r]) for r in [0,rows): one wavefront per row, rows strided over the 16 waves.
+// W row-major [rows, HID]; v in LDS.
+__device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* __restrict__ bias, int rows,
+                                            const float* v_lds, float* out_lds, float* out_glb, int lane, int wave) {
+    const float v0 = v_lds[lane], v1 = v_lds[lane + 64], v2 = v_lds[lane + 128], v3 = v_lds[lane + 192];
+    const float v4 = lane + 256 < HID ? v_lds[lane + 256] : 0.f;
+    for (int r0 = wave; r0 < rows; r0 += 4 * NW) {
+        float acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * NW;
+            float a = 0.f;
+            if (r < rows) {
+                const float* w = W + (int64_t)r * HID;
+                a = w[lane] * v0 + w[lane + 64] * v1 + w[lane + 128] * v2 + w[lane + 192] * v3;
+                if (lane + 256 < HID) a += w[lane + 256] * v4;
+            }
+            acc[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u * NW;
+            const float s = wave_sum(acc[u]);
+            if (r < rows && lane == 0) {
+                const float o = s + (bias ? bias[r] : 0.f);
+                if (out_lds) out_lds[r] = o;
+                if (out_glb) out_glb[r] = o;
+            }
+        }
+    }
+}
+
+// part[wave][k] += sum_{r owned by wave} W[r,k] * d[r]  (transposed product), d in LDS
+__device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, int rows, const float* d_lds, float acc[5],
+                                               int lane, int wave) {
+    for (int r = wave; r < rows; r += NW) {
+        const float d = d_lds[r];
+        const float* w = W + (int64_t)r * HID;
+        acc[0] += w[lane] * d;
+        acc[1] += w[lane + 64] * d;
+        acc[2] += w[lane + 128] * d;
+        acc[3] += w[lane + 192] * d;
+        if (lane + 256 < HID) acc[4] += w[lane + 256] * d;
+    }
+}
+
+// ----------------------------------------------------------------------------- meta
+// speaker ids, DAG predecessor, valid-row map.  One workgroup per dialogue.
+__global__ __launch_bounds__(256) void dag_meta_kernel(const float* __restrict__ onehot, const int64_t* __restrict__ ids,
+                                                       int64_t sb, int64_t st, int S, const int64_t* __restrict__ lengths,
+                                                       int B, int T, int32_t* __restrict__ spk, int32_t* __restrict__ pred,
+                                                       int32_t* __restrict__ node_off, int32_t* __restrict__ node_row) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_spk[MAX_T];
+    __shared__ int red[256];
+    int acc = 0;
+    for (int i = tid; i < b; i += 256) acc += (int)lengths[i];
+    red[tid] = acc;
+    for (int t = tid; t < T; t += 256) {
+        int s = 0;
+        if (onehot) {  // argmax of the one-hot row (first maximum, like torch.argmax)
+            const float* row = onehot + (int64_t)b * sb + (int64_t)t * st;
+            float best = row[0];
+            for (int c = 1; c < S; ++c)
+                if (row[c] > best) best = row[c], s = c;
+        } else {
+            s = (int)ids[(int64_t)b * sb + (int64_t)t * st];
+        }
+        s_spk[t] = s;
+        spk[b * T + t] = s;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const int noff = red[0], L = (int)lengths[b];
+    if (tid == 0) {
+        node_off[b] = noff;
+        if (b == B - 1) node_off[B] = noff + L;
+    }
+    for (int t = tid; t < T; t += 256) {
+        int p = -1;
+        for (int j = t - 1; j >= 0; --j)
+            if (s_spk[j] == s_spk[t]) {
+                p = j;
+                break;
+            }
+        pred[b * T + t] = p;
+        if (t < L) node_row[noff + t] = b * T + t;
+    }
+}
+
+// ----------------------------------------------------------------------------- forward scan
+struct DagFwd {
+    const float* Hl; int ldh;          // layer input  [B*T, HID] (row pitch ldh)
+    const float* GI;                   // hoisted gates [B*T, 1800]
+    const float *W_hh_c, *b_hh_c, *W_ih_p, *b_ih_p;   // [900,300],[900]
+    const float* Wr;                   // [600,300] = Wr0 ; Wr1
+    const float* w_lin;                // [601] = w_q(300) | w_k(300) | b
+    const int32_t *pred, *spk;
+    float* H1; int ldo;                // layer output [B*T, HID] (row pitch ldo)
+    float *Mseq, *GH, *R, *ks, *alpha; // [B*T,300],[B*T,1800],[B*T,600],[B*T],[B,T,T]
+    int B, T;
+};
+
+__global__ __launch_bounds__(NT) void dag_scan_fwd_kernel(DagFwd p) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.T;
+    __shared__ float v_m[320], v_h[320], v_x[320], gates[2 * G3], s_alpha[MAX_T];
+    __shared__ float s_qs;
+    const float* w_q = p.w_lin;
+    const float* w_k = p.w_lin + HID;
+    const float b_lin = p.w_lin[2 * HID];
+
+    for (int i = 0; i < T; ++i) {
+        const int64_t row = (int64_t)b * T + i;
+        const float* x = p.Hl + row * p.ldh;
+        if (tid < HID) v_x[tid] = x[tid];
+        __syncthreads();
+        // ---- A: attention over the DAG predecessors [lo, i-1]
+        int lo = 0, n = 0;
+        if (i > 0) {
+            const int pr = p.pred[row];
+            lo = pr > 0 ? pr : 0;
+            n = i - lo;
+            if (wave == 0) {
+                float a = w_q[lane] * v_x[lane] + w_q[lane + 64] * v_x[lane + 64] + w_q[lane + 128] * v_x[lane + 128] +
+                          w_q[lane + 192] * v_x[lane + 192];
+                if (lane + 256 < HID) a += w_q[lane + 256] * v_x[lane + 256];
+                const float qs = wave_sum(a) + b_lin;
+                float mx = -INFINITY;
+                for (int j = lane; j < n; j += 64) mx = fmaxf(mx, qs + p.ks[(int64_t)b * T + lo + j]);
+                mx = wave_max(mx);
+                float den = 0.f;
+                for (int j = lane; j < n; j += 64) {
+                    const float e = expf(qs + p.ks[(int64_t)b * T + lo + j] - mx);
+                    s_alpha[j] = e;
+                    den += e;
+                }
+                den = wave_sum(den);
+                const float inv = 1.0f / den;
+                for (int j = lane; j < n; j += 64) {
+                    const float al = s_alpha[j] * inv;
+                    s_alpha[j] = al;
+                    p.alpha[((int64_t)b * T + i) * T + lo + j] = al;
+                }
+            }
+            __syncthreads();
+            if (tid < HID) {
+                const int si = p.spk[row];
+                float m = 0.f;
+                for (int j = 0; j < n; ++j) {
+                    const int64_t rj = (int64_t)b * T + lo + j;
+                    const int same = p.spk[rj] == si;
+                    m += s_alpha[j] * p.R[rj * 2 * HID + (same ? 0 : HID) + tid];
+                }
+                v_m[tid] = m;
+                p.Mseq[row * HID + tid] = m;
+            }
+        } else if (tid < HID) {
+            v_m[tid] = 0.f;
+            p.Mseq[row * HID + tid] = 0.f;
+        }
+        __syncthreads();
+        // ---- B: sequential gate pre-activations
+        float* gh = p.GH + row * 2 * G3;
+        if (i > 0) {
+            matvec_rows(p.W_hh_c, p.b_hh_c, G3, v_m, gates, gh, lane, wave);
+            matvec_rows(p.W_ih_p, p.b_ih_p, G3, v_m, gates + G3, gh + G3, lane, wave);
+        } else {
+            for (int r = tid; r < G3; r += NT) {
+                gates[r] = gh[r] = p.b_hh_c[r];
+                gates[G3 + r] = gh[G3 + r] = p.b_ih_p[r];
+            }
+        }
+        __syncthreads();
+        // ---- C: the two GRU cells, h1 = C + P
+        if (tid < HID) {
+            const float* gi = p.GI + row * 2 * G3;
+            // cell C: x = H_l[i] (hoisted gi), h = M_i (gates[0:900])
+            float r = sigmoidf_(gi[tid] + gates[tid]);
+            float z = sigmoidf_(gi[HID + tid] + gates[HID + tid]);
+            float nn = tanhf(gi[2 * HID + tid] + r * gates[2 * HID + tid]);
+            const float c = (1.f - z) * nn + z * v_m[tid];
+            // cell P: x = M_i (gates[900:1800]), h = H_l[i] (hoisted gi[900:1800])
+            r = sigmoidf_(gates[G3 + tid] + gi[G3 + tid]);
+            z = sigmoidf_(gates[G3 + HID + tid] + gi[G3 + HID + tid]);
+            nn = tanhf(gates[G3 + 2 * HID + tid] + r * gi[G3 + 2 * HID + tid]);
+            const float pp = (1.f - z) * nn + z * v_x[tid];
+            const float h1 = c + pp;
+            v_h[tid] = h1;
+            p.H1[row * p.ldo + tid] = h1;
+        }
+        __syncthreads();
+        // ---- D: relation transforms and key score of the new node (used by later steps)
+        matvec_rows(p.Wr, nullptr, 2 * HID, v_h, nullptr, p.R + row * 2 * HID, lane, wave);
+        if (wave == NW - 1) {
+            float a = w_k[lane] * v_h[lane] + w_k[lane + 64] * v_h[lane + 64] + w_k[lane + 128] * v_h[lane + 128] +
+                      w_k[lane + 192] * v_h[lane + 192];
+            if (lane + 256 < HID) a += w_k[lane + 256] * v_h[lane + 256];
+            a = wave_sum(a);
+            if (lane == 0) p.ks[row] = a;
+        }
+        __syncthreads();  // R / ks of this step are read from global memory by the following steps
+    }
+}
+
+// ----------------------------------------------------------------------------- backward scan
+struct DagBwd {
+    const float* Hl; int ldh;
+    const float *GI, *GH, *Mseq, *R, *alpha;
+    const float* H1; int ldo;
+    const float *W_hh_c, *W_ih_p, *Wr, *w_lin;
+    const int32_t *pred, *spk;
+    const float* dH1; int ldd;          // gradient wrt this layer's outputs (complete), row pitch ldd
+    float* dHl; int lddl;               // += direct gradient wrt H_l (z_p*dP + dqs*w_q), row pitch lddl
+    float *DGI, *DGH;                   // [B*T,1800] each (written)
+    float *dR, *dks;                    // [B*T,600], [B*T]  (zero-initialised by the caller; accumulated here)
+    float* dlin;                        // [B,601] per-dialogue partial gradient of gather.linear
+    int B, T;
+};
+
+__global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.T;
+    __shared__ float v_g[320], v_dm[320], v_x[320], v_m[320], v_in[2 * G3], part[NW][320], s_al[MAX_T], s_da[MAX_T];
+    __shared__ float s_dqs;
+    const float* w_q = p.w_lin;
+    const float* w_k = p.w_lin + HID;
+    float dwq = 0.f, dwk = 0.f, dbl = 0.f;  // thread tid < HID owns element tid of dw_q / dw_k; thread 0 owns db
+
+    for (int i = T - 1; i >= 0; --i) {
+        const int64_t row = (int64_t)b * T + i;
+        // ---- 1: total gradient wrt h1_i = dH1_i + Wr^T dR_i + w_k dks_i
+        for (int r = tid; r < 2 * HID; r += NT) v_in[r] = p.dR[row * 2 * HID + r];
+        if (tid < HID) {
+            v_x[tid] = p.Hl[row * p.ldh + tid];
+            v_m[tid] = p.Mseq[row * HID + tid];
+        }
+        __syncthreads();
+        {
+            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            matvec_t_accum(p.Wr, 2 * HID, v_in, acc, lane, wave);
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+                if (lane + 64 * u < HID) part[wave][lane + 64 * u] = acc[u];
+        }
+        __syncthreads();
+        const float dks_i = p.dks[row];
+        if (tid < HID) {
+            float g = p.dH1[row * p.ldd + tid] + w_k[tid] * dks_i;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) g += part[w][tid];
+            v_g[tid] = g;
+            dwk += dks_i * p.H1[row * p.ldo + tid];
+        }
+        __syncthreads();
+        // ---- 2: GRU cells backward (elementwise), gate gradients out
+        if (tid < HID) {
+            const float* gi = p.GI + row * 2 * G3;
+            const float* gh = p.GH + row * 2 * G3;
+            float* dgi = p.DGI + row * 2 * G3;
+            float* dgh = p.DGH + row * 2 * G3;
+            const float g = v_g[tid];
+            // cell C: h = M_i
+            {
+                const float r = sigmoidf_(gi[tid] + gh[tid]);
+                const float z = sigmoidf_(gi[HID + tid] + gh[HID + tid]);
+                const float ghn = gh[2 * HID + tid];
+                const float nn = tanhf(gi[2 * HID + tid] + r * ghn);
+                const float dn_pre = g * (1.f - z) * (1.f - nn * nn);
+                const float dz_pre = g * (v_m[tid] - nn) * z * (1.f - z);
+                const float dr_pre = dn_pre * ghn * r * (1.f - r);
+                dgi[tid] = dr_pre; dgi[HID + tid] = dz_pre; dgi[2 * HID + tid] = dn_pre;
+                dgh[tid] = dr_pre; dgh[HID + tid] = dz_pre; dgh[2 * HID + tid] = dn_pre * r;
+                v_in[tid] = dr_pre; v_in[HID + tid] = dz_pre; v_in[2 * HID + tid] = dn_pre * r;
+                v_dm[tid] = g * z;  // direct path into M_i
+            }
+            // cell P: x = M_i (sequential side = GH[900:]), h = H_l[i] (hoisted side = GI[900:])
+            {
+                const float r = sigmoidf_(gh[G3 + tid] + gi[G3 + tid]);
+                const float z = sigmoidf_(gh[G3 + HID + tid] + gi[G3 + HID + tid]);
+                const float hn = gi[G3 + 2 * HID + tid];  // W_hn h + b_hn
+                const float nn = tanhf(gh[G3 + 2 * HID + tid] + r * hn);
+                const float dn_pre = g * (1.f - z) * (1.f - nn * nn);
+                const float dz_pre = g * (v_x[tid] - nn) * z * (1.f - z);
+                const float dr_pre = dn_pre * hn * r * (1.f - r);
+                dgh[G3 + tid] = dr_pre; dgh[G3 + HID + tid] = dz_pre; dgh[G3 + 2 * HID + tid] = dn_pre;
+                dgi[G3 + tid] = dr_pre; dgi[G3 + HID + tid] = dz_pre; dgi[G3 + 2 * HID + tid] = dn_pre * r;
+                v_in[G3 + tid] = dr_pre; v_in[G3 + HID + tid] = dz_pre; v_in[G3 + 2 * HID + tid] = dn_pre;
+                p.dHl[row * p.lddl + tid] += g * z;  // direct path into H_l[i]
+            }
+        }
+        __syncthreads();
+        if (i == 0) break;  // M_0 = 0 has no producers
+        // ---- 3: dM_i = direct + W_hh_c^T dgh_c + W_ih_p^T dgi_p
+        {
+            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            matvec_t_accum(p.W_hh_c, G3, v_in, acc, lane, wave);
+            matvec_t_accum(p.W_ih_p, G3, v_in + G3, acc, lane, wave);
+#pragma unroll
+            for (int u = 0; u < 5; ++u)
+                if (lane + 64 * u < HID) part[wave][lane + 64 * u] = acc[u];
+        }
+        __syncthreads();
+        if (tid < HID) {
+            float d = v_dm[tid];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) d += part[w][tid];
+            v_dm[tid] = d;
+        }
+        __syncthreads();
+        // ---- 4: attention backward over the window [lo, i-1]
+        const int pr = p.pred[row];
+        const int lo = pr > 0 ? pr : 0;
+        const int n = i - lo;
+        const int si = p.spk[row];
+        for (int j = wave; j < n; j += NW) {  // d alpha_j = dM . V_j
+            const int64_t rj = (int64_t)b * T + lo + j;
+            const float* v = p.R + rj * 2 * HID + (p.spk[rj] == si ? 0 : HID);
+            float a = v_dm[lane] * v[lane] + v_dm[lane + 64] * v[lane + 64] + v_dm[lane + 128] * v[lane + 128] +
+                      v_dm[lane + 192] * v[lane + 192];
+            if (lane + 256 < HID) a += v_dm[lane + 256] * v[lane + 256];
+            a = wave_sum(a);
+            if (lane == 0) {
+                s_da[j] = a;
+                s_al[j] = p.alpha[((int64_t)b * T + i) * T + lo + j];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float t = 0.f;
+            for (int j = lane; j < n; j += 64) t += s_al[j] * s_da[j];
+            t = wave_sum(t);
+            float dq = 0.f;
+            for (int j = lane; j < n; j += 64) {
+                const float ds = s_al[j] * (s_da[j] - t);
+                dq += ds;
+                p.dks[(int64_t)b * T + lo + j] += ds;
+            }
+            dq = wave_sum(dq);
+            if (lane == 0) s_dqs = dq;
+        }
+        __syncthreads();
+        if (tid < HID) {
+            const float dq = s_dqs;
+            const float dm = v_dm[tid];
+            for (int j = 0; j < n; ++j) {  // dV_j = alpha_j dM into the relation slot that was read
+                const int64_t rj = (int64_t)b * T + lo + j;
+                p.dR[rj * 2 * HID + (p.spk[rj] == si ? 0 : HID) + tid] += s_al[j] * dm;
+            }
+            p.dHl[row * p.lddl + tid] += dq * w_q[tid];
+            dwq += dq * v_x[tid];
+            if (tid == 0) dbl += dq;
+        }
+        __syncthreads();  // dR / dks updates must be visible to the earlier steps processed next
+    }
+    if (tid < HID) {
+        p.dlin[(int64_t)b * (2 * HID + 1) + tid] = dwq;
+        p.dlin[(int64_t)b * (2 * HID + 1) + HID + tid] = dwk;
+        if (tid == 0) p.dlin[(int64_t)b * (2 * HID + 1) + 2 * HID] = dbl;
+    }
+}
+
+}  // namespace
+
+extern "C" int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_t spk_sb, int64_t spk_st,
+                            int n_speakers, const int64_t* lengths, int B, int T, int32_t* spk, int32_t* pred,
+                            int32_t* node_off, int32_t* node_row, void* stream) {
+    ERC_REQUIRE((speaker_onehot != nullptr) != (speaker_ids != nullptr), "dag_meta: give one-hot OR ids");
+    ERC_REQUIRE(lengths && spk && pred && node_off && node_row, "dag_meta: null pointer");
+    ERC_REQUIRE(B > 0 && T > 0 && T <= MAX_T && n_speakers > 0, "dag_meta: B=%d T=%d (T <= %d)", B, T, MAX_T);
+    hipLaunchKernelGGL(dag_meta_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, speaker_onehot, speaker_ids, spk_sb,
+                       spk_st, n_speakers, lengths, B, T, spk, pred, node_off, node_row);
+    ERC_LAUNCH_CHECK("dag_meta");
+    return ERC_OK;
+}
+
+extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const float* W_hh_c, const float* b_hh_c,
+                                const float* W_ih_p, const float* b_ih_p, const float* Wr, const float* w_lin,
+                                const int32_t* pred, const int32_t* spk, int B, int T, float* H1, int ldo, float* Mseq,
+                                float* GH, float* R, float* ks, float* alpha, void* stream) {
+    ERC_REQUIRE(Hl && GI && W_hh_c && b_hh_c && W_ih_p && b_ih_p && Wr && w_lin && pred && spk && H1 && Mseq && GH &&
+                    R && ks && alpha,
+                "dag_scan_fwd: null pointer");
+    ERC_REQUIRE(B > 0 && T > 0 && T <= MAX_T && ldh >= HID && ldo >= HID, "dag_scan_fwd: bad sizes B=%d T=%d", B, T);
+    DagFwd p{Hl, ldh, GI, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_lin, pred, spk, H1, ldo, Mseq, GH, R, ks, alpha, B, T};
+    hipLaunchKernelGGL(dag_scan_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
+    ERC_LAUNCH_CHECK("dag_scan_fwd");
+    return ERC_OK;
+}
+
+extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
+                                const float* R, const float* alpha, const float* H1, int ldo, const float* W_hh_c,
+                                const float* W_ih_p, const float* Wr, const float* w_lin, const int32_t* pred,
+                                const int32_t* spk, int B, int T, const float* dH1, int ldd, float* dHl, int lddl,
+                                float* DGI, float* DGH, float* dR, float* dks, float* dlin, void* stream) {
+    ERC_REQUIRE(Hl && GI && GH && Mseq && R && alpha && H1 && W_hh_c && W_ih_p && Wr && w_lin && pred && spk && dH1 &&
+                    dHl && DGI && DGH && dR && dks && dlin,
+                "dag_scan_bwd: null pointer");
+    ERC_REQUIRE(B > 0 && T > 0 && T <= MAX_T, "dag_scan_bwd: bad sizes B=%d T=%d", B, T);
+    DagBwd p{Hl, ldh, GI, GH, Mseq, R, alpha, H1, ldo, W_hh_c, W_ih_p, Wr, w_lin, pred, spk,
+             dH1, ldd, dHl, lddl, DGI, DGH, dR, dks, dlin, B, T};
+    hipLaunchKernelGGL(dag_scan_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
+    ERC_LAUNCH_CHECK("dag_scan_bwd");
+    return ERC_OK;
+}

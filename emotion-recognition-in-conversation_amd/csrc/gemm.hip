@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
                 continue;
             }
             if (col < p.N) {
+                float* dst = C + (int64_t)row * p.ldc + col;
                 if (p.bias) v += p.bias[col];
+                if (p.accumulate) v += *dst;  // accumulate BEFORE the activation: relu(C_old + A B + bias)
                 if (p.act == 1)
                     v = fmaxf(v, 0.f);
                 else if (p.act == 2)
@@ -229,8 +231,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
                     const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)p.N + col);
                     v = (u >= p.drop_p) ? fmaxf(v, 0.f) * p.act_scale : 0.f;
                 }
-                float* dst = C + (int64_t)row * p.ldc + col;
-                *dst = p.accumulate ? (*dst + v) : v;
+                *dst = v;
             } else if (col == p.N && p.ones_col == 1 && p.bias_out) {
                 p.bias_out[(int64_t)z * p.bias_slab + row] = v;
             }
@@ -410,13 +411,16 @@ __global__ __launch_bounds__(256) void gemm_bf16x_kernel(GemmP p) {
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, int64_t stride,
                                                           const float* __restrict__ bias, int n_cols, int act,
-                                                          float* __restrict__ out, int64_t numel) {
+                                                          float* __restrict__ out, int ld_out, int64_t numel) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < S; ++s) v += slabs[(int64_t)s * stride + i];
         if (bias) v += bias[i % n_cols];
         if (act == 1) v = fmaxf(v, 0.f);
-        out[i] = v;
+        if (ld_out > 0)
+            out[(i / n_cols) * ld_out + i % n_cols] = v;
+        else
+            out[i] = v;
     }
 }
 
@@ -465,7 +469,7 @@ extern "C" int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux;
     p.M = M; p.N = N; p.K = K;
     const int nchunk = erc_cdiv(K, BK);
-    if (split_k > nchunk) split_k = nchunk;
+    ERC_REQUIRE(split_k <= nchunk, "gemm_f32: split_k %d exceeds the %d K-chunks (unwritten slabs)", split_k, nchunk);
     p.chunks_per_split = erc_cdiv(nchunk, split_k);
     p.ones_col = ones_col; p.act = act; p.accumulate = accumulate;
     p.a_vec = aligned16(A) && (lda % 4 == 0);
@@ -503,7 +507,7 @@ extern "C" int erc_gemm_bf16x(const void* A, int lda, int a_kmajor, const int32_
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;
     const int nchunk = erc_cdiv(K, BKH);
-    if (split_k > nchunk) split_k = nchunk;
+    ERC_REQUIRE(split_k <= nchunk, "gemm_bf16x: split_k %d exceeds the %d K-chunks (unwritten slabs)", split_k, nchunk);
     p.chunks_per_split = erc_cdiv(nchunk, split_k);
     p.ones_col = ones_col;
     // vector path: bf16 operand: 2 = 16-byte loads (ld % 8 == 0), 1 = 8-byte loads (ld % 4 == 0);
@@ -532,12 +536,12 @@ extern "C" int erc_gemm_bf16x(const void* A, int lda, int a_kmajor, const int32_
 }
 
 extern "C" int erc_slab_reduce(const float* slabs, int S, int64_t slab_stride, const float* bias, int n_cols, int act,
-                               float* out, int64_t numel, void* stream) {
+                               float* out, int ld_out, int64_t numel, void* stream) {
     ERC_REQUIRE(slabs && out && S >= 1 && numel > 0, "slab_reduce: bad arguments");
-    ERC_REQUIRE(!bias || n_cols > 0, "slab_reduce: bias needs n_cols");
+    ERC_REQUIRE((!bias && ld_out <= 0) || n_cols > 0, "slab_reduce: bias / ld_out need n_cols");
     const int grid = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, S, slab_stride, bias,
-                       n_cols, act, out, numel);
+                       n_cols, act, out, ld_out, numel);
     ERC_LAUNCH_CHECK("slab_reduce");
     return ERC_OK;
 }

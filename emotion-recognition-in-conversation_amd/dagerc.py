@@ -1,0 +1,263 @@
+"""DAG-ERC on the MI355X hot path (drop-in for track_mm/dagerc.py:73-237).
+
+``DAGERCModule`` keeps the reference's constructor signature, ``state_dict``
+keys (including the never-trained ``fcs.*`` and
+``attentive_node_features.transform.*``) and the
+``forward(**batch) -> (logits [B,T,C] padded, None)`` contract; the harness masks
+with ``attention_mask`` exactly as for the reference (dagerc.py:225).
+
+Per layer: one hoisted GEMM for the input-side gates of ``grus_c`` and the
+hidden-side gates of ``grus_p`` over all B*T rows, then the persistent
+per-dialogue scan kernel (csrc/dag_scan.hip).  The five hidden states
+H0..H4 are written straight into one [B*T, 1500] buffer, so the
+``torch.cat`` of dagerc.py:190-192 never happens: the head's first Linear is
+two GEMMs (hidden block, raw-feature block) summed by the slab reducer.
+"""
+import torch
+from torch import nn
+
+from . import capi
+from .engine import FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad
+
+HID = 300
+
+
+class _Gather(nn.Module):
+    """Parameter holder named like GAT_dialoggcn_v1 (dagerc_models.py:319-324)."""
+
+    def __init__(self, hidden):
+        super().__init__()
+        self.linear = nn.Linear(hidden * 2, 1)
+        self.Wr0 = nn.Linear(hidden, hidden, bias=False)
+        self.Wr1 = nn.Linear(hidden, hidden, bias=False)
+
+
+class _Attentive(nn.Module):
+    def __init__(self, hidden):
+        super().__init__()
+        self.transform = nn.Linear(hidden, hidden)   # unused (nodal_att_type None), dagerc_models.py:441-442
+
+
+class DAGERCModule(nn.Module):
+    def __init__(self, emb_dim=100, dropout=0.2, n_classes=7, gnn_layers=4, compute="f32", seed=1):
+        super().__init__()
+        self.emb_dim, self.n_classes, self.gnn_layers, self.compute = emb_dim, n_classes, gnn_layers, compute
+        self.drop_p = float(dropout)
+        self.dropout = nn.Dropout(dropout)
+        self.gather = nn.ModuleList([_Gather(HID) for _ in range(gnn_layers)])
+        self.grus_c = nn.ModuleList([nn.GRUCell(HID, HID) for _ in range(gnn_layers)])
+        self.grus_p = nn.ModuleList([nn.GRUCell(HID, HID) for _ in range(gnn_layers)])
+        self.fcs = nn.ModuleList([nn.Linear(HID * 2, HID) for _ in range(gnn_layers)])   # never used
+        self.fc1 = nn.Linear(emb_dim, HID)
+        in_dim = HID * (gnn_layers + 1) + emb_dim
+        self.in_dim = in_dim
+        self.out_mlp = nn.Sequential(nn.Linear(in_dim, HID), nn.ReLU(), nn.Linear(HID, HID), nn.ReLU(),
+                                     nn.Dropout(dropout), nn.Linear(HID, n_classes))
+        self.attentive_node_features = _Attentive(in_dim)
+        self.flat = None
+        self._ws = {}
+        self._seed = seed
+
+    # ------------------------------------------------------------------ setup
+    def live_groups(self):
+        groups = [[("fc1.weight", self.fc1.weight)], [("fc1.bias", self.fc1.bias)]]
+        for l in range(self.gnn_layers):
+            c, p, g = self.grus_c[l], self.grus_p[l], self.gather[l]
+            groups += [
+                [("grus_c.%d.weight_ih" % l, c.weight_ih), ("grus_p.%d.weight_hh" % l, p.weight_hh)],   # hoisted
+                [("grus_c.%d.bias_ih" % l, c.bias_ih), ("grus_p.%d.bias_hh" % l, p.bias_hh)],
+                [("grus_c.%d.weight_hh" % l, c.weight_hh), ("grus_p.%d.weight_ih" % l, p.weight_ih)],   # sequential
+                [("grus_c.%d.bias_hh" % l, c.bias_hh), ("grus_p.%d.bias_ih" % l, p.bias_ih)],
+                [("gather.%d.Wr0.weight" % l, g.Wr0.weight), ("gather.%d.Wr1.weight" % l, g.Wr1.weight)],
+                [("gather.%d.linear.weight" % l, g.linear.weight), ("gather.%d.linear.bias" % l, g.linear.bias)],
+            ]
+        m = self.out_mlp
+        groups += [[("out_mlp.0.weight", m[0].weight)], [("out_mlp.0.bias", m[0].bias)],
+                   [("out_mlp.2.weight", m[2].weight)], [("out_mlp.2.bias", m[2].bias)],
+                   [("out_mlp.5.weight", m[5].weight)], [("out_mlp.5.bias", m[5].bias)]]
+        return groups
+
+    def finalize(self, device):
+        self.to(device)
+        self.flat = FlatParams(self.live_groups(), device)
+        self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
+        return self
+
+    def _workspace(self, B, T, N, device):
+        key = (B, T, N)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        BT, L, C, D = B * T, self.gnn_layers, self.n_classes, self.emb_dim
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        ws = dict(
+            spk=i32(B, T), pred=i32(B, T), node_off=i32(B + 1), node_row=i32(max(N, 1)),
+            Hall=f32(BT, HID * (L + 1)), dHall=f32(BT, HID * (L + 1)),
+            GI=[f32(BT, 6 * HID) for _ in range(L)], GH=[f32(BT, 6 * HID) for _ in range(L)],
+            Mseq=[f32(BT, HID) for _ in range(L)], R=[f32(BT, 2 * HID) for _ in range(L)],
+            ks=[f32(BT) for _ in range(L)], alpha=[f32(B, T, T) for _ in range(L)],
+            Y1=f32(BT, HID), Y2=f32(BT, HID), logits=f32(BT, C), dlogits=f32(BT, C), dY2=f32(BT, HID),
+            dY1=f32(BT, HID), DGI=f32(BT, 6 * HID), DGH=f32(BT, 6 * HID),
+            zero=torch.zeros(BT * (2 * HID + 1), dtype=torch.float32, device=device),   # dR | dks, re-zeroed per layer
+            stats=f32(4),
+        )
+        ws["dR"] = ws["zero"][:BT * 2 * HID].view(BT, 2 * HID)
+        ws["dks"] = ws["zero"][BT * 2 * HID:]
+        slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
+        ws["planner"] = GemmPlanner(device, slab)
+        ws["jobs"] = None
+        self._ws[key] = ws
+        return ws
+
+    def _shape(self, input_tensor, text_length, label):
+        B, T = input_tensor.shape[0], input_tensor.shape[1]
+        N = int(label.shape[0]) if label is not None else int(text_length.sum().item())
+        return B, T, N
+
+    def _layer_w(self, l):
+        fp = self.flat
+        return dict(Whoist=fp.w("grus_c.%d.weight_ih" % l), bhoist=fp.w("grus_c.%d.bias_ih" % l),
+                    W_hh_c=fp.w("grus_c.%d.weight_hh" % l), b_hh_c=fp.w("grus_c.%d.bias_hh" % l),
+                    W_ih_p=fp.w("grus_p.%d.weight_ih" % l), b_ih_p=fp.w("grus_p.%d.bias_ih" % l),
+                    Wr=fp.w("gather.%d.Wr0.weight" % l), w_lin=fp.w("gather.%d.linear.weight" % l))
+
+    # ---------------------------------------------------------------- forward
+    def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training):
+        fp, dev = self.flat, x.device
+        ws = self._workspace(B, T, N, dev)
+        pl = ws["planner"]
+        pl.reset()
+        BT, L, C, D, W5 = B * T, self.gnn_layers, self.n_classes, self.emb_dim, HID * (self.gnn_layers + 1)
+        x_bf16 = x.dtype == torch.bfloat16
+        if speaker_tensor.dim() == 3:     # one-hot [B,T,S] (speaker_onehot=True, dagerc.py:41)
+            if speaker_tensor.stride(2) != 1:
+                speaker_tensor = speaker_tensor.contiguous()
+            capi.dag_meta(speaker_tensor.float() if speaker_tensor.dtype != torch.float32 else speaker_tensor, None,
+                          speaker_tensor.stride(0), speaker_tensor.stride(1), speaker_tensor.shape[2], text_length,
+                          B, T, ws["spk"], ws["pred"], ws["node_off"], ws["node_row"])
+        else:
+            capi.dag_meta(None, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
+                          1 << 30, text_length, B, T, ws["spk"], ws["pred"], ws["node_off"], ws["node_row"])
+        Hall = ws["Hall"]
+        # H0 = relu(fc1(x)) over ALL B*T rows, padded ones included (dagerc.py:164)
+        linear_fwd(pl, x, D, None, fp.w("fc1.weight"), fp.w("fc1.bias"), Hall, W5, BT, HID, D, act=1, x_bf16=x_bf16)
+        for l in range(L):
+            w = self._layer_w(l)
+            Hl, H1 = Hall[:, HID * l:], Hall[:, HID * (l + 1):]
+            linear_fwd(pl, Hl, W5, None, w["Whoist"], w["bhoist"], ws["GI"][l], 6 * HID, BT, 6 * HID, HID)
+            capi.dag_scan_fwd(Hl, W5, ws["GI"][l], w["W_hh_c"], w["b_hh_c"], w["W_ih_p"], w["b_ih_p"], w["Wr"],
+                              w["w_lin"], ws["pred"], ws["spk"], B, T, H1, W5, ws["Mseq"][l], ws["GH"][l], ws["R"][l],
+                              ws["ks"][l], ws["alpha"][l])
+        # head: Y1 = relu([Hall | x] W0^T + b0) as two GEMMs into one slab set
+        W0 = fp.w("out_mlp.0.weight")
+        Sa = pl.split_for(BT, HID, W5)
+        Sx = pl.split_for(BT, HID, D, bk=64 if x_bf16 else None, min_chunks=4 if x_bf16 else None)
+        src = pl.take((Sa + Sx) * BT * HID)
+        capi.gemm_f32(Hall, W5, 0, None, W0, self.in_dim, 0, None, pl.ws[src:], HID, BT, HID, W5, split_k=Sa,
+                      c_slab=BT * HID)
+        xs = pl.ws[src + Sa * BT * HID:]
+        if x_bf16:
+            capi.gemm_bf16x(x, D, 0, None, W0[:, W5:], self.in_dim, 0, None, 1, xs, HID, BT, HID, D, split_k=Sx,
+                            c_slab=BT * HID)
+        else:
+            capi.gemm_f32(x, D, 0, None, W0[:, W5:], self.in_dim, 0, None, xs, HID, BT, HID, D, split_k=Sx,
+                          c_slab=BT * HID)
+        capi.slab_reduce(pl.ws[src:], Sa + Sx, BT * HID, fp.w("out_mlp.0.bias"), HID, 1, ws["Y1"], BT * HID)
+        p = self.drop_p if training else 0.0
+        linear_fwd(pl, ws["Y1"], HID, None, fp.w("out_mlp.2.weight"), fp.w("out_mlp.2.bias"), ws["Y2"], HID, BT, HID,
+                   HID, act=3 if p > 0 else 1, drop_p=p, rng=self.rng_state)
+        linear_fwd(pl, ws["Y2"], HID, None, fp.w("out_mlp.5.weight"), fp.w("out_mlp.5.bias"), ws["logits"], C, BT, C,
+                   HID)
+        return ws
+
+    def forward(self, input_tensor, text_length, speaker_tensor, label=None, **kwargs):
+        if self.flat is None:
+            raise capi.ErcGraftError("call DAGERCModule.finalize(device) before forward")
+        B, T, N = self._shape(input_tensor, text_length, label)
+        ws = self._forward_impl(input_tensor, speaker_tensor, text_length, B, T, N, self.training)
+        return ws["logits"].view(B, T, self.n_classes), None
+
+    # --------------------------------------------------------------- training
+    def loss_and_grads(self, batch):
+        x, spk, lens, ys = batch["input_tensor"], batch["speaker_tensor"], batch["text_length"], batch["label"]
+        B, T, N = self._shape(x, lens, ys)
+        training = self.training
+        ws = self._forward_impl(x, spk, lens, B, T, N, training)
+        fp, pl = self.flat, ws["planner"]
+        BT, L, C, D, W5 = B * T, self.gnn_layers, self.n_classes, self.emb_dim, HID * (self.gnn_layers + 1)
+        x_bf16 = x.dtype == torch.bfloat16
+        off = fp.offsets
+        # masked CE (dagerc.py:225-226): the mask is the valid-row map; padded rows get zero gradient
+        ws["dlogits"].zero_()
+        capi.cross_entropy(ws["logits"], C, C, N, ws["node_row"], ys, None, 1.0, ws["dlogits"], C, ws["stats"])
+        p = self.drop_p if training else 0.0
+        capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("out_mlp.5.weight"), HID, 1, None, ws["dY2"], HID, BT, HID, C,
+                      act=2, aux=ws["Y2"], ldaux=HID, act_scale=1.0 / (1.0 - p))
+        linear_wgrad(pl, ws["dlogits"], C, ws["Y2"], HID, None, C, HID, BT, off["out_mlp.5.weight"],
+                     off["out_mlp.5.bias"])
+        capi.gemm_f32(ws["dY2"], HID, 0, None, fp.w("out_mlp.2.weight"), HID, 1, None, ws["dY1"], HID, BT, HID, HID,
+                      act=2, aux=ws["Y1"], ldaux=HID, act_scale=1.0)
+        linear_wgrad(pl, ws["dY2"], HID, ws["Y1"], HID, None, HID, HID, BT, off["out_mlp.2.weight"],
+                     off["out_mlp.2.bias"])
+        # dHall = dY1 W0[:, :1500]; dW0 = dY1^T [Hall | x] as two column slices of one slab set
+        W0 = fp.w("out_mlp.0.weight")
+        capi.gemm_f32(ws["dY1"], HID, 0, None, W0, self.in_dim, 1, None, ws["dHall"], W5, BT, W5, HID)
+        slab = linear_wgrad(pl, ws["dY1"], HID, ws["Hall"], W5, None, HID, W5, BT, off["out_mlp.0.weight"], None,
+                            ld_w=self.in_dim)
+        linear_wgrad(pl, ws["dY1"], HID, x, D, None, HID, D, BT, None, off["out_mlp.0.bias"], x_bf16=x_bf16,
+                     slab=slab, col_off=W5)
+        for l in range(L - 1, -1, -1):
+            w = self._layer_w(l)
+            Hl, H1 = ws["Hall"][:, HID * l:], ws["Hall"][:, HID * (l + 1):]
+            dHl, dH1 = ws["dHall"][:, HID * l:], ws["dHall"][:, HID * (l + 1):]
+            ws["zero"].zero_()
+            dlin = pl.take(B * (2 * HID + 1))
+            capi.dag_scan_bwd(Hl, W5, ws["GI"][l], ws["GH"][l], ws["Mseq"][l], ws["R"][l], ws["alpha"][l], H1, W5,
+                              w["W_hh_c"], w["W_ih_p"], w["Wr"], w["w_lin"], ws["pred"], ws["spk"], B, T, dH1, W5,
+                              dHl, W5, ws["DGI"], ws["DGH"], ws["dR"], ws["dks"], pl.ws[dlin:])
+            pl.add_job(dlin, 2 * HID + 1, B, 2 * HID + 1, off["gather.%d.linear.weight" % l])
+            # dH_l += DGI [W_ih_c ; W_hh_p]; on layer 0 the same launch applies the relu mask of fc1
+            capi.gemm_f32(ws["DGI"], 6 * HID, 0, None, w["Whoist"], HID, 1, None, dHl, W5, BT, HID, 6 * HID,
+                          accumulate=1, act=2 if l == 0 else 0, aux=Hl if l == 0 else None, ldaux=W5, act_scale=1.0)
+            linear_wgrad(pl, ws["DGI"], 6 * HID, Hl, W5, None, 6 * HID, HID, BT, off["grus_c.%d.weight_ih" % l],
+                         off["grus_c.%d.bias_ih" % l])
+            linear_wgrad(pl, ws["DGH"], 6 * HID, ws["Mseq"][l], HID, None, 6 * HID, HID, BT,
+                         off["grus_c.%d.weight_hh" % l], off["grus_c.%d.bias_hh" % l])
+            linear_wgrad(pl, ws["dR"], 2 * HID, H1, W5, None, 2 * HID, HID, BT, off["gather.%d.Wr0.weight" % l], None)
+        linear_wgrad(pl, ws["dHall"], W5, x, D, None, HID, D, BT, off["fc1.weight"], off["fc1.bias"], x_bf16=x_bf16)
+        if ws["jobs"] is None or ws["jobs"].shape[0] != len(pl.jobs):
+            ws["jobs"] = pl.job_table()
+        capi.slab_reduce_batched(pl.ws, fp.grad, ws["jobs"], len(pl.jobs), pl.max_numel)
+        return ws["stats"]
+
+
+class DAGERCTrainer:
+    """train_step / to_logits of track_mm/dagerc.py:201-237 (masked CE, clip_grad_norm_ 5, AdamW)."""
+
+    def __init__(self, params, device):
+        self.params, self.device = params, torch.device(device)
+        torch.manual_seed(params.seed)
+        self.model = DAGERCModule(emb_dim=params.hidden_all, dropout=params.get("dropout", 0),
+                                  n_classes=params.n_classes, gnn_layers=params.get("gnn_layers", 4),
+                                  compute=params.get("compute", "f32"), seed=params.seed).finalize(self.device)
+        o = params.optim
+        self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.get("weight_decay", 1e-2),
+                               decoupled=(o.name == "AdamW"), clip_norm=5.0, seed=params.seed)
+        self.model.rng_state = self.optim.rng_state
+
+    def to_logits(self, batch):
+        return self.model(**batch)[0]
+
+    def prepare_batch(self, batch):
+        out = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        if self.model.compute == "bf16":
+            out["input_tensor"] = out["input_tensor"].to(torch.bfloat16)
+        return out
+
+    def train_step(self, batch):
+        self.model.train()
+        stats = self.model.loss_and_grads(batch)
+        scale = all_reduce_grads(self.model.flat)
+        self.optim.step(grad_scale=scale)
+        return stats

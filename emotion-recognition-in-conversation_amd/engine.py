@@ -104,44 +104,55 @@ class GemmPlanner:
         return torch.tensor(self.jobs, dtype=torch.int64, device=self.device)
 
 
-def linear_fwd(pl, x, ldx, gather, W, bias, out, ldo, M, N, K, act=0, drop_p=0.0, rng=None, x_bf16=False):
-    """out[M,N] = act(x[M,K] @ W[N,K]^T + bias): nn.Linear forward.  Split-K + slab reduce when K is long."""
+def linear_fwd(pl, x, ldx, gather, W, bias, out, ldo, M, N, K, act=0, drop_p=0.0, rng=None, x_bf16=False, ldw=None):
+    """out[M,N] (row pitch ldo) = act(x[M,K] @ W[N,K]^T + bias): nn.Linear forward.
+    Split-K + slab reduce when K is long.  ``ldw`` = row pitch of W (column slice of a wider weight)."""
+    ldw = K if ldw is None else ldw
     if x_bf16:
         S = pl.split_for(M, N, K, bk=64, min_chunks=4)
         src = pl.take(S * M * N)
-        capi.gemm_bf16x(x, ldx, 0, gather, W, K, 0, None, 1, pl.ws[src:], N, M, N, K, split_k=S, c_slab=M * N)
-        capi.slab_reduce(pl.ws[src:], S, M * N, bias, N, act, out, M * N)
-        assert ldo == N
+        capi.gemm_bf16x(x, ldx, 0, gather, W, ldw, 0, None, 1, pl.ws[src:], N, M, N, K, split_k=S, c_slab=M * N)
+        capi.slab_reduce(pl.ws[src:], S, M * N, bias, N, act, out, M * N, ld_out=0 if ldo == N else ldo)
         return
     S = pl.split_for(M, N, K)
     if S == 1:
-        capi.gemm_f32(x, ldx, 0, gather, W, K, 0, None, out, ldo, M, N, K, bias=bias, act=act,
+        capi.gemm_f32(x, ldx, 0, gather, W, ldw, 0, None, out, ldo, M, N, K, bias=bias, act=act,
                       act_scale=(1.0 / (1.0 - drop_p) if act == 3 else 1.0), drop_p=drop_p, rng_state=rng)
     else:
-        assert act in (0, 1) and ldo == N
+        assert act in (0, 1)
         src = pl.take(S * M * N)
-        capi.gemm_f32(x, ldx, 0, gather, W, K, 0, None, pl.ws[src:], N, M, N, K, split_k=S, c_slab=M * N)
-        capi.slab_reduce(pl.ws[src:], S, M * N, bias, N, act, out, M * N)
+        capi.gemm_f32(x, ldx, 0, gather, W, ldw, 0, None, pl.ws[src:], N, M, N, K, split_k=S, c_slab=M * N)
+        capi.slab_reduce(pl.ws[src:], S, M * N, bias, N, act, out, M * N, ld_out=0 if ldo == N else ldo)
 
 
-def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off, x_bf16=False):
+def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off, x_bf16=False,
+                 slab=None, col_off=0, ld_w=None):
     """dW[n_out,n_in] = dy^T x and db[n_out] = colsum(dy) into slabs; registers the reduce jobs.
-    (nn.Linear weight layout [out,in].)"""
-    if x_bf16:
-        S = pl.split_for(n_out, n_in + 1, n_rows, bk=64, min_chunks=2)
+    (nn.Linear weight layout [out,in].)  ``slab`` = (src_w, S, ld_w) lets several calls fill column slices
+    [col_off, col_off+n_in) of ONE wider gradient (concatenated inputs); only the call that passes
+    ``w_off`` registers the job."""
+    ld_w = n_in if ld_w is None else ld_w
+    if slab is None:
+        S = pl.split_for(n_out, n_in + 1, n_rows, bk=64 if x_bf16 else None, min_chunks=2)
+        src_w = pl.take(S * n_out * ld_w)
     else:
-        S = pl.split_for(n_out, n_in + 1, n_rows, min_chunks=2)
-    src_w = pl.take(S * n_out * n_in)
-    src_b = pl.take(S * n_out)
+        src_w, S, ld_w = slab
+    want_b = b_off is not None
+    src_b = pl.take(S * n_out) if want_b else 0
+    cbase = pl.ws[src_w + col_off:]
     if x_bf16:
-        capi.gemm_bf16x(dy, lddy, 1, None, x, ldx, 1, gather, 0, pl.ws[src_w:], n_in, n_out, n_in, n_rows,
-                        split_k=S, c_slab=n_out * n_in, ones_col=1, bias_out=pl.ws[src_b:], bias_slab=n_out)
+        capi.gemm_bf16x(dy, lddy, 1, None, x, ldx, 1, gather, 0, cbase, ld_w, n_out, n_in, n_rows,
+                        split_k=S, c_slab=n_out * ld_w, ones_col=1 if want_b else 0,
+                        bias_out=pl.ws[src_b:] if want_b else None, bias_slab=n_out)
     else:
-        capi.gemm_f32(dy, lddy, 1, None, x, ldx, 1, gather, pl.ws[src_w:], n_in, n_out, n_in, n_rows,
-                      split_k=S, c_slab=n_out * n_in, ones_col=1, bias_out=pl.ws[src_b:], bias_slab=n_out)
-    pl.add_job(src_w, n_out * n_in, S, n_out * n_in, w_off)
-    if b_off is not None:
+        capi.gemm_f32(dy, lddy, 1, None, x, ldx, 1, gather, cbase, ld_w, n_out, n_in, n_rows,
+                      split_k=S, c_slab=n_out * ld_w, ones_col=1 if want_b else 0,
+                      bias_out=pl.ws[src_b:] if want_b else None, bias_slab=n_out)
+    if w_off is not None:
+        pl.add_job(src_w, n_out * ld_w, S, n_out * ld_w, w_off)
+    if want_b:
         pl.add_job(src_b, n_out, S, n_out, b_off)
+    return src_w, S, ld_w
 
 
 def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off):

@@ -116,9 +116,10 @@ int erc_gemm_bf16x(const void* A, int lda, int a_kmajor, const int32_t* a_gather
                    int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
                    void* stream);
 
-/* out[i] = act( sum_{s<S} slabs[s*slab_stride + i] + (bias ? bias[i % n_cols] : 0) ), i < numel */
+/* out[(i / n_cols)*ld_out + i % n_cols] = act( sum_{s<S} slabs[s*slab_stride + i] + (bias ? bias[i % n_cols] : 0) ),
+ * i < numel; ld_out = 0 means contiguous (ld_out = n_cols). */
 int erc_slab_reduce(const float* slabs, int S, int64_t slab_stride, const float* bias, int n_cols, int act,
-                    float* out, int64_t numel, void* stream);
+                    float* out, int ld_out, int64_t numel, void* stream);
 
 /* Batched form for weight gradients: job j reduces S[j] slabs of numel[j]
  * floats at ws + src[j] (stride = stride[j]) into dst + dst_off[j].
@@ -213,6 +214,50 @@ int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float grad_scale, float clip_norm, const float* gnorm, int64_t* state, void* stream);
 /* gnorm[0] = ||g * grad_scale||_2 ; ws >= 1024 floats */
 int erc_grad_norm(const float* g, int64_t n, float grad_scale, float* gnorm, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K6  DAG-ERC (track_mm/dagerc.py:109-189, track_mm/dagerc_models.py:312-365).
+ *
+ * erc_dag_meta: speaker ids (argmax of the one-hot speaker tensor, or integer
+ * ids), DAG predecessor pred[b,t] = largest j < t with the same speaker (-1 if
+ * none) -- row t of get_adj_v1's matrix (dagerc.py:109-129, windowp = 1) is
+ * ones on [max(pred,0), t-1]; get_s_mask (dagerc.py:131-154) is spk[b,i]==spk[b,j].
+ * Runs over the padded length T like the reference (pad = speaker 0).  Also
+ * emits node_off [B+1] / node_row [N] (valid row b*T+t per utterance) used as
+ * the row map of the masked cross entropy (dagerc.py:225).
+ *   speaker_onehot: float, element (b,t,c) at [b*spk_sb + t*spk_st + c]; or
+ *   speaker_ids: int64, element (b,t) at [b*spk_sb + t*spk_st].
+ */
+int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_t spk_sb, int64_t spk_st,
+                 int n_speakers, const int64_t* lengths, int B, int T,
+                 int32_t* spk, int32_t* pred, int32_t* node_off, int32_t* node_row, void* stream);
+
+/* One layer of the recurrence (dagerc.py:167-189), hidden size 300, one
+ * persistent workgroup per dialogue, steps t = 0..T-1:
+ *   M_t  = sum_{j in [max(pred,0), t-1]} softmax_j(w_q.H_l[t] + w_k.h_j + b) * (same speaker ? Wr0 h_j : Wr1 h_j)
+ *   h_t  = GRUCell_c(x = H_l[t], h = M_t) + GRUCell_p(x = M_t, h = H_l[t])
+ * GI [B*T,1800] holds the hoisted gate pre-activations
+ *   [W_ih(grus_c) H_l + b_ih(grus_c) | W_hh(grus_p) H_l + b_hh(grus_p)]  (one GEMM by the caller);
+ * W_hh_c/b_hh_c = grus_c.weight_hh/bias_hh, W_ih_p/b_ih_p = grus_p.weight_ih/bias_ih, Wr = [Wr0;Wr1] [600,300],
+ * w_lin [601] = gather.linear.weight (w_q | w_k) followed by its bias.
+ * Saved for the backward: Mseq [B*T,300], GH [B*T,1800] (sequential gate pre-activations),
+ * R [B*T,600] (Wr0 h | Wr1 h), ks [B*T] (w_k.h), alpha [B,T,T].
+ */
+int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
+                     const float* W_hh_c, const float* b_hh_c, const float* W_ih_p, const float* b_ih_p,
+                     const float* Wr, const float* w_lin, const int32_t* pred, const int32_t* spk, int B, int T,
+                     float* H1, int ldo, float* Mseq, float* GH, float* R, float* ks, float* alpha, void* stream);
+/* Reverse scan.  dH1 = complete gradient wrt the layer outputs.  Writes the gate gradients DGI / DGH
+ * [B*T,1800] (weight gradients are then plain GEMMs: d[W_ih_c;W_hh_p] = DGI^T H_l, d[W_hh_c;W_ih_p] = DGH^T Mseq,
+ * d[Wr0;Wr1] = dR^T H1, dH_l += DGI [W_ih_c;W_hh_p]); accumulates dR [B*T,600] / dks [B*T] (caller zero-fills),
+ * ADDS the direct gradient wrt H_l into dHl, and writes the per-dialogue partial gradient of gather.linear
+ * to dlin [B,601]. */
+int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
+                     const float* R, const float* alpha, const float* H1, int ldo,
+                     const float* W_hh_c, const float* W_ih_p, const float* Wr, const float* w_lin,
+                     const int32_t* pred, const int32_t* spk, int B, int T,
+                     const float* dH1, int ldd, float* dHl, int lddl,
+                     float* DGI, float* DGH, float* dR, float* dks, float* dlin, void* stream);
 
 #ifdef __cplusplus
 }

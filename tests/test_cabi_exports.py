@@ -23,7 +23,7 @@ def test_library_builds_and_exports_header_symbols():
 
 def test_argument_errors_are_reported_not_thrown():
     lib = capi.lib()
-    rc = lib.erc_slab_reduce(None, 1, 0, None, 0, 0, None, 0, None)
+    rc = lib.erc_slab_reduce(None, 1, 0, None, 0, 0, None, 0, 0, None)
     assert rc == -1 and b"slab_reduce" in lib.erc_last_error()
 
 

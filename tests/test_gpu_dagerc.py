@@ -1,0 +1,110 @@
+"""DAG-ERC on the GPU vs (a) golden vectors produced by the REFERENCE's own DAGERCModule and (b) the CPU oracle
+at larger shapes.  Integer structure (predecessors / speaker ids) bit-exact; logits within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util_cases import check_grad_digest, fill_params, make_batch, rel_err, to_device
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _load(golden, name, compute="f32"):
+    from erc_amd.dagerc import DAGERCModule
+    fx = golden(name)
+    batch = {k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("in_")}
+    D, C = int(fx["dims"].sum()), int(fx["n_classes"])
+    model = DAGERCModule(emb_dim=D, dropout=0.0, n_classes=C, gnn_layers=4, compute=compute)
+    fill_params(model, int(fx["param_seed"]))
+    model.finalize(DEV)
+    return fx, batch, model
+
+
+@pytest.mark.parametrize("name", ["dagerc_small", "dagerc_s3"])
+def test_dag_structure_bit_exact_vs_reference(golden, name):
+    fx, batch, model = _load(golden, name)
+    model.eval()
+    model(**to_device(batch, DEV))
+    B, T = batch["input_tensor"].shape[:2]
+    ws = model._ws[(B, T, int(batch["label"].shape[0]))]
+    spk, pred = ws["spk"].cpu().numpy(), ws["pred"].cpu().numpy()
+    adj = np.zeros((B, T, T), dtype=np.float32)
+    for b in range(B):
+        for i in range(T):
+            adj[b, i, max(pred[b, i], 0):i] = 1
+    np.testing.assert_array_equal(adj, fx["adj"])                                  # get_adj_v1
+    np.testing.assert_array_equal((spk[:, :, None] == spk[:, None, :]).astype(np.int64), fx["s_mask"])  # get_s_mask
+    rows = np.concatenate([b * T + np.arange(L) for b, L in enumerate(batch["text_length"].tolist())])
+    np.testing.assert_array_equal(ws["node_row"].cpu().numpy(), rows)
+
+
+@pytest.mark.parametrize("name", ["dagerc_small", "dagerc_s3"])
+def test_dagerc_matches_reference_golden(golden, name):
+    """logits (all B*T padded rows), masked CE loss and every live gradient vs the reference's own module."""
+    fx, batch, model = _load(golden, name)
+    model.train()
+    stats = model.loss_and_grads(to_device(batch, DEV)).cpu()
+    B, T = batch["input_tensor"].shape[:2]
+    logits = model._ws[(B, T, int(batch["label"].shape[0]))]["logits"].view(B, T, -1).cpu()
+    assert float((logits - torch.from_numpy(fx["logits"])).abs().max()) < 1e-4
+    assert abs(float(stats[0]) - float(fx["loss"])) < 1e-5
+    worst = check_grad_digest(fx, [(n, model.flat.g(n)) for n in model.flat.params], tol=2e-3)
+    live = set(model.flat.params)
+    assert live.isdisjoint(set(fx["grad_none"].tolist()))            # never-trained parameters stay out of the flat buffer
+    assert len(live) + len(fx["grad_none"]) == len(list(model.named_parameters()))
+    print("worst relative gradient error", worst)
+
+
+@pytest.mark.parametrize("B,lens,dims,S,C", [(16, (20, 110), dict(a=100, t=100, v=512), 2, 6),
+                                             (5, (1, 40), dict(a=30, t=60, v=34), 9, 7)])
+def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C):
+    """BASELINE config-4 shape (B=16, T=110, D=712) and a multi-speaker ragged case vs the (reference-pinned) oracle."""
+    from oracle.dagerc import DAGERCOracle, dagerc_loss
+    from erc_amd.dagerc import DAGERCModule
+    batch = make_batch(B, dims, n_speakers=S, n_classes=C, min_len=lens[0], max_len=lens[1], seed=8,
+                       speaker_onehot=True, force_max=True)
+    D = sum(dims.values())
+    torch.manual_seed(5)
+    ref = DAGERCOracle(emb_dim=D, dropout=0.0, n_classes=C, gnn_layers=4)
+    mine = DAGERCModule(emb_dim=D, dropout=0.0, n_classes=C, gnn_layers=4)
+    mine.load_state_dict(ref.state_dict())
+    mine.finalize(DEV)
+    ref.train(), mine.train()
+    torch.set_num_threads(8)
+    loss, _ = dagerc_loss(ref, batch)
+    loss.backward()
+    want, _ = ref(**batch)
+    stats = mine.loss_and_grads(to_device(batch, DEV)).cpu()
+    T = batch["input_tensor"].shape[1]
+    got = mine._ws[(B, T, int(batch["label"].shape[0]))]["logits"].view(B, T, -1).cpu()
+    valid = batch["attention_mask"].bool()
+    assert float((got[valid] - want.detach()[valid]).abs().max()) < 1e-4
+    assert float((got - want.detach()).abs().max()) < 1e-4              # padded rows too (finite garbage, same garbage)
+    assert abs(float(stats[0]) - float(loss)) < 1e-5
+    refp = dict(ref.named_parameters())
+    for n in mine.flat.params:
+        assert rel_err(mine.flat.g(n).cpu(), refp[n].grad) < 2e-3, n
+
+
+def test_dagerc_train_step_clip_adamw():
+    from oracle.dagerc import DAGERCOracle, dagerc_train_step
+    from erc_amd.dagerc import DAGERCTrainer
+    from erc_amd.params import ERCParams, Group
+    p = ERCParams().from_args(["--dataset=iemocap-cogmen-6", "--modality=at"])
+    p.optim = Group(name="AdamW", lr=1e-3, weight_decay=1e-2)
+    p.speaker_onehot, p.dropout = True, 0.0
+    tr = DAGERCTrainer(p, DEV)
+    ref = DAGERCOracle(emb_dim=p.hidden_all, dropout=0.0, n_classes=p.n_classes)
+    ref.load_state_dict({k: v.cpu() for k, v in tr.model.state_dict().items()})
+    opt = torch.optim.AdamW([q for q in ref.parameters()], lr=1e-3)
+    ref.train()
+    for step in range(2):
+        batch = make_batch(3, p.dims(), n_classes=6, min_len=2, max_len=12, seed=30 + step, modality="at",
+                           speaker_onehot=True)
+        loss, _ = dagerc_train_step(ref, opt, batch)
+        stats = tr.train_step(tr.prepare_batch(batch)).cpu()
+        assert abs(float(stats[0]) - float(loss)) < 2e-5
+    refp = dict(ref.named_parameters())
+    for n in tr.model.flat.params:
+        assert float((tr.model.flat.w(n).cpu() - refp[n].detach()).abs().max()) < 2e-4, n
