@@ -37,6 +37,10 @@ _SIGS = {
     "erc_cross_entropy": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp]),
     "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
+    "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
+                                    C.c_uint64, _vp, _vp, _vp, _vp]),
+    "erc_lstm_scan_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _i, _f, _vp, C.c_uint64, _vp,
+                                    _vp]),
     "erc_dag_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_dag_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
                                    _vp, _vp, _vp, _vp]),
@@ -211,3 +215,16 @@ def dag_scan_bwd(Hl, ldh, GI, GH, Mseq, R, alpha, H1, ldo, W_hh_c, W_ih_p, Wr, w
                                   ptr(W_hh_c), ptr(W_ih_p), ptr(Wr), ptr(w_lin), ptr(pred), ptr(spk), B, T, ptr(dH1),
                                   ldd, ptr(dHl), lddl, ptr(DGI), ptr(DGH), ptr(dR), ptr(dks), ptr(dlin), stream()),
            "erc_dag_scan_bwd")
+
+
+def lstm_scan_fwd(GX, ldgx, W_hh, b_hh, lengths, node_off, sb, st, B, T, Hout, ldh, Hdrop, ldhd, drop_p, rng,
+                  rng_stream, gates, Cst, Hprev):
+    _check(lib().erc_lstm_scan_fwd(ptr(GX), ldgx, ptr(W_hh), ptr(b_hh), ptr(lengths), ptr(node_off), sb, st, B, T,
+                                   ptr(Hout), ldh, ptr(Hdrop), ldhd, drop_p, ptr(rng), rng_stream, ptr(gates),
+                                   ptr(Cst), ptr(Hprev), stream()), "erc_lstm_scan_fwd")
+
+
+def lstm_scan_bwd(W_hh, lengths, node_off, sb, st, B, T, gates, Cst, dHout, lddh, drop_p, rng, rng_stream, dGX):
+    _check(lib().erc_lstm_scan_bwd(ptr(W_hh), ptr(lengths), ptr(node_off), sb, st, B, T, ptr(gates), ptr(Cst),
+                                   ptr(dHout), lddh, drop_p, ptr(rng), rng_stream, ptr(dGX), stream()),
+           "erc_lstm_scan_bwd")

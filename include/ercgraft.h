@@ -259,6 +259,30 @@ int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH,
                      const float* dH1, int ldd, float* dHl, int lddl,
                      float* DGI, float* DGH, float* dR, float* dks, float* dlin, void* stream);
 
+/* ------------------------------------------------------------------------
+ * (Bi)LSTM recurrence, hidden 100 per direction, torch.nn.LSTM semantics (gate order i|f|g|o):
+ * DialogueGCN SeqContext (packed; track_mm/dgcn_models.py:10-33) and MMGCN's text branch (unpacked over
+ * the padded length; track_mm/mmgcn.py:69,113-114).  One layer, both directions per call.
+ *   GX [rows, >=800]: hoisted x W_ih^T + b_ih, direction d in columns [400d, 400d+400)  (one GEMM by the caller)
+ *   W_hh [2][400,100], b_hh [2][400]: weight_hh_l{k}, weight_hh_l{k}_reverse and their biases
+ *   lengths: int64 [B] (packed: dialogue b runs L_b steps, the reverse direction starts at L_b-1; positions
+ *            >= L_b produce zeros) or NULL (every dialogue runs T steps)
+ *   rows: row(b,t) = b*sb + t*st (in rows), or node_off[b] + t when node_off != NULL
+ *   Hout [rows, ldh] columns [100d,100d+100); Hdrop (optional): the same with inverted dropout(drop_p)
+ *   applied -- the inter-layer dropout of nn.LSTM; mask keyed by (rng_state, rng_stream, element)
+ *   saved for the backward: gates [rows,800] (post-activation), Cst [rows,200], Hprev [rows,200] (h_{t-1} in
+ *   scan order: dW_hh[d] = dGX[:,400d:]^T Hprev[:,100d:])
+ * Backward: dHout = gradient wrt Hout (wrt Hdrop when drop_p > 0); writes dGX [rows,800] (zero on padded
+ * rows); dW_ih = dGX^T x, db = colsum(dGX), dx = dGX W_ih are GEMMs by the caller.
+ */
+int erc_lstm_scan_fwd(const float* GX, int ldgx, const float* W_hh, const float* b_hh, const int64_t* lengths,
+                      const int32_t* node_off, int64_t sb, int64_t st, int B, int T,
+                      float* Hout, int ldh, float* Hdrop, int ldhd, float drop_p, const uint64_t* rng_state,
+                      uint64_t rng_stream, float* gates, float* Cst, float* Hprev, void* stream);
+int erc_lstm_scan_bwd(const float* W_hh, const int64_t* lengths, const int32_t* node_off, int64_t sb, int64_t st,
+                      int B, int T, const float* gates, const float* Cst, const float* dHout, int lddh,
+                      float drop_p, const uint64_t* rng_state, uint64_t rng_stream, float* dGX, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
