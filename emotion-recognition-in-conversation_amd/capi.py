@@ -41,6 +41,15 @@ _SIGS = {
                                     C.c_uint64, _vp, _vp, _vp, _vp]),
     "erc_lstm_scan_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _i, _f, _vp, C.c_uint64, _vp,
                                     _vp]),
+    "erc_gather_rows": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "erc_edge_att_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "erc_edge_att_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i,
+                                   _vp, _vp]),
+    "erc_brgcn_agg_fwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "erc_brgcn_bwd_edges": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "erc_brgcn_bwd_source": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "erc_transpose_batched": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
+    "erc_csr_sum": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "erc_dag_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_dag_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
                                    _vp, _vp, _vp, _vp]),
@@ -228,3 +237,45 @@ def lstm_scan_bwd(W_hh, lengths, node_off, sb, st, B, T, gates, Cst, dHout, lddh
     _check(lib().erc_lstm_scan_bwd(ptr(W_hh), ptr(lengths), ptr(node_off), sb, st, B, T, ptr(gates), ptr(Cst),
                                    ptr(dHout), lddh, drop_p, ptr(rng), rng_stream, ptr(dGX), stream()),
            "erc_lstm_scan_bwd")
+
+
+def gather_rows(src, lds, map_, N, F, dst, ldd, scatter=0):
+    _check(lib().erc_gather_rows(ptr(src), lds, ptr(map_), N, F, ptr(dst), ldd, scatter, stream()), "erc_gather_rows")
+
+
+def edge_att_fwd(x, ldx, att, lda, F, N, g, norm):
+    _check(lib().erc_edge_att_fwd(ptr(x), ldx, ptr(att), lda, F, N, ptr(g["out_ptr"]), ptr(g["out_dst"]),
+                                  ptr(g["out_eid"]), ptr(norm), stream()), "erc_edge_att_fwd")
+
+
+def edge_att_bwd(x, ldx, att, lda, F, N, g, norm, dnorm, dx, lddx, accumulate_dx, datt, ldda, dscore):
+    _check(lib().erc_edge_att_bwd(ptr(x), ldx, ptr(att), lda, F, N, ptr(g["in_ptr"]), ptr(g["in_src"]),
+                                  ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_eid"]), ptr(norm), ptr(dnorm),
+                                  ptr(dx), lddx, accumulate_dx, ptr(datt), ldda, ptr(dscore), stream()),
+           "erc_edge_att_bwd")
+
+
+def brgcn_agg_fwd(x, ldx, F, N, g, norm, att, nb, Z):
+    _check(lib().erc_brgcn_agg_fwd(ptr(x), ldx, F, N, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]), ptr(norm),
+                                   ptr(att), nb, ptr(Z), stream()), "erc_brgcn_agg_fwd")
+
+
+def brgcn_bwd_edges(x, ldx, F, N, R, g, norm, att, nb, dZ, dnorm, TT, datt):
+    _check(lib().erc_brgcn_bwd_edges(ptr(x), ldx, F, N, R, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
+                                     ptr(g["counts"]), ptr(norm), ptr(att), nb, ptr(dZ), ptr(dnorm), ptr(TT),
+                                     ptr(datt), stream()), "erc_brgcn_bwd_edges")
+
+
+def brgcn_bwd_source(dH, lddh, O, N, g, norm, att, nb, U):
+    _check(lib().erc_brgcn_bwd_source(ptr(dH), lddh, O, N, ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]),
+                                      ptr(g["out_eid"]), ptr(norm), ptr(att), nb, ptr(U), stream()),
+           "erc_brgcn_bwd_source")
+
+
+def transpose_batched(inp, nb, rows, cols, out):
+    _check(lib().erc_transpose_batched(ptr(inp), nb, rows, cols, ptr(out), stream()), "erc_transpose_batched")
+
+
+def csr_sum(x, ldx, F, N, ptr_, idx, out, ldo, accumulate=0):
+    _check(lib().erc_csr_sum(ptr(x), ldx, F, N, ptr(ptr_), ptr(idx), ptr(out), ldo, accumulate, stream()),
+           "erc_csr_sum")

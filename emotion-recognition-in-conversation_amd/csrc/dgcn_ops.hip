@@ -1,0 +1,355 @@
+// DialogueGCN graph operators (track_mm/dgcn_models.py:36-152, models/rgcn.py:264-355), one wavefront per
+// node, gathers over the CSRs of K1 (deterministic, no float atomics).
+//
+//  * EdgeAtt: per SOURCE node softmax over its window (out-edges) of (W x_k).x_j -> edge_norm
+//  * basis-decomposed RGCNConv with edge_norm, add aggregation.  With W_r = sum_b att[r,b] basis[b],
+//      out_i = sum_b ( sum_{e -> i} norm_e att[type_e,b] x_src(e) ) basis[b] + x_i root + bias
+//    so the kernel aggregates in BASIS space, Z[i] = [30 x F], and the transform is ONE dense GEMM
+//    [N, 30F] x [30F, out]: no per-edge [E, in, out] weight tensor (the reference materialises 759 MB of it,
+//    models/rgcn.py:339-341) and no dependence on the number of relations (R = 162 for MELD).
+//  * GraphConv's neighbour sum.
+// Feature rows: F <= 256, lane l owns channels l, l+64, l+128, l+192.
+#include "erc_common.h"
+
+namespace {
+
+constexpr int NB = 30;  // num_bases (dgcn_models.py:41)
+
+struct Lane4 {
+    float v[4];
+};
+
+__device__ __forceinline__ Lane4 load4(const float* row, int F, int lane) {
+    Lane4 r;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r.v[u] = lane + 64 * u < F ? row[lane + 64 * u] : 0.f;
+    return r;
+}
+__device__ __forceinline__ float dot4(const Lane4& a, const Lane4& b) {
+    return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2] + a.v[3] * b.v[3];
+}
+
+// dst[i,:] = src[map[i],:]  /  dst[map[i],:] = src[i,:]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int lds, const int32_t* __restrict__ map,
+                                                          int N, int F, float* __restrict__ dst, int ldd, int scatter) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N) return;
+    const int64_t rs = scatter ? i : map[i], rd = scatter ? map[i] : i;
+    for (int c = lane; c < F; c += 64) dst[rd * ldd + c] = src[rs * lds + c];
+}
+
+// ------------------------------------------------------------------ EdgeAtt
+__global__ __launch_bounds__(256) void edge_att_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ att,
+                                                           int lda, int F, int N, const int32_t* __restrict__ out_ptr,
+                                                           const int32_t* __restrict__ out_dst,
+                                                           const int32_t* __restrict__ out_eid, float* __restrict__ norm) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const Lane4 xj = load4(x + (int64_t)j * ldx, F, lane);
+    const int e0 = out_ptr[j], e1 = out_ptr[j + 1];
+    const int head = min(e1 - e0, 64);  // lane l keeps the score of out-edge l (window graphs: degree <= 21)
+    float mx = -INFINITY, mine = -INFINITY;
+    for (int e = e0; e < e1; ++e) {
+        const float s = wave_sum(dot4(load4(att + (int64_t)out_dst[e] * lda, F, lane), xj));
+        mx = fmaxf(mx, s);
+        if (e - e0 == lane) mine = s;
+    }
+    const float pexp = lane < head ? expf(mine - mx) : 0.f;
+    float den = wave_sum(pexp);
+    for (int e = e0 + 64; e < e1; ++e)  // degree > 64: recompute
+        den += expf(wave_sum(dot4(load4(att + (int64_t)out_dst[e] * lda, F, lane), xj)) - mx);
+    if (lane < head) norm[out_eid[e0 + lane]] = pexp / den;
+    for (int e = e0 + 64; e < e1; ++e) {
+        const float s = wave_sum(dot4(load4(att + (int64_t)out_dst[e] * lda, F, lane), xj));
+        if (lane == 0) norm[out_eid[e]] = expf(s - mx) / den;
+    }
+}
+
+// source side of the backward: ds_e = a_e (dnorm_e - sum a dnorm); dx_j = sum_e ds_e att_dst(e)
+__global__ __launch_bounds__(256) void edge_att_bwd_source_kernel(const float* __restrict__ att, int lda, int F, int N,
+                                                                  const int32_t* __restrict__ out_ptr,
+                                                                  const int32_t* __restrict__ out_dst,
+                                                                  const int32_t* __restrict__ out_eid,
+                                                                  const float* __restrict__ norm,
+                                                                  const float* __restrict__ dnorm, float* __restrict__ dx,
+                                                                  int lddx, float* __restrict__ dscore, int accumulate) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    const int e0 = out_ptr[j], e1 = out_ptr[j + 1];
+    float t = 0.f;
+    for (int e = e0 + lane; e < e1; e += 64) t += norm[out_eid[e]] * dnorm[out_eid[e]];
+    t = wave_sum(t);
+    Lane4 acc = {{0.f, 0.f, 0.f, 0.f}};
+    for (int e = e0; e < e1; ++e) {
+        const int id = out_eid[e];
+        const float ds = norm[id] * (dnorm[id] - t);
+        if (lane == 0) dscore[id] = ds;
+        const Lane4 a = load4(att + (int64_t)out_dst[e] * lda, F, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc.v[u] += ds * a.v[u];
+    }
+    float* d = dx + (int64_t)j * lddx;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < F) d[lane + 64 * u] = accumulate ? d[lane + 64 * u] + acc.v[u] : acc.v[u];
+}
+
+// target side: datt_k = sum_{e into k} dscore_e x_src(e)
+__global__ __launch_bounds__(256) void edge_att_bwd_target_kernel(const float* __restrict__ x, int ldx, int F, int N,
+                                                                  const int32_t* __restrict__ in_ptr,
+                                                                  const int32_t* __restrict__ in_src,
+                                                                  const float* __restrict__ dscore,
+                                                                  float* __restrict__ datt, int ldda) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= N) return;
+    Lane4 acc = {{0.f, 0.f, 0.f, 0.f}};
+    for (int e = in_ptr[k]; e < in_ptr[k + 1]; ++e) {
+        const float ds = dscore[e];
+        const Lane4 xs = load4(x + (int64_t)in_src[e] * ldx, F, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc.v[u] += ds * xs.v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < F) datt[(int64_t)k * ldda + lane + 64 * u] = acc.v[u];
+}
+
+// ------------------------------------------------------------------ basis RGCN
+// Z[i, b*F + c] = sum_{e into i} norm_e att[type_e, b] x[src_e, c]
+__global__ __launch_bounds__(256) void brgcn_agg_fwd_kernel(const float* __restrict__ x, int ldx, int F, int N,
+                                                            const int32_t* __restrict__ in_ptr,
+                                                            const int32_t* __restrict__ in_src,
+                                                            const int32_t* __restrict__ in_typ,
+                                                            const float* __restrict__ norm, const float* __restrict__ attw,
+                                                            float* __restrict__ Z) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N) return;
+    float acc[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[b][u] = 0.f;
+    for (int e = in_ptr[i]; e < in_ptr[i + 1]; ++e) {
+        const Lane4 xs = load4(x + (int64_t)in_src[e] * ldx, F, lane);
+        const float ne = norm[e];
+        const float* ar = attw + (int64_t)in_typ[e] * NB;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float c = ne * ar[b];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[b][u] += c * xs.v[u];
+        }
+    }
+    float* z = Z + (int64_t)i * NB * F;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lane + 64 * u < F) z[b * F + lane + 64 * u] = acc[b][u];
+}
+
+// per target i, per in-edge e: T_e[b] = x_src . dZ[i, b, :]  ->  dnorm_e = sum_b att[type_e,b] T_e[b],
+// TT[e, b] = norm_e T_e[b]  (summed per relation by rel_sum_kernel -> d att)
+__global__ __launch_bounds__(256) void brgcn_bwd_target_kernel(const float* __restrict__ x, int ldx, int F, int N,
+                                                               const int32_t* __restrict__ in_ptr,
+                                                               const int32_t* __restrict__ in_src,
+                                                               const int32_t* __restrict__ in_typ,
+                                                               const float* __restrict__ norm, const float* __restrict__ attw,
+                                                               const float* __restrict__ dZ, float* __restrict__ dnorm,
+                                                               float* __restrict__ TT) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N) return;
+    float dz[NB][4];
+    const float* z = dZ + (int64_t)i * NB * F;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dz[b][u] = lane + 64 * u < F ? z[b * F + lane + 64 * u] : 0.f;
+    for (int e = in_ptr[i]; e < in_ptr[i + 1]; ++e) {
+        const Lane4 xs = load4(x + (int64_t)in_src[e] * ldx, F, lane);
+        float mine = 0.f;  // lane b keeps T_e[b]
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float t = wave_sum(xs.v[0] * dz[b][0] + xs.v[1] * dz[b][1] + xs.v[2] * dz[b][2] + xs.v[3] * dz[b][3]);
+            if (lane == b) mine = t;
+        }
+        const float ab = lane < NB ? attw[(int64_t)in_typ[e] * NB + lane] : 0.f;
+        const float dn = wave_sum(ab * mine);
+        if (lane == 0) dnorm[e] = dn;
+        if (lane < NB) TT[(int64_t)e * NB + lane] = norm[e] * mine;
+    }
+}
+
+// datt[r, b] = sum_{e: type_e == r} TT[e, b]; one workgroup per relation, fixed summation order
+__global__ __launch_bounds__(256) void rel_sum_kernel(const float* __restrict__ TT, const int32_t* __restrict__ typ,
+                                                      const int32_t* __restrict__ counts, float* __restrict__ datt) {
+    const int r = blockIdx.x, b = threadIdx.x & 31, slot = threadIdx.x >> 5;  // 8 edge slots x 32 lanes (30 used)
+    const int E = counts[1];
+    __shared__ float sh[8][32];
+    float acc = 0.f;
+    for (int e = slot; e < E; e += 8)
+        if (typ[e] == r && b < NB) acc += TT[(int64_t)e * NB + b];
+    sh[slot][b] = acc;
+    __syncthreads();
+    if (slot == 0 && b < NB) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += sh[k][b];
+        datt[r * NB + b] = s;
+    }
+}
+
+// U[j, b*O + c] = sum_{e out of j} norm_e att[type_e, b] dH[dst_e, c]   (O <= 128 output channels)
+__global__ __launch_bounds__(256) void brgcn_bwd_source_kernel(const float* __restrict__ dH, int lddh, int O, int N,
+                                                               const int32_t* __restrict__ out_ptr,
+                                                               const int32_t* __restrict__ out_dst,
+                                                               const int32_t* __restrict__ out_typ,
+                                                               const int32_t* __restrict__ out_eid,
+                                                               const float* __restrict__ norm, const float* __restrict__ attw,
+                                                               float* __restrict__ U) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    float acc[NB][2];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b][0] = acc[b][1] = 0.f;
+    const bool h0 = lane < O, h1 = lane + 64 < O;
+    for (int e = out_ptr[j]; e < out_ptr[j + 1]; ++e) {
+        const float* g = dH + (int64_t)out_dst[e] * lddh;
+        const float g0 = h0 ? g[lane] : 0.f, g1 = h1 ? g[lane + 64] : 0.f;
+        const float ne = norm[out_eid[e]];
+        const float* ar = attw + (int64_t)out_typ[e] * NB;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float c = ne * ar[b];
+            acc[b][0] += c * g0;
+            acc[b][1] += c * g1;
+        }
+    }
+    float* u = U + (int64_t)j * NB * O;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (h0) u[b * O + lane] = acc[b][0];
+        if (h1) u[b * O + lane + 64] = acc[b][1];
+    }
+}
+
+// out[n][c][r] = in[n][r][c]  (basis[b] [F,O] -> [O,F] so that dx = U [N,30*O] x basisT [30*O, F] is one GEMM)
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, int nb, int R, int Cc,
+                                                                float* __restrict__ out) {
+    const int64_t total = (int64_t)nb * R * Cc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cc);
+        const int r = (int)((i / Cc) % R);
+        const int64_t n = i / ((int64_t)Cc * R);
+        out[(n * Cc + c) * R + r] = in[i];
+    }
+}
+
+// out[i,:] (+)= sum_{e in row i of the CSR} x[idx[e],:]     (GraphConv aggregation and its transpose)
+__global__ __launch_bounds__(256) void csr_sum_kernel(const float* __restrict__ x, int ldx, int F, int N,
+                                                      const int32_t* __restrict__ ptr, const int32_t* __restrict__ idx,
+                                                      float* __restrict__ out, int ldo, int accumulate) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N) return;
+    Lane4 acc = {{0.f, 0.f, 0.f, 0.f}};
+    for (int e = ptr[i]; e < ptr[i + 1]; ++e) {
+        const Lane4 v = load4(x + (int64_t)idx[e] * ldx, F, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc.v[u] += v.v[u];
+    }
+    float* o = out + (int64_t)i * ldo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (lane + 64 * u < F) o[lane + 64 * u] = accumulate ? o[lane + 64 * u] + acc.v[u] : acc.v[u];
+}
+
+}  // namespace
+
+#define NODE_GRID(N) dim3(erc_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream
+
+extern "C" int erc_gather_rows(const float* src, int lds, const int32_t* map, int N, int F, float* dst, int ldd,
+                               int scatter, void* stream) {
+    ERC_REQUIRE(src && map && dst && N > 0 && F > 0, "gather_rows: bad arguments");
+    hipLaunchKernelGGL(gather_rows_kernel, NODE_GRID(N), src, lds, map, N, F, dst, ldd, scatter);
+    ERC_LAUNCH_CHECK("gather_rows");
+    return ERC_OK;
+}
+
+extern "C" int erc_edge_att_fwd(const float* x, int ldx, const float* att, int lda, int F, int N,
+                                const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* norm,
+                                void* stream) {
+    ERC_REQUIRE(x && att && out_ptr && out_dst && out_eid && norm, "edge_att_fwd: null pointer");
+    ERC_REQUIRE(N > 0 && F > 0 && F <= 256, "edge_att_fwd: N=%d F=%d", N, F);
+    hipLaunchKernelGGL(edge_att_fwd_kernel, NODE_GRID(N), x, ldx, att, lda, F, N, out_ptr, out_dst, out_eid, norm);
+    ERC_LAUNCH_CHECK("edge_att_fwd");
+    return ERC_OK;
+}
+
+extern "C" int erc_edge_att_bwd(const float* x, int ldx, const float* att, int lda, int F, int N, const int32_t* in_ptr,
+                                const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                const int32_t* out_eid, const float* norm, const float* dnorm, float* dx, int lddx,
+                                int accumulate_dx, float* datt, int ldda, float* dscore, void* stream) {
+    ERC_REQUIRE(x && att && in_ptr && in_src && out_ptr && out_dst && out_eid && norm && dnorm && dx && datt && dscore,
+                "edge_att_bwd: null pointer");
+    ERC_REQUIRE(N > 0 && F > 0 && F <= 256, "edge_att_bwd: N=%d F=%d", N, F);
+    hipLaunchKernelGGL(edge_att_bwd_source_kernel, NODE_GRID(N), att, lda, F, N, out_ptr, out_dst, out_eid, norm, dnorm,
+                       dx, lddx, dscore, accumulate_dx);
+    ERC_LAUNCH_CHECK("edge_att_bwd_source");
+    hipLaunchKernelGGL(edge_att_bwd_target_kernel, NODE_GRID(N), x, ldx, F, N, in_ptr, in_src, dscore, datt, ldda);
+    ERC_LAUNCH_CHECK("edge_att_bwd_target");
+    return ERC_OK;
+}
+
+extern "C" int erc_brgcn_agg_fwd(const float* x, int ldx, int F, int N, const int32_t* in_ptr, const int32_t* in_src,
+                                 const int32_t* in_typ, const float* norm, const float* att, int num_bases, float* Z,
+                                 void* stream) {
+    ERC_REQUIRE(x && in_ptr && in_src && in_typ && norm && att && Z, "brgcn_agg_fwd: null pointer");
+    ERC_REQUIRE(num_bases == NB && N > 0 && F > 0 && F <= 256, "brgcn_agg_fwd: num_bases=%d (built for %d) F=%d", num_bases, NB, F);
+    hipLaunchKernelGGL(brgcn_agg_fwd_kernel, NODE_GRID(N), x, ldx, F, N, in_ptr, in_src, in_typ, norm, att, Z);
+    ERC_LAUNCH_CHECK("brgcn_agg_fwd");
+    return ERC_OK;
+}
+
+extern "C" int erc_brgcn_bwd_edges(const float* x, int ldx, int F, int N, int R, const int32_t* in_ptr,
+                                   const int32_t* in_src, const int32_t* in_typ, const int32_t* counts,
+                                   const float* norm, const float* att, int num_bases, const float* dZ, float* dnorm,
+                                   float* TT, float* datt, void* stream) {
+    ERC_REQUIRE(x && in_ptr && in_src && in_typ && counts && norm && att && dZ && dnorm && TT && datt,
+                "brgcn_bwd_edges: null pointer");
+    ERC_REQUIRE(num_bases == NB && N > 0 && R > 0 && F > 0 && F <= 256, "brgcn_bwd_edges: bad sizes");
+    hipLaunchKernelGGL(brgcn_bwd_target_kernel, NODE_GRID(N), x, ldx, F, N, in_ptr, in_src, in_typ, norm, att, dZ, dnorm,
+                       TT);
+    ERC_LAUNCH_CHECK("brgcn_bwd_target");
+    hipLaunchKernelGGL(rel_sum_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, TT, in_typ, counts, datt);
+    ERC_LAUNCH_CHECK("rel_sum");
+    return ERC_OK;
+}
+
+extern "C" int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, const int32_t* out_ptr,
+                                    const int32_t* out_dst, const int32_t* out_typ, const int32_t* out_eid,
+                                    const float* norm, const float* att, int num_bases, float* U, void* stream) {
+    ERC_REQUIRE(dH && out_ptr && out_dst && out_typ && out_eid && norm && att && U, "brgcn_bwd_source: null pointer");
+    ERC_REQUIRE(num_bases == NB && N > 0 && O > 0 && O <= 128, "brgcn_bwd_source: bad sizes");
+    hipLaunchKernelGGL(brgcn_bwd_source_kernel, NODE_GRID(N), dH, lddh, O, N, out_ptr, out_dst, out_typ, out_eid, norm,
+                       att, U);
+    ERC_LAUNCH_CHECK("brgcn_bwd_source");
+    return ERC_OK;
+}
+
+extern "C" int erc_transpose_batched(const float* in, int nb, int rows, int cols, float* out, void* stream) {
+    ERC_REQUIRE(in && out && nb > 0 && rows > 0 && cols > 0, "transpose_batched: bad arguments");
+    const int64_t total = (int64_t)nb * rows * cols;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, nb, rows, cols, out);
+    ERC_LAUNCH_CHECK("transpose_batched");
+    return ERC_OK;
+}
+
+extern "C" int erc_csr_sum(const float* x, int ldx, int F, int N, const int32_t* ptr, const int32_t* idx, float* out,
+                           int ldo, int accumulate, void* stream) {
+    ERC_REQUIRE(x && ptr && idx && out && N > 0 && F > 0 && F <= 256, "csr_sum: bad arguments");
+    hipLaunchKernelGGL(csr_sum_kernel, NODE_GRID(N), x, ldx, F, N, ptr, idx, out, ldo, accumulate);
+    ERC_LAUNCH_CHECK("csr_sum");
+    return ERC_OK;
+}

@@ -157,13 +157,15 @@ def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off
 
 def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off):
     """dW[n_in,n_out] = x^T dy and db[n_out] = colsum(dy) for [in,out]-stored weights (PyG RGCNConv)."""
+    want_b = b_off is not None
     S = pl.split_for(n_in + 1, n_out, n_rows, min_chunks=2)
     src_w = pl.take(S * n_in * n_out)
-    src_b = pl.take(S * n_out)
+    src_b = pl.take(S * n_out) if want_b else 0
     capi.gemm_f32(x, ldx, 1, None, dy, lddy, 1, None, pl.ws[src_w:], n_out, n_in, n_out, n_rows,
-                  split_k=S, c_slab=n_in * n_out, ones_col=2, bias_out=pl.ws[src_b:], bias_slab=n_out)
+                  split_k=S, c_slab=n_in * n_out, ones_col=2 if want_b else 0,
+                  bias_out=pl.ws[src_b:] if want_b else None, bias_slab=n_out)
     pl.add_job(src_w, n_in * n_out, S, n_in * n_out, w_off)
-    if b_off is not None:
+    if want_b:
         pl.add_job(src_b, n_out, S, n_out, b_off)
 
 

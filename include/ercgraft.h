@@ -283,6 +283,46 @@ int erc_lstm_scan_bwd(const float* W_hh, const int64_t* lengths, const int32_t* 
                       int B, int T, const float* gates, const float* Cst, const float* dHout, int lddh,
                       float drop_p, const uint64_t* rng_state, uint64_t rng_stream, float* dGX, void* stream);
 
+/* ------------------------------------------------------------------------
+ * DialogueGCN graph operators (track_mm/dgcn_models.py:36-152, models/rgcn.py:264-355) over the CSRs of K1.
+ */
+/* dst[i,:] = src[map[i],:] (scatter = 0) or dst[map[i],:] = src[i,:] (scatter = 1): compaction of the valid rows of
+ * a padded [B,T,F] block (node_features.append(features[j,:cur_len]), dgcn_models.py:67) and its transpose. */
+int erc_gather_rows(const float* src, int lds, const int32_t* map, int N, int F, float* dst, int ldd, int scatter,
+                    void* stream);
+/* EdgeAtt (dgcn_models.py:121-152): att = x W^T is a GEMM by the caller; per SOURCE node j
+ * norm[e] = softmax_{e out of j} ( att[dst_e] . x_j ), written in in-CSR (edge_index) order via out_eid. */
+int erc_edge_att_fwd(const float* x, int ldx, const float* att, int lda, int F, int N,
+                     const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid, float* norm, void* stream);
+/* backward: dx (+)= sum_e dscore_e att[dst_e] per source, datt[k] = sum_{e into k} dscore_e x[src_e] per target;
+ * dscore [E] is scratch (in-CSR order). */
+int erc_edge_att_bwd(const float* x, int ldx, const float* att, int lda, int F, int N,
+                     const int32_t* in_ptr, const int32_t* in_src,
+                     const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                     const float* norm, const float* dnorm, float* dx, int lddx, int accumulate_dx,
+                     float* datt, int ldda, float* dscore, void* stream);
+/* basis-decomposed RGCNConv with edge_norm, add aggregation (models/rgcn.py:329-355), num_bases = 30:
+ *   Z[i, b*F + c] = sum_{e into i} norm_e att[type_e, b] x[src_e, c]      so that
+ *   conv(x) = Z @ basis.view(30F, out) + x @ root + bias                  (two GEMMs by the caller). */
+int erc_brgcn_agg_fwd(const float* x, int ldx, int F, int N, const int32_t* in_ptr, const int32_t* in_src,
+                      const int32_t* in_typ, const float* norm, const float* att, int num_bases, float* Z, void* stream);
+/* edge-side backward from dZ = dOut @ basis.view(30F,out)^T: dnorm[e] (gradient into EdgeAtt), TT [E,30] scratch,
+ * datt [R,30] = gradient of conv1.att (one workgroup per relation, fixed order); counts = {N,E} of K1. */
+int erc_brgcn_bwd_edges(const float* x, int ldx, int F, int N, int R, const int32_t* in_ptr, const int32_t* in_src,
+                        const int32_t* in_typ, const int32_t* counts, const float* norm, const float* att,
+                        int num_bases, const float* dZ, float* dnorm, float* TT, float* datt, void* stream);
+/* node-side backward: U[j, b*O + c] = sum_{e out of j} norm_e att[type_e,b] dOut[dst_e, c]; then
+ * dx = U @ basisT with basisT [30*O, F] = erc_transpose_batched(basis) (one GEMM by the caller). */
+int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, const int32_t* out_ptr, const int32_t* out_dst,
+                         const int32_t* out_typ, const int32_t* out_eid, const float* norm, const float* att,
+                         int num_bases, float* U, void* stream);
+/* out[n][c][r] = in[n][r][c] */
+int erc_transpose_batched(const float* in, int nb, int rows, int cols, float* out, void* stream);
+/* out[i,:] (+)= sum_{e in CSR row i} x[idx[e],:]: the neighbour sum of torch_geometric GraphConv(aggr='add')
+ * (call site dgcn_models.py:42,46) with the in-CSR, its transpose with the out-CSR.  F <= 256. */
+int erc_csr_sum(const float* x, int ldx, int F, int N, const int32_t* ptr, const int32_t* idx, float* out, int ldo,
+                int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

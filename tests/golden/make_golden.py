@@ -251,7 +251,39 @@ def gen_dagerc(ref):
              grad_none=np.array(none), **grad_digest([(n, q.grad) for n, q in model.named_parameters()]))
 
 
-GENERATORS = {"collate": gen_collate, "window_graph": gen_window_graph, "dagerc": gen_dagerc}
+def gen_dgcn(ref):
+    """DialogueGCN pieces that run from the reference's own files: EdgeAtt + batch_graphify
+    (track_mm/dgcn_models.py:51-152) and the vendored RGCNConv (models/rgcn.py:264-355) forward/backward."""
+    from oracle.graph import relation_table, canonical_edges
+    dm = importlib.import_module("track_mm.dgcn_models")
+    rg = importlib.import_module("models.rgcn")
+    g = torch.Generator().manual_seed(3)
+    for tag, S, lens in (("s2", 2, [3, 12, 25, 1]), ("s9", 9, [7, 33, 2, 21, 16])):
+        B, T = len(lens), max(lens)
+        lengths = torch.tensor(lens)
+        spk = torch.randint(0, S, (B, T), generator=g)
+        feats = torch.randn(B, T, 200, generator=g) * 0.5
+        for b, L in enumerate(lens):
+            feats[b, L:] = 0
+            spk[b, L:] = 0
+        feats.requires_grad_()
+        att = dm.EdgeAtt(200, 10, 10)
+        fill_params(att, 5)
+        x, ei, en, et, _ = dm.batch_graphify(feats, lengths, spk, 10, 10, relation_table(S), att)
+        R = 2 * S * S
+        conv = rg.RGCNConv(200, 100, R, num_bases=30)
+        fill_params(conv, 6)
+        out = conv(x, ei, et, edge_norm=en)
+        gout = torch.randn(out.shape, generator=g)
+        out.backward(gout)
+        ei_s, et_s, en_s = canonical_edges(ei.numpy(), et.numpy(), en.detach().numpy())
+        save("dgcn_" + tag, lengths=lengths.numpy(), speakers=spk.numpy(), n_speakers=S, features=feats.detach().numpy(),
+             edge_index=ei_s, edge_type=et_s, edge_norm=en_s, rgcn_out=out.detach().numpy(), gout=gout.numpy(),
+             att_seed=5, conv_seed=6, dfeatures=feats.grad.numpy(),
+             **grad_digest([("edge_att.weight", att.weight.grad)] + [("conv1." + n, q.grad) for n, q in conv.named_parameters()]))
+
+
+GENERATORS = {"collate": gen_collate, "window_graph": gen_window_graph, "dagerc": gen_dagerc, "dgcn": gen_dgcn}
 
 
 def main():

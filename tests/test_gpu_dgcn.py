@@ -1,0 +1,133 @@
+"""DialogueGCN on the GPU: (a) EdgeAtt + basis RGCNConv pieces directly against golden vectors produced by the
+REFERENCE's own dgcn_models.EdgeAtt / batch_graphify / models.rgcn.RGCNConv, (b) the whole module (eval logits,
+train-mode loss + every live gradient, one optimizer step) against the reference-pinned CPU oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+from torch.nn import functional as F
+
+from tests.util_cases import check_grad_digest, fill_params, make_batch, rel_err, to_device
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("name", ["dgcn_s2", "dgcn_s9"])
+def test_edge_att_and_basis_rgcn_vs_reference_golden(golden, name):
+    from erc_amd import capi
+    from erc_amd.cogmen import build_graph_tensors
+    fx = golden(name)
+    S, R, NB, Fd, O = int(fx["n_speakers"]), 2 * int(fx["n_speakers"]) ** 2, 30, 200, 100
+    lengths, spk = torch.from_numpy(fx["lengths"]).to(DEV), torch.from_numpy(fx["speakers"]).to(DEV)
+    feats = torch.from_numpy(fx["features"])
+    B, T = feats.shape[:2]
+    g, ei, et = build_graph_tensors(lengths, spk, 10, 10, S)
+    N, E = g["counts"].cpu().tolist()
+    np.testing.assert_array_equal(ei[:, :E].cpu().numpy(), fx["edge_index"])     # bit-exact edges / relation ids
+    np.testing.assert_array_equal(et[:E].cpu().numpy(), fx["edge_type"])
+    # parameters exactly as make_golden filled them
+    att_w = torch.nn.Module(); att_w.weight = torch.nn.Parameter(torch.zeros(Fd, Fd)); fill_params(att_w, int(fx["att_seed"]))
+    conv = torch.nn.Module()
+    conv.basis, conv.att = torch.nn.Parameter(torch.zeros(NB, Fd, O)), torch.nn.Parameter(torch.zeros(R, NB))
+    conv.root, conv.bias = torch.nn.Parameter(torch.zeros(Fd, O)), torch.nn.Parameter(torch.zeros(O))
+    fill_params(conv, int(fx["conv_seed"]))
+    W, basis, attp, root, bias = [t.detach().to(DEV) for t in (att_w.weight, conv.basis, conv.att, conv.root, conv.bias)]
+    x = torch.zeros(N, Fd, device=DEV)
+    capi.gather_rows(feats.to(DEV).view(B * T, Fd), Fd, g["node_row"], N, Fd, x, Fd)
+    ATT = torch.zeros(N, Fd, device=DEV)
+    capi.gemm_f32(x, Fd, 0, None, W, Fd, 0, None, ATT, Fd, N, Fd, Fd)
+    norm = torch.zeros(E, device=DEV)
+    capi.edge_att_fwd(x, Fd, ATT, Fd, Fd, N, g, norm)
+    np.testing.assert_allclose(norm.cpu().numpy(), fx["edge_norm"], atol=2e-6, rtol=2e-5)
+    Z = torch.zeros(N, NB * Fd, device=DEV)
+    capi.brgcn_agg_fwd(x, Fd, Fd, N, g, norm, attp, NB, Z)
+    out = torch.zeros(N, O, device=DEV)
+    capi.gemm_f32(Z, NB * Fd, 0, None, basis, O, 1, None, out, O, N, O, NB * Fd, bias=bias)
+    capi.gemm_f32(x, Fd, 0, None, root, O, 1, None, out, O, N, O, Fd, accumulate=1)
+    np.testing.assert_allclose(out.cpu().numpy(), fx["rgcn_out"], atol=1e-4, rtol=1e-4)
+    # backward of the two operators from the fixture's upstream gradient
+    gout = torch.from_numpy(fx["gout"]).to(DEV)
+    dZ = torch.zeros(N, NB * Fd, device=DEV)
+    capi.gemm_f32(gout, O, 0, None, basis, O, 0, None, dZ, NB * Fd, N, NB * Fd, O)
+    dnorm, TT, datt = torch.zeros(E, device=DEV), torch.zeros(E, NB, device=DEV), torch.zeros(R, NB, device=DEV)
+    capi.brgcn_bwd_edges(x, Fd, Fd, N, R, g, norm, attp, NB, dZ, dnorm, TT, datt)
+    dbasis, dbias = torch.zeros(NB * Fd, O, device=DEV), torch.zeros(O, device=DEV)
+    capi.gemm_f32(Z, NB * Fd, 1, None, gout, O, 1, None, dbasis, O, NB * Fd, O, N, ones_col=2, bias_out=dbias)
+    droot = torch.zeros(Fd, O, device=DEV)
+    capi.gemm_f32(x, Fd, 1, None, gout, O, 1, None, droot, O, Fd, O, N)
+    U, basisT = torch.zeros(N, NB * O, device=DEV), torch.zeros(NB * O, Fd, device=DEV)
+    capi.brgcn_bwd_source(gout, O, O, N, g, norm, attp, NB, U)
+    capi.transpose_batched(basis, NB, Fd, O, basisT)
+    dx = torch.zeros(N, Fd, device=DEV)
+    capi.gemm_f32(U, NB * O, 0, None, basisT, Fd, 1, None, dx, Fd, N, Fd, NB * O)
+    capi.gemm_f32(gout, O, 0, None, root, O, 0, None, dx, Fd, N, Fd, O, accumulate=1)
+    DATT, dscore = torch.zeros(N, Fd, device=DEV), torch.zeros(E, device=DEV)
+    capi.edge_att_bwd(x, Fd, ATT, Fd, Fd, N, g, norm, dnorm, dx, Fd, 1, DATT, Fd, dscore)
+    dW = torch.zeros(Fd, Fd, device=DEV)
+    capi.gemm_f32(DATT, Fd, 1, None, x, Fd, 1, None, dW, Fd, Fd, Fd, N)
+    capi.gemm_f32(DATT, Fd, 0, None, W, Fd, 1, None, dx, Fd, N, Fd, Fd, accumulate=1)
+    dfeat = torch.zeros(B * T, Fd, device=DEV)
+    capi.gather_rows(dx, Fd, g["node_row"], N, Fd, dfeat, Fd, scatter=1)
+    np.testing.assert_allclose(dfeat.cpu().view(B, T, Fd).numpy(), fx["dfeatures"], atol=2e-4, rtol=2e-3)
+    check_grad_digest(fx, [("edge_att.weight", dW), ("conv1.basis", dbasis.view(NB, Fd, O)), ("conv1.att", datt),
+                           ("conv1.root", droot), ("conv1.bias", dbias)], tol=2e-3)
+
+
+def _pair(case, compute="f32"):
+    from oracle.dgcn import DGCNOracle
+    from erc_amd.dgcn import DGCNModule
+    torch.manual_seed(case["seed"])
+    ref = DGCNOracle(case["S"], input_size=case["D"], hidden_size=200, n_classes=case["C"])
+    mine = DGCNModule(case["S"], input_size=case["D"], hidden_size=200, n_classes=case["C"], compute=compute)
+    mine.load_state_dict(ref.state_dict())
+    mine.finalize(DEV)
+    return ref, mine
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=4, lens=(2, 14), dims=dict(a=10, t=14, v=12), S=2, C=6, seed=1, weights=True),
+    dict(B=6, lens=(1, 33), dims=dict(a=300, t=600, v=342), S=9, C=7, seed=2, weights=False),   # MELD dims, D=1242, R=162
+    dict(B=8, lens=(20, 60), dims=dict(a=100, t=100, v=512), S=2, C=6, seed=3, weights=True),   # IEMOCAP dims
+], ids=["tiny", "meld-1242", "iemocap-712"])
+def test_dgcn_module_parity_vs_oracle(case):
+    from oracle.dgcn import IEMOCAP6_WEIGHTS
+    batch = make_batch(case["B"], case["dims"], n_speakers=case["S"], n_classes=case["C"], min_len=case["lens"][0],
+                       max_len=case["lens"][1], seed=case["seed"], force_max=True)
+    case = dict(case, D=sum(case["dims"].values()))
+    ref, mine = _pair(case)
+    w = torch.tensor(IEMOCAP6_WEIGHTS) if case["weights"] else None
+    dbatch = to_device(batch, DEV)
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        want, want_g = ref(**batch)
+    got, got_g = mine(**dbatch)
+    assert float((got.cpu() - want).abs().max()) < 1e-4
+    assert float((got_g.cpu() - want_g).abs().max()) < 1e-4
+    ref.train(), mine.train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    ref.rnn.rnn.dropout = 0.0
+    mine.drop_p, mine.lstm.drop_p = 0.0, 0.0
+    logits, _ = ref(**batch)
+    loss = F.cross_entropy(logits, batch["label"], weight=w)
+    loss.backward()
+    stats = mine.loss_and_grads(dbatch, w.to(DEV) if w is not None else None).cpu()
+    assert abs(float(stats[0]) - float(loss.detach())) < 2e-5
+    refp = dict(ref.named_parameters())
+    errs = {n: rel_err(mine.flat.g(n).cpu(), refp[n].grad) for n in mine.flat.params}
+    assert max(errs.values()) < 3e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert [n for n, p in ref.named_parameters() if p.grad is None] == ["clf.emotion_att.lin.weight", "clf.emotion_att.lin.bias"]
+
+
+def test_dgcn_train_steps_with_dropout_run():
+    from erc_amd.dgcn import DGCNTrainer
+    from erc_amd.params import ERCParams, Group
+    p = ERCParams().from_args(["--dataset=meld-mmgcn-7", "--modality=atv", "--loss_weights=False"])
+    p.optim = Group(name="Adam", lr=3e-4, weight_decay=0.0)
+    tr = DGCNTrainer(p, DEV)
+    batch = make_batch(8, p.dims(), n_speakers=9, n_classes=7, min_len=1, max_len=33, seed=4)
+    losses = [float(tr.train_step(tr.prepare_batch(batch)).cpu()[0]) for _ in range(4)]
+    assert all(math.isfinite(l) for l in losses) and losses[-1] < losses[0] + 0.5

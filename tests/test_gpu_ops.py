@@ -158,6 +158,24 @@ def test_gemm_wgrad_tn(capi, rows, n_out, n_in):
     _close(bslabs2.sum(0), dY.double().sum(0).float(), tol)
 
 
+def test_gemm_wide_tiles(capi):
+    """problems big enough to select the 64x128 workgroup tile (NF = 8), all three operand layouts."""
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 2100, 6000, 100
+    A, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    out = torch.zeros(M, N, device=DEV)
+    capi.gemm_f32(A.to(DEV), K, 0, None, W.to(DEV), K, 0, None, out, N, M, N, K)            # NT
+    _close(out, _gemm_ref(A, W.t()), 3e-4)
+    Wk = W.t().contiguous()
+    capi.gemm_f32(A.to(DEV), K, 0, None, Wk.to(DEV), N, 1, None, out, N, M, N, K)           # NN
+    _close(out, _gemm_ref(A, W.t()), 3e-4)
+    At = torch.randn(300, 4200, generator=g)                                               # TN: K-major A [K=300, M=4200]
+    Bk = torch.randn(300, 900, generator=g)
+    o2 = torch.zeros(4200, 900, device=DEV)
+    capi.gemm_f32(At.to(DEV), 4200, 1, None, Bk.to(DEV), 900, 1, None, o2, 900, 4200, 900, 300)
+    _close(o2, _gemm_ref(At.t(), Bk), 5e-4)
+
+
 def test_gemm_gather_and_unaligned(capi):
     """fused gather of valid rows of the padded block; leading dimension not a multiple of 4 (MELD D=1242)."""
     g = torch.Generator().manual_seed(9)
