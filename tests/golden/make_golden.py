@@ -283,7 +283,46 @@ def gen_dgcn(ref):
              **grad_digest([("edge_att.weight", att.weight.grad)] + [("conv1." + n, q.grad) for n, q in conv.named_parameters()]))
 
 
-GENERATORS = {"collate": gen_collate, "window_graph": gen_window_graph, "dagerc": gen_dagerc, "dgcn": gen_dgcn}
+def gen_mmgcn(ref):
+    """MMGCN end to end through the reference's own MMGCNModule (track_mm/mmgcn.py:56-123), eval mode (every
+    dropout off): normalised big adjacency, logits, CE loss, every gradient."""
+    from erc_amd.collate import ERCCollate
+    from erc_amd.synthetic import make_dialogues
+    import torch.nn.functional as F
+    load_with_patch(ref, "track_mm.mmgcn_models", "track_mm/mmgcn_models.py", "adj[idx] = dia_sim",
+                    "adj[tuple(idx)] = dia_sim")
+    mm = importlib.import_module("track_mm.mmgcn")
+    for tag, modality, B, dims, S, C, lens in (("atv", "atv", 3, dict(a=10, t=12, v=8), 2, 6, (2, 7)),
+                                               ("tv_s3", "tv", 4, dict(a=4, t=9, v=6), 3, 7, (1, 6))):
+        dialogs = make_dialogues(B, dims, n_speakers=S, n_classes=C, min_len=lens[0], max_len=lens[1], seed=31,
+                                 force_max=True)
+        p = types.SimpleNamespace(batch_first=False, speaker_onehot=True, n_classes=C, n_speakers=S, modality=modality)
+        batch = ERCCollate(p)([[d] for d in dialogs])
+        batch.pop("utterance_texts", None)
+        model = mm.MMGCNModule(hidden_text=dims["t"], hidden_visual=dims["v"], hidden_audio=dims["a"], n_speakers=S,
+                               n_classes=C, modals=modality)
+        fill_params(model, 91)
+        model.eval()
+        captured = {}
+        orig = model.graph_model.create_big_adj
+
+        def spy(*a, **k):
+            captured["adj"] = orig(*a, **k)
+            return captured["adj"]
+        model.graph_model.create_big_adj = spy
+        logits, _ = model(**batch)
+        loss = F.cross_entropy(logits, batch["label"])
+        loss.backward()
+        none = [n for n, q in model.named_parameters() if q.grad is None]
+        save("mmgcn_" + tag, param_seed=91, n_classes=C, n_speakers=S, dims=np.array([dims["a"], dims["t"], dims["v"]]),
+             modality=np.array(modality), adj=captured["adj"].detach().numpy(),
+             **{"in_" + k: v.numpy() for k, v in batch.items() if torch.is_tensor(v)},
+             logits=logits.detach().numpy(), loss=np.array(float(loss)), grad_none=np.array(none),
+             **grad_digest([(n, q.grad) for n, q in model.named_parameters()]))
+
+
+GENERATORS = {"collate": gen_collate, "window_graph": gen_window_graph, "dagerc": gen_dagerc, "dgcn": gen_dgcn,
+              "mmgcn": gen_mmgcn}
 
 
 def main():
