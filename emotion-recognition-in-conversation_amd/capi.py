@@ -50,6 +50,23 @@ _SIGS = {
     "erc_brgcn_bwd_source": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_transpose_batched": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "erc_csr_sum": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "erc_gemm_f32_grouped": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f,
+                                       _vp]),
+    "erc_mm_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "erc_mm_flatten": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "erc_mm_emb_grad": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "erc_mm_row_normalize": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
+    "erc_mm_row_normalize_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "erc_mm_adj_finish": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "erc_mm_adj_finish_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_mm_cross_apply": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "erc_mm_cross_grad": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "erc_gcnii_combine_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _vp, C.c_uint64, _vp, _vp]),
+    "erc_gcnii_combine_bwd": (C.c_int, [_vp, _vp, _i64, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "erc_dropout_fwd": (C.c_int, [_vp, _i64, _f, _vp, C.c_uint64, _vp, _vp]),
+    "erc_mm_regroup_fwd": (C.c_int, [_vp, _vp, _i, _i, _f, _vp, C.c_uint64, _vp, _vp]),
+    "erc_mm_regroup_bwd": (C.c_int, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    "erc_axpy_mask": (C.c_int, [_vp, _vp, _i64, _f, _i, _vp, _vp]),
     "erc_dag_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_dag_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
                                    _vp, _vp, _vp, _vp]),
@@ -279,3 +296,74 @@ def transpose_batched(inp, nb, rows, cols, out):
 def csr_sum(x, ldx, F, N, ptr_, idx, out, ldo, accumulate=0):
     _check(lib().erc_csr_sum(ptr(x), ldx, F, N, ptr(ptr_), ptr(idx), ptr(out), ldo, accumulate, stream()),
            "erc_csr_sum")
+
+
+def gemm_grouped(form, A, lda, B, ldb, Cm, ldc, n_or_k, node_off, n_dlg, n_mod, n_nodes, max_len, pitch, accumulate=0,
+                 act=0, aux=None, ldaux=0, act_scale=1.0):
+    _check(lib().erc_gemm_f32_grouped(form, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, n_or_k, ptr(node_off), n_dlg, n_mod,
+                                      n_nodes, max_len, pitch, accumulate, act, ptr(aux), ldaux, act_scale, stream()),
+           "erc_gemm_f32_grouped")
+
+
+def _call(name, *args):
+    _check(getattr(lib(), name)(*[ptr(a) if torch.is_tensor(a) or a is None else a for a in args], stream()), name)
+
+
+def mm_meta(lengths, qmask, q_st, q_sb, S, B, node_off, node_row, node_dlg, node_spk):
+    _call("erc_mm_meta", lengths, qmask, q_st, q_sb, S, B, node_off, node_row, node_dlg, node_spk)
+
+
+def mm_flatten(src, lds, row_map, emb, spk, N, dst, ldd):
+    _call("erc_mm_flatten", src, lds, row_map, emb, spk, N, dst, ldd)
+
+
+def mm_emb_grad(dl, ld, spk, N, S, demb):
+    _call("erc_mm_emb_grad", dl, ld, spk, N, S, demb)
+
+
+def mm_row_normalize(x, R, xhat, inv):
+    _call("erc_mm_row_normalize", x, R, xhat, inv)
+
+
+def mm_row_normalize_bwd(xhat, inv, dxhat, R, dx):
+    _call("erc_mm_row_normalize_bwd", xhat, inv, dxhat, R, dx)
+
+
+def mm_adj_finish(COS, xhat, node_off, B, M, N, P, ADJ, CR, CCOS, DEG):
+    _call("erc_mm_adj_finish", COS, xhat, node_off, B, M, N, P, ADJ, CR, CCOS, DEG)
+
+
+def mm_adj_finish_bwd(COS, CCOS, DEG, dADJ, dCR, node_off, B, M, N, P, G, GC):
+    _call("erc_mm_adj_finish_bwd", COS, CCOS, DEG, dADJ, dCR, node_off, B, M, N, P, G, GC)
+
+
+def mm_cross_apply(CR, h, ldh, node_dlg, node_off, M, N, P, out, ldo):
+    _call("erc_mm_cross_apply", CR, h, ldh, node_dlg, node_off, M, N, P, out, ldo)
+
+
+def mm_cross_grad(dhi, ldd, h, ldh, node_dlg, node_off, M, N, P, dCR):
+    _call("erc_mm_cross_grad", dhi, ldd, h, ldh, node_dlg, node_off, M, N, P, dCR)
+
+
+def gcnii_combine_fwd(G, hi, h0, n, theta, alpha, drop_p, rng, rng_stream, hd):
+    _call("erc_gcnii_combine_fwd", G, hi, h0, n, theta, alpha, drop_p, rng, rng_stream, hd)
+
+
+def gcnii_combine_bwd(d_hd, hd, n, theta, alpha, keep_scale, plain, dG, dhi, dh0):
+    _call("erc_gcnii_combine_bwd", d_hd, hd, n, theta, alpha, keep_scale, plain, dG, dhi, dh0)
+
+
+def dropout_fwd(x, n, drop_p, rng, rng_stream, y):
+    _call("erc_dropout_fwd", x, n, drop_p, rng, rng_stream, y)
+
+
+def mm_regroup_fwd(xd, hl, M, N, drop_p, rng, rng_stream, FE):
+    _call("erc_mm_regroup_fwd", xd, hl, M, N, drop_p, rng, rng_stream, FE)
+
+
+def mm_regroup_bwd(dFE, FE, M, N, keep_scale, d_xd, d_h):
+    _call("erc_mm_regroup_bwd", dFE, FE, M, N, keep_scale, d_xd, d_h)
+
+
+def axpy_mask(x, mask, n, scale, accumulate, y):
+    _call("erc_axpy_mask", x, mask, n, scale, accumulate, y)

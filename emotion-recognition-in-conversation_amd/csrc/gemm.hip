@@ -58,7 +58,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int valid, bool vec)
 }
 
 template <int A_KMAJOR, int B_KMAJOR, int NF>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bx, const int by, const int z) {
     constexpr int BN = 16 * NF;
     constexpr int A_ELEMS = A_KMAJOR ? BK * (BM + 16) : BM * KC_STRIDE;
     constexpr int B_ELEMS = B_KMAJOR ? BK * (BN + 16) : BN * KC_STRIDE;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
     const float* __restrict__ B = (const float*)p.B;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM, z = blockIdx.z;
+    const int n0 = bx * BN, m0 = by * BM;
     const int nchunk = (p.K + BK - 1) / BK;
     const int c_begin = z * p.chunks_per_split;
     const int c_end = min(nchunk, c_begin + p.chunks_per_split);
@@ -236,6 +236,48 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
                 p.bias_out[(int64_t)z * p.bias_slab + row] = v;
             }
         }
+    }
+}
+
+template <int A_KMAJOR, int B_KMAJOR, int NF>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
+    gemm_f32_body<A_KMAJOR, B_KMAJOR, NF>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped products over the per-(dialogue, modality) blocks of MMGCN's adjacency (mmgcn_models.py:582-646):
+// group z = b*n_mod + m covers the L_b nodes [m*n_nodes + node_off[b], +L_b) and the block blk + z*pitch*pitch.
+//   FORM 0 ("block x nodes"):  C_nodes[L,N] (+)= Blk[L,L] * B_nodes[L,N]
+//   FORM 1 ("nodes x nodes^T"): Blk[L,L]    (+)= A_nodes[L,K] * B_nodes[L,K]^T
+struct GroupP {
+    const int32_t* node_off;
+    int n_mod, n_nodes, pitch;
+};
+
+template <int FORM>
+__global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmP p, GroupP g) {
+    const int z = blockIdx.z, b = z / g.n_mod, m = z % g.n_mod;
+    const int off = g.node_off[b], L = g.node_off[b + 1] - off;
+    if ((int)blockIdx.y * BM >= L) return;
+    const int64_t row0 = (int64_t)m * g.n_nodes + off;
+    const int64_t blk = (int64_t)z * g.pitch * g.pitch;
+    if (FORM == 0) {
+        if ((int)blockIdx.x * 32 >= p.N) return;
+        p.A = (const float*)p.A + blk;
+        p.B = (const float*)p.B + row0 * p.ldb;
+        p.C = p.C + row0 * p.ldc;
+        if (p.aux) p.aux = p.aux + row0 * p.ldaux;
+        p.M = L;
+        p.K = L;
+        p.chunks_per_split = (L + BK - 1) / BK;
+        gemm_f32_body<0, 1, 2>(p, blockIdx.x, blockIdx.y, 0);
+    } else {
+        if ((int)blockIdx.x * 32 >= L) return;
+        p.A = (const float*)p.A + row0 * p.lda;
+        p.B = (const float*)p.B + row0 * p.ldb;
+        p.C = p.C + blk;
+        p.M = L;
+        p.N = L;
+        gemm_f32_body<0, 0, 2>(p, blockIdx.x, blockIdx.y, 0);
     }
 }
 
@@ -491,6 +533,40 @@ extern "C" int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t
     else
         launch_f32<1, 1>(p, nf, grid, st);
     ERC_LAUNCH_CHECK("gemm_f32");
+    return ERC_OK;
+}
+
+extern "C" int erc_gemm_f32_grouped(int form, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                    int N_or_K, const int32_t* node_off, int n_dialogues, int n_mod, int n_nodes,
+                                    int max_len, int pitch, int accumulate, int act, const float* aux, int ldaux,
+                                    float act_scale, void* stream) {
+    ERC_REQUIRE(A && B && C && node_off, "gemm_f32_grouped: null pointer");
+    ERC_REQUIRE(form == 0 || form == 1, "gemm_f32_grouped: form %d", form);
+    ERC_REQUIRE(n_dialogues > 0 && n_mod > 0 && n_nodes > 0 && max_len > 0 && pitch >= max_len && N_or_K > 0,
+                "gemm_f32_grouped: bad sizes");
+    ERC_REQUIRE(act == 0 || (act == 2 && aux && form == 0), "gemm_f32_grouped: act %d unsupported here", act);
+    GemmP p{};
+    p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.accumulate = accumulate; p.act = act; p.aux = aux; p.ldaux = ldaux; p.act_scale = act_scale;
+    GroupP g{node_off, n_mod, n_nodes, pitch};
+    hipStream_t st = (hipStream_t)stream;
+    if (form == 0) {
+        p.N = N_or_K;
+        p.lda = pitch;
+        p.a_vec = aligned16(A) && (pitch % 4 == 0);
+        p.b_vec = aligned16(B) && (ldb % 4 == 0);
+        dim3 grid(erc_cdiv(N_or_K, 32), erc_cdiv(max_len, BM), n_dialogues * n_mod);
+        hipLaunchKernelGGL(gemm_f32_grouped_kernel<0>, grid, dim3(256), 0, st, p, g);
+    } else {
+        p.K = N_or_K;
+        p.ldc = pitch;
+        p.chunks_per_split = erc_cdiv(N_or_K, BK);
+        p.a_vec = aligned16(A) && (lda % 4 == 0);
+        p.b_vec = aligned16(B) && (ldb % 4 == 0);
+        dim3 grid(erc_cdiv(max_len, 32), erc_cdiv(max_len, BM), n_dialogues * n_mod);
+        hipLaunchKernelGGL(gemm_f32_grouped_kernel<1>, grid, dim3(256), 0, st, p, g);
+    }
+    ERC_LAUNCH_CHECK("gemm_f32_grouped");
     return ERC_OK;
 }
 

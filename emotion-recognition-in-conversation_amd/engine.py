@@ -70,6 +70,7 @@ class GemmPlanner:
     TARGET_WG = 512
     MIN_CHUNKS = 8
     BK = 32
+    MAX_SPLIT = 64
 
     def __init__(self, device, ws_floats):
         self.device = device
@@ -87,7 +88,7 @@ class GemmPlanner:
         tiles = -(-N // 32) * -(-M // 64)
         nchunk = -(-K // bk)
         want = max(1, -(-self.TARGET_WG // tiles))
-        return max(1, min(want, nchunk // min_chunks if nchunk >= min_chunks else 1))
+        return max(1, min(want, self.MAX_SPLIT, nchunk // min_chunks if nchunk >= min_chunks else 1))
 
     def take(self, n):
         start = (self.cursor + ALIGN - 1) // ALIGN * ALIGN

@@ -1,0 +1,323 @@
+"""MMGCN on the MI355X hot path (drop-in for track_mm/mmgcn.py:56-157).
+
+``MMGCNModule`` keeps the reference's constructor signature, ``state_dict`` keys (the
+constructed-but-unused ``att_model.*``, ``gatedatt.*`` and ``graph_model.{a_fc,...}`` parameters included) and
+``forward(**batch) -> (logits [N,C], None)`` on the time-major batch layout (batch_first=False, one-hot speakers).
+
+Chain: per-modality Linear(d_m,200) on the padded [T,B,.] blocks (+ unpacked BiLSTM on text, rnn.py) -> valid
+rows, modality-major node order [a | v | l(+speaker embedding)] -> block-structured adjacency (cosine blocks by a
+grouped MFMA GEMM, arccos similarity, cross-modal same-utterance entries, symmetric degree normalisation) ->
+64 GCNII layers, each: grouped block product A*h + cross terms, [hi | h0] W_l as two accumulating GEMMs,
+fused theta/alpha combine + ReLU + dropout -> regroup + dropout + ReLU -> Linear -> CE; hand-written backward
+including the gradient THROUGH the adjacency into the features (the reference's adjacency is built with autograd
+on, mmgcn_models.py:582-646).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import capi
+from .engine import FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
+    matmul_wgrad_io
+from .rnn import BiLSTM2, lstm_groups
+
+FD, NLAYERS, LAMDA, ALPHA, DROP = 200, 64, 0.5, 0.1, 0.4
+_KEY = {"a": "audio_feature", "v": "visual_feature", "t": "text_feature"}
+_LIN = {"a": "linear_a", "v": "linear_v", "t": "linear_l"}
+
+
+class _Holder(nn.Module):
+    """Registers parameters by dotted name: sub-modules the reference constructs but never uses."""
+
+    def __init__(self, table=()):
+        super().__init__()
+        for name, shape in table:
+            self._add(name, shape)
+
+    def _add(self, name, shape):
+        head, _, rest = name.partition(".")
+        if rest:
+            if not hasattr(self, head):
+                setattr(self, head, _Holder())
+            getattr(self, head)._add(rest, shape)
+        else:
+            self.register_parameter(name, nn.Parameter(torch.zeros(*shape).uniform_(-0.05, 0.05)))
+
+
+class _Conv(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(2 * FD, FD).uniform_(-1.0 / math.sqrt(FD), 1.0 / math.sqrt(FD)))
+
+
+class _GraphNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.convs = nn.ModuleList([_Conv() for _ in range(NLAYERS)])
+        self.fcs = nn.ModuleList([nn.Linear(FD, FD)])
+
+
+class _GraphModel(_Holder):
+    def __init__(self, n_classes, n_speakers):
+        super().__init__([("a_fc.weight", (FD, FD)), ("a_fc.bias", (FD,)), ("v_fc.weight", (FD, FD)), ("v_fc.bias", (FD,)),
+                          ("l_fc.weight", (FD, FD)), ("l_fc.bias", (FD,)), ("feature_fc.weight", (FD, 6 * FD)),
+                          ("feature_fc.bias", (FD,)), ("final_fc.weight", (n_classes, FD)), ("final_fc.bias", (n_classes,)),
+                          ("modal_embeddings.weight", (3, FD)), ("a_spk_embs.weight", (n_speakers, FD)),
+                          ("v_spk_embs.weight", (n_speakers, FD)), ("l_spk_embs.weight", (n_speakers, FD))])
+        self.graph_net = _GraphNet()
+        self.speaker_embeddings = nn.Embedding(n_speakers, FD)
+
+
+def _unused_tables():
+    att = [("scalar.weight", (200, 200)), ("matchatt.transform.weight", (200, 200)), ("matchatt.transform.bias", (200,)),
+           ("simpleatt.scalar.weight", (1, 200)), ("att.weight", (400,)), ("att.w_k.weight", (200, 200)),
+           ("att.w_k.bias", (200,)), ("att.w_q.weight", (200, 200)), ("att.w_q.bias", (200,)),
+           ("att.proj.weight", (200, 200)), ("att.proj.bias", (200,))]
+    gated = []
+    for n in ("l", "v", "a"):
+        gated += [("transform_%s.weight" % n, (200, 400)), ("transform_%s.bias" % n, (200,))]
+    for n in ("av", "al", "vl"):
+        gated += [("transform_%s.weight" % n, (1, 1200)), ("transform_%s.bias" % n, (1,))]
+    return att, gated
+
+
+class MMGCNModule(nn.Module):
+    def __init__(self, hidden_text=100, D_e=100, graph_hidden_size=200, n_speakers=2, max_seq_len=200, window_past=10,
+                 window_future=10, n_classes=7, nodal_attention=True, hidden_visual=512, hidden_audio=100, modals="atv",
+                 seed=1):
+        super().__init__()
+        if len(modals) < 2:
+            raise NotImplementedError("MMGCN needs at least two modalities (mmgcn_models.py:594-595)")
+        self.modals, self.n_speakers, self.n_classes = modals, n_speakers, n_classes
+        self.dims = {"a": hidden_audio, "v": hidden_visual, "t": hidden_text}
+        self.order = [m for m in "avt" if m in modals]            # [a, v, l] order of create_big_adj
+        self.linear_l = nn.Linear(hidden_text, FD)
+        self.lstm_l = nn.LSTM(FD, 100, 2, bidirectional=True, dropout=DROP)
+        self.linear_a = nn.Linear(hidden_audio, FD)
+        self.linear_v = nn.Linear(hidden_visual, FD)
+        att, gated = _unused_tables()
+        self.att_model = _Holder(att)
+        self.graph_model = _GraphModel(n_classes, n_speakers)
+        self.gatedatt = _Holder(gated)
+        self.smax_fc = nn.Linear(2 * FD * len(modals), n_classes)
+        self.drop_p = DROP
+        self.flat, self._ws, self._seed = None, {}, seed
+
+    def live_groups(self):
+        groups = []
+        for m in self.order:
+            lin = getattr(self, _LIN[m])
+            groups += [[(_LIN[m] + ".weight", lin.weight)], [(_LIN[m] + ".bias", lin.bias)]]
+        if "t" in self.order:
+            groups += lstm_groups("lstm_l.", self.lstm_l)
+            groups += [[("graph_model.speaker_embeddings.weight", self.graph_model.speaker_embeddings.weight)]]
+        gn = self.graph_model.graph_net
+        groups += [[("graph_model.graph_net.fcs.0.weight", gn.fcs[0].weight)],
+                   [("graph_model.graph_net.fcs.0.bias", gn.fcs[0].bias)]]
+        groups += [[("graph_model.graph_net.convs.%d.weight" % i, gn.convs[i].weight)] for i in range(NLAYERS)]
+        groups += [[("smax_fc.weight", self.smax_fc.weight)], [("smax_fc.bias", self.smax_fc.bias)]]
+        return groups
+
+    def finalize(self, device):
+        self.to(device)
+        self.flat = FlatParams(self.live_groups(), device)
+        self.lstm = BiLSTM2(self.flat, "lstm_l.", FD, drop_p=DROP) if "t" in self.order else None
+        self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
+        return self
+
+    def _workspace(self, B, T, N, device):
+        key = (B, T, N)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        Mo, C = len(self.order), self.n_classes
+        R3, TB, P = Mo * N, T * B, (T + 3) // 4 * 4
+        ws = dict(P=P, node_off=i32(B + 1), node_row=i32(N), node_dlg=i32(N), node_spk=i32(N),
+                  LIN={m: f32(TB, FD) for m in self.order}, LO=f32(TB, FD), X=f32(R3, FD), XD=f32(R3, FD),
+                  XH=f32(R3, FD), INV=f32(R3), COS=f32(B * Mo, P, P), ADJ=f32(B * Mo, P, P), CR=f32(B, Mo * Mo, P),
+                  CCOS=f32(B, Mo * Mo, P), DEG=f32(R3), H0=f32(R3, FD), Gt=f32(R3, FD),
+                  HI=f32(NLAYERS + 1, R3, FD), HD=f32(NLAYERS + 2, R3, FD), FE=f32(N, Mo * 2 * FD), logits=f32(N, C),
+                  stats=f32(4), dlogits=f32(N, C), dFE=f32(N, Mo * 2 * FD), dXD=f32(R3, FD), DH=f32(R3, FD),
+                  dG=f32(R3, FD), dHI=f32(R3, FD), dH0=f32(R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
+                  Gb=f32(B * Mo, P, P), GC=f32(B, Mo * Mo, P), dXH=f32(R3, FD), dX=f32(R3, FD),
+                  dLIN={m: f32(TB, FD) for m in self.order}, dLL=f32(TB, FD))
+        dmax = max(self.dims[m] for m in self.order)
+        slab = 4 * TB * 800 + 8 * (800 * FD + 2 * 400 * 100 * 2) + 8 * FD * dmax * 3 + NLAYERS * 2 * 8 * FD * FD + \
+            8 * FD * FD + 8 * self.n_classes * Mo * 2 * FD + 8 * R3 * FD + (1 << 21)
+        ws["planner"] = GemmPlanner(device, slab)
+        ws["planner"].MAX_SPLIT = 8      # 128 weight-gradient GEMMs per step: keep their slab sets small
+        ws["jobs"] = None
+        self._ws[key] = ws
+        return ws
+
+    def _shape(self, batch_feat, lens, label):
+        T, B = batch_feat.shape[0], batch_feat.shape[1]
+        N = int(label.shape[0]) if label is not None else int(lens.sum().item())
+        return B, T, N
+
+    @staticmethod
+    def theta(l):
+        return math.log(LAMDA / l + 1)
+
+    # ---------------------------------------------------------------- forward
+    def _forward_impl(self, feats, qmask, lens, B, T, N, training):
+        fp = self.flat
+        dev = lens.device
+        ws = self._workspace(B, T, N, dev)
+        pl = ws["planner"]
+        pl.reset()
+        Mo, C, TB, P = len(self.order), self.n_classes, T * B, ws["P"]
+        R3 = Mo * N
+        p = self.drop_p if training else 0.0
+        rng = self.rng_state
+        if qmask.stride(2) != 1:
+            qmask = qmask.contiguous()
+        capi.mm_meta(lens, qmask, qmask.stride(0), qmask.stride(1), qmask.shape[2], B, ws["node_off"], ws["node_row"],
+                     ws["node_dlg"], ws["node_spk"])
+        X = ws["X"]
+        for mi, m in enumerate(self.order):
+            x = feats[m].reshape(TB, self.dims[m])
+            linear_fwd(pl, x, self.dims[m], None, fp.w(_LIN[m] + ".weight"), fp.w(_LIN[m] + ".bias"), ws["LIN"][m], FD, TB,
+                       FD, self.dims[m])
+            src = ws["LIN"][m]
+            emb = spk = None
+            if m == "t":
+                # unpacked BiLSTM over the padded [T,B,200] block (row(b,t) = t*B + b): mmgcn.py:113-114
+                self.lstm.forward(pl, ws["LIN"][m], FD, TB, B, T, 1, B, None, training, rng, ws["LO"], FD)
+                src, emb, spk = ws["LO"], fp.w("graph_model.speaker_embeddings.weight"), ws["node_spk"]
+            capi.mm_flatten(src, FD, ws["node_row"], emb, spk, N, X[mi * N:], FD)
+        # adjacency (mmgcn_models.py:582-646)
+        capi.mm_row_normalize(X, R3, ws["XH"], ws["INV"])
+        capi.gemm_grouped(1, ws["XH"], FD, ws["XH"], FD, ws["COS"], P, FD, ws["node_off"], B, Mo, N, T, P)
+        capi.mm_adj_finish(ws["COS"], ws["XH"], ws["node_off"], B, Mo, N, P, ws["ADJ"], ws["CR"], ws["CCOS"], ws["DEG"])
+        # GCNII input layer (mmgcn_models.py:382-384)
+        n_el = R3 * FD
+        XD = ws["XD"] if p > 0 else X
+        if p > 0:
+            capi.dropout_fwd(X, n_el, p, rng, 1000, XD)
+        gn = "graph_model.graph_net."
+        linear_fwd(pl, XD, FD, None, fp.w(gn + "fcs.0.weight"), fp.w(gn + "fcs.0.bias"), ws["H0"], FD, R3, FD, FD, act=1)
+        HD, HI = ws["HD"], ws["HI"]
+        if p > 0:
+            capi.dropout_fwd(ws["H0"], n_el, p, rng, 1001, HD[1])
+        else:
+            HD[1].copy_(ws["H0"])
+        for l in range(1, NLAYERS + 1):
+            W = fp.w(gn + "convs.%d.weight" % (l - 1))
+            capi.gemm_grouped(0, ws["ADJ"], P, HD[l], FD, HI[l], FD, FD, ws["node_off"], B, Mo, N, T, P)
+            capi.mm_cross_apply(ws["CR"], HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, HI[l], FD)
+            capi.gemm_f32(HI[l], FD, 0, None, W, FD, 1, None, ws["Gt"], FD, R3, FD, FD)
+            capi.gemm_f32(ws["H0"], FD, 0, None, W[FD:], FD, 1, None, ws["Gt"], FD, R3, FD, FD, accumulate=1)
+            capi.gcnii_combine_fwd(ws["Gt"], HI[l], ws["H0"], n_el, self.theta(l), ALPHA, p, rng, 2000 + l, HD[l + 1])
+        capi.mm_regroup_fwd(XD, HD[NLAYERS + 1], Mo, N, p, rng, 3000, ws["FE"])
+        linear_fwd(pl, ws["FE"], Mo * 2 * FD, None, fp.w("smax_fc.weight"), fp.w("smax_fc.bias"), ws["logits"], C, N, C,
+                   Mo * 2 * FD)
+        ws["_p"], ws["_XD"] = p, XD
+        return ws
+
+    def _feats(self, kw):
+        return {m: kw[_KEY[m]] for m in self.order}
+
+    def forward(self, text_feature=None, audio_feature=None, visual_feature=None, speaker_tensor=None,
+                text_length=None, label=None, **kwargs):
+        if self.flat is None:
+            raise capi.ErcGraftError("call MMGCNModule.finalize(device) before forward")
+        feats = self._feats(dict(text_feature=text_feature, audio_feature=audio_feature, visual_feature=visual_feature))
+        B, T, N = self._shape(feats[self.order[0]], text_length, label)
+        ws = self._forward_impl(feats, speaker_tensor, text_length, B, T, N, self.training)
+        return ws["logits"], None
+
+    # --------------------------------------------------------------- training
+    def loss_and_grads(self, batch):
+        feats = self._feats(batch)
+        qmask, lens, ys = batch["speaker_tensor"], batch["text_length"], batch["label"]
+        B, T, N = self._shape(feats[self.order[0]], lens, ys)
+        ws = self._forward_impl(feats, qmask, lens, B, T, N, self.training)
+        fp, pl, off = self.flat, ws["planner"], self.flat.offsets
+        Mo, C, TB, P = len(self.order), self.n_classes, T * B, ws["P"]
+        R3, n_el = Mo * N, Mo * N * FD
+        p, XD = ws["_p"], ws["_XD"]
+        ks = 1.0 / (1.0 - p)
+        HD, HI = ws["HD"], ws["HI"]
+        gn = "graph_model.graph_net."
+        capi.cross_entropy(ws["logits"], C, C, N, None, ys, None, 1.0, ws["dlogits"], C, ws["stats"])
+        FW = Mo * 2 * FD
+        capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("smax_fc.weight"), FW, 1, None, ws["dFE"], FW, N, FW, C)
+        linear_wgrad(pl, ws["dlogits"], C, ws["FE"], FW, None, C, FW, N, off["smax_fc.weight"], off["smax_fc.bias"])
+        DH = ws["DH"]
+        capi.mm_regroup_bwd(ws["dFE"], ws["FE"], Mo, N, ks, ws["dXD"], DH)
+        ws["dH0"].zero_(), ws["dADJ"].zero_(), ws["dCR"].zero_()
+        for l in range(NLAYERS, 0, -1):
+            Wn = gn + "convs.%d.weight" % (l - 1)
+            W = fp.w(Wn)
+            capi.gcnii_combine_bwd(DH, HD[l + 1], n_el, self.theta(l), ALPHA, ks, 0, ws["dG"], ws["dHI"], ws["dH0"])
+            capi.gemm_f32(ws["dG"], FD, 0, None, W, FD, 0, None, ws["dHI"], FD, R3, FD, FD, accumulate=1)
+            capi.gemm_f32(ws["dG"], FD, 0, None, W[FD:], FD, 0, None, ws["dH0"], FD, R3, FD, FD, accumulate=1)
+            matmul_wgrad_io(pl, HI[l], FD, ws["dG"], FD, FD, FD, R3, off[Wn], None)
+            matmul_wgrad_io(pl, ws["H0"], FD, ws["dG"], FD, FD, FD, R3, off[Wn] + FD * FD, None)
+            capi.gemm_grouped(1, ws["dHI"], FD, HD[l], FD, ws["dADJ"], P, FD, ws["node_off"], B, Mo, N, T, P, accumulate=1)
+            capi.mm_cross_grad(ws["dHI"], FD, HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"])
+            capi.gemm_grouped(0, ws["ADJ"], P, ws["dHI"], FD, DH, FD, FD, ws["node_off"], B, Mo, N, T, P)
+            capi.mm_cross_apply(ws["CR"], ws["dHI"], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, DH, FD)
+        # input layer: HD[1] = dropout(H0), H0 = relu(fc0(XD))
+        capi.axpy_mask(DH, HD[1] if p > 0 else None, n_el, ks, 1, ws["dH0"])
+        capi.gcnii_combine_bwd(ws["dH0"], ws["H0"], n_el, 0.0, 0.0, 1.0, 1, ws["dG"], None, None)
+        capi.gemm_f32(ws["dG"], FD, 0, None, fp.w(gn + "fcs.0.weight"), FD, 1, None, ws["dXD"], FD, R3, FD, FD, accumulate=1)
+        linear_wgrad(pl, ws["dG"], FD, XD, FD, None, FD, FD, R3, off[gn + "fcs.0.weight"], off[gn + "fcs.0.bias"])
+        dX = ws["dX"]
+        capi.axpy_mask(ws["dXD"], XD if p > 0 else None, n_el, ks, 0, dX)
+        # through the adjacency into the features
+        capi.mm_adj_finish_bwd(ws["COS"], ws["CCOS"], ws["DEG"], ws["dADJ"], ws["dCR"], ws["node_off"], B, Mo, N, P,
+                               ws["Gb"], ws["GC"])
+        capi.gemm_grouped(0, ws["Gb"], P, ws["XH"], FD, ws["dXH"], FD, FD, ws["node_off"], B, Mo, N, T, P)
+        capi.mm_cross_apply(ws["GC"], ws["XH"], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dXH"], FD)
+        capi.mm_row_normalize_bwd(ws["XH"], ws["INV"], ws["dXH"], R3, dX)
+        # per modality: back to the padded [T,B] rows, (speaker embedding, BiLSTM,) Linear
+        for mi, m in enumerate(self.order):
+            dm = dX[mi * N:]
+            dpad = ws["dLIN"][m]
+            dpad.zero_()
+            capi.gather_rows(dm, FD, ws["node_row"], N, FD, dpad, FD, scatter=1)
+            dlin = dpad
+            if m == "t":
+                capi.mm_emb_grad(dm, FD, ws["node_spk"], N, self.n_speakers, fp.g("graph_model.speaker_embeddings.weight"))
+                self.lstm.backward(pl, dpad, FD, dx=ws["dLL"], lddx=FD)
+                dlin = ws["dLL"]
+            x = feats[m].reshape(TB, self.dims[m])
+            linear_wgrad(pl, dlin, FD, x, self.dims[m], None, FD, self.dims[m], TB, off[_LIN[m] + ".weight"],
+                         off[_LIN[m] + ".bias"])
+        if ws["jobs"] is None or ws["jobs"].shape[0] != len(pl.jobs):
+            ws["jobs"] = pl.job_table()
+        capi.slab_reduce_batched(pl.ws, fp.grad, ws["jobs"], len(pl.jobs), pl.max_numel)
+        return ws["stats"]
+
+
+class MMGCNTrainer:
+    """train_step / to_logits of track_mm/mmgcn.py:126-157 (CE, Adam lr 3e-4 wd 3e-5)."""
+
+    def __init__(self, params, device):
+        self.params, self.device = params, torch.device(device)
+        torch.manual_seed(params.seed)
+        self.model = MMGCNModule(hidden_text=params.hidden_text, hidden_visual=params.hidden_visual,
+                                 hidden_audio=params.hidden_audio, n_speakers=params.n_speakers,
+                                 n_classes=params.n_classes, modals=params.modality, seed=params.seed).finalize(self.device)
+        o = params.optim
+        self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.get("weight_decay", 0.0),
+                               decoupled=(o.name == "AdamW"), seed=params.seed)
+        self.model.rng_state = self.optim.rng_state
+
+    def to_logits(self, batch):
+        return self.model(**batch)[0]
+
+    def prepare_batch(self, batch):
+        return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+    def train_step(self, batch):
+        self.model.train()
+        stats = self.model.loss_and_grads(batch)
+        scale = all_reduce_grads(self.model.flat)
+        self.optim.step(grad_scale=scale)
+        return stats

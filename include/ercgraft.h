@@ -323,6 +323,57 @@ int erc_transpose_batched(const float* in, int nb, int rows, int cols, float* ou
 int erc_csr_sum(const float* x, int ldx, int F, int N, const int32_t* ptr, const int32_t* idx, float* out, int ldo,
                 int accumulate, void* stream);
 
+/* ------------------------------------------------------------------------
+ * MMGCN (track_mm/mmgcn.py:56-123, track_mm/mmgcn_models.py:8-39,344-394,493-646).  Node rows are
+ * modality-major: node (m, i) = m*N + i, i = node_off[b] + t, in the modality order [a, v, l] of
+ * mmgcn_models.py:586-593.  The (modalities*N)^2 adjacency of create_big_adj is kept as its non-zero
+ * structure: blocks [B*M][P][P] (P >= max length, multiple of 4) + cross entries [B][M*M][P].
+ */
+/* Grouped block products on the matrix cores.  form 0: C_nodes[L,N] (+)= Blk[L,L] B_nodes[L,N] (A*h of
+ * GraphConvolution.forward, mmgcn_models.py:29, and its transpose: the normalised adjacency is symmetric);
+ * form 1: Blk[L,L] (+)= A_nodes[L,K] B_nodes[L,K]^T (cosine blocks of mmgcn_models.py:604-608, and dAdj). */
+int erc_gemm_f32_grouped(int form, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                         int N_or_K, const int32_t* node_off, int n_dialogues, int n_mod, int n_nodes,
+                         int max_len, int pitch, int accumulate, int act, const float* aux, int ldaux,
+                         float act_scale, void* stream);
+/* node tables from text_length and the time-major one-hot qmask [T,B,S] (element (t,b,c) at t*q_st + b*q_sb + c) */
+int erc_mm_meta(const int64_t* lengths, const float* qmask, int64_t q_st, int64_t q_sb, int n_speakers, int B,
+                int32_t* node_off, int32_t* node_row, int32_t* node_dlg, int32_t* node_spk, void* stream);
+/* simple_batch_graphify (mmgcn_utils.py:5-21) [+ speaker embedding add, mmgcn_models.py:540-545]; F = 200 */
+int erc_mm_flatten(const float* src, int lds, const int32_t* row_map, const float* emb, const int32_t* spk, int N,
+                   float* dst, int ldd, void* stream);
+int erc_mm_emb_grad(const float* dl, int ld, const int32_t* spk, int N, int n_speakers, float* demb, void* stream);
+int erc_mm_row_normalize(const float* x, int R, float* xhat, float* inv, void* stream);
+int erc_mm_row_normalize_bwd(const float* xhat, const float* inv, const float* dxhat, int R, float* dx, void* stream);
+/* COS blocks (raw cosines, form-1 grouped GEMM of xhat) -> sim = 1 - acos(0.99999 cos)/pi, cross-modal
+ * same-utterance sims, degrees over the full row, D^-1/2 A D^-1/2 (mmgcn_models.py:604-644). */
+int erc_mm_adj_finish(const float* COS, const float* xhat, const int32_t* node_off, int B, int M, int N, int P,
+                      float* ADJ, float* CR, float* CCOS, float* DEG, void* stream);
+/* its backward: G = dCOS + dCOS^T per block (dXhat_block = G Xhat by a form-0 grouped GEMM), GC per cross pair */
+int erc_mm_adj_finish_bwd(const float* COS, const float* CCOS, const float* DEG, const float* dADJ, const float* dCR,
+                          const int32_t* node_off, int B, int M, int N, int P, float* G, float* GC, void* stream);
+/* out[(m,i),:] += sum_{n != m} CR[b][m*M+n][p] h[(n,i),:] ;  dCR[b][m*M+n][p] += dhi[(m,i),:] . h[(n,i),:] */
+int erc_mm_cross_apply(const float* CR, const float* h, int ldh, const int32_t* node_dlg, const int32_t* node_off,
+                       int M, int N, int P, float* out, int ldo, void* stream);
+int erc_mm_cross_grad(const float* dhi, int ldd, const float* h, int ldh, const int32_t* node_dlg,
+                      const int32_t* node_off, int M, int N, int P, float* dCR, void* stream);
+/* GCNII layer tail (mmgcn_models.py:27-39,385-388): hd = dropout(relu(theta*G + (1-theta)((1-alpha) hi + alpha h0)));
+ * hi == NULL: hd = dropout(relu(G)) (the input layer fcs[0]).  Backward: dG, dhi (written), dh0 (accumulated). */
+int erc_gcnii_combine_fwd(const float* G, const float* hi, const float* h0, int64_t n, float theta, float alpha,
+                          float drop_p, const uint64_t* rng_state, uint64_t rng_stream, float* hd, void* stream);
+int erc_gcnii_combine_bwd(const float* d_hd, const float* hd, int64_t n, float theta, float alpha, float keep_scale,
+                          int plain, float* dG, float* dhi, float* dh0, void* stream);
+int erc_dropout_fwd(const float* x, int64_t n, float drop_p, const uint64_t* rng_state, uint64_t rng_stream, float* y,
+                    void* stream);
+/* FE[i, m*400 + c] = relu(dropout(cat[xd, h][(m,i), c])): regroup (mmgcn_models.py:570-576) + dropout_/ReLU
+ * (mmgcn.py:119-120); backward scatters to d_xd / d_h. */
+int erc_mm_regroup_fwd(const float* xd, const float* hl, int M, int N, float drop_p, const uint64_t* rng_state,
+                       uint64_t rng_stream, float* FE, void* stream);
+int erc_mm_regroup_bwd(const float* dFE, const float* FE, int M, int N, float keep_scale, float* d_xd, float* d_h,
+                       void* stream);
+/* y (+)= scale * x, optionally masked by mask != 0 */
+int erc_axpy_mask(const float* x, const float* mask, int64_t n, float scale, int accumulate, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
