@@ -32,33 +32,66 @@ def synthetic_batch(params, B, T, seed):
     from erc_amd.collate import ERCCollate
     from erc_amd.synthetic import make_dialogues
     dialogs = make_dialogues(B, params.dims(), n_speakers=params.n_speakers, n_classes=params.n_classes,
-                             min_len=20, max_len=T, seed=seed, force_max=True)
+                             min_len=20 if T >= 40 else 1, max_len=T, seed=seed, force_max=True)
     batch = ERCCollate(params)([[d] for d in dialogs])
     batch.pop("utterance_texts", None)
     return batch
 
 
-def cpu_baseline(params, batch, budget_s=20.0):
-    """The reference CPU path = the oracle (structure-faithful PyTorch-CPU restatement, dead encoder and
-    per-edge python graph construction included) timed on this box's host cores, on a bounded sample."""
-    from oracle.cogmen import COGMENOracle, cogmen_train_step
+def _time_cpu(step, n_utt, budget_s, max_steps=10):
+    step()  # warm-up
+    times, t_all = [], time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_all < budget_s and len(times) < max_steps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return n_utt / times[len(times) // 2], len(times)
+
+
+def cpu_baseline(module, params, batch, budget_s=20.0):
+    """The reference CPU path = the oracle (structure-faithful PyTorch-CPU restatement: dead encoder, per-edge
+    python graph construction, per-step torch.cat regrowth, dense (3N)^2 adjacency ...) timed on this box's host
+    cores, on a bounded sample."""
     n_utt = int(batch["label"].shape[0])
-    out = {}
-    for tag, dead in (("with_dead_encoder", True), ("without_dead_encoder", False)):
-        torch.manual_seed(1)
-        model = COGMENOracle(params.hidden_all, 100, 17, params.n_speakers, params.n_classes, dead_encoder=dead)
-        model.train()
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-8)
-        cogmen_train_step(model, opt, batch)  # warm-up
-        times = []
-        t_all = time.perf_counter()
-        while len(times) < 2 or (time.perf_counter() - t_all < budget_s / 2 and len(times) < 10):
-            t0 = time.perf_counter()
-            cogmen_train_step(model, opt, batch)
-            times.append(time.perf_counter() - t0)
-        times.sort()
-        out[tag] = (n_utt / times[len(times) // 2], len(times))
-    return out
+    torch.manual_seed(1)
+    if module == "cogmen":
+        from oracle.cogmen import COGMENOracle, cogmen_train_step
+        out = {}
+        for tag, dead in (("with_dead_encoder", True), ("without_dead_encoder", False)):
+            model = COGMENOracle(params.hidden_all, 100, 17, params.n_speakers, params.n_classes, dead_encoder=dead)
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-8)
+            out[tag] = _time_cpu(lambda: cogmen_train_step(model, opt, batch), n_utt, budget_s / 2)
+        return out
+    if module == "dagerc":
+        from oracle.dagerc import DAGERCOracle, dagerc_train_step
+        model = DAGERCOracle(emb_dim=params.hidden_all, dropout=params.get("dropout", 0.0), n_classes=params.n_classes)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        step = lambda: dagerc_train_step(model, opt, batch)
+    elif module == "dgcn":
+        from oracle.dgcn import DGCNOracle, dgcn_train_step
+        model = DGCNOracle(params.n_speakers, input_size=params.hidden_all, n_classes=params.n_classes)
+        opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+        step = lambda: dgcn_train_step(model, opt, batch)
+    else:
+        from oracle.mmgcn import MMGCNOracle, mmgcn_train_step
+        model = MMGCNOracle(hidden_text=params.hidden_text, hidden_visual=params.hidden_visual,
+                            hidden_audio=params.hidden_audio, n_speakers=params.n_speakers, n_classes=params.n_classes,
+                            modals=params.modality)
+        opt = torch.optim.Adam(model.parameters(), lr=3e-4, weight_decay=3e-5)
+        step = lambda: mmgcn_train_step(model, opt, batch)
+    model.train()
+    return {"with_dead_encoder": _time_cpu(step, n_utt, budget_s, max_steps=5)}
+
+
+# module -> (default dataset, default per-GPU batch, max length, extra flags): BASELINE.json configs[1..4]
+WORKLOADS = {
+    "cogmen": ("iemocap-cogmen-sbert-6", 32, 110, []),
+    "mmgcn": ("iemocap-cogmen-sbert-6", 16, 110, []),
+    "dagerc": ("iemocap-cogmen-6", 16, 110, ["--reimplement"]),
+    "dgcn": ("meld-mmgcn-7", 32, 33, ["--loss_weights=False"]),
+}
 
 
 def main():
@@ -67,12 +100,14 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--max_len", type=int, default=110)
-    ap.add_argument("--dataset", default="iemocap-cogmen-sbert-6")  # d_t=768 -> D=1380 as BASELINE.json config 2
+    ap.add_argument("--module", default="cogmen", choices=sorted(WORKLOADS))  # headline = cogmen (configs[1])
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--max_len", type=int, default=None)
+    ap.add_argument("--dataset", default=None)  # cogmen default: d_t=768 -> D=1380 as BASELINE.json config 2
     ap.add_argument("--no_graph", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--kernel_reps", type=int, default=200)
+    ap.add_argument("--clock_probe", action="store_true", help="diagnostic: append a clock-probe kernel to the step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,29 +123,41 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    import importlib
     from erc_amd import capi
-    from erc_amd.cogmen import COGMENTrainer
     from erc_amd.engine import GraphedStep, all_reduce_grads
-    from erc_amd.params import ERCParams
     capi.lib()  # fail loudly if the HIP library is missing
 
-    params = ERCParams().from_args(["--dataset=" + args.dataset, "--modality=atv", "--compute=" + args.dtype,
-                                    "--optim.lr=0.0001", "--optim.weight_decay=1e-8"])
+    ds, bsz, mlen, extra = WORKLOADS[args.module]
+    args.dataset, args.batch, args.max_len = args.dataset or ds, args.batch or bsz, args.max_len or mlen
+    if args.module == "mmgcn":
+        args.dtype = "f32"  # three separate feature blocks; no bf16 feature mode for MMGCN
+    plugin = importlib.import_module("track_mm." + args.module)
+    params = plugin.ParamsType().from_args(["--dataset=" + args.dataset, "--modality=atv", "--compute=" + args.dtype]
+                                           + extra)
     params.train.batch_size = args.batch
-    trainer = COGMENTrainer(params, device)
+    trainer = getattr(plugin, {"cogmen": "COGMENTrainer", "mmgcn": "MMGCNTrainer", "dagerc": "DAGERCTrainer",
+                               "dgcn": "DGCNTrainer"}[args.module])(params, device)
     host_batch = synthetic_batch(params, args.batch, args.max_len, seed=1 + rank)
     batch = trainer.prepare_batch(host_batch)
     n_utt = int(host_batch["label"].shape[0])
 
     # ---------------------------------------------------------------- step function
     use_graph = not args.no_graph
+    probe = torch.zeros(4, dtype=torch.int64, device=device) if args.clock_probe else None
     if world == 1:
-        step_fn = lambda: trainer.train_step(batch)
+        def step_fn():
+            out = trainer.train_step(batch)
+            if probe is not None:
+                capi.clock_probe(probe, 400)
+            return out
         step = GraphedStep(step_fn) if use_graph else step_fn
     else:
         # forward+backward in one graph; the RCCL all-reduce and the optimizer stay eager (2 launches)
         trainer.model.train()
-        fb = lambda: trainer.model.loss_and_grads(batch, trainer.class_weight)
+        cw = getattr(trainer, "class_weight", None)
+        fb = (lambda: trainer.model.loss_and_grads(batch, cw)) if args.module in ("cogmen", "dgcn") else \
+            (lambda: trainer.model.loss_and_grads(batch))
         fb_g = GraphedStep(fb) if use_graph else fb
 
         def step():
@@ -144,7 +191,7 @@ def main():
 
     # ---------------------------------------------------------------- dominant kernel, HIP events on its stream
     roof = None
-    if rank == 0:
+    if rank == 0 and args.module == "cogmen":
         roof = trainer.model.dominant_kernel_probe(batch, reps=args.kernel_reps)
         roof = {"bound": "hbm", "kernel": roof["kernel"], "achieved": roof["gbs"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": None,
@@ -159,24 +206,33 @@ def main():
             avail = os.cpu_count() or 1
         cores = min(16, avail)  # the 1-GPU box's CPU share (16 threads); more threads only slow small ops down
         torch.set_num_threads(cores)
-        res = cpu_baseline(params, host_batch)
+        res = cpu_baseline(args.module, params, host_batch)
         cpu = {"value": res["with_dead_encoder"][0], "unit": "utterances/s", "cores": cores, "kind": "port",
-               "sample": "%d full train steps of the same B=%d batch (median), oracle/cogmen.py incl. the "
-                         "reference's dead Transformer encoder and per-edge python graph build"
-                         % (res["with_dead_encoder"][1], args.batch),
-               "value_without_dead_encoder": res["without_dead_encoder"][0]}
+               "sample": "%d full train steps of the same B=%d batch (median), oracle/%s.py with the reference's "
+                         "own host-side structure (python graph build%s)"
+                         % (res["with_dead_encoder"][1], args.batch, args.module,
+                            ", dead Transformer encoder" if args.module == "cogmen" else "")}
+        if "without_dead_encoder" in res:
+            cpu["value_without_dead_encoder"] = res["without_dead_encoder"][0]
 
+    if probe is not None and rank == 0:
+        c = probe.cpu().tolist()
+        print("clock probe inside the step: %d cycles in %.2f us -> %.3f GHz" % (c[0], c[1] / 100.0, c[0] / (c[1] * 10.0)),
+              file=sys.stderr)
     if rank == 0:
         value = total_utt * args.steps / elapsed
         line = {
-            "metric": "utterances/sec training step, COGMEN IEMOCAP-6 atv", "value": value,
+            "metric": "utterances/sec training step, COGMEN IEMOCAP-6 atv" if args.module == "cogmen" else
+            "utterances/sec training step, %s %s atv" % (args.module, args.dataset), "value": value,
             "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "COGMEN iemocap-cogmen-6 atv train step (BASELINE.json configs[1]): "
-                                   "B=%d dialogues/GPU, T=%d, d_a=100 d_t=768 d_v=512 (D=%d), C=%d, "
-                                   "graph build + fwd + CE + bwd + Adam" % (args.batch, args.max_len,
-                                                                           params.hidden_all, params.n_classes),
+            "config": {"workload": ("COGMEN iemocap-cogmen-6 atv train step (BASELINE.json configs[1]): "
+                                    if args.module == "cogmen" else "%s %s train step: " % (args.module, args.dataset)) +
+                                   "B=%d dialogues/GPU, T=%d, d_a=%d d_t=%d d_v=%d (D=%d), C=%d, "
+                                   "graph build + fwd + CE + bwd + optimizer" % (
+                                       args.batch, args.max_len, params.hidden_audio, params.hidden_text,
+                                       params.hidden_visual, params.hidden_all, params.n_classes),
                        "utterances_per_step_per_gpu": n_utt, "global_batch_dialogues": args.batch * world,
                        "parallelism": "dp%d" % world, "hip_graph": use_graph,
                        "features_dtype": args.dtype, "loss": stats[0]},

@@ -22,6 +22,9 @@ _SIGS = {
     "erc_window_graph_build": (C.c_int, [_vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _i] + [_vp] * 13 + [_vp]),
     "erc_gemm_f32": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp, _i64,
                                _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
+    "erc_gemm_f32_stream": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp, _i64,
+                                      _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
+    "erc_gemm_bf16a_stream": (C.c_int, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
                                  _i64, _vp]),
     "erc_slab_reduce": (C.c_int, [_vp, _i, _i64, _vp, _i, _i, _vp, _i, _i64, _vp]),
@@ -36,6 +39,7 @@ _SIGS = {
     "erc_bn_lrelu_bwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "erc_cross_entropy": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp]),
     "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp]),
+    "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
     "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
                                     C.c_uint64, _vp, _vp, _vp, _vp]),
@@ -158,6 +162,12 @@ def gemm_bf16x(A, lda, a_kmajor, a_gather, B, ldb, b_kmajor, b_gather, x_is_a, C
     _check(lib().erc_gemm_bf16x(ptr(A), lda, a_kmajor, ptr(a_gather), ptr(B), ldb, b_kmajor, ptr(b_gather), x_is_a,
                                 ptr(Cmat), ldc, M, N, K, split_k, c_slab, ones_col, ptr(bias_out), bias_slab,
                                 stream()), "erc_gemm_bf16x")
+
+
+def gemm_bf16a_stream(X, ldx, gather, W, ldw, Cm, ldc, M, N, K, bias=None, act=0):
+    _dev(X, W, Cm)
+    _check(lib().erc_gemm_bf16a_stream(ptr(X), ldx, ptr(gather), ptr(W), ldw, ptr(Cm), ldc, M, N, K, ptr(bias), act,
+                                       stream()), "erc_gemm_bf16a_stream")
 
 
 def slab_reduce(slabs, S, stride, bias, n_cols, act, out, numel, ld_out=0):
@@ -367,3 +377,7 @@ def mm_regroup_bwd(dFE, FE, M, N, keep_scale, d_xd, d_h):
 
 def axpy_mask(x, mask, n, scale, accumulate, y):
     _call("erc_axpy_mask", x, mask, n, scale, accumulate, y)
+
+
+def clock_probe(out, iters):
+    _call("erc_clock_probe", out, iters)

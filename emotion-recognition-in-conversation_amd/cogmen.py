@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from . import capi
-from .engine import FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
+from .engine import FlatParams, FusedAdam, GemmPlanner, SideStream, all_reduce_grads, linear_fwd, linear_wgrad, \
     matmul_wgrad_io
 
 F_HID = 100
@@ -110,6 +110,7 @@ class COGMENModule(nn.Module):
         self.to(device)
         self.flat = FlatParams(self.live_groups(), device)
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
+        self.side = SideStream()
         return self
 
     def _workspace(self, B, T, N, device):
@@ -127,13 +128,13 @@ class COGMENModule(nn.Module):
             g=g, E=E,
             H0=f32(N, F), M=f32(N, 9 * F), inv_cnt=f32(N, N_REL), H1=f32(N, F), QKVS=f32(N, 4 * F),
             alpha=f32(E), H2=f32(N, F), H3=f32(N, F), Z=f32(N, F), logits=f32(N, C),
-            bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=f32(4),
+            bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=torch.zeros(256, dtype=torch.float32, device=device),
             dlogits=f32(N, C), dZ=f32(N, F), dH3=f32(N, F), dH2=f32(N, F), dQKVS=f32(N, 4 * F), dscore=f32(E),
             dH1=f32(N, F), dM=f32(N, 9 * F), dH0=f32(N, F),
         )
         # slab space: forward split-K of the input projection + every weight gradient, sized generously
         slab = 16 * N * F + 8 * (F * D + 9 * F * F + 4 * F * F + 2 * F * F) + (1 << 20)
-        ws["planner"] = GemmPlanner(device, slab)
+        ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
         self._ws[key] = ws
         return ws
@@ -177,8 +178,6 @@ class COGMENModule(nn.Module):
         capi.bn_lrelu_fwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), bn.running_mean,
                           bn.running_var, bn.momentum, bn.eps, 0.01, training, ws["bn_saved"], ws["H3"], F,
                           ws["bn_ws"])
-        if training:
-            bn.num_batches_tracked += 1
         p = self.drop_p if training else 0.0
         linear_fwd(pl, ws["H3"], F, None, fp.w("cls.0.weight"), fp.w("cls.0.bias"), ws["Z"], F, N, F, F,
                    act=3 if p > 0 else 1, drop_p=p, rng=self.rng_state)
@@ -208,11 +207,13 @@ class COGMENModule(nn.Module):
         # head
         capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
                       act=2, aux=ws["Z"], ldaux=F, act_scale=1.0 / (1.0 - p))
-        linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
-                     fp.offsets["cls.3.bias"])
+        with self.side.fork():
+            linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
+                         fp.offsets["cls.3.bias"])
         capi.gemm_f32(ws["dZ"], F, 0, None, fp.w("cls.0.weight"), F, 1, None, ws["dH3"], F, N, F, F)
-        linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
-                     fp.offsets["cls.0.bias"])
+        with self.side.fork():
+            linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
+                         fp.offsets["cls.0.bias"])
         # BatchNorm + LeakyReLU
         capi.bn_lrelu_bwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
                           ws["dH3"], F, ws["dH2"], F, fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"), ws["bn_ws"])
@@ -221,20 +222,27 @@ class COGMENModule(nn.Module):
                             ws["dQKVS"], ws["dscore"])
         capi.gemm_f32(ws["dQKVS"], 4 * F, 0, None, fp.w("gcn.conv2.lin_query.weight"), F, 1, None, ws["dH1"], F,
                       N, F, 4 * F)
-        linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1"], F, None, 4 * F, F, N,
-                     fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"])
+        with self.side.fork():
+            linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1"], F, None, 4 * F, F, N,
+                         fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"])
         # RGCN: dM = dH1 @ Wcat^T ; dWcat = M^T dH1 ; dbias = colsum(dH1)
         capi.gemm_f32(ws["dH1"], F, 0, None, fp.w("gcn.conv1.weight"), F, 0, None, ws["dM"], 9 * F, N, 9 * F, F)
-        matmul_wgrad_io(pl, ws["M"], 9 * F, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
-                        fp.offsets["gcn.conv1.bias"])
+        with self.side.fork():
+            matmul_wgrad_io(pl, ws["M"], 9 * F, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
+                            fp.offsets["gcn.conv1.bias"])
         capi.rgcn_mean_bwd(ws["dM"], 9 * F, F, N_REL, N, g, ws["inv_cnt"], ws["dH0"], F)
         # input projection (no gradient into the features)
-        linear_wgrad(pl, ws["dH0"], F, x, D, g["node_row"], F, D, N, fp.offsets["rnn.1.weight"],
-                     fp.offsets["rnn.1.bias"], x_bf16=x_bf16)
-        if ws["jobs"] is None or ws["jobs"].shape[0] != len(pl.jobs):
-            ws["jobs"] = pl.job_table()
-        capi.slab_reduce_batched(pl.ws, fp.grad, ws["jobs"], len(pl.jobs), pl.max_numel)
+        with self.side.fork():
+            linear_wgrad(pl, ws["dH0"], F, x, D, g["node_row"], F, D, N, fp.offsets["rnn.1.weight"],
+                         fp.offsets["rnn.1.bias"], x_bf16=x_bf16)
+        self.side.join()
+        pl.reduce_into(ws, fp.grad)
         return ws["stats"]
+
+    def sync_buffers(self, optimizer_steps):
+        """BatchNorm1d.num_batches_tracked is bookkeeping only (momentum is fixed): it is set from the optimizer's
+        device step counter when a checkpoint is taken instead of costing a launch per step."""
+        self.gcn.bn.num_batches_tracked.fill_(int(optimizer_steps))
 
     def last_graph(self, B, T, N):
         return self._ws[(B, T, N)]["g"]
@@ -252,15 +260,14 @@ class COGMENModule(nn.Module):
         F, D = F_HID, self.input_size
         x_bf16 = x.dtype == torch.bfloat16
         if x_bf16:
-            S = pl.split_for(N, F, D, bk=64, min_chunks=4)
-            launch = lambda: capi.gemm_bf16x(x, D, 0, g["node_row"], fp.w("rnn.1.weight"), D, 0, None, 1,
-                                             pl.ws, F, N, F, D, split_k=S, c_slab=N * F)
-            name = "gemm_bf16x_kernel<0,0,1,2> (input projection, bf16 features)"
+            launch = lambda: capi.gemm_bf16a_stream(x, D, g["node_row"], fp.w("rnn.1.weight"), D, ws["H0"], F, N, F, D,
+                                                    bias=fp.w("rnn.1.bias"))
+            name = "gemm_bf16a_stream_kernel<8> (input projection, bf16 features)"
         else:
-            S = pl.split_for(N, F, D)
-            launch = lambda: capi.gemm_f32(x, D, 0, g["node_row"], fp.w("rnn.1.weight"), D, 0, None,
-                                           pl.ws, F, N, F, D, split_k=S, c_slab=N * F)
-            name = "gemm_f32_kernel<0,0,2> (input projection, fp32 features)"
+            launch = lambda: capi.gemm_f32(x, D, 0, g["node_row"], fp.w("rnn.1.weight"), D, 0, None, ws["H0"], F, N, F, D,
+                                           bias=fp.w("rnn.1.bias"))
+            name = "gemm_f32_stream_kernel<0,0,8> (input projection, fp32 features)"
+        S = 1
         nbytes = N * D * x.element_size() + F * D * 4 + N * F * 4 + N * 4
         for _ in range(10):
             launch()

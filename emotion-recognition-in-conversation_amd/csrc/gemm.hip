@@ -490,6 +490,14 @@ bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_gather, const float* B, int ldb,
+                                   int b_kmajor, const int32_t* b_gather, float* C, int ldc, int M, int N, int K,
+                                   int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
+                                   const float* bias, int act, const float* aux, int ldaux, float act_scale, float drop_p,
+                                   const uint64_t* rng_state, int accumulate, void* stream);
+extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const float* W, int ldw, float* C,
+                                     int ldc, int M, int N, int K, const float* bias, int act, void* stream);
+
 extern "C" int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t* a_gather, const float* B, int ldb,
                             int b_kmajor, const int32_t* b_gather, float* C, int ldc, int M, int N, int K, int split_k,
                             int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab, const float* bias,
@@ -497,6 +505,11 @@ extern "C" int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t
                             const uint64_t* rng_state, int accumulate, void* stream) {
     ERC_REQUIRE(A && B && C, "gemm_f32: null operand");
     ERC_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f32: bad shape M=%d N=%d K=%d", M, N, K);
+    // skinny outputs (everything but the basis-space products of DialogueGCN): register-streaming kernel
+    if (N + (ones_col == 1 ? 1 : 0) <= 1024)
+        return erc_gemm_f32_stream(A, lda, a_kmajor, a_gather, B, ldb, b_kmajor, b_gather, C, ldc, M, N, K, split_k, c_slab,
+                                   ones_col, bias_out, bias_slab, bias, act, aux, ldaux, act_scale, drop_p, rng_state,
+                                   accumulate, stream);
     ERC_REQUIRE(split_k >= 1, "gemm_f32: split_k must be >= 1");
     ERC_REQUIRE(!(a_kmajor && !b_kmajor), "gemm_f32: (A k-major, B k-contiguous) is not built");
     ERC_REQUIRE(split_k == 1 || (!bias && act == 0 && !accumulate), "gemm_f32: epilogue requires split_k == 1");

@@ -1,0 +1,410 @@
+// K2 (skinny shapes): register-streaming MFMA GEMM, no LDS staging, no barrier in the K loop.
+//
+// The matrices of this workload are skinny (M ~ 2000 nodes, N ~ 100, K 100..2000) and L2-resident, so a
+// tiled/LDS GEMM spends its time in the global->LDS->barrier chain of each K chunk (measured: ~1.9 us per
+// 32-deep chunk with 124 workgroups).  Here every wavefront owns a 16 x 32 output tile, loads its MFMA
+// fragments STRAIGHT from global memory (one 16-byte load per fragment and 16-deep K block, several blocks in
+// flight), and the wavefronts of a workgroup split K among themselves (in-workgroup split-K, reduced once through
+// LDS).  Weight gradients (K = #nodes) therefore need no partial slabs and no reduce pass.
+//
+// K permutation: v_mfma_f32_16x16x4_f32 sums over its 4 k-slots g = lane>>4.  For a 16-deep block at kb, MFMA t
+// (t < 4) uses k = kb + 4g + t for BOTH operands, so a lane's four A values are the contiguous A[row][kb+4g..+3]
+// (one float4) and likewise for a K-contiguous B; the sum over t and g covers the 16 k's exactly once.
+#include "erc_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+struct T {
+    static constexpr bool value = true;
+};
+struct Fx {
+    static constexpr bool value = false;
+};
+
+struct StreamP {
+    const void* A;
+    const void* B;
+    float* C;
+    const int32_t* a_gather;
+    const int32_t* b_gather;
+    const float* bias;
+    const float* aux;
+    float* bias_out;
+    const uint64_t* rng;
+    int64_t c_slab, bias_slab;
+    int lda, ldb, ldc, ldaux;
+    int M, N, K;
+    int kblocks_per_split;
+    int ones, act, accumulate;
+    int a_vec, b_vec;
+    float act_scale, drop_p;
+};
+
+__device__ __forceinline__ float4 ld4g(const float* p, int valid, bool vec) {
+    if (valid >= 4 && vec) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid > 0) v.x = p[0];
+    if (valid > 1) v.y = p[1];
+    if (valid > 2) v.z = p[2];
+    if (valid > 3) v.w = p[3];
+    return v;
+}
+
+template <int NW>
+__device__ __forceinline__ void reduce_and_store(const StreamP& p, f32x4 acc[2], float* red, int m0, int n0, int z) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    if (NW > 1) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(w * 8 + f * 4 + i) * 64 + lane] = acc[f][i];
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) s += red[(ww * 8 + f * 4 + i) * 64 + lane];
+                acc[f][i] = s;
+            }
+    }
+    float* __restrict__ C = p.C + (int64_t)z * p.c_slab;
+    uint64_t rng_off = 0, rng_seed = 0;
+    if (p.act == 3) rng_off = p.rng[0], rng_seed = p.rng[1];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int col = n0 + 16 * f + r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + 4 * g + i;
+            float v = acc[f][i];
+            if (row >= p.M) {
+                if (row == p.M && p.ones == 2 && col < p.N && p.bias_out) p.bias_out[(int64_t)z * p.bias_slab + col] = v;
+                continue;
+            }
+            if (col < p.N) {
+                float* dst = C + (int64_t)row * p.ldc + col;
+                if (p.bias) v += p.bias[col];
+                if (p.accumulate) v += *dst;
+                if (p.act == 1)
+                    v = fmaxf(v, 0.f);
+                else if (p.act == 2)
+                    v = p.aux[(int64_t)row * p.ldaux + col] > 0.f ? v * p.act_scale : 0.f;
+                else if (p.act == 3) {
+                    const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)p.N + col);
+                    v = (u >= p.drop_p) ? fmaxf(v, 0.f) * p.act_scale : 0.f;
+                }
+                *dst = v;
+            } else if (col == p.N && p.ones == 1 && p.bias_out) {
+                p.bias_out[(int64_t)z * p.bias_slab + row] = v;
+            }
+        }
+    }
+}
+
+// A_MODE: 0 rows K-contiguous (optional row gather), 1 K-major.  B_MODE: 0 "NT" (B[n][k]), 1 K-major (optional k gather).
+// GA / GB (gather present) and VEC (16-byte loads legal) are COMPILE-TIME: a runtime "pointer ? load : value" makes
+// hipcc branch around the load and drain vmcnt per element.
+template <int A_MODE, int B_MODE, int NW, bool GA, bool GB, bool VEC>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_stream_kernel(StreamP p) {
+    __shared__ float red[NW > 1 ? NW * 8 * 64 : 1];
+    const float* __restrict__ A = (const float*)p.A;
+    const float* __restrict__ B = (const float*)p.B;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 16, z = blockIdx.z;
+    const int nkb = (p.K + 15) / 16;
+    const int kb_begin = z * p.kblocks_per_split;
+    const int kb_end = min(nkb, kb_begin + p.kblocks_per_split);
+    const int kb_full_end = min(kb_end, p.K / 16);  // blocks entirely inside K
+
+    // Out-of-range rows / columns / k are CLAMPED to a valid address and the loaded value is replaced afterwards
+    // by a select: every load is unconditional, so no branch and no s_waitcnt separates them.
+    const int m = m0 + r;
+    const bool m_ok = m < p.M, m_one = (m == p.M && p.ones == 2);
+    const int mc = min(m, p.M - 1);
+    int64_t a_row;
+    if (A_MODE == 0)
+        a_row = (GA ? (int64_t)p.a_gather[mc] : (int64_t)mc) * p.lda;
+    else
+        a_row = mc;
+    int nc[2];
+    bool n_ok[2];
+    float b_fill[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int n = n0 + 16 * f + r;
+        n_ok[f] = n < p.N;
+        b_fill[f] = (n == p.N && p.ones == 1) ? 1.f : 0.f;
+        nc[f] = min(n, p.N - 1);
+    }
+    const float a_fill = m_one ? 1.f : 0.f;
+
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    // FULL: the block lies inside K (vector loads allowed, no k masking)
+    auto load = [&](const int kb, float (&a)[4], float (&b)[2][4], auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int k = kb * 16 + 4 * g;
+        int kc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kc[j] = FULL ? k + j : min(k + j, p.K - 1);
+        if (A_MODE == 0) {
+            if (FULL && VEC) {
+                const float4 v = *reinterpret_cast<const float4*>(A + a_row + k);
+                a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = A[a_row + kc[j]];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = A[(int64_t)kc[j] * p.lda + a_row];
+        }
+        if (B_MODE == 0) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const float* bp = B + (int64_t)nc[f] * p.ldb;
+                if (FULL && VEC) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + k);
+                    b[f][0] = v.x, b[f][1] = v.y, b[f][2] = v.z, b[f][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[f][j] = bp[kc[j]];
+                }
+            }
+        } else {
+            int64_t brow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) brow[j] = (GB ? (int64_t)p.b_gather[kc[j]] : (int64_t)kc[j]) * p.ldb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int f = 0; f < 2; ++f) b[f][j] = B[brow[j] + nc[f]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool kin = FULL || (k + j < p.K);
+            a[j] = kin ? (m_ok ? a[j] : a_fill) : 0.f;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) b[f][j] = kin ? (n_ok[f] ? b[f][j] : b_fill[f]) : 0.f;
+        }
+    };
+    auto mma = [&](const float (&a)[4], const float (&b)[2][4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[0][j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[1][j], acc[1], 0, 0, 0);
+        }
+    };
+    // four independent K blocks per iteration: all their fragment loads are issued before the first MFMA
+    int kb = kb_begin + w;
+    for (; kb + 3 * NW < kb_full_end; kb += 4 * NW) {
+        float a0[4], b0[2][4], a1[4], b1[2][4], a2[4], b2[2][4], a3[4], b3[2][4];
+        load(kb, a0, b0, T{});
+        load(kb + NW, a1, b1, T{});
+        load(kb + 2 * NW, a2, b2, T{});
+        load(kb + 3 * NW, a3, b3, T{});
+        mma(a0, b0);
+        mma(a1, b1);
+        mma(a2, b2);
+        mma(a3, b3);
+    }
+    for (; kb < kb_full_end; kb += NW) {
+        float a0[4], b0[2][4];
+        load(kb, a0, b0, T{});
+        mma(a0, b0);
+    }
+    if (kb < kb_end) {  // the one partial block of this split (k-clamped scalar loads)
+        float a0[4], b0[2][4];
+        load(kb, a0, b0, Fx{});
+        mma(a0, b0);
+    }
+    reduce_and_store<NW>(p, acc, red, m0, n0, z);
+}
+
+// bf16 feature block as the A operand (rows K-contiguous, optional gather), fp32 B [N,K] rounded to bf16 on the fly:
+// the forward input projection.  v_mfma_f32_16x16x32_bf16: lane (r,g) holds k = kb*32 + 8g + j, j < 8.
+__device__ __forceinline__ short f2bf_s(float f) {
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(short, h);
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
+    __shared__ float red[NW > 1 ? NW * 8 * 64 : 1];
+    const unsigned short* __restrict__ A = (const unsigned short*)p.A;
+    const float* __restrict__ B = (const float*)p.B;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 16, z = blockIdx.z;
+    const int nkb = (p.K + 31) / 32;
+    const int kb_begin = z * p.kblocks_per_split;
+    const int kb_end = min(nkb, kb_begin + p.kblocks_per_split);
+    const int m = m0 + r;
+    const bool m_ok = m < p.M;
+    const int mc = min(m, p.M - 1);
+    const int64_t a_row = (p.a_gather ? (int64_t)p.a_gather[mc] : (int64_t)mc) * p.lda;
+    int nc[2];
+    bool n_ok[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        const int n = n0 + 16 * f + r;
+        n_ok[f] = n < p.N;
+        nc[f] = min(n, p.N - 1);
+    }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    // every load is unconditional (clamped address + select afterwards): no branch, no wait between loads
+    auto load = [&](const int kb, bf16x8& a, bf16x8 (&b)[2]) {
+        const int k = kb * 32 + 8 * g;
+        const bool full = kb * 32 + 32 <= p.K;  // wave-uniform
+        const unsigned short* s = A + a_row;
+        if (full && p.a_vec == 2) {
+            a = *reinterpret_cast<const bf16x8*>(s + k);
+        } else if (full && p.a_vec == 1) {
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(s + k), hi = *reinterpret_cast<const bf16x4*>(s + k + 4);
+            a = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const short v = (short)s[min(k + j, p.K - 1)];
+                a[j] = (k + j < p.K) ? v : (short)0;
+            }
+        }
+        a = m_ok ? a : zero8;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const float* bp = B + (int64_t)nc[f] * p.ldb;
+            float t[8];
+            if (full && p.b_vec) {
+                const float4 lo = *reinterpret_cast<const float4*>(bp + k), hi = *reinterpret_cast<const float4*>(bp + k + 4);
+                t[0] = lo.x, t[1] = lo.y, t[2] = lo.z, t[3] = lo.w, t[4] = hi.x, t[5] = hi.y, t[6] = hi.z, t[7] = hi.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = bp[min(k + j, p.K - 1)];
+                    t[j] = (k + j < p.K) ? v : 0.f;
+                }
+            }
+            const bf16x8 v = {f2bf_s(t[0]), f2bf_s(t[1]), f2bf_s(t[2]), f2bf_s(t[3]),
+                              f2bf_s(t[4]), f2bf_s(t[5]), f2bf_s(t[6]), f2bf_s(t[7])};
+            b[f] = n_ok[f] ? v : zero8;
+        }
+    };
+    auto mma = [&](const bf16x8& a, const bf16x8 (&b)[2]) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1], acc[1], 0, 0, 0);
+    };
+    int kb = kb_begin + w;
+    for (; kb + 2 * NW < kb_end; kb += 3 * NW) {
+        bf16x8 a0, b0[2], a1, b1[2], a2, b2[2];
+        load(kb, a0, b0);
+        load(kb + NW, a1, b1);
+        load(kb + 2 * NW, a2, b2);
+        mma(a0, b0);
+        mma(a1, b1);
+        mma(a2, b2);
+    }
+    for (; kb < kb_end; kb += NW) {
+        bf16x8 a0, b0[2];
+        load(kb, a0, b0);
+        mma(a0, b0);
+    }
+    reduce_and_store<NW>(p, acc, red, m0, n0, z);
+}
+
+bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+// Same contract as erc_gemm_f32 (ercgraft.h); selected by the host for skinny problems.
+extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_gather, const float* B, int ldb,
+                                   int b_kmajor, const int32_t* b_gather, float* C, int ldc, int M, int N, int K,
+                                   int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
+                                   const float* bias, int act, const float* aux, int ldaux, float act_scale, float drop_p,
+                                   const uint64_t* rng_state, int accumulate, void* stream) {
+    ERC_REQUIRE(A && B && C, "gemm_f32_stream: null operand");
+    ERC_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_f32_stream: bad shape M=%d N=%d K=%d", M, N, K);
+    ERC_REQUIRE(split_k >= 1, "gemm_f32_stream: split_k must be >= 1");
+    ERC_REQUIRE(!(a_kmajor && !b_kmajor), "gemm_f32_stream: (A k-major, B k-contiguous) is not built");
+    ERC_REQUIRE(split_k == 1 || (!bias && act == 0 && !accumulate), "gemm_f32_stream: epilogue requires split_k == 1");
+    ERC_REQUIRE(act >= 0 && act <= 3 && (act != 2 || aux) && (act != 3 || rng_state), "gemm_f32_stream: bad epilogue");
+    ERC_REQUIRE(!(a_gather && a_kmajor) && !(b_gather && !b_kmajor), "gemm_f32_stream: gather on a contiguous-K index only");
+    ERC_REQUIRE(ones_col >= 0 && ones_col <= 2, "gemm_f32_stream: ones mode %d", ones_col);
+    StreamP p{};
+    p.A = A; p.B = B; p.C = C; p.a_gather = a_gather; p.b_gather = b_gather; p.bias = bias; p.aux = aux;
+    p.bias_out = bias_out; p.rng = rng_state; p.c_slab = c_slab; p.bias_slab = bias_slab;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldaux = ldaux; p.M = M; p.N = N; p.K = K;
+    const int nkb = erc_cdiv(K, 16);
+    ERC_REQUIRE(split_k <= nkb, "gemm_f32_stream: split_k %d exceeds the %d K-blocks", split_k, nkb);
+    p.kblocks_per_split = erc_cdiv(nkb, split_k);
+    p.ones = ones_col; p.act = act; p.accumulate = accumulate;
+    p.a_vec = al16(A) && (lda % 4 == 0);
+    p.b_vec = al16(B) && (ldb % 4 == 0);
+    p.act_scale = act_scale; p.drop_p = drop_p;
+    const int Nlog = N + (ones_col == 1 ? 1 : 0), Mlog = M + (ones_col == 2 ? 1 : 0);
+    dim3 grid(erc_cdiv(Nlog, 32), erc_cdiv(Mlog, 16), split_k);
+    const int kb_split = p.kblocks_per_split;
+    // wavefronts per workgroup: enough to cut the K chain, not more than there are blocks
+    const int nw = kb_split >= 32 ? 8 : (kb_split >= 6 ? 4 : 1);
+    hipStream_t st = (hipStream_t)stream;
+    const bool ga = a_gather != nullptr, gb = b_gather != nullptr;
+    const bool vec = (a_kmajor || p.a_vec) && (b_kmajor || p.b_vec);
+#define ERC_SL3(AM, BM_, GA_, GB_, V_)                                                                                  \
+    do {                                                                                                               \
+        if (nw == 8) hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BM_, 8, GA_, GB_, V_>), grid, dim3(512), 0, st, p); \
+        else if (nw == 4) hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BM_, 4, GA_, GB_, V_>), grid, dim3(256), 0, st, p); \
+        else hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BM_, 1, GA_, GB_, V_>), grid, dim3(64), 0, st, p);          \
+    } while (0)
+#define ERC_SL2(AM, BM_, GA_, GB_)              \
+    do {                                        \
+        if (vec) ERC_SL3(AM, BM_, GA_, GB_, true); \
+        else ERC_SL3(AM, BM_, GA_, GB_, false);    \
+    } while (0)
+    if (!a_kmajor && !b_kmajor) {
+        if (ga) ERC_SL2(0, 0, true, false); else ERC_SL2(0, 0, false, false);
+    } else if (!a_kmajor && b_kmajor) {
+        if (ga && gb) ERC_SL2(0, 1, true, true);
+        else if (ga) ERC_SL2(0, 1, true, false);
+        else if (gb) ERC_SL2(0, 1, false, true);
+        else ERC_SL2(0, 1, false, false);
+    } else {
+        if (gb) ERC_SL3(1, 1, false, true, false); else ERC_SL3(1, 1, false, false, false);
+    }
+#undef ERC_SL2
+#undef ERC_SL3
+    ERC_LAUNCH_CHECK("gemm_f32_stream");
+    return ERC_OK;
+}
+
+// C[M,N] = X[gather(m), :K] (bf16) * W[N,K]^T (fp32 rounded to bf16), fp32 accumulate: forward input projection.
+extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const float* W, int ldw, float* C,
+                                     int ldc, int M, int N, int K, const float* bias, int act, void* stream) {
+    ERC_REQUIRE(X && W && C && M > 0 && N > 0 && K > 0, "gemm_bf16a_stream: bad arguments");
+    ERC_REQUIRE(act == 0 || act == 1, "gemm_bf16a_stream: act %d", act);
+    StreamP p{};
+    p.A = X; p.B = W; p.C = C; p.a_gather = gather; p.bias = bias; p.lda = ldx; p.ldb = ldw; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.act = act;
+    const int nkb = erc_cdiv(K, 32);
+    p.kblocks_per_split = nkb;
+    p.a_vec = !al16(X) ? 0 : (ldx % 8 == 0 ? 2 : (ldx % 4 == 0 ? 1 : 0));
+    p.b_vec = al16(W) && (ldw % 4 == 0);
+    dim3 grid(erc_cdiv(N, 32), erc_cdiv(M, 16), 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (nkb >= 16)
+        hipLaunchKernelGGL((gemm_bf16a_stream_kernel<8>), grid, dim3(512), 0, st, p);
+    else if (nkb >= 4)
+        hipLaunchKernelGGL((gemm_bf16a_stream_kernel<4>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((gemm_bf16a_stream_kernel<1>), grid, dim3(64), 0, st, p);
+    ERC_LAUNCH_CHECK("gemm_bf16a_stream");
+    return ERC_OK;
+}

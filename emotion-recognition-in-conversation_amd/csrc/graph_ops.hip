@@ -10,6 +10,22 @@
 namespace {
 
 constexpr int MAX_R = 8;
+constexpr int CH = 8;  // neighbour rows fetched together (their loads are all in flight before the first use)
+
+// Every kernel below follows the same latency discipline (one dependent global round trip costs ~0.5 us here,
+// a 20-edge neighbourhood walked edge by edge ~20 of them): the CSR slice of the node is loaded lane-parallel
+// (lane l holds edge e0+l of a 64-edge window), indices are broadcast with __shfl, and the neighbour rows of CH
+// edges are fetched by unconditional loads (clamped indices, results masked afterwards) before any arithmetic.
+struct Row2 {
+    float a, b;
+};
+__device__ __forceinline__ Row2 ldrow(const float* base, int64_t row, int ld, int c0, int c1) {
+    const float* p = base + row * ld;
+    Row2 r;
+    r.a = p[c0];
+    r.b = p[c1];
+    return r;
+}
 
 // ---------------------------------------------------------------- RGCN mean
 __global__ __launch_bounds__(256) void rgcn_mean_fwd_kernel(const float* __restrict__ x, int ldx, int F, int R, int N,
@@ -21,39 +37,50 @@ __global__ __launch_bounds__(256) void rgcn_mean_fwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= N) return;
-    const int c0 = lane, c1 = lane + 64;
-    const bool h0 = c0 < F, h1 = c1 < F;
+    const bool h0 = lane < F, h1 = lane + 64 < F;
+    const int c0 = min(lane, F - 1), c1 = min(lane + 64, F - 1);
     float s0[MAX_R], s1[MAX_R];
     int cnt[MAX_R];
 #pragma unroll
     for (int r = 0; r < MAX_R; ++r) s0[r] = s1[r] = 0.f, cnt[r] = 0;
     const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
-    for (int e = e0; e < e1; ++e) {
-        const int j = in_src[e];
-        const int t = in_typ[e];
-        const float v0 = h0 ? x[(int64_t)j * ldx + c0] : 0.f;
-        const float v1 = h1 ? x[(int64_t)j * ldx + c1] : 0.f;
+    const Row2 self = ldrow(x, i, ldx, c0, c1);
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_src = in_src[el], my_typ = in_typ[el];
+        for (int base = 0; base < nwin; base += CH) {
+            Row2 v[CH];
+            int t[CH];
 #pragma unroll
-        for (int r = 0; r < MAX_R; ++r) {
-            const bool hit = (t == r);
-            s0[r] += hit ? v0 : 0.f;
-            s1[r] += hit ? v1 : 0.f;
-            cnt[r] += hit ? 1 : 0;
+            for (int u = 0; u < CH; ++u) {
+                const int sl = min(base + u, nwin - 1);
+                v[u] = ldrow(x, __shfl(my_src, sl, 64), ldx, c0, c1);
+                t[u] = (base + u < nwin) ? __shfl(my_typ, sl, 64) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int r = 0; r < MAX_R; ++r) {
+                    const bool hit = (t[u] == r);
+                    s0[r] += hit ? v[u].a : 0.f;
+                    s1[r] += hit ? v[u].b : 0.f;
+                    cnt[r] += hit ? 1 : 0;
+                }
         }
     }
     float* mrow = Mout + (int64_t)i * ldm;
 #pragma unroll
     for (int r = 0; r < MAX_R; ++r) {
         if (r < R) {
-            const float inv = cnt[r] > 0 ? 1.0f / (float)cnt[r] : 0.f;
-            // mean = sum / count (a division, like scatter-mean) -- inv is only kept for the backward
-            if (h0) mrow[r * F + c0] = cnt[r] > 0 ? s0[r] / (float)cnt[r] : 0.f;
-            if (h1) mrow[r * F + c1] = cnt[r] > 0 ? s1[r] / (float)cnt[r] : 0.f;
-            if (lane == 0) inv_cnt[(int64_t)i * R + r] = inv;
+            // mean = sum / count (a division, like scatter-mean); 1/count is kept for the backward
+            if (h0) mrow[r * F + lane] = cnt[r] > 0 ? s0[r] / (float)cnt[r] : 0.f;
+            if (h1) mrow[r * F + lane + 64] = cnt[r] > 0 ? s1[r] / (float)cnt[r] : 0.f;
+            if (lane == 0) inv_cnt[(int64_t)i * R + r] = cnt[r] > 0 ? 1.0f / (float)cnt[r] : 0.f;
         }
     }
-    if (h0) mrow[R * F + c0] = x[(int64_t)i * ldx + c0];
-    if (h1) mrow[R * F + c1] = x[(int64_t)i * ldx + c1];
+    if (h0) mrow[R * F + lane] = self.a;
+    if (h1) mrow[R * F + lane + 64] = self.b;
 }
 
 __global__ __launch_bounds__(256) void rgcn_mean_bwd_kernel(const float* __restrict__ dM, int ldm, int F, int R, int N,
@@ -65,22 +92,33 @@ __global__ __launch_bounds__(256) void rgcn_mean_bwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= N) return;
-    const int c0 = lane, c1 = lane + 64;
-    const bool h0 = c0 < F, h1 = c1 < F;
-    float a0 = h0 ? dM[(int64_t)j * ldm + R * F + c0] : 0.f;
-    float a1 = h1 ? dM[(int64_t)j * ldm + R * F + c1] : 0.f;
+    const bool h0 = lane < F, h1 = lane + 64 < F;
+    const int c0 = min(lane, F - 1), c1 = min(lane + 64, F - 1);
+    const Row2 self = ldrow(dM + R * F, j, ldm, c0, c1);
+    float a0 = self.a, a1 = self.b;
     const int e0 = out_ptr[j], e1 = out_ptr[j + 1];
-    for (int e = e0; e < e1; ++e) {
-        const int i = out_dst[e];
-        const int t = out_typ[e];
-        if (t >= R) continue;
-        const float w = inv_cnt[(int64_t)i * R + t];
-        const float* row = dM + (int64_t)i * ldm + t * F;
-        if (h0) a0 += row[c0] * w;
-        if (h1) a1 += row[c1] * w;
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_dst = out_dst[el];
+        const int my_typ = min(out_typ[el], R);           // relation ids >= R are ignored (weight 0 below)
+        const float my_w = my_typ < R ? inv_cnt[(int64_t)my_dst * R + my_typ] : 0.f;
+        const int my_off = min(my_typ, R - 1) * F;
+        for (int base = 0; base < nwin; base += CH) {
+            Row2 v[CH];
+            float w[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int sl = min(base + u, nwin - 1);
+                v[u] = ldrow(dM + __shfl(my_off, sl, 64), __shfl(my_dst, sl, 64), ldm, c0, c1);
+                w[u] = (base + u < nwin) ? __shfl(my_w, sl, 64) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) a0 += v[u].a * w[u], a1 += v[u].b * w[u];
+        }
     }
-    if (h0) dx[(int64_t)j * lddx + c0] = a0;
-    if (h1) dx[(int64_t)j * lddx + c1] = a1;
+    if (h0) dx[(int64_t)j * lddx + lane] = a0;
+    if (h1) dx[(int64_t)j * lddx + lane + 64] = a1;
 }
 
 // ------------------------------------------------- TransformerConv, heads=1
@@ -91,42 +129,59 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= N) return;
-    const int c0 = lane, c1 = lane + 64;
-    const bool h0 = c0 < F, h1 = c1 < F;
-    const float* qi = qkvs + (int64_t)i * ld;
-    const float q0 = h0 ? qi[c0] : 0.f, q1 = h1 ? qi[c1] : 0.f;
+    const bool h0 = lane < F, h1 = lane + 64 < F;
+    const int c0 = min(lane, F - 1), c1 = min(lane + 64, F - 1);
+    const float m0 = h0 ? 1.f : 0.f, m1 = h1 ? 1.f : 0.f;
+    const Row2 q = ldrow(qkvs, i, ld, c0, c1);
+    const Row2 sk = ldrow(qkvs + 3 * F, i, ld, c0, c1);
+    const float q0 = q.a * m0, q1 = q.b * m1;
     const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
-    // pass 1: max of the raw scores
-    float mx = -INFINITY;
-    for (int e = e0; e < e1; ++e) {
-        const float* kj = qkvs + (int64_t)in_src[e] * ld + F;
-        const float part = (h0 ? q0 * kj[c0] : 0.f) + (h1 ? q1 * kj[c1] : 0.f);
-        mx = fmaxf(mx, wave_sum(part) * scale);
-    }
-    // pass 2: exp, denominator, weighted values (unnormalised); lane (e-e0) keeps exp_e of the first 64 edges
-    float den = 0.f, o0 = 0.f, o1 = 0.f, mine = 0.f;
-    for (int e = e0; e < e1; ++e) {
-        const float* kj = qkvs + (int64_t)in_src[e] * ld + F;
-        const float part = (h0 ? q0 * kj[c0] : 0.f) + (h1 ? q1 * kj[c1] : 0.f);
-        const float pexp = expf(wave_sum(part) * scale - mx);
-        den += pexp;
-        const float* vj = qkvs + (int64_t)in_src[e] * ld + 2 * F;
-        if (h0) o0 += pexp * vj[c0];
-        if (h1) o1 += pexp * vj[c1];
-        if (e - e0 == lane) mine = pexp;
+    // online softmax over 64-edge windows (one window for window graphs): running max mx, denominator den,
+    // unnormalised output o; lane l keeps exp-score of edge l of the current window until it is rescaled.
+    float mx = -INFINITY, den = 0.f, o0 = 0.f, o1 = 0.f;
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int my_src = in_src[w0 + min(lane, nwin - 1)];
+        float my_s = -INFINITY;  // raw score of edge `lane` of this window
+        for (int base = 0; base < nwin; base += CH) {
+            Row2 k[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) k[u] = ldrow(qkvs + F, __shfl(my_src, min(base + u, nwin - 1), 64), ld, c0, c1);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float sc = wave_sum(q0 * k[u].a + q1 * k[u].b) * scale;
+                if (lane == base + u) my_s = sc;
+            }
+        }
+        const float wmx = wave_max(my_s);           // lanes >= nwin hold -inf
+        const float nmx = fmaxf(mx, wmx);
+        const float resc = expf(mx - nmx);          // 0 on the first window (mx = -inf)
+        den *= resc, o0 *= resc, o1 *= resc;
+        mx = nmx;
+        const float my_p = lane < nwin ? expf(my_s - mx) : 0.f;
+        den += wave_sum(my_p);
+        for (int base = 0; base < nwin; base += CH) {
+            Row2 v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) v[u] = ldrow(qkvs + 2 * F, __shfl(my_src, min(base + u, nwin - 1), 64), ld, c0, c1);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float pw = (base + u < nwin) ? __shfl(my_p, min(base + u, 63), 64) : 0.f;
+                o0 += pw * v[u].a, o1 += pw * v[u].b;
+            }
+        }
+        // provisional weights (exact when there is a single window; rescaled below otherwise)
+        if (lane < nwin) alpha[w0 + lane] = my_p;
+        if (w0 > e0) {  // earlier windows were written relative to an older max
+            // (degree > 64 only) bring them to the current max
+            for (int e = e0 + lane; e < w0; e += 64) alpha[e] *= resc;
+        }
     }
     const float inv = 1.0f / (den + 1e-16f);
-    const float* si = qi + 3 * F;
-    if (h0) out[(int64_t)i * ldo + c0] = o0 * inv + si[c0];
-    if (h1) out[(int64_t)i * ldo + c1] = o1 * inv + si[c1];
-    // pass 3: normalised weights for the backward; no memory round trip inside the wave
-    if (e0 + lane < e1) alpha[e0 + lane] = mine * inv;
-    for (int e = e0 + 64; e < e1; ++e) {  // degree > 64 (never for window graphs): recompute
-        const float* kj = qkvs + (int64_t)in_src[e] * ld + F;
-        const float part = (h0 ? q0 * kj[c0] : 0.f) + (h1 ? q1 * kj[c1] : 0.f);
-        const float a = expf(wave_sum(part) * scale - mx) * inv;
-        if (lane == 0) alpha[e] = a;
-    }
+    if (h0) out[(int64_t)i * ldo + lane] = o0 * inv + sk.a;
+    if (h1) out[(int64_t)i * ldo + lane + 64] = o1 * inv + sk.b;
+    // normalise: each lane rescales the entries it wrote itself (same lane -> same addresses, program order holds)
+    for (int e = e0 + lane; e < e1; e += 64) alpha[e] *= inv;
 }
 
 __global__ __launch_bounds__(256) void tconv_bwd_target_kernel(const float* __restrict__ qkvs, int ld, int F, int N,
@@ -139,32 +194,65 @@ __global__ __launch_bounds__(256) void tconv_bwd_target_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= N) return;
-    const int c0 = lane, c1 = lane + 64;
-    const bool h0 = c0 < F, h1 = c1 < F;
-    const float g0 = h0 ? dout[(int64_t)i * lddo + c0] : 0.f;
-    const float g1 = h1 ? dout[(int64_t)i * lddo + c1] : 0.f;
+    const bool h0 = lane < F, h1 = lane + 64 < F;
+    const int c0 = min(lane, F - 1), c1 = min(lane + 64, F - 1);
+    const Row2 gr = ldrow(dout, i, lddo, c0, c1);
+    const float g0 = h0 ? gr.a : 0.f, g1 = h1 ? gr.b : 0.f;
     const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
-    // t = sum_e alpha_e * (dout_i . v_src(e))
+    // pass 1: t = sum_e alpha_e (dout_i . v_src(e)); lane l keeps d alpha of edge l (first window)
     float t = 0.f;
-    for (int e = e0; e < e1; ++e) {
-        const float* vj = qkvs + (int64_t)in_src[e] * ld + 2 * F;
-        const float da = wave_sum((h0 ? g0 * vj[c0] : 0.f) + (h1 ? g1 * vj[c1] : 0.f));
-        t += alpha[e] * da;
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_src = in_src[el];
+        const float my_al = lane < nwin ? alpha[el] : 0.f;
+        float my_da = 0.f;
+        for (int base = 0; base < nwin; base += CH) {
+            Row2 v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) v[u] = ldrow(qkvs + 2 * F, __shfl(my_src, min(base + u, nwin - 1), 64), ld, c0, c1);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float da = wave_sum(g0 * v[u].a + g1 * v[u].b);
+                if (lane == base + u) my_da = da;
+            }
+        }
+        t += wave_sum(my_al * my_da);
     }
+    // pass 2: ds_e = alpha_e (d alpha_e - t) scale ; dq_i = sum_e ds_e k_src(e)
     float dq0 = 0.f, dq1 = 0.f;
-    for (int e = e0; e < e1; ++e) {
-        const int j = in_src[e];
-        const float* vj = qkvs + (int64_t)j * ld + 2 * F;
-        const float da = wave_sum((h0 ? g0 * vj[c0] : 0.f) + (h1 ? g1 * vj[c1] : 0.f));
-        const float ds = alpha[e] * (da - t) * scale;  // dL/d(q.k)
-        if (lane == 0) dscore[e] = ds;
-        const float* kj = qkvs + (int64_t)j * ld + F;
-        if (h0) dq0 += ds * kj[c0];
-        if (h1) dq1 += ds * kj[c1];
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_src = in_src[el];
+        const float my_al = lane < nwin ? alpha[el] : 0.f;
+        float my_da = 0.f;
+        Row2 kk[CH];
+        for (int base = 0; base < nwin; base += CH) {
+            Row2 v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) v[u] = ldrow(qkvs + 2 * F, __shfl(my_src, min(base + u, nwin - 1), 64), ld, c0, c1);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float da = wave_sum(g0 * v[u].a + g1 * v[u].b);
+                if (lane == base + u) my_da = da;
+            }
+        }
+        const float my_ds = my_al * (my_da - t) * scale;
+        if (lane < nwin) dscore[el] = my_ds;
+        for (int base = 0; base < nwin; base += CH) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) kk[u] = ldrow(qkvs + F, __shfl(my_src, min(base + u, nwin - 1), 64), ld, c0, c1);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const float ds = (base + u < nwin) ? __shfl(my_ds, min(base + u, 63), 64) : 0.f;
+                dq0 += ds * kk[u].a, dq1 += ds * kk[u].b;
+            }
+        }
     }
     float* d = dqkvs + (int64_t)i * ld;
-    if (h0) d[c0] = dq0, d[3 * F + c0] = g0;
-    if (h1) d[c1] = dq1, d[3 * F + c1] = g1;
+    if (h0) d[lane] = dq0, d[3 * F + lane] = g0;
+    if (h1) d[lane + 64] = dq1, d[3 * F + lane + 64] = g1;
 }
 
 __global__ __launch_bounds__(256) void tconv_bwd_source_kernel(const float* __restrict__ qkvs, int ld, int F, int N,
@@ -178,22 +266,38 @@ __global__ __launch_bounds__(256) void tconv_bwd_source_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= N) return;
-    const int c0 = lane, c1 = lane + 64;
-    const bool h0 = c0 < F, h1 = c1 < F;
+    const bool h0 = lane < F, h1 = lane + 64 < F;
+    const int c0 = min(lane, F - 1), c1 = min(lane + 64, F - 1);
     float dk0 = 0.f, dk1 = 0.f, dv0 = 0.f, dv1 = 0.f;
     const int e0 = out_ptr[j], e1 = out_ptr[j + 1];
-    for (int e = e0; e < e1; ++e) {
-        const int i = out_dst[e];
-        const int id = out_eid[e];
-        const float ds = dscore[id], al = alpha[id];
-        const float* qi = qkvs + (int64_t)i * ld;
-        const float* gi = dout + (int64_t)i * lddo;
-        if (h0) dk0 += ds * qi[c0], dv0 += al * gi[c0];
-        if (h1) dk1 += ds * qi[c1], dv1 += al * gi[c1];
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_dst = out_dst[el];
+        const int id = out_eid[el];
+        const float my_ds = lane < nwin ? dscore[id] : 0.f;
+        const float my_al = lane < nwin ? alpha[id] : 0.f;
+        for (int base = 0; base < nwin; base += CH) {
+            Row2 qv[CH], gv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int dst = __shfl(my_dst, min(base + u, nwin - 1), 64);
+                qv[u] = ldrow(qkvs, dst, ld, c0, c1);
+                gv[u] = ldrow(dout, dst, lddo, c0, c1);
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int sl = min(base + u, 63);
+                const float ds = (base + u < nwin) ? __shfl(my_ds, sl, 64) : 0.f;
+                const float al = (base + u < nwin) ? __shfl(my_al, sl, 64) : 0.f;
+                dk0 += ds * qv[u].a, dk1 += ds * qv[u].b;
+                dv0 += al * gv[u].a, dv1 += al * gv[u].b;
+            }
+        }
     }
     float* d = dqkvs + (int64_t)j * ld;
-    if (h0) d[F + c0] = dk0, d[2 * F + c0] = dv0;
-    if (h1) d[F + c1] = dk1, d[2 * F + c1] = dv1;
+    if (h0) d[F + lane] = dk0, d[2 * F + lane] = dv0;
+    if (h1) d[F + lane + 64] = dk1, d[2 * F + lane + 64] = dv1;
 }
 
 }  // namespace

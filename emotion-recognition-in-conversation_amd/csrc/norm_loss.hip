@@ -127,34 +127,41 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------ cross entropy
-// One workgroup of 1024 threads walks all rows (N is a few thousand): the loss
-// and accuracy reductions are then a plain, deterministic block reduction.
-__global__ __launch_bounds__(1024) void cross_entropy_kernel(const float* __restrict__ logits, int ld, int C,
-                                                             int n_rows, const int32_t* __restrict__ row_map,
-                                                             const int64_t* __restrict__ labels,
-                                                             const float* __restrict__ weight, float grad_scale,
-                                                             float* __restrict__ dlogits, int lddl,
-                                                             float* __restrict__ stats) {
-    __shared__ double red[1024];
+// Rows are spread over up to CE_MAXWG workgroups (the gradient needs only the normaliser, which every workgroup
+// recomputes from the labels); loss / accuracy partials are combined by the LAST workgroup to finish, in
+// workgroup order, so the result is independent of scheduling.  stats[] layout: [0] loss [1] #correct [2] sum of
+// weights [8 + 2w], [9 + 2w] partials of workgroup w, [4] (as int) arrival counter (zero between calls).
+constexpr int CE_MAXWG = 64;
+
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ logits, int ld, int C,
+                                                            int n_rows, const int32_t* __restrict__ row_map,
+                                                            const int64_t* __restrict__ labels,
+                                                            const float* __restrict__ weight, float grad_scale,
+                                                            float* __restrict__ dlogits, int lddl,
+                                                            float* __restrict__ stats) {
+    __shared__ double red[256];
     __shared__ double s_wsum;
+    __shared__ int s_last;
     const int tid = threadIdx.x;
-    // pass A: normaliser
     double wacc = 0.0;
-    for (int i = tid; i < n_rows; i += 1024) wacc += weight ? (double)weight[labels[i]] : 1.0;
-    red[tid] = wacc;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if (tid < o) red[tid] += red[tid + o];
+    if (weight) {
+        for (int i = tid; i < n_rows; i += 256) wacc += (double)weight[labels[i]];
+        red[tid] = wacc;
         __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) s_wsum = red[0];
+    } else if (tid == 0) {
+        s_wsum = (double)n_rows;
     }
-    if (tid == 0) s_wsum = red[0];
     __syncthreads();
     const double wsum = s_wsum;
     const float inv_w = (float)(1.0 / wsum);
-    // pass B
     double lacc = 0.0;
     int hit = 0;
-    for (int i = tid; i < n_rows; i += 1024) {
+    for (int i = blockIdx.x * 256 + tid; i < n_rows; i += gridDim.x * 256) {
         const int64_t row = row_map ? (int64_t)row_map[i] : (int64_t)i;
         const float* z = logits + row * ld;
         const int y = (int)labels[i];
@@ -179,22 +186,37 @@ __global__ __launch_bounds__(1024) void cross_entropy_kernel(const float* __rest
     __syncthreads();
     red[tid] = lacc;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
-    const double loss = red[0] / wsum;
+    const double lsum = red[0];
     __syncthreads();
     red[tid] = (double)hit;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
     if (tid == 0) {
-        stats[0] = (float)loss;
-        stats[1] = (float)red[0];
+        stats[8 + 2 * blockIdx.x] = (float)lsum;
+        stats[9 + 2 * blockIdx.x] = (float)red[0];
+        __threadfence();
+        const int prev = atomicAdd(reinterpret_cast<int*>(stats + 4), 1);
+        s_last = (prev == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last && tid == 0) {
+        __threadfence();
+        double l = 0.0, h = 0.0;
+        for (int w = 0; w < (int)gridDim.x; ++w) {
+            l += (double)__hip_atomic_load(stats + 8 + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h += (double)__hip_atomic_load(stats + 9 + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        stats[0] = (float)(l / wsum);
+        stats[1] = (float)h;
         stats[2] = (float)wsum;
+        *reinterpret_cast<int*>(stats + 4) = 0;
     }
 }
 
@@ -248,7 +270,9 @@ extern "C" int erc_cross_entropy(const float* logits, int ld, int C, int n_rows,
                                  int lddl, float* stats, void* stream) {
     ERC_REQUIRE(logits && labels && stats, "cross_entropy: null pointer");
     ERC_REQUIRE(C > 0 && n_rows > 0 && ld >= C, "cross_entropy: C=%d n_rows=%d ld=%d", C, n_rows, ld);
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ld, C, n_rows,
+    int grid = erc_cdiv(n_rows, 256);
+    if (grid > CE_MAXWG) grid = CE_MAXWG;
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, ld, C, n_rows,
                        row_map, labels, weight, grad_scale, dlogits, lddl, stats);
     ERC_LAUNCH_CHECK("cross_entropy");
     return ERC_OK;

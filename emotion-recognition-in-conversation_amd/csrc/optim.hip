@@ -25,8 +25,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, int decoupled,
                                                    float grad_scale, float clip_norm,
-                                                   const float* __restrict__ gnorm, const int64_t* state) {
-    const int64_t step = state[0] + 1;  // state is bumped by adam_bump_kernel after this launch
+                                                   const float* __restrict__ gnorm, int64_t* state) {
+    const int64_t step = state[0] + 1;  // every block reads it before it signals arrival (below)
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
     const float step_size = lr / bc1;
@@ -48,11 +48,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         v[i] = vi;
         p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     }
-}
-
-__global__ void adam_bump_kernel(int64_t* state) {
-    state[0] += 1;  // optimizer step
-    state[1] += 1;  // RNG offset: a fresh dropout mask next step
+    // the LAST block to finish bumps {step, RNG offset}: by then every block has read state[0]
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(state + 3), 1ull);
+        if (prev == (unsigned long long)gridDim.x - 1) {
+            state[0] += 1;  // optimizer step
+            state[1] += 1;  // RNG offset: a fresh dropout mask next step
+            state[3] = 0;   // arrival counter back to zero for the next call
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float scale,
@@ -80,7 +85,30 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const double* __restric
     if (threadIdx.x == 0) gnorm[0] = (float)sqrt(sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// Diagnostic only (bench.py --clock_probe): one wavefront runs a dependent MFMA chain and records shader cycles
+// (s_memtime) against the 100 MHz real-time counter, i.e. the clock the chip holds at that point of the stream.
+typedef float probe_f4 __attribute__((ext_vector_type(4)));
+__global__ void clock_probe_kernel(unsigned long long* out, int iters) {
+    probe_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float a = (float)threadIdx.x, b = 1.0f;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = r1 - r0;
+    }
+    if (acc[0] == 12345.f) out[2] = 1;
+}
+
 }  // namespace
+
+extern "C" int erc_clock_probe(uint64_t* out, int iters, void* stream) {
+    ERC_REQUIRE(out && iters > 0, "clock_probe: bad arguments");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, iters);
+    ERC_LAUNCH_CHECK("clock_probe");
+    return ERC_OK;
+}
 
 extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
@@ -88,13 +116,11 @@ extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64
     ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
     ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
     int grid = (int)((n + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    if (grid > 256) grid = 256;  // one arrival atomic per block on a single word: keep the count low
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                        decoupled, grad_scale, clip_norm, gnorm, state);
     ERC_LAUNCH_CHECK("adam_step");
-    hipLaunchKernelGGL(adam_bump_kernel, dim3(1), dim3(1), 0, st, state);
-    ERC_LAUNCH_CHECK("adam_bump");
     return ERC_OK;
 }
 

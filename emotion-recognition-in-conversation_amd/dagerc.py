@@ -100,12 +100,12 @@ class DAGERCModule(nn.Module):
             Y1=f32(BT, HID), Y2=f32(BT, HID), logits=f32(BT, C), dlogits=f32(BT, C), dY2=f32(BT, HID),
             dY1=f32(BT, HID), DGI=f32(BT, 6 * HID), DGH=f32(BT, 6 * HID),
             zero=torch.zeros(BT * (2 * HID + 1), dtype=torch.float32, device=device),   # dR | dks, re-zeroed per layer
-            stats=f32(4),
+            stats=torch.zeros(256, dtype=torch.float32, device=device),
         )
         ws["dR"] = ws["zero"][:BT * 2 * HID].view(BT, 2 * HID)
         ws["dks"] = ws["zero"][BT * 2 * HID:]
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
-        ws["planner"] = GemmPlanner(device, slab)
+        ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
         self._ws[key] = ws
         return ws
@@ -204,7 +204,7 @@ class DAGERCModule(nn.Module):
         W0 = fp.w("out_mlp.0.weight")
         capi.gemm_f32(ws["dY1"], HID, 0, None, W0, self.in_dim, 1, None, ws["dHall"], W5, BT, W5, HID)
         slab = linear_wgrad(pl, ws["dY1"], HID, ws["Hall"], W5, None, HID, W5, BT, off["out_mlp.0.weight"], None,
-                            ld_w=self.in_dim)
+                            ld_w=self.in_dim, force_slab=x_bf16)
         linear_wgrad(pl, ws["dY1"], HID, x, D, None, HID, D, BT, None, off["out_mlp.0.bias"], x_bf16=x_bf16,
                      slab=slab, col_off=W5)
         for l in range(L - 1, -1, -1):
@@ -226,9 +226,7 @@ class DAGERCModule(nn.Module):
                          off["grus_c.%d.weight_hh" % l], off["grus_c.%d.bias_hh" % l])
             linear_wgrad(pl, ws["dR"], 2 * HID, H1, W5, None, 2 * HID, HID, BT, off["gather.%d.Wr0.weight" % l], None)
         linear_wgrad(pl, ws["dHall"], W5, x, D, None, HID, D, BT, off["fc1.weight"], off["fc1.bias"], x_bf16=x_bf16)
-        if ws["jobs"] is None or ws["jobs"].shape[0] != len(pl.jobs):
-            ws["jobs"] = pl.job_table()
-        capi.slab_reduce_batched(pl.ws, fp.grad, ws["jobs"], len(pl.jobs), pl.max_numel)
+        pl.reduce_into(ws, fp.grad)
         return ws["stats"]
 
 

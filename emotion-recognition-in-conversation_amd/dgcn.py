@@ -120,14 +120,14 @@ class DGCNModule(nn.Module):
         g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E),
                  in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
         ws = dict(g=g, E=E, rnn_out=f32(BT, G_DIM), Xc=f32(N, G_DIM + H1), ATT=f32(N, G_DIM), norm=f32(E),
-                  Z=f32(N, NB * G_DIM), Hc=f32(N, H1), AGG=f32(N, H1), Zc=f32(N, 100), logits=f32(N, C), stats=f32(4),
+                  Z=f32(N, NB * G_DIM), Hc=f32(N, H1), AGG=f32(N, H1), Zc=f32(N, 100), logits=f32(N, C), stats=torch.zeros(256, dtype=torch.float32, device=device),
                   dlogits=f32(N, C), dZc=f32(N, 100), dXc=f32(N, G_DIM + H1), dAGG=f32(N, H1), dHc=f32(N, H1),
                   dZ=f32(N, NB * G_DIM), dnorm=f32(E), TT=f32(E, NB), U=f32(N, NB * H1), basisT=f32(NB * H1, G_DIM),
                   DATT=f32(N, G_DIM), dscore=f32(E), drnn=f32(BT, G_DIM))
         D = self.input_size
         slab = 12 * N * H1 + 4 * BT * 800 + 10 * (800 * D + 800 * 200 + 2 * 400 * 100 * 2) + 4 * NB * G_DIM * H1 + \
             8 * (G_DIM * G_DIM + 300 * 100) + (1 << 21)
-        ws["planner"] = GemmPlanner(device, slab)
+        ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
         self._ws[key] = ws
         return ws
@@ -227,9 +227,7 @@ class DGCNModule(nn.Module):
         ws["drnn"].zero_()
         capi.gather_rows(dXc, XW, g["node_row"], N, G_DIM, ws["drnn"], G_DIM, scatter=1)
         self.lstm.backward(pl, ws["drnn"], G_DIM)
-        if ws["jobs"] is None or ws["jobs"].shape[0] != len(pl.jobs):
-            ws["jobs"] = pl.job_table()
-        capi.slab_reduce_batched(pl.ws, fp.grad, ws["jobs"], len(pl.jobs), pl.max_numel)
+        pl.reduce_into(ws, fp.grad)
         return ws["stats"]
 
 

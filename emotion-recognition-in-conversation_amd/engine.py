@@ -72,9 +72,10 @@ class GemmPlanner:
     BK = 32
     MAX_SPLIT = 64
 
-    def __init__(self, device, ws_floats):
+    def __init__(self, device, ws_floats, grad=None):
         self.device = device
         self.ws = torch.empty(ws_floats, dtype=torch.float32, device=device)
+        self.grad = grad      # flat gradient buffer: unsplit weight gradients are written there directly
         self.reset()
 
     def reset(self):
@@ -83,6 +84,8 @@ class GemmPlanner:
         self.max_numel = 0
 
     def split_for(self, M, N, K, bk=None, min_chunks=None):
+        if N <= 1025 and bk is None:
+            return 1   # skinny output: the register-streaming kernel splits K inside the workgroup, no slabs
         bk = bk or self.BK
         min_chunks = self.MIN_CHUNKS if min_chunks is None else min_chunks
         tiles = -(-N // 32) * -(-M // 64)
@@ -104,16 +107,22 @@ class GemmPlanner:
     def job_table(self):
         return torch.tensor(self.jobs, dtype=torch.int64, device=self.device)
 
+    def reduce_into(self, cache, grad):
+        """Run the batched slab reduce for the registered jobs (no-op when every gradient was written directly)."""
+        if not self.jobs:
+            return
+        if cache.get("jobs") is None or cache["jobs"].shape[0] != len(self.jobs):
+            cache["jobs"] = self.job_table()
+        capi.slab_reduce_batched(self.ws, grad, cache["jobs"], len(self.jobs), self.max_numel)
+
 
 def linear_fwd(pl, x, ldx, gather, W, bias, out, ldo, M, N, K, act=0, drop_p=0.0, rng=None, x_bf16=False, ldw=None):
     """out[M,N] (row pitch ldo) = act(x[M,K] @ W[N,K]^T + bias): nn.Linear forward.
     Split-K + slab reduce when K is long.  ``ldw`` = row pitch of W (column slice of a wider weight)."""
     ldw = K if ldw is None else ldw
     if x_bf16:
-        S = pl.split_for(M, N, K, bk=64, min_chunks=4)
-        src = pl.take(S * M * N)
-        capi.gemm_bf16x(x, ldx, 0, gather, W, ldw, 0, None, 1, pl.ws[src:], N, M, N, K, split_k=S, c_slab=M * N)
-        capi.slab_reduce(pl.ws[src:], S, M * N, bias, N, act, out, M * N, ld_out=0 if ldo == N else ldo)
+        assert act in (0, 1)
+        capi.gemm_bf16a_stream(x, ldx, gather, W, ldw, out, ldo, M, N, K, bias=bias, act=act)
         return
     S = pl.split_for(M, N, K)
     if S == 1:
@@ -127,18 +136,27 @@ def linear_fwd(pl, x, ldx, gather, W, bias, out, ldo, M, N, K, act=0, drop_p=0.0
 
 
 def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off, x_bf16=False,
-                 slab=None, col_off=0, ld_w=None):
-    """dW[n_out,n_in] = dy^T x and db[n_out] = colsum(dy) into slabs; registers the reduce jobs.
-    (nn.Linear weight layout [out,in].)  ``slab`` = (src_w, S, ld_w) lets several calls fill column slices
-    [col_off, col_off+n_in) of ONE wider gradient (concatenated inputs); only the call that passes
-    ``w_off`` registers the job."""
+                 slab=None, col_off=0, ld_w=None, force_slab=False):
+    """dW[n_out,n_in] = dy^T x and db[n_out] = colsum(dy)  (nn.Linear weight layout [out,in]).
+    Unsplit products are written straight into the flat gradient buffer; split ones go to partial slabs and
+    register a reduce job.  ``slab`` (the return value of a previous call) lets several calls fill column
+    slices [col_off, col_off+n_in) of ONE wider gradient (concatenated inputs)."""
     ld_w = n_in if ld_w is None else ld_w
+    want_b = b_off is not None
     if slab is None:
         S = pl.split_for(n_out, n_in + 1, n_rows, bk=64 if x_bf16 else None, min_chunks=2)
-        src_w = pl.take(S * n_out * ld_w)
-    else:
-        src_w, S, ld_w = slab
-    want_b = b_off is not None
+        direct = S == 1 and pl.grad is not None and not force_slab and not x_bf16
+        slab = ("direct", w_off, ld_w) if direct else (pl.take(S * n_out * ld_w), S, ld_w)
+        if not direct and w_off is not None:
+            pl.add_job(slab[0], n_out * ld_w, S, n_out * ld_w, w_off)
+    if slab[0] == "direct":
+        _, base, ld_w = slab
+        if x_bf16:
+            raise capi.ErcGraftError("bf16 column slice into a directly written gradient: pass force_slab=True")
+        capi.gemm_f32(dy, lddy, 1, None, x, ldx, 1, gather, pl.grad[base + col_off:], ld_w, n_out, n_in, n_rows,
+                      ones_col=1 if want_b else 0, bias_out=pl.grad[b_off:] if want_b else None)
+        return slab
+    src_w, S, ld_w = slab
     src_b = pl.take(S * n_out) if want_b else 0
     cbase = pl.ws[src_w + col_off:]
     if x_bf16:
@@ -149,17 +167,19 @@ def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off
         capi.gemm_f32(dy, lddy, 1, None, x, ldx, 1, gather, cbase, ld_w, n_out, n_in, n_rows,
                       split_k=S, c_slab=n_out * ld_w, ones_col=1 if want_b else 0,
                       bias_out=pl.ws[src_b:] if want_b else None, bias_slab=n_out)
-    if w_off is not None:
-        pl.add_job(src_w, n_out * ld_w, S, n_out * ld_w, w_off)
     if want_b:
         pl.add_job(src_b, n_out, S, n_out, b_off)
-    return src_w, S, ld_w
+    return slab
 
 
 def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off):
-    """dW[n_in,n_out] = x^T dy and db[n_out] = colsum(dy) for [in,out]-stored weights (PyG RGCNConv)."""
+    """dW[n_in,n_out] = x^T dy and db[n_out] = colsum(dy) for [in,out]-stored weights (PyG RGCNConv, GCNII)."""
     want_b = b_off is not None
     S = pl.split_for(n_in + 1, n_out, n_rows, min_chunks=2)
+    if S == 1 and pl.grad is not None:
+        capi.gemm_f32(x, ldx, 1, None, dy, lddy, 1, None, pl.grad[w_off:], n_out, n_in, n_out, n_rows,
+                      ones_col=2 if want_b else 0, bias_out=pl.grad[b_off:] if want_b else None)
+        return
     src_w = pl.take(S * n_in * n_out)
     src_b = pl.take(S * n_out) if want_b else 0
     capi.gemm_f32(x, ldx, 1, None, dy, lddy, 1, None, pl.ws[src_w:], n_out, n_in, n_out, n_rows,
@@ -179,13 +199,13 @@ class FusedAdam:
         self.weight_decay, self.decoupled, self.clip_norm = weight_decay, decoupled, clip_norm
         dev = flat.device
         # {step, rng offset, rng seed}
-        self.state = torch.tensor([0, 0, seed], dtype=torch.int64, device=dev)
+        self.state = torch.tensor([0, 0, seed, 0], dtype=torch.int64, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.norm_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
 
     @property
     def rng_state(self):
-        return self.state[1:]
+        return self.state[1:3]
 
     def step(self, grad_scale=1.0):
         f = self.flat
@@ -204,6 +224,51 @@ def all_reduce_grads(flat):
         dist.all_reduce(flat.grad)
         return 1.0 / dist.get_world_size()
     return 1.0
+
+
+class SideStream:
+    """Fork / join helper: weight-gradient GEMMs are off the critical path of the backward chain (nothing but the
+    optimizer consumes them), so they are enqueued on a second stream and overlap the next stages.  Works the same
+    eagerly and under HIP-graph capture (event fork/join becomes graph dependencies)."""
+
+    def __init__(self, enabled=None):
+        # measured on MI355X / ROCm 7.2: replayed HIP graphs run the forked branch no earlier than the main one
+        # (step 299 us forked vs 282 us in-line), so the fork is opt-in (ERC_SIDE_STREAM=1)
+        if enabled is None:
+            import os
+            enabled = os.environ.get("ERC_SIDE_STREAM", "0") == "1"
+        self.enabled = enabled and torch.cuda.is_available()
+        self.stream = torch.cuda.Stream() if self.enabled else None
+        self._dirty = False
+
+    def fork(self):
+        return _Fork(self)
+
+    def join(self):
+        if self.enabled and self._dirty:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._dirty = False
+
+
+class _Fork:
+    def __init__(self, side):
+        self.side = side
+
+    def __enter__(self):
+        if self.side.enabled:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.side.stream.wait_event(ev)
+            self.ctx = torch.cuda.stream(self.side.stream)
+            self.ctx.__enter__()
+            self.side._dirty = True
+
+    def __exit__(self, *exc):
+        if self.side.enabled:
+            self.ctx.__exit__(*exc)
+        return False
 
 
 class GraphedStep:

@@ -140,14 +140,14 @@ class MMGCNModule(nn.Module):
                   XH=f32(R3, FD), INV=f32(R3), COS=f32(B * Mo, P, P), ADJ=f32(B * Mo, P, P), CR=f32(B, Mo * Mo, P),
                   CCOS=f32(B, Mo * Mo, P), DEG=f32(R3), H0=f32(R3, FD), Gt=f32(R3, FD),
                   HI=f32(NLAYERS + 1, R3, FD), HD=f32(NLAYERS + 2, R3, FD), FE=f32(N, Mo * 2 * FD), logits=f32(N, C),
-                  stats=f32(4), dlogits=f32(N, C), dFE=f32(N, Mo * 2 * FD), dXD=f32(R3, FD), DH=f32(R3, FD),
+                  stats=torch.zeros(256, dtype=torch.float32, device=device), dlogits=f32(N, C), dFE=f32(N, Mo * 2 * FD), dXD=f32(R3, FD), DH=f32(R3, FD),
                   dG=f32(R3, FD), dHI=f32(R3, FD), dH0=f32(R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
                   Gb=f32(B * Mo, P, P), GC=f32(B, Mo * Mo, P), dXH=f32(R3, FD), dX=f32(R3, FD),
                   dLIN={m: f32(TB, FD) for m in self.order}, dLL=f32(TB, FD))
         dmax = max(self.dims[m] for m in self.order)
         slab = 4 * TB * 800 + 8 * (800 * FD + 2 * 400 * 100 * 2) + 8 * FD * dmax * 3 + NLAYERS * 2 * 8 * FD * FD + \
             8 * FD * FD + 8 * self.n_classes * Mo * 2 * FD + 8 * R3 * FD + (1 << 21)
-        ws["planner"] = GemmPlanner(device, slab)
+        ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["planner"].MAX_SPLIT = 8      # 128 weight-gradient GEMMs per step: keep their slab sets small
         ws["jobs"] = None
         self._ws[key] = ws
@@ -289,9 +289,7 @@ class MMGCNModule(nn.Module):
             x = feats[m].reshape(TB, self.dims[m])
             linear_wgrad(pl, dlin, FD, x, self.dims[m], None, FD, self.dims[m], TB, off[_LIN[m] + ".weight"],
                          off[_LIN[m] + ".bias"])
-        if ws["jobs"] is None or ws["jobs"].shape[0] != len(pl.jobs):
-            ws["jobs"] = pl.job_table()
-        capi.slab_reduce_batched(pl.ws, fp.grad, ws["jobs"], len(pl.jobs), pl.max_numel)
+        pl.reduce_into(ws, fp.grad)
         return ws["stats"]
 
 

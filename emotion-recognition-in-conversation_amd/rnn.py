@@ -76,7 +76,8 @@ class BiLSTM2:
                 xin, ldin, d_in, bf = x, ldx, self.d_in, x_bf16
             # W_ih (both directions stacked [800, d_in]) and b_ih; b_hh receives the same gradient
             src_w, S, _ = linear_wgrad(pl, ws["dGX"], 8 * H, xin, ldin, None, 8 * H, d_in, rows,
-                                       self._off("weight_ih_l%d" % k), self._off("bias_ih_l%d" % k), x_bf16=bf)
+                                       self._off("weight_ih_l%d" % k), self._off("bias_ih_l%d" % k), x_bf16=bf,
+                                       force_slab=True)
             src_b = pl.jobs[-1][0]
             pl.add_job(src_b, 8 * H, S, 8 * H, self._off("bias_hh_l%d" % k))
             # W_hh per direction: dGX[:, 400d:]^T Hprev[:, 100d:]

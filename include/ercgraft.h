@@ -105,6 +105,21 @@ int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t* a_gather,
                  const float* bias, int act, const float* aux, int ldaux, float act_scale,
                  float drop_p, const uint64_t* rng_state, int accumulate, void* stream);
 
+/* erc_gemm_f32 dispatches on the output width: N <= 512 runs the register-streaming kernel (16x32 tile per
+ * wavefront, fragments loaded straight from global memory, K split over the wavefronts of a workgroup), wider
+ * outputs the LDS-tiled kernel.  The streaming kernel is also exported under its own name (same contract). */
+int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_gather,
+                        const float* B, int ldb, int b_kmajor, const int32_t* b_gather,
+                        float* C, int ldc, int M, int N, int K,
+                        int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
+                        const float* bias, int act, const float* aux, int ldaux, float act_scale,
+                        float drop_p, const uint64_t* rng_state, int accumulate, void* stream);
+/* Forward input projection on a bf16 feature block: C[M,N] = act(X[gather(m), :K] W[N,K]^T + bias), X bf16,
+ * W fp32 rounded to bf16 while loaded, fp32 accumulate (v_mfma_f32_16x16x32_bf16); act 0 | 1 (relu).
+ * The HBM-dominant kernel of the COGMEN step (nn.Linear(D,100), track_mm/cogmen.py:103-105,147). */
+int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const float* W, int ldw, float* C, int ldc,
+                          int M, int N, int K, const float* bias, int act, void* stream);
+
 /* Same contract with bf16 operands for the big streamed operand (the padded
  * feature block): A or B given as bf16 (uint16 storage), the other operand is
  * converted from fp32 while staging; v_mfma_f32_16x16x32_bf16, fp32 accumulate.
@@ -191,7 +206,8 @@ int erc_bn_lrelu_bwd(const float* x, int ldx, int N, int F, const float* gamma, 
  *   row_map (int32 [n_rows] or NULL): logits row of sample i is row_map[i]
  *     (DAG-ERC keeps padded [B*T,C] logits; the mask becomes a row map)
  *   weight (float [C] or NULL): loss = sum w_y nll / sum w_y
- *   out: stats[0] = loss, stats[1] = #(argmax == y), stats[2] = sum of weights
+ *   out: stats[0] = loss, stats[1] = #(argmax == y), stats[2] = sum of weights; stats must hold >= 256
+ *   floats, zero-initialised once by the caller (per-workgroup partials + an arrival counter live there)
  *   dlogits (may be NULL): gradient, same row addressing as logits; rows that
  *     no sample maps to are NOT written (caller zero-fills when row_map != NULL)
  */
@@ -202,8 +218,8 @@ int erc_cross_entropy(const float* logits, int ld, int C, int n_rows, const int3
 /* ------------------------------------------------------------------------
  * S4  optimizer over the flat live-parameter buffer (torch.optim.Adam /
  * AdamW, track_mm/cogmen.py:50,187-189; dagerc.py:39,230-231).
- *   state: device int64 [3] = {step count, RNG offset, RNG seed}; the call
- *   increments state[0] and state[1] (so state+1 is a valid rng_state).
+ *   state: device int64 [4] = {step count, RNG offset, RNG seed, arrival counter (0 between calls)}; the
+ *   call increments state[0] and state[1] (so state+1 is a valid rng_state).
  *   clip_norm > 0: grads are scaled by min(1, clip_norm/(gnorm+1e-6)) where
  *   gnorm[0] was produced by erc_grad_norm (clip_grad_norm_ semantics).
  *   decoupled != 0 -> AdamW (p *= 1 - lr*wd) else L2 (g += wd*p).
@@ -212,6 +228,8 @@ int erc_cross_entropy(const float* logits, int ld, int C, int n_rows, const int3
 int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
                   float grad_scale, float clip_norm, const float* gnorm, int64_t* state, void* stream);
+/* diagnostic: out[0] = shader cycles, out[1] = 10-ns ticks of a fixed dependent-MFMA loop (bench.py --clock_probe) */
+int erc_clock_probe(uint64_t* out, int iters, void* stream);
 /* gnorm[0] = ||g * grad_scale||_2 ; ws >= 1024 floats */
 int erc_grad_norm(const float* g, int64_t n, float grad_scale, float* gnorm, float* ws, void* stream);
 

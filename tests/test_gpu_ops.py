@@ -387,7 +387,7 @@ def test_cross_entropy(capi, weighted, mapped):
     loss = torch.nn.functional.cross_entropy(sel, ys, weight=w)
     loss.backward()
     dl = torch.zeros(rows, C, device=DEV)
-    stats = torch.zeros(4, device=DEV)
+    stats = torch.zeros(256, device=DEV)
     capi.cross_entropy(logits.detach().to(DEV), C, C, n, row_map.to(DEV) if mapped else None, ys.to(DEV),
                        w.to(DEV) if weighted else None, 1.0, dl, C, stats)
     s = stats.cpu()
@@ -405,7 +405,7 @@ def test_fused_adam_matches_torch(capi, decoupled, wd, clip):
     opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref], lr=1e-3, weight_decay=wd)
     p = p0.clone().to(DEV)
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    state = torch.tensor([0, 0, 1], dtype=torch.int64, device=DEV)
+    state = torch.tensor([0, 0, 1, 0], dtype=torch.int64, device=DEV)
     gnorm, ws = torch.zeros(1, device=DEV), torch.zeros(1024, device=DEV)
     for it in range(4):
         g = torch.randn(n) * (0.01 if it % 2 else 1.0)
@@ -419,4 +419,4 @@ def test_fused_adam_matches_torch(capi, decoupled, wd, clip):
             assert abs(float(gnorm) - float(g.norm())) < 1e-4 * float(g.norm())
         capi.adam_step(p, gd, m, v, n, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, 1.0, clip, gnorm if clip > 0 else None, state)
         _close(p, ref.detach(), 2e-6, 1e-5)
-    assert state.cpu().tolist() == [4, 4, 1]
+    assert state.cpu().tolist() == [4, 4, 1, 0]
