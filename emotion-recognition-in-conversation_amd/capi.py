@@ -25,6 +25,7 @@ _SIGS = {
     "erc_gemm_f32_stream": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp, _i64,
                                       _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
     "erc_gemm_bf16a_stream": (C.c_int, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "erc_wgrad_table": (C.c_int, [_vp, _i, _i, _i, _vp]),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
                                  _i64, _vp]),
     "erc_slab_reduce": (C.c_int, [_vp, _i, _i64, _vp, _i, _i, _vp, _i, _i64, _vp]),
@@ -381,3 +382,7 @@ def axpy_mask(x, mask, n, scale, accumulate, y):
 
 def clock_probe(out, iters):
     _call("erc_clock_probe", out, iters)
+
+
+def wgrad_table(table, n, max_m, max_n):
+    _call("erc_wgrad_table", table, n, max_m, max_n)

@@ -209,11 +209,11 @@ class COGMENModule(nn.Module):
                       act=2, aux=ws["Z"], ldaux=F, act_scale=1.0 / (1.0 - p))
         with self.side.fork():
             linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
-                         fp.offsets["cls.3.bias"])
+                         fp.offsets["cls.3.bias"], defer=True)
         capi.gemm_f32(ws["dZ"], F, 0, None, fp.w("cls.0.weight"), F, 1, None, ws["dH3"], F, N, F, F)
         with self.side.fork():
             linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
-                         fp.offsets["cls.0.bias"])
+                         fp.offsets["cls.0.bias"], defer=True)
         # BatchNorm + LeakyReLU
         capi.bn_lrelu_bwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
                           ws["dH3"], F, ws["dH2"], F, fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"), ws["bn_ws"])
@@ -224,17 +224,17 @@ class COGMENModule(nn.Module):
                       N, F, 4 * F)
         with self.side.fork():
             linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1"], F, None, 4 * F, F, N,
-                         fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"])
+                         fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"], defer=True)
         # RGCN: dM = dH1 @ Wcat^T ; dWcat = M^T dH1 ; dbias = colsum(dH1)
         capi.gemm_f32(ws["dH1"], F, 0, None, fp.w("gcn.conv1.weight"), F, 0, None, ws["dM"], 9 * F, N, 9 * F, F)
         with self.side.fork():
             matmul_wgrad_io(pl, ws["M"], 9 * F, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
-                            fp.offsets["gcn.conv1.bias"])
+                            fp.offsets["gcn.conv1.bias"], defer=True)
         capi.rgcn_mean_bwd(ws["dM"], 9 * F, F, N_REL, N, g, ws["inv_cnt"], ws["dH0"], F)
         # input projection (no gradient into the features)
         with self.side.fork():
             linear_wgrad(pl, ws["dH0"], F, x, D, g["node_row"], F, D, N, fp.offsets["rnn.1.weight"],
-                         fp.offsets["rnn.1.bias"], x_bf16=x_bf16)
+                         fp.offsets["rnn.1.bias"], x_bf16=x_bf16, defer=True)
         self.side.join()
         pl.reduce_into(ws, fp.grad)
         return ws["stats"]

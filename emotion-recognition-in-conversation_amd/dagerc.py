@@ -98,12 +98,13 @@ class DAGERCModule(nn.Module):
             Mseq=[f32(BT, HID) for _ in range(L)], R=[f32(BT, 2 * HID) for _ in range(L)],
             ks=[f32(BT) for _ in range(L)], alpha=[f32(B, T, T) for _ in range(L)],
             Y1=f32(BT, HID), Y2=f32(BT, HID), logits=f32(BT, C), dlogits=f32(BT, C), dY2=f32(BT, HID),
-            dY1=f32(BT, HID), DGI=f32(BT, 6 * HID), DGH=f32(BT, 6 * HID),
-            zero=torch.zeros(BT * (2 * HID + 1), dtype=torch.float32, device=device),   # dR | dks, re-zeroed per layer
+            dY1=f32(BT, HID), DGI=[f32(BT, 6 * HID) for _ in range(L)], DGH=[f32(BT, 6 * HID) for _ in range(L)],
+            # dR | dks per layer (kept until the batched weight-gradient launch at the end of the step)
+            zero=torch.zeros(L, BT * (2 * HID + 1), dtype=torch.float32, device=device),
             stats=torch.zeros(256, dtype=torch.float32, device=device),
         )
-        ws["dR"] = ws["zero"][:BT * 2 * HID].view(BT, 2 * HID)
-        ws["dks"] = ws["zero"][BT * 2 * HID:]
+        ws["dR"] = [ws["zero"][l, :BT * 2 * HID].view(BT, 2 * HID) for l in range(L)]
+        ws["dks"] = [ws["zero"][l, BT * 2 * HID:] for l in range(L)]
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
@@ -195,11 +196,11 @@ class DAGERCModule(nn.Module):
         capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("out_mlp.5.weight"), HID, 1, None, ws["dY2"], HID, BT, HID, C,
                       act=2, aux=ws["Y2"], ldaux=HID, act_scale=1.0 / (1.0 - p))
         linear_wgrad(pl, ws["dlogits"], C, ws["Y2"], HID, None, C, HID, BT, off["out_mlp.5.weight"],
-                     off["out_mlp.5.bias"])
+                     off["out_mlp.5.bias"], defer=True)
         capi.gemm_f32(ws["dY2"], HID, 0, None, fp.w("out_mlp.2.weight"), HID, 1, None, ws["dY1"], HID, BT, HID, HID,
                       act=2, aux=ws["Y1"], ldaux=HID, act_scale=1.0)
         linear_wgrad(pl, ws["dY2"], HID, ws["Y1"], HID, None, HID, HID, BT, off["out_mlp.2.weight"],
-                     off["out_mlp.2.bias"])
+                     off["out_mlp.2.bias"], defer=True)
         # dHall = dY1 W0[:, :1500]; dW0 = dY1^T [Hall | x] as two column slices of one slab set
         W0 = fp.w("out_mlp.0.weight")
         capi.gemm_f32(ws["dY1"], HID, 0, None, W0, self.in_dim, 1, None, ws["dHall"], W5, BT, W5, HID)
@@ -207,24 +208,24 @@ class DAGERCModule(nn.Module):
                             ld_w=self.in_dim, force_slab=x_bf16)
         linear_wgrad(pl, ws["dY1"], HID, x, D, None, HID, D, BT, None, off["out_mlp.0.bias"], x_bf16=x_bf16,
                      slab=slab, col_off=W5)
+        ws["zero"].zero_()
         for l in range(L - 1, -1, -1):
             w = self._layer_w(l)
             Hl, H1 = ws["Hall"][:, HID * l:], ws["Hall"][:, HID * (l + 1):]
             dHl, dH1 = ws["dHall"][:, HID * l:], ws["dHall"][:, HID * (l + 1):]
-            ws["zero"].zero_()
             dlin = pl.take(B * (2 * HID + 1))
             capi.dag_scan_bwd(Hl, W5, ws["GI"][l], ws["GH"][l], ws["Mseq"][l], ws["R"][l], ws["alpha"][l], H1, W5,
                               w["W_hh_c"], w["W_ih_p"], w["Wr"], w["w_lin"], ws["pred"], ws["spk"], B, T, dH1, W5,
-                              dHl, W5, ws["DGI"], ws["DGH"], ws["dR"], ws["dks"], pl.ws[dlin:])
+                              dHl, W5, ws["DGI"][l], ws["DGH"][l], ws["dR"][l], ws["dks"][l], pl.ws[dlin:])
             pl.add_job(dlin, 2 * HID + 1, B, 2 * HID + 1, off["gather.%d.linear.weight" % l])
             # dH_l += DGI [W_ih_c ; W_hh_p]; on layer 0 the same launch applies the relu mask of fc1
-            capi.gemm_f32(ws["DGI"], 6 * HID, 0, None, w["Whoist"], HID, 1, None, dHl, W5, BT, HID, 6 * HID,
+            capi.gemm_f32(ws["DGI"][l], 6 * HID, 0, None, w["Whoist"], HID, 1, None, dHl, W5, BT, HID, 6 * HID,
                           accumulate=1, act=2 if l == 0 else 0, aux=Hl if l == 0 else None, ldaux=W5, act_scale=1.0)
-            linear_wgrad(pl, ws["DGI"], 6 * HID, Hl, W5, None, 6 * HID, HID, BT, off["grus_c.%d.weight_ih" % l],
-                         off["grus_c.%d.bias_ih" % l])
-            linear_wgrad(pl, ws["DGH"], 6 * HID, ws["Mseq"][l], HID, None, 6 * HID, HID, BT,
-                         off["grus_c.%d.weight_hh" % l], off["grus_c.%d.bias_hh" % l])
-            linear_wgrad(pl, ws["dR"], 2 * HID, H1, W5, None, 2 * HID, HID, BT, off["gather.%d.Wr0.weight" % l], None)
+            linear_wgrad(pl, ws["DGI"][l], 6 * HID, Hl, W5, None, 6 * HID, HID, BT, off["grus_c.%d.weight_ih" % l],
+                         off["grus_c.%d.bias_ih" % l], defer=True)
+            linear_wgrad(pl, ws["DGH"][l], 6 * HID, ws["Mseq"][l], HID, None, 6 * HID, HID, BT,
+                         off["grus_c.%d.weight_hh" % l], off["grus_c.%d.bias_hh" % l], defer=True)
+            linear_wgrad(pl, ws["dR"][l], 2 * HID, H1, W5, None, 2 * HID, HID, BT, off["gather.%d.Wr0.weight" % l], None, defer=True)
         linear_wgrad(pl, ws["dHall"], W5, x, D, None, HID, D, BT, off["fc1.weight"], off["fc1.bias"], x_bf16=x_bf16)
         pl.reduce_into(ws, fp.grad)
         return ws["stats"]

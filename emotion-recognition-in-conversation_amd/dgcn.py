@@ -195,15 +195,15 @@ class DGCNModule(nn.Module):
         # classifier
         capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("clf.lin2.weight"), 100, 1, None, ws["dZc"], 100, N, 100, C,
                       act=2, aux=ws["Zc"], ldaux=100, act_scale=1.0 / (1.0 - p))
-        linear_wgrad(pl, ws["dlogits"], C, ws["Zc"], 100, None, C, 100, N, off["clf.lin2.weight"], off["clf.lin2.bias"])
+        linear_wgrad(pl, ws["dlogits"], C, ws["Zc"], 100, None, C, 100, N, off["clf.lin2.weight"], off["clf.lin2.bias"], defer=True)
         capi.gemm_f32(ws["dZc"], 100, 0, None, fp.w("clf.lin1.weight"), XW, 1, None, dXc, XW, N, XW, 100)
-        linear_wgrad(pl, ws["dZc"], 100, Xc, XW, None, 100, XW, N, off["clf.lin1.weight"], off["clf.lin1.bias"])
+        linear_wgrad(pl, ws["dZc"], 100, Xc, XW, None, 100, XW, N, off["clf.lin1.weight"], off["clf.lin1.bias"], defer=True)
         # GraphConv
         dG = dXc[:, G_DIM:]
         capi.gemm_f32(dG, XW, 0, None, fp.w("gcn.conv2.lin_rel.weight"), H1, 1, None, ws["dAGG"], H1, N, H1, H1)
         linear_wgrad(pl, dG, XW, ws["AGG"], H1, None, H1, H1, N, off["gcn.conv2.lin_rel.weight"],
-                     off["gcn.conv2.lin_rel.bias"])
-        linear_wgrad(pl, dG, XW, ws["Hc"], H1, None, H1, H1, N, off["gcn.conv2.lin_root.weight"], None)
+                     off["gcn.conv2.lin_rel.bias"], defer=True)
+        linear_wgrad(pl, dG, XW, ws["Hc"], H1, None, H1, H1, N, off["gcn.conv2.lin_root.weight"], None, defer=True)
         capi.gemm_f32(dG, XW, 0, None, fp.w("gcn.conv2.lin_root.weight"), H1, 1, None, ws["dHc"], H1, N, H1, H1)
         capi.csr_sum(ws["dAGG"], H1, H1, N, g["out_ptr"], g["out_dst"], ws["dHc"], H1, accumulate=1)
         # RGCNConv(basis)
@@ -211,8 +211,8 @@ class DGCNModule(nn.Module):
         capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.basis"), H1, 0, None, ws["dZ"], K1, N, K1, H1)
         capi.brgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["dZ"], ws["dnorm"],
                              ws["TT"], fp.g("gcn.conv1.att"))
-        matmul_wgrad_io(pl, ws["Z"], K1, ws["dHc"], H1, K1, H1, N, off["gcn.conv1.basis"], off["gcn.conv1.bias"])
-        matmul_wgrad_io(pl, Xc, XW, ws["dHc"], H1, G_DIM, H1, N, off["gcn.conv1.root"], None)
+        matmul_wgrad_io(pl, ws["Z"], K1, ws["dHc"], H1, K1, H1, N, off["gcn.conv1.basis"], off["gcn.conv1.bias"], defer=True)
+        matmul_wgrad_io(pl, Xc, XW, ws["dHc"], H1, G_DIM, H1, N, off["gcn.conv1.root"], None, defer=True)
         capi.brgcn_bwd_source(ws["dHc"], H1, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["U"])
         capi.transpose_batched(fp.w("gcn.conv1.basis"), NB, G_DIM, H1, ws["basisT"])
         capi.gemm_f32(ws["U"], NB * H1, 0, None, ws["basisT"], G_DIM, 1, None, dXc, XW, N, G_DIM, NB * H1, accumulate=1)
@@ -220,7 +220,7 @@ class DGCNModule(nn.Module):
         # EdgeAtt
         capi.edge_att_bwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"], ws["dnorm"], dXc, XW, 1, ws["DATT"], G_DIM,
                           ws["dscore"])
-        linear_wgrad(pl, ws["DATT"], G_DIM, Xc, XW, None, G_DIM, G_DIM, N, off["edge_att.weight"], None)
+        linear_wgrad(pl, ws["DATT"], G_DIM, Xc, XW, None, G_DIM, G_DIM, N, off["edge_att.weight"], None, defer=True)
         capi.gemm_f32(ws["DATT"], G_DIM, 0, None, fp.w("edge_att.weight"), G_DIM, 1, None, dXc, XW, N, G_DIM, G_DIM,
                       accumulate=1)
         # back to the padded rows and through the BiLSTM

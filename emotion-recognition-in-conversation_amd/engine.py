@@ -82,6 +82,28 @@ class GemmPlanner:
         self.cursor = 0
         self.jobs = []
         self.max_numel = 0
+        self.deferred = []     # (A, lda, B, ldb, C, ldc, M, N, K, ones, bias_out): one batched launch at the end
+
+    def defer(self, A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out):
+        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out))
+
+    def flush_wgrads(self, cache):
+        """Run every deferred K-major x K-major weight-gradient product as ONE launch (erc_wgrad_table).  The
+        descriptor table is built on the first call and reused (operands live in fixed workspace buffers)."""
+        if not self.deferred:
+            return
+        import struct
+        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K) for a, _, b, _, c, _, M, N, K, _, _ in self.deferred)
+        if cache.get("wgrad_key") != key:
+            raw = b"".join(struct.pack("<QQQQiiiiiiii", a.data_ptr(), b.data_ptr(), c.data_ptr(),
+                                       bo.data_ptr() if bo is not None else 0, lda, ldb, ldc, M, N, K, ones, 0)
+                           for a, lda, b, ldb, c, ldc, M, N, K, ones, bo in self.deferred)
+            cache["wgrad_table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            cache["wgrad_key"] = key
+            cache["wgrad_max"] = (max(M + (1 if o == 2 else 0) for _, _, _, _, _, _, M, _, _, o, _ in self.deferred),
+                                  max(N + (1 if o == 1 else 0) for _, _, _, _, _, _, _, N, _, o, _ in self.deferred))
+        mm, mn = cache["wgrad_max"]
+        capi.wgrad_table(cache["wgrad_table"], len(self.deferred), mm, mn)
 
     def split_for(self, M, N, K, bk=None, min_chunks=None):
         if N <= 1025 and bk is None:
@@ -108,7 +130,9 @@ class GemmPlanner:
         return torch.tensor(self.jobs, dtype=torch.int64, device=self.device)
 
     def reduce_into(self, cache, grad):
-        """Run the batched slab reduce for the registered jobs (no-op when every gradient was written directly)."""
+        """Flush the deferred weight gradients, then run the batched slab reduce for the registered jobs (no-op
+        when every gradient was written directly)."""
+        self.flush_wgrads(cache)
         if not self.jobs:
             return
         if cache.get("jobs") is None or cache["jobs"].shape[0] != len(self.jobs):
@@ -136,11 +160,12 @@ def linear_fwd(pl, x, ldx, gather, W, bias, out, ldo, M, N, K, act=0, drop_p=0.0
 
 
 def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off, x_bf16=False,
-                 slab=None, col_off=0, ld_w=None, force_slab=False):
+                 slab=None, col_off=0, ld_w=None, force_slab=False, defer=False):
     """dW[n_out,n_in] = dy^T x and db[n_out] = colsum(dy)  (nn.Linear weight layout [out,in]).
     Unsplit products are written straight into the flat gradient buffer; split ones go to partial slabs and
     register a reduce job.  ``slab`` (the return value of a previous call) lets several calls fill column
-    slices [col_off, col_off+n_in) of ONE wider gradient (concatenated inputs)."""
+    slices [col_off, col_off+n_in) of ONE wider gradient (concatenated inputs).  ``defer``: postpone the product to
+    the planner's batched launch (only legal when dy and x are not overwritten before GemmPlanner.flush_wgrads)."""
     ld_w = n_in if ld_w is None else ld_w
     want_b = b_off is not None
     if slab is None:
@@ -153,8 +178,12 @@ def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off
         _, base, ld_w = slab
         if x_bf16:
             raise capi.ErcGraftError("bf16 column slice into a directly written gradient: pass force_slab=True")
-        capi.gemm_f32(dy, lddy, 1, None, x, ldx, 1, gather, pl.grad[base + col_off:], ld_w, n_out, n_in, n_rows,
-                      ones_col=1 if want_b else 0, bias_out=pl.grad[b_off:] if want_b else None)
+        if gather is None and defer:
+            pl.defer(dy, lddy, x, ldx, pl.grad[base + col_off:], ld_w, n_out, n_in, n_rows, 1 if want_b else 0,
+                     pl.grad[b_off:] if want_b else None)
+        else:
+            capi.gemm_f32(dy, lddy, 1, None, x, ldx, 1, gather, pl.grad[base + col_off:], ld_w, n_out, n_in, n_rows,
+                          ones_col=1 if want_b else 0, bias_out=pl.grad[b_off:] if want_b else None)
         return slab
     src_w, S, ld_w = slab
     src_b = pl.take(S * n_out) if want_b else 0
@@ -172,13 +201,17 @@ def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off
     return slab
 
 
-def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off):
+def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off, defer=False):
     """dW[n_in,n_out] = x^T dy and db[n_out] = colsum(dy) for [in,out]-stored weights (PyG RGCNConv, GCNII)."""
     want_b = b_off is not None
     S = pl.split_for(n_in + 1, n_out, n_rows, min_chunks=2)
     if S == 1 and pl.grad is not None:
-        capi.gemm_f32(x, ldx, 1, None, dy, lddy, 1, None, pl.grad[w_off:], n_out, n_in, n_out, n_rows,
-                      ones_col=2 if want_b else 0, bias_out=pl.grad[b_off:] if want_b else None)
+        if defer:
+            pl.defer(x, ldx, dy, lddy, pl.grad[w_off:], n_out, n_in, n_out, n_rows, 2 if want_b else 0,
+                     pl.grad[b_off:] if want_b else None)
+        else:
+            capi.gemm_f32(x, ldx, 1, None, dy, lddy, 1, None, pl.grad[w_off:], n_out, n_in, n_out, n_rows,
+                          ones_col=2 if want_b else 0, bias_out=pl.grad[b_off:] if want_b else None)
         return
     src_w = pl.take(S * n_in * n_out)
     src_b = pl.take(S * n_out) if want_b else 0

@@ -141,7 +141,7 @@ class MMGCNModule(nn.Module):
                   CCOS=f32(B, Mo * Mo, P), DEG=f32(R3), H0=f32(R3, FD), Gt=f32(R3, FD),
                   HI=f32(NLAYERS + 1, R3, FD), HD=f32(NLAYERS + 2, R3, FD), FE=f32(N, Mo * 2 * FD), logits=f32(N, C),
                   stats=torch.zeros(256, dtype=torch.float32, device=device), dlogits=f32(N, C), dFE=f32(N, Mo * 2 * FD), dXD=f32(R3, FD), DH=f32(R3, FD),
-                  dG=f32(R3, FD), dHI=f32(R3, FD), dH0=f32(R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
+                  dG=f32(NLAYERS + 1, R3, FD), dHI=f32(R3, FD), dH0=f32(R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
                   Gb=f32(B * Mo, P, P), GC=f32(B, Mo * Mo, P), dXH=f32(R3, FD), dX=f32(R3, FD),
                   dLIN={m: f32(TB, FD) for m in self.order}, dLL=f32(TB, FD))
         dmax = max(self.dims[m] for m in self.order)
@@ -246,27 +246,30 @@ class MMGCNModule(nn.Module):
         capi.cross_entropy(ws["logits"], C, C, N, None, ys, None, 1.0, ws["dlogits"], C, ws["stats"])
         FW = Mo * 2 * FD
         capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("smax_fc.weight"), FW, 1, None, ws["dFE"], FW, N, FW, C)
-        linear_wgrad(pl, ws["dlogits"], C, ws["FE"], FW, None, C, FW, N, off["smax_fc.weight"], off["smax_fc.bias"])
+        linear_wgrad(pl, ws["dlogits"], C, ws["FE"], FW, None, C, FW, N, off["smax_fc.weight"], off["smax_fc.bias"],
+                     defer=True)
         DH = ws["DH"]
         capi.mm_regroup_bwd(ws["dFE"], ws["FE"], Mo, N, ks, ws["dXD"], DH)
         ws["dH0"].zero_(), ws["dADJ"].zero_(), ws["dCR"].zero_()
         for l in range(NLAYERS, 0, -1):
             Wn = gn + "convs.%d.weight" % (l - 1)
             W = fp.w(Wn)
-            capi.gcnii_combine_bwd(DH, HD[l + 1], n_el, self.theta(l), ALPHA, ks, 0, ws["dG"], ws["dHI"], ws["dH0"])
-            capi.gemm_f32(ws["dG"], FD, 0, None, W, FD, 0, None, ws["dHI"], FD, R3, FD, FD, accumulate=1)
-            capi.gemm_f32(ws["dG"], FD, 0, None, W[FD:], FD, 0, None, ws["dH0"], FD, R3, FD, FD, accumulate=1)
-            matmul_wgrad_io(pl, HI[l], FD, ws["dG"], FD, FD, FD, R3, off[Wn], None)
-            matmul_wgrad_io(pl, ws["H0"], FD, ws["dG"], FD, FD, FD, R3, off[Wn] + FD * FD, None)
+            dG = ws["dG"][l]     # kept per layer: the 128 weight-gradient products run as one launch at the end
+            capi.gcnii_combine_bwd(DH, HD[l + 1], n_el, self.theta(l), ALPHA, ks, 0, dG, ws["dHI"], ws["dH0"])
+            capi.gemm_f32(dG, FD, 0, None, W, FD, 0, None, ws["dHI"], FD, R3, FD, FD, accumulate=1)
+            capi.gemm_f32(dG, FD, 0, None, W[FD:], FD, 0, None, ws["dH0"], FD, R3, FD, FD, accumulate=1)
+            matmul_wgrad_io(pl, HI[l], FD, dG, FD, FD, FD, R3, off[Wn], None, defer=True)
+            matmul_wgrad_io(pl, ws["H0"], FD, dG, FD, FD, FD, R3, off[Wn] + FD * FD, None, defer=True)
             capi.gemm_grouped(1, ws["dHI"], FD, HD[l], FD, ws["dADJ"], P, FD, ws["node_off"], B, Mo, N, T, P, accumulate=1)
             capi.mm_cross_grad(ws["dHI"], FD, HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"])
             capi.gemm_grouped(0, ws["ADJ"], P, ws["dHI"], FD, DH, FD, FD, ws["node_off"], B, Mo, N, T, P)
             capi.mm_cross_apply(ws["CR"], ws["dHI"], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, DH, FD)
         # input layer: HD[1] = dropout(H0), H0 = relu(fc0(XD))
         capi.axpy_mask(DH, HD[1] if p > 0 else None, n_el, ks, 1, ws["dH0"])
-        capi.gcnii_combine_bwd(ws["dH0"], ws["H0"], n_el, 0.0, 0.0, 1.0, 1, ws["dG"], None, None)
-        capi.gemm_f32(ws["dG"], FD, 0, None, fp.w(gn + "fcs.0.weight"), FD, 1, None, ws["dXD"], FD, R3, FD, FD, accumulate=1)
-        linear_wgrad(pl, ws["dG"], FD, XD, FD, None, FD, FD, R3, off[gn + "fcs.0.weight"], off[gn + "fcs.0.bias"])
+        dG0 = ws["dG"][0]
+        capi.gcnii_combine_bwd(ws["dH0"], ws["H0"], n_el, 0.0, 0.0, 1.0, 1, dG0, None, None)
+        capi.gemm_f32(dG0, FD, 0, None, fp.w(gn + "fcs.0.weight"), FD, 1, None, ws["dXD"], FD, R3, FD, FD, accumulate=1)
+        linear_wgrad(pl, dG0, FD, XD, FD, None, FD, FD, R3, off[gn + "fcs.0.weight"], off[gn + "fcs.0.bias"], defer=True)
         dX = ws["dX"]
         capi.axpy_mask(ws["dXD"], XD if p > 0 else None, n_el, ks, 0, dX)
         # through the adjacency into the features

@@ -114,6 +114,13 @@ int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_
                         int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
                         const float* bias, int act, const float* aux, int ldaux, float act_scale,
                         float drop_p, const uint64_t* rng_state, int accumulate, void* stream);
+/* Batched weight gradients: n independent products C_i[M_i,N_i] = A_i^T B_i (A_i [K,M_i], B_i [K,N_i], both
+ * K-major fp32, same contract as erc_gemm_f32 with a_kmajor = b_kmajor = 1 and the ones_col bias trick) in ONE
+ * launch.  `table` is a device array of n 64-byte records
+ *   { const float* A, B; float* C, bias_out; int32 lda, ldb, ldc, M, N, K, ones, pad; }
+ * max_m / max_n = largest M_i (+1 if ones = 2) / N_i (+1 if ones = 1). */
+int erc_wgrad_table(const void* table, int n_problems, int max_m, int max_n, void* stream);
+
 /* Forward input projection on a bf16 feature block: C[M,N] = act(X[gather(m), :K] W[N,K]^T + bias), X bf16,
  * W fp32 rounded to bf16 while loaded, fp32 accumulate (v_mfma_f32_16x16x32_bf16); act 0 | 1 (relu).
  * The HBM-dominant kernel of the COGMEN step (nn.Linear(D,100), track_mm/cogmen.py:103-105,147). */
