@@ -33,27 +33,42 @@ constexpr int MAX_T = 512;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// out[r] = W[r,:] . v (+ bias[r]) for r in [0,rows): one wavefront per row, rows strided over the 16 waves.
-// W row-major [rows, HID]; v in LDS.
+// Row layout of a [rows, 300] fp32 matrix for one wavefront: lane l owns the float4 at columns 4l..4l+3
+// (256 floats) and lanes 0..10 additionally the float4 at 256+4l (the remaining 44): two 16-byte loads per row.
+// All loads are unconditional (clamped addresses, zero multipliers) so that a batch of RB rows is in flight
+// before the first reduction -- the weights (2.9 MB per layer) are streamed from L2 every step and the scan is
+// bound by how many of those loads are outstanding.
+constexpr int RB = 8;
+
+struct Vec300 {
+    float4 lo, hi;  // hi is zero for lanes >= 11
+};
+__device__ __forceinline__ Vec300 load_vec300(const float* v_lds, int lane) {
+    Vec300 r;
+    r.lo = *reinterpret_cast<const float4*>(v_lds + 4 * lane);
+    const float4 h = *reinterpret_cast<const float4*>(v_lds + 256 + 4 * min(lane, 10));
+    const float m = lane < 11 ? 1.f : 0.f;
+    r.hi = make_float4(h.x * m, h.y * m, h.z * m, h.w * m);
+    return r;
+}
+__device__ __forceinline__ float dot300(const float* __restrict__ wrow, const Vec300& v, int lane) {
+    const float4 a = *reinterpret_cast<const float4*>(wrow + 4 * lane);
+    const float4 b = *reinterpret_cast<const float4*>(wrow + 256 + 4 * min(lane, 10));
+    return a.x * v.lo.x + a.y * v.lo.y + a.z * v.lo.z + a.w * v.lo.w + b.x * v.hi.x + b.y * v.hi.y + b.z * v.hi.z +
+           b.w * v.hi.w;
+}
+
+// out[r] = W[r,:] . v (+ bias[r]) for r in [0,rows): one wavefront per row, rows strided over the 16 waves,
+// RB rows per batch.  W row-major [rows, HID]; v in LDS (16-byte aligned).
 __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const float* __restrict__ bias, int rows,
                                             const float* v_lds, float* out_lds, float* out_glb, int lane, int wave) {
-    const float v0 = v_lds[lane], v1 = v_lds[lane + 64], v2 = v_lds[lane + 128], v3 = v_lds[lane + 192];
-    const float v4 = lane + 256 < HID ? v_lds[lane + 256] : 0.f;
-    for (int r0 = wave; r0 < rows; r0 += 4 * NW) {
-        float acc[4];
+    const Vec300 v = load_vec300(v_lds, lane);
+    for (int r0 = wave; r0 < rows; r0 += RB * NW) {
+        float acc[RB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + u * NW;
-            float a = 0.f;
-            if (r < rows) {
-                const float* w = W + (int64_t)r * HID;
-                a = w[lane] * v0 + w[lane + 64] * v1 + w[lane + 128] * v2 + w[lane + 192] * v3;
-                if (lane + 256 < HID) a += w[lane + 256] * v4;
-            }
-            acc[u] = a;
-        }
+        for (int u = 0; u < RB; ++u) acc[u] = dot300(W + (int64_t)min(r0 + u * NW, rows - 1) * HID, v, lane);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < RB; ++u) {
             const int r = r0 + u * NW;
             const float s = wave_sum(acc[u]);
             if (r < rows && lane == 0) {
@@ -65,18 +80,31 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
     }
 }
 
-// part[wave][k] += sum_{r owned by wave} W[r,k] * d[r]  (transposed product), d in LDS
-__device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, int rows, const float* d_lds, float acc[5],
+// acc += sum_{r owned by wave} W[r,:] * d[r]  (transposed product); acc is this lane's slice in the Vec300 layout
+__device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, int rows, const float* d_lds, Vec300& acc,
                                                int lane, int wave) {
-    for (int r = wave; r < rows; r += NW) {
-        const float d = d_lds[r];
-        const float* w = W + (int64_t)r * HID;
-        acc[0] += w[lane] * d;
-        acc[1] += w[lane + 64] * d;
-        acc[2] += w[lane + 128] * d;
-        acc[3] += w[lane + 192] * d;
-        if (lane + 256 < HID) acc[4] += w[lane + 256] * d;
+    for (int r0 = wave; r0 < rows; r0 += RB * NW) {
+        float4 a[RB], b[RB];
+        float d[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int r = min(r0 + u * NW, rows - 1);
+            const float* w = W + (int64_t)r * HID;
+            a[u] = *reinterpret_cast<const float4*>(w + 4 * lane);
+            b[u] = *reinterpret_cast<const float4*>(w + 256 + 4 * min(lane, 10));
+            d[u] = (r0 + u * NW < rows) ? d_lds[r] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            acc.lo.x += a[u].x * d[u], acc.lo.y += a[u].y * d[u], acc.lo.z += a[u].z * d[u], acc.lo.w += a[u].w * d[u];
+            acc.hi.x += b[u].x * d[u], acc.hi.y += b[u].y * d[u], acc.hi.z += b[u].z * d[u], acc.hi.w += b[u].w * d[u];
+        }
     }
+}
+// store a lane's Vec300 slice into part[wave][0..299]
+__device__ __forceinline__ void store_vec300(float* dst, const Vec300& v, int lane) {
+    *reinterpret_cast<float4*>(dst + 4 * lane) = v.lo;
+    if (lane < 11) *reinterpret_cast<float4*>(dst + 256 + 4 * lane) = v.hi;
 }
 
 // ----------------------------------------------------------------------------- meta
@@ -142,7 +170,7 @@ struct DagFwd {
 __global__ __launch_bounds__(NT) void dag_scan_fwd_kernel(DagFwd p) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T;
-    __shared__ float v_m[320], v_h[320], v_x[320], gates[2 * G3], s_alpha[MAX_T];
+    __shared__ __attribute__((aligned(16))) float v_m[320], v_h[320], v_x[320], gates[2 * G3], s_alpha[MAX_T];
     __shared__ float s_qs;
     const float* w_q = p.w_lin;
     const float* w_k = p.w_lin + HID;
@@ -160,10 +188,7 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_kernel(DagFwd p) {
             lo = pr > 0 ? pr : 0;
             n = i - lo;
             if (wave == 0) {
-                float a = w_q[lane] * v_x[lane] + w_q[lane + 64] * v_x[lane + 64] + w_q[lane + 128] * v_x[lane + 128] +
-                          w_q[lane + 192] * v_x[lane + 192];
-                if (lane + 256 < HID) a += w_q[lane + 256] * v_x[lane + 256];
-                const float qs = wave_sum(a) + b_lin;
+                const float qs = wave_sum(dot300(w_q, load_vec300(v_x, lane), lane)) + b_lin;
                 float mx = -INFINITY;
                 for (int j = lane; j < n; j += 64) mx = fmaxf(mx, qs + p.ks[(int64_t)b * T + lo + j]);
                 mx = wave_max(mx);
@@ -231,10 +256,7 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_kernel(DagFwd p) {
         // ---- D: relation transforms and key score of the new node (used by later steps)
         matvec_rows(p.Wr, nullptr, 2 * HID, v_h, nullptr, p.R + row * 2 * HID, lane, wave);
         if (wave == NW - 1) {
-            float a = w_k[lane] * v_h[lane] + w_k[lane + 64] * v_h[lane + 64] + w_k[lane + 128] * v_h[lane + 128] +
-                      w_k[lane + 192] * v_h[lane + 192];
-            if (lane + 256 < HID) a += w_k[lane + 256] * v_h[lane + 256];
-            a = wave_sum(a);
+            const float a = wave_sum(dot300(w_k, load_vec300(v_h, lane), lane));
             if (lane == 0) p.ks[row] = a;
         }
         __syncthreads();  // R / ks of this step are read from global memory by the following steps
@@ -259,7 +281,7 @@ struct DagBwd {
 __global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T;
-    __shared__ float v_g[320], v_dm[320], v_x[320], v_m[320], v_in[2 * G3], part[NW][320], s_al[MAX_T], s_da[MAX_T];
+    __shared__ __attribute__((aligned(16))) float v_g[320], v_dm[320], v_x[320], v_m[320], v_in[2 * G3], part[NW][320], s_al[MAX_T], s_da[MAX_T];
     __shared__ float s_dqs;
     const float* w_q = p.w_lin;
     const float* w_k = p.w_lin + HID;
@@ -275,11 +297,9 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
         }
         __syncthreads();
         {
-            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
             matvec_t_accum(p.Wr, 2 * HID, v_in, acc, lane, wave);
-#pragma unroll
-            for (int u = 0; u < 5; ++u)
-                if (lane + 64 * u < HID) part[wave][lane + 64 * u] = acc[u];
+            store_vec300(part[wave], acc, lane);
         }
         __syncthreads();
         const float dks_i = p.dks[row];
@@ -331,12 +351,10 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
         if (i == 0) break;  // M_0 = 0 has no producers
         // ---- 3: dM_i = direct + W_hh_c^T dgh_c + W_ih_p^T dgi_p
         {
-            float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
             matvec_t_accum(p.W_hh_c, G3, v_in, acc, lane, wave);
             matvec_t_accum(p.W_ih_p, G3, v_in + G3, acc, lane, wave);
-#pragma unroll
-            for (int u = 0; u < 5; ++u)
-                if (lane + 64 * u < HID) part[wave][lane + 64 * u] = acc[u];
+            store_vec300(part[wave], acc, lane);
         }
         __syncthreads();
         if (tid < HID) {
@@ -354,10 +372,7 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
         for (int j = wave; j < n; j += NW) {  // d alpha_j = dM . V_j
             const int64_t rj = (int64_t)b * T + lo + j;
             const float* v = p.R + rj * 2 * HID + (p.spk[rj] == si ? 0 : HID);
-            float a = v_dm[lane] * v[lane] + v_dm[lane + 64] * v[lane + 64] + v_dm[lane + 128] * v[lane + 128] +
-                      v_dm[lane + 192] * v[lane + 192];
-            if (lane + 256 < HID) a += v_dm[lane + 256] * v[lane + 256];
-            a = wave_sum(a);
+            const float a = wave_sum(dot300(v, load_vec300(v_dm, lane), lane));
             if (lane == 0) {
                 s_da[j] = a;
                 s_al[j] = p.alpha[((int64_t)b * T + i) * T + lo + j];
