@@ -24,7 +24,7 @@ _SIGS = {
                                _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
     "erc_gemm_f32_stream": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp, _i64,
                                       _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
-    "erc_gemm_bf16a_stream": (C.c_int, [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "erc_gemm_bf16a_stream": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "erc_wgrad_table": (C.c_int, [_vp, _i, _i, _i, _vp]),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
                                  _i64, _vp]),
@@ -39,7 +39,10 @@ _SIGS = {
     "erc_bn_lrelu_fwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _vp, _vp, _i, _vp, _vp]),
     "erc_bn_lrelu_bwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "erc_cross_entropy": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp]),
-    "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp]),
+    "erc_head_ce_stats_floats": (C.c_int64, [_i]),
+    "erc_head_ce": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _i64, _i64,
+                                _vp]),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
     "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
@@ -167,8 +170,8 @@ def gemm_bf16x(A, lda, a_kmajor, a_gather, B, ldb, b_kmajor, b_gather, x_is_a, C
 
 def gemm_bf16a_stream(X, ldx, gather, W, ldw, Cm, ldc, M, N, K, bias=None, act=0):
     _dev(X, W, Cm)
-    _check(lib().erc_gemm_bf16a_stream(ptr(X), ldx, ptr(gather), ptr(W), ldw, ptr(Cm), ldc, M, N, K, ptr(bias), act,
-                                       stream()), "erc_gemm_bf16a_stream")
+    _check(lib().erc_gemm_bf16a_stream(ptr(X), ldx, ptr(gather), ptr(W), ldw, int(W.dtype == torch.bfloat16), ptr(Cm), ldc,
+                                       M, N, K, ptr(bias), act, stream()), "erc_gemm_bf16a_stream")
 
 
 def slab_reduce(slabs, S, stride, bias, n_cols, act, out, numel, ld_out=0):
@@ -225,9 +228,11 @@ def cross_entropy(logits, ld, Cn, n_rows, row_map, labels, weight, grad_scale, d
                                    ptr(dlogits), lddl, ptr(stats), stream()), "erc_cross_entropy")
 
 
-def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_norm, gnorm, state):
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_norm, gnorm, state, shadow=None,
+              shadow_off=0, shadow_n=0):
     _check(lib().erc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale,
-                               clip_norm, ptr(gnorm), ptr(state), stream()), "erc_adam_step")
+                               clip_norm, ptr(gnorm), ptr(state), ptr(shadow), shadow_off, shadow_n, stream()),
+           "erc_adam_step")
 
 
 def grad_norm(g, n, grad_scale, gnorm, ws):
@@ -386,3 +391,12 @@ def clock_probe(out, iters):
 
 def wgrad_table(table, n, max_m, max_n):
     _call("erc_wgrad_table", table, n, max_m, max_n)
+
+
+def head_ce_stats_floats(n_rows):
+    return int(lib().erc_head_ce_stats_floats(n_rows))
+
+
+def head_ce(Z, ldz, F, Cn, n_rows, W, bias, labels, weight, mask_scale, logits, ldl, dlogits, lddl, dZ, lddz, stats):
+    _call("erc_head_ce", Z, ldz, F, Cn, n_rows, W, bias, labels, weight, mask_scale, logits, ldl, dlogits, lddl, dZ, lddz,
+          stats)

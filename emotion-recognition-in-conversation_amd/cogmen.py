@@ -111,7 +111,14 @@ class COGMENModule(nn.Module):
         self.flat = FlatParams(self.live_groups(), device)
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
         self.side = SideStream()
+        self.w1_shadow = None     # bf16 copy of rnn.1.weight, valid only while an optimizer keeps it in sync
         return self
+
+    def attach_bf16_shadow(self, optim):
+        """bf16 mode: let the fused optimizer maintain a bf16 copy of rnn.1.weight for the input projection."""
+        w = self.flat.w("rnn.1.weight")
+        self.w1_shadow = w.to(torch.bfloat16).contiguous()
+        optim.shadow = (self.w1_shadow, self.flat.offsets["rnn.1.weight"], w.numel())
 
     def _workspace(self, B, T, N, device):
         key = (B, T, N)
@@ -128,7 +135,7 @@ class COGMENModule(nn.Module):
             g=g, E=E,
             H0=f32(N, F), M=f32(N, 9 * F), inv_cnt=f32(N, N_REL), H1=f32(N, F), QKVS=f32(N, 4 * F),
             alpha=f32(E), H2=f32(N, F), H3=f32(N, F), Z=f32(N, F), logits=f32(N, C),
-            bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=torch.zeros(256, dtype=torch.float32, device=device),
+            bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=torch.zeros(1024, dtype=torch.float32, device=device),
             dlogits=f32(N, C), dZ=f32(N, F), dH3=f32(N, F), dH2=f32(N, F), dQKVS=f32(N, 4 * F), dscore=f32(E),
             dH1=f32(N, F), dM=f32(N, 9 * F), dH0=f32(N, F),
         )
@@ -148,7 +155,7 @@ class COGMENModule(nn.Module):
             N = int(text_length.sum().item())
         return B, T, N
 
-    def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training):
+    def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training, with_logits=True):
         fp, dev = self.flat, x.device
         ws = self._workspace(B, T, N, dev)
         g, pl = ws["g"], ws["planner"]
@@ -157,8 +164,8 @@ class COGMENModule(nn.Module):
         x_bf16 = x.dtype == torch.bfloat16
         capi.window_graph_build(text_length, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
                                 B, T, WP, WF, self.n_speakers, N, ws["E"], g)
-        linear_fwd(pl, x, D, g["node_row"], fp.w("rnn.1.weight"), fp.w("rnn.1.bias"), ws["H0"], F, N, F, D,
-                   x_bf16=x_bf16)
+        W1 = self.w1_shadow if (x_bf16 and self.w1_shadow is not None) else fp.w("rnn.1.weight")
+        linear_fwd(pl, x, D, g["node_row"], W1, fp.w("rnn.1.bias"), ws["H0"], F, N, F, D, x_bf16=x_bf16)
         capi.rgcn_mean_fwd(ws["H0"], F, F, N_REL, N, g, ws["M"], 9 * F, ws["inv_cnt"])
         # H1 = M @ [W_r ; W_root] + bias : B operand is the [9F, F] k-major stack conv1.weight|conv1.root
         Wcat = fp.w("gcn.conv1.weight")
@@ -181,7 +188,8 @@ class COGMENModule(nn.Module):
         p = self.drop_p if training else 0.0
         linear_fwd(pl, ws["H3"], F, None, fp.w("cls.0.weight"), fp.w("cls.0.bias"), ws["Z"], F, N, F, F,
                    act=3 if p > 0 else 1, drop_p=p, rng=self.rng_state)
-        linear_fwd(pl, ws["Z"], F, None, fp.w("cls.3.weight"), fp.w("cls.3.bias"), ws["logits"], C, N, C, F)
+        if with_logits:   # the training path computes them inside the fused head_ce kernel instead
+            linear_fwd(pl, ws["Z"], F, None, fp.w("cls.3.weight"), fp.w("cls.3.bias"), ws["logits"], C, N, C, F)
         return ws
 
     def forward(self, input_tensor, speaker_tensor, text_length, *args, label=None, **kwargs):
@@ -198,15 +206,20 @@ class COGMENModule(nn.Module):
         x, spk, lens, ys = batch["input_tensor"], batch["speaker_tensor"], batch["text_length"], batch["label"]
         B, T, N = self._shape(x, lens, ys)
         training = self.training
-        ws = self._forward_impl(x, spk, lens, B, T, N, training)
+        fused_head = self.n_classes <= 8
+        ws = self._forward_impl(x, spk, lens, B, T, N, training, with_logits=not fused_head)
         fp, g, pl = self.flat, ws["g"], ws["planner"]
         F, C, D = F_HID, self.n_classes, self.input_size
         x_bf16 = x.dtype == torch.bfloat16
-        capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
         p = self.drop_p if training else 0.0
-        # head
-        capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
-                      act=2, aux=ws["Z"], ldaux=F, act_scale=1.0 / (1.0 - p))
+        # head: logits + cross entropy + gradient through relu/dropout into Z
+        if fused_head:
+            capi.head_ce(ws["Z"], F, F, C, N, fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys, class_weight,
+                         1.0 / (1.0 - p), ws["logits"], C, ws["dlogits"], C, ws["dZ"], F, ws["stats"])
+        else:
+            capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
+            capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
+                          act=2, aux=ws["Z"], ldaux=F, act_scale=1.0 / (1.0 - p))
         with self.side.fork():
             linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
                          fp.offsets["cls.3.bias"], defer=True)
@@ -260,15 +273,18 @@ class COGMENModule(nn.Module):
         F, D = F_HID, self.input_size
         x_bf16 = x.dtype == torch.bfloat16
         if x_bf16:
-            launch = lambda: capi.gemm_bf16a_stream(x, D, g["node_row"], fp.w("rnn.1.weight"), D, ws["H0"], F, N, F, D,
+            W1 = self.w1_shadow if self.w1_shadow is not None else fp.w("rnn.1.weight")
+            launch = lambda: capi.gemm_bf16a_stream(x, D, g["node_row"], W1, D, ws["H0"], F, N, F, D,
                                                     bias=fp.w("rnn.1.bias"))
-            name = "gemm_bf16a_stream_kernel<8> (input projection, bf16 features)"
+            name = "gemm_bf16a_stream_kernel<8,%s> (input projection, bf16 features)" % (
+                "true" if self.w1_shadow is not None else "false")
         else:
             launch = lambda: capi.gemm_f32(x, D, 0, g["node_row"], fp.w("rnn.1.weight"), D, 0, None, ws["H0"], F, N, F, D,
                                            bias=fp.w("rnn.1.bias"))
             name = "gemm_f32_stream_kernel<0,0,8> (input projection, fp32 features)"
         S = 1
-        nbytes = N * D * x.element_size() + F * D * 4 + N * F * 4 + N * 4
+        wbytes = 2 if (x_bf16 and self.w1_shadow is not None) else 4
+        nbytes = N * D * x.element_size() + F * D * wbytes + N * F * 4 + N * 4
         for _ in range(10):
             launch()
         torch.cuda.synchronize()
@@ -319,6 +335,8 @@ class COGMENTrainer:
         self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.weight_decay,
                                decoupled=(o.name == "AdamW"), seed=params.seed)
         self.model.rng_state = self.optim.rng_state   # dropout offset advances with the optimizer step
+        if self.model.compute == "bf16":
+            self.model.attach_bf16_shadow(self.optim)
         self.class_weight = None
 
     def to_logits(self, batch):

@@ -495,8 +495,6 @@ extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const 
                                    int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
                                    const float* bias, int act, const float* aux, int ldaux, float act_scale, float drop_p,
                                    const uint64_t* rng_state, int accumulate, void* stream);
-extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const float* W, int ldw, float* C,
-                                     int ldc, int M, int N, int K, const float* bias, int act, void* stream);
 
 extern "C" int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t* a_gather, const float* B, int ldb,
                             int b_kmajor, const int32_t* b_gather, float* C, int ldc, int M, int N, int K, int split_k,

@@ -265,21 +265,28 @@ __device__ __forceinline__ short f2bf_s(float f) {
     return __builtin_bit_cast(short, h);
 }
 
-template <int NW>
+// Wave tile 32 rows x 32 columns (2 x 2 MFMA tiles: every B fragment is used for two row blocks, which halves the
+// W traffic through the per-CU L2 path -- the measured limiter of this kernel, ~70 GB/s per CU), 8 wavefronts
+// split K.  WB = true: W is given as a bf16 shadow copy (refreshed by the optimizer kernel), else fp32 rounded
+// while loaded.
+template <int NW, bool WB>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
-    __shared__ float red[NW > 1 ? NW * 8 * 64 : 1];
+    __shared__ float red[NW > 1 ? NW * 16 * 64 : 1];
     const unsigned short* __restrict__ A = (const unsigned short*)p.A;
-    const float* __restrict__ B = (const float*)p.B;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 16, z = blockIdx.z;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int nkb = (p.K + 31) / 32;
-    const int kb_begin = z * p.kblocks_per_split;
-    const int kb_end = min(nkb, kb_begin + p.kblocks_per_split);
-    const int m = m0 + r;
-    const bool m_ok = m < p.M;
-    const int mc = min(m, p.M - 1);
-    const int64_t a_row = (p.a_gather ? (int64_t)p.a_gather[mc] : (int64_t)mc) * p.lda;
+    const int kb_full_end = p.K / 32;
+    int64_t a_row[2];
+    bool m_ok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int m = m0 + 16 * h + r;
+        m_ok[h] = m < p.M;
+        const int mc = min(m, p.M - 1);
+        a_row[h] = (p.a_gather ? (int64_t)p.a_gather[mc] : (int64_t)mc) * p.lda;
+    }
     int nc[2];
     bool n_ok[2];
 #pragma unroll
@@ -289,65 +296,132 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
         nc[f] = min(n, p.N - 1);
     }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[h][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     // every load is unconditional (clamped address + select afterwards): no branch, no wait between loads
-    auto load = [&](const int kb, bf16x8& a, bf16x8 (&b)[2]) {
+    auto load = [&](const int kb, bf16x8 (&a)[2], bf16x8 (&b)[2], auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const int k = kb * 32 + 8 * g;
-        const bool full = kb * 32 + 32 <= p.K;  // wave-uniform
-        const unsigned short* s = A + a_row;
-        if (full && p.a_vec == 2) {
-            a = *reinterpret_cast<const bf16x8*>(s + k);
-        } else if (full && p.a_vec == 1) {
-            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(s + k), hi = *reinterpret_cast<const bf16x4*>(s + k + 4);
-            a = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const short v = (short)s[min(k + j, p.K - 1)];
-                a[j] = (k + j < p.K) ? v : (short)0;
-            }
-        }
-        a = m_ok ? a : zero8;
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-            const float* bp = B + (int64_t)nc[f] * p.ldb;
-            float t[8];
-            if (full && p.b_vec) {
-                const float4 lo = *reinterpret_cast<const float4*>(bp + k), hi = *reinterpret_cast<const float4*>(bp + k + 4);
-                t[0] = lo.x, t[1] = lo.y, t[2] = lo.z, t[3] = lo.w, t[4] = hi.x, t[5] = hi.y, t[6] = hi.z, t[7] = hi.w;
+        for (int h = 0; h < 2; ++h) {
+            const unsigned short* s = A + a_row[h];
+            if (FULL && p.a_vec == 2) {
+                a[h] = *reinterpret_cast<const bf16x8*>(s + k);
+            } else if (FULL && p.a_vec == 1) {
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(s + k), hi = *reinterpret_cast<const bf16x4*>(s + k + 4);
+                a[h] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float v = bp[min(k + j, p.K - 1)];
-                    t[j] = (k + j < p.K) ? v : 0.f;
+                    const short v = (short)s[min(k + j, p.K - 1)];
+                    a[h][j] = (FULL || k + j < p.K) ? v : (short)0;
                 }
             }
-            const bf16x8 v = {f2bf_s(t[0]), f2bf_s(t[1]), f2bf_s(t[2]), f2bf_s(t[3]),
-                              f2bf_s(t[4]), f2bf_s(t[5]), f2bf_s(t[6]), f2bf_s(t[7])};
+            a[h] = m_ok[h] ? a[h] : zero8;
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            bf16x8 v;
+            if (WB) {
+                const unsigned short* bp = (const unsigned short*)p.B + (int64_t)nc[f] * p.ldb;
+                if (FULL && p.b_vec == 2) {
+                    v = *reinterpret_cast<const bf16x8*>(bp + k);
+                } else if (FULL && p.b_vec == 1) {
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(bp + k), hi = *reinterpret_cast<const bf16x4*>(bp + k + 4);
+                    v = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const short t = (short)bp[min(k + j, p.K - 1)];
+                        v[j] = (FULL || k + j < p.K) ? t : (short)0;
+                    }
+                }
+            } else {
+                const float* bp = (const float*)p.B + (int64_t)nc[f] * p.ldb;
+                float t[8];
+                if (FULL && p.b_vec) {
+                    const float4 lo = *reinterpret_cast<const float4*>(bp + k), hi = *reinterpret_cast<const float4*>(bp + k + 4);
+                    t[0] = lo.x, t[1] = lo.y, t[2] = lo.z, t[3] = lo.w, t[4] = hi.x, t[5] = hi.y, t[6] = hi.z, t[7] = hi.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = bp[min(k + j, p.K - 1)];
+                        t[j] = (FULL || k + j < p.K) ? x : 0.f;
+                    }
+                }
+                v = (bf16x8){f2bf_s(t[0]), f2bf_s(t[1]), f2bf_s(t[2]), f2bf_s(t[3]),
+                             f2bf_s(t[4]), f2bf_s(t[5]), f2bf_s(t[6]), f2bf_s(t[7])};
+            }
             b[f] = n_ok[f] ? v : zero8;
         }
     };
-    auto mma = [&](const bf16x8& a, const bf16x8 (&b)[2]) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1], acc[1], 0, 0, 0);
+    auto mma = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[h][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[h], b[f], acc[h][f], 0, 0, 0);
     };
-    int kb = kb_begin + w;
-    for (; kb + 2 * NW < kb_end; kb += 3 * NW) {
-        bf16x8 a0, b0[2], a1, b1[2], a2, b2[2];
-        load(kb, a0, b0);
-        load(kb + NW, a1, b1);
-        load(kb + 2 * NW, a2, b2);
+    int kb = w;
+    for (; kb + 2 * NW < kb_full_end; kb += 3 * NW) {
+        bf16x8 a0[2], b0[2], a1[2], b1[2], a2[2], b2[2];
+        load(kb, a0, b0, T{});
+        load(kb + NW, a1, b1, T{});
+        load(kb + 2 * NW, a2, b2, T{});
         mma(a0, b0);
         mma(a1, b1);
         mma(a2, b2);
     }
-    for (; kb < kb_end; kb += NW) {
-        bf16x8 a0, b0[2];
-        load(kb, a0, b0);
+    for (; kb < kb_full_end; kb += NW) {
+        bf16x8 a0[2], b0[2];
+        load(kb, a0, b0, T{});
         mma(a0, b0);
     }
-    reduce_and_store<NW>(p, acc, red, m0, n0, z);
+    if (kb < nkb) {
+        bf16x8 a0[2], b0[2];
+        load(kb, a0, b0, Fx{});
+        mma(a0, b0);
+    }
+    // in-workgroup split-K reduction, then bias / relu epilogue
+    if (NW > 1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[(w * 16 + h * 8 + f * 4 + i) * 64 + lane] = acc[h][f][i];
+        __syncthreads();
+        if (w != 0) return;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) s += red[(ww * 16 + h * 8 + f * 4 + i) * 64 + lane];
+                    acc[h][f][i] = s;
+                }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            const int col = n0 + 16 * f + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + 16 * h + 4 * g + i;
+                if (row < p.M && col < p.N) {
+                    float v = acc[h][f][i] + (p.bias ? p.bias[col] : 0.f);
+                    if (p.act == 1) v = fmaxf(v, 0.f);
+                    p.C[(int64_t)row * p.ldc + col] = v;
+                }
+            }
+        }
 }
 
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -422,9 +496,10 @@ extern "C" int erc_wgrad_table(const void* table, int n_problems, int max_m, int
     return ERC_OK;
 }
 
-// C[M,N] = X[gather(m), :K] (bf16) * W[N,K]^T (fp32 rounded to bf16), fp32 accumulate: forward input projection.
-extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const float* W, int ldw, float* C,
-                                     int ldc, int M, int N, int K, const float* bias, int act, void* stream) {
+// C[M,N] = act(X[gather(m), :K] (bf16) * W[N,K]^T + bias), fp32 accumulate: forward input projection.
+// w_is_bf16 != 0: W is a bf16 copy [N, ldw] (kept in sync by erc_adam_step's shadow output), else fp32.
+extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const void* W, int ldw, int w_is_bf16,
+                                     float* C, int ldc, int M, int N, int K, const float* bias, int act, void* stream) {
     ERC_REQUIRE(X && W && C && M > 0 && N > 0 && K > 0, "gemm_bf16a_stream: bad arguments");
     ERC_REQUIRE(act == 0 || act == 1, "gemm_bf16a_stream: act %d", act);
     StreamP p{};
@@ -432,16 +507,21 @@ extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gath
     p.M = M; p.N = N; p.K = K; p.act = act;
     const int nkb = erc_cdiv(K, 32);
     p.kblocks_per_split = nkb;
-    p.a_vec = !al16(X) ? 0 : (ldx % 8 == 0 ? 2 : (ldx % 4 == 0 ? 1 : 0));
-    p.b_vec = al16(W) && (ldw % 4 == 0);
-    dim3 grid(erc_cdiv(N, 32), erc_cdiv(M, 16), 1);
+    auto bvec = [](const void* q, int ld) { return !al16(q) ? 0 : (ld % 8 == 0 ? 2 : (ld % 4 == 0 ? 1 : 0)); };
+    p.a_vec = bvec(X, ldx);
+    p.b_vec = w_is_bf16 ? bvec(W, ldw) : ((al16(W) && ldw % 4 == 0) ? 1 : 0);
+    dim3 grid(erc_cdiv(N, 32), erc_cdiv(M, 32), 1);
     hipStream_t st = (hipStream_t)stream;
-    if (nkb >= 16)
-        hipLaunchKernelGGL((gemm_bf16a_stream_kernel<8>), grid, dim3(512), 0, st, p);
-    else if (nkb >= 4)
-        hipLaunchKernelGGL((gemm_bf16a_stream_kernel<4>), grid, dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((gemm_bf16a_stream_kernel<1>), grid, dim3(64), 0, st, p);
+    if (nkb >= 16) {
+        if (w_is_bf16) hipLaunchKernelGGL((gemm_bf16a_stream_kernel<8, true>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16a_stream_kernel<8, false>), grid, dim3(512), 0, st, p);
+    } else if (nkb >= 4) {
+        if (w_is_bf16) hipLaunchKernelGGL((gemm_bf16a_stream_kernel<4, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16a_stream_kernel<4, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (w_is_bf16) hipLaunchKernelGGL((gemm_bf16a_stream_kernel<1, true>), grid, dim3(64), 0, st, p);
+        else hipLaunchKernelGGL((gemm_bf16a_stream_kernel<1, false>), grid, dim3(64), 0, st, p);
+    }
     ERC_LAUNCH_CHECK("gemm_bf16a_stream");
     return ERC_OK;
 }

@@ -140,6 +140,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
                                                             float* __restrict__ dlogits, int lddl,
                                                             float* __restrict__ stats) {
     __shared__ double red[256];
+    double* const s_red = red;
     __shared__ double s_wsum;
     __shared__ int s_last;
     const int tid = threadIdx.x;
@@ -206,21 +207,184 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restr
         s_last = (prev == (int)gridDim.x - 1);
     }
     __syncthreads();
-    if (s_last && tid == 0) {
+    if (s_last) {  // the last workgroup combines the partials: one (parallel) load per thread, fixed-order tree
         __threadfence();
         double l = 0.0, h = 0.0;
-        for (int w = 0; w < (int)gridDim.x; ++w) {
-            l += (double)__hip_atomic_load(stats + 8 + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            h += (double)__hip_atomic_load(stats + 9 + 2 * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < (int)gridDim.x) {
+            l = (double)__hip_atomic_load(stats + 8 + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h = (double)__hip_atomic_load(stats + 9 + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        stats[0] = (float)(l / wsum);
-        stats[1] = (float)h;
-        stats[2] = (float)wsum;
-        *reinterpret_cast<int*>(stats + 4) = 0;
+        __syncthreads();
+        s_red[tid] = l;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        const double lsum = s_red[0];
+        __syncthreads();
+        s_red[tid] = h;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            stats[0] = (float)(lsum / wsum);
+            stats[1] = (float)s_red[0];
+            stats[2] = (float)wsum;
+            *reinterpret_cast<int*>(stats + 4) = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------ fused classifier tail
+// logits = Z W^T + b (C <= 8 classes, F <= 128 features), cross entropy, and the gradient wrt Z through the
+// relu/dropout mask -- cls[3] + F.cross_entropy + their backward (track_mm/cogmen.py:116-122,185) in ONE launch
+// instead of GEMM + CE + GEMM.  One wavefront per row, lane l owns features l and l+64.
+constexpr int HC_MAXC = 8;
+constexpr int HC_MAXWG = 256;  // workgroups (one arrival atomic each)
+
+__global__ __launch_bounds__(256) void head_ce_kernel(const float* __restrict__ Z, int ldz, int F, int C, int n_rows,
+                                                      const float* __restrict__ W, const float* __restrict__ bias,
+                                                      const int64_t* __restrict__ labels,
+                                                      const float* __restrict__ weight, float mask_scale,
+                                                      float* __restrict__ logits, int ldl, float* __restrict__ dlogits,
+                                                      int lddl, float* __restrict__ dZ, int lddz,
+                                                      float* __restrict__ stats, int rows_per_wg) {
+    __shared__ double s_red[256];
+    __shared__ double s_wsum;
+    __shared__ float s_part[4][2];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (weight) {
+        double wacc = 0.0;
+        for (int i = tid; i < n_rows; i += 256) wacc += (double)weight[labels[i]];
+        s_red[tid] = wacc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) s_wsum = s_red[0];
+    } else if (tid == 0) {
+        s_wsum = (double)n_rows;
+    }
+    __syncthreads();
+    const double wsum = s_wsum;
+    const float inv_w = (float)(1.0 / wsum);
+    const bool h0 = lane < F, h1 = lane + 64 < F;
+    const int c0 = min(lane, F - 1), c1 = min(lane + 64, F - 1);
+    // unconditional clamped loads, masked afterwards (a guarded load costs a full round trip each)
+    float w0[HC_MAXC], w1[HC_MAXC], bk[HC_MAXC];
+    const float m0 = h0 ? 1.f : 0.f, m1 = h1 ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < HC_MAXC; ++k) {
+        const int kc = min(k, C - 1);
+        w0[k] = W[(int64_t)kc * F + c0] * m0;
+        w1[k] = W[(int64_t)kc * F + c1] * m1;
+        bk[k] = bias[kc];
+    }
+    float lacc = 0.f, hits = 0.f;
+    for (int rr = wave; rr < rows_per_wg; rr += 4) {
+        const int row = blockIdx.x * rows_per_wg + rr;
+        if (row >= n_rows) break;
+        const float z0 = Z[(int64_t)row * ldz + c0], z1 = Z[(int64_t)row * ldz + c1];
+        const int y = (int)labels[row];
+        float lg[HC_MAXC];
+#pragma unroll
+        for (int k = 0; k < HC_MAXC; ++k) lg[k] = wave_sum(z0 * w0[k] + z1 * w1[k]) + bk[k];
+        float mx = lg[0];
+        int am = 0;
+#pragma unroll
+        for (int k = 1; k < HC_MAXC; ++k)
+            if (k < C && lg[k] > mx) mx = lg[k], am = k;
+        float se = 0.f;
+#pragma unroll
+        for (int k = 0; k < HC_MAXC; ++k)
+            if (k < C) se += expf(lg[k] - mx);
+        const float lse = mx + logf(se);
+        float wy = 1.f;
+        if (weight) wy = weight[y];   // wave-uniform branch
+        float ly = 0.f, g0 = 0.f, g1 = 0.f;
+        const float coef = wy * inv_w;
+#pragma unroll
+        for (int k = 0; k < HC_MAXC; ++k) {
+            if (k < C) {
+                const float d = coef * (expf(lg[k] - lse) - (k == y ? 1.f : 0.f));
+                if (k == y) ly = lg[k];
+                g0 += d * w0[k];
+                g1 += d * w1[k];
+                if (lane == k) {
+                    logits[(int64_t)row * ldl + k] = lg[k];
+                    dlogits[(int64_t)row * lddl + k] = d;
+                }
+            }
+        }
+        if (h0) dZ[(int64_t)row * lddz + lane] = z0 > 0.f ? g0 * mask_scale : 0.f;
+        if (h1) dZ[(int64_t)row * lddz + lane + 64] = z1 > 0.f ? g1 * mask_scale : 0.f;
+        lacc += wy * (lse - ly);
+        hits += (am == y) ? 1.f : 0.f;
+    }
+    if (lane == 0) s_part[wave][0] = lacc, s_part[wave][1] = hits;
+    __syncthreads();
+    if (tid == 0) {
+        stats[8 + 2 * blockIdx.x] = s_part[0][0] + s_part[1][0] + s_part[2][0] + s_part[3][0];
+        stats[9 + 2 * blockIdx.x] = s_part[0][1] + s_part[1][1] + s_part[2][1] + s_part[3][1];
+        __threadfence();
+        const int prev = atomicAdd(reinterpret_cast<int*>(stats + 4), 1);
+        s_last = (prev == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last) {  // the last workgroup combines the partials: one (parallel) load per thread, fixed-order tree
+        __threadfence();
+        double l = 0.0, h = 0.0;
+        if (tid < (int)gridDim.x) {
+            l = (double)__hip_atomic_load(stats + 8 + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            h = (double)__hip_atomic_load(stats + 9 + 2 * tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        s_red[tid] = l;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        const double lsum = s_red[0];
+        __syncthreads();
+        s_red[tid] = h;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) s_red[tid] += s_red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            stats[0] = (float)(lsum / wsum);
+            stats[1] = (float)s_red[0];
+            stats[2] = (float)wsum;
+            *reinterpret_cast<int*>(stats + 4) = 0;
+        }
     }
 }
 
 }  // namespace
+
+extern "C" int64_t erc_head_ce_stats_floats(int n_rows) { return 16 + 2 * HC_MAXWG; }
+
+extern "C" int erc_head_ce(const float* Z, int ldz, int F, int C, int n_rows, const float* W, const float* bias,
+                           const int64_t* labels, const float* weight, float mask_scale, float* logits, int ldl,
+                           float* dlogits, int lddl, float* dZ, int lddz, float* stats, void* stream) {
+    ERC_REQUIRE(Z && W && bias && labels && logits && dlogits && dZ && stats, "head_ce: null pointer");
+    ERC_REQUIRE(F > 0 && F <= 128 && C > 0 && C <= HC_MAXC && n_rows > 0, "head_ce: F=%d C=%d n_rows=%d unsupported", F, C, n_rows);
+    int grid = erc_cdiv(n_rows, 16);
+    if (grid > HC_MAXWG) grid = HC_MAXWG;
+    const int rows_per_wg = erc_cdiv(n_rows, grid);
+    grid = erc_cdiv(n_rows, rows_per_wg);
+    hipLaunchKernelGGL(head_ce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Z, ldz, F, C, n_rows, W, bias,
+                       labels, weight, mask_scale, logits, ldl, dlogits, lddl, dZ, lddz, stats, rows_per_wg);
+    ERC_LAUNCH_CHECK("head_ce");
+    return ERC_OK;
+}
 
 extern "C" int64_t erc_bn_ws_floats(int F) { return (int64_t)BN_G * 2 * F * 2 + 16; }
 

@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                    float b1, float b2, float eps, float wd, int decoupled,
                                                    float grad_scale, float clip_norm,
-                                                   const float* __restrict__ gnorm, int64_t* state) {
+                                                   const float* __restrict__ gnorm, int64_t* state,
+                                                   unsigned short* __restrict__ shadow, int64_t shadow_off,
+                                                   int64_t shadow_n) {
     const int64_t step = state[0] + 1;  // every block reads it before it signals arrival (below)
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
@@ -46,7 +48,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
-        p[i] = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        const float pn = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        p[i] = pn;
+        if (shadow && i >= shadow_off && i < shadow_off + shadow_n) {  // bf16 copy for the bf16 input GEMM
+            const __bf16 h = (__bf16)pn;
+            shadow[i - shadow_off] = __builtin_bit_cast(unsigned short, h);
+        }
     }
     // the LAST block to finish bumps {step, RNG offset}: by then every block has read state[0]
     __syncthreads();
@@ -112,14 +119,15 @@ extern "C" int erc_clock_probe(uint64_t* out, int iters, void* stream) {
 
 extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
-                             float clip_norm, const float* gnorm, int64_t* state, void* stream) {
+                             float clip_norm, const float* gnorm, int64_t* state, void* bf16_shadow,
+                             int64_t shadow_off, int64_t shadow_n, void* stream) {
     ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
     ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
     int grid = (int)((n + 255) / 256);
     if (grid > 256) grid = 256;  // one arrival atomic per block on a single word: keep the count low
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                       decoupled, grad_scale, clip_norm, gnorm, state);
+                       decoupled, grad_scale, clip_norm, gnorm, state, (unsigned short*)bf16_shadow, shadow_off, shadow_n);
     ERC_LAUNCH_CHECK("adam_step");
     return ERC_OK;
 }

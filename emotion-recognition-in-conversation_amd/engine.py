@@ -235,6 +235,7 @@ class FusedAdam:
         self.state = torch.tensor([0, 0, seed, 0], dtype=torch.int64, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.norm_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self.shadow = None   # (bf16 tensor, offset, numel): kept in sync with the fp32 master weights by the step
 
     @property
     def rng_state(self):
@@ -246,7 +247,8 @@ class FusedAdam:
             capi.grad_norm(f.grad, f.numel, grad_scale, self.gnorm, self.norm_ws)
         capi.adam_step(f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, self.lr, self.betas[0], self.betas[1],
                        self.eps, self.weight_decay, self.decoupled, grad_scale, self.clip_norm,
-                       self.gnorm if self.clip_norm > 0 else None, self.state)
+                       self.gnorm if self.clip_norm > 0 else None, self.state,
+                       *(self.shadow if self.shadow is not None else (None, 0, 0)))
 
 
 def all_reduce_grads(flat):

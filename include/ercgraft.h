@@ -122,10 +122,11 @@ int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_
 int erc_wgrad_table(const void* table, int n_problems, int max_m, int max_n, void* stream);
 
 /* Forward input projection on a bf16 feature block: C[M,N] = act(X[gather(m), :K] W[N,K]^T + bias), X bf16,
- * W fp32 rounded to bf16 while loaded, fp32 accumulate (v_mfma_f32_16x16x32_bf16); act 0 | 1 (relu).
+ * W either fp32 (rounded to bf16 while loaded) or a bf16 shadow copy (w_is_bf16; see erc_adam_step), fp32
+ * accumulate (v_mfma_f32_16x16x32_bf16); act 0 | 1 (relu).
  * The HBM-dominant kernel of the COGMEN step (nn.Linear(D,100), track_mm/cogmen.py:103-105,147). */
-int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const float* W, int ldw, float* C, int ldc,
-                          int M, int N, int K, const float* bias, int act, void* stream);
+int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const void* W, int ldw, int w_is_bf16,
+                          float* C, int ldc, int M, int N, int K, const float* bias, int act, void* stream);
 
 /* Same contract with bf16 operands for the big streamed operand (the padded
  * feature block): A or B given as bf16 (uint16 storage), the other operand is
@@ -222,6 +223,15 @@ int erc_cross_entropy(const float* logits, int ld, int C, int n_rows, const int3
                       const int64_t* labels, const float* weight, float grad_scale,
                       float* dlogits, int lddl, float* stats, void* stream);
 
+/* Fused classifier tail: logits = Z W^T + b (W [C,F], C <= 8, F <= 128), cross entropy as above, and
+ * dZ = (Z > 0 ? mask_scale : 0) * (dlogits W)  -- the last Linear of the head, F.cross_entropy and their backward
+ * through the preceding ReLU(+inverted dropout, mask_scale = 1/(1-p)) in one launch (track_mm/cogmen.py:116-122,185;
+ * dgcn_models.py:163-170).  stats: >= erc_head_ce_stats_floats(n_rows) floats, zero-initialised once. */
+int64_t erc_head_ce_stats_floats(int n_rows);
+int erc_head_ce(const float* Z, int ldz, int F, int C, int n_rows, const float* W, const float* bias,
+                const int64_t* labels, const float* weight, float mask_scale, float* logits, int ldl,
+                float* dlogits, int lddl, float* dZ, int lddz, float* stats, void* stream);
+
 /* ------------------------------------------------------------------------
  * S4  optimizer over the flat live-parameter buffer (torch.optim.Adam /
  * AdamW, track_mm/cogmen.py:50,187-189; dagerc.py:39,230-231).
@@ -231,10 +241,13 @@ int erc_cross_entropy(const float* logits, int ld, int C, int n_rows, const int3
  *   gnorm[0] was produced by erc_grad_norm (clip_grad_norm_ semantics).
  *   decoupled != 0 -> AdamW (p *= 1 - lr*wd) else L2 (g += wd*p).
  *   grad_scale multiplies g first (1/world_size after a sum all-reduce).
+ *   bf16_shadow (optional): the updated p[shadow_off, shadow_off+shadow_n) is also written as bf16 -- the weight
+ *   operand of erc_gemm_bf16a_stream stays in sync without a conversion launch.
  */
 int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
-                  float grad_scale, float clip_norm, const float* gnorm, int64_t* state, void* stream);
+                  float grad_scale, float clip_norm, const float* gnorm, int64_t* state,
+                  void* bf16_shadow, int64_t shadow_off, int64_t shadow_n, void* stream);
 /* diagnostic: out[0] = shader cycles, out[1] = 10-ns ticks of a fixed dependent-MFMA loop (bench.py --clock_probe) */
 int erc_clock_probe(uint64_t* out, int iters, void* stream);
 /* gnorm[0] = ||g * grad_scale||_2 ; ws >= 1024 floats */

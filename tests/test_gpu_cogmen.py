@@ -115,3 +115,27 @@ def test_train_mm_cli_plugin_surface():
     assert set(epochs[-1]["test"]) >= {"acc", "wa", "f1", "mif1", "maf1"}
     bad = subprocess.run([sys.executable, "train_mm.py", "--module=nope"], cwd=repo, capture_output=True, text=True)
     assert bad.returncode == 1 and "cogmen" in bad.stdout
+
+
+def test_bf16_weight_shadow_tracks_master_weights():
+    """bf16 mode: the optimizer kernel keeps a bf16 copy of rnn.1.weight in sync (it is the W operand of the input
+    projection), bit-identical to rounding the fp32 master after every step."""
+    from erc_amd.cogmen import COGMENTrainer
+    from erc_amd.params import ERCParams
+    p = ERCParams().from_args(["--dataset=iemocap-cogmen-sbert-6", "--compute=bf16", "--optim.lr=0.01"])
+    tr = COGMENTrainer(p, "cuda:0")
+    assert tr.model.w1_shadow is not None
+    case = cogmen_case(B=6, min_len=5, max_len=25, dims=dict(a=100, t=768, v=512), seed=2)
+    b = tr.prepare_batch(case["batch"])
+    before = tr.model.flat.w("rnn.1.weight").clone()
+    for _ in range(3):
+        tr.train_step(b)
+    w = tr.model.flat.w("rnn.1.weight")
+    assert not torch.equal(w, before)
+    assert torch.equal(tr.model.w1_shadow.view(torch.int16), w.to(torch.bfloat16).view(torch.int16))
+    # and the projection through the shadow equals the projection through the fp32 weights rounded on the fly
+    tr.model.eval()
+    with_shadow = tr.model(**b)[0].clone()
+    tr.model.w1_shadow = None
+    without = tr.model(**b)[0]
+    assert torch.equal(with_shadow, without)
