@@ -275,7 +275,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
     const unsigned short* __restrict__ A = (const unsigned short*)p.A;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    // XCD-aware tile mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so blocks b and b+8
+    // share an L2.  All column tiles of one 32-row group are given to the same XCD, which then fetches that
+    // group's feature rows from HBM once instead of once per column tile (measured: FETCH_SIZE 4x -> ~1x).
+    const int n_ct = (p.N + 31) / 32, n_rg = (p.M + 31) / 32;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int rg = xcd + 8 * (j / n_ct), ct = j % n_ct;
+    if (rg >= n_rg) return;
+    const int n0 = ct * 32, m0 = rg * 32;
     const int nkb = (p.K + 31) / 32;
     const int kb_full_end = p.K / 32;
     int64_t a_row[2];
@@ -510,7 +517,7 @@ extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gath
     auto bvec = [](const void* q, int ld) { return !al16(q) ? 0 : (ld % 8 == 0 ? 2 : (ld % 4 == 0 ? 1 : 0)); };
     p.a_vec = bvec(X, ldx);
     p.b_vec = w_is_bf16 ? bvec(W, ldw) : ((al16(W) && ldw % 4 == 0) ? 1 : 0);
-    dim3 grid(erc_cdiv(N, 32), erc_cdiv(M, 32), 1);
+    dim3 grid(8 * erc_cdiv(erc_cdiv(M, 32), 8) * erc_cdiv(N, 32), 1, 1);  // see the XCD-aware mapping in the kernel
     hipStream_t st = (hipStream_t)stream;
     if (nkb >= 16) {
         if (w_is_bf16) hipLaunchKernelGGL((gemm_bf16a_stream_kernel<8, true>), grid, dim3(512), 0, st, p);
