@@ -108,14 +108,21 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--kernel_reps", type=int, default=200)
     ap.add_argument("--clock_probe", action="store_true", help="diagnostic: append a clock-probe kernel to the step")
+    ap.add_argument("--rehearse_dp", action="store_true",
+                    help="diagnostic: run the N>1 step structure (RCCL group, eager exchange + optimizer) on one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    dp = world > 1 or args.rehearse_dp
+    if dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29573")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
@@ -145,7 +152,7 @@ def main():
     # ---------------------------------------------------------------- step function
     use_graph = not args.no_graph
     probe = torch.zeros(4, dtype=torch.int64, device=device) if args.clock_probe else None
-    if world == 1:
+    if not dp:
         def step_fn():
             out = trainer.train_step(batch)
             if probe is not None:
@@ -162,11 +169,11 @@ def main():
 
         def step():
             out = fb_g()
-            trainer.optim.step(grad_scale=all_reduce_grads(trainer.model.flat))
+            trainer.optim.step(grad_scale=all_reduce_grads(trainer.model.flat, always=args.rehearse_dp))
             return out
 
     def barrier():
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -178,7 +185,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -193,8 +200,16 @@ def main():
     roof = None
     if rank == 0 and args.module == "cogmen":
         roof = trainer.model.dominant_kernel_probe(batch, reps=args.kernel_reps)
+        traffic, tsrc = None, None
+        pmc = os.path.join(REPO, "profiles", "r01_cogmen_b32_%s_pmc.json" % args.dtype)
+        if args.batch == 32 and args.max_len == 110 and os.path.exists(pmc):
+            # HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+            # same command (tools/pmc_summary.py; gfx950 correction: read bytes = 2 x FETCH_SIZE)
+            with open(pmc) as fh:
+                rec = json.load(fh)
+            traffic, tsrc = rec.get("hbm_bytes_per_launch"), os.path.relpath(pmc, REPO)
         roof = {"bound": "hbm", "kernel": roof["kernel"], "achieved": roof["gbs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                 "algorithmic_bytes": roof["bytes"], "avg_us": roof["us"], "launches_timed": args.kernel_reps}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
@@ -239,7 +254,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dp:
         torch.distributed.destroy_process_group()
 
 

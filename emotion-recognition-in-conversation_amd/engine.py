@@ -251,11 +251,12 @@ class FusedAdam:
                        *(self.shadow if self.shadow is not None else (None, 0, 0)))
 
 
-def all_reduce_grads(flat):
+def all_reduce_grads(flat, always=False):
     """DP exchange step (SURVEY.md 8e): one sum all-reduce of the flat live-gradient buffer;
-    the 1/world scaling is folded into the optimizer's grad_scale."""
+    the 1/world scaling is folded into the optimizer's grad_scale.  `always` issues the collective on a
+    one-rank group too (bench.py --rehearse_dp)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or always):
         dist.all_reduce(flat.grad)
         return 1.0 / dist.get_world_size()
     return 1.0
