@@ -25,7 +25,9 @@ _SIGS = {
     "erc_gemm_f32_stream": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp, _i64,
                                       _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
     "erc_gemm_bf16a_stream": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
-    "erc_wgrad_table": (C.c_int, [_vp, _i, _i, _i, _vp]),
+    "erc_wgrad_table": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "erc_wgrad_slab_floats": (C.c_int64, []),
+    "erc_wgrad_max_k_per_split": (C.c_int, []),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
                                  _i64, _vp]),
     "erc_slab_reduce": (C.c_int, [_vp, _i, _i64, _vp, _i, _i, _vp, _i, _i64, _vp]),
@@ -389,8 +391,18 @@ def clock_probe(out, iters):
     _call("erc_clock_probe", out, iters)
 
 
-def wgrad_table(table, n, max_m, max_n):
-    _call("erc_wgrad_table", table, n, max_m, max_n)
+def wgrad_table(table, n_desc, item_base, n_items, slabs, counters):
+    """item_base: ctypes int32 array (host) with the first work item of every descriptor."""
+    _check(lib().erc_wgrad_table(ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), stream()),
+           "erc_wgrad_table")
+
+
+def wgrad_slab_floats():
+    return int(lib().erc_wgrad_slab_floats())
+
+
+def wgrad_max_k_per_split():
+    return int(lib().erc_wgrad_max_k_per_split())
 
 
 def head_ce_stats_floats(n_rows):

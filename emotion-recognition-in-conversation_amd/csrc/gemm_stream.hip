@@ -234,30 +234,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_f32_stream_kernel(StreamP p) {
     gemm_f32_stream_body<A_MODE, B_MODE, NW, GA, GB, VEC>(p, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// Batched weight gradients: blockIdx.z selects one of n independent K-major x K-major products described by a
-// device-resident table (all of a step's dW = dY^T X products whose operands are complete at the end of the
-// backward chain run as ONE launch instead of one ~6 us-floor launch each).
-struct WgradDesc {
-    const float* A;
-    const float* B;
-    float* C;
-    float* bias_out;
-    int lda, ldb, ldc, M, N, K, ones, pad;
-};
-
-__global__ __launch_bounds__(512) void gemm_f32_stream_table_kernel(const WgradDesc* __restrict__ table) {
-    __shared__ float red[8 * 8 * 64];
-    const WgradDesc d = table[blockIdx.z];
-    const int Nlog = d.N + (d.ones == 1 ? 1 : 0), Mlog = d.M + (d.ones == 2 ? 1 : 0);
-    if ((int)blockIdx.x * 32 >= Nlog || (int)blockIdx.y * 16 >= Mlog) return;
-    StreamP p{};
-    p.A = d.A; p.B = d.B; p.C = d.C; p.bias_out = d.bias_out;
-    p.lda = d.lda; p.ldb = d.ldb; p.ldc = d.ldc; p.M = d.M; p.N = d.N; p.K = d.K;
-    p.kblocks_per_split = (d.K + 15) / 16;
-    p.ones = d.ones;
-    gemm_f32_stream_body<1, 1, 8, false, false, false>(p, red, blockIdx.x, blockIdx.y, 0);
-}
-
 // bf16 feature block as the A operand (rows K-contiguous, optional gather), fp32 B [N,K] rounded to bf16 on the fly:
 // the forward input projection.  v_mfma_f32_16x16x32_bf16: lane (r,g) holds k = kb*32 + 8g + j, j < 8.
 __device__ __forceinline__ short f2bf_s(float f) {
@@ -492,14 +468,6 @@ extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const 
 #undef ERC_SL2
 #undef ERC_SL3
     ERC_LAUNCH_CHECK("gemm_f32_stream");
-    return ERC_OK;
-}
-
-extern "C" int erc_wgrad_table(const void* table, int n_problems, int max_m, int max_n, void* stream) {
-    ERC_REQUIRE(table && n_problems > 0 && max_m > 0 && max_n > 0, "wgrad_table: bad arguments");
-    dim3 grid(erc_cdiv(max_n, 32), erc_cdiv(max_m, 16), n_problems);
-    hipLaunchKernelGGL(gemm_f32_stream_table_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const WgradDesc*)table);
-    ERC_LAUNCH_CHECK("wgrad_table");
     return ERC_OK;
 }
 

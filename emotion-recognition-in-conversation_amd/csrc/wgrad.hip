@@ -1,0 +1,345 @@
+// Batched weight gradients: every dW = A^T B product of a training step (A [K, M] and B [K, N] both K-major, K = #nodes)
+// as ONE launch over a device-resident descriptor table.
+//
+// Replaces the autograd weight-gradient GEMMs behind loss.backward() (reference: track_mm/cogmen.py:187-189 and the
+// other train_step bodies).
+//
+// Wave tile 64 x 64.  A K-major operand has its m (resp. n) index contiguous in memory, so one 16-byte load gives a
+// lane FOUR neighbouring rows of the output for one k:  lane (r = lane & 15, g = lane >> 4) loads
+// A[k0 + g][m0 + 4r .. 4r+3] and B[k0 + g][n0 + 4r .. 4r+3].  v_mfma_f32_16x16x4_f32 number (i, j) takes a[i] and
+// b[j]: its 16 x 16 result holds the output rows {m0 + 4r' + i} and columns {n0 + 4r + j} -- a fixed permutation of
+// the tile that is undone when the tile is stored.  2 loads feed 16 MFMAs (the 16 x 32 streaming kernel needs 12 for
+// 8), and the bf16 feature block (input projection gradient) is read 8 bytes per lane, fully coalesced, with its row
+// gather staged once per workgroup in LDS.
+//
+// K is split over the 4 wavefronts of a workgroup (reduced through LDS) and over `splits` workgroups per tile:
+// partial tiles go to a slab, the workgroup that arrives last (agent-scope counter) sums the slabs in split order
+// and writes the gradient -- no float atomics, bit-reproducible, no separate reduce launch.
+#include "erc_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Pointers read from the descriptor table are generic to the compiler: without the explicit global address space it
+// emits flat_load, which also counts on lgkmcnt and so serialises with the LDS reads of the gather stage.
+#define ERC_GLOBAL __attribute__((address_space(1)))
+typedef const ERC_GLOBAL float* gfloat_cp;
+typedef const ERC_GLOBAL unsigned short* gushort_cp;
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef const ERC_GLOBAL f32x4* gfloat4_cp;
+typedef const ERC_GLOBAL u16x4* gushort4_cp;
+
+constexpr int WG_U = 4;            // k-steps (of 4 k each) whose loads are in flight together
+constexpr int WG_IDX_CAP = 2048;   // k per split (row-gather stage in LDS)
+constexpr int WG_SLAB = 4096 + 64; // floats per partial tile: 64 x 64 + one bias strip
+constexpr int WG_MAX_DESC = 32;
+
+struct WgDesc {  // 96 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQQQQ14i")
+    const float* A;
+    const void* B;
+    float* C;
+    float* bias_out;          // ones == 1: [M] column sums of A;  ones == 2: [N] column sums of B
+    const int32_t* b_gather;  // row of B for every k, or null
+    int lda, ldb, ldc, M, N, K;
+    int ones, b_bf16, splits, tiles_n, item_base, n_items, tile_base, vec;  // vec: bit0 A, bit1 B, bit2 C 16-byte ok
+};
+
+// Cross-workgroup hand-off of the partial tiles WITHOUT fences (an agent-scope release/acquire fence pair costs
+// ~3.5 us per workgroup on MI355X: L2 write-back + invalidate): the slab is written with write-through (sc1) stores,
+// one full 256-byte run per wave instruction, drained with s_waitcnt vmcnt(0) before the workgroup's arrival
+// ticket; the last arriver reads it with sc1 loads.
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// VEC (16-byte operand loads legal for BOTH operands) is compile-time: a runtime flag around a load makes hipcc
+// branch and drain vmcnt per load.
+template <bool BF16, bool VEC>
+__device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, float* red, float* bred, int* idx,
+                                           int* s_flag, float* slabs, int* counters) {
+    const gfloat_cp A = (gfloat_cp)d.A;
+    const ERC_GLOBAL int32_t* const gather = (const ERC_GLOBAL int32_t*)d.b_gather;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int split = local % d.splits, tile = local / d.splits;
+    const int tm = tile / d.tiles_n, tn = tile % d.tiles_n;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int nks = (d.K + 3) >> 2;
+    const int per = (nks + d.splits - 1) / d.splits;
+    const int ks_begin = split * per, ks_end = min(nks, ks_begin + per);
+    const int k_begin = ks_begin * 4;
+    const int nk = max(0, min(d.K, ks_end * 4) - k_begin);
+    for (int t = tid; t < nk; t += 256) idx[t] = gather ? gather[k_begin + t] : k_begin + t;
+    __syncthreads();
+
+    constexpr bool avec = VEC, bvec = VEC;
+    const int ma = m0 + 4 * r, nb = n0 + 4 * r;
+    int mc[4], nc[4];
+    bool m_ok[4], n_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        m_ok[i] = ma + i < d.M, n_ok[i] = nb + i < d.N;
+        mc[i] = min(ma + i, d.M - 1), nc[i] = min(nb + i, d.N - 1);
+    }
+    const int mav = m_ok[3] ? ma : 0, nbv = n_ok[3] ? nb : 0;  // vector paths: M, N multiples of 4 (host contract)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsa[4] = {0.f, 0.f, 0.f, 0.f}, bsb[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // Every global load is unconditional and nothing SELECTS on its result (hipcc sinks a load under the select's
+    // condition: exec-masked branch + s_waitcnt per load).  Out-of-range k: address clamped, value multiplied by 0
+    // (the clamped row is real data, so a NaN there is a NaN of the true result too).  Out-of-range m / n: address
+    // clamped, the garbage only reaches output rows / columns that are never stored.
+    // (the multiply is done in mma(), after the NEXT batch's loads have been issued: placed here it would make the
+    // compiler wait for this batch right away)
+    auto load = [&](const int ks, float (&a)[4], float (&b)[4], float& kf) {
+        const int k = 4 * ks + g;
+        kf = (ks < ks_end && k < d.K) ? 1.f : 0.f;
+        const int kl = max(0, min(k - k_begin, nk - 1));
+        const int64_t arow = (int64_t)(k_begin + kl) * d.lda;
+        const int64_t brow = (int64_t)idx[kl] * d.ldb;
+        if (avec) {
+            const f32x4 v = *(gfloat4_cp)(A + arow + mav);
+            a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = A[arow + mc[i]];
+        }
+        if (BF16) {
+            const gushort_cp Bh = (gushort_cp)d.B;
+            unsigned short h[4];
+            if (bvec) {
+                const u16x4 v = *(gushort4_cp)(Bh + brow + nbv);
+                h[0] = v.x, h[1] = v.y, h[2] = v.z, h[3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) h[j] = Bh[brow + nc[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = __builtin_bit_cast(float, (unsigned)h[j] << 16);
+        } else {
+            const gfloat_cp Bf = (gfloat_cp)d.B;
+            if (bvec) {
+                const f32x4 v = *(gfloat4_cp)(Bf + brow + nbv);
+                b[0] = v.x, b[1] = v.y, b[2] = v.z, b[3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = Bf[brow + nc[j]];
+            }
+        }
+    };
+    auto mma = [&](const float (&a0)[4], const float (&b0)[4], const float kf) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = a0[i] * kf, b[i] = b0[i] * kf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bsa[i] += a[i], bsb[i] += b[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // wavefront w takes k-steps ks_begin + w + 4 s; batches of WG_U steps, the next batch's loads issued before
+    // the current batch's MFMAs
+    const int ns = (max(0, ks_end - ks_begin) + 3) >> 2;
+    if (ns > 0) {
+        // software pipeline without a conditional around any load (hipcc drains vmcnt at the end of a conditional
+        // block that holds loads): batch b+1 is loaded unconditionally, batch b multiplied, registers rotated
+        float xa[WG_U][4], xb[WG_U][4], xk[WG_U];
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) load(ks_begin + w + 4 * u, xa[u], xb[u], xk[u]);
+        for (int s0 = WG_U; s0 < ns; s0 += WG_U) {
+            float ya[WG_U][4], yb[WG_U][4], yk[WG_U];
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) load(ks_begin + w + 4 * (s0 + u), ya[u], yb[u], yk[u]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads in front of the MFMAs
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) mma(xa[u], xb[u], xk[u]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u) {
+                xk[u] = yk[u];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xa[u][i] = ya[u][i], xb[u][i] = yb[u][i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < WG_U; ++u) mma(xa[u], xb[u], xk[u]);
+    }
+
+    // bias strips: sum over the 4 k-slots g, then over wavefronts (below)
+    const bool want_a = d.ones == 1 && tn == 0, want_b = d.ones == 2 && tm == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = want_b ? bsb[i] : bsa[i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) bred[w * 64 + 4 * r + i] = v;
+    }
+
+    float* const slab = slabs + (int64_t)(d.item_base + local) * WG_SLAB;
+    const bool direct = d.splits == 1;
+    const bool cvec = d.vec & 4;
+    auto store_c = [&](const int f4, const int h, const float4 v) {
+        const int ilq = f4 >> 6, ln = f4 & 63;
+        const int i = 2 * h + (ilq >> 2), q = ilq & 3;
+        const int m = m0 + 4 * (4 * (ln >> 4) + q) + i, n = n0 + 4 * (ln & 15);
+        if (m >= d.M || n >= d.N) return;
+        ERC_GLOBAL float* dst = (ERC_GLOBAL float*)d.C + (int64_t)m * d.ldc + n;
+        if (cvec) {
+            *(ERC_GLOBAL f32x4*)dst = (f32x4){v.x, v.y, v.z, v.w};
+        } else {
+            dst[0] = v.x;
+            if (n + 1 < d.N) dst[1] = v.y;
+            if (n + 2 < d.N) dst[2] = v.z;
+            if (n + 3 < d.N) dst[3] = v.w;
+        }
+    };
+    // in-workgroup reduction in two passes (output-row tiles i = 2h, 2h+1): 32 KB of LDS
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();  // pass 0: idx[] reads finished (red aliases nothing, but bred must be complete); pass 1: red reuse
+#pragma unroll
+        for (int il = 0; il < 2; ++il)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = 2 * h + il;
+                const float4 v = make_float4(acc[i][0][q], acc[i][1][q], acc[i][2][q], acc[i][3][q]);
+                *reinterpret_cast<float4*>(red + w * 2048 + ((il * 4 + q) * 64 + lane) * 4) = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int f4 = tid + 256 * u;
+            float4 s = *reinterpret_cast<const float4*>(red + f4 * 4);
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) {
+                const float4 t = *reinterpret_cast<const float4*>(red + ww * 2048 + f4 * 4);
+                s.x += t.x, s.y += t.y, s.z += t.z, s.w += t.w;
+            }
+            if (direct) {
+                store_c(f4, h, s);
+            } else {  // slab layout [h][u][component][thread]
+                float* q = slab + ((h * 2 + u) * 4) * 256 + tid;
+                st_sc1(q, s.x), st_sc1(q + 256, s.y), st_sc1(q + 512, s.z), st_sc1(q + 768, s.w);
+            }
+        }
+    }
+    if ((want_a || want_b) && tid < 64) {
+        const float v = bred[tid] + bred[64 + tid] + bred[128 + tid] + bred[192 + tid];
+        if (direct) {
+            const int c = (want_a ? m0 : n0) + tid;
+            if (c < (want_a ? d.M : d.N)) ((ERC_GLOBAL float*)d.bias_out)[c] = v;
+        } else {
+            st_sc1(slab + 4096 + tid, v);
+        }
+    }
+    if (direct) return;
+
+    // publish the partial tile; the workgroup that arrives last reduces the slabs in split order
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const counter = counters + d.tile_base + tile;
+    if (tid == 0) {
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == d.splits - 1;
+        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        *s_flag = last;
+    }
+    __syncthreads();
+    if (!*s_flag) return;
+    // 8 splits x 4 components in flight per thread (one dependent round trip per split would cost ~1 us each)
+    const float* const tile_slabs = slabs + (int64_t)(d.item_base + tile * d.splits) * WG_SLAB;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int sp0 = 0; sp0 < d.splits; sp0 += 8) {
+                float v[8][4], mk[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    mk[j] = sp0 + j < d.splits ? 1.f : 0.f;
+                    const float* p = tile_slabs + (int64_t)min(sp0 + j, d.splits - 1) * WG_SLAB + ((h * 2 + u) * 4) * 256 + tid;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[j][c] = ld_sc1(p + 256 * c);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s.x += v[j][0] * mk[j], s.y += v[j][1] * mk[j], s.z += v[j][2] * mk[j], s.w += v[j][3] * mk[j];
+            }
+            store_c(tid + 256 * u, h, s);
+        }
+    if ((want_a || want_b) && tid < 64) {
+        float v = 0.f;
+        for (int sp0 = 0; sp0 < d.splits; sp0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = ld_sc1(tile_slabs + (int64_t)min(sp0 + j, d.splits - 1) * WG_SLAB + 4096 + tid);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += t[j] * (sp0 + j < d.splits ? 1.f : 0.f);
+        }
+        const int c = (want_a ? m0 : n0) + tid;
+        if (c < (want_a ? d.M : d.N)) ((ERC_GLOBAL float*)d.bias_out)[c] = v;
+    }
+}
+
+struct WgBases {  // first work item of every descriptor, passed by value (no dependent table reads to find one's descriptor)
+    int v[WG_MAX_DESC];
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_table_kernel(const WgDesc* __restrict__ table, const int n_desc,
+                                                          const WgBases bases, const int item_offset, float* slabs,
+                                                          int* counters) {
+    __shared__ float red[4 * 2048];
+    __shared__ float bred[4 * 64];
+    __shared__ int idx[WG_IDX_CAP];
+    __shared__ int s_flag;
+    const int L = blockIdx.x + item_offset;
+    int di = 0;
+#pragma unroll
+    for (int t = 1; t < WG_MAX_DESC; ++t)
+        if (t < n_desc && L >= bases.v[t]) di = t;
+    const WgDesc d = table[di];
+    const int local = L - d.item_base;
+    if (local >= d.n_items) return;
+    const bool vec = (d.vec & 3) == 3;
+    if (d.b_bf16) {
+        if (vec) wgrad_body<true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+    } else {
+        if (vec) wgrad_body<false, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t erc_wgrad_slab_floats(void) { return WG_SLAB; }
+extern "C" int erc_wgrad_max_k_per_split(void) { return WG_IDX_CAP; }
+
+// table: n_desc WgDesc records (device memory); item_base: HOST array of the records' item_base fields; n_items = sum of tiles * splits; slabs: n_items * erc_wgrad_slab_floats()
+// floats; counters: one zero-initialised int32 per output tile (left zero by the launch).
+extern "C" int erc_wgrad_table(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                               int32_t* counters, void* stream) {
+    ERC_REQUIRE(table && item_base && n_desc > 0 && n_items > 0 && slabs && counters, "wgrad_table: bad arguments");
+    for (int t = 0; t < n_desc; ++t)
+        ERC_REQUIRE(item_base[t] >= 0 && item_base[t] < n_items && (t == 0 ? item_base[0] == 0 : item_base[t] > item_base[t - 1]),
+                    "wgrad_table: item_base[%d] = %d", t, item_base[t]);
+    // the kernel finds a block's descriptor from by-value bases: at most WG_MAX_DESC descriptors per launch
+    for (int t0 = 0; t0 < n_desc; t0 += WG_MAX_DESC) {
+        const int nd = n_desc - t0 < WG_MAX_DESC ? n_desc - t0 : WG_MAX_DESC;
+        WgBases bases{};
+        for (int t = 0; t < nd; ++t) bases.v[t] = item_base[t0 + t];
+        const int end = t0 + nd < n_desc ? item_base[t0 + nd] : n_items;
+        hipLaunchKernelGGL(wgrad_table_kernel, dim3(end - item_base[t0]), dim3(256), 0, (hipStream_t)stream,
+                           (const WgDesc*)table + t0, nd, bases, item_base[t0], slabs, counters);
+        ERC_LAUNCH_CHECK("wgrad_table");
+    }
+    return ERC_OK;
+}

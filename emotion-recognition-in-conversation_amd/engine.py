@@ -14,6 +14,8 @@
 """
 import math
 
+import os
+
 import torch
 
 from . import capi
@@ -84,26 +86,57 @@ class GemmPlanner:
         self.max_numel = 0
         self.deferred = []     # (A, lda, B, ldb, C, ldc, M, N, K, ones, bias_out): one batched launch at the end
 
-    def defer(self, A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out):
-        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out))
+    def defer(self, A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather=None):
+        """C[M,N] = A[K,M]^T B[gather(K),N] (+ bias strip); B may be the bf16 feature block."""
+        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather))
+
+    WG_STEPS = 96   # k-steps (4 k each) per work item: 24 per wavefront (measured best of 48..128 on COGMEN B=32)
 
     def flush_wgrads(self, cache):
-        """Run every deferred K-major x K-major weight-gradient product as ONE launch (erc_wgrad_table).  The
-        descriptor table is built on the first call and reused (operands live in fixed workspace buffers)."""
+        """Run every deferred K-major x K-major weight-gradient product as ONE launch (erc_wgrad_table, csrc/wgrad.hip).
+        The descriptor table, the partial-tile slabs and the per-tile arrival counters are built on the first call
+        and reused (operands live in fixed workspace buffers)."""
         if not self.deferred:
             return
         import struct
-        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K) for a, _, b, _, c, _, M, N, K, _, _ in self.deferred)
+        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, g.data_ptr() if g is not None else 0)
+                    for a, _, b, _, c, _, M, N, K, _, _, g in self.deferred)
         if cache.get("wgrad_key") != key:
-            raw = b"".join(struct.pack("<QQQQiiiiiiii", a.data_ptr(), b.data_ptr(), c.data_ptr(),
-                                       bo.data_ptr() if bo is not None else 0, lda, ldb, ldc, M, N, K, ones, 0)
-                           for a, lda, b, ldb, c, ldc, M, N, K, ones, bo in self.deferred)
-            cache["wgrad_table"] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            cap = capi.wgrad_max_k_per_split()
+            raw, items, tiles, bases = [], 0, 0, []
+            steps = int(os.environ.get("ERC_WG_STEPS", self.WG_STEPS))
+            for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g in self.deferred:
+                bf16 = b.dtype == torch.bfloat16
+                if a.dtype != torch.float32 or c.dtype != torch.float32 or (not bf16 and b.dtype != torch.float32):
+                    raise capi.ErcGraftError("wgrad table: operand dtypes %s %s %s" % (a.dtype, b.dtype, c.dtype))
+                nks = -(-K // 4)
+                splits = max(1, min(32, (nks + steps // 2) // steps))
+                splits = max(splits, -(-K // cap))
+                per = -(-nks // splits)
+                splits = -(-nks // per)                       # no empty split
+                if per * 4 > cap:
+                    raise capi.ErcGraftError("wgrad table: K=%d needs more than 32 splits" % K)
+                tm, tn = -(-M // 64), -(-N // 64)
+                vec = (1 if (M % 4 == 0 and lda % 4 == 0 and a.data_ptr() % 16 == 0) else 0) \
+                    | (2 if (N % 4 == 0 and ldb % 4 == 0 and b.data_ptr() % (8 if bf16 else 16) == 0) else 0) \
+                    | (4 if (N % 4 == 0 and ldc % 4 == 0 and c.data_ptr() % 16 == 0) else 0)
+                n_it = tm * tn * splits
+                raw.append(struct.pack("<QQQQQ14i", a.data_ptr(), b.data_ptr(), c.data_ptr(),
+                                       bo.data_ptr() if bo is not None else 0, g.data_ptr() if g is not None else 0,
+                                       lda, ldb, ldc, M, N, K, ones if bo is not None else 0, int(bf16), splits, tn,
+                                       items, n_it, tiles, vec))
+                bases.append(items)
+                items += n_it
+                tiles += tm * tn
+            cache["wgrad_table"] = torch.frombuffer(bytearray(b"".join(raw)), dtype=torch.uint8).to(self.device)
+            cache["wgrad_slabs"] = torch.empty(items * capi.wgrad_slab_floats(), dtype=torch.float32, device=self.device)
+            cache["wgrad_counters"] = torch.zeros(tiles, dtype=torch.int32, device=self.device)
+            cache["wgrad_items"] = items
+            import ctypes
+            cache["wgrad_bases"] = (ctypes.c_int32 * len(bases))(*bases)
             cache["wgrad_key"] = key
-            cache["wgrad_max"] = (max(M + (1 if o == 2 else 0) for _, _, _, _, _, _, M, _, _, o, _ in self.deferred),
-                                  max(N + (1 if o == 1 else 0) for _, _, _, _, _, _, _, N, _, o, _ in self.deferred))
-        mm, mn = cache["wgrad_max"]
-        capi.wgrad_table(cache["wgrad_table"], len(self.deferred), mm, mn)
+        capi.wgrad_table(cache["wgrad_table"], len(self.deferred), cache["wgrad_bases"], cache["wgrad_items"],
+                         cache["wgrad_slabs"], cache["wgrad_counters"])
 
     def split_for(self, M, N, K, bk=None, min_chunks=None):
         if N <= 1025 and bk is None:
@@ -170,17 +203,17 @@ def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off
     want_b = b_off is not None
     if slab is None:
         S = pl.split_for(n_out, n_in + 1, n_rows, bk=64 if x_bf16 else None, min_chunks=2)
-        direct = S == 1 and pl.grad is not None and not force_slab and not x_bf16
+        direct = pl.grad is not None and not force_slab and (defer or (S == 1 and not x_bf16))
         slab = ("direct", w_off, ld_w) if direct else (pl.take(S * n_out * ld_w), S, ld_w)
         if not direct and w_off is not None:
             pl.add_job(slab[0], n_out * ld_w, S, n_out * ld_w, w_off)
     if slab[0] == "direct":
         _, base, ld_w = slab
-        if x_bf16:
-            raise capi.ErcGraftError("bf16 column slice into a directly written gradient: pass force_slab=True")
-        if gather is None and defer:
+        if defer:
             pl.defer(dy, lddy, x, ldx, pl.grad[base + col_off:], ld_w, n_out, n_in, n_rows, 1 if want_b else 0,
-                     pl.grad[b_off:] if want_b else None)
+                     pl.grad[b_off:] if want_b else None, gather=gather)
+        elif x_bf16:
+            raise capi.ErcGraftError("bf16 column slice into a directly written gradient: pass force_slab=True")
         else:
             capi.gemm_f32(dy, lddy, 1, None, x, ldx, 1, gather, pl.grad[base + col_off:], ld_w, n_out, n_in, n_rows,
                           ones_col=1 if want_b else 0, bias_out=pl.grad[b_off:] if want_b else None)
@@ -205,7 +238,7 @@ def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off, def
     """dW[n_in,n_out] = x^T dy and db[n_out] = colsum(dy) for [in,out]-stored weights (PyG RGCNConv, GCNII)."""
     want_b = b_off is not None
     S = pl.split_for(n_in + 1, n_out, n_rows, min_chunks=2)
-    if S == 1 and pl.grad is not None:
+    if (S == 1 or defer) and pl.grad is not None:
         if defer:
             pl.defer(x, ldx, dy, lddy, pl.grad[w_off:], n_out, n_in, n_out, n_rows, 2 if want_b else 0,
                      pl.grad[b_off:] if want_b else None)

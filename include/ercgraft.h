@@ -114,12 +114,24 @@ int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_
                         int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
                         const float* bias, int act, const float* aux, int ldaux, float act_scale,
                         float drop_p, const uint64_t* rng_state, int accumulate, void* stream);
-/* Batched weight gradients: n independent products C_i[M_i,N_i] = A_i^T B_i (A_i [K,M_i], B_i [K,N_i], both
- * K-major fp32, same contract as erc_gemm_f32 with a_kmajor = b_kmajor = 1 and the ones_col bias trick) in ONE
- * launch.  `table` is a device array of n 64-byte records
- *   { const float* A, B; float* C, bias_out; int32 lda, ldb, ldc, M, N, K, ones, pad; }
- * max_m / max_n = largest M_i (+1 if ones = 2) / N_i (+1 if ones = 1). */
-int erc_wgrad_table(const void* table, int n_problems, int max_m, int max_n, void* stream);
+/* Batched weight gradients (autograd of every nn.Linear / matmul weight behind loss.backward(),
+ * track_mm/cogmen.py:187-189, dagerc.py:228-231, mmgcn.py:150-152, dgcn.py:127-129): n_desc independent products
+ * C_i[M_i,N_i] = A_i^T B_i[gather_i] in ONE launch.  A_i [K,M_i] fp32 K-major; B_i [*,N_i] K-major, fp32 or bf16 (the
+ * feature block), optionally row-gathered; bias strip: ones = 1 -> bias_out[m] = sum_k A[k][m], ones = 2 ->
+ * bias_out[n] = sum_k B[k][n].  64 x 64 tiles, K split over `splits` workgroups per tile; partial tiles are summed in
+ * split order by the last-arriving workgroup (deterministic).  `table` is a device array of n_desc 96-byte records
+ *   { const float* A; const void* B; float* C; float* bias_out; const int32_t* b_gather;
+ *     int32 lda, ldb, ldc, M, N, K, ones, b_bf16, splits, tiles_n, item_base, n_items, tile_base, vec; }
+ * with tiles_n = ceil(N/64), n_items = ceil(M/64)*tiles_n*splits, item_base / tile_base = running sums over the
+ * previous records, ceil(ceil(K/4)/splits)*4 <= erc_wgrad_max_k_per_split(), no empty split, and vec bit0/1/2 set
+ * when 16-byte (bf16: 8-byte) vector access to A / B / C is legal (M resp. N, the pitch and the base all multiples of
+ * 4 elements).  item_base: HOST copy of the records' item_base fields (passed to the kernel by value, 32 records
+ * per launch); n_items = sum of the records' n_items; slabs: n_items * erc_wgrad_slab_floats() floats of scratch;
+ * counters: one int32 per output tile, zero before the first launch (every launch leaves them zero). */
+int erc_wgrad_table(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                    int32_t* counters, void* stream);
+int64_t erc_wgrad_slab_floats(void);
+int erc_wgrad_max_k_per_split(void);
 
 /* Forward input projection on a bf16 feature block: C[M,N] = act(X[gather(m), :K] W[N,K]^T + bias), X bf16,
  * W either fp32 (rounded to bf16 while loaded) or a bf16 shadow copy (w_is_bf16; see erc_adam_step), fp32

@@ -420,3 +420,45 @@ def test_fused_adam_matches_torch(capi, decoupled, wd, clip):
         capi.adam_step(p, gd, m, v, n, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, 1.0, clip, gnorm if clip > 0 else None, state)
         _close(p, ref.detach(), 2e-6, 1e-5)
     assert state.cpu().tolist() == [4, 4, 1, 0]
+
+
+def test_wgrad_table(capi):
+    """erc_wgrad_table: several dW = A^T B[gather] products in one launch (fp32 / bf16 B, bias strips, vector and
+    scalar access paths, split and unsplit K), launched twice to check that the arrival counters are left zero."""
+    from erc_amd.engine import GemmPlanner
+    g = torch.Generator().manual_seed(77)
+    cases = [  # K, M, N, ones, gather, bf16
+        (1982, 100, 1380, 1, True, True),
+        (1982, 900, 100, 2, False, False),
+        (1982, 400, 100, 1, False, False),
+        (1982, 6, 100, 1, False, False),
+        (333, 100, 1380, 1, True, False),
+        (61, 7, 13, 2, False, False),
+        (9000, 68, 72, 1, True, True),
+        (3, 100, 100, 1, False, False),
+    ]
+    pl = GemmPlanner(DEV, 16)
+    refs = []
+    for K, M, N, ones, gather, bf16 in cases:
+        A = torch.randn(K, M, generator=g).to(DEV)
+        rows_b = K + 50 if gather else K
+        Bm = torch.randn(rows_b, N, generator=g)
+        if bf16:
+            Bm = Bm.bfloat16()
+        gi = torch.randperm(rows_b, generator=g)[:K].int().to(DEV) if gather else None
+        Bd = Bm.to(DEV)
+        Cm = torch.full((M, N), float("nan"), device=DEV)
+        bo = torch.full((M if ones == 1 else N,), float("nan"), device=DEV)
+        pl.defer(A, M, Bd, N, Cm, N, M, N, K, ones, bo, gather=gi)
+        Bg = Bm.float()[gi.cpu().long()] if gather else Bm.float()
+        refs.append((Cm, bo, _gemm_ref(A.cpu().t(), Bg), (A.cpu() if ones == 1 else Bg).double().sum(0).float(), K))
+    cache = {}
+    for rep in range(2):
+        pl.flush_wgrads(cache)
+        torch.cuda.synchronize()
+        assert int(cache["wgrad_counters"].abs().sum()) == 0
+        for Cm, bo, ref, bref, K in refs:
+            tol = 3e-4 * math.sqrt(max(K, 100) / 100)
+            _close(Cm, ref, tol)
+            _close(bo, bref, tol)
+            Cm.fill_(float("nan")), bo.fill_(float("nan"))
