@@ -27,6 +27,12 @@ _SIGS = {
     "erc_gemm_bf16a_stream": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "erc_wgrad_table": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_slab_floats": (C.c_int64, []),
+    "erc_bn_batch_stats_ws_floats": (C.c_int64, [_i]),
+    "erc_bn_batch_stats": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "erc_head_fused_ws_floats": (C.c_int64, [_i]),
+    "erc_head_fused": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "erc_bn_bwd_apply": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_wgrad_max_k_per_split": (C.c_int, []),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
                                  _i64, _vp]),
@@ -395,6 +401,28 @@ def wgrad_table(table, n_desc, item_base, n_items, slabs, counters):
     """item_base: ctypes int32 array (host) with the first work item of every descriptor."""
     _check(lib().erc_wgrad_table(ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), stream()),
            "erc_wgrad_table")
+
+
+def bn_batch_stats_ws_floats(F):
+    return int(lib().erc_bn_batch_stats_ws_floats(F))
+
+
+def bn_batch_stats(x, ldx, N, F, running_mean, running_var, momentum, eps, saved, ws):
+    _call("erc_bn_batch_stats", x, ldx, N, F, running_mean, running_var, float(momentum), float(eps), saved, ws)
+
+
+def head_fused_ws_floats(n_rows):
+    return int(lib().erc_head_fused_ws_floats(n_rows))
+
+
+def head_fused(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
+               H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws):
+    _call("erc_head_fused", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
+          float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws)
+
+
+def bn_bwd_apply(x, ldx, N, F, gamma, saved, bn_bwd, dY, lddy, dx, lddx):
+    _call("erc_bn_bwd_apply", x, ldx, N, F, gamma, saved, bn_bwd, dY, lddy, dx, lddx)
 
 
 def wgrad_slab_floats():

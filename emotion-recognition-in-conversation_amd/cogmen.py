@@ -85,6 +85,7 @@ class COGMENModule(nn.Module):
         self.gcn = _GNNParams(hidden_size, hidden_size, hidden_size)
         self.cls = nn.Sequential(nn.Linear(100, 100), nn.ReLU(), nn.Dropout(p=0.5), nn.Linear(100, n_classes))
         self.drop_p = 0.5
+        self.fuse_head = True   # training path: csrc/head.hip instead of separate BN / Linear / CE launches
         self.flat = None
         self._ws = {}
         self._seed = seed
@@ -136,6 +137,8 @@ class COGMENModule(nn.Module):
             H0=f32(N, F), M=f32(N, 9 * F), inv_cnt=f32(N, N_REL), H1=f32(N, F), QKVS=f32(N, 4 * F),
             alpha=f32(E), H2=f32(N, F), H3=f32(N, F), Z=f32(N, F), logits=f32(N, C),
             bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=torch.zeros(1024, dtype=torch.float32, device=device),
+            bn_stats_ws=torch.zeros(capi.bn_batch_stats_ws_floats(F), dtype=torch.float32, device=device),
+            head_ws=torch.zeros(capi.head_fused_ws_floats(N), dtype=torch.float32, device=device), bn_bwd=f32(2 * F),
             dlogits=f32(N, C), dZ=f32(N, F), dH3=f32(N, F), dH2=f32(N, F), dQKVS=f32(N, 4 * F), dscore=f32(E),
             dH1=f32(N, F), dM=f32(N, 9 * F), dH0=f32(N, F),
         )
@@ -155,7 +158,7 @@ class COGMENModule(nn.Module):
             N = int(text_length.sum().item())
         return B, T, N
 
-    def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training, with_logits=True):
+    def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training, upto_h2=False):
         fp, dev = self.flat, x.device
         ws = self._workspace(B, T, N, dev)
         g, pl = ws["g"], ws["planner"]
@@ -181,6 +184,8 @@ class COGMENModule(nn.Module):
         linear_fwd(pl, ws["H1"], F, None, fp.w("gcn.conv2.lin_query.weight"), fp.w("gcn.conv2.lin_query.bias"),
                    ws["QKVS"], 4 * F, N, 4 * F, F)
         capi.tconv_attn_fwd(ws["QKVS"], 4 * F, F, N, 1.0 / math.sqrt(F), g, ws["H2"], F, ws["alpha"])
+        if upto_h2:      # the training path runs everything behind H2 in the fused head kernel
+            return ws
         bn = self.gcn.bn
         capi.bn_lrelu_fwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), bn.running_mean,
                           bn.running_var, bn.momentum, bn.eps, 0.01, training, ws["bn_saved"], ws["H3"], F,
@@ -188,8 +193,7 @@ class COGMENModule(nn.Module):
         p = self.drop_p if training else 0.0
         linear_fwd(pl, ws["H3"], F, None, fp.w("cls.0.weight"), fp.w("cls.0.bias"), ws["Z"], F, N, F, F,
                    act=3 if p > 0 else 1, drop_p=p, rng=self.rng_state)
-        if with_logits:   # the training path computes them inside the fused head_ce kernel instead
-            linear_fwd(pl, ws["Z"], F, None, fp.w("cls.3.weight"), fp.w("cls.3.bias"), ws["logits"], C, N, C, F)
+        linear_fwd(pl, ws["Z"], F, None, fp.w("cls.3.weight"), fp.w("cls.3.bias"), ws["logits"], C, N, C, F)
         return ws
 
     def forward(self, input_tensor, speaker_tensor, text_length, *args, label=None, **kwargs):
@@ -206,16 +210,22 @@ class COGMENModule(nn.Module):
         x, spk, lens, ys = batch["input_tensor"], batch["speaker_tensor"], batch["text_length"], batch["label"]
         B, T, N = self._shape(x, lens, ys)
         training = self.training
-        fused_head = self.n_classes <= 8
-        ws = self._forward_impl(x, spk, lens, B, T, N, training, with_logits=not fused_head)
-        fp, g, pl = self.flat, ws["g"], ws["planner"]
         F, C, D = F_HID, self.n_classes, self.input_size
+        # fused head (csrc/head.hip): BatchNorm apply .. cross entropy .. BatchNorm-backward sums in one launch
+        fused_head = self.fuse_head and training and C <= 8 and F % 4 == 0 and F <= 100
+        ws = self._forward_impl(x, spk, lens, B, T, N, training, upto_h2=fused_head)
+        fp, g, pl = self.flat, ws["g"], ws["planner"]
         x_bf16 = x.dtype == torch.bfloat16
         p = self.drop_p if training else 0.0
-        # head: logits + cross entropy + gradient through relu/dropout into Z
+        bn = self.gcn.bn
         if fused_head:
-            capi.head_ce(ws["Z"], F, F, C, N, fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys, class_weight,
-                         1.0 / (1.0 - p), ws["logits"], C, ws["dlogits"], C, ws["dZ"], F, ws["stats"])
+            capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
+                                ws["bn_stats_ws"])
+            capi.head_fused(ws["H2"], F, N, F, C, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
+                            fp.w("cls.0.weight"), fp.w("cls.0.bias"), fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys,
+                            class_weight, p, self.rng_state if p > 0 else None, ws["H3"], ws["Z"], ws["logits"],
+                            ws["dlogits"], ws["dZ"], ws["dH3"], ws["bn_bwd"], fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"),
+                            ws["stats"], ws["head_ws"])
         else:
             capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
             capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
@@ -223,13 +233,17 @@ class COGMENModule(nn.Module):
         with self.side.fork():
             linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
                          fp.offsets["cls.3.bias"], defer=True)
-        capi.gemm_f32(ws["dZ"], F, 0, None, fp.w("cls.0.weight"), F, 1, None, ws["dH3"], F, N, F, F)
         with self.side.fork():
             linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
                          fp.offsets["cls.0.bias"], defer=True)
-        # BatchNorm + LeakyReLU
-        capi.bn_lrelu_bwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
-                          ws["dH3"], F, ws["dH2"], F, fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"), ws["bn_ws"])
+        if fused_head:
+            capi.bn_bwd_apply(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["dH3"], F,
+                              ws["dH2"], F)
+        else:
+            capi.gemm_f32(ws["dZ"], F, 0, None, fp.w("cls.0.weight"), F, 1, None, ws["dH3"], F, N, F, F)
+            # BatchNorm + LeakyReLU
+            capi.bn_lrelu_bwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
+                              ws["dH3"], F, ws["dH2"], F, fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"), ws["bn_ws"])
         # TransformerConv
         capi.tconv_attn_bwd(ws["QKVS"], 4 * F, F, N, 1.0 / math.sqrt(F), g, ws["alpha"], ws["dH2"], F,
                             ws["dQKVS"], ws["dscore"])

@@ -1,0 +1,541 @@
+// K5: the classifier head of COGMEN as one row-tile kernel.
+//
+//   H3 = LeakyReLU(BatchNorm(H2))                      gcn.bn + leaky_relu      track_mm/cogmen.py:67-68,72-73
+//   Z  = Dropout(ReLU(H3 W0^T + b0))                   cls[0..2]                track_mm/cogmen.py:116-121
+//   logits = Z W3^T + b3 ; loss = cross_entropy        cls[3], F.cross_entropy  track_mm/cogmen.py:122,185
+//   and the backward of all of it down to dY = dL/d(BatchNorm output), plus the two column sums BatchNorm's
+//   backward needs (sum dY, sum dY*xhat) -- what loss.backward() does for these layers (cogmen.py:187-188).
+//
+// Given the batch statistics, every row is independent until BatchNorm's backward reduction, so a 16-row tile goes
+// through the whole chain on chip: two 16x100x100 products on v_mfma_f32_16x16x4_f32 (W0 staged once per workgroup in
+// LDS, read row-wise for the forward and column-wise for the backward), the 100 -> C product and its transpose on the
+// VALU straight from the MFMA accumulator layout, one LDS transposition of the 16 x 100 dZ tile between the MFMA
+// products.  The 7 column tiles of a row tile are spread over 4 wavefronts (a single wavefront per row tile measured
+// 40 us: ~8000 instructions of serial VALU work); they meet in the 8-wide class space through LDS.  Replaces five launches (BN apply, Linear, Linear+CE, dgrad Linear,
+// BN-backward statistics); the activations the weight-gradient launch needs (H3, Z, dZ, dlogits) are written once.
+//
+// Cross-workgroup sums (BatchNorm backward, loss, accuracy): per-workgroup partials written with write-through (sc1)
+// stores, an arrival counter, and the last workgroup adds them in workgroup order in fp64 -- deterministic, no fences.
+#include "erc_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HF_S = 108;      // LDS row pitch in floats: 16-byte aligned rows, 108 mod 64 = 44 -> conflict-free b128 rows
+constexpr int HF_ST = 116;     // pitch of the dZ row tiles: >= 112 (7 full column tiles are written), 116 mod 64 = 52
+constexpr int HF_NT = 7;       // column tiles of 16 (F <= 100 -> 7 tiles, the last one partial)
+constexpr int HF_MAXF = 100;
+constexpr int HF_MAXC = 8;
+constexpr int HF_PART = 2 * 112 + 2;  // floats per workgroup partial record
+constexpr int BS_G = 64;       // workgroups of the statistics pass
+
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1d(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1d(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training-mode BatchNorm statistics: column mean / rstd of x [N,F] into saved[2F], running statistics updated
+// (torch.nn.BatchNorm1d, cogmen.py:67).  One launch: fp64 partials per workgroup, finalised by the last arriver.
+__global__ __launch_bounds__(256) void bn_batch_stats_kernel(const float* __restrict__ x, int ldx, int N, int F,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var, float momentum, float eps,
+                                                             float* __restrict__ saved, double* partial, int* counter) {
+    __shared__ double sh[2][128];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, c = tid & 127, half = tid >> 7;
+    const int cc = min(c, F - 1);
+    double a = 0.0, b = 0.0;
+    // rows blockIdx*2 + half + 2G*i: eight unconditional (row-clamped, masked by multiplication) loads in flight
+    const int stride = 2 * (int)gridDim.x;
+    for (int row0 = (int)blockIdx.x * 2 + half; row0 < N; row0 += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = x[(int64_t)min(row0 + j * stride, N - 1) * ldx + cc];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double t = (double)v[j] * (row0 + j * stride < N ? 1.0 : 0.0);
+            a += t, b += t * t;
+        }
+    }
+    if (half == 1) sh[0][c] = a, sh[1][c] = b;
+    __syncthreads();
+    if (half == 0 && c < F) {
+        st_sc1d(partial + (int64_t)blockIdx.x * 2 * F + c, a + sh[0][c]);
+        st_sc1d(partial + (int64_t)blockIdx.x * 2 * F + F + c, b + sh[1][c]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // thread (c, half): half 0 sums x, half 1 sums x^2, over the workgroups in order, 8 loads in flight
+    double s = 0.0;
+    if (c < F) {
+        const int G = (int)gridDim.x;
+        for (int g0 = 0; g0 < G; g0 += 32) {
+            double t[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) t[j] = ld_sc1d(partial + (int64_t)min(g0 + j, G - 1) * 2 * F + half * F + c);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) s += t[j] * (g0 + j < G ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    sh[half][c] = s;
+    __syncthreads();
+    if (half == 0 && c < F) {
+        const double m = sh[0][c] / (double)N;
+        double var = sh[1][c] / (double)N - m * m;
+        if (var < 0.0) var = 0.0;
+        saved[c] = (float)m;
+        saved[F + c] = (float)(1.0 / sqrt(var + (double)eps));
+        const double unbiased = N > 1 ? var * (double)N / (double)(N - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct HeadP {
+    const float* H2;
+    const float* gamma;
+    const float* beta;
+    const float* saved;  // [0,F) mean, [F,2F) rstd of the batch
+    const float* W0;
+    const float* b0;
+    const float* W3;
+    const float* b3;
+    const int64_t* labels;
+    const float* weight;  // class weights or null
+    const uint64_t* rng;  // {offset, seed}, read when drop_p > 0
+    float* H3;
+    float* Z;
+    float* logits;
+    float* dlogits;
+    float* dZ;
+    float* dY;
+    float* part;
+    int* counter;
+    float* bn_bwd;  // [0,F) mean of dY, [F,2F) mean of dY*xhat
+    float* dgamma;
+    float* dbeta;
+    float* stats;
+    float slope, drop_p;
+    int ldh, N, F, C;
+};
+
+// DPP lane exchanges inside a row of 16 lanes (VALU, no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_X1 = 0xB1, DPP_X2 = 0x4E, DPP_HMIR = 0x141, DPP_MIR = 0x140;  // quad_perm xor 1 / xor 2, row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {  // total over the 16 lanes r, in every lane
+    v += dpp_f<DPP_X1>(v), v += dpp_f<DPP_X2>(v), v += dpp_f<DPP_HMIR>(v), v += dpp_f<DPP_MIR>(v);
+    return v;
+}
+__device__ __forceinline__ float row8_sum(float v) {  // total over each half row of 8 lanes
+    v += dpp_f<DPP_X1>(v), v += dpp_f<DPP_X2>(v), v += dpp_f<DPP_HMIR>(v);
+    return v;
+}
+__device__ __forceinline__ float row8_max(float v) {
+    v = fmaxf(v, dpp_f<DPP_X1>(v)), v = fmaxf(v, dpp_f<DPP_X2>(v)), v = fmaxf(v, dpp_f<DPP_HMIR>(v));
+    return v;
+}
+__device__ __forceinline__ float row8_min(float v) {
+    v = fminf(v, dpp_f<DPP_X1>(v)), v = fminf(v, dpp_f<DPP_X2>(v)), v = fminf(v, dpp_f<DPP_HMIR>(v));
+    return v;
+}
+
+// Workgroup = 8 wavefronts = 32 rows: wavefront w works on row tile rt = w >> 2 (16 rows) and column tiles
+// nt = 2 (w & 3), 2 (w & 3) + 1 of the 7; the class-space quantities (8 wide) are exchanged through LDS.
+__global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
+    __shared__ __attribute__((aligned(16))) float sW[HF_MAXF * HF_S];  // W0, row pitch HF_S
+    __shared__ __attribute__((aligned(16))) float sT[2][16 * HF_ST];    // dZ row tiles (transposition between the MFMA products); sT[0] first holds sLg
+    __shared__ __attribute__((aligned(16))) float sD[2][16][8];  // dlogits of the two row tiles
+    __shared__ float sCol[2][2][112];
+    __shared__ float sLoss[2][2];
+    __shared__ double sRed[8];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rt = w >> 2, cq = w & 3;
+    const int r = lane & 15, g = lane >> 4;
+    const int F = p.F, C = p.C, N = p.N;
+    float* const sLg = &sT[0][0];  // [rt][cq][16 rows][8 classes] partial logits, dead before sT is written
+
+    // ---- stage W0 (F x F) into LDS: F*F/4 <= 2500 float4 over 512 threads, all loads in flight
+    {
+        const int nq = F * F / 4, per_row = F / 4;
+        f32x4 v[5];
+        int dst[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = min(j * 512 + tid, nq - 1);
+            const int row = i / per_row, q = i - row * per_row;
+            v[j] = *reinterpret_cast<const f32x4*>(p.W0 + (int64_t)row * F + 4 * q);
+            dst[j] = row * HF_S + 4 * q;
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            if (j * 512 + tid < nq) *reinterpret_cast<f32x4*>(sW + dst[j]) = v[j];
+    }
+    // ---- cross-entropy normaliser: sum of the class weights of all rows (every workgroup computes it)
+    if (p.weight) {
+        double wacc = 0.0;
+        for (int i0 = 0; i0 < N; i0 += 4 * 512) {
+            int y[4];
+            float wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (int)p.labels[min(i0 + j * 512 + tid, N - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = p.weight[y[j]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wacc += (double)wv[j] * (i0 + j * 512 + tid < N ? 1.0 : 0.0);
+        }
+        wacc = wave_sum_d(wacc);
+        if (lane == 0) sRed[w] = wacc;
+    }
+
+    // ---- P1: A fragments of H3 = lrelu(bn(H2)); lane (r,g): row m0 + r, k = 16 kb + 4 g + t
+    const int m0 = ((int)blockIdx.x * 2 + rt) * 16;
+    const int mrow = m0 + r, mrc = min(mrow, N - 1);
+    float a1[HF_NT][4];
+#pragma unroll
+    for (int kb = 0; kb < HF_NT; ++kb) {
+        const int k0 = 16 * kb + 4 * g;
+        const bool kv = k0 < F;
+        const int k0c = kv ? k0 : 0;
+        const float km = kv ? 1.f : 0.f;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(p.H2 + (int64_t)mrc * p.ldh + k0c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.saved + k0c), rs = *reinterpret_cast<const f32x4*>(p.saved + F + k0c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + k0c), be = *reinterpret_cast<const f32x4*>(p.beta + k0c);
+        f32x4 h;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float z = (x[t] - mu[t]) * rs[t] * ga[t] + be[t];
+            h[t] = (z > 0.f ? z : z * p.slope);
+            a1[kb][t] = h[t] * km;
+        }
+        if ((kb & 3) == cq && mrow < N && kv) *reinterpret_cast<f32x4*>(p.H3 + (int64_t)mrow * F + k0) = h;
+    }
+    // operands of the later phases, requested now so that their latency hides behind the first MFMA product
+    int ylab[4];
+    float wyq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ylab[q] = (int)p.labels[min(m0 + 4 * g + q, N - 1)];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wyq[q] = p.weight ? p.weight[ylab[q]] : 1.f;
+    int colc[2];
+    float cm[2], x6[2][4], mu6[2], rs6[2], ga6[2], be6[2], b0c[2], w3[HF_MAXC][2];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int col = 16 * (2 * cq + jn) + r;
+        colc[jn] = min(col, F - 1);
+        cm[jn] = col < F ? 1.f : 0.f;
+        mu6[jn] = p.saved[colc[jn]], rs6[jn] = p.saved[F + colc[jn]], ga6[jn] = p.gamma[colc[jn]], be6[jn] = p.beta[colc[jn]];
+        b0c[jn] = p.b0[colc[jn]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x6[jn][q] = p.H2[(int64_t)min(m0 + 4 * g + q, N - 1) * p.ldh + colc[jn]];
+#pragma unroll
+        for (int c = 0; c < HF_MAXC; ++c) w3[c][jn] = p.W3[(int64_t)min(c, C - 1) * F + colc[jn]] * cm[jn] * (c < C ? 1.f : 0.f);
+    }
+    const int cr = r & 7;
+    const float b3c = p.b3[min(cr, C - 1)];
+    __syncthreads();  // sW, sRed complete
+    double wsum = (double)N;
+    if (p.weight) {
+        wsum = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wsum += sRed[j];
+    }
+    const float inv_w = (float)(1.0 / wsum);
+
+    // ---- P2: Z = dropout(relu(H3 W0^T + b0)) for this wavefront's column tiles; rows m0 + 4g + q, columns 16 nt + r
+    float zreg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const float scale = 1.f / (1.f - p.drop_p);
+    uint64_t rng_off = 0, rng_seed = 0;
+    if (p.drop_p > 0.f) rng_off = p.rng[0], rng_seed = p.rng[1];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int nt = 2 * cq + jn;
+        if (nt < HF_NT) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < HF_NT; ++kb) {
+                const int k0 = 16 * kb + 4 * g;
+                const int k0c = k0 < F ? k0 : 0;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(sW + colc[jn] * HF_S + k0c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb][t], wv[t], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + 4 * g + q;
+                float z = fmaxf(acc[q] + b0c[jn], 0.f);
+                if (p.drop_p > 0.f) {
+                    const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)F + (uint64_t)(16 * nt + r));
+                    z = (u >= p.drop_p) ? z * scale : 0.f;
+                }
+                z *= cm[jn];
+                zreg[jn][q] = z;
+                if (row < N && 16 * nt + r < F) p.Z[(int64_t)row * F + 16 * nt + r] = z;
+            }
+        }
+    }
+
+    // ---- P3a: this wavefront's share of the logits: dot products over its columns, summed over the 16 lanes r
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float mine = 0.f;
+#pragma unroll
+        for (int c = 0; c < HF_MAXC; ++c) {
+            const float s = row16_sum(zreg[0][q] * w3[c][0] + zreg[1][q] * w3[c][1]);
+            if (c == cr) mine = s;
+        }
+        if (r < 8) sLg[((rt * 4 + cq) * 16 + 4 * g + q) * 8 + cr] = mine;
+    }
+    __syncthreads();
+    // ---- P3b: cross entropy with one class per lane (lanes r and r + 8 duplicate); rows 4g + q
+    float lsum = 0.f, hsum = 0.f;
+    const bool cv = cr < C;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = m0 + 4 * g + q;
+        const bool rv = row < N;
+        float v = b3c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += sLg[((rt * 4 + j) * 16 + 4 * g + q) * 8 + cr];
+        const float mx = row8_max(cv ? v : -3.0e38f);
+        const float se = row8_sum(cv ? expf(v - mx) : 0.f);
+        const float lse = mx + logf(se);
+        const int y = ylab[q];
+        const float coef = rv ? wyq[q] * inv_w : 0.f;
+        const float dq = cv ? coef * (expf(v - lse) - (cr == y ? 1.f : 0.f)) : 0.f;
+        const float ly = row8_sum(cr == y ? v : 0.f);
+        const float am = row8_min((cv && v == mx) ? (float)cr : 99.f);
+        if (cq == 0) {
+            if (r < 8) sD[rt][4 * g + q][cr] = dq;
+            if (rv && r < C) {
+                p.logits[(int64_t)row * C + r] = v;
+                p.dlogits[(int64_t)row * C + r] = dq;
+            }
+            if (rv && r == 0) lsum += wyq[q] * (lse - ly), hsum += ((int)am == y) ? 1.f : 0.f;
+        }
+    }
+    if (cq == 0) {
+        lsum = wave_sum(lsum), hsum = wave_sum(hsum);
+        if (lane == 0) sLoss[rt][0] = lsum, sLoss[rt][1] = hsum;
+    }
+    __syncthreads();
+
+    // ---- P4: dZ = (dlogits W3) * relu/dropout mask for this wavefront's columns; into the row tile in LDS
+    float* const tile = sT[rt];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 dlo = *reinterpret_cast<const f32x4*>(&sD[rt][4 * g + q][0]);
+        const f32x4 dhi = *reinterpret_cast<const f32x4*>(&sD[rt][4 * g + q][4]);
+        const int row = m0 + 4 * g + q;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int nt = 2 * cq + jn;
+            if (nt < HF_NT) {
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s += dlo[c] * w3[c][jn];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s += dhi[c] * w3[4 + c][jn];
+                const float dz = zreg[jn][q] > 0.f ? s * scale : 0.f;
+                if (row < N && 16 * nt + r < F) p.dZ[(int64_t)row * F + 16 * nt + r] = dz;
+                tile[(4 * g + q) * HF_ST + 16 * nt + r] = dz;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- P5: dH3 = dZ W0 : A fragments from the transposed tile, B[k = j][n = i] = W0[j][i] read column-wise from LDS
+    float a2[HF_NT][4];
+#pragma unroll
+    for (int kb = 0; kb < HF_NT; ++kb) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * HF_ST + 16 * kb + 4 * g);  // columns >= F hold zeros
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a2[kb][t] = v[t];
+    }
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int nt = 2 * cq + jn;
+        if (nt < HF_NT) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < HF_NT; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int jc = min(16 * kb + 4 * g + t, F - 1);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kb][t], sW[jc * HF_S + colc[jn]], acc, 0, 0, 0);
+                }
+            // ---- P6: dY = dH3 * lrelu'(bn output), BatchNorm-backward column partials
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + 4 * g + q;
+                const bool ok = row < N && 16 * nt + r < F;
+                const float xh = (x6[jn][q] - mu6[jn]) * rs6[jn];
+                const float zz = xh * ga6[jn] + be6[jn];
+                const float dy = ok ? acc[q] * (zz > 0.f ? 1.f : p.slope) : 0.f;
+                if (ok) p.dY[(int64_t)row * F + 16 * nt + r] = dy;
+                a += dy, b += dy * xh;
+            }
+            a += __shfl_xor(a, 16, 64), a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 16, 64), b += __shfl_xor(b, 32, 64);
+            if (g == 0) sCol[rt][0][16 * nt + r] = a, sCol[rt][1][16 * nt + r] = b;
+        }
+    }
+    __syncthreads();
+    float* const rec = p.part + (int64_t)blockIdx.x * HF_PART;
+    if (tid < 112) {
+        st_sc1(rec + tid, sCol[0][0][tid] + sCol[1][0][tid]);
+        st_sc1(rec + 112 + tid, sCol[0][1][tid] + sCol[1][1][tid]);
+    } else if (tid < 114) {
+        st_sc1(rec + 224 + (tid - 112), sLoss[0][tid - 112] + sLoss[1][tid - 112]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int prev = __hip_atomic_fetch_add(p.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(p.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- last arriver: column sums over the workgroups, in order, fp64.  thread c < F: both sums of column c;
+    //      threads F, F+1: loss and accuracy
+    const int G = (int)gridDim.x;
+    const bool col = tid < F, aux = tid >= F && tid < F + 2;
+    const int o1 = col ? tid : 224 + (tid - F), o2 = col ? 112 + tid : 224 + (tid - F);
+    double s1 = 0.0, s2 = 0.0;
+    if (col || aux) {
+        for (int g0 = 0; g0 < G; g0 += 32) {
+            float t1[32], t2[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const float* q = p.part + (int64_t)min(g0 + j, G - 1) * HF_PART;
+                t1[j] = ld_sc1(q + o1), t2[j] = ld_sc1(q + o2);
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const double m = g0 + j < G ? 1.0 : 0.0;
+                s1 += (double)t1[j] * m, s2 += (double)t2[j] * m;
+            }
+        }
+    }
+    if (col) {
+        p.bn_bwd[tid] = (float)(s1 / (double)N);
+        p.bn_bwd[F + tid] = (float)(s2 / (double)N);
+        p.dbeta[tid] = (float)s1;
+        p.dgamma[tid] = (float)s2;
+    } else if (tid == F) {
+        p.stats[0] = (float)(s1 / wsum);
+        p.stats[2] = (float)wsum;
+    } else if (tid == F + 1) {
+        p.stats[1] = (float)s1;
+    }
+}
+
+// dx = gamma * rstd * (dY - mean(dY) - xhat * mean(dY * xhat)): the elementwise part of BatchNorm's backward
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int ldx, int N, int F,
+                                                           const float* __restrict__ gamma, const float* __restrict__ saved,
+                                                           const float* __restrict__ bn_bwd, const float* __restrict__ dY,
+                                                           int lddy, float* __restrict__ dx, int lddx) {
+    const int per_row = F / 4;
+    const int64_t total = (int64_t)N * per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int row = (int)(i / per_row), c = 4 * (int)(i - (int64_t)row * per_row);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)row * ldx + c);
+        const f32x4 dy = *reinterpret_cast<const f32x4*>(dY + (int64_t)row * lddy + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(saved + c), rs = *reinterpret_cast<const f32x4*>(saved + F + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 ma = *reinterpret_cast<const f32x4*>(bn_bwd + c), mb = *reinterpret_cast<const f32x4*>(bn_bwd + F + c);
+        f32x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float xh = (xv[t] - mu[t]) * rs[t];
+            o[t] = ga[t] * rs[t] * (dy[t] - ma[t] - xh * mb[t]);
+        }
+        *reinterpret_cast<f32x4*>(dx + (int64_t)row * lddx + c) = o;
+    }
+}
+
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int64_t erc_bn_batch_stats_ws_floats(int F) { return (int64_t)BS_G * 2 * F * 2 + 16; }
+
+extern "C" int erc_bn_batch_stats(const float* x, int ldx, int N, int F, float* running_mean, float* running_var,
+                                  float momentum, float eps, float* saved, float* ws, void* stream) {
+    ERC_REQUIRE(x && running_mean && running_var && saved && ws, "bn_batch_stats: null pointer");
+    ERC_REQUIRE(N > 0 && F > 0 && F <= 128 && ldx >= F, "bn_batch_stats: N=%d F=%d ldx=%d", N, F, ldx);
+    ERC_REQUIRE(((uintptr_t)ws & 7) == 0, "bn_batch_stats: ws must be 8-byte aligned");
+    const int grid = erc_cdiv(N, 8) < BS_G ? erc_cdiv(N, 8) : BS_G;
+    int* counter = reinterpret_cast<int*>(ws + (int64_t)BS_G * 2 * F * 2);
+    hipLaunchKernelGGL(bn_batch_stats_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, F, running_mean,
+                       running_var, momentum, eps, saved, reinterpret_cast<double*>(ws), counter);
+    ERC_LAUNCH_CHECK("bn_batch_stats");
+    return ERC_OK;
+}
+
+extern "C" int64_t erc_head_fused_ws_floats(int n_rows) { return (int64_t)erc_cdiv(n_rows, 32) * HF_PART + 16; }
+
+extern "C" int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
+                              const float* saved, float slope, const float* W0, const float* b0, const float* W3,
+                              const float* b3, const int64_t* labels, const float* weight, float drop_p,
+                              const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
+                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* stream) {
+    ERC_REQUIRE(H2 && gamma && beta && saved && W0 && b0 && W3 && b3 && labels && H3 && Z && logits && dlogits && dZ && dY &&
+                    bn_bwd && dgamma && dbeta && stats && ws,
+                "head_fused: null pointer");
+    ERC_REQUIRE(n_rows > 0 && F >= 4 && F <= HF_MAXF && F % 4 == 0 && C > 0 && C <= HF_MAXC && ldh >= F && ldh % 4 == 0,
+                "head_fused: n_rows=%d F=%d C=%d ldh=%d unsupported (F <= %d, F %% 4 == 0, C <= %d)", n_rows, F, C, ldh,
+                HF_MAXF, HF_MAXC);
+    ERC_REQUIRE(al16(H2) && al16(gamma) && al16(beta) && al16(saved) && al16(W0) && al16(H3), "head_fused: 16-byte alignment");
+    ERC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state), "head_fused: drop_p=%f", (double)drop_p);
+    HeadP p{};
+    p.H2 = H2, p.gamma = gamma, p.beta = beta, p.saved = saved, p.W0 = W0, p.b0 = b0, p.W3 = W3, p.b3 = b3;
+    p.labels = labels, p.weight = weight, p.rng = rng_state, p.H3 = H3, p.Z = Z, p.logits = logits, p.dlogits = dlogits;
+    p.dZ = dZ, p.dY = dY, p.bn_bwd = bn_bwd, p.dgamma = dgamma, p.dbeta = dbeta, p.stats = stats;
+    p.slope = slope, p.drop_p = drop_p, p.ldh = ldh, p.N = n_rows, p.F = F, p.C = C;
+    const int grid = erc_cdiv(n_rows, 32);
+    p.part = ws;
+    p.counter = reinterpret_cast<int*>(ws + (int64_t)grid * HF_PART);
+    hipLaunchKernelGGL(head_fused_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    ERC_LAUNCH_CHECK("head_fused");
+    return ERC_OK;
+}
+
+extern "C" int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,
+                                const float* bn_bwd, const float* dY, int lddy, float* dx, int lddx, void* stream) {
+    ERC_REQUIRE(x && gamma && saved && bn_bwd && dY && dx, "bn_bwd_apply: null pointer");
+    ERC_REQUIRE(N > 0 && F >= 4 && F % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0,
+                "bn_bwd_apply: N=%d F=%d pitches %d %d %d", N, F, ldx, lddy, lddx);
+    ERC_REQUIRE(al16(x) && al16(gamma) && al16(saved) && al16(bn_bwd) && al16(dY) && al16(dx), "bn_bwd_apply: 16-byte alignment");
+    const int64_t total = (int64_t)N * (F / 4);
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, ldx, N, F, gamma, saved, bn_bwd,
+                       dY, lddy, dx, lddx);
+    ERC_LAUNCH_CHECK("bn_bwd_apply");
+    return ERC_OK;
+}

@@ -235,6 +235,34 @@ int erc_cross_entropy(const float* logits, int ld, int C, int n_rows, const int3
                       const int64_t* labels, const float* weight, float grad_scale,
                       float* dlogits, int lddl, float* stats, void* stream);
 
+/* Training-mode BatchNorm1d statistics (track_mm/cogmen.py:67): column mean / rstd of x [N,F] into saved[0,F) /
+ * saved[F,2F), running_mean / running_var updated with `momentum` (unbiased variance), one launch.
+ * ws: erc_bn_batch_stats_ws_floats(F) floats, 8-byte aligned, zero before the first call. */
+int64_t erc_bn_batch_stats_ws_floats(int F);
+int erc_bn_batch_stats(const float* x, int ldx, int N, int F, float* running_mean, float* running_var,
+                       float momentum, float eps, float* saved, float* ws, void* stream);
+
+/* COGMEN classifier head, forward + loss + backward in one launch (track_mm/cogmen.py:67-68,72-73 BatchNorm1d +
+ * leaky_relu; :116-122 cls = Linear, ReLU, Dropout, Linear; :185 F.cross_entropy; :187-188 their backward):
+ *   H3 = lrelu(bn(H2; saved, gamma, beta), slope);  Z = dropout(relu(H3 W0^T + b0), drop_p);  logits = Z W3^T + b3
+ *   dlogits, dZ (through the relu / dropout mask), dY = dL/d(bn output) = (dZ W0) * lrelu'
+ *   bn_bwd[0,F) = mean_rows(dY), bn_bwd[F,2F) = mean_rows(dY * xhat);  dbeta = sum dY, dgamma = sum dY * xhat
+ *   stats[0] = weighted mean loss, [1] = #correct, [2] = sum of sample weights.
+ * H2 [n_rows, ldh]; H3, Z, dZ, dY [n_rows, F]; logits, dlogits [n_rows, C]; W0 [F,F], W3 [C,F] row-major.
+ * F <= 100, F % 4 == 0, C <= 8, 16-byte aligned H2 / gamma / beta / saved / W0 / H3.  Dropout uses the counter RNG
+ * of erc_gemm_f32 act = 3 (element index row * F + col; rng_state = {offset, seed}), so the mask is the one
+ * a separate Linear launch would draw.  ws: erc_head_fused_ws_floats(n_rows) floats, zero before the first call. */
+int64_t erc_head_fused_ws_floats(int n_rows);
+int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
+                   const float* saved, float slope, const float* W0, const float* b0, const float* W3,
+                   const float* b3, const int64_t* labels, const float* weight, float drop_p,
+                   const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
+                   float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* stream);
+
+/* Elementwise part of BatchNorm1d's backward: dx = gamma * rstd * (dY - bn_bwd[c] - xhat * bn_bwd[F + c]). */
+int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,
+                     const float* bn_bwd, const float* dY, int lddy, float* dx, int lddx, void* stream);
+
 /* Fused classifier tail: logits = Z W^T + b (W [C,F], C <= 8, F <= 128), cross entropy as above, and
  * dZ = (Z > 0 ? mask_scale : 0) * (dlogits W)  -- the last Linear of the head, F.cross_entropy and their backward
  * through the preceding ReLU(+inverted dropout, mask_scale = 1/(1-p)) in one launch (track_mm/cogmen.py:116-122,185;

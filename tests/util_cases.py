@@ -40,7 +40,7 @@ def rel_err(a, b, floor=1e-5):
     return float((a - b).abs().max() / (b.abs().max() + floor))
 
 
-def run_cogmen_parity(case, device="cuda:0", compute="f32"):
+def run_cogmen_parity(case, device="cuda:0", compute="f32", zero_grad=()):
     """eval-mode logits and train-mode (dropout p=0) loss/gradients: HIP path vs oracle."""
     from oracle.cogmen import COGMENOracle
     from erc_amd.cogmen import COGMENModule
@@ -91,7 +91,7 @@ def run_cogmen_parity(case, device="cuda:0", compute="f32"):
     worst, names = 0.0, {}
     ref_params = dict(ref.named_parameters())
     for name in mine.flat.params:
-        if name in ZERO_GRAD:
+        if name in ZERO_GRAD or name in zero_grad:
             # mathematically zero: softmax shift invariance (key bias) / constant shift in front of BatchNorm
             assert float(mine.flat.g(name).abs().max()) < 1e-5 and float(ref_params[name].grad.abs().max()) < 1e-5
             continue
