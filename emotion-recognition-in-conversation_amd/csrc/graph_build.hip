@@ -27,9 +27,13 @@ __global__ __launch_bounds__(256) void window_graph_kernel(
     int32_t* __restrict__ counts) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
-    __shared__ int red_n[256];
-    __shared__ int red_e[256];
+    __shared__ int red_n[4];
+    __shared__ int red_e[4];
+    extern __shared__ int s_spk[];  // speakers of this dialogue (T entries): one global round trip instead of one per edge
 
+    const int64_t* spk = speakers + (int64_t)b * spk_sb;
+    const int L = (int)lengths[b];
+    for (int p = tid; p < min(L, T); p += 256) s_spk[p] = (int)spk[(int64_t)p * spk_st];
     // exclusive prefix of node / edge counts over the dialogues before b
     int acc_n = 0, acc_e = 0;
     for (int i = tid; i < b; i += 256) {
@@ -37,19 +41,12 @@ __global__ __launch_bounds__(256) void window_graph_kernel(
         acc_n += Li;
         acc_e += window_prefix(Li, Li, wf, wp);
     }
-    red_n[tid] = acc_n;
-    red_e[tid] = acc_e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc_n += __shfl_xor(acc_n, o, 64), acc_e += __shfl_xor(acc_e, o, 64);
+    if ((tid & 63) == 0) red_n[tid >> 6] = acc_n, red_e[tid >> 6] = acc_e;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            red_n[tid] += red_n[tid + o];
-            red_e[tid] += red_e[tid + o];
-        }
-        __syncthreads();
-    }
-    const int noff = red_n[0];
-    const int eoff = red_e[0];
-    const int L = (int)lengths[b];
+    const int noff = red_n[0] + red_n[1] + red_n[2] + red_n[3];
+    const int eoff = red_e[0] + red_e[1] + red_e[2] + red_e[3];
     const int E_b = window_prefix(L, L, wf, wp);
 
     if (tid == 0) {
@@ -64,12 +61,11 @@ __global__ __launch_bounds__(256) void window_graph_kernel(
             }
         }
     }
-    if (noff + L > n_cap || eoff + E_b > e_cap) return;  // capacity guard (host checks counts)
+    if (noff + L > n_cap || eoff + E_b > e_cap || L > T) return;  // capacity guard (host checks counts)
 
-    const int64_t* spk = speakers + (int64_t)b * spk_sb;
     for (int p = tid; p < L; p += 256) {
         const int n = noff + p;
-        const int sp = (int)spk[(int64_t)p * spk_st];
+        const int sp = s_spk[p];
         node_row[n] = b * T + p;
         node_spk[n] = sp;
 
@@ -80,7 +76,7 @@ __global__ __launch_bounds__(256) void window_graph_kernel(
             in_ptr[n] = base;
             for (int j = lo; j <= hi; ++j) {
                 const int e = base + (j - lo);
-                const int sj = (int)spk[(int64_t)j * spk_st];
+                const int sj = s_spk[j];
                 const int ty = 2 * (sj * S + sp) + (j < p ? 0 : 1);
                 in_src[e] = noff + j;
                 in_typ[e] = ty;
@@ -98,7 +94,7 @@ __global__ __launch_bounds__(256) void window_graph_kernel(
             out_ptr[n] = base;
             for (int k = lo; k <= hi; ++k) {
                 const int e = base + (k - lo);
-                const int sk = (int)spk[(int64_t)k * spk_st];
+                const int sk = s_spk[k];
                 out_dst[e] = noff + k;
                 out_typ[e] = 2 * (sp * S + sk) + (p < k ? 0 : 1);
                 out_eid[e] = eoff + window_prefix(k, L, wf, wp) + (p - max(0, k - wf));
@@ -122,7 +118,8 @@ extern "C" int erc_window_graph_build(const int64_t* lengths, const int64_t* spe
     ERC_REQUIRE(wp >= -1 && wf >= -1, "window_graph_build: window must be >= -1");
     if (wp < 0) wp = T;  // -1 = unbounded past   (cogmen_utils.py:158-163)
     if (wf < 0) wf = T;  // -1 = unbounded future
-    hipLaunchKernelGGL(window_graph_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, lengths, speakers, spk_sb,
+    ERC_REQUIRE(T <= 12288, "window_graph_build: T=%d exceeds the LDS speaker stage", T);
+    hipLaunchKernelGGL(window_graph_kernel, dim3(B), dim3(256), (size_t)T * sizeof(int), (hipStream_t)stream, lengths, speakers, spk_sb,
                        spk_st, B, T, wp, wf, n_speakers, n_cap, e_cap, node_off, node_row, node_spk, in_ptr, in_src,
                        in_typ, out_ptr, out_dst, out_typ, out_eid, edge_index, edge_type, counts);
     ERC_LAUNCH_CHECK("window_graph_build");

@@ -28,6 +28,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    const float* __restrict__ gnorm, int64_t* state,
                                                    unsigned short* __restrict__ shadow, int64_t shadow_off,
                                                    int64_t shadow_n) {
+    // first quad of this thread: requested before the (dependent, transcendental) bias-correction math
+    const int64_t nq = n >> 2;
+    const int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t q0c = q0 < nq ? q0 : 0;
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), mv = pv, vv = pv, gv = pv;
+    if (nq > 0) {  // uniform
+        pv = reinterpret_cast<float4*>(p)[q0c], mv = reinterpret_cast<float4*>(m)[q0c], vv = reinterpret_cast<float4*>(v)[q0c];
+        gv = reinterpret_cast<const float4*>(g)[q0c];
+    }
     const int64_t step = state[0] + 1;  // every block reads it before it signals arrival (below)
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2 = 1.0f - powf(b2, (float)step);
@@ -38,22 +47,37 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float coef = clip_norm / (gnorm[0] + 1e-6f);
         if (coef < 1.f) gs *= coef;
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float pi = p[i], gi = g[i] * gs;
-        if (decoupled)
-            pi *= 1.0f - lr * wd;
-        else if (wd != 0.f)
-            gi += wd * pi;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float pn = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-        p[i] = pn;
-        if (shadow && i >= shadow_off && i < shadow_off + shadow_n) {  // bf16 copy for the bf16 input GEMM
+    const float decay = decoupled ? 1.0f - lr * wd : 1.0f, l2 = decoupled ? 0.f : wd;
+    auto update = [&](float& pi, float gi, float& mi, float& vi) {
+        pi *= decay;
+        gi = gi * gs + l2 * pi;
+        mi = b1 * mi + (1.f - b1) * gi;
+        vi = b2 * vi + (1.f - b2) * gi * gi;
+        pi = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    };
+    auto to_shadow = [&](int64_t i, float pn) {  // bf16 copy for the bf16 input GEMM
+        if (shadow && i >= shadow_off && i < shadow_off + shadow_n) {
             const __bf16 h = (__bf16)pn;
             shadow[i - shadow_off] = __builtin_bit_cast(unsigned short, h);
         }
+    };
+    // 16-byte accesses: one quad per thread and grid stride (the launch sizes the grid for a single pass)
+    for (int64_t q = q0; q < nq; q += (int64_t)gridDim.x * 256) {
+        if (q != q0) {
+            pv = reinterpret_cast<float4*>(p)[q], mv = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q];
+            gv = reinterpret_cast<const float4*>(g)[q];
+        }
+        update(pv.x, gv.x, mv.x, vv.x), update(pv.y, gv.y, mv.y, vv.y);
+        update(pv.z, gv.z, mv.z, vv.z), update(pv.w, gv.w, mv.w, vv.w);
+        reinterpret_cast<float4*>(m)[q] = mv, reinterpret_cast<float4*>(v)[q] = vv, reinterpret_cast<float4*>(p)[q] = pv;
+        if (shadow) to_shadow(4 * q, pv.x), to_shadow(4 * q + 1, pv.y), to_shadow(4 * q + 2, pv.z), to_shadow(4 * q + 3, pv.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nq << 2) + threadIdx.x;
+        float pi = p[i], mi = m[i], vi = v[i];
+        update(pi, g[i], mi, vi);
+        m[i] = mi, v[i] = vi, p[i] = pi;
+        to_shadow(i, pi);
     }
     // the LAST block to finish bumps {step, RNG offset}: by then every block has read state[0]
     __syncthreads();
@@ -123,8 +147,10 @@ extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64
                              int64_t shadow_off, int64_t shadow_n, void* stream) {
     ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
     ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
-    int grid = (int)((n + 255) / 256);
-    if (grid > 256) grid = 256;  // one arrival atomic per block on a single word: keep the count low
+    ERC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: 16-byte alignment");
+    int grid = (int)((n / 4 + 255) / 256);   // one float4 per thread
+    if (grid < 1) grid = 1;
+    if (grid > 512) grid = 512;  // one arrival atomic per block on a single word: keep the count low
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                        decoupled, grad_scale, clip_norm, gnorm, state, (unsigned short*)bf16_shadow, shadow_off, shadow_n);
