@@ -58,6 +58,38 @@ template <int NW>
 __device__ __forceinline__ void reduce_and_store(const StreamP& p, f32x4 acc[2], float* red, int m0, int n0, int z) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
+    float* __restrict__ C = p.C + (int64_t)z * p.c_slab;
+    uint64_t rng_off = 0, rng_seed = 0;
+    if (p.act == 3) rng_off = p.rng[0], rng_seed = p.rng[1];
+    // bias of this lane's two columns, requested once (a guarded load per stored element costs a round trip each)
+    float bv[2] = {0.f, 0.f};
+    if (p.bias) {  // uniform
+#pragma unroll
+        for (int f = 0; f < 2; ++f) bv[f] = p.bias[min(n0 + 16 * f + r, p.N - 1)];
+    }
+    auto finish = [&](const int f, const int i, float v) {
+        const int col = n0 + 16 * f + r, row = m0 + 4 * g + i;
+        if (row >= p.M) {
+            if (row == p.M && p.ones == 2 && col < p.N && p.bias_out) p.bias_out[(int64_t)z * p.bias_slab + col] = v;
+            return;
+        }
+        if (col < p.N) {
+            float* dst = C + (int64_t)row * p.ldc + col;
+            v += f ? bv[1] : bv[0];
+            if (p.accumulate) v += *dst;
+            if (p.act == 1)
+                v = fmaxf(v, 0.f);
+            else if (p.act == 2)
+                v = p.aux[(int64_t)row * p.ldaux + col] > 0.f ? v * p.act_scale : 0.f;
+            else if (p.act == 3) {
+                const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)p.N + col);
+                v = (u >= p.drop_p) ? fmaxf(v, 0.f) * p.act_scale : 0.f;
+            }
+            *dst = v;
+        } else if (col == p.N && p.ones == 1 && p.bias_out) {
+            p.bias_out[(int64_t)z * p.bias_slab + row] = v;
+        }
+    };
     if (NW > 1) {
 #pragma unroll
         for (int f = 0; f < 2; ++f)
@@ -75,38 +107,10 @@ __device__ __forceinline__ void reduce_and_store(const StreamP& p, f32x4 acc[2],
                 acc[f][i] = s;
             }
     }
-    float* __restrict__ C = p.C + (int64_t)z * p.c_slab;
-    uint64_t rng_off = 0, rng_seed = 0;
-    if (p.act == 3) rng_off = p.rng[0], rng_seed = p.rng[1];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int col = n0 + 16 * f + r;
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + 4 * g + i;
-            float v = acc[f][i];
-            if (row >= p.M) {
-                if (row == p.M && p.ones == 2 && col < p.N && p.bias_out) p.bias_out[(int64_t)z * p.bias_slab + col] = v;
-                continue;
-            }
-            if (col < p.N) {
-                float* dst = C + (int64_t)row * p.ldc + col;
-                if (p.bias) v += p.bias[col];
-                if (p.accumulate) v += *dst;
-                if (p.act == 1)
-                    v = fmaxf(v, 0.f);
-                else if (p.act == 2)
-                    v = p.aux[(int64_t)row * p.ldaux + col] > 0.f ? v * p.act_scale : 0.f;
-                else if (p.act == 3) {
-                    const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)p.N + col);
-                    v = (u >= p.drop_p) ? fmaxf(v, 0.f) * p.act_scale : 0.f;
-                }
-                *dst = v;
-            } else if (col == p.N && p.ones == 1 && p.bias_out) {
-                p.bias_out[(int64_t)z * p.bias_slab + row] = v;
-            }
-        }
-    }
+        for (int i = 0; i < 4; ++i) finish(f, i, acc[f][i]);
 }
 
 // A_MODE: 0 rows K-contiguous (optional row gather), 1 K-major.  B_MODE: 0 "NT" (B[n][k]), 1 K-major (optional k gather).
@@ -348,26 +352,33 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
 #pragma unroll
             for (int f = 0; f < 2; ++f) acc[h][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[h], b[f], acc[h][f], 0, 0, 0);
     };
-    int kb = w;
-    for (; kb + 2 * NW < kb_full_end; kb += 3 * NW) {
-        bf16x8 a0[2], b0[2], a1[2], b1[2], a2[2], b2[2];
-        load(kb, a0, b0, T{});
-        load(kb + NW, a1, b1, T{});
-        load(kb + 2 * NW, a2, b2, T{});
-        mma(a0, b0);
-        mma(a1, b1);
-        mma(a2, b2);
+    // bias of this lane's two columns, requested up front (a guarded load in the epilogue costs a round trip per use)
+    float bv[2] = {0.f, 0.f};
+    if (p.bias) {  // uniform
+#pragma unroll
+        for (int f = 0; f < 2; ++f) bv[f] = p.bias[nc[f]];
     }
-    for (; kb < kb_full_end; kb += NW) {
-        bf16x8 a0[2], b0[2];
-        load(kb, a0, b0, T{});
-        mma(a0, b0);
+    // the one partial K block belongs to wavefront (kb_full_end % NW): loaded first, multiplied last
+    const bool has_tail = nkb > kb_full_end && (kb_full_end % NW) == w;
+    bf16x8 ta[2] = {zero8, zero8}, tb[2] = {zero8, zero8};
+    if (has_tail) load(kb_full_end, ta, tb, Fx{});
+    // batches of 6 K blocks per wavefront, all loads of a batch in flight; blocks past the end are clamped to a valid
+    // one and their A fragments ANDed with zero (no select on a load result: hipcc would branch around the load)
+    for (int kb = w; kb < kb_full_end; kb += 6 * NW) {
+        bf16x8 a[6][2], b[6][2];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const bool valid = kb + u * NW < kb_full_end;
+            load(valid ? kb + u * NW : kb, a[u], b[u], T{});
+            const short mk = valid ? (short)-1 : (short)0;
+            const bf16x8 m8 = {mk, mk, mk, mk, mk, mk, mk, mk};
+            a[u][0] &= m8, a[u][1] &= m8;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) mma(a[u], b[u]);
     }
-    if (kb < nkb) {
-        bf16x8 a0[2], b0[2];
-        load(kb, a0, b0, Fx{});
-        mma(a0, b0);
-    }
+    if (has_tail) mma(ta, tb);
     // in-workgroup split-K reduction, then bias / relu epilogue
     if (NW > 1) {
 #pragma unroll
@@ -377,18 +388,21 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) red[(w * 16 + h * 8 + f * 4 + i) * 64 + lane] = acc[h][f][i];
         __syncthreads();
-        if (w != 0) return;
+        // every wavefront finalises 16 / NW of the 16 accumulator slots (sum over the wavefronts in order) and stores them
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int s = 0; s < 16 / NW; ++s) {
+            const int slot = w + NW * s, h = slot >> 3, f = (slot >> 2) & 1, i = slot & 3;
+            float sum = 0.f;
 #pragma unroll
-            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int ww = 0; ww < NW; ++ww) s += red[(ww * 16 + h * 8 + f * 4 + i) * 64 + lane];
-                    acc[h][f][i] = s;
-                }
+            for (int ww = 0; ww < NW; ++ww) sum += red[(ww * 16 + slot) * 64 + lane];
+            const int row = m0 + 16 * h + 4 * g + i, col = n0 + 16 * f + r;
+            if (row < p.M && col < p.N) {
+                float v = sum + (f ? bv[1] : bv[0]);
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                p.C[(int64_t)row * p.ldc + col] = v;
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -399,7 +413,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
             for (int i = 0; i < 4; ++i) {
                 const int row = m0 + 16 * h + 4 * g + i;
                 if (row < p.M && col < p.N) {
-                    float v = acc[h][f][i] + (p.bias ? p.bias[col] : 0.f);
+                    float v = acc[h][f][i] + bv[f];
                     if (p.act == 1) v = fmaxf(v, 0.f);
                     p.C[(int64_t)row * p.ldc + col] = v;
                 }
