@@ -54,75 +54,89 @@ __device__ __forceinline__ float4 ld4g(const float* p, int valid, bool vec) {
     return v;
 }
 
-template <int NW>
-__device__ __forceinline__ void reduce_and_store(const StreamP& p, f32x4 acc[2], float* red, int m0, int n0, int z) {
+template <int NW, int RM, int CF>
+__device__ __forceinline__ void reduce_and_store(const StreamP& p, f32x4 (&acc)[RM][CF], float* red, int m0, int n0, int z) {
+    constexpr int SLOTS = RM * CF * 4;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     float* __restrict__ C = p.C + (int64_t)z * p.c_slab;
     uint64_t rng_off = 0, rng_seed = 0;
     if (p.act == 3) rng_off = p.rng[0], rng_seed = p.rng[1];
-    // bias of this lane's two columns, requested once (a guarded load per stored element costs a round trip each)
-    float bv[2] = {0.f, 0.f};
-    if (p.bias) {  // uniform
-#pragma unroll
-        for (int f = 0; f < 2; ++f) bv[f] = p.bias[min(n0 + 16 * f + r, p.N - 1)];
-    }
-    auto finish = [&](const int f, const int i, float v) {
-        const int col = n0 + 16 * f + r, row = m0 + 4 * g + i;
-        if (row >= p.M) {
-            if (row == p.M && p.ones == 2 && col < p.N && p.bias_out) p.bias_out[(int64_t)z * p.bias_slab + col] = v;
-            return;
-        }
-        if (col < p.N) {
-            float* dst = C + (int64_t)row * p.ldc + col;
-            v += f ? bv[1] : bv[0];
-            if (p.accumulate) v += *dst;
-            if (p.act == 1)
-                v = fmaxf(v, 0.f);
-            else if (p.act == 2)
-                v = p.aux[(int64_t)row * p.ldaux + col] > 0.f ? v * p.act_scale : 0.f;
-            else if (p.act == 3) {
-                const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)p.N + col);
-                v = (u >= p.drop_p) ? fmaxf(v, 0.f) * p.act_scale : 0.f;
-            }
-            *dst = v;
-        } else if (col == p.N && p.ones == 1 && p.bias_out) {
-            p.bias_out[(int64_t)z * p.bias_slab + row] = v;
-        }
-    };
     if (NW > 1) {
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int h = 0; h < RM; ++h)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) red[(w * 8 + f * 4 + i) * 64 + lane] = acc[f][i];
+            for (int f = 0; f < CF; ++f)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) red[(w * SLOTS + (h * CF + f) * 4 + i) * 64 + lane] = acc[h][f][i];
         __syncthreads();
         if (w != 0) return;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int h = 0; h < RM; ++h)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float s = 0.f;
+            for (int f = 0; f < CF; ++f)
 #pragma unroll
-                for (int ww = 0; ww < NW; ++ww) s += red[(ww * 8 + f * 4 + i) * 64 + lane];
-                acc[f][i] = s;
-            }
+                for (int i = 0; i < 4; ++i) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) s += red[(ww * SLOTS + (h * CF + f) * 4 + i) * 64 + lane];
+                    acc[h][f][i] = s;
+                }
+    }
+    // bias of this lane's columns, requested once (a guarded load per stored element costs a round trip each)
+    float bv[CF];
+#pragma unroll
+    for (int f = 0; f < CF; ++f) bv[f] = 0.f;
+    if (p.bias) {  // uniform
+#pragma unroll
+        for (int f = 0; f < CF; ++f) bv[f] = p.bias[min(n0 + 16 * f + r, p.N - 1)];
     }
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int h = 0; h < RM; ++h)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) finish(f, i, acc[f][i]);
+        for (int f = 0; f < CF; ++f) {
+            const int col = n0 + 16 * f + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + 16 * h + 4 * g + i;
+                float v = acc[h][f][i];
+                if (row >= p.M) {
+                    if (row == p.M && p.ones == 2 && col < p.N && p.bias_out) p.bias_out[(int64_t)z * p.bias_slab + col] = v;
+                    continue;
+                }
+                if (col < p.N) {
+                    float* dst = C + (int64_t)row * p.ldc + col;
+                    v += bv[f];
+                    if (p.accumulate) v += *dst;
+                    if (p.act == 1)
+                        v = fmaxf(v, 0.f);
+                    else if (p.act == 2)
+                        v = p.aux[(int64_t)row * p.ldaux + col] > 0.f ? v * p.act_scale : 0.f;
+                    else if (p.act == 3) {
+                        const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)p.N + col);
+                        v = (u >= p.drop_p) ? fmaxf(v, 0.f) * p.act_scale : 0.f;
+                    }
+                    *dst = v;
+                } else if (col == p.N && p.ones == 1 && p.bias_out) {
+                    p.bias_out[(int64_t)z * p.bias_slab + row] = v;
+                }
+            }
+        }
 }
 
 // A_MODE: 0 rows K-contiguous (optional row gather), 1 K-major.  B_MODE: 0 "NT" (B[n][k]), 1 K-major (optional k gather).
 // GA / GB (gather present) and VEC (16-byte loads legal) are COMPILE-TIME: a runtime "pointer ? load : value" makes
 // hipcc branch around the load and drain vmcnt per element.
-template <int A_MODE, int B_MODE, int NW, bool GA, bool GB, bool VEC>
+// Wave tile (16 RM) x (16 CF): RM x CF MFMA tiles share the RM + CF fragments of a K block.  The skinny products of
+// this workload are bound by the per-CU L2 path (~70 GB/s), so bigger wave tiles (fewer fragment bytes per MFMA) win
+// as long as enough workgroups remain to fill the chip; the host picks (1,2), (1,4) or (2,4).
+template <int A_MODE, int B_MODE, int NW, bool GA, bool GB, bool VEC, int RM, int CF>
 __device__ __forceinline__ void gemm_f32_stream_body(const StreamP& p, float* red, const int bx, const int by, const int z) {
     const float* __restrict__ A = (const float*)p.A;
     const float* __restrict__ B = (const float*)p.B;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = bx * 32, m0 = by * 16;
+    const int n0 = bx * 16 * CF, m0 = by * 16 * RM;
     const int nkb = (p.K + 15) / 16;
     const int kb_begin = z * p.kblocks_per_split;
     const int kb_end = min(nkb, kb_begin + p.kblocks_per_split);
@@ -130,49 +144,61 @@ __device__ __forceinline__ void gemm_f32_stream_body(const StreamP& p, float* re
 
     // Out-of-range rows / columns / k are CLAMPED to a valid address and the loaded value is replaced afterwards
     // by a select: every load is unconditional, so no branch and no s_waitcnt separates them.
-    const int m = m0 + r;
-    const bool m_ok = m < p.M, m_one = (m == p.M && p.ones == 2);
-    const int mc = min(m, p.M - 1);
-    int64_t a_row;
-    if (A_MODE == 0)
-        a_row = (GA ? (int64_t)p.a_gather[mc] : (int64_t)mc) * p.lda;
-    else
-        a_row = mc;
-    int nc[2];
-    bool n_ok[2];
-    float b_fill[2];
+    int64_t a_row[RM];
+    bool m_ok[RM];
+    float a_fill[RM];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
+    for (int h = 0; h < RM; ++h) {
+        const int m = m0 + 16 * h + r;
+        m_ok[h] = m < p.M;
+        a_fill[h] = (m == p.M && p.ones == 2) ? 1.f : 0.f;
+        const int mc = min(m, p.M - 1);
+        if (A_MODE == 0)
+            a_row[h] = (GA ? (int64_t)p.a_gather[mc] : (int64_t)mc) * p.lda;
+        else
+            a_row[h] = mc;
+    }
+    int nc[CF];
+    bool n_ok[CF];
+    float b_fill[CF];
+#pragma unroll
+    for (int f = 0; f < CF; ++f) {
         const int n = n0 + 16 * f + r;
         n_ok[f] = n < p.N;
         b_fill[f] = (n == p.N && p.ones == 1) ? 1.f : 0.f;
         nc[f] = min(n, p.N - 1);
     }
-    const float a_fill = m_one ? 1.f : 0.f;
 
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[RM][CF];
+#pragma unroll
+    for (int h = 0; h < RM; ++h)
+#pragma unroll
+        for (int f = 0; f < CF; ++f) acc[h][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // FULL: the block lies inside K (vector loads allowed, no k masking)
-    auto load = [&](const int kb, float (&a)[4], float (&b)[2][4], auto full_tag) {
+    auto load = [&](const int kb, float (&a)[RM][4], float (&b)[CF][4], auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int k = kb * 16 + 4 * g;
         int kc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) kc[j] = FULL ? k + j : min(k + j, p.K - 1);
-        if (A_MODE == 0) {
-            if (FULL && VEC) {
-                const float4 v = *reinterpret_cast<const float4*>(A + a_row + k);
-                a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
+#pragma unroll
+        for (int h = 0; h < RM; ++h) {
+            if (A_MODE == 0) {
+                if (FULL && VEC) {
+                    const float4 v = *reinterpret_cast<const float4*>(A + a_row[h] + k);
+                    a[h][0] = v.x, a[h][1] = v.y, a[h][2] = v.z, a[h][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[h][j] = A[a_row[h] + kc[j]];
+                }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) a[j] = A[a_row + kc[j]];
+                for (int j = 0; j < 4; ++j) a[h][j] = A[(int64_t)kc[j] * p.lda + a_row[h]];
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] = A[(int64_t)kc[j] * p.lda + a_row];
         }
         if (B_MODE == 0) {
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
+            for (int f = 0; f < CF; ++f) {
                 const float* bp = B + (int64_t)nc[f] * p.ldb;
                 if (FULL && VEC) {
                     const float4 v = *reinterpret_cast<const float4*>(bp + k);
@@ -189,53 +215,67 @@ __device__ __forceinline__ void gemm_f32_stream_body(const StreamP& p, float* re
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int f = 0; f < 2; ++f) b[f][j] = B[brow[j] + nc[f]];
+                for (int f = 0; f < CF; ++f) b[f][j] = B[brow[j] + nc[f]];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool kin = FULL || (k + j < p.K);
-            a[j] = kin ? (m_ok ? a[j] : a_fill) : 0.f;
 #pragma unroll
-            for (int f = 0; f < 2; ++f) b[f][j] = kin ? (n_ok[f] ? b[f][j] : b_fill[f]) : 0.f;
+            for (int h = 0; h < RM; ++h) a[h][j] = kin ? (m_ok[h] ? a[h][j] : a_fill[h]) : 0.f;
+#pragma unroll
+            for (int f = 0; f < CF; ++f) b[f][j] = kin ? (n_ok[f] ? b[f][j] : b_fill[f]) : 0.f;
         }
     };
-    auto mma = [&](const float (&a)[4], const float (&b)[2][4]) {
+    auto mma = [&](const float (&a)[RM][4], const float (&b)[CF][4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[0][j], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[1][j], acc[1], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < RM; ++h)
+#pragma unroll
+                for (int f = 0; f < CF; ++f) acc[h][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[h][j], b[f][j], acc[h][f], 0, 0, 0);
     };
-    // four independent K blocks per iteration: all their fragment loads are issued before the first MFMA
+    // UB independent K blocks per iteration: all their fragment loads are issued before the first MFMA
+    constexpr int UB = (RM * CF >= 8) ? 2 : 4;
     int kb = kb_begin + w;
-    for (; kb + 3 * NW < kb_full_end; kb += 4 * NW) {
-        float a0[4], b0[2][4], a1[4], b1[2][4], a2[4], b2[2][4], a3[4], b3[2][4];
-        load(kb, a0, b0, T{});
-        load(kb + NW, a1, b1, T{});
-        load(kb + 2 * NW, a2, b2, T{});
-        load(kb + 3 * NW, a3, b3, T{});
-        mma(a0, b0);
-        mma(a1, b1);
-        mma(a2, b2);
-        mma(a3, b3);
+    for (; kb + (UB - 1) * NW < kb_full_end; kb += UB * NW) {
+        float a[UB][RM][4], b[UB][CF][4];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) load(kb + u * NW, a[u], b[u], T{});
+#pragma unroll
+        for (int u = 0; u < UB; ++u) mma(a[u], b[u]);
     }
-    for (; kb < kb_full_end; kb += NW) {
-        float a0[4], b0[2][4];
+    // the 1 .. UB-1 full blocks that remain for this wavefront: one batch (one round trip), not one per block
+    const int rem = kb < kb_full_end ? (kb_full_end - kb + NW - 1) / NW : 0;  // wave-uniform
+    if (rem == 3) {
+        float a[3][RM][4], b[3][CF][4];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) load(kb + u * NW, a[u], b[u], T{});
+#pragma unroll
+        for (int u = 0; u < 3; ++u) mma(a[u], b[u]);
+    } else if (rem == 2) {
+        float a[2][RM][4], b[2][CF][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) load(kb + u * NW, a[u], b[u], T{});
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mma(a[u], b[u]);
+    } else if (rem == 1) {
+        float a0[RM][4], b0[CF][4];
         load(kb, a0, b0, T{});
         mma(a0, b0);
     }
+    kb += rem * NW;
     if (kb < kb_end) {  // the one partial block of this split (k-clamped scalar loads)
-        float a0[4], b0[2][4];
+        float a0[RM][4], b0[CF][4];
         load(kb, a0, b0, Fx{});
         mma(a0, b0);
     }
-    reduce_and_store<NW>(p, acc, red, m0, n0, z);
+    reduce_and_store<NW, RM, CF>(p, acc, red, m0, n0, z);
 }
 
-template <int A_MODE, int B_MODE, int NW, bool GA, bool GB, bool VEC>
+template <int A_MODE, int B_MODE, int NW, bool GA, bool GB, bool VEC, int RM, int CF>
 __global__ __launch_bounds__(64 * NW) void gemm_f32_stream_kernel(StreamP p) {
-    __shared__ float red[NW > 1 ? NW * 8 * 64 : 1];
-    gemm_f32_stream_body<A_MODE, B_MODE, NW, GA, GB, VEC>(p, red, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ float red[NW > 1 ? NW * RM * CF * 4 * 64 : 1];
+    gemm_f32_stream_body<A_MODE, B_MODE, NW, GA, GB, VEC, RM, CF>(p, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // bf16 feature block as the A operand (rows K-contiguous, optional gather), fp32 B [N,K] rounded to bf16 on the fly:
@@ -451,18 +491,23 @@ extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const 
     p.b_vec = al16(B) && (ldb % 4 == 0);
     p.act_scale = act_scale; p.drop_p = drop_p;
     const int Nlog = N + (ones_col == 1 ? 1 : 0), Mlog = M + (ones_col == 2 ? 1 : 0);
-    dim3 grid(erc_cdiv(Nlog, 32), erc_cdiv(Mlog, 16), split_k);
     const int kb_split = p.kblocks_per_split;
     // wavefronts per workgroup: enough to cut the K chain, not more than there are blocks
     const int nw = kb_split >= 32 ? 8 : (kb_split >= 6 ? 4 : 1);
+    // Wave tile 16 x 32.  Measured on MI355X (COGMEN B=32 shapes, M = 1982): 32x64 / 16x64 tiles (the body is generic in
+    // RM, CF) were SLOWER -- 14.1 vs 10.5 us (K=100, N=400/900), 13.9 vs 12.5 (K=900, N=100), 11.7 vs 7.9 (K=400,
+    // N=100): these products are bound by the length of the per-wavefront chain, not by fragment traffic.
+    dim3 grid(erc_cdiv(Nlog, 32), erc_cdiv(Mlog, 16), split_k);
     hipStream_t st = (hipStream_t)stream;
     const bool ga = a_gather != nullptr, gb = b_gather != nullptr;
     const bool vec = (a_kmajor || p.a_vec) && (b_kmajor || p.b_vec);
-#define ERC_SL3(AM, BM_, GA_, GB_, V_)                                                                                  \
-    do {                                                                                                               \
-        if (nw == 8) hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BM_, 8, GA_, GB_, V_>), grid, dim3(512), 0, st, p); \
-        else if (nw == 4) hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BM_, 4, GA_, GB_, V_>), grid, dim3(256), 0, st, p); \
-        else hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BM_, 1, GA_, GB_, V_>), grid, dim3(64), 0, st, p);          \
+#define ERC_SL4(AM, BM_, NW_, GA_, GB_, V_) \
+    hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BM_, NW_, GA_, GB_, V_, 1, 2>), grid, dim3(64 * NW_), 0, st, p)
+#define ERC_SL3(AM, BM_, GA_, GB_, V_)                        \
+    do {                                                      \
+        if (nw == 8) ERC_SL4(AM, BM_, 8, GA_, GB_, V_);       \
+        else if (nw == 4) ERC_SL4(AM, BM_, 4, GA_, GB_, V_);  \
+        else ERC_SL4(AM, BM_, 1, GA_, GB_, V_);               \
     } while (0)
 #define ERC_SL2(AM, BM_, GA_, GB_)              \
     do {                                        \
@@ -481,6 +526,7 @@ extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const 
     }
 #undef ERC_SL2
 #undef ERC_SL3
+#undef ERC_SL4
     ERC_LAUNCH_CHECK("gemm_f32_stream");
     return ERC_OK;
 }
