@@ -9,7 +9,10 @@ set of mmbase.py:253-323.  One process per GPU; under torch.distributed the
 trainers all-reduce the flat gradient buffer (RCCL) once per step.
 
 There are no dataset pickles offline: ``--synthetic`` (default) draws seeded
-IEMOCAP-/MELD-shaped dialogues (synthetic.py).
+IEMOCAP-/MELD-shaped dialogues (synthetic.py); ``--synthetic=False --data_root=<dir>``
+(or $ERC_IEMOCAP_ROOT / $ERC_MELD_ROOT) reads the reference's feature pickles
+(datasets.py).  ``--device_collate`` keeps the dialogues resident in HBM and builds
+every batch on the device (datasets.DeviceDialogueStore) instead of in a DataLoader.
 """
 import json
 import os
@@ -22,6 +25,17 @@ from torch.utils.data import DataLoader
 
 from .collate import ERCCollate
 from .synthetic import make_dialogues
+
+
+def fix_seed(seed):
+    """What ``trainer.rnd.mark(seed)`` amounts to on a first run (lumo/trainer/rnd.py:17-33, lumo/utils/random.py:22-43):
+    python / numpy / torch generators seeded, so parameter initialisation and shuffling repeat run to run."""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
 
 
 class ListDataset(torch.utils.data.Dataset):
@@ -37,15 +51,45 @@ class ListDataset(torch.utils.data.Dataset):
         return [self.dialogs[i]]
 
 
-def make_loaders(params, rank=0, world=1):
+class StoreLoader:
+    """DataLoader-shaped iterator over a DeviceDialogueStore: seeded shuffle on the host, batch assembly on the device."""
+
+    def __init__(self, store, batch_size, shuffle, seed):
+        self.store, self.batch_size, self.shuffle = store, batch_size, shuffle
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        return -(-len(self.store) // self.batch_size)
+
+    def __iter__(self):
+        n = len(self.store)
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        for i in range(0, n, self.batch_size):
+            yield self.store.batch(order[i:i + self.batch_size])
+
+
+def load_dialogues(params, rank=0, world=1):
+    """(train dialogues of this rank, test dialogues)."""
     if not params.get("synthetic", True):
-        raise NotImplementedError("real-data pickle readers are a 'next' row (SURVEY.md 8f-2); use --synthetic")
+        from .datasets import read_dialogues
+        roots = params.get("data_root", None)
+        train = read_dialogues(params.dataset, "train", roots)
+        return train[rank::world], read_dialogues(params.dataset, "test", roots)   # dialogues sharded over the ranks
     meld = "meld" in params.dataset
     lo, hi = (1, 33) if meld else (20, 110)
     mk = lambda n, seed: make_dialogues(n, params.dims(), n_speakers=params.n_speakers, n_classes=params.n_classes,
                                         min_len=lo, max_len=hi, seed=seed)
-    train = ListDataset(mk(params.n_train, params.seed + 1000 * rank))   # every rank draws its own batches
-    test = ListDataset(mk(params.n_test, params.seed + 7))
+    return mk(params.n_train, params.seed + 1000 * rank), mk(params.n_test, params.seed + 7)   # every rank draws its own
+
+
+def make_loaders(params, rank=0, world=1, device=None):
+    train_d, test_d = load_dialogues(params, rank, world)
+    if params.get("device_collate", False):
+        from .datasets import DeviceDialogueStore
+        dt = torch.bfloat16 if params.compute == "bf16" else torch.float32
+        return (StoreLoader(DeviceDialogueStore(train_d, params, device, dt), params.train.batch_size, True, params.seed + rank),
+                StoreLoader(DeviceDialogueStore(test_d, params, device, dt), params.test.batch_size, False, 0))
+    train, test = ListDataset(train_d), ListDataset(test_d)
     collate = ERCCollate(params)
     gen = torch.Generator().manual_seed(params.seed + rank)
     tl = DataLoader(train, batch_size=params.train.batch_size, shuffle=True, collate_fn=collate,
@@ -84,8 +128,12 @@ def run(trainer_cls, params_cls, argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+    fix_seed(params.seed)
     trainer = trainer_cls(params, device)
-    train_loader, test_loader = make_loaders(params, rank, world)
+    if params.get("load"):      # checkpoint in the reference's envelope (checkpoint.py)
+        from . import checkpoint
+        checkpoint.load(trainer, params.load)
+    train_loader, test_loader = make_loaders(params, rank, world, device)
     best = {}
     for epoch in range(params.epoch):
         trainer.model.train()
@@ -115,6 +163,9 @@ def run(trainer_cls, params_cls, argv=None):
                 best[k] = max(best.get(k, 0.0), rep[k])
             print(json.dumps({"epoch": epoch, "train_utt_per_s": n_utt / dt, "test": {k: rep[k] for k in rep if k != "cm"},
                               "best": best}), flush=True)
+    if params.get("save") and rank == 0:
+        from . import checkpoint
+        checkpoint.save(trainer, params.save)
     if world > 1:
         torch.distributed.destroy_process_group()
     return best

@@ -170,3 +170,84 @@ def test_fused_head_equals_separate_launches_with_dropout():
     assert float(s0[1]) == float(s1[1]) and abs(float(s0[2]) - float(s1[2])) < 1e-4
     assert float((g0 - g1).abs().max()) <= 2e-5 * max(1.0, float(g1.abs().max()))
     assert float((rm0 - rm1).abs().max()) < 1e-6 and float((rv0 - rv1).abs().max()) < 1e-6
+
+
+def test_real_data_path_with_device_collate(tmp_path):
+    """``--synthetic=False --data_root=... --device_collate``: the reference's IEMOCAP pickle layout (synthetic content)
+    is read by datasets.py, kept resident in HBM and batched on the device; loss curve identical to the DataLoader path
+    with the same shuffle seed is not required -- both must train and report the metric set."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.test_datasets import _write_iemocap
+    _write_iemocap(str(tmp_path), 6, np.random.default_rng(5), with_maps=False)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = str(tmp_path / "last_model.ckpt")
+    for extra in (["--device_collate", "--save=" + ck], ["--load=" + ck]):
+        res = subprocess.run([sys.executable, "train_mm.py", "--module=cogmen", "--dataset=iemocap-cogmen-6", "--epoch=1",
+                              "--synthetic=False", "--data_root=" + str(tmp_path), "--train.batch_size=2",
+                              "--test.batch_size=2", "--compute=bf16"] + extra,
+                             cwd=repo, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+        assert len([l for l in lines if "Lall" in l]) == 2 and len([l for l in lines if "test" in l]) == 1
+        assert all(np.isfinite(l["Lall"]) for l in lines if "Lall" in l)
+        assert os.path.exists(ck)
+
+
+def test_checkpoint_envelope_round_trip_with_reference_style_trainer(tmp_path):
+    """Checkpoints in the reference's envelope ({'models': {'model': ...}, 'optims': {'optim': Adam state_dict}, ...},
+    mmbase.py:325-333): (1) a file written the way the reference trainer writes it (oracle module + torch.optim.Adam)
+    loads into the HIP trainer and training continues identically; (2) a file written here loads into the reference-style
+    pair with plain load_state_dict calls and continues identically."""
+    from oracle.cogmen import COGMENOracle, cogmen_train_step
+    from erc_amd import checkpoint
+    from erc_amd.cogmen import COGMENTrainer
+    from erc_amd.params import ERCParams
+    p = ERCParams().from_args(["--dataset=iemocap-cogmen-4", "--optim.lr=0.001", "--optim.weight_decay=1e-8"])
+    batches = [cogmen_case(B=5, min_len=2, max_len=20, dims=dict(a=100, t=100, v=512), seed=40 + s, n_classes=4)["batch"]
+               for s in range(4)]
+
+    def make_ref():
+        ref = COGMENOracle(p.hidden_all, 100, 17, p.n_speakers, p.n_classes, dead_encoder=False)
+        for m in ref.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        return ref.train(), torch.optim.Adam(ref.parameters(), lr=1e-3, weight_decay=1e-8)
+
+    def close(tr, ref, tol):
+        refp = dict(ref.named_parameters())
+        for name in tr.model.flat.params:
+            if name not in ZERO_GRAD:
+                assert float((tr.model.flat.w(name).cpu() - refp[name].detach()).abs().max()) < tol, name
+
+    # (1) reference-style file -> HIP trainer
+    torch.manual_seed(11)
+    ref, opt = make_ref()
+    for b in batches[:2]:
+        cogmen_train_step(ref, opt, b)
+    f1 = str(tmp_path / "best_model.ckpt")
+    torch.save({"optims": {"optim": opt.state_dict()}, "models": {"model": ref.state_dict()}, "others": {},
+                "thtensor": {}, "nptensor": {}}, f1)
+    tr = COGMENTrainer(p, "cuda:0")
+    tr.model.drop_p = 0.0
+    checkpoint.load(tr, f1)
+    assert int(tr.optim.state[0]) == 2
+    close(tr, ref, 1e-6)
+    l_ref, _ = cogmen_train_step(ref, opt, batches[2])
+    l_hip = float(tr.train_step(tr.prepare_batch(batches[2])).cpu()[0])
+    assert abs(l_hip - float(l_ref)) < 2e-5
+    close(tr, ref, 1e-4)
+    # (2) HIP trainer file -> reference-style pair
+    f2 = checkpoint.save(tr, str(tmp_path / "last_model.ckpt"))
+    ck = torch.load(f2, map_location="cpu", weights_only=True)
+    assert set(ck) == {"optims", "models", "others", "thtensor", "nptensor"}
+    assert int(ck["models"]["model"]["gcn.bn.num_batches_tracked"]) == 3
+    ref2, opt2 = make_ref()
+    ref2.load_state_dict(ck["models"]["model"])
+    opt2.load_state_dict(ck["optims"]["optim"])
+    l_ref2, _ = cogmen_train_step(ref2, opt2, batches[3])
+    l_hip2 = float(tr.train_step(tr.prepare_batch(batches[3])).cpu()[0])
+    assert abs(l_hip2 - float(l_ref2)) < 2e-5
+    close(tr, ref2, 1e-4)
