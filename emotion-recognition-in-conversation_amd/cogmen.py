@@ -277,8 +277,8 @@ class COGMENModule(nn.Module):
     def dominant_kernel_probe(self, batch, reps=200):
         """Time the HBM-dominant kernel of the step -- the input projection H0 = X[node_row] W1^T, the only
         kernel that touches the [B,T,D] feature block in the forward -- with HIP events on the stream it is
-        launched on: ``reps`` back-to-back launches between one event pair (inter-launch gaps included, so
-        the figure is conservative w.r.t. rocprofv3's per-dispatch duration).
+        launched on: ``reps`` back-to-back launches (one HIP-graph replay) between one event pair; inter-launch
+        gaps are included, so the figure is conservative w.r.t. rocprofv3's per-dispatch duration.
         Algorithmic bytes per launch: N*D*sizeof(x) + F*D*4 + N*F*4 + N*4."""
         x, lens, ys = batch["input_tensor"], batch["text_length"], batch["label"]
         B, T, N = self._shape(x, lens, ys)
@@ -302,10 +302,17 @@ class COGMENModule(nn.Module):
         for _ in range(10):
             launch()
         torch.cuda.synchronize()
+        # the reps launches are captured into one HIP graph and replayed: eager launches from Python are host-bound
+        # (~10 us per ctypes call), which would time the interpreter, not the kernel
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(reps):
+                launch()
+        graph.replay()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(reps):
-            launch()
+        graph.replay()
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
