@@ -289,7 +289,9 @@ __device__ __forceinline__ short f2bf_s(float f) {
 // W traffic through the per-CU L2 path -- the measured limiter of this kernel, ~70 GB/s per CU), 8 wavefronts
 // split K.  WB = true: W is given as a bf16 shadow copy (refreshed by the optimizer kernel), else fp32 rounded
 // while loaded.
-template <int NW, bool WB>
+// UB = K blocks per load batch: 6 (one batch covers K = 1380 / 8 wavefronts: fewest round trips, 188 VGPRs, one
+// workgroup per CU).
+template <int NW, bool WB, int UB>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
     __shared__ float red[NW > 1 ? NW * 16 * 64 : 1];
     const unsigned short* __restrict__ A = (const unsigned short*)p.A;
@@ -402,12 +404,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
     const bool has_tail = nkb > kb_full_end && (kb_full_end % NW) == w;
     bf16x8 ta[2] = {zero8, zero8}, tb[2] = {zero8, zero8};
     if (has_tail) load(kb_full_end, ta, tb, Fx{});
-    // batches of 6 K blocks per wavefront, all loads of a batch in flight; blocks past the end are clamped to a valid
+    // batches of UB K blocks per wavefront, all loads of a batch in flight; blocks past the end are clamped to a valid
     // one and their A fragments ANDed with zero (no select on a load result: hipcc would branch around the load)
-    for (int kb = w; kb < kb_full_end; kb += 6 * NW) {
-        bf16x8 a[6][2], b[6][2];
+    for (int kb = w; kb < kb_full_end; kb += UB * NW) {
+        bf16x8 a[UB][2], b[UB][2];
 #pragma unroll
-        for (int u = 0; u < 6; ++u) {
+        for (int u = 0; u < UB; ++u) {
             const bool valid = kb + u * NW < kb_full_end;
             load(valid ? kb + u * NW : kb, a[u], b[u], T{});
             const short mk = valid ? (short)-1 : (short)0;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 6; ++u) mma(a[u], b[u]);
+        for (int u = 0; u < UB; ++u) mma(a[u], b[u]);
     }
     if (has_tail) mma(ta, tb);
     // in-workgroup split-K reduction, then bias / relu epilogue
@@ -547,16 +549,22 @@ extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gath
     p.b_vec = w_is_bf16 ? bvec(W, ldw) : ((al16(W) && ldw % 4 == 0) ? 1 : 0);
     dim3 grid(8 * erc_cdiv(erc_cdiv(M, 32), 8) * erc_cdiv(N, 32), 1, 1);  // see the XCD-aware mapping in the kernel
     hipStream_t st = (hipStream_t)stream;
+    // UB = 3 with two workgroups per CU (<= 128 VGPRs) was tried for big grids: it spills (42 VGPRs) and ran 192 vs 118 us at
+    // B = 512; with 173 VGPRs and one workgroup per CU 143 us.  The single 6-block batch is kept for every size.
+    const bool big = false;
+#define ERC_BA(NW_, WB_)                                                                                          \
+    do {                                                                                                          \
+        if (big) hipLaunchKernelGGL((gemm_bf16a_stream_kernel<NW_, WB_, 3>), grid, dim3(64 * NW_), 0, st, p);     \
+        else hipLaunchKernelGGL((gemm_bf16a_stream_kernel<NW_, WB_, 6>), grid, dim3(64 * NW_), 0, st, p);         \
+    } while (0)
     if (nkb >= 16) {
-        if (w_is_bf16) hipLaunchKernelGGL((gemm_bf16a_stream_kernel<8, true>), grid, dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16a_stream_kernel<8, false>), grid, dim3(512), 0, st, p);
+        if (w_is_bf16) ERC_BA(8, true); else ERC_BA(8, false);
     } else if (nkb >= 4) {
-        if (w_is_bf16) hipLaunchKernelGGL((gemm_bf16a_stream_kernel<4, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16a_stream_kernel<4, false>), grid, dim3(256), 0, st, p);
+        if (w_is_bf16) ERC_BA(4, true); else ERC_BA(4, false);
     } else {
-        if (w_is_bf16) hipLaunchKernelGGL((gemm_bf16a_stream_kernel<1, true>), grid, dim3(64), 0, st, p);
-        else hipLaunchKernelGGL((gemm_bf16a_stream_kernel<1, false>), grid, dim3(64), 0, st, p);
+        if (w_is_bf16) ERC_BA(1, true); else ERC_BA(1, false);
     }
+#undef ERC_BA
     ERC_LAUNCH_CHECK("gemm_bf16a_stream");
     return ERC_OK;
 }

@@ -29,7 +29,7 @@ typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef const ERC_GLOBAL f32x4* gfloat4_cp;
 typedef const ERC_GLOBAL u16x4* gushort4_cp;
 
-constexpr int WG_U = 4;            // k-steps (of 4 k each) whose loads are in flight together
+constexpr int WG_U = 2;            // k-steps (of 4 k each) per load batch; 2 keeps 3 workgroups per CU (146 VGPRs)
 constexpr int WG_IDX_CAP = 2048;   // k per split (row-gather stage in LDS)
 constexpr int WG_SLAB = 4096 + 64; // floats per partial tile: 64 x 64 + one bias strip
 constexpr int WG_MAX_DESC = 32;
@@ -293,7 +293,7 @@ struct WgBases {  // first work item of every descriptor, passed by value (no de
     int v[WG_MAX_DESC];
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad_table_kernel(const WgDesc* __restrict__ table, const int n_desc,
+__global__ __launch_bounds__(256, 3) void wgrad_table_kernel(const WgDesc* __restrict__ table, const int n_desc,
                                                           const WgBases bases, const int item_offset, float* slabs,
                                                           int* counters) {
     __shared__ float red[4 * 2048];

@@ -90,7 +90,7 @@ class GemmPlanner:
         """C[M,N] = A[K,M]^T B[gather(K),N] (+ bias strip); B may be the bf16 feature block."""
         self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather))
 
-    WG_STEPS = 96   # k-steps (4 k each) per work item: 24 per wavefront (measured best of 48..128 on COGMEN B=32)
+    WG_STEPS = 64   # k-steps (4 k each) per work item: 16 per wavefront (measured best of 48..128 on COGMEN B=32)
 
     def flush_wgrads(self, cache):
         """Run every deferred K-major x K-major weight-gradient product as ONE launch (erc_wgrad_table, csrc/wgrad.hip).
