@@ -41,7 +41,8 @@ _SIGS = {
     "erc_rgcn_mean_fwd": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_rgcn_mean_bwd": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "erc_tconv_attn_fwd": (C.c_int, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp]),
-    "erc_tconv_attn_bwd_target": (C.c_int, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "erc_tconv_attn_bwd_target": (C.c_int, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _i, _vp, _vp,
+                                            _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_tconv_attn_bwd_source": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_bn_ws_floats": (C.c_int64, [_i]),
     "erc_bn_lrelu_fwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _f, _i, _vp, _vp, _i, _vp, _vp]),
@@ -207,12 +208,19 @@ def tconv_attn_fwd(qkvs, ld, F, N, scale, g, out, ldo, alpha):
                                     ptr(alpha), stream()), "erc_tconv_attn_fwd")
 
 
-def tconv_attn_bwd(qkvs, ld, F, N, scale, g, alpha, dout, lddo, dqkvs, dscore):
+def tconv_attn_bwd(qkvs, ld, F, N, scale, g, alpha, dout, lddo, dqkvs, dscore, bn=None):
+    """``bn`` = (x, ldx, gamma, saved, bn_bwd, dout_store): ``dout`` is then dY of the BatchNorm behind the layer and the
+    layer's own output gradient is derived inside the target pass (and stored in ``dout_store``)."""
+    if bn is None:
+        bn_args, dsrc = (None, 0, None, None, None, None), dout
+    else:
+        x, ldx, gamma, saved, bn_bwd, dsrc = bn
+        bn_args = (ptr(x), ldx, ptr(gamma), ptr(saved), ptr(bn_bwd), ptr(dsrc))
     _check(lib().erc_tconv_attn_bwd_target(ptr(qkvs), ld, F, N, scale, ptr(g["in_ptr"]), ptr(g["in_src"]),
-                                           ptr(alpha), ptr(dout), lddo, ptr(dqkvs), ptr(dscore), stream()),
+                                           ptr(alpha), ptr(dout), lddo, ptr(dqkvs), ptr(dscore), *bn_args, stream()),
            "erc_tconv_attn_bwd_target")
     _check(lib().erc_tconv_attn_bwd_source(ptr(qkvs), ld, F, N, ptr(g["out_ptr"]), ptr(g["out_dst"]),
-                                           ptr(g["out_eid"]), ptr(alpha), ptr(dscore), ptr(dout), lddo, ptr(dqkvs),
+                                           ptr(g["out_eid"]), ptr(alpha), ptr(dscore), ptr(dsrc), lddo, ptr(dqkvs),
                                            stream()), "erc_tconv_attn_bwd_source")
 
 

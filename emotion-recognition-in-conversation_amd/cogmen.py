@@ -236,17 +236,17 @@ class COGMENModule(nn.Module):
         with self.side.fork():
             linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
                          fp.offsets["cls.0.bias"], defer=True)
-        if fused_head:
-            capi.bn_bwd_apply(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["dH3"], F,
-                              ws["dH2"], F)
+        bn_prologue = None
+        if fused_head:   # BatchNorm's elementwise backward runs inside the attention backward (one launch less)
+            bn_prologue = (ws["H2"], F, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["dH2"])
         else:
             capi.gemm_f32(ws["dZ"], F, 0, None, fp.w("cls.0.weight"), F, 1, None, ws["dH3"], F, N, F, F)
             # BatchNorm + LeakyReLU
             capi.bn_lrelu_bwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
                               ws["dH3"], F, ws["dH2"], F, fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"), ws["bn_ws"])
         # TransformerConv
-        capi.tconv_attn_bwd(ws["QKVS"], 4 * F, F, N, 1.0 / math.sqrt(F), g, ws["alpha"], ws["dH2"], F,
-                            ws["dQKVS"], ws["dscore"])
+        capi.tconv_attn_bwd(ws["QKVS"], 4 * F, F, N, 1.0 / math.sqrt(F), g, ws["alpha"],
+                            ws["dH3"] if fused_head else ws["dH2"], F, ws["dQKVS"], ws["dscore"], bn=bn_prologue)
         capi.gemm_f32(ws["dQKVS"], 4 * F, 0, None, fp.w("gcn.conv2.lin_query.weight"), F, 1, None, ws["dH1"], F,
                       N, F, 4 * F)
         with self.side.fork():

@@ -184,19 +184,42 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(const float* __restrict_
     for (int e = e0 + lane; e < e1; e += 64) alpha[e] *= inv;
 }
 
+// BN = true: the gradient wrt this layer's output is not given but derived on the fly from the BatchNorm that follows
+// (elementwise part of BatchNorm1d's backward, cogmen.py:67,72): dout = gamma * rstd * (dY - ma - xhat * mb), with
+// `dout` = dY, x = the BatchNorm input (= this layer's forward output), and written to dout_store for the source pass.
+struct BnBwd {
+    const float* x;       // [N, ldx]
+    const float* gamma;   // [F]
+    const float* saved;   // [0,F) mean, [F,2F) rstd
+    const float* bn_bwd;  // [0,F) mean of dY, [F,2F) mean of dY * xhat
+    float* dout_store;    // [N, lddo]
+    int ldx;
+};
+
+template <bool BN>
 __global__ __launch_bounds__(256) void tconv_bwd_target_kernel(const float* __restrict__ qkvs, int ld, int F, int N,
                                                                float scale, const int32_t* __restrict__ in_ptr,
                                                                const int32_t* __restrict__ in_src,
                                                                const float* __restrict__ alpha,
                                                                const float* __restrict__ dout, int lddo,
                                                                float* __restrict__ dqkvs,
-                                                               float* __restrict__ dscore) {
+                                                               float* __restrict__ dscore, const BnBwd bn) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= N) return;
     const bool h0 = lane < F, h1 = lane + 64 < F;
     const int c0 = min(lane, F - 1), c1 = min(lane + 64, F - 1);
-    const Row2 gr = ldrow(dout, i, lddo, c0, c1);
+    Row2 gr = ldrow(dout, i, lddo, c0, c1);
+    if (BN) {
+        const Row2 xr = ldrow(bn.x, i, bn.ldx, c0, c1);
+        const float mu0 = bn.saved[c0], mu1 = bn.saved[c1], rs0 = bn.saved[F + c0], rs1 = bn.saved[F + c1];
+        const float ga0 = bn.gamma[c0], ga1 = bn.gamma[c1];
+        const float ma0 = bn.bn_bwd[c0], ma1 = bn.bn_bwd[c1], mb0 = bn.bn_bwd[F + c0], mb1 = bn.bn_bwd[F + c1];
+        gr.a = ga0 * rs0 * (gr.a - ma0 - (xr.a - mu0) * rs0 * mb0);
+        gr.b = ga1 * rs1 * (gr.b - ma1 - (xr.b - mu1) * rs1 * mb1);
+        if (h0) bn.dout_store[(int64_t)i * lddo + lane] = gr.a;
+        if (h1) bn.dout_store[(int64_t)i * lddo + lane + 64] = gr.b;
+    }
     const float g0 = h0 ? gr.a : 0.f, g1 = h1 ? gr.b : 0.f;
     const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
     // pass 1: t = sum_e alpha_e (dout_i . v_src(e)); lane l keeps d alpha of edge l (first window)
@@ -337,11 +360,19 @@ extern "C" int erc_tconv_attn_fwd(const float* qkvs, int ld, int F, int N, float
 
 extern "C" int erc_tconv_attn_bwd_target(const float* qkvs, int ld, int F, int N, float scale, const int32_t* in_ptr,
                                          const int32_t* in_src, const float* alpha, const float* dout, int lddo,
-                                         float* dqkvs, float* dscore, void* stream) {
+                                         float* dqkvs, float* dscore, const float* bn_x, int bn_ldx, const float* bn_gamma,
+                                         const float* bn_saved, const float* bn_bwd, float* dout_store, void* stream) {
     ERC_REQUIRE(qkvs && in_ptr && in_src && alpha && dout && dqkvs && dscore, "tconv_attn_bwd_target: null pointer");
     ERC_REQUIRE(F > 0 && F <= 128 && N > 0 && ld >= 4 * F, "tconv_attn_bwd_target: bad sizes");
-    hipLaunchKernelGGL(tconv_bwd_target_kernel, dim3(erc_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, qkvs, ld, F, N,
-                       scale, in_ptr, in_src, alpha, dout, lddo, dqkvs, dscore);
+    const BnBwd bn{bn_x, bn_gamma, bn_saved, bn_bwd, dout_store, bn_ldx};
+    if (bn_x) {
+        ERC_REQUIRE(bn_gamma && bn_saved && bn_bwd && dout_store && bn_ldx >= F, "tconv_attn_bwd_target: BatchNorm prologue operands");
+        hipLaunchKernelGGL(tconv_bwd_target_kernel<true>, dim3(erc_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, qkvs, ld, F,
+                           N, scale, in_ptr, in_src, alpha, dout, lddo, dqkvs, dscore, bn);
+    } else {
+        hipLaunchKernelGGL(tconv_bwd_target_kernel<false>, dim3(erc_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, qkvs, ld,
+                           F, N, scale, in_ptr, in_src, alpha, dout, lddo, dqkvs, dscore, bn);
+    }
     ERC_LAUNCH_CHECK("tconv_attn_bwd_target");
     return ERC_OK;
 }

@@ -191,10 +191,17 @@ int erc_rgcn_mean_bwd(const float* dM, int ldm, int F, int R, int N,
 int erc_tconv_attn_fwd(const float* qkvs, int ld, int F, int N, float scale,
                        const int32_t* in_ptr, const int32_t* in_src,
                        float* out, int ldo, float* alpha, void* stream);
-/* backward, target side: dq_i, dskip_i and dscore_e (= dL/d(q.k), scale folded in) */
+/* backward, target side: dq_i, dskip_i and dscore_e (= dL/d(q.k), scale folded in).
+ * Optional BatchNorm-backward prologue (bn_x != NULL; the BatchNorm1d that follows the layer, cogmen.py:67,72): `dout`
+ * then holds dY = dL/d(BatchNorm output) and the kernel derives the layer's output gradient itself,
+ *   dout_i = gamma * rstd * (dY_i - bn_bwd[c] - xhat_i * bn_bwd[F + c]),  xhat = (bn_x - saved[c]) * saved[F + c],
+ * writing it to dout_store [N, lddo] (the source-side pass reads it there) -- one launch less than
+ * erc_bn_bwd_apply + this. */
 int erc_tconv_attn_bwd_target(const float* qkvs, int ld, int F, int N, float scale,
                               const int32_t* in_ptr, const int32_t* in_src, const float* alpha,
-                              const float* dout, int lddo, float* dqkvs, float* dscore, void* stream);
+                              const float* dout, int lddo, float* dqkvs, float* dscore,
+                              const float* bn_x, int bn_ldx, const float* bn_gamma, const float* bn_saved,
+                              const float* bn_bwd, float* dout_store, void* stream);
 /* backward, source side: dk_j = sum_{e out of j} dscore_e q_dst, dv_j = sum alpha_e dout_dst */
 int erc_tconv_attn_bwd_source(const float* qkvs, int ld, int F, int N,
                               const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
