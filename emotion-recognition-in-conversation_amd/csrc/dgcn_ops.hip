@@ -180,15 +180,63 @@ __global__ __launch_bounds__(256) void brgcn_bwd_target_kernel(const float* __re
     }
 }
 
-// datt[r, b] = sum_{e: type_e == r} TT[e, b]; one workgroup per relation, fixed summation order
+// datt[r, b] = sum_{e: type_e == r} TT[e, b]; one workgroup per relation, fixed summation order.
+// Phase 1: every wavefront scans a contiguous quarter of the edge types (coalesced, 8 loads in flight) and appends the
+// matching edge ids to its own LDS list with ballot / popcount -- no barrier, lists stay in edge order.  Phase 2: the
+// four lists are walked by 8 slots x 32 lanes (8 rows of TT in flight per slot); slots are combined in fixed order.
+// (The first version tested typ[e] == r per edge inside the accumulation loop: ~1750 dependent guarded loads per
+// thread, 120 us for E = 14 k edges; this one 1/10 of that.)
+constexpr int RS_CAP = 2048;  // matching edges kept per wavefront; more fall back to the scan-and-add path
+
 __global__ __launch_bounds__(256) void rel_sum_kernel(const float* __restrict__ TT, const int32_t* __restrict__ typ,
                                                       const int32_t* __restrict__ counts, float* __restrict__ datt) {
-    const int r = blockIdx.x, b = threadIdx.x & 31, slot = threadIdx.x >> 5;  // 8 edge slots x 32 lanes (30 used)
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int E = counts[1];
+    if (E <= 0) {
+        if (tid < NB) datt[r * NB + tid] = 0.f;
+        return;
+    }
+    __shared__ int list[4][RS_CAP];
+    __shared__ int cnt[4];
     __shared__ float sh[8][32];
+    const int per = (E + 3) / 4, e_lo = w * per, e_hi = min(E, e_lo + per);
+    int n = 0;
+    for (int e0 = e_lo; e0 < e_hi; e0 += 8 * 64) {
+        int t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = typ[min(e0 + u * 64 + lane, E - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 64 + lane;
+            const bool hit = e < e_hi && t[u] == r;
+            const unsigned long long m = __ballot(hit);
+            const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && pos < RS_CAP) list[w][pos] = e;
+            n += __popcll(m);
+        }
+    }
+    if (lane == 0) cnt[w] = n;
+    __syncthreads();
+    const int b = tid & 31, slot = tid >> 5;  // 8 slots x 32 lanes (NB = 30 used)
+    const int bc = min(b, NB - 1);
     float acc = 0.f;
-    for (int e = slot; e < E; e += 8)
-        if (typ[e] == r && b < NB) acc += TT[(int64_t)e * NB + b];
+    const bool overflow = cnt[0] > RS_CAP || cnt[1] > RS_CAP || cnt[2] > RS_CAP || cnt[3] > RS_CAP;
+    if (!overflow) {
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const int c = cnt[ww];
+            for (int i0 = slot; i0 < c; i0 += 8 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = TT[(int64_t)list[ww][min(i0 + 8 * u, c - 1)] * NB + bc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u] * (i0 + 8 * u < c ? 1.f : 0.f);
+            }
+        }
+    } else {
+        for (int e = slot; e < E; e += 8)
+            if (typ[e] == r) acc += TT[(int64_t)e * NB + bc];
+    }
     sh[slot][b] = acc;
     __syncthreads();
     if (slot == 0 && b < NB) {

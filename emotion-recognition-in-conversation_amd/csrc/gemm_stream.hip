@@ -343,6 +343,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
             } else if (FULL && p.a_vec == 1) {
                 const bf16x4 lo = *reinterpret_cast<const bf16x4*>(s + k), hi = *reinterpret_cast<const bf16x4*>(s + k + 4);
                 a[h] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else if (FULL && p.a_vec == 4) {   // rows only 4-byte aligned (odd multiples of 2 elements, e.g. D = 1242)
+                typedef short bf16x2 __attribute__((ext_vector_type(2)));
+                const bf16x2 q0 = *reinterpret_cast<const bf16x2*>(s + k), q1 = *reinterpret_cast<const bf16x2*>(s + k + 2);
+                const bf16x2 q2 = *reinterpret_cast<const bf16x2*>(s + k + 4), q3 = *reinterpret_cast<const bf16x2*>(s + k + 6);
+                a[h] = (bf16x8){q0[0], q0[1], q1[0], q1[1], q2[0], q2[1], q3[0], q3[1]};
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -372,9 +377,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
             } else {
                 const float* bp = (const float*)p.B + (int64_t)nc[f] * p.ldb;
                 float t[8];
-                if (FULL && p.b_vec) {
+                if (FULL && p.b_vec == 1) {
                     const float4 lo = *reinterpret_cast<const float4*>(bp + k), hi = *reinterpret_cast<const float4*>(bp + k + 4);
                     t[0] = lo.x, t[1] = lo.y, t[2] = lo.z, t[3] = lo.w, t[4] = hi.x, t[5] = hi.y, t[6] = hi.z, t[7] = hi.w;
+                } else if (FULL && p.b_vec == 3) {   // rows only 8-byte aligned
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float2 v2 = *reinterpret_cast<const float2*>(bp + k + 2 * j);
+                        t[2 * j] = v2.x, t[2 * j + 1] = v2.y;
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -544,9 +555,10 @@ extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gath
     p.M = M; p.N = N; p.K = K; p.act = act;
     const int nkb = erc_cdiv(K, 32);
     p.kblocks_per_split = nkb;
-    auto bvec = [](const void* q, int ld) { return !al16(q) ? 0 : (ld % 8 == 0 ? 2 : (ld % 4 == 0 ? 1 : 0)); };
+    // widest legal access per 8-element fragment: 2 = 16 B, 1 = 8 B, 4 = 4 B (bf16 operands); fp32 W: 1 = 16 B, 3 = 8 B
+    auto bvec = [](const void* q, int ld) { return !al16(q) ? 0 : (ld % 8 == 0 ? 2 : (ld % 4 == 0 ? 1 : (ld % 2 == 0 ? 4 : 0))); };
     p.a_vec = bvec(X, ldx);
-    p.b_vec = w_is_bf16 ? bvec(W, ldw) : ((al16(W) && ldw % 4 == 0) ? 1 : 0);
+    p.b_vec = w_is_bf16 ? bvec(W, ldw) : (!al16(W) ? 0 : (ldw % 4 == 0 ? 1 : (ldw % 2 == 0 ? 3 : 0)));
     dim3 grid(8 * erc_cdiv(erc_cdiv(M, 32), 8) * erc_cdiv(N, 32), 1, 1);  // see the XCD-aware mapping in the kernel
     hipStream_t st = (hipStream_t)stream;
     // UB = 3 with two workgroups per CU (<= 128 VGPRs) was tried for big grids: it spills (42 VGPRs) and ran 192 vs 118 us at
