@@ -107,6 +107,56 @@ __device__ __forceinline__ void store_vec300(float* dst, const Vec300& v, int la
     if (lane < 11) *reinterpret_cast<float4*>(dst + 256 + 4 * lane) = v.hi;
 }
 
+// ----------------------------------------------------------------------------- cluster scan (P workgroups per dialogue)
+// The per-step weight traffic (2.9 MB) through ONE CU's L2 path (~70 GB/s) is what bounds the single-workgroup scan
+// (66 us / step forward).  In cluster mode P workgroups share a dialogue: each streams 1/P of the rows of the three
+// matrices, the results are exchanged through the buffers the scan writes anyway (GH, R, ks; partial vectors in the
+// backward) with write-through (sc1) stores, and everything cheap (attention over the window, the GRU cells) is
+// computed redundantly by every member.  Synchronisation: one monotonic arrival counter per dialogue (zero at
+// launch): stores drained (s_waitcnt vmcnt(0)) -> workgroup barrier -> one lane adds 1 and polls (sc1 load) until all
+// P members of the phase have arrived -> workgroup barrier -> sc1 loads.  All B * P workgroups must be co-resident
+// (the host keeps B * P <= 224, one 1024-thread workgroup per CU); the poll is bounded so that a violated
+// assumption ends in a flagged error, not in a hung GPU.
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int CL_SPIN_LIMIT = 4000000;   // ~ seconds; a step normally waits a few microseconds
+
+__device__ __forceinline__ void cluster_sync(int* ctr, int target, int* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > CL_SPIN_LIMIT) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// rows [r_lo, r_hi) of out = W v (+ bias), results to global memory with write-through stores
+__device__ __forceinline__ void matvec_rows_sc1(const float* __restrict__ W, const float* __restrict__ bias, int r_lo, int r_hi,
+                                                const float* v_lds, float* out_glb, int lane, int wave) {
+    const Vec300 v = load_vec300(v_lds, lane);
+    const int rows = r_hi - r_lo;
+    for (int r0 = wave; r0 < rows; r0 += RB * NW) {
+        float acc[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) acc[u] = dot300(W + (int64_t)(r_lo + min(r0 + u * NW, rows - 1)) * HID, v, lane);
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int r = r0 + u * NW;
+            const float s = wave_sum(acc[u]);
+            if (r < rows && lane == 0) st_sc1(out_glb + r_lo + r, s + (bias ? bias[r_lo + r] : 0.f));
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- meta
 // speaker ids, DAG predecessor, valid-row map.  One workgroup per dialogue.
 __global__ __launch_bounds__(256) void dag_meta_kernel(const float* __restrict__ onehot, const int64_t* __restrict__ ids,
@@ -263,6 +313,134 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_kernel(DagFwd p) {
     }
 }
 
+// ----------------------------------------------------------------------------- forward scan, cluster mode
+struct DagCluster {
+    int P;          // workgroups per dialogue
+    int* ctr;       // [B] arrival counters, zero at launch
+    int* err;       // set to 1 if a poll ran into its bound
+    float* scratch; // backward only: [B][2][P][320] partial vectors
+};
+
+// workgroup id -> (dialogue, member): the members of a dialogue get ids that are equal mod 8, i.e. the same XCD under
+// round-robin placement (speed only: the exchange then stays inside one L2)
+__device__ __forceinline__ void cluster_ids(int P, int& b, int& m) {
+    const int id = blockIdx.x;
+    b = (id / (8 * P)) * 8 + (id & 7);
+    m = (id >> 3) % P;
+}
+
+__global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagCluster cl) {
+    int b, mem;
+    cluster_ids(cl.P, b, mem);
+    if (b >= p.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.T, P = cl.P;
+    __shared__ __attribute__((aligned(16))) float v_m[320], v_h[320], v_x[320], gates[2 * G3], s_alpha[MAX_T];
+    const float* w_q = p.w_lin;
+    const float* w_k = p.w_lin + HID;
+    const float b_lin = p.w_lin[2 * HID];
+    int* const ctr = cl.ctr + b;
+    const int g_lo = mem * G3 / P, g_hi = (mem + 1) * G3 / P;              // rows of each 900-row gate matrix
+    const int r_lo = mem * 2 * HID / P, r_hi = (mem + 1) * 2 * HID / P;    // rows of Wr
+    int phase = 0;
+
+    for (int i = 0; i < T; ++i) {
+        const int64_t row = (int64_t)b * T + i;
+        const float* x = p.Hl + row * p.ldh;
+        if (tid < HID) v_x[tid] = x[tid];
+        __syncthreads();
+        // ---- A: attention over the DAG predecessors [lo, i-1] (every member; R / ks come from all members: sc1 loads)
+        int lo = 0, n = 0;
+        if (i > 0) {
+            const int pr = p.pred[row];
+            lo = pr > 0 ? pr : 0;
+            n = i - lo;
+            if (wave == 0) {
+                const float qs = wave_sum(dot300(w_q, load_vec300(v_x, lane), lane)) + b_lin;
+                float mx = -INFINITY;
+                for (int j = lane; j < n; j += 64) {
+                    const float k = ld_sc1(p.ks + (int64_t)b * T + lo + j);
+                    s_alpha[j] = k;
+                    mx = fmaxf(mx, qs + k);
+                }
+                mx = wave_max(mx);
+                float den = 0.f;
+                for (int j = lane; j < n; j += 64) {
+                    const float e = expf(qs + s_alpha[j] - mx);
+                    s_alpha[j] = e;
+                    den += e;
+                }
+                den = wave_sum(den);
+                const float inv = 1.0f / den;
+                for (int j = lane; j < n; j += 64) {
+                    const float al = s_alpha[j] * inv;
+                    s_alpha[j] = al;
+                    if (mem == 0) p.alpha[((int64_t)b * T + i) * T + lo + j] = al;
+                }
+            }
+            __syncthreads();
+            if (tid < HID) {
+                const int si = p.spk[row];
+                float m = 0.f;
+                for (int j0 = 0; j0 < n; j0 += 8) {      // 8 predecessor rows in flight
+                    float rv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t rj = (int64_t)b * T + lo + min(j0 + u, n - 1);
+                        rv[u] = ld_sc1(p.R + rj * 2 * HID + (p.spk[rj] == si ? 0 : HID) + tid);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) m += (j0 + u < n ? s_alpha[j0 + u] : 0.f) * rv[u];
+                }
+                v_m[tid] = m;
+                if (mem == 0) p.Mseq[row * HID + tid] = m;
+            }
+        } else if (tid < HID) {
+            v_m[tid] = 0.f;
+            if (mem == 0) p.Mseq[row * HID + tid] = 0.f;
+        }
+        __syncthreads();
+        // ---- B: this member's rows of the sequential gate pre-activations, exchanged through GH
+        float* gh = p.GH + row * 2 * G3;
+        if (i > 0) {
+            matvec_rows_sc1(p.W_hh_c, p.b_hh_c, g_lo, g_hi, v_m, gh, lane, wave);
+            matvec_rows_sc1(p.W_ih_p, p.b_ih_p, g_lo, g_hi, v_m, gh + G3, lane, wave);
+            cluster_sync(ctr, P * (++phase), cl.err);
+            for (int r = tid; r < 2 * G3; r += NT) gates[r] = ld_sc1(gh + r);
+        } else {
+            for (int r = tid; r < G3; r += NT) {
+                gates[r] = p.b_hh_c[r];
+                gates[G3 + r] = p.b_ih_p[r];
+                if (mem == 0) gh[r] = p.b_hh_c[r], gh[G3 + r] = p.b_ih_p[r];
+            }
+        }
+        __syncthreads();
+        // ---- C: the two GRU cells, h1 = C + P (every member)
+        if (tid < HID) {
+            const float* gi = p.GI + row * 2 * G3;
+            float r = sigmoidf_(gi[tid] + gates[tid]);
+            float z = sigmoidf_(gi[HID + tid] + gates[HID + tid]);
+            float nn = tanhf(gi[2 * HID + tid] + r * gates[2 * HID + tid]);
+            const float c = (1.f - z) * nn + z * v_m[tid];
+            r = sigmoidf_(gates[G3 + tid] + gi[G3 + tid]);
+            z = sigmoidf_(gates[G3 + HID + tid] + gi[G3 + HID + tid]);
+            nn = tanhf(gates[G3 + 2 * HID + tid] + r * gi[G3 + 2 * HID + tid]);
+            const float pp = (1.f - z) * nn + z * v_x[tid];
+            const float h1 = c + pp;
+            v_h[tid] = h1;
+            if (mem == 0) p.H1[row * p.ldo + tid] = h1;
+        }
+        __syncthreads();
+        // ---- D: this member's rows of the relation transforms; the key score by the last member
+        matvec_rows_sc1(p.Wr, nullptr, r_lo, r_hi, v_h, p.R + row * 2 * HID, lane, wave);
+        if (mem == P - 1 && wave == NW - 1) {
+            const float a = wave_sum(dot300(w_k, load_vec300(v_h, lane), lane));
+            if (lane == 0) st_sc1(p.ks + row, a);
+        }
+        if (i + 1 < T) cluster_sync(ctr, P * (++phase), cl.err);   // R / ks of this step visible to every member
+    }
+}
+
 // ----------------------------------------------------------------------------- backward scan
 struct DagBwd {
     const float* Hl; int ldh;
@@ -413,6 +591,178 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
     }
 }
 
+// ----------------------------------------------------------------------------- backward scan, cluster mode
+// Transposed products: a member covers its rows of Wr / W_hh_c / W_ih_p and gets a PARTIAL 300-vector; the partials
+// are exchanged through scratch[b][phase][member][320] and summed by every member in member order.  The
+// accumulations into dR are owned column-wise (member m updates columns [300 m / P, 300 (m+1) / P) of both relation
+// slots), those into dks / dH_l / the linear-layer gradients by member 0.
+__device__ __forceinline__ void reduce_wave_partials(const float (*part)[320], float* dst_glb, int tid) {
+    if (tid < HID) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += part[w][tid];
+        st_sc1(dst_glb + tid, s);
+    }
+}
+
+__global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagCluster cl) {
+    int b, mem;
+    cluster_ids(cl.P, b, mem);
+    if (b >= p.B) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.T, P = cl.P;
+    __shared__ __attribute__((aligned(16))) float v_g[320], v_dm[320], v_x[320], v_m[320], v_in[2 * G3], part[NW][320], s_al[MAX_T], s_da[MAX_T];
+    __shared__ float s_dqs;
+    const float* w_q = p.w_lin;
+    const float* w_k = p.w_lin + HID;
+    float dwq = 0.f, dwk = 0.f, dbl = 0.f;
+    int* const ctr = cl.ctr + b;
+    const int g_lo = mem * G3 / P, g_hi = (mem + 1) * G3 / P;
+    const int r_lo = mem * 2 * HID / P, r_hi = (mem + 1) * 2 * HID / P;
+    const int c_lo = mem * HID / P, c_hi = (mem + 1) * HID / P;      // columns of dR this member accumulates
+    float* const sc0 = cl.scratch + ((int64_t)b * 2 + 0) * P * 320;
+    float* const sc1_ = cl.scratch + ((int64_t)b * 2 + 1) * P * 320;
+    int phase = 0;
+
+    for (int i = T - 1; i >= 0; --i) {
+        const int64_t row = (int64_t)b * T + i;
+        // ---- 1: total gradient wrt h1_i = dH1_i + Wr^T dR_i + w_k dks_i
+        for (int r = tid; r < 2 * HID; r += NT) v_in[r] = ld_sc1(p.dR + row * 2 * HID + r);
+        if (tid < HID) {
+            v_x[tid] = p.Hl[row * p.ldh + tid];
+            v_m[tid] = p.Mseq[row * HID + tid];
+        }
+        __syncthreads();
+        {
+            Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            matvec_t_accum(p.Wr + (int64_t)r_lo * HID, r_hi - r_lo, v_in + r_lo, acc, lane, wave);
+            store_vec300(part[wave], acc, lane);
+        }
+        __syncthreads();
+        reduce_wave_partials(part, sc0 + mem * 320, tid);
+        cluster_sync(ctr, P * (++phase), cl.err);
+        const float dks_i = ld_sc1(p.dks + row);
+        if (tid < HID) {
+            float g = p.dH1[row * p.ldd + tid] + w_k[tid] * dks_i;
+            for (int m = 0; m < P; ++m) g += ld_sc1(sc0 + m * 320 + tid);
+            v_g[tid] = g;
+            dwk += dks_i * p.H1[row * p.ldo + tid];
+        }
+        __syncthreads();
+        // ---- 2: GRU cells backward (elementwise, every member; member 0 stores)
+        if (tid < HID) {
+            const float* gi = p.GI + row * 2 * G3;
+            const float* gh = p.GH + row * 2 * G3;
+            float* dgi = p.DGI + row * 2 * G3;
+            float* dgh = p.DGH + row * 2 * G3;
+            const float g = v_g[tid];
+            const bool st = mem == 0;
+            {
+                const float r = sigmoidf_(gi[tid] + gh[tid]);
+                const float z = sigmoidf_(gi[HID + tid] + gh[HID + tid]);
+                const float ghn = gh[2 * HID + tid];
+                const float nn = tanhf(gi[2 * HID + tid] + r * ghn);
+                const float dn_pre = g * (1.f - z) * (1.f - nn * nn);
+                const float dz_pre = g * (v_m[tid] - nn) * z * (1.f - z);
+                const float dr_pre = dn_pre * ghn * r * (1.f - r);
+                if (st) {
+                    dgi[tid] = dr_pre; dgi[HID + tid] = dz_pre; dgi[2 * HID + tid] = dn_pre;
+                    dgh[tid] = dr_pre; dgh[HID + tid] = dz_pre; dgh[2 * HID + tid] = dn_pre * r;
+                }
+                v_in[tid] = dr_pre; v_in[HID + tid] = dz_pre; v_in[2 * HID + tid] = dn_pre * r;
+                v_dm[tid] = g * z;
+            }
+            {
+                const float r = sigmoidf_(gh[G3 + tid] + gi[G3 + tid]);
+                const float z = sigmoidf_(gh[G3 + HID + tid] + gi[G3 + HID + tid]);
+                const float hn = gi[G3 + 2 * HID + tid];
+                const float nn = tanhf(gh[G3 + 2 * HID + tid] + r * hn);
+                const float dn_pre = g * (1.f - z) * (1.f - nn * nn);
+                const float dz_pre = g * (v_x[tid] - nn) * z * (1.f - z);
+                const float dr_pre = dn_pre * hn * r * (1.f - r);
+                if (st) {
+                    dgh[G3 + tid] = dr_pre; dgh[G3 + HID + tid] = dz_pre; dgh[G3 + 2 * HID + tid] = dn_pre;
+                    dgi[G3 + tid] = dr_pre; dgi[G3 + HID + tid] = dz_pre; dgi[G3 + 2 * HID + tid] = dn_pre * r;
+                    p.dHl[row * p.lddl + tid] += g * z;
+                }
+                v_in[G3 + tid] = dr_pre; v_in[G3 + HID + tid] = dz_pre; v_in[G3 + 2 * HID + tid] = dn_pre;
+            }
+        }
+        __syncthreads();
+        if (i == 0) break;  // M_0 = 0 has no producers
+        // ---- 3: dM_i = direct + W_hh_c^T dgh_c + W_ih_p^T dgi_p
+        {
+            Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            matvec_t_accum(p.W_hh_c + (int64_t)g_lo * HID, g_hi - g_lo, v_in + g_lo, acc, lane, wave);
+            matvec_t_accum(p.W_ih_p + (int64_t)g_lo * HID, g_hi - g_lo, v_in + G3 + g_lo, acc, lane, wave);
+            store_vec300(part[wave], acc, lane);
+        }
+        __syncthreads();
+        reduce_wave_partials(part, sc1_ + mem * 320, tid);
+        cluster_sync(ctr, P * (++phase), cl.err);
+        if (tid < HID) {
+            float d = v_dm[tid];
+            for (int m = 0; m < P; ++m) d += ld_sc1(sc1_ + m * 320 + tid);
+            v_dm[tid] = d;
+        }
+        __syncthreads();
+        // ---- 4: attention backward over the window [lo, i-1]
+        const int pr = p.pred[row];
+        const int lo = pr > 0 ? pr : 0;
+        const int n = i - lo;
+        const int si = p.spk[row];
+        for (int j = wave; j < n; j += NW) {  // d alpha_j = dM . V_j
+            const int64_t rj = (int64_t)b * T + lo + j;
+            const float* v = p.R + rj * 2 * HID + (p.spk[rj] == si ? 0 : HID);
+            const float a = wave_sum(dot300(v, load_vec300(v_dm, lane), lane));
+            if (lane == 0) {
+                s_da[j] = a;
+                s_al[j] = p.alpha[((int64_t)b * T + i) * T + lo + j];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float t = 0.f;
+            for (int j = lane; j < n; j += 64) t += s_al[j] * s_da[j];
+            t = wave_sum(t);
+            float dq = 0.f;
+            for (int j = lane; j < n; j += 64) {
+                const float ds = s_al[j] * (s_da[j] - t);
+                dq += ds;
+                if (mem == 0) {
+                    float* q = p.dks + (int64_t)b * T + lo + j;
+                    st_sc1(q, ld_sc1(q) + ds);
+                }
+            }
+            dq = wave_sum(dq);
+            if (lane == 0) s_dqs = dq;
+        }
+        __syncthreads();
+        if (tid < HID) {
+            const float dq = s_dqs;
+            const float dm = v_dm[tid];
+            if (tid >= c_lo && tid < c_hi) {
+                for (int j = 0; j < n; ++j) {  // dV_j = alpha_j dM into the relation slot that was read
+                    const int64_t rj = (int64_t)b * T + lo + j;
+                    float* q = p.dR + rj * 2 * HID + (p.spk[rj] == si ? 0 : HID) + tid;
+                    st_sc1(q, ld_sc1(q) + s_al[j] * dm);
+                }
+            }
+            if (mem == 0) {
+                p.dHl[row * p.lddl + tid] += dq * w_q[tid];
+                dwq += dq * v_x[tid];
+                if (tid == 0) dbl += dq;
+            }
+        }
+        cluster_sync(ctr, P * (++phase), cl.err);  // dR / dks updates visible to every member before the earlier steps
+    }
+    if (mem == 0 && tid < HID) {
+        p.dlin[(int64_t)b * (2 * HID + 1) + tid] = dwq;
+        p.dlin[(int64_t)b * (2 * HID + 1) + HID + tid] = dwk;
+        if (tid == 0) p.dlin[(int64_t)b * (2 * HID + 1) + 2 * HID] = dbl;
+    }
+}
+
 }  // namespace
 
 extern "C" int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_t spk_sb, int64_t spk_st,
@@ -427,32 +777,61 @@ extern "C" int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_
     return ERC_OK;
 }
 
+extern "C" int erc_dag_cluster_size(int B) {
+    // workgroups per dialogue: all B * P persistent 1024-thread workgroups must be resident at once (256 CUs)
+    int P = 224 / (B > 0 ? B : 1);
+    if (P > 8) P = 8;
+    return P < 2 ? 1 : P;
+}
+
 extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const float* W_hh_c, const float* b_hh_c,
                                 const float* W_ih_p, const float* b_ih_p, const float* Wr, const float* w_lin,
                                 const int32_t* pred, const int32_t* spk, int B, int T, float* H1, int ldo, float* Mseq,
-                                float* GH, float* R, float* ks, float* alpha, void* stream) {
+                                float* GH, float* R, float* ks, float* alpha, int cluster, int32_t* cl_state, void* stream) {
     ERC_REQUIRE(Hl && GI && W_hh_c && b_hh_c && W_ih_p && b_ih_p && Wr && w_lin && pred && spk && H1 && Mseq && GH &&
                     R && ks && alpha,
                 "dag_scan_fwd: null pointer");
     ERC_REQUIRE(B > 0 && T > 0 && T <= MAX_T && ldh >= HID && ldo >= HID, "dag_scan_fwd: bad sizes B=%d T=%d", B, T);
     DagFwd p{Hl, ldh, GI, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_lin, pred, spk, H1, ldo, Mseq, GH, R, ks, alpha, B, T};
-    hipLaunchKernelGGL(dag_scan_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
+    if (cluster <= 1) {
+        hipLaunchKernelGGL(dag_scan_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
+    } else {
+        ERC_REQUIRE(cl_state && cluster <= 8 && (int64_t)B * cluster <= 224,
+                    "dag_scan_fwd: cluster=%d with B=%d (needs cl_state, cluster <= 8, B * cluster <= 224)", cluster, B);
+        // cl_state: [0] error flag, [1 .. B] arrival counters (zeroed here, on the stream)
+        hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
+        ERC_REQUIRE(e == hipSuccess, "dag_scan_fwd: memset failed: %s", hipGetErrorString(e));
+        DagCluster cl{cluster, cl_state + 1, cl_state, nullptr};
+        hipLaunchKernelGGL(dag_scan_fwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(NT), 0, (hipStream_t)stream, p, cl);
+    }
     ERC_LAUNCH_CHECK("dag_scan_fwd");
     return ERC_OK;
 }
+
+extern "C" int64_t erc_dag_cluster_scratch_floats(int B) { return (int64_t)B * 2 * 8 * 320; }
 
 extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
                                 const float* R, const float* alpha, const float* H1, int ldo, const float* W_hh_c,
                                 const float* W_ih_p, const float* Wr, const float* w_lin, const int32_t* pred,
                                 const int32_t* spk, int B, int T, const float* dH1, int ldd, float* dHl, int lddl,
-                                float* DGI, float* DGH, float* dR, float* dks, float* dlin, void* stream) {
+                                float* DGI, float* DGH, float* dR, float* dks, float* dlin, int cluster, int32_t* cl_state,
+                                float* cl_scratch, void* stream) {
     ERC_REQUIRE(Hl && GI && GH && Mseq && R && alpha && H1 && W_hh_c && W_ih_p && Wr && w_lin && pred && spk && dH1 &&
                     dHl && DGI && DGH && dR && dks && dlin,
                 "dag_scan_bwd: null pointer");
     ERC_REQUIRE(B > 0 && T > 0 && T <= MAX_T, "dag_scan_bwd: bad sizes B=%d T=%d", B, T);
     DagBwd p{Hl, ldh, GI, GH, Mseq, R, alpha, H1, ldo, W_hh_c, W_ih_p, Wr, w_lin, pred, spk,
              dH1, ldd, dHl, lddl, DGI, DGH, dR, dks, dlin, B, T};
-    hipLaunchKernelGGL(dag_scan_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
+    if (cluster <= 1) {
+        hipLaunchKernelGGL(dag_scan_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
+    } else {
+        ERC_REQUIRE(cl_state && cl_scratch && cluster <= 8 && (int64_t)B * cluster <= 224,
+                    "dag_scan_bwd: cluster=%d with B=%d (needs cl_state, cl_scratch, cluster <= 8, B * cluster <= 224)", cluster, B);
+        hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
+        ERC_REQUIRE(e == hipSuccess, "dag_scan_bwd: memset failed: %s", hipGetErrorString(e));
+        DagCluster cl{cluster, cl_state + 1, cl_state, cl_scratch};
+        hipLaunchKernelGGL(dag_scan_bwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(NT), 0, (hipStream_t)stream, p, cl);
+    }
     ERC_LAUNCH_CHECK("dag_scan_bwd");
     return ERC_OK;
 }

@@ -103,6 +103,11 @@ class DAGERCModule(nn.Module):
             zero=torch.zeros(L, BT * (2 * HID + 1), dtype=torch.float32, device=device),
             stats=torch.zeros(256, dtype=torch.float32, device=device),
         )
+        # P workgroups per dialogue in the recurrence kernels (csrc/dag_scan.hip, cluster mode); ERC_DAG_CLUSTER overrides
+        import os
+        ws["cluster"] = min(int(os.environ.get("ERC_DAG_CLUSTER", capi.dag_cluster_size(B))), capi.dag_cluster_size(B))
+        ws["cl_state"] = i32(B + 1)
+        ws["cl_scratch"] = f32(capi.dag_cluster_scratch_floats(B))
         ws["dR"] = [ws["zero"][l, :BT * 2 * HID].view(BT, 2 * HID) for l in range(L)]
         ws["dks"] = [ws["zero"][l, BT * 2 * HID:] for l in range(L)]
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
@@ -149,7 +154,7 @@ class DAGERCModule(nn.Module):
             linear_fwd(pl, Hl, W5, None, w["Whoist"], w["bhoist"], ws["GI"][l], 6 * HID, BT, 6 * HID, HID)
             capi.dag_scan_fwd(Hl, W5, ws["GI"][l], w["W_hh_c"], w["b_hh_c"], w["W_ih_p"], w["b_ih_p"], w["Wr"],
                               w["w_lin"], ws["pred"], ws["spk"], B, T, H1, W5, ws["Mseq"][l], ws["GH"][l], ws["R"][l],
-                              ws["ks"][l], ws["alpha"][l])
+                              ws["ks"][l], ws["alpha"][l], cluster=ws["cluster"], cl_state=ws["cl_state"])
         # head: Y1 = relu([Hall | x] W0^T + b0) as two GEMMs into one slab set
         W0 = fp.w("out_mlp.0.weight")
         Sa = pl.split_for(BT, HID, W5)
@@ -216,7 +221,8 @@ class DAGERCModule(nn.Module):
             dlin = pl.take(B * (2 * HID + 1))
             capi.dag_scan_bwd(Hl, W5, ws["GI"][l], ws["GH"][l], ws["Mseq"][l], ws["R"][l], ws["alpha"][l], H1, W5,
                               w["W_hh_c"], w["W_ih_p"], w["Wr"], w["w_lin"], ws["pred"], ws["spk"], B, T, dH1, W5,
-                              dHl, W5, ws["DGI"][l], ws["DGH"][l], ws["dR"][l], ws["dks"][l], pl.ws[dlin:])
+                              dHl, W5, ws["DGI"][l], ws["DGH"][l], ws["dR"][l], ws["dks"][l], pl.ws[dlin:],
+                              cluster=ws["cluster"], cl_state=ws["cl_state"], cl_scratch=ws["cl_scratch"])
             pl.add_job(dlin, 2 * HID + 1, B, 2 * HID + 1, off["gather.%d.linear.weight" % l])
             # dH_l += DGI [W_ih_c ; W_hh_p]; on layer 0 the same launch applies the relu mask of fc1
             capi.gemm_f32(ws["DGI"][l], 6 * HID, 0, None, w["Whoist"], HID, 1, None, dHl, W5, BT, HID, 6 * HID,

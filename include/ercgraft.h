@@ -327,22 +327,31 @@ int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_
  * w_lin [601] = gather.linear.weight (w_q | w_k) followed by its bias.
  * Saved for the backward: Mseq [B*T,300], GH [B*T,1800] (sequential gate pre-activations),
  * R [B*T,600] (Wr0 h | Wr1 h), ks [B*T] (w_k.h), alpha [B,T,T].
- */
+ * cluster = P > 1: P cooperating workgroups per dialogue (each streams 1/P of the weight rows per step; results
+ * exchanged through GH / R / ks with write-through stores and a per-dialogue arrival counter).  P <= 8 and
+ * B * P <= 224 (all workgroups must be resident at once: erc_dag_cluster_size(B) gives the largest legal P);
+ * cl_state: B + 1 int32 of scratch -- [0] is set to 1 if a member timed out waiting (the result is then invalid),
+ * the caller zero-fills it once and may check it after the step.  cluster <= 1: one workgroup per dialogue. */
+int erc_dag_cluster_size(int B);
 int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
                      const float* W_hh_c, const float* b_hh_c, const float* W_ih_p, const float* b_ih_p,
                      const float* Wr, const float* w_lin, const int32_t* pred, const int32_t* spk, int B, int T,
-                     float* H1, int ldo, float* Mseq, float* GH, float* R, float* ks, float* alpha, void* stream);
+                     float* H1, int ldo, float* Mseq, float* GH, float* R, float* ks, float* alpha,
+                     int cluster, int32_t* cl_state, void* stream);
 /* Reverse scan.  dH1 = complete gradient wrt the layer outputs.  Writes the gate gradients DGI / DGH
  * [B*T,1800] (weight gradients are then plain GEMMs: d[W_ih_c;W_hh_p] = DGI^T H_l, d[W_hh_c;W_ih_p] = DGH^T Mseq,
  * d[Wr0;Wr1] = dR^T H1, dH_l += DGI [W_ih_c;W_hh_p]); accumulates dR [B*T,600] / dks [B*T] (caller zero-fills),
  * ADDS the direct gradient wrt H_l into dHl, and writes the per-dialogue partial gradient of gather.linear
  * to dlin [B,601]. */
+/* (cluster / cl_state as in erc_dag_scan_fwd; cl_scratch: erc_dag_cluster_scratch_floats(B) floats for the partial vectors) */
+int64_t erc_dag_cluster_scratch_floats(int B);
 int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
                      const float* R, const float* alpha, const float* H1, int ldo,
                      const float* W_hh_c, const float* W_ih_p, const float* Wr, const float* w_lin,
                      const int32_t* pred, const int32_t* spk, int B, int T,
                      const float* dH1, int ldd, float* dHl, int lddl,
-                     float* DGI, float* DGH, float* dR, float* dks, float* dlin, void* stream);
+                     float* DGI, float* DGH, float* dR, float* dks, float* dlin,
+                     int cluster, int32_t* cl_state, float* cl_scratch, void* stream);
 
 /* ------------------------------------------------------------------------
  * (Bi)LSTM recurrence, hidden 100 per direction, torch.nn.LSTM semantics (gate order i|f|g|o):
