@@ -115,7 +115,7 @@ __device__ __forceinline__ void store_vec300(float* dst, const Vec300& v, int la
 // computed redundantly by every member.  Synchronisation: one monotonic arrival counter per dialogue (zero at
 // launch): stores drained (s_waitcnt vmcnt(0)) -> workgroup barrier -> one lane adds 1 and polls (sc1 load) until all
 // P members of the phase have arrived -> workgroup barrier -> sc1 loads.  All B * P workgroups must be co-resident
-// (the host keeps B * P <= 224, one 1024-thread workgroup per CU); the poll is bounded so that a violated
+// (the host keeps B * P <= 256, one 1024-thread workgroup per CU); the poll is bounded so that a violated
 // assumption ends in a flagged error, not in a hung GPU.
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -336,6 +336,9 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T, P = cl.P;
     __shared__ __attribute__((aligned(16))) float v_m[320], v_h[320], v_x[320], gates[2 * G3], s_alpha[MAX_T];
+    __shared__ float s_ks[MAX_T];            // key scores of the steps done so far (one sc1 load per step keeps it current)
+    __shared__ int s_spk[MAX_T], s_pred[MAX_T];
+    for (int t = tid; t < T; t += NT) s_spk[t] = p.spk[(int64_t)b * T + t], s_pred[t] = p.pred[(int64_t)b * T + t];
     const float* w_q = p.w_lin;
     const float* w_k = p.w_lin + HID;
     const float b_lin = p.w_lin[2 * HID];
@@ -347,19 +350,27 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
     for (int i = 0; i < T; ++i) {
         const int64_t row = (int64_t)b * T + i;
         const float* x = p.Hl + row * p.ldh;
-        if (tid < HID) v_x[tid] = x[tid];
+        // operands that do not depend on the exchange: requested first (hoisted gates of this row, newest key score)
+        float gi_r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (tid < HID) {
+            v_x[tid] = x[tid];
+            const float* gi = p.GI + row * 2 * G3;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) gi_r[u] = gi[u * HID + tid];
+        }
+        if (i > 0 && tid == NT - 1) s_ks[i - 1] = ld_sc1(p.ks + row - 1);
         __syncthreads();
         // ---- A: attention over the DAG predecessors [lo, i-1] (every member; R / ks come from all members: sc1 loads)
         int lo = 0, n = 0;
         if (i > 0) {
-            const int pr = p.pred[row];
+            const int pr = s_pred[i];
             lo = pr > 0 ? pr : 0;
             n = i - lo;
             if (wave == 0) {
                 const float qs = wave_sum(dot300(w_q, load_vec300(v_x, lane), lane)) + b_lin;
                 float mx = -INFINITY;
                 for (int j = lane; j < n; j += 64) {
-                    const float k = ld_sc1(p.ks + (int64_t)b * T + lo + j);
+                    const float k = s_ks[lo + j];
                     s_alpha[j] = k;
                     mx = fmaxf(mx, qs + k);
                 }
@@ -380,14 +391,14 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
             }
             __syncthreads();
             if (tid < HID) {
-                const int si = p.spk[row];
+                const int si = s_spk[i];
                 float m = 0.f;
                 for (int j0 = 0; j0 < n; j0 += 8) {      // 8 predecessor rows in flight
                     float rv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int64_t rj = (int64_t)b * T + lo + min(j0 + u, n - 1);
-                        rv[u] = ld_sc1(p.R + rj * 2 * HID + (p.spk[rj] == si ? 0 : HID) + tid);
+                        const int tj = lo + min(j0 + u, n - 1);
+                        rv[u] = ld_sc1(p.R + ((int64_t)b * T + tj) * 2 * HID + (s_spk[tj] == si ? 0 : HID) + tid);
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) m += (j0 + u < n ? s_alpha[j0 + u] : 0.f) * rv[u];
@@ -417,14 +428,13 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
         __syncthreads();
         // ---- C: the two GRU cells, h1 = C + P (every member)
         if (tid < HID) {
-            const float* gi = p.GI + row * 2 * G3;
-            float r = sigmoidf_(gi[tid] + gates[tid]);
-            float z = sigmoidf_(gi[HID + tid] + gates[HID + tid]);
-            float nn = tanhf(gi[2 * HID + tid] + r * gates[2 * HID + tid]);
+            float r = sigmoidf_(gi_r[0] + gates[tid]);
+            float z = sigmoidf_(gi_r[1] + gates[HID + tid]);
+            float nn = tanhf(gi_r[2] + r * gates[2 * HID + tid]);
             const float c = (1.f - z) * nn + z * v_m[tid];
-            r = sigmoidf_(gates[G3 + tid] + gi[G3 + tid]);
-            z = sigmoidf_(gates[G3 + HID + tid] + gi[G3 + HID + tid]);
-            nn = tanhf(gates[G3 + 2 * HID + tid] + r * gi[G3 + 2 * HID + tid]);
+            r = sigmoidf_(gates[G3 + tid] + gi_r[3]);
+            z = sigmoidf_(gates[G3 + HID + tid] + gi_r[4]);
+            nn = tanhf(gates[G3 + 2 * HID + tid] + r * gi_r[5]);
             const float pp = (1.f - z) * nn + z * v_x[tid];
             const float h1 = c + pp;
             v_h[tid] = h1;
@@ -613,6 +623,9 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagC
     const int T = p.T, P = cl.P;
     __shared__ __attribute__((aligned(16))) float v_g[320], v_dm[320], v_x[320], v_m[320], v_in[2 * G3], part[NW][320], s_al[MAX_T], s_da[MAX_T];
     __shared__ float s_dqs;
+    __shared__ int s_spk[MAX_T], s_pred[MAX_T];
+    for (int t = tid; t < T; t += NT) s_spk[t] = p.spk[(int64_t)b * T + t], s_pred[t] = p.pred[(int64_t)b * T + t];
+    __syncthreads();
     const float* w_q = p.w_lin;
     const float* w_k = p.w_lin + HID;
     float dwq = 0.f, dwk = 0.f, dbl = 0.f;
@@ -707,13 +720,13 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagC
         }
         __syncthreads();
         // ---- 4: attention backward over the window [lo, i-1]
-        const int pr = p.pred[row];
+        const int pr = s_pred[i];
         const int lo = pr > 0 ? pr : 0;
         const int n = i - lo;
-        const int si = p.spk[row];
+        const int si = s_spk[i];
         for (int j = wave; j < n; j += NW) {  // d alpha_j = dM . V_j
             const int64_t rj = (int64_t)b * T + lo + j;
-            const float* v = p.R + rj * 2 * HID + (p.spk[rj] == si ? 0 : HID);
+            const float* v = p.R + rj * 2 * HID + (s_spk[lo + j] == si ? 0 : HID);
             const float a = wave_sum(dot300(v, load_vec300(v_dm, lane), lane));
             if (lane == 0) {
                 s_da[j] = a;
@@ -744,7 +757,7 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagC
             if (tid >= c_lo && tid < c_hi) {
                 for (int j = 0; j < n; ++j) {  // dV_j = alpha_j dM into the relation slot that was read
                     const int64_t rj = (int64_t)b * T + lo + j;
-                    float* q = p.dR + rj * 2 * HID + (p.spk[rj] == si ? 0 : HID) + tid;
+                    float* q = p.dR + rj * 2 * HID + (s_spk[lo + j] == si ? 0 : HID) + tid;
                     st_sc1(q, ld_sc1(q) + s_al[j] * dm);
                 }
             }
@@ -779,8 +792,8 @@ extern "C" int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_
 
 extern "C" int erc_dag_cluster_size(int B) {
     // workgroups per dialogue: all B * P persistent 1024-thread workgroups must be resident at once (256 CUs)
-    int P = 224 / (B > 0 ? B : 1);
-    if (P > 8) P = 8;
+    int P = 256 / (B > 0 ? B : 1);
+    if (P > 8) P = 8;   // measured (B = 16): P = 2 / 4 / 8 / 12 / 16 -> 41.6 / 28.4 / 23.5 / 24.9 / 26.9 ms per step
     return P < 2 ? 1 : P;
 }
 
@@ -796,8 +809,8 @@ extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const
     if (cluster <= 1) {
         hipLaunchKernelGGL(dag_scan_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
     } else {
-        ERC_REQUIRE(cl_state && cluster <= 8 && (int64_t)B * cluster <= 224,
-                    "dag_scan_fwd: cluster=%d with B=%d (needs cl_state, cluster <= 8, B * cluster <= 224)", cluster, B);
+        ERC_REQUIRE(cl_state && cluster <= 16 && (int64_t)B * cluster <= 256,
+                    "dag_scan_fwd: cluster=%d with B=%d (needs cl_state, cluster <= 16, B * cluster <= 256)", cluster, B);
         // cl_state: [0] error flag, [1 .. B] arrival counters (zeroed here, on the stream)
         hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
         ERC_REQUIRE(e == hipSuccess, "dag_scan_fwd: memset failed: %s", hipGetErrorString(e));
@@ -808,7 +821,7 @@ extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const
     return ERC_OK;
 }
 
-extern "C" int64_t erc_dag_cluster_scratch_floats(int B) { return (int64_t)B * 2 * 8 * 320; }
+extern "C" int64_t erc_dag_cluster_scratch_floats(int B) { return (int64_t)B * 2 * 16 * 320; }
 
 extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
                                 const float* R, const float* alpha, const float* H1, int ldo, const float* W_hh_c,
@@ -825,8 +838,8 @@ extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const
     if (cluster <= 1) {
         hipLaunchKernelGGL(dag_scan_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
     } else {
-        ERC_REQUIRE(cl_state && cl_scratch && cluster <= 8 && (int64_t)B * cluster <= 224,
-                    "dag_scan_bwd: cluster=%d with B=%d (needs cl_state, cl_scratch, cluster <= 8, B * cluster <= 224)", cluster, B);
+        ERC_REQUIRE(cl_state && cl_scratch && cluster <= 16 && (int64_t)B * cluster <= 256,
+                    "dag_scan_bwd: cluster=%d with B=%d (needs cl_state, cl_scratch, cluster <= 16, B * cluster <= 256)", cluster, B);
         hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
         ERC_REQUIRE(e == hipSuccess, "dag_scan_bwd: memset failed: %s", hipGetErrorString(e));
         DagCluster cl{cluster, cl_state + 1, cl_state, cl_scratch};
