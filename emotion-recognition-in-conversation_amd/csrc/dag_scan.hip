@@ -120,7 +120,7 @@ __device__ __forceinline__ void store_vec300(float* dst, const Vec300& v, int la
 __device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-constexpr int CL_SPIN_LIMIT = 4000000;   // ~ seconds; a step normally waits a few microseconds
+constexpr int CL_SPIN_LIMIT = 2000000;   // ~ a second; a step normally waits a few microseconds
 
 __device__ __forceinline__ void cluster_sync(int* ctr, int target, int* err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -130,10 +130,13 @@ __device__ __forceinline__ void cluster_sync(int* ctr, int target, int* err) {
         int spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > CL_SPIN_LIMIT) {
+            ++spins;
+            if (spins > CL_SPIN_LIMIT) {   // a member never arrived (workgroups not co-resident?): flag and give up
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
+            // once any member has given up every later wait would time out too: drain quickly instead
+            if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         }
     }
     __syncthreads();

@@ -116,6 +116,15 @@ class DAGERCModule(nn.Module):
         self._ws[key] = ws
         return ws
 
+    def check_cluster(self):
+        """Raise if a cluster-mode recurrence kernel flagged a wait that ran into its bound (its workgroups were not all
+        resident at once, e.g. another process shares the GPU): the results of that step are invalid.  Costs one
+        device->host copy per workspace, so it is called at epoch boundaries / in tests, not per step."""
+        for key, ws in self._ws.items():
+            if int(ws["cl_state"][0].item()) != 0:
+                raise capi.ErcGraftError("DAG-ERC cluster scan timed out waiting for a member workgroup (B,T,N=%s); "
+                                         "rerun with ERC_DAG_CLUSTER=1" % (key,))
+
     def _shape(self, input_tensor, text_length, label):
         B, T = input_tensor.shape[0], input_tensor.shape[1]
         N = int(label.shape[0]) if label is not None else int(text_length.sum().item())

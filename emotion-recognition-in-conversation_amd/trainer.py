@@ -147,6 +147,8 @@ def run(trainer_cls, params_cls, argv=None):
                 last = {"epoch": epoch, "step": i, "Lall": s[0], "Acc": s[1] / max(1, batch["label"].shape[0])}
                 print(json.dumps(last), flush=True)
         torch.cuda.synchronize()
+        if hasattr(trainer.model, "check_cluster"):
+            trainer.model.check_cluster()
         dt = time.perf_counter() - t0
         # test after every epoch (mmbase.py:136,180-201)
         trainer.model.eval()

@@ -85,6 +85,30 @@ def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C):
     refp = dict(ref.named_parameters())
     for n in mine.flat.params:
         assert rel_err(mine.flat.g(n).cpu(), refp[n].grad) < 2e-3, n
+    mine.check_cluster()      # no member of a cluster-mode recurrence kernel timed out
+
+
+def test_cluster_scan_equals_single_workgroup_scan(monkeypatch):
+    """The recurrence kernels in cluster mode (P workgroups per dialogue) against one workgroup per dialogue: forward
+    bit-identical (same per-row dot products), gradients equal up to the order of the cross-member partial sums."""
+    from erc_amd import capi
+    from erc_amd.dagerc import DAGERCModule
+    dims = dict(a=30, t=60, v=34)
+    batch = make_batch(6, dims, n_speakers=3, n_classes=5, min_len=2, max_len=37, seed=4, speaker_onehot=True, force_max=True)
+    res = {}
+    for P in (1, 4, 8):
+        monkeypatch.setenv("ERC_DAG_CLUSTER", str(P))
+        torch.manual_seed(9)
+        m = DAGERCModule(emb_dim=sum(dims.values()), dropout=0.0, n_classes=5, gnn_layers=2).finalize(DEV)
+        m.train()
+        stats = m.loss_and_grads(to_device(batch, DEV)).cpu()
+        ws = next(iter(m._ws.values()))
+        assert ws["cluster"] == min(P, capi.dag_cluster_size(6))
+        m.check_cluster()
+        res[P] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone())
+    for P in (4, 8):
+        assert res[P][0] == res[1][0] and torch.equal(res[P][1], res[1][1])
+        assert float((res[P][2] - res[1][2]).abs().max()) <= 1e-6 * max(1.0, float(res[1][2].abs().max()))
 
 
 def test_dagerc_train_step_clip_adamw():
