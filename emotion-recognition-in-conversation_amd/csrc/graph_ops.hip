@@ -10,7 +10,8 @@
 namespace {
 
 constexpr int MAX_R = 8;
-constexpr int CH = 8;  // neighbour rows fetched together (their loads are all in flight before the first use)
+constexpr int CH = 12; // neighbour rows fetched together (all loads in flight before the first use); the COGMEN window
+                       // graph (wp = wf = 5) has at most 11 in-edges per node: one batch
 
 // Every kernel below follows the same latency discipline (one dependent global round trip costs ~0.5 us here,
 // a 20-edge neighbourhood walked edge by edge ~20 of them): the CSR slice of the node is loaded lane-parallel
@@ -139,6 +140,39 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(const float* __restrict_
     // online softmax over 64-edge windows (one window for window graphs): running max mx, denominator den,
     // unnormalised output o; lane l keeps exp-score of edge l of the current window until it is rescaled.
     float mx = -INFINITY, den = 0.f, o0 = 0.f, o1 = 0.f;
+    if (e1 - e0 <= CH && e1 > e0) {   // whole neighbourhood in one batch (wave-uniform): key AND value rows requested together
+        const int nwin = e1 - e0;
+        const int my_src = in_src[e0 + min(lane, max(nwin - 1, 0))];
+        Row2 k[CH], v[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int sj = __shfl(my_src, min(u, max(nwin - 1, 0)), 64);
+            k[u] = ldrow(qkvs + F, sj, ld, c0, c1);
+            v[u] = ldrow(qkvs + 2 * F, sj, ld, c0, c1);
+        }
+        float sc[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            sc[u] = wave_sum(q0 * k[u].a + q1 * k[u].b) * scale;
+            if (u < nwin) mx = fmaxf(mx, sc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const float pw = u < nwin ? expf(sc[u] - mx) : 0.f;
+            sc[u] = pw;
+            den += pw;
+            o0 += pw * v[u].a, o1 += pw * v[u].b;
+        }
+        const float inv = 1.0f / (den + 1e-16f);
+        if (h0) out[(int64_t)i * ldo + lane] = o0 * inv + sk.a;
+        if (h1) out[(int64_t)i * ldo + lane + 64] = o1 * inv + sk.b;
+        float mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (lane == u) mine = sc[u];
+        if (lane < nwin) alpha[e0 + lane] = mine * inv;
+        return;
+    }
     for (int w0 = e0; w0 < e1; w0 += 64) {
         const int nwin = min(64, e1 - w0);
         const int my_src = in_src[w0 + min(lane, nwin - 1)];
@@ -222,6 +256,38 @@ __global__ __launch_bounds__(256) void tconv_bwd_target_kernel(const float* __re
     }
     const float g0 = h0 ? gr.a : 0.f, g1 = h1 ? gr.b : 0.f;
     const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
+    if (e1 - e0 <= CH && e1 > e0) {   // whole neighbourhood in one batch: value and key rows requested together, one pass
+        const int nwin = e1 - e0;
+        const int el = e0 + min(lane, nwin - 1);
+        const int my_src = in_src[el];
+        const float my_al = lane < nwin ? alpha[el] : 0.f;
+        Row2 v[CH], kk[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int sj = __shfl(my_src, min(u, nwin - 1), 64);
+            v[u] = ldrow(qkvs + 2 * F, sj, ld, c0, c1);
+            kk[u] = ldrow(qkvs + F, sj, ld, c0, c1);
+        }
+        float da[CH], al[CH], t = 0.f;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            da[u] = wave_sum(g0 * v[u].a + g1 * v[u].b);
+            al[u] = u < nwin ? __shfl(my_al, u, 64) : 0.f;
+            t += al[u] * da[u];
+        }
+        float dq0 = 0.f, dq1 = 0.f, mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const float ds = al[u] * (da[u] - t) * scale;
+            dq0 += ds * kk[u].a, dq1 += ds * kk[u].b;
+            if (lane == u) mine = ds;
+        }
+        if (lane < nwin) dscore[el] = mine;
+        float* d = dqkvs + (int64_t)i * ld;
+        if (h0) d[lane] = dq0, d[3 * F + lane] = g0;
+        if (h1) d[lane + 64] = dq1, d[3 * F + lane + 64] = g1;
+        return;
+    }
     // pass 1: t = sum_e alpha_e (dout_i . v_src(e)); lane l keeps d alpha of edge l (first window)
     float t = 0.f;
     for (int w0 = e0; w0 < e1; w0 += 64) {
