@@ -506,7 +506,7 @@ extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const 
     const int Nlog = N + (ones_col == 1 ? 1 : 0), Mlog = M + (ones_col == 2 ? 1 : 0);
     const int kb_split = p.kblocks_per_split;
     // wavefronts per workgroup: enough to cut the K chain, not more than there are blocks
-    const int nw = kb_split >= 32 ? 8 : (kb_split >= 6 ? 4 : 1);
+    const int nw = kb_split >= 32 ? 8 : (kb_split >= 6 ? 4 : 1);   // (1 wavefront for K = 100 measured slower: 11.2 vs 10.0 us)
     // Wave tile 16 x 32.  Measured on MI355X (COGMEN B=32 shapes, M = 1982): 32x64 / 16x64 tiles (the body is generic in
     // RM, CF) were SLOWER -- 14.1 vs 10.5 us (K=100, N=400/900), 13.9 vs 12.5 (K=900, N=100), 11.7 vs 7.9 (K=400,
     // N=100): these products are bound by the length of the per-wavefront chain, not by fragment traffic.

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void bn_batch_stats_kernel(const float* __rest
     double s = 0.0;
     if (c < F) {
         const int G = (int)gridDim.x;
-        for (int g0 = 0; g0 < G; g0 += 32) {
+        for (int g0 = 0; g0 < G; g0 += 32) {   // (64 doubles in flight per thread measured slower: 9.7 vs 7.4 us)
             double t[32];
 #pragma unroll
             for (int j = 0; j < 32; ++j) t[j] = ld_sc1d(partial + (int64_t)min(g0 + j, G - 1) * 2 * F + half * F + c);
@@ -428,15 +428,15 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     const int o1 = col ? tid : 224 + (tid - F), o2 = col ? 112 + tid : 224 + (tid - F);
     double s1 = 0.0, s2 = 0.0;
     if (col || aux) {
-        for (int g0 = 0; g0 < G; g0 += 32) {
-            float t1[32], t2[32];
+        for (int g0 = 0; g0 < G; g0 += 64) {   // 62 workgroups at B = 32: one batch of loads
+            float t1[64], t2[64];
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
+            for (int j = 0; j < 64; ++j) {
                 const float* q = p.part + (int64_t)min(g0 + j, G - 1) * HF_PART;
                 t1[j] = ld_sc1(q + o1), t2[j] = ld_sc1(q + o2);
             }
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
+            for (int j = 0; j < 64; ++j) {
                 const double m = g0 + j < G ? 1.0 : 0.0;
                 s1 += (double)t1[j] * m, s2 += (double)t2[j] * m;
             }
