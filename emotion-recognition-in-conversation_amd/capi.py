@@ -79,7 +79,8 @@ _SIGS = {
     "erc_mm_cross_apply": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "erc_mm_cross_grad": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "erc_gcnii_combine_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _vp, C.c_uint64, _vp, _vp]),
-    "erc_gcnii_combine_bwd": (C.c_int, [_vp, _vp, _i64, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "erc_gcnii_combine_bwd": (C.c_int, [_vp, _vp, _i64, _f, _f, _f, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "erc_gcnii_layer_fwd": (C.c_int, [_vp, _i, _vp, _i, _f, _f, _f, _vp, C.c_uint64, _vp, _i, _i, _i, _vp]),
     "erc_dropout_fwd": (C.c_int, [_vp, _i64, _f, _vp, C.c_uint64, _vp, _vp]),
     "erc_mm_regroup_fwd": (C.c_int, [_vp, _vp, _i, _i, _f, _vp, C.c_uint64, _vp, _vp]),
     "erc_mm_regroup_bwd": (C.c_int, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
@@ -392,8 +393,12 @@ def gcnii_combine_fwd(G, hi, h0, n, theta, alpha, drop_p, rng, rng_stream, hd):
     _call("erc_gcnii_combine_fwd", G, hi, h0, n, theta, alpha, drop_p, rng, rng_stream, hd)
 
 
-def gcnii_combine_bwd(d_hd, hd, n, theta, alpha, keep_scale, plain, dG, dhi, dh0):
-    _call("erc_gcnii_combine_bwd", d_hd, hd, n, theta, alpha, keep_scale, plain, dG, dhi, dh0)
+def gcnii_combine_bwd(d_hd, hd, n, theta, alpha, keep_scale, plain, dG, dhi, dh0, F=0, ld_d=0):
+    _call("erc_gcnii_combine_bwd", d_hd, hd, n, theta, alpha, keep_scale, plain, dG, dhi, dh0, F, ld_d)
+
+
+def gcnii_layer_fwd(hih0, lda, W, ldw, theta, alpha, drop_p, rng, rng_stream, hd, ldo, rows, F):
+    _call("erc_gcnii_layer_fwd", hih0, lda, W, ldw, theta, alpha, drop_p, rng, rng_stream, hd, ldo, rows, F)
 
 
 def dropout_fwd(x, n, drop_p, rng, rng_stream, y):

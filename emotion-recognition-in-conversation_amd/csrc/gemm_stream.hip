@@ -42,6 +42,8 @@ struct StreamP {
     int ones, act, accumulate;
     int a_vec, b_vec;
     float act_scale, drop_p;
+    float alpha;           // act 4 (GCNII layer tail)
+    uint64_t rng_stream;   // act 4: xor-ed into the RNG seed (one dropout stream per layer)
 };
 
 __device__ __forceinline__ float4 ld4g(const float* p, int valid, bool vec) {
@@ -61,7 +63,7 @@ __device__ __forceinline__ void reduce_and_store(const StreamP& p, f32x4 (&acc)[
     const int r = lane & 15, g = lane >> 4;
     float* __restrict__ C = p.C + (int64_t)z * p.c_slab;
     uint64_t rng_off = 0, rng_seed = 0;
-    if (p.act == 3) rng_off = p.rng[0], rng_seed = p.rng[1];
+    if (p.act == 3 || (p.act == 4 && p.drop_p > 0.f)) rng_off = p.rng[0], rng_seed = p.rng[1] ^ p.rng_stream;
     if (NW > 1) {
 #pragma unroll
         for (int h = 0; h < RM; ++h)
@@ -115,6 +117,14 @@ __device__ __forceinline__ void reduce_and_store(const StreamP& p, f32x4 (&acc)[
                     else if (p.act == 3) {
                         const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)p.N + col);
                         v = (u >= p.drop_p) ? fmaxf(v, 0.f) * p.act_scale : 0.f;
+                    } else if (p.act == 4) {   // GCNII layer tail: aux = [hi | h0] rows (pitch ldaux, h0 at column N)
+                        const float* ar = p.aux + (int64_t)row * p.ldaux + col;
+                        v = p.act_scale * v + (1.f - p.act_scale) * ((1.f - p.alpha) * ar[0] + p.alpha * ar[p.N]);
+                        v = fmaxf(v, 0.f);
+                        if (p.drop_p > 0.f) {
+                            const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)p.N + col);
+                            v = (u >= p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+                        }
                     }
                     *dst = v;
                 } else if (col == p.N && p.ones == 1 && p.bias_out) {
@@ -124,9 +134,6 @@ __device__ __forceinline__ void reduce_and_store(const StreamP& p, f32x4 (&acc)[
         }
 }
 
-// A_MODE: 0 rows K-contiguous (optional row gather), 1 K-major.  B_MODE: 0 "NT" (B[n][k]), 1 K-major (optional k gather).
-// GA / GB (gather present) and VEC (16-byte loads legal) are COMPILE-TIME: a runtime "pointer ? load : value" makes
-// hipcc branch around the load and drain vmcnt per element.
 // Wave tile (16 RM) x (16 CF): RM x CF MFMA tiles share the RM + CF fragments of a K block.  The skinny products of
 // this workload are bound by the per-CU L2 path (~70 GB/s), so bigger wave tiles (fewer fragment bytes per MFMA) win
 // as long as enough workgroups remain to fill the chip; the host picks (1,2), (1,4) or (2,4).
@@ -578,5 +585,35 @@ extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gath
     }
 #undef ERC_BA
     ERC_LAUNCH_CHECK("gemm_bf16a_stream");
+    return ERC_OK;
+}
+
+// One GCNII layer's dense part with its tail in the epilogue (mmgcn_models.py GraphConvolution + GCNII.forward):
+//   hd = dropout(relu(theta * ([hi | h0] W) + (1 - theta) * ((1 - alpha) hi + alpha h0)))
+// A = [hi | h0] rows of pitch lda (hi = adj-propagated features, h0 = the initial residual, both F wide), W [2F, F]
+// stored [in, out].  Replaces two GEMMs (hi W[:F], h0 W[F:]) and the elementwise combine launch.
+extern "C" int erc_gcnii_layer_fwd(const float* hih0, int lda, const float* W, int ldw, float theta, float alpha, float drop_p,
+                                   const uint64_t* rng_state, uint64_t rng_stream, float* hd, int ldo, int rows, int F,
+                                   void* stream) {
+    ERC_REQUIRE(hih0 && W && hd && rows > 0 && F > 0 && lda >= 2 * F && ldw >= F && ldo >= F, "gcnii_layer_fwd: bad arguments");
+    ERC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state), "gcnii_layer_fwd: drop_p=%f", (double)drop_p);
+    StreamP p{};
+    p.A = hih0; p.B = W; p.C = hd; p.aux = hih0; p.rng = rng_state; p.rng_stream = rng_stream;
+    p.lda = lda; p.ldb = ldw; p.ldc = ldo; p.ldaux = lda; p.M = rows; p.N = F; p.K = 2 * F;
+    const int nkb = erc_cdiv(p.K, 16);
+    p.kblocks_per_split = nkb;
+    p.act = 4; p.act_scale = theta; p.alpha = alpha; p.drop_p = drop_p;
+    p.a_vec = al16(hih0) && (lda % 4 == 0);
+    p.b_vec = 0;
+    dim3 grid(erc_cdiv(F, 32), erc_cdiv(rows, 16), 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.a_vec) {
+        if (nkb >= 32) hipLaunchKernelGGL((gemm_f32_stream_kernel<0, 1, 8, false, false, true, 1, 2>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_stream_kernel<0, 1, 4, false, false, true, 1, 2>), grid, dim3(256), 0, st, p);
+    } else {
+        if (nkb >= 32) hipLaunchKernelGGL((gemm_f32_stream_kernel<0, 1, 8, false, false, false, 1, 2>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((gemm_f32_stream_kernel<0, 1, 4, false, false, false, 1, 2>), grid, dim3(256), 0, st, p);
+    }
+    ERC_LAUNCH_CHECK("gcnii_layer_fwd");
     return ERC_OK;
 }

@@ -288,15 +288,16 @@ __global__ __launch_bounds__(256) void gcnii_combine_fwd_kernel(const float* __r
 __global__ __launch_bounds__(256) void gcnii_combine_bwd_kernel(const float* __restrict__ d_hd, const float* __restrict__ hd,
                                                                 int64_t n, float theta, float alpha, float keep_scale,
                                                                 int plain, float* __restrict__ dG, float* __restrict__ dhi,
-                                                                float* __restrict__ dh0) {
+                                                                float* __restrict__ dh0, int F, int ld_d) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float g = hd[i] > 0.f ? d_hd[i] * keep_scale : 0.f;
         if (plain) {
             dG[i] = g;
         } else {
+            const int64_t row = i / F, j = row * ld_d + (i - row * F);   // dhi / dh0 rows have pitch ld_d
             dG[i] = theta * g;
-            dhi[i] = (1.f - theta) * (1.f - alpha) * g;
-            dh0[i] += (1.f - theta) * alpha * g;
+            dhi[j] = (1.f - theta) * (1.f - alpha) * g;
+            dh0[j] += (1.f - theta) * alpha * g;
         }
     }
 }
@@ -440,10 +441,11 @@ extern "C" int erc_gcnii_combine_fwd(const float* G, const float* hi, const floa
     return ERC_OK;
 }
 extern "C" int erc_gcnii_combine_bwd(const float* d_hd, const float* hd, int64_t n, float theta, float alpha,
-                                     float keep_scale, int plain, float* dG, float* dhi, float* dh0, void* stream) {
-    ERC_REQUIRE(d_hd && hd && dG && n > 0 && (plain || (dhi && dh0)), "gcnii_combine_bwd: bad arguments");
+                                     float keep_scale, int plain, float* dG, float* dhi, float* dh0, int F, int ld_d,
+                                     void* stream) {
+    ERC_REQUIRE(d_hd && hd && dG && n > 0 && (plain || (dhi && dh0 && F > 0 && ld_d >= F)), "gcnii_combine_bwd: bad arguments");
     hipLaunchKernelGGL(gcnii_combine_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, d_hd, hd, n, theta,
-                       alpha, keep_scale, plain, dG, dhi, dh0);
+                       alpha, keep_scale, plain, dG, dhi, dh0, F > 0 ? F : 1, ld_d);
     ERC_LAUNCH_CHECK("gcnii_combine_bwd");
     return ERC_OK;
 }

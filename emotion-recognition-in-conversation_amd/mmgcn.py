@@ -139,9 +139,9 @@ class MMGCNModule(nn.Module):
                   LIN={m: f32(TB, FD) for m in self.order}, LO=f32(TB, FD), X=f32(R3, FD), XD=f32(R3, FD),
                   XH=f32(R3, FD), INV=f32(R3), COS=f32(B * Mo, P, P), ADJ=f32(B * Mo, P, P), CR=f32(B, Mo * Mo, P),
                   CCOS=f32(B, Mo * Mo, P), DEG=f32(R3), H0=f32(R3, FD), Gt=f32(R3, FD),
-                  HI=f32(NLAYERS + 1, R3, FD), HD=f32(NLAYERS + 2, R3, FD), FE=f32(N, Mo * 2 * FD), logits=f32(N, C),
+                  HI=f32(NLAYERS + 1, R3, 2 * FD), HD=f32(NLAYERS + 2, R3, FD), FE=f32(N, Mo * 2 * FD), logits=f32(N, C),
                   stats=torch.zeros(256, dtype=torch.float32, device=device), dlogits=f32(N, C), dFE=f32(N, Mo * 2 * FD), dXD=f32(R3, FD), DH=f32(R3, FD),
-                  dG=f32(NLAYERS + 1, R3, FD), dHI=f32(R3, FD), dH0=f32(R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
+                  dG=f32(NLAYERS + 1, R3, FD), dHIH0=f32(R3, 2 * FD), dH0=f32(R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
                   Gb=f32(B * Mo, P, P), GC=f32(B, Mo * Mo, P), dXH=f32(R3, FD), dX=f32(R3, FD),
                   dLIN={m: f32(TB, FD) for m in self.order}, dLL=f32(TB, FD))
         dmax = max(self.dims[m] for m in self.order)
@@ -205,13 +205,14 @@ class MMGCNModule(nn.Module):
             capi.dropout_fwd(ws["H0"], n_el, p, rng, 1001, HD[1])
         else:
             HD[1].copy_(ws["H0"])
+        # every layer's input rows are [hi_l | h0] (pitch 2 FD): h0 is copied next to the 64 hi slots once per step, so that
+        # [hi | h0] W is ONE product per layer, with the GCNII tail (residual mix, relu, dropout) in its epilogue
+        HI[1:, :, FD:] = ws["H0"]
         for l in range(1, NLAYERS + 1):
             W = fp.w(gn + "convs.%d.weight" % (l - 1))
-            capi.gemm_grouped(0, ws["ADJ"], P, HD[l], FD, HI[l], FD, FD, ws["node_off"], B, Mo, N, T, P)
-            capi.mm_cross_apply(ws["CR"], HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, HI[l], FD)
-            capi.gemm_f32(HI[l], FD, 0, None, W, FD, 1, None, ws["Gt"], FD, R3, FD, FD)
-            capi.gemm_f32(ws["H0"], FD, 0, None, W[FD:], FD, 1, None, ws["Gt"], FD, R3, FD, FD, accumulate=1)
-            capi.gcnii_combine_fwd(ws["Gt"], HI[l], ws["H0"], n_el, self.theta(l), ALPHA, p, rng, 2000 + l, HD[l + 1])
+            capi.gemm_grouped(0, ws["ADJ"], P, HD[l], FD, HI[l], 2 * FD, FD, ws["node_off"], B, Mo, N, T, P)
+            capi.mm_cross_apply(ws["CR"], HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, HI[l], 2 * FD)
+            capi.gcnii_layer_fwd(HI[l], 2 * FD, W, FD, self.theta(l), ALPHA, p, rng, 2000 + l, HD[l + 1], FD, R3, FD)
         capi.mm_regroup_fwd(XD, HD[NLAYERS + 1], Mo, N, p, rng, 3000, ws["FE"])
         linear_fwd(pl, ws["FE"], Mo * 2 * FD, None, fp.w("smax_fc.weight"), fp.w("smax_fc.bias"), ws["logits"], C, N, C,
                    Mo * 2 * FD)
@@ -250,21 +251,22 @@ class MMGCNModule(nn.Module):
                      defer=True)
         DH = ws["DH"]
         capi.mm_regroup_bwd(ws["dFE"], ws["FE"], Mo, N, ks, ws["dXD"], DH)
-        ws["dH0"].zero_(), ws["dADJ"].zero_(), ws["dCR"].zero_()
+        dHIH0 = ws["dHIH0"]               # [dhi | dh0] rows, pitch 2 FD: one product per layer accumulates into both halves
+        dHI, dH0 = dHIH0, dHIH0[:, FD:]
+        dHIH0.zero_(), ws["dADJ"].zero_(), ws["dCR"].zero_()
         for l in range(NLAYERS, 0, -1):
             Wn = gn + "convs.%d.weight" % (l - 1)
             W = fp.w(Wn)
             dG = ws["dG"][l]     # kept per layer: the 128 weight-gradient products run as one launch at the end
-            capi.gcnii_combine_bwd(DH, HD[l + 1], n_el, self.theta(l), ALPHA, ks, 0, dG, ws["dHI"], ws["dH0"])
-            capi.gemm_f32(dG, FD, 0, None, W, FD, 0, None, ws["dHI"], FD, R3, FD, FD, accumulate=1)
-            capi.gemm_f32(dG, FD, 0, None, W[FD:], FD, 0, None, ws["dH0"], FD, R3, FD, FD, accumulate=1)
-            matmul_wgrad_io(pl, HI[l], FD, dG, FD, FD, FD, R3, off[Wn], None, defer=True)
-            matmul_wgrad_io(pl, ws["H0"], FD, dG, FD, FD, FD, R3, off[Wn] + FD * FD, None, defer=True)
-            capi.gemm_grouped(1, ws["dHI"], FD, HD[l], FD, ws["dADJ"], P, FD, ws["node_off"], B, Mo, N, T, P, accumulate=1)
-            capi.mm_cross_grad(ws["dHI"], FD, HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"])
-            capi.gemm_grouped(0, ws["ADJ"], P, ws["dHI"], FD, DH, FD, FD, ws["node_off"], B, Mo, N, T, P)
-            capi.mm_cross_apply(ws["CR"], ws["dHI"], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, DH, FD)
+            capi.gcnii_combine_bwd(DH, HD[l + 1], n_el, self.theta(l), ALPHA, ks, 0, dG, dHI, dH0, F=FD, ld_d=2 * FD)
+            capi.gemm_f32(dG, FD, 0, None, W, FD, 0, None, dHIH0, 2 * FD, R3, 2 * FD, FD, accumulate=1)   # [dhi|dh0] += dG W^T
+            matmul_wgrad_io(pl, HI[l], 2 * FD, dG, FD, 2 * FD, FD, R3, off[Wn], None, defer=True)        # dW = [hi|h0]^T dG
+            capi.gemm_grouped(1, dHI, 2 * FD, HD[l], FD, ws["dADJ"], P, FD, ws["node_off"], B, Mo, N, T, P, accumulate=1)
+            capi.mm_cross_grad(dHI, 2 * FD, HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"])
+            capi.gemm_grouped(0, ws["ADJ"], P, dHI, 2 * FD, DH, FD, FD, ws["node_off"], B, Mo, N, T, P)
+            capi.mm_cross_apply(ws["CR"], dHI, 2 * FD, ws["node_dlg"], ws["node_off"], Mo, N, P, DH, FD)
         # input layer: HD[1] = dropout(H0), H0 = relu(fc0(XD))
+        ws["dH0"].copy_(dH0)              # contiguous copy of the accumulated residual gradient for the elementwise tail
         capi.axpy_mask(DH, HD[1] if p > 0 else None, n_el, ks, 1, ws["dH0"])
         dG0 = ws["dG"][0]
         capi.gcnii_combine_bwd(ws["dH0"], ws["H0"], n_el, 0.0, 0.0, 1.0, 1, dG0, None, None)

@@ -456,7 +456,15 @@ int erc_mm_cross_grad(const float* dhi, int ldd, const float* h, int ldh, const 
 int erc_gcnii_combine_fwd(const float* G, const float* hi, const float* h0, int64_t n, float theta, float alpha,
                           float drop_p, const uint64_t* rng_state, uint64_t rng_stream, float* hd, void* stream);
 int erc_gcnii_combine_bwd(const float* d_hd, const float* hd, int64_t n, float theta, float alpha, float keep_scale,
-                          int plain, float* dG, float* dhi, float* dh0, void* stream);
+                          int plain, float* dG, float* dhi, float* dh0, int F, int ld_d, void* stream);
+/* One GCNII layer's dense part with its tail in the epilogue (mmgcn_models.py GraphConvolution.forward / GCNII.forward):
+ *   hd = dropout(relu(theta * ([hi | h0] W) + (1 - theta) * ((1 - alpha) hi + alpha h0)))
+ * hih0: rows [hi | h0] of pitch lda (both F wide); W [2F, F] stored [in, out]; dropout stream rng_stream of the counter
+ * RNG (element index row * F + col), so the mask equals erc_gcnii_combine_fwd's.  One launch instead of two GEMMs and
+ * the combine; in the backward dhi / dh0 are the halves of one [rows, 2F] buffer (pitch ld_d above) so that
+ * [dhi | dh0] += dG W^T is one GEMM as well. */
+int erc_gcnii_layer_fwd(const float* hih0, int lda, const float* W, int ldw, float theta, float alpha, float drop_p,
+                        const uint64_t* rng_state, uint64_t rng_stream, float* hd, int ldo, int rows, int F, void* stream);
 int erc_dropout_fwd(const float* x, int64_t n, float drop_p, const uint64_t* rng_state, uint64_t rng_stream, float* y,
                     void* stream);
 /* FE[i, m*400 + c] = relu(dropout(cat[xd, h][(m,i), c])): regroup (mmgcn_models.py:570-576) + dropout_/ReLU
