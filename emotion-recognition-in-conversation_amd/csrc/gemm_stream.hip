@@ -517,6 +517,8 @@ extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const 
     // Wave tile 16 x 32.  Measured on MI355X (COGMEN B=32 shapes, M = 1982): 32x64 / 16x64 tiles (the body is generic in
     // RM, CF) were SLOWER -- 14.1 vs 10.5 us (K=100, N=400/900), 13.9 vs 12.5 (K=900, N=100), 11.7 vs 7.9 (K=400,
     // N=100): these products are bound by the length of the per-wavefront chain, not by fragment traffic.
+    // Re-checked on every module's step (16x64 / 32x64 whenever >= 300..700 workgroups remain): MMGCN 8.18 -> 8.41..8.90 ms,
+    // COGMEN 0.154 -> 0.160..0.169 ms, DialogueGCN 0.746 -> 0.749..0.874 ms.
     dim3 grid(erc_cdiv(Nlog, 32), erc_cdiv(Mlog, 16), split_k);
     hipStream_t st = (hipStream_t)stream;
     const bool ga = a_gather != nullptr, gb = b_gather != nullptr;
