@@ -68,7 +68,7 @@ _SIGS = {
     "erc_transpose_batched": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "erc_csr_sum": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "erc_gemm_f32_grouped": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f,
-                                       _vp]),
+                                       _vp, _vp]),
     "erc_mm_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_mm_flatten": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_mm_emb_grad": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _vp]),
@@ -343,9 +343,10 @@ def csr_sum(x, ldx, F, N, ptr_, idx, out, ldo, accumulate=0):
 
 
 def gemm_grouped(form, A, lda, B, ldb, Cm, ldc, n_or_k, node_off, n_dlg, n_mod, n_nodes, max_len, pitch, accumulate=0,
-                 act=0, aux=None, ldaux=0, act_scale=1.0):
+                 act=0, aux=None, ldaux=0, act_scale=1.0, cross=None):
     _check(lib().erc_gemm_f32_grouped(form, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, n_or_k, ptr(node_off), n_dlg, n_mod,
-                                      n_nodes, max_len, pitch, accumulate, act, ptr(aux), ldaux, act_scale, stream()),
+                                      n_nodes, max_len, pitch, accumulate, act, ptr(aux), ldaux, act_scale, ptr(cross),
+                                      stream()),
            "erc_gemm_f32_grouped")
 
 

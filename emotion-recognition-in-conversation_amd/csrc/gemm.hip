@@ -40,6 +40,10 @@ struct GemmP {
     int ones_col, act, accumulate;
     int a_vec, b_vec;
     float act_scale, drop_p;
+    // grouped form 0 only: cross-modal entries of MMGCN's adjacency added in the epilogue (xr_CR != null)
+    const float* xr_CR;   // [B][M*M][P]
+    const float* xr_h;    // the un-offset B operand (node rows, pitch ldb)
+    int xr_M, xr_N, xr_P, xr_m, xr_b, xr_off;
 };
 
 constexpr int BM = 64;
@@ -207,6 +211,32 @@ __device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bx, cons
         rng_off = p.rng[0];
         rng_seed = p.rng[1];
     }
+    // MMGCN cross-modal terms: out[(m,t), :] += sum_{n != m} CR[b][m*M+n][t] * h[(n,t), :]  (the off-block-diagonal
+    // entries of create_big_adj, mmgcn_models.py:617-640).  All operands of this lane's elements are requested up front.
+    if (p.xr_CR) {   // uniform; two or three modalities: the (at most two) other ones, in ascending order
+        const int M_ = p.xr_M, m_ = p.xr_m;
+        const int na = m_ == 0 ? 1 : 0, nb = (M_ > 2) ? (m_ == 2 ? 1 : 2) : na;
+        const float wb = M_ > 2 ? 1.f : 0.f;
+        float ca[4], cb[4], ha[NF][4], hb[NF][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int t = min(m0 + 16 * w + 4 * g + i, p.M - 1);
+            const int64_t cbase = ((int64_t)p.xr_b * M_ * M_ + m_ * M_) * p.xr_P + t;
+            ca[i] = p.xr_CR[cbase + (int64_t)na * p.xr_P];
+            cb[i] = p.xr_CR[cbase + (int64_t)nb * p.xr_P];
+            const float* hra = p.xr_h + ((int64_t)na * p.xr_N + p.xr_off + t) * p.ldb;
+            const float* hrb = p.xr_h + ((int64_t)nb * p.xr_N + p.xr_off + t) * p.ldb;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int cc = min(n0 + 16 * f + r, p.N - 1);
+                ha[f][i] = hra[cc], hb[f][i] = hrb[cc];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f][i] = (acc[f][i] + ca[i] * ha[f][i]) + wb * cb[i] * hb[f][i];
+    }
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
         const int col = n0 + 16 * f + r;
@@ -263,6 +293,8 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmP p, GroupP g
     if (FORM == 0) {
         if ((int)blockIdx.x * 32 >= p.N) return;
         p.A = (const float*)p.A + blk;
+        p.xr_h = (const float*)p.B;
+        p.xr_m = m, p.xr_b = b, p.xr_off = off;
         p.B = (const float*)p.B + row0 * p.ldb;
         p.C = p.C + row0 * p.ldc;
         if (p.aux) p.aux = p.aux + row0 * p.ldaux;
@@ -550,15 +582,17 @@ extern "C" int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t
 extern "C" int erc_gemm_f32_grouped(int form, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                                     int N_or_K, const int32_t* node_off, int n_dialogues, int n_mod, int n_nodes,
                                     int max_len, int pitch, int accumulate, int act, const float* aux, int ldaux,
-                                    float act_scale, void* stream) {
+                                    float act_scale, const float* cross, void* stream) {
     ERC_REQUIRE(A && B && C && node_off, "gemm_f32_grouped: null pointer");
     ERC_REQUIRE(form == 0 || form == 1, "gemm_f32_grouped: form %d", form);
     ERC_REQUIRE(n_dialogues > 0 && n_mod > 0 && n_nodes > 0 && max_len > 0 && pitch >= max_len && N_or_K > 0,
                 "gemm_f32_grouped: bad sizes");
     ERC_REQUIRE(act == 0 || (act == 2 && aux && form == 0), "gemm_f32_grouped: act %d unsupported here", act);
+    ERC_REQUIRE(!cross || form == 0, "gemm_f32_grouped: cross entries go with form 0");
     GemmP p{};
     p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.accumulate = accumulate; p.act = act; p.aux = aux; p.ldaux = ldaux; p.act_scale = act_scale;
+    p.xr_CR = cross; p.xr_M = n_mod; p.xr_N = n_nodes; p.xr_P = pitch;
     GroupP g{node_off, n_mod, n_nodes, pitch};
     hipStream_t st = (hipStream_t)stream;
     if (form == 0) {

@@ -210,8 +210,7 @@ class MMGCNModule(nn.Module):
         HI[1:, :, FD:] = ws["H0"]
         for l in range(1, NLAYERS + 1):
             W = fp.w(gn + "convs.%d.weight" % (l - 1))
-            capi.gemm_grouped(0, ws["ADJ"], P, HD[l], FD, HI[l], 2 * FD, FD, ws["node_off"], B, Mo, N, T, P)
-            capi.mm_cross_apply(ws["CR"], HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, HI[l], 2 * FD)
+            capi.gemm_grouped(0, ws["ADJ"], P, HD[l], FD, HI[l], 2 * FD, FD, ws["node_off"], B, Mo, N, T, P, cross=ws["CR"])
             capi.gcnii_layer_fwd(HI[l], 2 * FD, W, FD, self.theta(l), ALPHA, p, rng, 2000 + l, HD[l + 1], FD, R3, FD)
         capi.mm_regroup_fwd(XD, HD[NLAYERS + 1], Mo, N, p, rng, 3000, ws["FE"])
         linear_fwd(pl, ws["FE"], Mo * 2 * FD, None, fp.w("smax_fc.weight"), fp.w("smax_fc.bias"), ws["logits"], C, N, C,
@@ -263,8 +262,7 @@ class MMGCNModule(nn.Module):
             matmul_wgrad_io(pl, HI[l], 2 * FD, dG, FD, 2 * FD, FD, R3, off[Wn], None, defer=True)        # dW = [hi|h0]^T dG
             capi.gemm_grouped(1, dHI, 2 * FD, HD[l], FD, ws["dADJ"], P, FD, ws["node_off"], B, Mo, N, T, P, accumulate=1)
             capi.mm_cross_grad(dHI, 2 * FD, HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"])
-            capi.gemm_grouped(0, ws["ADJ"], P, dHI, 2 * FD, DH, FD, FD, ws["node_off"], B, Mo, N, T, P)
-            capi.mm_cross_apply(ws["CR"], dHI, 2 * FD, ws["node_dlg"], ws["node_off"], Mo, N, P, DH, FD)
+            capi.gemm_grouped(0, ws["ADJ"], P, dHI, 2 * FD, DH, FD, FD, ws["node_off"], B, Mo, N, T, P, cross=ws["CR"])
         # input layer: HD[1] = dropout(H0), H0 = relu(fc0(XD))
         ws["dH0"].copy_(dH0)              # contiguous copy of the accumulated residual gradient for the elementwise tail
         capi.axpy_mask(DH, HD[1] if p > 0 else None, n_el, ks, 1, ws["dH0"])

@@ -425,11 +425,15 @@ int erc_csr_sum(const float* x, int ldx, int F, int N, const int32_t* ptr, const
  */
 /* Grouped block products on the matrix cores.  form 0: C_nodes[L,N] (+)= Blk[L,L] B_nodes[L,N] (A*h of
  * GraphConvolution.forward, mmgcn_models.py:29, and its transpose: the normalised adjacency is symmetric);
- * form 1: Blk[L,L] (+)= A_nodes[L,K] B_nodes[L,K]^T (cosine blocks of mmgcn_models.py:604-608, and dAdj). */
+ * form 1: Blk[L,L] (+)= A_nodes[L,K] B_nodes[L,K]^T (cosine blocks of mmgcn_models.py:604-608, and dAdj).
+ * cross (form 0, optional): the cross-modal entries [B][M*M][P] of the adjacency; their contribution
+ * C[(m,t),:] += sum_{n != m} cross[b][m*M+n][t] * B_nodes[(n,t),:] is added in the epilogue (what
+ * erc_mm_cross_apply does as a launch of its own). */
 int erc_gemm_f32_grouped(int form, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          int N_or_K, const int32_t* node_off, int n_dialogues, int n_mod, int n_nodes,
                          int max_len, int pitch, int accumulate, int act, const float* aux, int ldaux,
-                         float act_scale, void* stream);
+                         float act_scale,
+                         const float* cross, void* stream);
 /* node tables from text_length and the time-major one-hot qmask [T,B,S] (element (t,b,c) at t*q_st + b*q_sb + c) */
 int erc_mm_meta(const int64_t* lengths, const float* qmask, int64_t q_st, int64_t q_sb, int n_speakers, int B,
                 int32_t* node_off, int32_t* node_row, int32_t* node_dlg, int32_t* node_spk, void* stream);
