@@ -129,7 +129,7 @@ __device__ __forceinline__ void cluster_sync(int* ctr, int target, int* err) {
         __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(1);
             ++spins;
             if (spins > CL_SPIN_LIMIT) {   // a member never arrived (workgroups not co-resident?): flag and give up
                 __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -142,21 +142,51 @@ __device__ __forceinline__ void cluster_sync(int* ctr, int target, int* err) {
     __syncthreads();
 }
 
-// rows [r_lo, r_hi) of out = W v (+ bias), results to global memory with write-through stores
-__device__ __forceinline__ void matvec_rows_sc1(const float* __restrict__ W, const float* __restrict__ bias, int r_lo, int r_hi,
-                                                const float* v_lds, float* out_glb, int lane, int wave) {
+// Sum each of 16 per-lane partials a[0..15] over the 64 lanes of the wavefront with a halving butterfly: 8 + 4 + 2 + 1
+// exchanges leave every lane with ONE row's partial over 4 lanes, two more finish it -- 17 shuffles instead of the
+// 96 of sixteen separate wave_sum()s.  Afterwards lane l holds the total of row bf16_row(l) (valid in every lane).
+__device__ __forceinline__ int butterfly_row(int lane) {
+    return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+__device__ __forceinline__ float butterfly16(const float (&a)[16], int lane) {
+    float b[8], c[4], d[2];
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (h5 ? a[8 + j] : a[j]) + __shfl_xor(h5 ? a[j] : a[8 + j], 32, 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = (h4 ? b[4 + j] : b[j]) + __shfl_xor(h4 ? b[j] : b[4 + j], 16, 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) d[j] = (h3 ? c[2 + j] : c[j]) + __shfl_xor(h3 ? c[j] : c[2 + j], 8, 64);
+    float e = (h2 ? d[1] : d[0]) + __shfl_xor(h2 ? d[0] : d[1], 4, 64);
+    e += __shfl_xor(e, 2, 64);
+    e += __shfl_xor(e, 1, 64);
+    return e;
+}
+
+// Rows [0, n) of a virtual row space -> out = W_row . v (+ bias): rowptr(r) gives the weight row, store(r, value) takes
+// the result.  A wavefront owns 16 consecutive rows per pass (8 + 8 rows of loads in flight, one butterfly).
+template <typename RowPtr, typename Store>
+__device__ __forceinline__ void matvec16(int n, const float* v_lds, int lane, int wave, RowPtr rowptr, Store store) {
     const Vec300 v = load_vec300(v_lds, lane);
-    const int rows = r_hi - r_lo;
-    for (int r0 = wave; r0 < rows; r0 += RB * NW) {
-        float acc[RB];
+    for (int r0 = 16 * wave; r0 < n; r0 += 16 * NW) {
+        float acc[16];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) acc[u] = dot300(W + (int64_t)(r_lo + min(r0 + u * NW, rows - 1)) * HID, v, lane);
+        for (int hb = 0; hb < 2; ++hb) {
+            float4 a[8], b[8];
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            const int r = r0 + u * NW;
-            const float s = wave_sum(acc[u]);
-            if (r < rows && lane == 0) st_sc1(out_glb + r_lo + r, s + (bias ? bias[r_lo + r] : 0.f));
+            for (int u = 0; u < 8; ++u) {
+                const float* wr = rowptr(min(r0 + 8 * hb + u, n - 1));
+                a[u] = *reinterpret_cast<const float4*>(wr + 4 * lane);
+                b[u] = *reinterpret_cast<const float4*>(wr + 256 + 4 * min(lane, 10));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc[8 * hb + u] = a[u].x * v.lo.x + a[u].y * v.lo.y + a[u].z * v.lo.z + a[u].w * v.lo.w + b[u].x * v.hi.x +
+                                  b[u].y * v.hi.y + b[u].z * v.hi.z + b[u].w * v.hi.w;
         }
+        const float tot = butterfly16(acc, lane);
+        const int r = r0 + butterfly_row(lane);
+        if ((lane & 3) == 0 && r < n) store(r, tot);
     }
 }
 
@@ -417,8 +447,13 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
         // ---- B: this member's rows of the sequential gate pre-activations, exchanged through GH
         float* gh = p.GH + row * 2 * G3;
         if (i > 0) {
-            matvec_rows_sc1(p.W_hh_c, p.b_hh_c, g_lo, g_hi, v_m, gh, lane, wave);
-            matvec_rows_sc1(p.W_ih_p, p.b_ih_p, g_lo, g_hi, v_m, gh + G3, lane, wave);
+            const int gn = g_hi - g_lo;   // this member's rows of each of the two 900-row matrices: one virtual row space
+            matvec16(2 * gn, v_m, lane, wave,
+                     [&](int r) { return (r < gn ? p.W_hh_c + (int64_t)(g_lo + r) * HID : p.W_ih_p + (int64_t)(g_lo + r - gn) * HID); },
+                     [&](int r, float t) {
+                         if (r < gn) st_sc1(gh + g_lo + r, t + p.b_hh_c[g_lo + r]);
+                         else st_sc1(gh + G3 + g_lo + r - gn, t + p.b_ih_p[g_lo + r - gn]);
+                     });
             cluster_sync(ctr, P * (++phase), cl.err);
             for (int r = tid; r < 2 * G3; r += NT) gates[r] = ld_sc1(gh + r);
         } else {
@@ -445,7 +480,8 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
         }
         __syncthreads();
         // ---- D: this member's rows of the relation transforms; the key score by the last member
-        matvec_rows_sc1(p.Wr, nullptr, r_lo, r_hi, v_h, p.R + row * 2 * HID, lane, wave);
+        matvec16(r_hi - r_lo, v_h, lane, wave, [&](int r) { return p.Wr + (int64_t)(r_lo + r) * HID; },
+                 [&](int r, float t) { st_sc1(p.R + row * 2 * HID + r_lo + r, t); });
         if (mem == P - 1 && wave == NW - 1) {
             const float a = wave_sum(dot300(w_k, load_vec300(v_h, lane), lane));
             if (lane == 0) st_sc1(p.ks + row, a);

@@ -1,19 +1,22 @@
 import sys, os; sys.path.insert(0, "/root/repo")
-import torch, importlib, time
+import torch, importlib
 from bench import synthetic_batch
+import erc_amd.dagerc as D
 plugin = importlib.import_module("track_mm.dagerc")
-outs = {}
-for P in (1, 8):
-    os.environ["ERC_DAG_CLUSTER"] = str(P)
-    params = plugin.ParamsType().from_args(["--dataset=iemocap-cogmen-6", "--modality=atv", "--reimplement"])
-    torch.manual_seed(0)
-    tr = plugin.DAGERCTrainer(params, torch.device("cuda:0"))
-    tr.model.train(); tr.model.drop_p = 0.0 if hasattr(tr.model, "drop_p") else None
-    b = tr.prepare_batch(synthetic_batch(params, 5, 23, seed=3))
-    stats = tr.model.loss_and_grads(b)
-    torch.cuda.synchronize()
-    ws = next(iter(tr.model._ws.values()))
-    print("P", P, "cluster", ws["cluster"], "err flag", int(ws["cl_state"][0]), "loss", float(stats[0]))
-    outs[P] = tr.model.flat.grad.clone()
-d = (outs[1] - outs[8]).abs()
-print("max |dgrad|", float(d.max()), "ref max", float(outs[1].abs().max()), "nan", bool(torch.isnan(outs[8]).any()))
+params = plugin.ParamsType().from_args(["--dataset=iemocap-cogmen-6", "--modality=atv", "--reimplement"])
+tr = plugin.DAGERCTrainer(params, torch.device("cuda:0"))
+b = tr.prepare_batch(synthetic_batch(params, 16, 110, seed=3))
+tr.model.train()
+# enlarge cl_state for the timestamps
+tr.model.loss_and_grads(b)
+ws = next(iter(tr.model._ws.values()))
+ws["cl_state"] = torch.zeros(16 + 1 + 16, dtype=torch.int32, device="cuda:0")
+for _ in range(3):
+    tr.model.loss_and_grads(b)
+torch.cuda.synchronize()
+t = ws["cl_state"][17:17 + 9].cpu().tolist()
+names = ["start", "x loaded", "A done (m ready)", "B matvec done", "B sync done", "gates loaded", "C done", "D matvec done", "D sync done"]
+for i in range(1, 9):
+    d = (t[i] - t[i - 1]) & 0xffffffff
+    print("%-18s +%6d ticks = %.2f us" % (names[i], d, d / 100.0))
+print("total", ((t[8] - t[0]) & 0xffffffff) / 100.0, "us")
