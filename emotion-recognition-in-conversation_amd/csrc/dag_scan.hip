@@ -30,6 +30,8 @@ constexpr int G3 = 900;       // 3 gates x HID
 constexpr int NT = 1024;      // threads per workgroup
 constexpr int NW = NT / 64;   // 16 wavefronts
 constexpr int MAX_T = 512;
+constexpr int CNT = 512;      // cluster-mode kernels: 8 wavefronts per member (256 VGPRs each: no spills)
+constexpr int CNW = CNT / 64;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -81,18 +83,19 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
 }
 
 // acc += sum_{r owned by wave} W[r,:] * d[r]  (transposed product); acc is this lane's slice in the Vec300 layout
+template <int NWV = NW>
 __device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, int rows, const float* d_lds, Vec300& acc,
                                                int lane, int wave) {
-    for (int r0 = wave; r0 < rows; r0 += RB * NW) {
+    for (int r0 = wave; r0 < rows; r0 += RB * NWV) {
         float4 a[RB], b[RB];
         float d[RB];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
-            const int r = min(r0 + u * NW, rows - 1);
+            const int r = min(r0 + u * NWV, rows - 1);
             const float* w = W + (int64_t)r * HID;
             a[u] = *reinterpret_cast<const float4*>(w + 4 * lane);
             b[u] = *reinterpret_cast<const float4*>(w + 256 + 4 * min(lane, 10));
-            d[u] = (r0 + u * NW < rows) ? d_lds[r] : 0.f;
+            d[u] = (r0 + u * NWV < rows) ? d_lds[r] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
@@ -165,10 +168,10 @@ __device__ __forceinline__ float butterfly16(const float (&a)[16], int lane) {
 
 // Rows [0, n) of a virtual row space -> out = W_row . v (+ bias): rowptr(r) gives the weight row, store(r, value) takes
 // the result.  A wavefront owns 16 consecutive rows per pass (8 + 8 rows of loads in flight, one butterfly).
-template <typename RowPtr, typename Store>
+template <int NWV, typename RowPtr, typename Store>
 __device__ __forceinline__ void matvec16(int n, const float* v_lds, int lane, int wave, RowPtr rowptr, Store store) {
     const Vec300 v = load_vec300(v_lds, lane);
-    for (int r0 = 16 * wave; r0 < n; r0 += 16 * NW) {
+    for (int r0 = 16 * wave; r0 < n; r0 += 16 * NWV) {
         float acc[16];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {
@@ -362,7 +365,7 @@ __device__ __forceinline__ void cluster_ids(int P, int& b, int& m) {
     m = (id >> 3) % P;
 }
 
-__global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagCluster cl) {
+__global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagCluster cl) {
     int b, mem;
     cluster_ids(cl.P, b, mem);
     if (b >= p.B) return;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
     __shared__ __attribute__((aligned(16))) float v_m[320], v_h[320], v_x[320], gates[2 * G3], s_alpha[MAX_T];
     __shared__ float s_ks[MAX_T];            // key scores of the steps done so far (one sc1 load per step keeps it current)
     __shared__ int s_spk[MAX_T], s_pred[MAX_T];
-    for (int t = tid; t < T; t += NT) s_spk[t] = p.spk[(int64_t)b * T + t], s_pred[t] = p.pred[(int64_t)b * T + t];
+    for (int t = tid; t < T; t += CNT) s_spk[t] = p.spk[(int64_t)b * T + t], s_pred[t] = p.pred[(int64_t)b * T + t];
     const float* w_q = p.w_lin;
     const float* w_k = p.w_lin + HID;
     const float b_lin = p.w_lin[2 * HID];
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
 #pragma unroll
             for (int u = 0; u < 6; ++u) gi_r[u] = gi[u * HID + tid];
         }
-        if (i > 0 && tid == NT - 1) s_ks[i - 1] = ld_sc1(p.ks + row - 1);
+        if (i > 0 && tid == CNT - 1) s_ks[i - 1] = ld_sc1(p.ks + row - 1);
         __syncthreads();
         // ---- A: attention over the DAG predecessors [lo, i-1] (every member; R / ks come from all members: sc1 loads)
         int lo = 0, n = 0;
@@ -448,16 +451,16 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
         float* gh = p.GH + row * 2 * G3;
         if (i > 0) {
             const int gn = g_hi - g_lo;   // this member's rows of each of the two 900-row matrices: one virtual row space
-            matvec16(2 * gn, v_m, lane, wave,
+            matvec16<CNW>(2 * gn, v_m, lane, wave,
                      [&](int r) { return (r < gn ? p.W_hh_c + (int64_t)(g_lo + r) * HID : p.W_ih_p + (int64_t)(g_lo + r - gn) * HID); },
                      [&](int r, float t) {
                          if (r < gn) st_sc1(gh + g_lo + r, t + p.b_hh_c[g_lo + r]);
                          else st_sc1(gh + G3 + g_lo + r - gn, t + p.b_ih_p[g_lo + r - gn]);
                      });
             cluster_sync(ctr, P * (++phase), cl.err);
-            for (int r = tid; r < 2 * G3; r += NT) gates[r] = ld_sc1(gh + r);
+            for (int r = tid; r < 2 * G3; r += CNT) gates[r] = ld_sc1(gh + r);
         } else {
-            for (int r = tid; r < G3; r += NT) {
+            for (int r = tid; r < G3; r += CNT) {
                 gates[r] = p.b_hh_c[r];
                 gates[G3 + r] = p.b_ih_p[r];
                 if (mem == 0) gh[r] = p.b_hh_c[r], gh[G3 + r] = p.b_ih_p[r];
@@ -480,9 +483,9 @@ __global__ __launch_bounds__(NT) void dag_scan_fwd_cluster_kernel(DagFwd p, DagC
         }
         __syncthreads();
         // ---- D: this member's rows of the relation transforms; the key score by the last member
-        matvec16(r_hi - r_lo, v_h, lane, wave, [&](int r) { return p.Wr + (int64_t)(r_lo + r) * HID; },
+        matvec16<CNW>(r_hi - r_lo, v_h, lane, wave, [&](int r) { return p.Wr + (int64_t)(r_lo + r) * HID; },
                  [&](int r, float t) { st_sc1(p.R + row * 2 * HID + r_lo + r, t); });
-        if (mem == P - 1 && wave == NW - 1) {
+        if (mem == P - 1 && wave == CNW - 1) {
             const float a = wave_sum(dot300(w_k, load_vec300(v_h, lane), lane));
             if (lane == 0) st_sc1(p.ks + row, a);
         }
@@ -645,25 +648,26 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
 // are exchanged through scratch[b][phase][member][320] and summed by every member in member order.  The
 // accumulations into dR are owned column-wise (member m updates columns [300 m / P, 300 (m+1) / P) of both relation
 // slots), those into dks / dH_l / the linear-layer gradients by member 0.
+template <int NWV>
 __device__ __forceinline__ void reduce_wave_partials(const float (*part)[320], float* dst_glb, int tid) {
     if (tid < HID) {
         float s = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) s += part[w][tid];
+        for (int w = 0; w < NWV; ++w) s += part[w][tid];
         st_sc1(dst_glb + tid, s);
     }
 }
 
-__global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagCluster cl) {
+__global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagCluster cl) {
     int b, mem;
     cluster_ids(cl.P, b, mem);
     if (b >= p.B) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T, P = cl.P;
-    __shared__ __attribute__((aligned(16))) float v_g[320], v_dm[320], v_x[320], v_m[320], v_in[2 * G3], part[NW][320], s_al[MAX_T], s_da[MAX_T];
+    __shared__ __attribute__((aligned(16))) float v_g[320], v_dm[320], v_x[320], v_m[320], v_in[2 * G3], part[CNW][320], s_al[MAX_T], s_da[MAX_T];
     __shared__ float s_dqs;
     __shared__ int s_spk[MAX_T], s_pred[MAX_T];
-    for (int t = tid; t < T; t += NT) s_spk[t] = p.spk[(int64_t)b * T + t], s_pred[t] = p.pred[(int64_t)b * T + t];
+    for (int t = tid; t < T; t += CNT) s_spk[t] = p.spk[(int64_t)b * T + t], s_pred[t] = p.pred[(int64_t)b * T + t];
     __syncthreads();
     const float* w_q = p.w_lin;
     const float* w_k = p.w_lin + HID;
@@ -679,41 +683,50 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagC
     for (int i = T - 1; i >= 0; --i) {
         const int64_t row = (int64_t)b * T + i;
         // ---- 1: total gradient wrt h1_i = dH1_i + Wr^T dR_i + w_k dks_i
-        for (int r = tid; r < 2 * HID; r += NT) v_in[r] = ld_sc1(p.dR + row * 2 * HID + r);
-        if (tid < HID) {
+        for (int r = tid; r < 2 * HID; r += CNT) v_in[r] = ld_sc1(p.dR + row * 2 * HID + r);
+        float gi_r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gh_r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dh1_r = 0.f, h1_r = 0.f;
+        if (tid < HID) {   // operands of the later phases of this step: requested now
             v_x[tid] = p.Hl[row * p.ldh + tid];
             v_m[tid] = p.Mseq[row * HID + tid];
+            const float* gi = p.GI + row * 2 * G3;
+            const float* gh = p.GH + row * 2 * G3;
+#pragma unroll
+            for (int u = 0; u < 6; ++u) gi_r[u] = gi[u * HID + tid], gh_r[u] = gh[u * HID + tid];
+            dh1_r = p.dH1[row * p.ldd + tid];
+            h1_r = p.H1[row * p.ldo + tid];
         }
         __syncthreads();
         {
             Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-            matvec_t_accum(p.Wr + (int64_t)r_lo * HID, r_hi - r_lo, v_in + r_lo, acc, lane, wave);
+            matvec_t_accum<CNW>(p.Wr + (int64_t)r_lo * HID, r_hi - r_lo, v_in + r_lo, acc, lane, wave);
             store_vec300(part[wave], acc, lane);
         }
         __syncthreads();
-        reduce_wave_partials(part, sc0 + mem * 320, tid);
+        reduce_wave_partials<CNW>(part, sc0 + mem * 320, tid);
         cluster_sync(ctr, P * (++phase), cl.err);
         const float dks_i = ld_sc1(p.dks + row);
         if (tid < HID) {
-            float g = p.dH1[row * p.ldd + tid] + w_k[tid] * dks_i;
-            for (int m = 0; m < P; ++m) g += ld_sc1(sc0 + m * 320 + tid);
+            float g = dh1_r + w_k[tid] * dks_i;
+            float pm[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) pm[m] = ld_sc1(sc0 + min(m, P - 1) * 320 + tid);   // all in flight (P <= 8)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) g += m < P ? pm[m] : 0.f;
             v_g[tid] = g;
-            dwk += dks_i * p.H1[row * p.ldo + tid];
+            dwk += dks_i * h1_r;
         }
         __syncthreads();
         // ---- 2: GRU cells backward (elementwise, every member; member 0 stores)
         if (tid < HID) {
-            const float* gi = p.GI + row * 2 * G3;
-            const float* gh = p.GH + row * 2 * G3;
             float* dgi = p.DGI + row * 2 * G3;
             float* dgh = p.DGH + row * 2 * G3;
             const float g = v_g[tid];
             const bool st = mem == 0;
             {
-                const float r = sigmoidf_(gi[tid] + gh[tid]);
-                const float z = sigmoidf_(gi[HID + tid] + gh[HID + tid]);
-                const float ghn = gh[2 * HID + tid];
-                const float nn = tanhf(gi[2 * HID + tid] + r * ghn);
+                const float r = sigmoidf_(gi_r[0] + gh_r[0]);
+                const float z = sigmoidf_(gi_r[1] + gh_r[1]);
+                const float ghn = gh_r[2];
+                const float nn = tanhf(gi_r[2] + r * ghn);
                 const float dn_pre = g * (1.f - z) * (1.f - nn * nn);
                 const float dz_pre = g * (v_m[tid] - nn) * z * (1.f - z);
                 const float dr_pre = dn_pre * ghn * r * (1.f - r);
@@ -725,10 +738,10 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagC
                 v_dm[tid] = g * z;
             }
             {
-                const float r = sigmoidf_(gh[G3 + tid] + gi[G3 + tid]);
-                const float z = sigmoidf_(gh[G3 + HID + tid] + gi[G3 + HID + tid]);
-                const float hn = gi[G3 + 2 * HID + tid];
-                const float nn = tanhf(gh[G3 + 2 * HID + tid] + r * hn);
+                const float r = sigmoidf_(gh_r[3] + gi_r[3]);
+                const float z = sigmoidf_(gh_r[4] + gi_r[4]);
+                const float hn = gi_r[5];
+                const float nn = tanhf(gh_r[5] + r * hn);
                 const float dn_pre = g * (1.f - z) * (1.f - nn * nn);
                 const float dz_pre = g * (v_x[tid] - nn) * z * (1.f - z);
                 const float dr_pre = dn_pre * hn * r * (1.f - r);
@@ -745,16 +758,20 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagC
         // ---- 3: dM_i = direct + W_hh_c^T dgh_c + W_ih_p^T dgi_p
         {
             Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-            matvec_t_accum(p.W_hh_c + (int64_t)g_lo * HID, g_hi - g_lo, v_in + g_lo, acc, lane, wave);
-            matvec_t_accum(p.W_ih_p + (int64_t)g_lo * HID, g_hi - g_lo, v_in + G3 + g_lo, acc, lane, wave);
+            matvec_t_accum<CNW>(p.W_hh_c + (int64_t)g_lo * HID, g_hi - g_lo, v_in + g_lo, acc, lane, wave);
+            matvec_t_accum<CNW>(p.W_ih_p + (int64_t)g_lo * HID, g_hi - g_lo, v_in + G3 + g_lo, acc, lane, wave);
             store_vec300(part[wave], acc, lane);
         }
         __syncthreads();
-        reduce_wave_partials(part, sc1_ + mem * 320, tid);
+        reduce_wave_partials<CNW>(part, sc1_ + mem * 320, tid);
         cluster_sync(ctr, P * (++phase), cl.err);
         if (tid < HID) {
             float d = v_dm[tid];
-            for (int m = 0; m < P; ++m) d += ld_sc1(sc1_ + m * 320 + tid);
+            float pm[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) pm[m] = ld_sc1(sc1_ + min(m, P - 1) * 320 + tid);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) d += m < P ? pm[m] : 0.f;
             v_dm[tid] = d;
         }
         __syncthreads();
@@ -763,7 +780,7 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagC
         const int lo = pr > 0 ? pr : 0;
         const int n = i - lo;
         const int si = s_spk[i];
-        for (int j = wave; j < n; j += NW) {  // d alpha_j = dM . V_j
+        for (int j = wave; j < n; j += CNW) {  // d alpha_j = dM . V_j
             const int64_t rj = (int64_t)b * T + lo + j;
             const float* v = p.R + rj * 2 * HID + (s_spk[lo + j] == si ? 0 : HID);
             const float a = wave_sum(dot300(v, load_vec300(v_dm, lane), lane));
@@ -794,10 +811,18 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagC
             const float dq = s_dqs;
             const float dm = v_dm[tid];
             if (tid >= c_lo && tid < c_hi) {
-                for (int j = 0; j < n; ++j) {  // dV_j = alpha_j dM into the relation slot that was read
-                    const int64_t rj = (int64_t)b * T + lo + j;
-                    float* q = p.dR + rj * 2 * HID + (s_spk[lo + j] == si ? 0 : HID) + tid;
-                    st_sc1(q, ld_sc1(q) + s_al[j] * dm);
+                for (int j0 = 0; j0 < n; j0 += 8) {  // dV_j = alpha_j dM into the relation slot that was read; 8 rows in flight
+                    float* q[8];
+                    float old[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int tj = lo + min(j0 + u, n - 1);
+                        q[u] = p.dR + ((int64_t)b * T + tj) * 2 * HID + (s_spk[tj] == si ? 0 : HID) + tid;
+                        old[u] = ld_sc1(q[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u < n) st_sc1(q[u], old[u] + s_al[j0 + u] * dm);
                 }
             }
             if (mem == 0) {
@@ -854,7 +879,7 @@ extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const
         hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
         ERC_REQUIRE(e == hipSuccess, "dag_scan_fwd: memset failed: %s", hipGetErrorString(e));
         DagCluster cl{cluster, cl_state + 1, cl_state, nullptr};
-        hipLaunchKernelGGL(dag_scan_fwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(NT), 0, (hipStream_t)stream, p, cl);
+        hipLaunchKernelGGL(dag_scan_fwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
     }
     ERC_LAUNCH_CHECK("dag_scan_fwd");
     return ERC_OK;
@@ -882,7 +907,7 @@ extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const
         hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
         ERC_REQUIRE(e == hipSuccess, "dag_scan_bwd: memset failed: %s", hipGetErrorString(e));
         DagCluster cl{cluster, cl_state + 1, cl_state, cl_scratch};
-        hipLaunchKernelGGL(dag_scan_bwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(NT), 0, (hipStream_t)stream, p, cl);
+        hipLaunchKernelGGL(dag_scan_bwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
     }
     ERC_LAUNCH_CHECK("dag_scan_bwd");
     return ERC_OK;
