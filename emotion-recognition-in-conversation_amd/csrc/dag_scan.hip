@@ -857,7 +857,7 @@ extern "C" int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_
 extern "C" int erc_dag_cluster_size(int B) {
     // workgroups per dialogue: all B * P persistent 1024-thread workgroups must be resident at once (256 CUs)
     int P = 256 / (B > 0 ? B : 1);
-    if (P > 8) P = 8;   // measured (B = 16): P = 2 / 4 / 8 / 12 / 16 -> 41.6 / 28.4 / 23.5 / 24.9 / 26.9 ms per step
+    if (P > 8) P = 8;   // measured (B = 16, step time): P = 4 / 8 / 12 / 16 -> 18.3 / 14.6 / 15.3 / 16.8 ms
     return P < 2 ? 1 : P;
 }
 
