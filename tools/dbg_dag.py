@@ -14,9 +14,9 @@ ws["cl_state"] = torch.zeros(16 + 1 + 16, dtype=torch.int32, device="cuda:0")
 for _ in range(3):
     tr.model.loss_and_grads(b)
 torch.cuda.synchronize()
-t = ws["cl_state"][17:17 + 10].cpu().tolist()
-names = ["start", "1 matvec_t Wr", "1 sync", "1 sum g", "2 pointwise", "3 matvec_t 1800", "3 sync", "3 sum dM", "4 attention bwd", "end sync"]
-for i in range(1, 10):
+t = ws["cl_state"][17:17 + 9].cpu().tolist()
+names = ["start", "x loaded", "A done (m ready)", "B matvec done", "B sync done", "gates loaded", "C done", "D matvec done", "D sync done"]
+for i in range(1, 9):
     d = (t[i] - t[i - 1]) & 0xffffffff
     print("%-18s +%6d ticks = %.2f us" % (names[i], d, d / 2270.0))
-print("total", ((t[9] - t[0]) & 0xffffffff) / 2270.0, "us")
+print("total", ((t[8] - t[0]) & 0xffffffff) / 2270.0, "us")
