@@ -26,6 +26,10 @@ _SIGS = {
                                       _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
     "erc_gemm_bf16a_stream": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "erc_wgrad_table": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "erc_enc_to_bf16": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "erc_enc_gemm_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "erc_enc_attention": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "erc_enc_add_layernorm": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
     "erc_wgrad_slab_floats": (C.c_int64, []),
     "erc_bn_batch_stats_ws_floats": (C.c_int64, [_i]),
     "erc_bn_batch_stats": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
@@ -448,6 +452,22 @@ def head_fused(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3,
 
 def bn_bwd_apply(x, ldx, N, F, gamma, saved, bn_bwd, dY, lddy, dx, lddx):
     _call("erc_bn_bwd_apply", x, ldx, N, F, gamma, saved, bn_bwd, dY, lddy, dx, lddx)
+
+
+def enc_to_bf16(x, n, y):
+    _call("erc_enc_to_bf16", x, n, y)
+
+
+def enc_gemm_bf16(A, lda, W, ldw, bias, C_f32, C_bf16, ldc, M, N, K, relu=0):
+    _call("erc_enc_gemm_bf16", A, lda, W, ldw, bias, C_f32, C_bf16, ldc, M, N, K, relu)
+
+
+def enc_attention(qkv, n_seq, S, D, heads, out):
+    _call("erc_enc_attention", qkv, n_seq, S, D, heads, out)
+
+
+def enc_add_layernorm(a, b, D, n_rows, gamma, beta, eps, y_f32, y_bf16):
+    _call("erc_enc_add_layernorm", a, b, D, n_rows, gamma, beta, float(eps), y_f32, y_bf16)
 
 
 def wgrad_slab_floats():

@@ -359,8 +359,16 @@ class COGMENTrainer:
         if self.model.compute == "bf16":
             self.model.attach_bf16_shadow(self.optim)
         self.class_weight = None
+        # faithful-cost mode: also run the reference's dead Transformer encoder on the padded
+        # [B, T, D] block and discard the result, so that a step does the same arithmetic as the reference's
+        self.encoder = None
+        if params.get("faithful_dead_encoder", False):
+            from .encoder import EncoderBlock
+            self.encoder = EncoderBlock(self.model.rnn[0], self.device)
 
     def to_logits(self, batch):
+        if self.encoder is not None:
+            self.encoder.forward(batch["input_tensor"])
         return self.model(**batch)[0]
 
     def prepare_batch(self, batch):
@@ -372,6 +380,8 @@ class COGMENTrainer:
     def train_step(self, batch):
         """forward + CE + backward + (DP all-reduce) + Adam.  Returns the device stats tensor."""
         self.model.train()
+        if self.encoder is not None:
+            self.encoder.forward(batch["input_tensor"])      # dead work, result discarded (cogmen.py:146-147)
         stats = self.model.loss_and_grads(batch, self.class_weight)
         scale = all_reduce_grads(self.model.flat)
         self.optim.step(grad_scale=scale)

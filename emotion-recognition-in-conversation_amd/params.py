@@ -71,6 +71,7 @@ class ERCParams:
         self.compute = "f32"           # 'f32' (parity) | 'bf16' (input GEMM operands in bf16)
         self.graph_replay = True       # capture the step in a HIP graph per shape bucket
         self.log_every = 1
+        self.faithful_dead_encoder = False   # COGMEN: also run the reference's dead encoder (cost parity, result discarded)
 
     # ------------------------------------------------------------------ CLI
     def from_args(self, argv=None):

@@ -242,6 +242,24 @@ int erc_cross_entropy(const float* logits, int ld, int C, int n_rows, const int3
                       const int64_t* labels, const float* weight, float grad_scale,
                       float* dlogits, int lddl, float* stats, void* stream);
 
+/* ------------------------------------------------------------------------
+ * K9  COGMEN's Transformer encoder block rnn.0 (track_mm/cogmen.py:94-102; contrib/nn.py:283-305: post-norm, ReLU,
+ * ffn 2048, batch_first, no padding mask).  Its output is DISCARDED by the reference (cogmen.py:146-147); these
+ * entry points serve the faithful-cost mode and are inference-mode math.
+ *   erc_enc_gemm_bf16:     C[M,N] = A[M,K] W[N,K]^T + bias (+ReLU), bf16 operands (K contiguous), fp32 accumulate on the
+ *                          matrix cores; C as fp32 and / or bf16 (either may be NULL).  K, lda, ldw multiples of 4.
+ *   erc_enc_attention:     qkv bf16 [n_seq*S, 3D] (q | k | v) -> softmax(q k^T / sqrt(D/heads)) v per (sequence, head)
+ *                          over all S positions, out bf16 [n_seq*S, D].  D / heads <= 256.
+ *   erc_enc_add_layernorm: y = LayerNorm(a + b) * gamma + beta per row of width D <= 2048, as fp32 and bf16.
+ *   erc_enc_to_bf16:       fp32 -> bf16 (RNE) copy.
+ */
+int erc_enc_to_bf16(const float* x, int64_t n, void* y, void* stream);
+int erc_enc_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, float* C_f32, void* C_bf16,
+                      int ldc, int M, int N, int K, int relu, void* stream);
+int erc_enc_attention(const void* qkv, int n_seq, int S, int D, int heads, void* out, void* stream);
+int erc_enc_add_layernorm(const float* a, const float* b, int D, int n_rows, const float* gamma, const float* beta,
+                          float eps, float* y_f32, void* y_bf16, void* stream);
+
 /* Training-mode BatchNorm1d statistics (track_mm/cogmen.py:67): column mean / rstd of x [N,F] into saved[0,F) /
  * saved[F,2F), running_mean / running_var updated with `momentum` (unbiased variance), one launch.
  * ws: erc_bn_batch_stats_ws_floats(F) floats, 8-byte aligned, zero before the first call. */

@@ -1,0 +1,33 @@
+"""K9 (faithful-cost mode of the dead COGMEN encoder): the HIP encoder block against torch.nn.TransformerEncoder with
+the same parameters (post-norm, ReLU, ffn 2048, batch_first, no padding mask -- the configuration of
+track_mm/cogmen.py:94-102) in inference mode.  bf16 operands / fp32 accumulate: tolerance is that of the bf16 rounding
+of activations and weights, measured relative to the output scale (LayerNorm outputs are O(1))."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("B,T,D", [(3, 13, 24), (2, 37, 712), (4, 110, 1380)])
+def test_encoder_block_matches_torch(B, T, D):
+    from erc_amd.cogmen import COGMENModule
+    from erc_amd.encoder import EncoderBlock
+    torch.manual_seed(B + T)
+    m = COGMENModule(D, 100, 17, 2, 6)
+    enc = m.rnn[0].eval()
+    with torch.no_grad():     # non-trivial LayerNorm affine parameters
+        for lyr in enc.layers:
+            lyr.norm1.weight.uniform_(0.5, 1.5), lyr.norm1.bias.uniform_(-0.3, 0.3)
+            lyr.norm2.weight.uniform_(0.5, 1.5), lyr.norm2.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(B, T, D)
+    blk = EncoderBlock(enc, DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        xin = x.to(dt)
+        got = blk.forward(xin.to(DEV)).cpu().clone()
+        with torch.no_grad():
+            want = enc(xin.float())
+        err = float((got - want).abs().max())
+        assert err < 6e-2, (dt, err)
+        assert float((got - want).abs().mean()) < 8e-3
+    assert blk.flops(B, T) > 0
