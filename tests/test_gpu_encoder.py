@@ -31,3 +31,19 @@ def test_encoder_block_matches_torch(B, T, D):
         assert err < 6e-2, (dt, err)
         assert float((got - want).abs().mean()) < 8e-3
     assert blk.flops(B, T) > 0
+
+
+def test_faithful_mode_changes_cost_not_results():
+    """--faithful_dead_encoder runs the dead encoder every step and discards its output: losses are bit-identical to the
+    default mode (the live path does not read anything the encoder writes)."""
+    from bench import synthetic_batch
+    from erc_amd.cogmen import COGMENTrainer
+    from erc_amd.params import ERCParams
+    losses = []
+    for extra in ([], ["--faithful_dead_encoder"]):
+        p = ERCParams().from_args(["--dataset=iemocap-cogmen-6", "--compute=bf16"] + extra)
+        tr = COGMENTrainer(p, DEV)
+        assert (tr.encoder is not None) == bool(extra)
+        b = tr.prepare_batch(synthetic_batch(p, 4, 30, seed=2))
+        losses.append([float(tr.train_step(b).cpu()[0]) for _ in range(3)])
+    assert losses[0] == losses[1]
