@@ -91,7 +91,7 @@ _SIGS = {
     "erc_axpy_mask": (C.c_int, [_vp, _vp, _i64, _f, _i, _vp, _vp]),
     "erc_dag_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_dag_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
-                                   _vp, _vp, _vp, _i, _vp, _vp]),
+                                   _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "erc_dag_cluster_size": (C.c_int, [_i]),
     "erc_dag_scan_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                    _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -272,10 +272,11 @@ def dag_cluster_size(B):
 
 
 def dag_scan_fwd(Hl, ldh, GI, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_lin, pred, spk, B, T, H1, ldo, Mseq, GH, R, ks,
-                 alpha, cluster=1, cl_state=None):
+                 alpha, cluster=1, cl_state=None, cl_scratch=None):
     _check(lib().erc_dag_scan_fwd(ptr(Hl), ldh, ptr(GI), ptr(W_hh_c), ptr(b_hh_c), ptr(W_ih_p), ptr(b_ih_p), ptr(Wr),
                                   ptr(w_lin), ptr(pred), ptr(spk), B, T, ptr(H1), ldo, ptr(Mseq), ptr(GH), ptr(R),
-                                  ptr(ks), ptr(alpha), cluster, ptr(cl_state), stream()), "erc_dag_scan_fwd")
+                                  ptr(ks), ptr(alpha), cluster, ptr(cl_state), ptr(cl_scratch), stream()),
+           "erc_dag_scan_fwd")
 
 
 def dag_cluster_scratch_floats(B):

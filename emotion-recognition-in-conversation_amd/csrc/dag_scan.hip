@@ -145,6 +145,40 @@ __device__ __forceinline__ void cluster_sync(int* ctr, int target, int* err) {
     __syncthreads();
 }
 
+// Tagged exchange records: a (value, tag) pair in ONE 8-byte write-through store.  A consumer polls the record itself
+// until the tag is the one of the current step, so producing a value and announcing it are the same store: no drain, no
+// counter, no separate data load (the counter scheme above costs ~2.5 us per exchange, this one a store-to-load round
+// trip).  tag = epoch * 1024 + step + 1; the per-dialogue epoch advances with every launch, so records left by the
+// previous launch never match.  Records are reused every step: a member can only produce step i+1 of an exchange after
+// it has consumed, from every member, the other exchange of step i -- which each member produces only after consuming
+// this exchange of step i.
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 ld64_sc1(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_tagged(u64* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// NV records rec[0 .. NV) (indices idx[u], clamped duplicates allowed): all requested at once, re-polled until tagged
+template <int NV>
+__device__ __forceinline__ void wait_tagged(const u64* base, const int (&idx)[NV], unsigned tag, float (&out)[NV], int* err) {
+    u64 v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) v[u] = ld64_sc1(base + idx[u]);
+    int spins = 0;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        while ((unsigned)(v[u] >> 32) != tag) {
+            ++spins;
+            if (spins > CL_SPIN_LIMIT) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            if ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            v[u] = ld64_sc1(base + idx[u]);
+        }
+        out[u] = __builtin_bit_cast(float, (unsigned)v[u]);
+    }
+}
+
 // Sum each of 16 per-lane partials a[0..15] over the 64 lanes of the wavefront with a halving butterfly: 8 + 4 + 2 + 1
 // exchanges leave every lane with ONE row's partial over 4 lanes, two more finish it -- 17 shuffles instead of the
 // 96 of sixteen separate wave_sum()s.  Afterwards lane l holds the total of row bf16_row(l) (valid in every lane).
@@ -355,6 +389,9 @@ struct DagCluster {
     int* ctr;       // [B] arrival counters, zero at launch
     int* err;       // set to 1 if a poll ran into its bound
     float* scratch; // backward only: [B][2][P][320] partial vectors
+    u64* xg;        // [B][1800] tagged gate pre-activations of the current step
+    u64* xr;        // [B][608]  tagged relation row (600) + key score of the current step
+    int* epoch;     // [B] launches seen so far (tags of different launches never collide)
 };
 
 // workgroup id -> (dialogue, member): the members of a dialogue get ids that are equal mod 8, i.e. the same XCD under
@@ -378,10 +415,27 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
     const float* w_q = p.w_lin;
     const float* w_k = p.w_lin + HID;
     const float b_lin = p.w_lin[2 * HID];
-    int* const ctr = cl.ctr + b;
+    const unsigned ep = (unsigned)cl.epoch[b] + 1u;      // read by every member before anything is exchanged
+    u64* const xg = cl.xg + (int64_t)b * 2 * G3;
+    u64* const xr = cl.xr + (int64_t)b * 608;
     const int g_lo = mem * G3 / P, g_hi = (mem + 1) * G3 / P;              // rows of each 900-row gate matrix
     const int r_lo = mem * 2 * HID / P, r_hi = (mem + 1) * 2 * HID / P;    // rows of Wr
-    int phase = 0;
+
+    // consume the relation row / key score of step j from the exchange records (every member writes the full row to
+    // R: later steps then read rows this member has stored itself, with plain loads)
+    auto take_row = [&](int j) {
+        const unsigned tag = ep * 1024u + (unsigned)j + 1u;
+        const int idx[2] = {tid, min(tid + CNT, 2 * HID)};
+        float v[2];
+        wait_tagged<2>(xr, idx, tag, v, cl.err);
+        float* rrow = p.R + ((int64_t)b * T + j) * 2 * HID;
+        rrow[tid] = v[0];
+        if (tid + CNT < 2 * HID) rrow[tid + CNT] = v[1];
+        if (tid + CNT == 2 * HID) {
+            s_ks[j] = v[1];
+            if (mem == 0) p.ks[(int64_t)b * T + j] = v[1];
+        }
+    };
 
     for (int i = 0; i < T; ++i) {
         const int64_t row = (int64_t)b * T + i;
@@ -394,7 +448,7 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
 #pragma unroll
             for (int u = 0; u < 6; ++u) gi_r[u] = gi[u * HID + tid];
         }
-        if (i > 0 && tid == CNT - 1) s_ks[i - 1] = ld_sc1(p.ks + row - 1);
+        if (i > 0) take_row(i - 1);
         __syncthreads();
         // ---- A: attention over the DAG predecessors [lo, i-1] (every member; R / ks come from all members: sc1 loads)
         int lo = 0, n = 0;
@@ -434,7 +488,7 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int tj = lo + min(j0 + u, n - 1);
-                        rv[u] = ld_sc1(p.R + ((int64_t)b * T + tj) * 2 * HID + (s_spk[tj] == si ? 0 : HID) + tid);
+                        rv[u] = p.R[((int64_t)b * T + tj) * 2 * HID + (s_spk[tj] == si ? 0 : HID) + tid];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) m += (j0 + u < n ? s_alpha[j0 + u] : 0.f) * rv[u];
@@ -451,14 +505,22 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
         float* gh = p.GH + row * 2 * G3;
         if (i > 0) {
             const int gn = g_hi - g_lo;   // this member's rows of each of the two 900-row matrices: one virtual row space
+            const unsigned tag = ep * 1024u + (unsigned)i + 1u;
             matvec16<CNW>(2 * gn, v_m, lane, wave,
                      [&](int r) { return (r < gn ? p.W_hh_c + (int64_t)(g_lo + r) * HID : p.W_ih_p + (int64_t)(g_lo + r - gn) * HID); },
                      [&](int r, float t) {
-                         if (r < gn) st_sc1(gh + g_lo + r, t + p.b_hh_c[g_lo + r]);
-                         else st_sc1(gh + G3 + g_lo + r - gn, t + p.b_ih_p[g_lo + r - gn]);
+                         const int e = r < gn ? g_lo + r : G3 + g_lo + r - gn;
+                         const float v = t + (r < gn ? p.b_hh_c[g_lo + r] : p.b_ih_p[g_lo + r - gn]);
+                         st_tagged(xg + e, v, tag);
+                         gh[e] = v;                       // saved for the backward (each member its rows)
                      });
-            cluster_sync(ctr, P * (++phase), cl.err);
-            for (int r = tid; r < 2 * G3; r += CNT) gates[r] = ld_sc1(gh + r);
+            {
+                const int idx[4] = {tid, tid + CNT, tid + 2 * CNT, min(tid + 3 * CNT, 2 * G3 - 1)};
+                float v[4];
+                wait_tagged<4>(xg, idx, tag, v, cl.err);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gates[idx[u]] = v[u];
+            }
         } else {
             for (int r = tid; r < G3; r += CNT) {
                 gates[r] = p.b_hh_c[r];
@@ -483,14 +545,18 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
         }
         __syncthreads();
         // ---- D: this member's rows of the relation transforms; the key score by the last member
-        matvec16<CNW>(r_hi - r_lo, v_h, lane, wave, [&](int r) { return p.Wr + (int64_t)(r_lo + r) * HID; },
-                 [&](int r, float t) { st_sc1(p.R + row * 2 * HID + r_lo + r, t); });
-        if (mem == P - 1 && wave == CNW - 1) {
-            const float a = wave_sum(dot300(w_k, load_vec300(v_h, lane), lane));
-            if (lane == 0) st_sc1(p.ks + row, a);
+        {
+            const unsigned tag = ep * 1024u + (unsigned)i + 1u;
+            matvec16<CNW>(r_hi - r_lo, v_h, lane, wave, [&](int r) { return p.Wr + (int64_t)(r_lo + r) * HID; },
+                     [&](int r, float t) { st_tagged(xr + r_lo + r, t, tag); });
+            if (mem == P - 1 && wave == CNW - 1) {
+                const float a = wave_sum(dot300(w_k, load_vec300(v_h, lane), lane));
+                if (lane == 0) st_tagged(xr + 2 * HID, a, tag);
+            }
         }
-        if (i + 1 < T) cluster_sync(ctr, P * (++phase), cl.err);   // R / ks of this step visible to every member
     }
+    take_row(T - 1);   // the last row still has to reach R (the backward reads it)
+    if (mem == 0 && tid == 0) cl.epoch[b] = (int)ep;
 }
 
 // ----------------------------------------------------------------------------- backward scan
@@ -861,10 +927,20 @@ extern "C" int erc_dag_cluster_size(int B) {
     return P < 2 ? 1 : P;
 }
 
+// cluster scratch (floats): [B][2][8][320] backward partial vectors | [B][1800] + [B][608] 8-byte exchange records
+static inline int64_t cl_partials_floats(int B) { return (int64_t)B * 2 * 8 * 320; }
+extern "C" int64_t erc_dag_cluster_scratch_floats(int B) { return cl_partials_floats(B) + 2 * ((int64_t)B * 2 * G3 + (int64_t)B * 608); }
+static inline DagCluster make_cluster(int cluster, int B, int32_t* cl_state, float* cl_scratch) {
+    // cl_state: [0] error flag | [1, 1+B) arrival counters | [1+B, 1+2B) launch epochs
+    u64* rec = reinterpret_cast<u64*>(cl_scratch + cl_partials_floats(B));
+    return DagCluster{cluster, cl_state + 1, cl_state, cl_scratch, rec, rec + (int64_t)B * 2 * G3, cl_state + 1 + B};
+}
+
 extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const float* W_hh_c, const float* b_hh_c,
                                 const float* W_ih_p, const float* b_ih_p, const float* Wr, const float* w_lin,
                                 const int32_t* pred, const int32_t* spk, int B, int T, float* H1, int ldo, float* Mseq,
-                                float* GH, float* R, float* ks, float* alpha, int cluster, int32_t* cl_state, void* stream) {
+                                float* GH, float* R, float* ks, float* alpha, int cluster, int32_t* cl_state,
+                                float* cl_scratch, void* stream) {
     ERC_REQUIRE(Hl && GI && W_hh_c && b_hh_c && W_ih_p && b_ih_p && Wr && w_lin && pred && spk && H1 && Mseq && GH &&
                     R && ks && alpha,
                 "dag_scan_fwd: null pointer");
@@ -873,19 +949,15 @@ extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const
     if (cluster <= 1) {
         hipLaunchKernelGGL(dag_scan_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
     } else {
-        ERC_REQUIRE(cl_state && cluster <= 16 && (int64_t)B * cluster <= 256,
-                    "dag_scan_fwd: cluster=%d with B=%d (needs cl_state, cluster <= 16, B * cluster <= 256)", cluster, B);
-        // cl_state: [0] error flag, [1 .. B] arrival counters (zeroed here, on the stream)
-        hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
-        ERC_REQUIRE(e == hipSuccess, "dag_scan_fwd: memset failed: %s", hipGetErrorString(e));
-        DagCluster cl{cluster, cl_state + 1, cl_state, nullptr};
+        ERC_REQUIRE(cl_state && cl_scratch && cluster <= 8 && (int64_t)B * cluster <= 256 && ((uintptr_t)cl_scratch & 7) == 0,
+                    "dag_scan_fwd: cluster=%d with B=%d (needs cl_state, 8-byte aligned cl_scratch, cluster <= 8, B * cluster <= 256)",
+                    cluster, B);
+        const DagCluster cl = make_cluster(cluster, B, cl_state, cl_scratch);   // the forward exchanges through tagged records only
         hipLaunchKernelGGL(dag_scan_fwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
     }
     ERC_LAUNCH_CHECK("dag_scan_fwd");
     return ERC_OK;
 }
-
-extern "C" int64_t erc_dag_cluster_scratch_floats(int B) { return (int64_t)B * 2 * 16 * 320; }
 
 extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
                                 const float* R, const float* alpha, const float* H1, int ldo, const float* W_hh_c,
@@ -902,11 +974,12 @@ extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const
     if (cluster <= 1) {
         hipLaunchKernelGGL(dag_scan_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
     } else {
-        ERC_REQUIRE(cl_state && cl_scratch && cluster <= 16 && (int64_t)B * cluster <= 256,
-                    "dag_scan_bwd: cluster=%d with B=%d (needs cl_state, cl_scratch, cluster <= 16, B * cluster <= 256)", cluster, B);
+        ERC_REQUIRE(cl_state && cl_scratch && cluster <= 8 && (int64_t)B * cluster <= 256 && ((uintptr_t)cl_scratch & 7) == 0,
+                    "dag_scan_bwd: cluster=%d with B=%d (needs cl_state, 8-byte aligned cl_scratch, cluster <= 8, B * cluster <= 256)",
+                    cluster, B);
         hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
         ERC_REQUIRE(e == hipSuccess, "dag_scan_bwd: memset failed: %s", hipGetErrorString(e));
-        DagCluster cl{cluster, cl_state + 1, cl_state, cl_scratch};
+        const DagCluster cl = make_cluster(cluster, B, cl_state, cl_scratch);
         hipLaunchKernelGGL(dag_scan_bwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
     }
     ERC_LAUNCH_CHECK("dag_scan_bwd");

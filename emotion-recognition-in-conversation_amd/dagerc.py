@@ -106,8 +106,8 @@ class DAGERCModule(nn.Module):
         # P workgroups per dialogue in the recurrence kernels (csrc/dag_scan.hip, cluster mode); ERC_DAG_CLUSTER overrides
         import os
         ws["cluster"] = min(int(os.environ.get("ERC_DAG_CLUSTER", capi.dag_cluster_size(B))), capi.dag_cluster_size(B))
-        ws["cl_state"] = i32(B + 1)
-        ws["cl_scratch"] = f32(capi.dag_cluster_scratch_floats(B))
+        ws["cl_state"] = i32(2 * B + 1)
+        ws["cl_scratch"] = torch.zeros(capi.dag_cluster_scratch_floats(B), dtype=torch.float32, device=device)
         ws["dR"] = [ws["zero"][l, :BT * 2 * HID].view(BT, 2 * HID) for l in range(L)]
         ws["dks"] = [ws["zero"][l, BT * 2 * HID:] for l in range(L)]
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
@@ -163,7 +163,8 @@ class DAGERCModule(nn.Module):
             linear_fwd(pl, Hl, W5, None, w["Whoist"], w["bhoist"], ws["GI"][l], 6 * HID, BT, 6 * HID, HID)
             capi.dag_scan_fwd(Hl, W5, ws["GI"][l], w["W_hh_c"], w["b_hh_c"], w["W_ih_p"], w["b_ih_p"], w["Wr"],
                               w["w_lin"], ws["pred"], ws["spk"], B, T, H1, W5, ws["Mseq"][l], ws["GH"][l], ws["R"][l],
-                              ws["ks"][l], ws["alpha"][l], cluster=ws["cluster"], cl_state=ws["cl_state"])
+                              ws["ks"][l], ws["alpha"][l], cluster=ws["cluster"], cl_state=ws["cl_state"],
+                              cl_scratch=ws["cl_scratch"])
         # head: Y1 = relu([Hall | x] W0^T + b0) as two GEMMs into one slab set
         W0 = fp.w("out_mlp.0.weight")
         Sa = pl.split_for(BT, HID, W5)

@@ -348,20 +348,22 @@ int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_
  * cluster = P > 1: P cooperating workgroups per dialogue (each streams 1/P of the weight rows per step; results
  * exchanged through GH / R / ks with write-through stores and a per-dialogue arrival counter).  P <= 8 and
  * B * P <= 224 (all workgroups must be resident at once: erc_dag_cluster_size(B) gives the largest legal P);
- * cl_state: B + 1 int32 of scratch -- [0] is set to 1 if a member timed out waiting (the result is then invalid),
- * the caller zero-fills it once and may check it after the step.  cluster <= 1: one workgroup per dialogue. */
+ * cl_state: 2 B + 1 int32 -- [0] is set to 1 if a member timed out waiting (the result is then invalid), then B
+ * arrival counters and B launch epochs; cl_scratch: erc_dag_cluster_scratch_floats(B) floats, 8-byte aligned (partial
+ * vectors of the backward, tagged exchange records).  The caller zero-fills both ONCE and may check cl_state[0]
+ * after a step.  cluster <= 1: one workgroup per dialogue. */
 int erc_dag_cluster_size(int B);
 int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
                      const float* W_hh_c, const float* b_hh_c, const float* W_ih_p, const float* b_ih_p,
                      const float* Wr, const float* w_lin, const int32_t* pred, const int32_t* spk, int B, int T,
                      float* H1, int ldo, float* Mseq, float* GH, float* R, float* ks, float* alpha,
-                     int cluster, int32_t* cl_state, void* stream);
+                     int cluster, int32_t* cl_state, float* cl_scratch, void* stream);
 /* Reverse scan.  dH1 = complete gradient wrt the layer outputs.  Writes the gate gradients DGI / DGH
  * [B*T,1800] (weight gradients are then plain GEMMs: d[W_ih_c;W_hh_p] = DGI^T H_l, d[W_hh_c;W_ih_p] = DGH^T Mseq,
  * d[Wr0;Wr1] = dR^T H1, dH_l += DGI [W_ih_c;W_hh_p]); accumulates dR [B*T,600] / dks [B*T] (caller zero-fills),
  * ADDS the direct gradient wrt H_l into dHl, and writes the per-dialogue partial gradient of gather.linear
  * to dlin [B,601]. */
-/* (cluster / cl_state as in erc_dag_scan_fwd; cl_scratch: erc_dag_cluster_scratch_floats(B) floats for the partial vectors) */
+/* (cluster / cl_state / cl_scratch as in erc_dag_scan_fwd) */
 int64_t erc_dag_cluster_scratch_floats(int B);
 int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
                      const float* R, const float* alpha, const float* H1, int ldo,
