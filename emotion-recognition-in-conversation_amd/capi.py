@@ -95,7 +95,7 @@ _SIGS = {
     "erc_dag_cluster_size": (C.c_int, [_i]),
     "erc_dag_scan_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                    _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
-    "erc_dag_cluster_scratch_floats": (C.c_int64, [_i]),
+    "erc_dag_cluster_scratch_floats": (C.c_int64, [_i, _i]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -279,8 +279,8 @@ def dag_scan_fwd(Hl, ldh, GI, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_lin, pred, s
            "erc_dag_scan_fwd")
 
 
-def dag_cluster_scratch_floats(B):
-    return int(lib().erc_dag_cluster_scratch_floats(B))
+def dag_cluster_scratch_floats(B, T):
+    return int(lib().erc_dag_cluster_scratch_floats(B, T))
 
 
 def dag_scan_bwd(Hl, ldh, GI, GH, Mseq, R, alpha, H1, ldo, W_hh_c, W_ih_p, Wr, w_lin, pred, spk, B, T, dH1, ldd, dHl,

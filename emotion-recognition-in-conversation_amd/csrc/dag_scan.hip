@@ -392,6 +392,8 @@ struct DagCluster {
     u64* xg;        // [B][1800] tagged gate pre-activations of the current step
     u64* xr;        // [B][608]  tagged relation row (600) + key score of the current step
     int* epoch;     // [B] launches seen so far (tags of different launches never collide)
+    u64* xp;        // backward: [B][2][8][320] tagged partial vectors
+    float* priv;    // backward: [B][7][T][601] private dR | dks copies of the members > 0 (zero at launch)
 };
 
 // workgroup id -> (dialogue, member): the members of a dialogue get ids that are equal mod 8, i.e. the same XCD under
@@ -738,18 +740,24 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
     const float* w_q = p.w_lin;
     const float* w_k = p.w_lin + HID;
     float dwq = 0.f, dwk = 0.f, dbl = 0.f;
-    int* const ctr = cl.ctr + b;
     const int g_lo = mem * G3 / P, g_hi = (mem + 1) * G3 / P;
     const int r_lo = mem * 2 * HID / P, r_hi = (mem + 1) * 2 * HID / P;
-    const int c_lo = mem * HID / P, c_hi = (mem + 1) * HID / P;      // columns of dR this member accumulates
-    float* const sc0 = cl.scratch + ((int64_t)b * 2 + 0) * P * 320;
-    float* const sc1_ = cl.scratch + ((int64_t)b * 2 + 1) * P * 320;
-    int phase = 0;
+    const unsigned ep = (unsigned)cl.epoch[b] + 1u;
+    // partial-vector exchange records [b][phase][member][320]
+    u64* const xp0 = cl.xp + ((int64_t)b * 2 + 0) * 8 * 320;
+    u64* const xp1 = cl.xp + ((int64_t)b * 2 + 1) * 8 * 320;
+    // The accumulators dR / dks receive, at every step, updates that depend only on replicated quantities (alpha, dM):
+    // EVERY member applies all of them to a copy of its own (member 0: the caller's buffers, which the weight-gradient
+    // products read afterwards; members > 0: zero-filled scratch), so no exchange is needed for them at all.
+    float* const dR_my = mem == 0 ? p.dR + (int64_t)b * T * 2 * HID
+                                  : cl.priv + ((int64_t)b * 7 + (mem - 1)) * (int64_t)T * (2 * HID + 1);
+    float* const dks_my = mem == 0 ? p.dks + (int64_t)b * T : dR_my + (int64_t)T * 2 * HID;
 
     for (int i = T - 1; i >= 0; --i) {
         const int64_t row = (int64_t)b * T + i;
         // ---- 1: total gradient wrt h1_i = dH1_i + Wr^T dR_i + w_k dks_i
-        for (int r = tid; r < 2 * HID; r += CNT) v_in[r] = ld_sc1(p.dR + row * 2 * HID + r);
+        const unsigned tag = ep * 1024u + (unsigned)i + 1u;
+        for (int r = tid; r < 2 * HID; r += CNT) v_in[r] = dR_my[(int64_t)i * 2 * HID + r];
         float gi_r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gh_r[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dh1_r = 0.f, h1_r = 0.f;
         if (tid < HID) {   // operands of the later phases of this step: requested now
             v_x[tid] = p.Hl[row * p.ldh + tid];
@@ -768,14 +776,18 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
             store_vec300(part[wave], acc, lane);
         }
         __syncthreads();
-        reduce_wave_partials<CNW>(part, sc0 + mem * 320, tid);
-        cluster_sync(ctr, P * (++phase), cl.err);
-        const float dks_i = ld_sc1(p.dks + row);
+        const float dks_i = dks_my[i];
         if (tid < HID) {
-            float g = dh1_r + w_k[tid] * dks_i;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < CNW; ++w) s += part[w][tid];
+            st_tagged(xp0 + mem * 320 + tid, s, tag);
+            int idx[8];
             float pm[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) pm[m] = ld_sc1(sc0 + min(m, P - 1) * 320 + tid);   // all in flight (P <= 8)
+            for (int m = 0; m < 8; ++m) idx[m] = min(m, P - 1) * 320 + tid;
+            wait_tagged<8>(xp0, idx, tag, pm, cl.err);
+            float g = dh1_r + w_k[tid] * dks_i;
 #pragma unroll
             for (int m = 0; m < 8; ++m) g += m < P ? pm[m] : 0.f;
             v_g[tid] = g;
@@ -829,13 +841,17 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
             store_vec300(part[wave], acc, lane);
         }
         __syncthreads();
-        reduce_wave_partials<CNW>(part, sc1_ + mem * 320, tid);
-        cluster_sync(ctr, P * (++phase), cl.err);
         if (tid < HID) {
-            float d = v_dm[tid];
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < CNW; ++w) s += part[w][tid];
+            st_tagged(xp1 + mem * 320 + tid, s, tag);
+            int idx[8];
             float pm[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) pm[m] = ld_sc1(sc1_ + min(m, P - 1) * 320 + tid);
+            for (int m = 0; m < 8; ++m) idx[m] = min(m, P - 1) * 320 + tid;
+            wait_tagged<8>(xp1, idx, tag, pm, cl.err);
+            float d = v_dm[tid];
 #pragma unroll
             for (int m = 0; m < 8; ++m) d += m < P ? pm[m] : 0.f;
             v_dm[tid] = d;
@@ -864,10 +880,7 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
             for (int j = lane; j < n; j += 64) {
                 const float ds = s_al[j] * (s_da[j] - t);
                 dq += ds;
-                if (mem == 0) {
-                    float* q = p.dks + (int64_t)b * T + lo + j;
-                    st_sc1(q, ld_sc1(q) + ds);
-                }
+                dks_my[lo + j] += ds;
             }
             dq = wave_sum(dq);
             if (lane == 0) s_dqs = dq;
@@ -876,20 +889,18 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
         if (tid < HID) {
             const float dq = s_dqs;
             const float dm = v_dm[tid];
-            if (tid >= c_lo && tid < c_hi) {
-                for (int j0 = 0; j0 < n; j0 += 8) {  // dV_j = alpha_j dM into the relation slot that was read; 8 rows in flight
-                    float* q[8];
-                    float old[8];
+            for (int j0 = 0; j0 < n; j0 += 8) {  // dV_j = alpha_j dM into the relation slot that was read; 8 rows in flight
+                float* q[8];
+                float old[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int tj = lo + min(j0 + u, n - 1);
-                        q[u] = p.dR + ((int64_t)b * T + tj) * 2 * HID + (s_spk[tj] == si ? 0 : HID) + tid;
-                        old[u] = ld_sc1(q[u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (j0 + u < n) st_sc1(q[u], old[u] + s_al[j0 + u] * dm);
+                for (int u = 0; u < 8; ++u) {
+                    const int tj = lo + min(j0 + u, n - 1);
+                    q[u] = dR_my + (int64_t)tj * 2 * HID + (s_spk[tj] == si ? 0 : HID) + tid;
+                    old[u] = *q[u];
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < n) *q[u] = old[u] + s_al[j0 + u] * dm;
             }
             if (mem == 0) {
                 p.dHl[row * p.lddl + tid] += dq * w_q[tid];
@@ -897,8 +908,9 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
                 if (tid == 0) dbl += dq;
             }
         }
-        cluster_sync(ctr, P * (++phase), cl.err);  // dR / dks updates visible to every member before the earlier steps
+        __syncthreads();  // this member's dR / dks updates are read by its next (earlier) step
     }
+    if (mem == 0 && tid == 0) cl.epoch[b] = (int)ep;
     if (mem == 0 && tid < HID) {
         p.dlin[(int64_t)b * (2 * HID + 1) + tid] = dwq;
         p.dlin[(int64_t)b * (2 * HID + 1) + HID + tid] = dwk;
@@ -927,15 +939,16 @@ extern "C" int erc_dag_cluster_size(int B) {
     return P < 2 ? 1 : P;
 }
 
-// cluster scratch (floats): [B][2][8][320] backward partial vectors | [B][1800] + [B][608] 8-byte exchange records
-static inline int64_t cl_partials_floats(int B) { return (int64_t)B * 2 * 8 * 320; }
-extern "C" int64_t erc_dag_cluster_scratch_floats(int B) { return cl_partials_floats(B) + 2 * ((int64_t)B * 2 * G3 + (int64_t)B * 608); }
+// cluster scratch (floats): [B][1800] + [B][608] forward exchange records (8 bytes each) | [B][2][8][320] backward
+// partial-vector records | [B][7][T][601] private accumulator copies of the backward
+static inline int64_t cl_rec_floats(int B) { return 2 * ((int64_t)B * 2 * G3 + (int64_t)B * 608 + (int64_t)B * 2 * 8 * 320); }
+extern "C" int64_t erc_dag_cluster_scratch_floats(int B, int T) { return cl_rec_floats(B) + (int64_t)B * 7 * T * (2 * HID + 1); }
 static inline DagCluster make_cluster(int cluster, int B, int32_t* cl_state, float* cl_scratch) {
-    // cl_state: [0] error flag | [1, 1+B) arrival counters | [1+B, 1+2B) launch epochs
-    u64* rec = reinterpret_cast<u64*>(cl_scratch + cl_partials_floats(B));
-    return DagCluster{cluster, cl_state + 1, cl_state, cl_scratch, rec, rec + (int64_t)B * 2 * G3, cl_state + 1 + B};
+    // cl_state: [0] error flag | [1, 1+B) arrival counters (unused by the tagged exchanges) | [1+B, 1+2B) launch epochs
+    u64* rec = reinterpret_cast<u64*>(cl_scratch);
+    u64* xg = rec, *xr = xg + (int64_t)B * 2 * G3, *xp = xr + (int64_t)B * 608;
+    return DagCluster{cluster, cl_state + 1, cl_state, cl_scratch, xg, xr, cl_state + 1 + B, xp, cl_scratch + cl_rec_floats(B)};
 }
-
 extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const float* W_hh_c, const float* b_hh_c,
                                 const float* W_ih_p, const float* b_ih_p, const float* Wr, const float* w_lin,
                                 const int32_t* pred, const int32_t* spk, int B, int T, float* H1, int ldo, float* Mseq,
@@ -977,9 +990,9 @@ extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const
         ERC_REQUIRE(cl_state && cl_scratch && cluster <= 8 && (int64_t)B * cluster <= 256 && ((uintptr_t)cl_scratch & 7) == 0,
                     "dag_scan_bwd: cluster=%d with B=%d (needs cl_state, 8-byte aligned cl_scratch, cluster <= 8, B * cluster <= 256)",
                     cluster, B);
-        hipError_t e = hipMemsetAsync(cl_state + 1, 0, sizeof(int32_t) * (size_t)B, (hipStream_t)stream);
-        ERC_REQUIRE(e == hipSuccess, "dag_scan_bwd: memset failed: %s", hipGetErrorString(e));
         const DagCluster cl = make_cluster(cluster, B, cl_state, cl_scratch);
+        hipError_t e = hipMemsetAsync(cl.priv, 0, sizeof(float) * (size_t)B * 7 * T * (2 * HID + 1), (hipStream_t)stream);
+        ERC_REQUIRE(e == hipSuccess, "dag_scan_bwd: memset failed: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(dag_scan_bwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
     }
     ERC_LAUNCH_CHECK("dag_scan_bwd");

@@ -107,7 +107,7 @@ class DAGERCModule(nn.Module):
         import os
         ws["cluster"] = min(int(os.environ.get("ERC_DAG_CLUSTER", capi.dag_cluster_size(B))), capi.dag_cluster_size(B))
         ws["cl_state"] = i32(2 * B + 1)
-        ws["cl_scratch"] = torch.zeros(capi.dag_cluster_scratch_floats(B), dtype=torch.float32, device=device)
+        ws["cl_scratch"] = torch.zeros(capi.dag_cluster_scratch_floats(B, T), dtype=torch.float32, device=device)
         ws["dR"] = [ws["zero"][l, :BT * 2 * HID].view(BT, 2 * HID) for l in range(L)]
         ws["dks"] = [ws["zero"][l, BT * 2 * HID:] for l in range(L)]
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)

@@ -349,8 +349,8 @@ int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_
  * exchanged through GH / R / ks with write-through stores and a per-dialogue arrival counter).  P <= 8 and
  * B * P <= 224 (all workgroups must be resident at once: erc_dag_cluster_size(B) gives the largest legal P);
  * cl_state: 2 B + 1 int32 -- [0] is set to 1 if a member timed out waiting (the result is then invalid), then B
- * arrival counters and B launch epochs; cl_scratch: erc_dag_cluster_scratch_floats(B) floats, 8-byte aligned (partial
- * vectors of the backward, tagged exchange records).  The caller zero-fills both ONCE and may check cl_state[0]
+ * arrival counters and B launch epochs; cl_scratch: erc_dag_cluster_scratch_floats(B, T) floats, 8-byte aligned (tagged
+ * exchange records, private accumulator copies of the backward).  The caller zero-fills both ONCE and may check cl_state[0]
  * after a step.  cluster <= 1: one workgroup per dialogue. */
 int erc_dag_cluster_size(int B);
 int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
@@ -364,7 +364,7 @@ int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
  * ADDS the direct gradient wrt H_l into dHl, and writes the per-dialogue partial gradient of gather.linear
  * to dlin [B,601]. */
 /* (cluster / cl_state / cl_scratch as in erc_dag_scan_fwd) */
-int64_t erc_dag_cluster_scratch_floats(int B);
+int64_t erc_dag_cluster_scratch_floats(int B, int T);
 int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
                      const float* R, const float* alpha, const float* H1, int ldo,
                      const float* W_hh_c, const float* W_ih_p, const float* Wr, const float* w_lin,
