@@ -290,8 +290,10 @@ class COGMENModule(nn.Module):
             W1 = self.w1_shadow if self.w1_shadow is not None else fp.w("rnn.1.weight")
             launch = lambda: capi.gemm_bf16a_stream(x, D, g["node_row"], W1, D, ws["H0"], F, N, F, D,
                                                     bias=fp.w("rnn.1.bias"))
-            name = "gemm_bf16a_stream_kernel<8,%s,*> (input projection, bf16 features)" % (
-                "true" if self.w1_shadow is not None else "false")
+            name = ("gemm_bf16a_persist_kernel (input projection, bf16 features, weights resident in registers)"
+                    if (self.w1_shadow is not None and N >= 1024) else
+                    "gemm_bf16a_stream_kernel<8,%s,6> (input projection, bf16 features)" % (
+                        "true" if self.w1_shadow is not None else "false"))
         else:
             launch = lambda: capi.gemm_f32(x, D, 0, g["node_row"], fp.w("rnn.1.weight"), D, 0, None, ws["H0"], F, N, F, D,
                                            bias=fp.w("rnn.1.bias"))

@@ -11,6 +11,7 @@
 // (t < 4) uses k = kb + 4g + t for BOTH operands, so a lane's four A values are the contiguous A[row][kb+4g..+3]
 // (one float4) and likewise for a K-contiguous B; the sum over t and g covers the 16 k's exactly once.
 #include "erc_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -481,6 +482,90 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16a_stream_kernel(StreamP p) {
         }
 }
 
+// Large row counts (many row groups per CU): persistent variant with the WEIGHTS RESIDENT IN REGISTERS.
+// The streaming kernel above re-reads its 32 x K slice of W for every 32 x 32 output tile through the per-CU L2 path
+// (~70 GB/s): at M = 32 k rows that path, not HBM, sets the time (118 us for 106 MB = 0.9 TB/s).  Here a workgroup of
+// 8 wavefronts splits K once (wavefront w owns the 32-deep K blocks w, w + 8, ...; at most 6), loads the W fragments of
+// FOUR column tiles of its K blocks into registers (6 x 4 fragments = 96 VGPRs; all 7 tiles would spill) and then walks
+// over 16-row groups: per group each lane loads its 6 A fragments -- the only memory traffic --, 24 MFMAs, the 8
+// partial 16 x 64 tiles are summed through LDS, bias / relu, store.  Two workgroups (column tiles 0-3 and 4-6) take the
+// same row groups; their ids are equal mod 8, i.e. they sit on one XCD and the second reader of a feature row hits L2.
+// N <= 112, bf16 W.
+constexpr int PJ_NB = 6;    // K blocks per wavefront (8 wavefronts: K <= 1536)
+constexpr int PJ_NT = 4;    // column tiles of 16 per workgroup
+
+__global__ __launch_bounds__(512) void gemm_bf16a_persist_kernel(StreamP p) {
+    __shared__ float red[8 * PJ_NT * 4 * 64];   // 32 KB: partial tiles of the 8 wavefronts
+    const unsigned short* __restrict__ A = (const unsigned short*)p.A;
+    const unsigned short* __restrict__ W = (const unsigned short*)p.B;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int id = blockIdx.x, half = (id >> 3) & 1, pair = (id & 7) + 8 * (id >> 4), n_pairs = (int)gridDim.x >> 1;
+    const int n_base = half * 16 * PJ_NT;            // first column of this workgroup
+    const int nkb = (p.K + 31) / 32;
+    // ---- this wavefront's K blocks.  A block that would run past K is shifted back to end at K; the k it then
+    //      shares with the previous block are zeroed in the W fragment (K >= 32, K % 4 == 0).
+    int k0[PJ_NB];
+    bf16x8 wf[PJ_NB][PJ_NT];
+#pragma unroll
+    for (int s = 0; s < PJ_NB; ++s) {
+        const int kb = w + 8 * s;
+        const bool live = kb < nkb;
+        const int kstart = kb * 32;
+        k0[s] = live ? min(kstart, p.K - 32) : 0;
+        const int k = k0[s] + 8 * g;                    // this lane's 8 consecutive k
+#pragma unroll
+        for (int nt = 0; nt < PJ_NT; ++nt) {
+            const int n = n_base + 16 * nt + r;
+            const unsigned short* wr = W + (int64_t)min(n, p.N - 1) * p.ldb + k;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(wr), hi = *reinterpret_cast<const bf16x4*>(wr + 4);
+            bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (live && n < p.N && k + j >= kstart) ? v[j] : (short)0;
+            wf[s][nt] = v;
+        }
+    }
+    const int n_rg = (p.M + 15) / 16;
+    for (int rg = pair; rg < n_rg; rg += n_pairs) {
+        const int m = rg * 16 + r, mc = min(m, p.M - 1);
+        const int64_t arow = (p.a_gather ? (int64_t)p.a_gather[mc] : (int64_t)mc) * p.lda;
+        bf16x8 af[PJ_NB];
+#pragma unroll
+        for (int s = 0; s < PJ_NB; ++s) {
+            const unsigned short* ar = A + arow + k0[s] + 8 * g;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(ar), hi = *reinterpret_cast<const bf16x4*>(ar + 4);
+            af[s] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        f32x4 acc[PJ_NT];
+#pragma unroll
+        for (int nt = 0; nt < PJ_NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < PJ_NB; ++s)
+#pragma unroll
+            for (int nt = 0; nt < PJ_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], wf[s][nt], acc[nt], 0, 0, 0);
+        __syncthreads();   // previous group's partials consumed
+#pragma unroll
+        for (int nt = 0; nt < PJ_NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[((w * PJ_NT + nt) * 4 + i) * 64 + lane] = acc[nt][i];
+        __syncthreads();
+        // 16 x 64 outputs over 512 threads: element e = tid + 512 u -> row e / 64, col e % 64
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + 512 * u, row = e >> 6, col = e & 63;
+            const int idx = (((col >> 4) * 4) + (row & 3)) * 64 + 16 * (row >> 2) + (col & 15);
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) sum += red[ww * PJ_NT * 4 * 64 + idx];
+            const int mrow = rg * 16 + row, ncol = n_base + col;
+            if (mrow < p.M && ncol < p.N) {
+                float v = sum + (p.bias ? p.bias[ncol] : 0.f);
+                if (p.act == 1) v = fmaxf(v, 0.f);
+                p.C[(int64_t)mrow * p.ldc + ncol] = v;
+            }
+        }
+    }
+}
+
 bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -570,6 +655,19 @@ extern "C" int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gath
     p.b_vec = w_is_bf16 ? bvec(W, ldw) : (!al16(W) ? 0 : (ldw % 4 == 0 ? 1 : (ldw % 2 == 0 ? 3 : 0)));
     dim3 grid(8 * erc_cdiv(erc_cdiv(M, 32), 8) * erc_cdiv(N, 32), 1, 1);  // see the XCD-aware mapping in the kernel
     hipStream_t st = (hipStream_t)stream;
+    // weights resident in registers, every feature row read once (see the kernel); ERC_PERSIST_MIN_M overrides the
+    // row count from which it is used
+    static int persist_min_m = -1;
+    if (persist_min_m < 0) {
+        const char* e = getenv("ERC_PERSIST_MIN_M");
+        persist_min_m = e ? atoi(e) : 1024;   // measured crossover: the persistent kernel wins from ~2 k rows (6.9 vs 7.1 us) up
+    }
+    if (w_is_bf16 && M >= persist_min_m && N <= 32 * PJ_NT && K >= 32 && K <= 32 * 8 * PJ_NB && K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&
+        ((uintptr_t)X & 7) == 0 && ((uintptr_t)W & 7) == 0) {
+        hipLaunchKernelGGL(gemm_bf16a_persist_kernel, dim3(256), dim3(512), 0, st, p);   // 128 pairs of workgroups
+        ERC_LAUNCH_CHECK("gemm_bf16a_persist");
+        return ERC_OK;
+    }
     // UB = 3 with two workgroups per CU (<= 128 VGPRs) was tried for big grids: it spills (42 VGPRs) and ran 192 vs 118 us at
     // B = 512; with 173 VGPRs and one workgroup per CU 143 us.  The single 6-block batch is kept for every size.
     const bool big = false;

@@ -462,3 +462,20 @@ def test_wgrad_table(capi):
             _close(Cm, ref, tol)
             _close(bo, bref, tol)
             Cm.fill_(float("nan")), bo.fill_(float("nan"))
+
+
+@pytest.mark.parametrize("M,K,N,w_bf16", [(1982, 1380, 100, True), (500, 712, 100, False), (700, 1242, 37, True),
+                                          (9000, 1380, 100, True), (8200, 712, 100, True), (8300, 96, 24, True)])
+def test_gemm_bf16a_projection(capi, M, K, N, w_bf16):
+    """Input projection on a bf16 feature block: C = relu(X[gather] W^T + b), fp32 accumulate.  Small row counts use the
+    streaming kernel, >= 8192 rows (bf16 W) the persistent kernel with the weights resident in registers."""
+    g = torch.Generator().manual_seed(M + K)
+    X = torch.randn(M + 40, K, generator=g).bfloat16()
+    Wf = (torch.randn(N, K, generator=g) / math.sqrt(K))
+    W = Wf.bfloat16() if w_bf16 else Wf
+    b = torch.randn(N, generator=g)
+    idx = torch.randperm(M + 40, generator=g)[:M].int()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    capi.gemm_bf16a_stream(X.to(DEV), K, idx.to(DEV), W.to(DEV), K, out, N, M, N, K, bias=b.to(DEV), act=1)
+    ref = torch.relu(X[idx.long()].double() @ W.bfloat16().double().t() + b.double()).float()
+    _close(out, ref, 2e-3)

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 outputs into the small tracked files under profiles/.
 
     python tools/pmc_summary.py --trace gpurun_out/<dir> --fetch gpurun_out/<dir> --write gpurun_out/<dir> \
-        --tag r01_cogmen_b32_bf16 --kernel gemm_bf16a_stream
+        --tag r01_cogmen_b32_bf16 --kernel gemm_bf16a_persist
 
 * <tag>_kernel_stats.csv : per-kernel calls / average duration (rocprofv3 --kernel-trace --stats)
 * <tag>_pmc.json         : per-launch HBM traffic of the dominant kernel from the FETCH_SIZE / WRITE_SIZE passes.
