@@ -136,6 +136,8 @@ int erc_wgrad_max_k_per_split(void);
 /* Forward input projection on a bf16 feature block: C[M,N] = act(X[gather(m), :K] W[N,K]^T + bias), X bf16,
  * W either fp32 (rounded to bf16 while loaded) or a bf16 shadow copy (w_is_bf16; see erc_adam_step), fp32
  * accumulate (v_mfma_f32_16x16x32_bf16); act 0 | 1 (relu).
+ * With a bf16 shadow, N <= 128, K <= 1536 and M >= 1024 (env ERC_PERSIST_MIN_M) the persistent form runs: one
+ * workgroup per CU keeps its share of W in registers and loops over 16-row groups, every feature row read once.
  * The HBM-dominant kernel of the COGMEN step (nn.Linear(D,100), track_mm/cogmen.py:103-105,147). */
 int erc_gemm_bf16a_stream(const void* X, int ldx, const int32_t* gather, const void* W, int ldw, int w_is_bf16,
                           float* C, int ldc, int M, int N, int K, const float* bias, int act, void* stream);
