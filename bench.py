@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--clock_probe", action="store_true", help="diagnostic: append a clock-probe kernel to the step")
     ap.add_argument("--faithful_dead_encoder", action="store_true",
                     help="COGMEN: also run the reference's dead Transformer encoder every step (SURVEY.md 8a C2 (ii))")
+    ap.add_argument("--chained_encoder", action="store_true",
+                    help="COGMEN: opt-in variant rnn.1(rnn.0(x, padding mask)) -- the encoder is trained (SURVEY.md 8f-4)")
     ap.add_argument("--rehearse_dp", action="store_true",
                     help="diagnostic: run the N>1 step structure (RCCL group, eager exchange + optimizer) on one rank")
     args = ap.parse_args()
@@ -144,6 +146,8 @@ def main():
     plugin = importlib.import_module("track_mm." + args.module)
     if args.faithful_dead_encoder and args.module == "cogmen":
         extra = extra + ["--faithful_dead_encoder"]
+    if args.chained_encoder and args.module == "cogmen":
+        extra = extra + ["--chained_encoder"]
     params = plugin.ParamsType().from_args(["--dataset=" + args.dataset, "--modality=atv", "--compute=" + args.dtype]
                                            + extra)
     params.train.batch_size = args.batch
@@ -255,7 +259,8 @@ def main():
                        "utterances_per_step_per_gpu": n_utt, "global_batch_dialogues": args.batch * world,
                        "parallelism": "dp%d" % world, "hip_graph": use_graph,
                        "features_dtype": args.dtype, "loss": stats[0],
-                       "faithful_dead_encoder": bool(args.faithful_dead_encoder and args.module == "cogmen")},
+                       "faithful_dead_encoder": bool(args.faithful_dead_encoder and args.module == "cogmen"),
+                       "chained_encoder": bool(args.chained_encoder and args.module == "cogmen")},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -30,6 +30,18 @@ _SIGS = {
     "erc_enc_gemm_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "erc_enc_attention": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "erc_enc_add_layernorm": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp]),
+    "erc_enc_gemm_bf16_ex": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _f, _f, _vp,
+                                       C.c_uint64, _vp]),
+    "erc_enc_attention_train": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _f, _vp, C.c_uint64, _vp, _vp]),
+    "erc_enc_attention_bwd": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _f, _vp, C.c_uint64, _vp, _vp]),
+    "erc_enc_add_layernorm_train": (C.c_int, [_vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp, C.c_uint64, _vp, _vp, _vp, _vp,
+                                              _vp]),
+    "erc_enc_layernorm_bwd_blocks": (C.c_int, [_i]),
+    "erc_enc_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, C.c_uint64, _vp, _vp, _vp, _vp]),
+    "erc_enc_transpose_bf16": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "erc_enc_colsum_ws_floats": (_i64, [_i]),
+    "erc_enc_colsum": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_enc_inverse_rows": (C.c_int, [_vp, _i, _vp, _i, _vp]),
     "erc_wgrad_slab_floats": (C.c_int64, []),
     "erc_bn_batch_stats_ws_floats": (C.c_int64, [_i]),
     "erc_bn_batch_stats": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
@@ -469,6 +481,52 @@ def enc_attention(qkv, n_seq, S, D, heads, out):
 
 def enc_add_layernorm(a, b, D, n_rows, gamma, beta, eps, y_f32, y_bf16):
     _call("erc_enc_add_layernorm", a, b, D, n_rows, gamma, beta, float(eps), y_f32, y_bf16)
+
+
+def enc_gemm_bf16_ex(A, lda, W, ldw, bias, C_f32, C_bf16, ldc, M, N, K, relu=0, epilogue=0, mask_src=None, ld_mask=0,
+                     scale=1.0, drop_p=0.0, rng_state=None, rng_stream=0):
+    _call("erc_enc_gemm_bf16_ex", A, lda, W, ldw, bias, C_f32, C_bf16, ldc, M, N, K, relu, epilogue, mask_src, ld_mask,
+          float(scale), float(drop_p), rng_state, rng_stream)
+
+
+def enc_attention_train(qkv, n_seq, S, D, heads, lengths, drop_p, rng_state, rng_stream, out):
+    _call("erc_enc_attention_train", qkv, n_seq, S, D, heads, lengths, float(drop_p), rng_state, rng_stream, out)
+
+
+def enc_attention_bwd(qkv, dout, n_seq, S, D, heads, lengths, drop_p, rng_state, rng_stream, dqkv):
+    _call("erc_enc_attention_bwd", qkv, dout, n_seq, S, D, heads, lengths, float(drop_p), rng_state, rng_stream, dqkv)
+
+
+def enc_add_layernorm_train(a, b, D, n_rows, gamma, beta, eps, drop_p, rng_state, rng_stream, y_f32, y_bf16, saved_sum,
+                            saved_stats):
+    _call("erc_enc_add_layernorm_train", a, b, D, n_rows, gamma, beta, float(eps), float(drop_p), rng_state, rng_stream,
+          y_f32, y_bf16, saved_sum, saved_stats)
+
+
+def enc_layernorm_bwd_blocks(n_rows):
+    return int(lib().erc_enc_layernorm_bwd_blocks(n_rows))
+
+
+def enc_layernorm_bwd(dy_a, dy_a_map, dy_b, saved_sum, saved_stats, gamma, D, n_rows, drop_p, rng_state, rng_stream, ds,
+                      db_bf16, partial):
+    _call("erc_enc_layernorm_bwd", dy_a, dy_a_map, dy_b, saved_sum, saved_stats, gamma, D, n_rows, float(drop_p), rng_state,
+          rng_stream, ds, db_bf16, partial)
+
+
+def enc_transpose_bf16(X, ldx, R, Cn, YT, ldyt, plain=None, ldp=0):
+    _call("erc_enc_transpose_bf16", X, 1 if X.dtype == torch.float32 else 0, ldx, R, Cn, YT, ldyt, plain, ldp)
+
+
+def enc_colsum_ws_floats(Cn):
+    return int(lib().erc_enc_colsum_ws_floats(Cn))
+
+
+def enc_colsum(X, ldx, R, Cn, out, ws):
+    _call("erc_enc_colsum", X, 1 if X.dtype == torch.bfloat16 else 0, ldx, R, Cn, out, ws)
+
+
+def enc_inverse_rows(node_row, N, inv, n_rows):
+    _call("erc_enc_inverse_rows", node_row, N, inv, n_rows)
 
 
 def wgrad_slab_floats():

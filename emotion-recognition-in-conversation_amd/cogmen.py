@@ -73,8 +73,13 @@ class _GNNParams(nn.Module):
 
 
 class COGMENModule(nn.Module):
-    def __init__(self, input_size, hidden_size, num_head, n_speakers, n_classes, compute="f32", seed=1):
+    def __init__(self, input_size, hidden_size, num_head, n_speakers, n_classes, compute="f32", seed=1,
+                 chained_encoder=False):
         super().__init__()
+        # chained_encoder (opt-in): rnn.1(rnn.0(x, key-padding mask)) -- the variant the encoder is
+        # built for -- instead of the reference's rnn.1(x) with rnn.0's output discarded (cogmen.py:145-147)
+        self.chained_encoder = chained_encoder
+        self.enc_train = None
         assert hidden_size == F_HID, "the reference hard-codes 100 (cogmen.py:116-122)"
         self.input_size, self.n_speakers, self.n_classes = input_size, n_speakers, n_classes
         self.compute = compute
@@ -94,7 +99,11 @@ class COGMENModule(nn.Module):
     def live_groups(self):
         g, c = self.gcn, self.cls
         named = lambda mod, pre, names: [(pre + n, getattr(mod, n)) for n in names]
-        return [
+        enc = []
+        if self.chained_encoder:
+            from .encoder import encoder_live_groups
+            enc = encoder_live_groups(self.rnn[0])
+        return enc + [
             [("rnn.1.weight", self.rnn[1].weight)], [("rnn.1.bias", self.rnn[1].bias)],
             named(g.conv1, "gcn.conv1.", ["weight", "root"]), [("gcn.conv1.bias", g.conv1.bias)],
             [("gcn.conv2.lin_query.weight", g.conv2.lin_query.weight), ("gcn.conv2.lin_key.weight", g.conv2.lin_key.weight),
@@ -113,6 +122,9 @@ class COGMENModule(nn.Module):
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
         self.side = SideStream()
         self.w1_shadow = None     # bf16 copy of rnn.1.weight, valid only while an optimizer keeps it in sync
+        if self.chained_encoder:
+            from .encoder import EncoderTrain
+            self.enc_train = EncoderTrain(self.rnn[0], self.flat, device, drop_p=0.5)
         return self
 
     def attach_bf16_shadow(self, optim):
@@ -167,6 +179,10 @@ class COGMENModule(nn.Module):
         x_bf16 = x.dtype == torch.bfloat16
         capi.window_graph_build(text_length, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
                                 B, T, WP, WF, self.n_speakers, N, ws["E"], g)
+        if self.enc_train is not None:      # chained mode: the projection reads the encoder's bf16 output
+            x = self.enc_train.forward(x, text_length, training, self.rng_state)
+            x_bf16 = True
+            ws["x_enc"] = x
         W1 = self.w1_shadow if (x_bf16 and self.w1_shadow is not None) else fp.w("rnn.1.weight")
         linear_fwd(pl, x, D, g["node_row"], W1, fp.w("rnn.1.bias"), ws["H0"], F, N, F, D, x_bf16=x_bf16)
         capi.rgcn_mean_fwd(ws["H0"], F, F, N_REL, N, g, ws["M"], 9 * F, ws["inv_cnt"])
@@ -259,11 +275,21 @@ class COGMENModule(nn.Module):
                             fp.offsets["gcn.conv1.bias"], defer=True)
         capi.rgcn_mean_bwd(ws["dM"], 9 * F, F, N_REL, N, g, ws["inv_cnt"], ws["dH0"], F)
         # input projection (no gradient into the features)
+        if self.enc_train is not None:
+            x, x_bf16 = ws["x_enc"], True
         with self.side.fork():
             linear_wgrad(pl, ws["dH0"], F, x, D, g["node_row"], F, D, N, fp.offsets["rnn.1.weight"],
                          fp.offsets["rnn.1.bias"], x_bf16=x_bf16, defer=True)
         self.side.join()
         pl.reduce_into(ws, fp.grad)
+        if self.enc_train is not None:
+            # d(encoder output) at the valid rows = dH0 W1; the encoder backward reads it through the inverse row map
+            ews = self.enc_train._last
+            if ews.get("dXn") is None or ews["dXn"].shape[0] != N:
+                ews["dXn"] = torch.zeros(N, D, dtype=torch.float32, device=x.device)
+            capi.gemm_f32(ws["dH0"], F, 0, None, fp.w("rnn.1.weight"), D, 1, None, ews["dXn"], D, N, D, F)
+            capi.enc_inverse_rows(g["node_row"], N, ews["inv"], B * T)
+            self.enc_train.backward(ews["dXn"], ews["inv"])
         return ws["stats"]
 
     def sync_buffers(self, optimizer_steps):
@@ -353,12 +379,13 @@ class COGMENTrainer:
         self.model = COGMENModule(input_size=params.hidden_all, hidden_size=100,
                                   num_head=params.get("num_heads", 17), n_speakers=params.n_speakers,
                                   n_classes=params.n_classes, compute=params.get("compute", "f32"),
-                                  seed=params.seed).finalize(self.device)
+                                  seed=params.seed,
+                                  chained_encoder=params.get("chained_encoder", False)).finalize(self.device)
         o = params.optim
         self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.weight_decay,
                                decoupled=(o.name == "AdamW"), seed=params.seed)
         self.model.rng_state = self.optim.rng_state   # dropout offset advances with the optimizer step
-        if self.model.compute == "bf16":
+        if self.model.compute == "bf16" and self.model.enc_train is None:
             self.model.attach_bf16_shadow(self.optim)
         self.class_weight = None
         # faithful-cost mode: also run the reference's dead Transformer encoder on the padded
@@ -387,4 +414,6 @@ class COGMENTrainer:
         stats = self.model.loss_and_grads(batch, self.class_weight)
         scale = all_reduce_grads(self.model.flat)
         self.optim.step(grad_scale=scale)
+        if self.model.enc_train is not None:
+            self.model.enc_train.refresh_shadows()
         return stats

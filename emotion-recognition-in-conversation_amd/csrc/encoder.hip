@@ -28,11 +28,23 @@ struct EgP1 { static constexpr int value = 1; };
 constexpr int EG_BM = 128, EG_BN = 128, EG_BK = 32;
 constexpr int EG_PITCH = 40;   // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
 
+// epilogue extras of the training path: EPI 1 = dropout after the (optional) ReLU, EPI 2 = multiply by
+// (mask_src[row, col] != 0) * scale: the backward of ReLU + dropout, read off the stored forward output
+struct EgEpi {
+    const unsigned short* mask_src;
+    int ld_mask;
+    float scale, drop_p;
+    const uint64_t* rng;
+    uint64_t rng_stream;
+};
+
 // C[M,N] = A[M,K] W[N,K]^T + bias (+ReLU); A, W bf16 with K contiguous (K, lda, ldw multiples of 4); C fp32 and / or bf16
+template <int EPI>
 __global__ __launch_bounds__(512) void enc_gemm_kernel(const unsigned short* __restrict__ A, int lda,
                                                        const unsigned short* __restrict__ W, int ldw,
                                                        const float* __restrict__ bias, float* __restrict__ Cf,
-                                                       unsigned short* __restrict__ Ch, int ldc, int M, int N, int K, int relu) {
+                                                       unsigned short* __restrict__ Ch, int ldc, int M, int N, int K, int relu,
+                                                       EgEpi ep) {
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][EG_BM * EG_PITCH], sB[2][EG_BN * EG_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;   // 8 wavefronts: 4 x 2, each 32 rows x 64 columns (the problem has only ~1 64x64
@@ -94,6 +106,8 @@ __global__ __launch_bounds__(512) void enc_gemm_kernel(const unsigned short* __r
         step(kb, EgP0{});
         if (kb + 1 < nkb) step(kb + 1, EgP1{});
     }
+    uint64_t rng_off = 0, rng_seed = 0;
+    if (EPI == 1) rng_off = ep.rng[0], rng_seed = ep.rng[1] ^ ep.rng_stream;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + 16 * j + r;
@@ -106,6 +120,9 @@ __global__ __launch_bounds__(512) void enc_gemm_kernel(const unsigned short* __r
                 if (row < M && col < N) {
                     float v = acc[i][j][q] + bv;
                     if (relu) v = fmaxf(v, 0.f);
+                    if (EPI == 1)
+                        v = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)N + col) >= ep.drop_p ? v * ep.scale : 0.f;
+                    if (EPI == 2) v = ep.mask_src[(int64_t)row * ep.ld_mask + col] != 0 ? v * ep.scale : 0.f;
                     if (Cf) Cf[(int64_t)row * ldc + col] = v;
                     if (Ch) Ch[(int64_t)row * ldc + col] = f2bf(v);
                 }
@@ -304,9 +321,30 @@ extern "C" int erc_enc_gemm_bf16(const void* A, int lda, const void* W, int ldw,
     ERC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 7) == 0 && ((uintptr_t)W & 7) == 0,
                 "enc_gemm_bf16: K / pitches must be multiples of 4 elements, operands 8-byte aligned");
     dim3 grid(erc_cdiv(N, EG_BN), erc_cdiv(M, EG_BM));
-    hipLaunchKernelGGL(enc_gemm_kernel, grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)A, lda,
-                       (const unsigned short*)W, ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu);
+    hipLaunchKernelGGL(enc_gemm_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)A, lda,
+                       (const unsigned short*)W, ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, EgEpi{});
     ERC_LAUNCH_CHECK("enc_gemm_bf16");
+    return ERC_OK;
+}
+
+extern "C" int erc_enc_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, const float* bias, float* C_f32, void* C_bf16,
+                                    int ldc, int M, int N, int K, int relu, int epilogue, const void* mask_src, int ld_mask,
+                                    float scale, float drop_p, const uint64_t* rng_state, uint64_t rng_stream, void* stream) {
+    ERC_REQUIRE(A && W && (C_f32 || C_bf16) && M > 0 && N > 0 && K > 0, "enc_gemm_bf16_ex: bad arguments");
+    ERC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 7) == 0 && ((uintptr_t)W & 7) == 0,
+                "enc_gemm_bf16_ex: K / pitches must be multiples of 4 elements, operands 8-byte aligned");
+    ERC_REQUIRE(epilogue == 1 ? (rng_state && drop_p > 0.f && drop_p < 1.f) : epilogue == 2 ? (mask_src && ld_mask >= N) : epilogue == 0,
+                "enc_gemm_bf16_ex: epilogue %d", epilogue);
+    EgEpi ep{(const unsigned short*)mask_src, ld_mask, scale, drop_p, rng_state, rng_stream};
+    dim3 grid(erc_cdiv(N, EG_BN), erc_cdiv(M, EG_BM));
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)A, lda, (const unsigned short*)W, ldw,
+                           bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, ep);
+    };
+    if (epilogue == 1) launch(enc_gemm_kernel<1>);
+    else if (epilogue == 2) launch(enc_gemm_kernel<2>);
+    else launch(enc_gemm_kernel<0>);
+    ERC_LAUNCH_CHECK("enc_gemm_bf16_ex");
     return ERC_OK;
 }
 

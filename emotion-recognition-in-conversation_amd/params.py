@@ -72,6 +72,7 @@ class ERCParams:
         self.graph_replay = True       # capture the step in a HIP graph per shape bucket
         self.log_every = 1
         self.faithful_dead_encoder = False   # COGMEN: also run the reference's dead encoder (cost parity, result discarded)
+        self.chained_encoder = False         # COGMEN: rnn.1(rnn.0(x, padding mask)) -- trains the encoder
 
     # ------------------------------------------------------------------ CLI
     def from_args(self, argv=None):

@@ -262,6 +262,47 @@ int erc_enc_attention(const void* qkv, int n_seq, int S, int D, int heads, void*
 int erc_enc_add_layernorm(const float* a, const float* b, int D, int n_rows, const float* gamma, const float* beta,
                           float eps, float* y_f32, void* y_bf16, void* stream);
 
+/* K9, training half (the chained COGMEN variant `transformer_out(encoder(x))` with the key-padding
+ * mask; layer math contrib/nn.py:283-305 in training mode and its backward; csrc/encoder_train.hip).
+ *   erc_enc_gemm_bf16_ex:        erc_enc_gemm_bf16 with an epilogue: 0 none | 1 dropout(drop_p, scale) after the
+ *                                optional ReLU | 2 multiply by (mask_src[row, col] != 0) * scale (backward of
+ *                                ReLU + dropout, read off the stored bf16 forward output).
+ *   erc_enc_attention_train:     attention with key-padding mask (keys >= lengths[seq] masked; lengths may be NULL) and
+ *                                dropout on the probabilities; S <= 128, head dim <= 256; nothing saved.
+ *   erc_enc_attention_bwd:       dqkv (bf16 [n_seq*S, 3D]) from qkv and dout (bf16 [n_seq*S, D]); recomputes the
+ *                                probabilities and the dropout decisions.
+ *   erc_enc_add_layernorm_train: y = LN(a + dropout(b)); saved_sum [n_rows, D] = a + dropout(b), saved_stats = mean
+ *                                [n_rows] | rstd [n_rows].
+ *   erc_enc_layernorm_bwd:       dy = dy_a[dy_a_map ? map[row] : row] (zero where map < 0) + dy_b (nullable);
+ *                                ds fp32 = d(a + dropout(b)); db_bf16 = ds through the dropout mask; partial
+ *                                [erc_enc_layernorm_bwd_blocks(n_rows)][2][D] = per-workgroup (dgamma | dbeta) sums,
+ *                                to be finished with erc_enc_colsum over [blocks, 2D].
+ *   erc_enc_transpose_bf16:      YT[c][r] = bf16(X[r][c]), r < R, zero for R <= r < ldyt (ldyt % 4 == 0); optional
+ *                                plain bf16 copy.  Weight gradients are NT products over the row axis.
+ *   erc_enc_colsum:              out[c] = sum_r X[r][c] (fp32 or bf16 X), fixed summation order; ws:
+ *                                erc_enc_colsum_ws_floats(C) floats.
+ *   erc_enc_inverse_rows:        inv[node_row[i]] = i, -1 elsewhere (inv: n_rows int32). */
+int erc_enc_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, const float* bias, float* C_f32, void* C_bf16,
+                         int ldc, int M, int N, int K, int relu, int epilogue, const void* mask_src, int ld_mask,
+                         float scale, float drop_p, const uint64_t* rng_state, uint64_t rng_stream, void* stream);
+int erc_enc_attention_train(const void* qkv, int n_seq, int S, int D, int heads, const int64_t* lengths, float drop_p,
+                            const uint64_t* rng_state, uint64_t rng_stream, void* out, void* stream);
+int erc_enc_attention_bwd(const void* qkv, const void* dout, int n_seq, int S, int D, int heads, const int64_t* lengths,
+                          float drop_p, const uint64_t* rng_state, uint64_t rng_stream, void* dqkv, void* stream);
+int erc_enc_add_layernorm_train(const float* a, const float* b, int D, int n_rows, const float* gamma, const float* beta,
+                                float eps, float drop_p, const uint64_t* rng_state, uint64_t rng_stream, float* y_f32,
+                                void* y_bf16, float* saved_sum, float* saved_stats, void* stream);
+int erc_enc_layernorm_bwd_blocks(int n_rows);
+int erc_enc_layernorm_bwd(const float* dy_a, const int32_t* dy_a_map, const float* dy_b, const float* saved_sum,
+                          const float* saved_stats, const float* gamma, int D, int n_rows, float drop_p,
+                          const uint64_t* rng_state, uint64_t rng_stream, float* ds, void* db_bf16, float* partial,
+                          void* stream);
+int erc_enc_transpose_bf16(const void* X, int x_is_f32, int ldx, int R, int C, void* YT, int ldyt, void* plain, int ldp,
+                           void* stream);
+int64_t erc_enc_colsum_ws_floats(int C);
+int erc_enc_colsum(const void* X, int x_is_bf16, int ldx, int R, int C, float* out, float* ws, void* stream);
+int erc_enc_inverse_rows(const int32_t* node_row, int N, int32_t* inv, int n_rows, void* stream);
+
 /* Training-mode BatchNorm1d statistics (track_mm/cogmen.py:67): column mean / rstd of x [N,F] into saved[0,F) /
  * saved[F,2F), running_mean / running_var updated with `momentum` (unbiased variance), one launch.
  * ws: erc_bn_batch_stats_ws_floats(F) floats, 8-byte aligned, zero before the first call. */

@@ -40,10 +40,14 @@ class GNN(nn.Module):
 
 class COGMENOracle(nn.Module):
     def __init__(self, input_size, hidden_size=100, num_head=17, n_speakers=2,
-                 n_classes=6, dead_encoder=True):
+                 n_classes=6, dead_encoder=True, chained=False):
         super().__init__()
         self.n_speakers = n_speakers
         self.dead_encoder = dead_encoder
+        # chained: rnn.1(rnn.0(x, src_key_padding_mask)) -- the variant cogmen.py:94-109 builds the encoder for; NOT
+        # what the reference computes ("parity unpinned": checked against torch autograd only)
+        self.chained = chained
+        self.enc_rnd = None      # chained mode: rounding hook of oracle/encoder.py (None: the torch module itself)
         layer = nn.TransformerEncoderLayer(d_model=input_size, nhead=pick_heads(input_size, num_head),
                                            dropout=0.5, batch_first=True)
         encoder = nn.TransformerEncoder(layer, num_layers=2, enable_nested_tensor=False)
@@ -53,6 +57,18 @@ class COGMENOracle(nn.Module):
                                  nn.Linear(100, n_classes))
 
     def forward(self, input_tensor, speaker_tensor, text_length, *args, **kwargs):
+        if self.chained:
+            T = input_tensor.shape[1]
+            pad = torch.arange(T)[None, :] >= text_length[:, None]
+            if self.enc_rnd is None:
+                h0 = self.rnn[1](self.rnn[0](input_tensor, src_key_padding_mask=pad))
+            else:
+                from .encoder import encoder
+                rnd = self.enc_rnd
+                h0 = F.linear(rnd(encoder(input_tensor, self.rnn[0], pad, rnd=rnd)), rnd(self.rnn[1].weight), self.rnn[1].bias)
+            x, edge_index, edge_type, _ = window_graph_loop(h0, text_length, speaker_tensor, 5, 5, self.n_speakers)
+            self.last_graph = (edge_index, edge_type)
+            return self.cls(self.gcn(x, edge_index, edge_type)), x
         node_features = input_tensor
         for mod in self.rnn:  # each module sees the raw input (cogmen.py:146-147)
             if mod is self.rnn[0] and not self.dead_encoder:
