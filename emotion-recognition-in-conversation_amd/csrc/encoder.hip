@@ -9,6 +9,8 @@
 // 97 % of the 95 GFLOP per layer are the four dense products: bf16 operands, fp32 accumulate on
 // v_mfma_f32_16x16x32_bf16, 128 x 128 x 32 workgroup tiles staged through LDS (rows padded to 80 bytes: the 16-byte
 // fragment reads of the 16 lanes r then fall into 16 distinct bank groups), double buffered, 8 wavefronts of 32 x 64.
+#include <stdlib.h>
+
 #include "erc_common.h"
 
 namespace {
@@ -38,73 +40,82 @@ struct EgEpi {
     uint64_t rng_stream;
 };
 
-// C[M,N] = A[M,K] W[N,K]^T + bias (+ReLU); A, W bf16 with K contiguous (K, lda, ldw multiples of 4); C fp32 and / or bf16
-template <int EPI>
-__global__ __launch_bounds__(512) void enc_gemm_kernel(const unsigned short* __restrict__ A, int lda,
-                                                       const unsigned short* __restrict__ W, int ldw,
-                                                       const float* __restrict__ bias, float* __restrict__ Cf,
-                                                       unsigned short* __restrict__ Ch, int ldc, int M, int N, int K, int relu,
-                                                       EgEpi ep) {
+// C[M,N] = A[M,K] W[N,K]^T + bias (+ReLU); A, W bf16 with K contiguous (K, lda, ldw multiples of 4); C fp32 and / or bf16.
+// NW wavefronts per 128 x 128 workgroup tile: 4 (2 x 2 wave tiles of 64 x 64) or 8 (4 x 2 of 32 x 64).
+template <int EPI, int NW>
+__global__ __launch_bounds__(64 * NW) void enc_gemm_kernel(const unsigned short* __restrict__ A, int lda,
+                                                           const unsigned short* __restrict__ W, int ldw,
+                                                           const float* __restrict__ bias, float* __restrict__ Cf,
+                                                           unsigned short* __restrict__ Ch, int ldc, int M, int N, int K, int relu,
+                                                           EgEpi ep) {
+    constexpr int NT = 64 * NW;              // threads
+    constexpr int MI = NW == 4 ? 4 : 2;      // 16-row tiles per wavefront (NJ = 4 column tiles)
+    constexpr int NC = 1024 / NT;            // 8-byte chunks per thread and operand tile (128 rows x 8 chunks)
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][EG_BM * EG_PITCH], sB[2][EG_BN * EG_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int wm = w >> 1, wn = w & 1;   // 8 wavefronts: 4 x 2, each 32 rows x 64 columns (the problem has only ~1 64x64
-                                         // tile per SIMD: smaller wave tiles give the SIMDs several wavefronts to interleave)
+    const int wm = w >> 1, wn = w & 1;
     const int m0 = (int)blockIdx.y * EG_BM, n0 = (int)blockIdx.x * EG_BN;
     const int nkb = (K + EG_BK - 1) / EG_BK;
 
-    // global -> register staging: 128 rows x 8 chunks of 4 bf16 (8 bytes) per operand tile = 4 chunks per thread.
-    // Prefetch distance 2: tile t travels through register set t & 1; while tile kb is multiplied out of LDS, tile
-    // kb + 1 is landing in one register set and tile kb + 2 is being requested into the other.
-    bf16x4 ra[2][2], rb[2][2];
-    auto gload = [&](int kb, bf16x4 (&qa)[2], bf16x4 (&qb)[2]) {
+    // global -> register staging, prefetch distance 2: tile t travels through register set t & 1; while tile kb is
+    // multiplied out of LDS, tile kb + 1 is landing in one register set and tile kb + 2 is being requested into the other.
+    // (The K-tail mask is applied when a tile is stored to LDS, not when it is loaded: masking the loaded value makes
+    //  hipcc wait for the load on the spot.)
+    bf16x4 ra[2][NC], rb[2][NC];
+    auto gload = [&](int kb, bf16x4 (&qa)[NC], bf16x4 (&qb)[NC]) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = tid + 512 * u, row = c >> 3, kc = (c & 7) * 4;
+        for (int u = 0; u < NC; ++u) {
+            const int c = tid + NT * u, row = c >> 3, kc = (c & 7) * 4;
             const int k = kb * EG_BK + kc;
-            const bool kv = k < K;                       // K % 4 == 0: a chunk is valid as a whole
-            const int kcl = kv ? k : 0;
-            const short mk = kv ? (short)-1 : (short)0;
+            const int kcl = k < K ? k : 0;               // K % 4 == 0: a chunk is valid as a whole
+            qa[u] = *reinterpret_cast<const bf16x4*>(A + (int64_t)min(m0 + row, M - 1) * lda + kcl);
+            qb[u] = *reinterpret_cast<const bf16x4*>(W + (int64_t)min(n0 + row, N - 1) * ldw + kcl);
+        }
+    };
+    auto lstore = [&](int buf, int kb, const bf16x4 (&qa)[NC], const bf16x4 (&qb)[NC]) {
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+            const int c = tid + NT * u, row = c >> 3, kc = (c & 7) * 4;
+            const short mk = kb * EG_BK + kc < K ? (short)-1 : (short)0;
             const bf16x4 m4 = {mk, mk, mk, mk};
-            qa[u] = *reinterpret_cast<const bf16x4*>(A + (int64_t)min(m0 + row, M - 1) * lda + kcl) & m4;
-            qb[u] = *reinterpret_cast<const bf16x4*>(W + (int64_t)min(n0 + row, N - 1) * ldw + kcl) & m4;
+            *reinterpret_cast<bf16x4*>(&sA[buf][row * EG_PITCH + kc]) = qa[u] & m4;
+            *reinterpret_cast<bf16x4*>(&sB[buf][row * EG_PITCH + kc]) = qb[u] & m4;
         }
     };
-    auto lstore = [&](int buf, const bf16x4 (&qa)[2], const bf16x4 (&qb)[2]) {
+    f32x4 acc[MI][4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = tid + 512 * u, row = c >> 3, kc = (c & 7) * 4;
-            *reinterpret_cast<bf16x4*>(&sA[buf][row * EG_PITCH + kc]) = qa[u];
-            *reinterpret_cast<bf16x4*>(&sB[buf][row * EG_PITCH + kc]) = qb[u];
-        }
-    };
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Straight-line pipeline: every step issues its loads and its LDS store unconditionally (tiles past the end are
+    // clamped to a valid address and masked to zero when stored; the k-block count is rounded up to even).  A branch
+    // around the loads makes hipcc's wait-count insertion assume the skipping path and drain ALL loads before each
+    // LDS store -- the prefetch then hides nothing.
+    const int nkb2 = (nkb + 1) & ~1;
     gload(0, ra[0], rb[0]);
-    if (nkb > 1) gload(1, ra[1], rb[1]);
-    lstore(0, ra[0], rb[0]);
+    gload(1, ra[1], rb[1]);
+    lstore(0, 0, ra[0], rb[0]);
     __syncthreads();
     auto step = [&](const int kb, auto parity) {
         constexpr int PAR = decltype(parity)::value;     // kb & 1 as a constant: register sets are indexed statically
-        if (kb + 2 < nkb) gload(kb + 2, ra[PAR], rb[PAR]);
-        bf16x8 fa[2], fb[4];
+        gload(kb + 2, ra[PAR], rb[PAR]);
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch at the top of the step
+        bf16x8 fa[MI], fb[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sA[PAR][(wm * 32 + 16 * i + r) * EG_PITCH + 8 * g]);
+        for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sA[PAR][(wm * 16 * MI + 16 * i + r) * EG_PITCH + 8 * g]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sB[PAR][(wn * 64 + 16 * j + r) * EG_PITCH + 8 * g]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        if (kb + 1 < nkb) lstore(PAR ^ 1, ra[PAR ^ 1], rb[PAR ^ 1]);
+        lstore(PAR ^ 1, kb + 1, ra[PAR ^ 1], rb[PAR ^ 1]);
         __syncthreads();
     };
-    for (int kb = 0; kb < nkb; kb += 2) {
+    for (int kb = 0; kb < nkb2; kb += 2) {
         step(kb, EgP0{});
-        if (kb + 1 < nkb) step(kb + 1, EgP1{});
+        step(kb + 1, EgP1{});
     }
     uint64_t rng_off = 0, rng_seed = 0;
     if (EPI == 1) rng_off = ep.rng[0], rng_seed = ep.rng[1] ^ ep.rng_stream;
@@ -113,10 +124,10 @@ __global__ __launch_bounds__(512) void enc_gemm_kernel(const unsigned short* __r
         const int col = n0 + wn * 64 + 16 * j + r;
         const float bv = bias ? bias[min(col, N - 1)] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = m0 + wm * 32 + 16 * i + 4 * g + q;
+                const int row = m0 + wm * 16 * MI + 16 * i + 4 * g + q;
                 if (row < M && col < N) {
                     float v = acc[i][j][q] + bv;
                     if (relu) v = fmaxf(v, 0.f);
@@ -307,6 +318,17 @@ __global__ __launch_bounds__(256) void enc_to_bf16_kernel(const float* __restric
 
 }  // namespace
 
+// Wavefronts per GEMM workgroup: 8 (32 x 64 wave tiles) by default.  4 wavefronts of 64 x 64 read a third less from LDS
+// per flop but leave one wavefront per SIMD and workgroup and measured 10 - 35 % slower on every encoder shape
+// (M = 3520: 231 - 358 against 262 - 414 TFLOP/s); ERC_ENC_GEMM_WAVES=4 selects them.
+static int eg_waves() {
+    static int v = [] {
+        const char* e = getenv("ERC_ENC_GEMM_WAVES");
+        return (e && atoi(e) == 4) ? 4 : 8;
+    }();
+    return v;
+}
+
 extern "C" int erc_enc_to_bf16(const float* x, int64_t n, void* y, void* stream) {
     ERC_REQUIRE(x && y && n > 0, "enc_to_bf16: bad arguments");
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -321,8 +343,12 @@ extern "C" int erc_enc_gemm_bf16(const void* A, int lda, const void* W, int ldw,
     ERC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 7) == 0 && ((uintptr_t)W & 7) == 0,
                 "enc_gemm_bf16: K / pitches must be multiples of 4 elements, operands 8-byte aligned");
     dim3 grid(erc_cdiv(N, EG_BN), erc_cdiv(M, EG_BM));
-    hipLaunchKernelGGL(enc_gemm_kernel<0>, grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)A, lda,
-                       (const unsigned short*)W, ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, EgEpi{});
+    if (eg_waves() == 4)
+        hipLaunchKernelGGL((enc_gemm_kernel<0, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)A, lda,
+                           (const unsigned short*)W, ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, EgEpi{});
+    else
+        hipLaunchKernelGGL((enc_gemm_kernel<0, 8>), grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)A, lda,
+                           (const unsigned short*)W, ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, EgEpi{});
     ERC_LAUNCH_CHECK("enc_gemm_bf16");
     return ERC_OK;
 }
@@ -337,13 +363,20 @@ extern "C" int erc_enc_gemm_bf16_ex(const void* A, int lda, const void* W, int l
                 "enc_gemm_bf16_ex: epilogue %d", epilogue);
     EgEpi ep{(const unsigned short*)mask_src, ld_mask, scale, drop_p, rng_state, rng_stream};
     dim3 grid(erc_cdiv(N, EG_BN), erc_cdiv(M, EG_BM));
+    const int nw = eg_waves();
     auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)A, lda, (const unsigned short*)W, ldw,
-                           bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, ep);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), 0, (hipStream_t)stream, (const unsigned short*)A, lda, (const unsigned short*)W,
+                           ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, ep);
     };
-    if (epilogue == 1) launch(enc_gemm_kernel<1>);
-    else if (epilogue == 2) launch(enc_gemm_kernel<2>);
-    else launch(enc_gemm_kernel<0>);
+    if (nw == 4) {
+        if (epilogue == 1) launch(enc_gemm_kernel<1, 4>);
+        else if (epilogue == 2) launch(enc_gemm_kernel<2, 4>);
+        else launch(enc_gemm_kernel<0, 4>);
+    } else {
+        if (epilogue == 1) launch(enc_gemm_kernel<1, 8>);
+        else if (epilogue == 2) launch(enc_gemm_kernel<2, 8>);
+        else launch(enc_gemm_kernel<0, 8>);
+    }
     ERC_LAUNCH_CHECK("enc_gemm_bf16_ex");
     return ERC_OK;
 }

@@ -58,22 +58,41 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
-// sA[pos][c] = src[pos, c0 + c] (c < 96), zero outside [0, S) x [0, hd)
+// sA[pos][c] = src[pos, c0 + c] (c < 96), zero outside [0, S) x [0, hd).  Loads in batches of 8 per thread, then the 8
+// LDS stores: one element per loop iteration is one exposed L2 round trip per iteration (24 per chunk).
 __device__ __forceinline__ void stage_natural(unsigned short* sA, const unsigned short* src, int ld, int S, int hd, int c0, int n_rows) {
-    for (int idx = threadIdx.x; idx < n_rows * AT_DC; idx += 512) {
-        const int j = idx / AT_DC, c = idx - j * AT_DC;
-        const bool ok = j < S && c0 + c < hd;
-        const unsigned short v = src[(int64_t)min(j, S - 1) * ld + min(c0 + c, hd - 1)];
-        sA[j * AT_KP + c] = v & (ok ? (unsigned short)0xffffu : (unsigned short)0);
+    const int total = n_rows * AT_DC;
+    for (int base = threadIdx.x; base < total; base += 512 * 8) {
+        unsigned short v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = min(base + 512 * u, total - 1), j = idx / AT_DC, c = idx - j * AT_DC;
+            v[u] = src[(int64_t)min(j, S - 1) * ld + min(c0 + c, hd - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + 512 * u, j = idx / AT_DC, c = idx - j * AT_DC;
+            const bool ok = j < S && c0 + c < hd;
+            if (idx < total) sA[j * AT_KP + c] = v[u] & (ok ? (unsigned short)0xffffu : (unsigned short)0);
+        }
     }
 }
 // sA[c][pos] = src[pos, c0 + c] for all 128 positions (zero outside): the contraction runs over positions
 __device__ __forceinline__ void stage_transposed(unsigned short* sA, const unsigned short* src, int ld, int S, int hd, int c0) {
-    for (int idx = threadIdx.x; idx < AT_S * AT_DC; idx += 512) {
-        const int j = idx / AT_DC, c = idx - j * AT_DC;
-        const bool ok = j < S && c0 + c < hd;
-        const unsigned short v = src[(int64_t)min(j, S - 1) * ld + min(c0 + c, hd - 1)];
-        sA[c * AT_PP + j] = v & (ok ? (unsigned short)0xffffu : (unsigned short)0);
+    constexpr int total = AT_S * AT_DC;      // 24 elements per thread
+    for (int base = threadIdx.x; base < total; base += 512 * 8) {
+        unsigned short v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + 512 * u, j = idx / AT_DC, c = idx - j * AT_DC;
+            v[u] = src[(int64_t)min(j, S - 1) * ld + min(c0 + c, hd - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + 512 * u, j = idx / AT_DC, c = idx - j * AT_DC;
+            const bool ok = j < S && c0 + c < hd;
+            sA[c * AT_PP + j] = v[u] & (ok ? (unsigned short)0xffffu : (unsigned short)0);
+        }
     }
 }
 // acc[jt] += F(rows of tile w, head dim) * X(positions, head dim)^T, both operands staged chunk by chunk in natural
@@ -333,44 +352,51 @@ __global__ __launch_bounds__(256) void enc_add_ln_train_kernel(LnP P) {
     }
 }
 
-template <int LN_MAXC>
+// One wavefront per row at a time, two passes over the row (8 columns per lane in flight, no per-row arrays: 65 VGPRs);
+// the gamma / beta column sums of a wavefront's rows accumulate in its private LDS strip and the four strips are added
+// in a fixed order at the end.  HAS_B is a template parameter: with `if (dy_b) dy += dy_b[..]` in the column loop hipcc
+// branches around the load and waits for it on the spot (74 us per launch instead of 30).
+template <int LN_MAXC, bool HAS_B>
 __global__ __launch_bounds__(256) void enc_ln_bwd_kernel(LnP P) {
-    __shared__ float sAcc[2][LN_MAXC * 64];
+    __shared__ float sAcc[4][2][LN_MAXC * 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, D = P.D;
     const float ks = 1.0f / (1.0f - P.drop_p);
     uint64_t off = 0, seed = 0;
     if (P.drop_p > 0.f) off = P.rng[0], seed = P.rng[1] ^ P.rng_stream;
-    float ag[LN_MAXC], ab[LN_MAXC];
 #pragma unroll
-    for (int u = 0; u < LN_MAXC; ++u) ag[u] = 0.f, ab[u] = 0.f;
+    for (int u = 0; u < LN_MAXC; ++u) sAcc[w][0][lane + 64 * u] = 0.f, sAcc[w][1][lane + 64 * u] = 0.f;
     for (int row = (int)blockIdx.x * 4 + w; row < P.n_rows; row += (int)gridDim.x * 4) {
         const float mean = P.stats[row], rstd = P.stats[P.n_rows + row];
         const int src = P.dy_a_map ? P.dy_a_map[row] : row;
         const float am = src >= 0 ? 1.f : 0.f;
-        const int64_t a_row = (int64_t)max(src, 0) * D;
-        float xh[LN_MAXC], gy[LN_MAXC];
+        const float* dya = P.dy_a + (int64_t)max(src, 0) * D;
+        const float* dyb = HAS_B ? P.dy_b + (int64_t)row * D : dya;
+        const float* srow = P.saved_s + (int64_t)row * D;
         float m1 = 0.f, m2 = 0.f;
-#pragma unroll
+#pragma unroll 8
         for (int u = 0; u < LN_MAXC; ++u) {
             const int c = lane + 64 * u, cc = min(c, D - 1);
             const float cm = c < D ? 1.f : 0.f;
-            float dy = P.dy_a[a_row + cc] * am;
-            if (P.dy_b) dy += P.dy_b[(int64_t)row * D + cc];
+            float dy = dya[cc] * am;
+            if (HAS_B) dy += dyb[cc];
             dy *= cm;
-            xh[u] = (P.saved_s[(int64_t)row * D + cc] - mean) * rstd * cm;
-            ag[u] += dy * xh[u];
-            ab[u] += dy;
-            gy[u] = dy * P.gamma[cc];
-            m1 += gy[u];
-            m2 += gy[u] * xh[u];
+            const float xh = (srow[cc] - mean) * rstd * cm;
+            sAcc[w][0][c] += dy * xh;
+            sAcc[w][1][c] += dy;
+            const float gy = dy * P.gamma[cc];
+            m1 += gy;
+            m2 += gy * xh;
         }
         m1 = wave_sum(m1) / (float)D;
         m2 = wave_sum(m2) / (float)D;
-#pragma unroll
+#pragma unroll 8
         for (int u = 0; u < LN_MAXC; ++u) {
-            const int c = lane + 64 * u;
+            const int c = lane + 64 * u, cc = min(c, D - 1);
+            float dy = dya[cc] * am;
+            if (HAS_B) dy += dyb[cc];
+            const float xh = (srow[cc] - mean) * rstd;
+            const float d = rstd * (dy * P.gamma[cc] - m1 - xh * m2);
             if (c < D) {
-                const float d = rstd * (gy[u] - m1 - xh[u] * m2);
                 const int64_t at = (int64_t)row * D + c;
                 P.ds[at] = d;
                 float db = d;
@@ -379,21 +405,10 @@ __global__ __launch_bounds__(256) void enc_ln_bwd_kernel(LnP P) {
             }
         }
     }
-    // the four wavefronts add their column sums in a fixed order
-    for (int ww = 0; ww < 4; ++ww) {
-        if (w == ww) {
-#pragma unroll
-            for (int u = 0; u < LN_MAXC; ++u) {
-                const int c = lane + 64 * u;
-                sAcc[0][c] = (ww ? sAcc[0][c] : 0.f) + ag[u];
-                sAcc[1][c] = (ww ? sAcc[1][c] : 0.f) + ab[u];
-            }
-        }
-        __syncthreads();
-    }
+    __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
-        P.partial[((int64_t)blockIdx.x * 2 + 0) * D + c] = sAcc[0][c];
-        P.partial[((int64_t)blockIdx.x * 2 + 1) * D + c] = sAcc[1][c];
+        P.partial[((int64_t)blockIdx.x * 2 + 0) * D + c] = (sAcc[0][0][c] + sAcc[1][0][c]) + (sAcc[2][0][c] + sAcc[3][0][c]);
+        P.partial[((int64_t)blockIdx.x * 2 + 1) * D + c] = (sAcc[0][1][c] + sAcc[1][1][c]) + (sAcc[2][1][c] + sAcc[3][1][c]);
     }
 }
 
@@ -512,7 +527,7 @@ extern "C" int erc_enc_add_layernorm_train(const float* a, const float* b, int D
     return ERC_OK;
 }
 
-extern "C" int erc_enc_layernorm_bwd_blocks(int n_rows) { return n_rows < 1024 ? (n_rows + 3) / 4 : 256; }
+extern "C" int erc_enc_layernorm_bwd_blocks(int n_rows) { return n_rows < 2048 ? (n_rows + 3) / 4 : 512; }
 
 extern "C" int erc_enc_layernorm_bwd(const float* dy_a, const int32_t* dy_a_map, const float* dy_b, const float* saved_sum,
                                      const float* saved_stats, const float* gamma, int D, int n_rows, float drop_p,
@@ -526,9 +541,16 @@ extern "C" int erc_enc_layernorm_bwd(const float* dy_a, const int32_t* dy_a_map,
     p.stats = const_cast<float*>(saved_stats), p.gamma = gamma, p.ds = ds, p.db = (unsigned short*)db_bf16, p.partial = partial;
     p.rng = rng_state, p.rng_stream = rng_stream, p.D = D, p.n_rows = n_rows, p.drop_p = drop_p;
     const dim3 grid(erc_enc_layernorm_bwd_blocks(n_rows));
-    if (D <= 768) hipLaunchKernelGGL(enc_ln_bwd_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (D <= 1536) hipLaunchKernelGGL(enc_ln_bwd_kernel<24>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(enc_ln_bwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, p); };
+    if (dy_b) {
+        if (D <= 768) launch(enc_ln_bwd_kernel<12, true>);
+        else if (D <= 1536) launch(enc_ln_bwd_kernel<24, true>);
+        else launch(enc_ln_bwd_kernel<32, true>);
+    } else {
+        if (D <= 768) launch(enc_ln_bwd_kernel<12, false>);
+        else if (D <= 1536) launch(enc_ln_bwd_kernel<24, false>);
+        else launch(enc_ln_bwd_kernel<32, false>);
+    }
     ERC_LAUNCH_CHECK("enc_layernorm_bwd");
     return ERC_OK;
 }

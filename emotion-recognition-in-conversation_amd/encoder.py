@@ -63,7 +63,10 @@ class EncoderBlock:
         xf = ws["xf"]
         for L in self.layers:
             capi.enc_gemm_bf16(xh, D, L["Win"], D, L["b_in"], None, ws["qkv"], 3 * D, M, 3 * D, D)
-            capi.enc_attention(ws["qkv"], B, T, D, L["heads"], ws["att"])
+            if T <= 128:    # matrix-core attention (csrc/encoder_train.hip) without mask / dropout: 41 us against 141 us
+                capi.enc_attention_train(ws["qkv"], B, T, D, L["heads"], None, 0.0, None, 0, ws["att"])
+            else:
+                capi.enc_attention(ws["qkv"], B, T, D, L["heads"], ws["att"])
             capi.enc_gemm_bf16(ws["att"], D, L["Wo"], D, L["bo"], ws["y"], None, D, M, D, D)
             capi.enc_add_layernorm(xf, ws["y"], D, M, L["g1"], L["be1"], L["eps1"], ws["x1f"], ws["x1h"])
             capi.enc_gemm_bf16(ws["x1h"], D, L["W1"], D, L["b1"], None, ws["hid"], self.ffn, M, self.ffn, D, relu=1)
