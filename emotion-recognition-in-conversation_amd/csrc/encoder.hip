@@ -27,8 +27,11 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_c
 
 struct EgP0 { static constexpr int value = 0; };
 struct EgP1 { static constexpr int value = 1; };
-constexpr int EG_BM = 128, EG_BN = 128, EG_BK = 32;
-constexpr int EG_PITCH = 40;   // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
+constexpr int EG_BM = 128, EG_BN = 128, EG_BK = 64;
+constexpr int EG_PITCH = 64;   // bf16 elements per LDS row: unpadded, chunk positions XOR-swizzled (see the kernel)
+constexpr int EG_TILE = 128 * EG_PITCH;            // elements of one operand tile
+constexpr int EG_LDS_BYTES = 4 * EG_TILE * 2;     // A, B x 2 buffers = 65 536 bytes (dynamic)
+typedef bf16x8 bf16x8_a8 __attribute__((aligned(8)));
 
 // epilogue extras of the training path: EPI 1 = dropout after the (optional) ReLU, EPI 2 = multiply by
 // (mask_src[row, col] != 0) * scale: the backward of ReLU + dropout, read off the stored forward output
@@ -40,58 +43,78 @@ struct EgEpi {
     uint64_t rng_stream;
 };
 
-// C[M,N] = A[M,K] W[N,K]^T + bias (+ReLU); A, W bf16 with K contiguous (K, lda, ldw multiples of 4); C fp32 and / or bf16.
-// NW wavefronts per 128 x 128 workgroup tile: 4 (2 x 2 wave tiles of 64 x 64) or 8 (4 x 2 of 32 x 64).
-template <int EPI, int NW>
-__global__ __launch_bounds__(64 * NW) void enc_gemm_kernel(const unsigned short* __restrict__ A, int lda,
-                                                           const unsigned short* __restrict__ W, int ldw,
-                                                           const float* __restrict__ bias, float* __restrict__ Cf,
-                                                           unsigned short* __restrict__ Ch, int ldc, int M, int N, int K, int relu,
-                                                           EgEpi ep) {
-    constexpr int NT = 64 * NW;              // threads
-    constexpr int MI = NW == 4 ? 4 : 2;      // 16-row tiles per wavefront (NJ = 4 column tiles)
-    constexpr int NC = 1024 / NT;            // 8-byte chunks per thread and operand tile (128 rows x 8 chunks)
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][EG_BM * EG_PITCH], sB[2][EG_BN * EG_PITCH];
+// C[M,N] = A[M,K] W[N,K]^T + bias (+ReLU); A, W bf16 with K contiguous (K, lda, ldw multiples of 4, K >= 8); C fp32 and /
+// or bf16.  128 x 128 x 64 workgroup tiles, 8 wavefronts (4 x 2) of 32 x 64, LDS double buffer (2 x 32 KB, dynamic).
+//  * operand rows are only 8-byte aligned (K = 1380): the 16-byte global loads are issued on 8-byte-aligned addresses
+//    (the hardware takes dword-aligned dwordx4 loads); a chunk that straddles K is loaded 4 elements early and
+//    shifted when it is stored to LDS, so nothing past a row's end is ever read;
+//  * straight-line pipeline, prefetch distance 2 through two register sets: every step issues its loads and its LDS
+//    store unconditionally (tiles past the end are clamped to a valid address and zeroed at the store; the k-block
+//    count is rounded up to even).  Masking the loaded value, or branching around the prefetch, makes hipcc wait for /
+//    drain the loads on the spot;
+//  * 4 wavefronts of 64 x 64 (a third fewer LDS fragment reads per flop) were 10 - 35 % slower on every encoder shape:
+//    one wavefront per SIMD and workgroup does not cover the barrier per k-step.
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void enc_gemm_kernel(const unsigned short* __restrict__ A, int lda,
+                                                       const unsigned short* __restrict__ W, int ldw,
+                                                       const float* __restrict__ bias, float* __restrict__ Cf,
+                                                       unsigned short* __restrict__ Ch, int ldc, int M, int N, int K, int relu,
+                                                       EgEpi ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short eg_lds[];
+    unsigned short* sA[2] = {eg_lds, eg_lds + EG_TILE};
+    unsigned short* sB[2] = {eg_lds + 2 * EG_TILE, eg_lds + 3 * EG_TILE};
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
-    const int m0 = (int)blockIdx.y * EG_BM, n0 = (int)blockIdx.x * EG_BN;
+    // XCD-aware tile order: workgroup id b runs on XCD b % 8 (each XCD has its own L2).  XCD x takes the contiguous run
+    // of tiles [x * per, (x + 1) * per) in row-major (m, n) order, so that the few A row-tiles it touches and W stay in
+    // its L2 instead of every XCD streaming all of A.
+    const int tiles_n = (N + EG_BN - 1) / EG_BN, n_tiles = tiles_n * ((M + EG_BM - 1) / EG_BM);
+    const int per = (n_tiles + 7) / 8;
+    const int tile = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (tile >= n_tiles || ((int)blockIdx.x >> 3) >= per) return;
+    const int m0 = (tile / tiles_n) * EG_BM, n0 = (tile % tiles_n) * EG_BN;
     const int nkb = (K + EG_BK - 1) / EG_BK;
 
-    // global -> register staging, prefetch distance 2: tile t travels through register set t & 1; while tile kb is
-    // multiplied out of LDS, tile kb + 1 is landing in one register set and tile kb + 2 is being requested into the other.
-    // (The K-tail mask is applied when a tile is stored to LDS, not when it is loaded: masking the loaded value makes
-    //  hipcc wait for the load on the spot.)
-    bf16x4 ra[2][NC], rb[2][NC];
-    auto gload = [&](int kb, bf16x4 (&qa)[NC], bf16x4 (&qb)[NC]) {
+    // this thread's two 16-byte chunks of an operand tile (128 rows x 8 chunks of 8 bf16): rows 16 w + sub (+ 8), chunk
+    // lane & 7.  LDS rows are unpadded (128 bytes); chunk c of row q lives at chunk position c ^ ((q >> 1) & 7).  With
+    // that swizzle both the 16-byte fragment reads (lanes r = row, g = chunk) and the tile stores are bank-conflict
+    // free; a padded pitch of 144 bytes measured 37 % of the LDS cycles as bank conflicts (SQ_LDS_BANK_CONFLICT /
+    // SQ_LDS_IDX_ACTIVE) -- ds_read_b128 does not serve its 64 lanes in four groups of 16 consecutive lanes.
+    const int sub = lane >> 3, ck = (lane & 7) * 8;
+    const int crow[2] = {16 * w + sub, 16 * w + sub + 8};
+    const int cpos[2] = {8 * ((lane & 7) ^ ((crow[0] >> 1) & 7)), 8 * ((lane & 7) ^ ((crow[1] >> 1) & 7))};
+    const unsigned short* arow[2] = {A + (int64_t)min(m0 + crow[0], M - 1) * lda, A + (int64_t)min(m0 + crow[1], M - 1) * lda};
+    const unsigned short* brow[2] = {W + (int64_t)min(n0 + crow[0], N - 1) * ldw, W + (int64_t)min(n0 + crow[1], N - 1) * ldw};
+    bf16x8 ra[2][2], rb[2][2];
+    auto gload = [&](int kb, bf16x8 (&qa)[2], bf16x8 (&qb)[2]) {
+        const int k = kb * EG_BK + ck;
+        const int kcl = k + 8 <= K ? k : (k < K ? K - 8 : 0);      // K % 4 == 0: a chunk is whole, half (tail) or absent
 #pragma unroll
-        for (int u = 0; u < NC; ++u) {
-            const int c = tid + NT * u, row = c >> 3, kc = (c & 7) * 4;
-            const int k = kb * EG_BK + kc;
-            const int kcl = k < K ? k : 0;               // K % 4 == 0: a chunk is valid as a whole
-            qa[u] = *reinterpret_cast<const bf16x4*>(A + (int64_t)min(m0 + row, M - 1) * lda + kcl);
-            qb[u] = *reinterpret_cast<const bf16x4*>(W + (int64_t)min(n0 + row, N - 1) * ldw + kcl);
+        for (int u = 0; u < 2; ++u) {
+            qa[u] = *reinterpret_cast<const bf16x8_a8*>(arow[u] + kcl);
+            qb[u] = *reinterpret_cast<const bf16x8_a8*>(brow[u] + kcl);
         }
     };
-    auto lstore = [&](int buf, int kb, const bf16x4 (&qa)[NC], const bf16x4 (&qb)[NC]) {
+    auto lstore = [&](int buf, int kb, const bf16x8 (&qa)[2], const bf16x8 (&qb)[2]) {
+        const int k = kb * EG_BK + ck;
+        const bool full = k + 8 <= K, tail = !full && k < K;       // tail: the valid 4 elements sit in the upper half
+        const short mf = full ? (short)-1 : (short)0, mt = tail ? (short)-1 : (short)0;
+        const bf16x8 m_lo = {mf, mf, mf, mf, mf, mf, mf, mf};
+        const bf16x8 m_tl = {mt, mt, mt, mt, 0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < NC; ++u) {
-            const int c = tid + NT * u, row = c >> 3, kc = (c & 7) * 4;
-            const short mk = kb * EG_BK + kc < K ? (short)-1 : (short)0;
-            const bf16x4 m4 = {mk, mk, mk, mk};
-            *reinterpret_cast<bf16x4*>(&sA[buf][row * EG_PITCH + kc]) = qa[u] & m4;
-            *reinterpret_cast<bf16x4*>(&sB[buf][row * EG_PITCH + kc]) = qb[u] & m4;
+        for (int u = 0; u < 2; ++u) {
+            const bf16x8 sa = __builtin_shufflevector(qa[u], qa[u], 4, 5, 6, 7, 0, 1, 2, 3);
+            const bf16x8 sb = __builtin_shufflevector(qb[u], qb[u], 4, 5, 6, 7, 0, 1, 2, 3);
+            *reinterpret_cast<bf16x8*>(&sA[buf][crow[u] * EG_PITCH + cpos[u]]) = (qa[u] & m_lo) | (sa & m_tl);
+            *reinterpret_cast<bf16x8*>(&sB[buf][crow[u] * EG_PITCH + cpos[u]]) = (qb[u] & m_lo) | (sb & m_tl);
         }
     };
-    f32x4 acc[MI][4];
+    f32x4 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Straight-line pipeline: every step issues its loads and its LDS store unconditionally (tiles past the end are
-    // clamped to a valid address and masked to zero when stored; the k-block count is rounded up to even).  A branch
-    // around the loads makes hipcc's wait-count insertion assume the skipping path and drain ALL loads before each
-    // LDS store -- the prefetch then hides nothing.
     const int nkb2 = (nkb + 1) & ~1;
     gload(0, ra[0], rb[0]);
     gload(1, ra[1], rb[1]);
@@ -101,15 +124,20 @@ __global__ __launch_bounds__(64 * NW) void enc_gemm_kernel(const unsigned short*
         constexpr int PAR = decltype(parity)::value;     // kb & 1 as a constant: register sets are indexed statically
         gload(kb + 2, ra[PAR], rb[PAR]);
         __builtin_amdgcn_sched_barrier(0);               // keep the prefetch at the top of the step
-        bf16x8 fa[MI], fb[4];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(&sA[PAR][(wm * 16 * MI + 16 * i + r) * EG_PITCH + 8 * g]);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 fa[2], fb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(&sB[PAR][(wn * 64 + 16 * j + r) * EG_PITCH + 8 * g]);
+            for (int i = 0; i < 2; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(&sA[PAR][(wm * 32 + 16 * i + r) * EG_PITCH + 8 * ((4 * s2 + g) ^ ((r >> 1) & 7))]);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int j = 0; j < 4; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(&sB[PAR][(wn * 64 + 16 * j + r) * EG_PITCH + 8 * ((4 * s2 + g) ^ ((r >> 1) & 7))]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
         lstore(PAR ^ 1, kb + 1, ra[PAR ^ 1], rb[PAR ^ 1]);
         __syncthreads();
     };
@@ -124,10 +152,10 @@ __global__ __launch_bounds__(64 * NW) void enc_gemm_kernel(const unsigned short*
         const int col = n0 + wn * 64 + 16 * j + r;
         const float bv = bias ? bias[min(col, N - 1)] : 0.f;
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = m0 + wm * 16 * MI + 16 * i + 4 * g + q;
+                const int row = m0 + wm * 32 + 16 * i + 4 * g + q;
                 if (row < M && col < N) {
                     float v = acc[i][j][q] + bv;
                     if (relu) v = fmaxf(v, 0.f);
@@ -318,15 +346,10 @@ __global__ __launch_bounds__(256) void enc_to_bf16_kernel(const float* __restric
 
 }  // namespace
 
-// Wavefronts per GEMM workgroup: 8 (32 x 64 wave tiles) by default.  4 wavefronts of 64 x 64 read a third less from LDS
-// per flop but leave one wavefront per SIMD and workgroup and measured 10 - 35 % slower on every encoder shape
-// (M = 3520: 231 - 358 against 262 - 414 TFLOP/s); ERC_ENC_GEMM_WAVES=4 selects them.
-static int eg_waves() {
-    static int v = [] {
-        const char* e = getenv("ERC_ENC_GEMM_WAVES");
-        return (e && atoi(e) == 4) ? 4 : 8;
-    }();
-    return v;
+// the GEMM's 64 KB of dynamic LDS has to be allowed once per kernel instantiation
+template <typename Kern>
+static bool eg_allow_lds(Kern kern) {
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, EG_LDS_BYTES) == hipSuccess;
 }
 
 extern "C" int erc_enc_to_bf16(const float* x, int64_t n, void* y, void* stream) {
@@ -337,48 +360,37 @@ extern "C" int erc_enc_to_bf16(const float* x, int64_t n, void* y, void* stream)
     return ERC_OK;
 }
 
+static int eg_launch(const void* A, int lda, const void* W, int ldw, const float* bias, float* C_f32, void* C_bf16, int ldc, int M,
+                     int N, int K, int relu, int epilogue, const EgEpi& ep, void* stream, const char* who) {
+    ERC_REQUIRE(A && W && (C_f32 || C_bf16) && M > 0 && N > 0 && K >= 8, "%s: bad arguments (K >= 8)", who);
+    ERC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 7) == 0 && ((uintptr_t)W & 7) == 0,
+                "%s: K / pitches must be multiples of 4 elements, operands 8-byte aligned", who);
+    static const bool ok0 = eg_allow_lds(enc_gemm_kernel<0>), ok1 = eg_allow_lds(enc_gemm_kernel<1>), ok2 = eg_allow_lds(enc_gemm_kernel<2>);
+    ERC_REQUIRE(ok0 && ok1 && ok2, "%s: %d bytes of dynamic LDS refused", who, EG_LDS_BYTES);
+    const dim3 grid(8 * erc_cdiv((int64_t)erc_cdiv(N, EG_BN) * erc_cdiv(M, EG_BM), 8));
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(512), EG_LDS_BYTES, (hipStream_t)stream, (const unsigned short*)A, lda,
+                           (const unsigned short*)W, ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, ep);
+    };
+    if (epilogue == 1) launch(enc_gemm_kernel<1>);
+    else if (epilogue == 2) launch(enc_gemm_kernel<2>);
+    else launch(enc_gemm_kernel<0>);
+    ERC_LAUNCH_CHECK(who);
+    return ERC_OK;
+}
+
 extern "C" int erc_enc_gemm_bf16(const void* A, int lda, const void* W, int ldw, const float* bias, float* C_f32, void* C_bf16,
                                  int ldc, int M, int N, int K, int relu, void* stream) {
-    ERC_REQUIRE(A && W && (C_f32 || C_bf16) && M > 0 && N > 0 && K > 0, "enc_gemm_bf16: bad arguments");
-    ERC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 7) == 0 && ((uintptr_t)W & 7) == 0,
-                "enc_gemm_bf16: K / pitches must be multiples of 4 elements, operands 8-byte aligned");
-    dim3 grid(erc_cdiv(N, EG_BN), erc_cdiv(M, EG_BM));
-    if (eg_waves() == 4)
-        hipLaunchKernelGGL((enc_gemm_kernel<0, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)A, lda,
-                           (const unsigned short*)W, ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, EgEpi{});
-    else
-        hipLaunchKernelGGL((enc_gemm_kernel<0, 8>), grid, dim3(512), 0, (hipStream_t)stream, (const unsigned short*)A, lda,
-                           (const unsigned short*)W, ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, EgEpi{});
-    ERC_LAUNCH_CHECK("enc_gemm_bf16");
-    return ERC_OK;
+    return eg_launch(A, lda, W, ldw, bias, C_f32, C_bf16, ldc, M, N, K, relu, 0, EgEpi{}, stream, "enc_gemm_bf16");
 }
 
 extern "C" int erc_enc_gemm_bf16_ex(const void* A, int lda, const void* W, int ldw, const float* bias, float* C_f32, void* C_bf16,
                                     int ldc, int M, int N, int K, int relu, int epilogue, const void* mask_src, int ld_mask,
                                     float scale, float drop_p, const uint64_t* rng_state, uint64_t rng_stream, void* stream) {
-    ERC_REQUIRE(A && W && (C_f32 || C_bf16) && M > 0 && N > 0 && K > 0, "enc_gemm_bf16_ex: bad arguments");
-    ERC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && ((uintptr_t)A & 7) == 0 && ((uintptr_t)W & 7) == 0,
-                "enc_gemm_bf16_ex: K / pitches must be multiples of 4 elements, operands 8-byte aligned");
     ERC_REQUIRE(epilogue == 1 ? (rng_state && drop_p > 0.f && drop_p < 1.f) : epilogue == 2 ? (mask_src && ld_mask >= N) : epilogue == 0,
                 "enc_gemm_bf16_ex: epilogue %d", epilogue);
-    EgEpi ep{(const unsigned short*)mask_src, ld_mask, scale, drop_p, rng_state, rng_stream};
-    dim3 grid(erc_cdiv(N, EG_BN), erc_cdiv(M, EG_BM));
-    const int nw = eg_waves();
-    auto launch = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), 0, (hipStream_t)stream, (const unsigned short*)A, lda, (const unsigned short*)W,
-                           ldw, bias, C_f32, (unsigned short*)C_bf16, ldc, M, N, K, relu, ep);
-    };
-    if (nw == 4) {
-        if (epilogue == 1) launch(enc_gemm_kernel<1, 4>);
-        else if (epilogue == 2) launch(enc_gemm_kernel<2, 4>);
-        else launch(enc_gemm_kernel<0, 4>);
-    } else {
-        if (epilogue == 1) launch(enc_gemm_kernel<1, 8>);
-        else if (epilogue == 2) launch(enc_gemm_kernel<2, 8>);
-        else launch(enc_gemm_kernel<0, 8>);
-    }
-    ERC_LAUNCH_CHECK("enc_gemm_bf16_ex");
-    return ERC_OK;
+    const EgEpi ep{(const unsigned short*)mask_src, ld_mask, scale, drop_p, rng_state, rng_stream};
+    return eg_launch(A, lda, W, ldw, bias, C_f32, C_bf16, ldc, M, N, K, relu, epilogue, ep, stream, "enc_gemm_bf16_ex");
 }
 
 extern "C" int erc_enc_attention(const void* qkv, int n_seq, int S, int D, int heads, void* out, void* stream) {

@@ -24,3 +24,18 @@ for M, N, K in shapes:
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 20
     print("M=%d N=%d K=%d  %.1f us  %.0f TFLOP/s" % (M, N, K, us, 2.0 * M * N * K / us * 1e-6), flush=True)
+    # the vendor library on the same shape (torch.matmul -> hipBLASLt), for reference only
+    import torch.nn.functional as F
+    c2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    f2 = lambda: torch.matmul(a, w.t(), out=c2)
+    for _ in range(3):
+        f2()
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        for _ in range(20):
+            f2()
+    g2.replay(); torch.cuda.synchronize()
+    e0.record(); g2.replay(); e1.record(); torch.cuda.synchronize()
+    us2 = e0.elapsed_time(e1) * 1e3 / 20
+    print("      hipBLASLt via torch.matmul: %.1f us  %.0f TFLOP/s" % (us2, 2.0 * M * N * K / us2 * 1e-6), flush=True)
