@@ -171,13 +171,22 @@ def main():
         # forward+backward in one graph; the RCCL all-reduce and the optimizer stay eager (2 launches)
         trainer.model.train()
         cw = getattr(trainer, "class_weight", None)
-        fb = (lambda: trainer.model.loss_and_grads(batch, cw)) if args.module in ("cogmen", "dgcn") else \
-            (lambda: trainer.model.loss_and_grads(batch))
+        dead_encoder = getattr(trainer, "encoder", None)            # --faithful_dead_encoder
+        trained_encoder = getattr(trainer.model, "enc_train", None)  # --chained_encoder
+
+        def fb():
+            if dead_encoder is not None:
+                dead_encoder.forward(batch["input_tensor"])
+            if args.module in ("cogmen", "dgcn"):
+                return trainer.model.loss_and_grads(batch, cw)
+            return trainer.model.loss_and_grads(batch)
         fb_g = GraphedStep(fb) if use_graph else fb
 
         def step():
             out = fb_g()
             trainer.optim.step(grad_scale=all_reduce_grads(trainer.model.flat, always=args.rehearse_dp))
+            if trained_encoder is not None:
+                trained_encoder.refresh_shadows()      # bf16 copies of the encoder weights follow the fp32 masters
             return out
 
     def barrier():
