@@ -206,21 +206,19 @@ template <int NWV, typename RowPtr, typename Store>
 __device__ __forceinline__ void matvec16(int n, const float* v_lds, int lane, int wave, RowPtr rowptr, Store store) {
     const Vec300 v = load_vec300(v_lds, lane);
     for (int r0 = 16 * wave; r0 < n; r0 += 16 * NWV) {
+        // all 16 rows of the pass are requested before the first FMA: one round trip per pass instead of two
+        float4 a[16], b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const float* wr = rowptr(min(r0 + u, n - 1));
+            a[u] = *reinterpret_cast<const float4*>(wr + 4 * lane);
+            b[u] = *reinterpret_cast<const float4*>(wr + 256 + 4 * min(lane, 10));
+        }
         float acc[16];
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            float4 a[8], b[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float* wr = rowptr(min(r0 + 8 * hb + u, n - 1));
-                a[u] = *reinterpret_cast<const float4*>(wr + 4 * lane);
-                b[u] = *reinterpret_cast<const float4*>(wr + 256 + 4 * min(lane, 10));
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                acc[8 * hb + u] = a[u].x * v.lo.x + a[u].y * v.lo.y + a[u].z * v.lo.z + a[u].w * v.lo.w + b[u].x * v.hi.x +
-                                  b[u].y * v.hi.y + b[u].z * v.hi.z + b[u].w * v.hi.w;
-        }
+        for (int u = 0; u < 16; ++u)
+            acc[u] = a[u].x * v.lo.x + a[u].y * v.lo.y + a[u].z * v.lo.z + a[u].w * v.lo.w + b[u].x * v.hi.x + b[u].y * v.hi.y +
+                     b[u].z * v.hi.z + b[u].w * v.hi.w;
         const float tot = butterfly16(acc, lane);
         const int r = r0 + butterfly_row(lane);
         if ((lane & 3) == 0 && r < n) store(r, tot);
