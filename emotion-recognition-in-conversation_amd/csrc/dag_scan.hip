@@ -204,21 +204,30 @@ __device__ __forceinline__ float butterfly16(const float (&a)[16], int lane) {
 // the result.  A wavefront owns 16 consecutive rows per pass (8 + 8 rows of loads in flight, one butterfly).
 template <int NWV, typename RowPtr, typename Store>
 __device__ __forceinline__ void matvec16(int n, const float* v_lds, int lane, int wave, RowPtr rowptr, Store store) {
-    const Vec300 v = load_vec300(v_lds, lane);
+    // A 300-float row is 64 lanes x 16 bytes + a 44-float tail.  The tails of FOUR rows share one load instruction
+    // (lane group q = lane >> 4 fetches the tail of row 4 k + q with its first 11 lanes): 20 instead of 32 load
+    // instructions per 16 rows -- the product is bound by the CU's fetch path, and a tail-only instruction costs as
+    // much of it as a full one.  All loads of the pass are requested before the first FMA.
+    const float4 vlo = *reinterpret_cast<const float4*>(v_lds + 4 * lane);
+    const int tl = min(lane & 15, 10), q = lane >> 4;
+    const float tm = (lane & 15) < 11 ? 1.f : 0.f;
+    float4 vhi = *reinterpret_cast<const float4*>(v_lds + 256 + 4 * tl);
+    vhi = make_float4(vhi.x * tm, vhi.y * tm, vhi.z * tm, vhi.w * tm);
     for (int r0 = 16 * wave; r0 < n; r0 += 16 * NWV) {
-        // all 16 rows of the pass are requested before the first FMA: one round trip per pass instead of two
-        float4 a[16], b[16];
+        float4 a[16], b[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const float* wr = rowptr(min(r0 + u, n - 1));
-            a[u] = *reinterpret_cast<const float4*>(wr + 4 * lane);
-            b[u] = *reinterpret_cast<const float4*>(wr + 256 + 4 * min(lane, 10));
-        }
+        for (int u = 0; u < 16; ++u) a[u] = *reinterpret_cast<const float4*>(rowptr(min(r0 + u, n - 1)) + 4 * lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = *reinterpret_cast<const float4*>(rowptr(min(r0 + 4 * k + q, n - 1)) + 256 + 4 * tl);
         float acc[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            acc[u] = a[u].x * v.lo.x + a[u].y * v.lo.y + a[u].z * v.lo.z + a[u].w * v.lo.w + b[u].x * v.hi.x + b[u].y * v.hi.y +
-                     b[u].z * v.hi.z + b[u].w * v.hi.w;
+        for (int u = 0; u < 16; ++u) acc[u] = a[u].x * vlo.x + a[u].y * vlo.y + a[u].z * vlo.z + a[u].w * vlo.w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = b[k].x * vhi.x + b[k].y * vhi.y + b[k].z * vhi.z + b[k].w * vhi.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * k + j] += (q == j) ? t : 0.f;
+        }
         const float tot = butterfly16(acc, lane);
         const int r = r0 + butterfly_row(lane);
         if ((lane & 3) == 0 && r < n) store(r, tot);

@@ -89,8 +89,10 @@ def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C):
 
 
 def test_cluster_scan_equals_single_workgroup_scan(monkeypatch):
-    """The recurrence kernels in cluster mode (P workgroups per dialogue) against one workgroup per dialogue: forward
-    bit-identical (same per-row dot products), gradients equal up to the order of the cross-member partial sums."""
+    """The recurrence kernels in cluster mode (P workgroups per dialogue) against one workgroup per dialogue: hidden
+    states equal up to the association order inside a row's dot product (the cluster kernels fetch the 44-float row
+    tails four rows per instruction, so a tail lands in a different lane of the butterfly sum), gradients up to the
+    order of the cross-member partial sums."""
     from erc_amd import capi
     from erc_amd.dagerc import DAGERCModule
     dims = dict(a=30, t=60, v=34)
@@ -107,7 +109,8 @@ def test_cluster_scan_equals_single_workgroup_scan(monkeypatch):
         m.check_cluster()
         res[P] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone())
     for P in (4, 8):
-        assert res[P][0] == res[1][0] and torch.equal(res[P][1], res[1][1])
+        assert abs(res[P][0] - res[1][0]) < 1e-6
+        assert float((res[P][1] - res[1][1]).abs().max()) <= 2e-6 * max(1.0, float(res[1][1].abs().max()))
         assert float((res[P][2] - res[1][2]).abs().max()) <= 1e-6 * max(1.0, float(res[1][2].abs().max()))
 
 
