@@ -82,32 +82,50 @@ __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, const f
     }
 }
 
-// acc += sum_{r owned by wave} W[r,:] * d[r]  (transposed product); acc is this lane's slice in the Vec300 layout
+// acc += sum_{r owned by wave} W[r,:] * d[r]  (transposed product).  acc.lo is this lane's 4 columns; the 44-float row
+// tails are fetched four rows per load instruction (lane group q = lane >> 4 takes the tail of rows u = 4 k + q of
+// the batch with its first 11 lanes), so acc.hi holds the partial sum of THIS lane group's rows: store_vec300_t adds
+// the four groups before it stores.
 template <int NWV = NW>
 __device__ __forceinline__ void matvec_t_accum(const float* __restrict__ W, int rows, const float* d_lds, Vec300& acc,
                                                int lane, int wave) {
+    static_assert(RB % 4 == 0, "row batches are multiples of 4");
+    const int tl = min(lane & 15, 10), q = lane >> 4;
     for (int r0 = wave; r0 < rows; r0 += RB * NWV) {
-        float4 a[RB], b[RB];
-        float d[RB];
+        float4 a[RB], b[RB / 4];
+        float d[RB], dq[RB / 4];
 #pragma unroll
         for (int u = 0; u < RB; ++u) {
             const int r = min(r0 + u * NWV, rows - 1);
-            const float* w = W + (int64_t)r * HID;
-            a[u] = *reinterpret_cast<const float4*>(w + 4 * lane);
-            b[u] = *reinterpret_cast<const float4*>(w + 256 + 4 * min(lane, 10));
+            a[u] = *reinterpret_cast<const float4*>(W + (int64_t)r * HID + 4 * lane);
             d[u] = (r0 + u * NWV < rows) ? d_lds[r] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < RB; ++u) {
-            acc.lo.x += a[u].x * d[u], acc.lo.y += a[u].y * d[u], acc.lo.z += a[u].z * d[u], acc.lo.w += a[u].w * d[u];
-            acc.hi.x += b[u].x * d[u], acc.hi.y += b[u].y * d[u], acc.hi.z += b[u].z * d[u], acc.hi.w += b[u].w * d[u];
+        for (int k = 0; k < RB / 4; ++k) {
+            const int rr = r0 + (4 * k + q) * NWV, r = min(rr, rows - 1);
+            b[k] = *reinterpret_cast<const float4*>(W + (int64_t)r * HID + 256 + 4 * tl);
+            dq[k] = rr < rows ? d_lds[r] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+            acc.lo.x += a[u].x * d[u], acc.lo.y += a[u].y * d[u], acc.lo.z += a[u].z * d[u], acc.lo.w += a[u].w * d[u];
+#pragma unroll
+        for (int k = 0; k < RB / 4; ++k)
+            acc.hi.x += b[k].x * dq[k], acc.hi.y += b[k].y * dq[k], acc.hi.z += b[k].z * dq[k], acc.hi.w += b[k].w * dq[k];
     }
 }
 // store a lane's Vec300 slice into part[wave][0..299]
 __device__ __forceinline__ void store_vec300(float* dst, const Vec300& v, int lane) {
     *reinterpret_cast<float4*>(dst + 4 * lane) = v.lo;
     if (lane < 11) *reinterpret_cast<float4*>(dst + 256 + 4 * lane) = v.hi;
+}
+// the same for an accumulator of matvec_t_accum: the tail is the sum over the four lane groups
+__device__ __forceinline__ void store_vec300_t(float* dst, const Vec300& v, int lane) {
+    float4 h = v.hi;
+    h.x += __shfl_xor(h.x, 16, 64), h.y += __shfl_xor(h.y, 16, 64), h.z += __shfl_xor(h.z, 16, 64), h.w += __shfl_xor(h.w, 16, 64);
+    h.x += __shfl_xor(h.x, 32, 64), h.y += __shfl_xor(h.y, 32, 64), h.z += __shfl_xor(h.z, 32, 64), h.w += __shfl_xor(h.w, 32, 64);
+    *reinterpret_cast<float4*>(dst + 4 * lane) = v.lo;
+    if (lane < 11) *reinterpret_cast<float4*>(dst + 256 + 4 * lane) = h;
 }
 
 // ----------------------------------------------------------------------------- cluster scan (P workgroups per dialogue)
@@ -604,7 +622,7 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
         {
             Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
             matvec_t_accum(p.Wr, 2 * HID, v_in, acc, lane, wave);
-            store_vec300(part[wave], acc, lane);
+            store_vec300_t(part[wave], acc, lane);
         }
         __syncthreads();
         const float dks_i = p.dks[row];
@@ -659,7 +677,7 @@ __global__ __launch_bounds__(NT) void dag_scan_bwd_kernel(DagBwd p) {
             Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
             matvec_t_accum(p.W_hh_c, G3, v_in, acc, lane, wave);
             matvec_t_accum(p.W_ih_p, G3, v_in + G3, acc, lane, wave);
-            store_vec300(part[wave], acc, lane);
+            store_vec300_t(part[wave], acc, lane);
         }
         __syncthreads();
         if (tid < HID) {
@@ -780,7 +798,7 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
         {
             Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
             matvec_t_accum<CNW>(p.Wr + (int64_t)r_lo * HID, r_hi - r_lo, v_in + r_lo, acc, lane, wave);
-            store_vec300(part[wave], acc, lane);
+            store_vec300_t(part[wave], acc, lane);
         }
         __syncthreads();
         const float dks_i = dks_my[i];
@@ -845,7 +863,7 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
             Vec300 acc = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
             matvec_t_accum<CNW>(p.W_hh_c + (int64_t)g_lo * HID, g_hi - g_lo, v_in + g_lo, acc, lane, wave);
             matvec_t_accum<CNW>(p.W_ih_p + (int64_t)g_lo * HID, g_hi - g_lo, v_in + G3 + g_lo, acc, lane, wave);
-            store_vec300(part[wave], acc, lane);
+            store_vec300_t(part[wave], acc, lane);
         }
         __syncthreads();
         if (tid < HID) {
