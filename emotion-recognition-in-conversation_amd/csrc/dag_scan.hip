@@ -417,12 +417,13 @@ struct DagCluster {
     u64* xg;        // [B][1800] tagged gate pre-activations of the current step
     u64* xr;        // [B][608]  tagged relation row (600) + key score of the current step
     int* epoch;     // [B] launches seen so far (tags of different launches never collide)
-    u64* xp;        // backward: [B][2][8][320] tagged partial vectors
-    float* priv;    // backward: [B][7][T][601] private dR | dks copies of the members > 0 (zero at launch)
+    u64* xp;        // backward: [B][2][CL_MAXP][320] tagged partial vectors
+    float* priv;    // backward: [B][P - 1][T][601] private dR | dks copies of the members > 0 (zero at launch)
 };
 
 // workgroup id -> (dialogue, member): the members of a dialogue get ids that are equal mod 8, i.e. the same XCD under
 // round-robin placement (speed only: the exchange then stays inside one L2)
+constexpr int CL_MAXP = 16;    // members per dialogue (the backward kernel is instantiated for 8 and 16 partial vectors)
 __device__ __forceinline__ void cluster_ids(int P, int& b, int& m) {
     const int id = blockIdx.x;
     b = (id / (8 * P)) * 8 + (id & 7);
@@ -751,6 +752,7 @@ __device__ __forceinline__ void reduce_wave_partials(const float (*part)[320], f
     }
 }
 
+template <int MP>
 __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, DagCluster cl) {
     int b, mem;
     cluster_ids(cl.P, b, mem);
@@ -769,13 +771,13 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
     const int r_lo = mem * 2 * HID / P, r_hi = (mem + 1) * 2 * HID / P;
     const unsigned ep = (unsigned)cl.epoch[b] + 1u;
     // partial-vector exchange records [b][phase][member][320]
-    u64* const xp0 = cl.xp + ((int64_t)b * 2 + 0) * 8 * 320;
-    u64* const xp1 = cl.xp + ((int64_t)b * 2 + 1) * 8 * 320;
+    u64* const xp0 = cl.xp + ((int64_t)b * 2 + 0) * CL_MAXP * 320;
+    u64* const xp1 = cl.xp + ((int64_t)b * 2 + 1) * CL_MAXP * 320;
     // The accumulators dR / dks receive, at every step, updates that depend only on replicated quantities (alpha, dM):
     // EVERY member applies all of them to a copy of its own (member 0: the caller's buffers, which the weight-gradient
     // products read afterwards; members > 0: zero-filled scratch), so no exchange is needed for them at all.
     float* const dR_my = mem == 0 ? p.dR + (int64_t)b * T * 2 * HID
-                                  : cl.priv + ((int64_t)b * 7 + (mem - 1)) * (int64_t)T * (2 * HID + 1);
+                                  : cl.priv + ((int64_t)b * (P - 1) + (mem - 1)) * (int64_t)T * (2 * HID + 1);
     float* const dks_my = mem == 0 ? p.dks + (int64_t)b * T : dR_my + (int64_t)T * 2 * HID;
 
     for (int i = T - 1; i >= 0; --i) {
@@ -807,14 +809,17 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
 #pragma unroll
             for (int w = 0; w < CNW; ++w) s += part[w][tid];
             st_tagged(xp0 + mem * 320 + tid, s, tag);
-            int idx[8];
-            float pm[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) idx[m] = min(m, P - 1) * 320 + tid;
-            wait_tagged<8>(xp0, idx, tag, pm, cl.err);
             float g = dh1_r + w_k[tid] * dks_i;
+#pragma unroll 1
+            for (int h8 = 0; h8 < MP; h8 += 8) {     // 8 members' partial vectors per poll (16 at once spill)
+                int idx[8];
+                float pm[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) g += m < P ? pm[m] : 0.f;
+                for (int m = 0; m < 8; ++m) idx[m] = min(h8 + m, P - 1) * 320 + tid;
+                wait_tagged<8>(xp0, idx, tag, pm, cl.err);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) g += h8 + m < P ? pm[m] : 0.f;
+            }
             v_g[tid] = g;
             dwk += dks_i * h1_r;
         }
@@ -871,14 +876,17 @@ __global__ __launch_bounds__(CNT) void dag_scan_bwd_cluster_kernel(DagBwd p, Dag
 #pragma unroll
             for (int w = 0; w < CNW; ++w) s += part[w][tid];
             st_tagged(xp1 + mem * 320 + tid, s, tag);
-            int idx[8];
-            float pm[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) idx[m] = min(m, P - 1) * 320 + tid;
-            wait_tagged<8>(xp1, idx, tag, pm, cl.err);
             float d = v_dm[tid];
+#pragma unroll 1
+            for (int h8 = 0; h8 < MP; h8 += 8) {
+                int idx[8];
+                float pm[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) d += m < P ? pm[m] : 0.f;
+                for (int m = 0; m < 8; ++m) idx[m] = min(h8 + m, P - 1) * 320 + tid;
+                wait_tagged<8>(xp1, idx, tag, pm, cl.err);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) d += h8 + m < P ? pm[m] : 0.f;
+            }
             v_dm[tid] = d;
         }
         __syncthreads();
@@ -960,14 +968,14 @@ extern "C" int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_
 extern "C" int erc_dag_cluster_size(int B) {
     // workgroups per dialogue: all B * P persistent 1024-thread workgroups must be resident at once (256 CUs)
     int P = 256 / (B > 0 ? B : 1);
-    if (P > 8) P = 8;   // measured (B = 16, step time): P = 4 / 8 / 12 / 16 -> 18.3 / 14.6 / 15.3 / 16.8 ms
+    if (P > CL_MAXP) P = CL_MAXP;
     return P < 2 ? 1 : P;
 }
 
-// cluster scratch (floats): [B][1800] + [B][608] forward exchange records (8 bytes each) | [B][2][8][320] backward
-// partial-vector records | [B][7][T][601] private accumulator copies of the backward
-static inline int64_t cl_rec_floats(int B) { return 2 * ((int64_t)B * 2 * G3 + (int64_t)B * 608 + (int64_t)B * 2 * 8 * 320); }
-extern "C" int64_t erc_dag_cluster_scratch_floats(int B, int T) { return cl_rec_floats(B) + (int64_t)B * 7 * T * (2 * HID + 1); }
+// cluster scratch (floats): [B][1800] + [B][608] forward exchange records (8 bytes each) | [B][2][CL_MAXP][320] backward
+// partial-vector records | [B][CL_MAXP - 1][T][601] private accumulator copies of the backward
+static inline int64_t cl_rec_floats(int B) { return 2 * ((int64_t)B * 2 * G3 + (int64_t)B * 608 + (int64_t)B * 2 * CL_MAXP * 320); }
+extern "C" int64_t erc_dag_cluster_scratch_floats(int B, int T) { return cl_rec_floats(B) + (int64_t)B * (CL_MAXP - 1) * T * (2 * HID + 1); }
 static inline DagCluster make_cluster(int cluster, int B, int32_t* cl_state, float* cl_scratch) {
     // cl_state: [0] error flag | [1, 1+B) arrival counters (unused by the tagged exchanges) | [1+B, 1+2B) launch epochs
     u64* rec = reinterpret_cast<u64*>(cl_scratch);
@@ -987,8 +995,8 @@ extern "C" int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI, const
     if (cluster <= 1) {
         hipLaunchKernelGGL(dag_scan_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
     } else {
-        ERC_REQUIRE(cl_state && cl_scratch && cluster <= 8 && (int64_t)B * cluster <= 256 && ((uintptr_t)cl_scratch & 7) == 0,
-                    "dag_scan_fwd: cluster=%d with B=%d (needs cl_state, 8-byte aligned cl_scratch, cluster <= 8, B * cluster <= 256)",
+        ERC_REQUIRE(cl_state && cl_scratch && cluster <= CL_MAXP && (int64_t)B * cluster <= 256 && ((uintptr_t)cl_scratch & 7) == 0,
+                    "dag_scan_fwd: cluster=%d with B=%d (needs cl_state, 8-byte aligned cl_scratch, cluster <= 16, B * cluster <= 256)",
                     cluster, B);
         const DagCluster cl = make_cluster(cluster, B, cl_state, cl_scratch);   // the forward exchanges through tagged records only
         hipLaunchKernelGGL(dag_scan_fwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
@@ -1012,13 +1020,14 @@ extern "C" int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const
     if (cluster <= 1) {
         hipLaunchKernelGGL(dag_scan_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, p);
     } else {
-        ERC_REQUIRE(cl_state && cl_scratch && cluster <= 8 && (int64_t)B * cluster <= 256 && ((uintptr_t)cl_scratch & 7) == 0,
-                    "dag_scan_bwd: cluster=%d with B=%d (needs cl_state, 8-byte aligned cl_scratch, cluster <= 8, B * cluster <= 256)",
+        ERC_REQUIRE(cl_state && cl_scratch && cluster <= CL_MAXP && (int64_t)B * cluster <= 256 && ((uintptr_t)cl_scratch & 7) == 0,
+                    "dag_scan_bwd: cluster=%d with B=%d (needs cl_state, 8-byte aligned cl_scratch, cluster <= 16, B * cluster <= 256)",
                     cluster, B);
         const DagCluster cl = make_cluster(cluster, B, cl_state, cl_scratch);
-        hipError_t e = hipMemsetAsync(cl.priv, 0, sizeof(float) * (size_t)B * 7 * T * (2 * HID + 1), (hipStream_t)stream);
+        hipError_t e = hipMemsetAsync(cl.priv, 0, sizeof(float) * (size_t)B * (cluster - 1) * T * (2 * HID + 1), (hipStream_t)stream);
         ERC_REQUIRE(e == hipSuccess, "dag_scan_bwd: memset failed: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(dag_scan_bwd_cluster_kernel, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
+        if (cluster <= 8) hipLaunchKernelGGL(dag_scan_bwd_cluster_kernel<8>, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
+        else hipLaunchKernelGGL(dag_scan_bwd_cluster_kernel<CL_MAXP>, dim3(erc_cdiv(B, 8) * 8 * cluster), dim3(CNT), 0, (hipStream_t)stream, p, cl);
     }
     ERC_LAUNCH_CHECK("dag_scan_bwd");
     return ERC_OK;
