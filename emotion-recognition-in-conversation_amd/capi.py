@@ -84,7 +84,8 @@ _SIGS = {
     "erc_transpose_batched": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "erc_csr_sum": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "erc_gemm_f32_grouped": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f,
-                                       _vp, _vp]),
+                                       _vp, _i, _i64, _i64, _i, _i64, _vp]),
+    "erc_gemm_f32_planes": (C.c_int, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i, _vp]),
     "erc_mm_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_mm_flatten": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_mm_emb_grad": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _vp]),
@@ -93,7 +94,7 @@ _SIGS = {
     "erc_mm_adj_finish": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_mm_adj_finish_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "erc_mm_cross_apply": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
-    "erc_mm_cross_grad": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "erc_mm_cross_grad": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i64, _i64, _vp]),
     "erc_gcnii_combine_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _vp, C.c_uint64, _vp, _vp]),
     "erc_gcnii_combine_bwd": (C.c_int, [_vp, _vp, _i64, _f, _f, _f, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "erc_gcnii_layer_fwd": (C.c_int, [_vp, _i, _vp, _i, _f, _f, _f, _vp, C.c_uint64, _vp, _i, _i, _i, _vp]),
@@ -360,11 +361,15 @@ def csr_sum(x, ldx, F, N, ptr_, idx, out, ldo, accumulate=0):
 
 
 def gemm_grouped(form, A, lda, B, ldb, Cm, ldc, n_or_k, node_off, n_dlg, n_mod, n_nodes, max_len, pitch, accumulate=0,
-                 act=0, aux=None, ldaux=0, act_scale=1.0, cross=None):
+                 act=0, aux=None, ldaux=0, act_scale=1.0, cross=None, planes=1, a_plane=0, b_plane=0, split=1, c_slab=0):
     _check(lib().erc_gemm_f32_grouped(form, ptr(A), lda, ptr(B), ldb, ptr(Cm), ldc, n_or_k, ptr(node_off), n_dlg, n_mod,
                                       n_nodes, max_len, pitch, accumulate, act, ptr(aux), ldaux, act_scale, ptr(cross),
-                                      stream()),
+                                      planes, a_plane, b_plane, split, c_slab, stream()),
            "erc_gemm_f32_grouped")
+
+
+def gemm_f32_planes(A, lda, a_plane, B, ldb, b_plane, Cm, ldc, M, N, K, planes, split_k=1, c_slab=0, accumulate=0):
+    _call("erc_gemm_f32_planes", A, lda, a_plane, B, ldb, b_plane, Cm, ldc, M, N, K, planes, split_k, c_slab, accumulate)
 
 
 def _call(name, *args):
@@ -403,8 +408,8 @@ def mm_cross_apply(CR, h, ldh, node_dlg, node_off, M, N, P, out, ldo):
     _call("erc_mm_cross_apply", CR, h, ldh, node_dlg, node_off, M, N, P, out, ldo)
 
 
-def mm_cross_grad(dhi, ldd, h, ldh, node_dlg, node_off, M, N, P, dCR):
-    _call("erc_mm_cross_grad", dhi, ldd, h, ldh, node_dlg, node_off, M, N, P, dCR)
+def mm_cross_grad(dhi, ldd, h, ldh, node_dlg, node_off, M, N, P, dCR, planes=1, d_plane=0, h_plane=0):
+    _call("erc_mm_cross_grad", dhi, ldd, h, ldh, node_dlg, node_off, M, N, P, dCR, planes, d_plane, h_plane)
 
 
 def gcnii_combine_fwd(G, hi, h0, n, theta, alpha, drop_p, rng, rng_stream, hd):

@@ -44,6 +44,10 @@ struct GemmP {
     const float* xr_CR;   // [B][M*M][P]
     const float* xr_h;    // the un-offset B operand (node rows, pitch ldb)
     int xr_M, xr_N, xr_P, xr_m, xr_b, xr_off;
+    // planes > 1: the K axis runs over `planes` operand planes of K columns each (A plane p at A + p * a_plane, B at
+    // B + p * b_plane): sum_p A_p B_p^T in ONE launch -- the per-layer products of MMGCN's backward that only meet in a sum
+    int planes;
+    int64_t a_plane, b_plane;
 };
 
 constexpr int BM = 64;
@@ -77,14 +81,25 @@ __device__ __forceinline__ void gemm_f32_body(const GemmP& p, const int bx, cons
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int n0 = bx * BN, m0 = by * BM;
-    const int nchunk = (p.K + BK - 1) / BK;
+    const int cpl = (p.K + BK - 1) / BK;                     // chunks per plane
+    const int nchunk = cpl * (p.planes > 1 ? p.planes : 1);
     const int c_begin = z * p.chunks_per_split;
     const int c_end = min(nchunk, c_begin + p.chunks_per_split);
+    const float* const A0 = A;
+    const float* const B0 = B;
 
     float4 ra[2], rb[B_PASS];
 
     auto load_chunk = [&](int c) {
-        const int k0 = c * BK;
+        int k0 = c * BK;
+        const float* A = A0;
+        const float* B = B0;
+        if (p.planes > 1) {
+            const int pl = c / cpl;
+            k0 = (c - pl * cpl) * BK;
+            A = A0 + (int64_t)pl * p.a_plane;
+            B = B0 + (int64_t)pl * p.b_plane;
+        }
         if (!A_KMAJOR) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -281,11 +296,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmP p) {
 struct GroupP {
     const int32_t* node_off;
     int n_mod, n_nodes, pitch;
+    int split;      // form 1: the chunk range is cut into `split` parts, part s writes slab s (C + s * c_slab)
 };
 
 template <int FORM>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmP p, GroupP g) {
-    const int z = blockIdx.z, b = z / g.n_mod, m = z % g.n_mod;
+    const int z = (int)blockIdx.z / g.split, sp = (int)blockIdx.z % g.split, b = z / g.n_mod, m = z % g.n_mod;
     const int off = g.node_off[b], L = g.node_off[b + 1] - off;
     if ((int)blockIdx.y * BM >= L) return;
     const int64_t row0 = (int64_t)m * g.n_nodes + off;
@@ -309,7 +325,7 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(GemmP p, GroupP g
         p.C = p.C + blk;
         p.M = L;
         p.N = L;
-        gemm_f32_body<0, 0, 2>(p, blockIdx.x, blockIdx.y, 0);
+        gemm_f32_body<0, 0, 2>(p, blockIdx.x, blockIdx.y, sp);
     }
 }
 
@@ -582,8 +598,11 @@ extern "C" int erc_gemm_f32(const float* A, int lda, int a_kmajor, const int32_t
 extern "C" int erc_gemm_f32_grouped(int form, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                                     int N_or_K, const int32_t* node_off, int n_dialogues, int n_mod, int n_nodes,
                                     int max_len, int pitch, int accumulate, int act, const float* aux, int ldaux,
-                                    float act_scale, const float* cross, void* stream) {
+                                    float act_scale, const float* cross, int planes, int64_t a_plane, int64_t b_plane,
+                                    int split, int64_t c_slab, void* stream) {
     ERC_REQUIRE(A && B && C && node_off, "gemm_f32_grouped: null pointer");
+    ERC_REQUIRE(planes <= 1 || form == 1, "gemm_f32_grouped: planes go with form 1");
+    ERC_REQUIRE(split <= 1 || (form == 1 && !accumulate && c_slab > 0), "gemm_f32_grouped: split goes with form 1, plain stores into slabs");
     ERC_REQUIRE(form == 0 || form == 1, "gemm_f32_grouped: form %d", form);
     ERC_REQUIRE(n_dialogues > 0 && n_mod > 0 && n_nodes > 0 && max_len > 0 && pitch >= max_len && N_or_K > 0,
                 "gemm_f32_grouped: bad sizes");
@@ -593,7 +612,7 @@ extern "C" int erc_gemm_f32_grouped(int form, const float* A, int lda, const flo
     p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.accumulate = accumulate; p.act = act; p.aux = aux; p.ldaux = ldaux; p.act_scale = act_scale;
     p.xr_CR = cross; p.xr_M = n_mod; p.xr_N = n_nodes; p.xr_P = pitch;
-    GroupP g{node_off, n_mod, n_nodes, pitch};
+    GroupP g{node_off, n_mod, n_nodes, pitch, split > 1 ? split : 1};
     hipStream_t st = (hipStream_t)stream;
     if (form == 0) {
         p.N = N_or_K;
@@ -605,13 +624,34 @@ extern "C" int erc_gemm_f32_grouped(int form, const float* A, int lda, const flo
     } else {
         p.K = N_or_K;
         p.ldc = pitch;
-        p.chunks_per_split = erc_cdiv(N_or_K, BK);
+        p.planes = planes > 1 ? planes : 1, p.a_plane = a_plane, p.b_plane = b_plane;
+        p.chunks_per_split = erc_cdiv(erc_cdiv(N_or_K, BK) * p.planes, g.split);
+        p.c_slab = c_slab;
         p.a_vec = aligned16(A) && (lda % 4 == 0);
         p.b_vec = aligned16(B) && (ldb % 4 == 0);
-        dim3 grid(erc_cdiv(max_len, 32), erc_cdiv(max_len, BM), n_dialogues * n_mod);
+        dim3 grid(erc_cdiv(max_len, 32), erc_cdiv(max_len, BM), n_dialogues * n_mod * g.split);
         hipLaunchKernelGGL(gemm_f32_grouped_kernel<1>, grid, dim3(256), 0, st, p, g);
     }
     ERC_LAUNCH_CHECK("gemm_f32_grouped");
+    return ERC_OK;
+}
+
+extern "C" int erc_gemm_f32_planes(const float* A, int lda, int64_t a_plane, const float* B, int ldb, int64_t b_plane, float* C,
+                                   int ldc, int M, int N, int K, int planes, int split_k, int64_t c_slab, int accumulate,
+                                   void* stream) {
+    ERC_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && planes >= 1 && split_k >= 1, "gemm_f32_planes: bad arguments");
+    ERC_REQUIRE(split_k == 1 || !accumulate, "gemm_f32_planes: accumulate needs split_k == 1");
+    GemmP p{};
+    p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    p.planes = planes; p.a_plane = a_plane; p.b_plane = b_plane; p.c_slab = c_slab; p.accumulate = accumulate;
+    const int nchunk = erc_cdiv(K, BK) * planes;
+    ERC_REQUIRE(split_k <= nchunk, "gemm_f32_planes: split_k %d exceeds the %d K-chunks", split_k, nchunk);
+    p.chunks_per_split = erc_cdiv(nchunk, split_k);
+    p.a_vec = aligned16(A) && (lda % 4 == 0) && (a_plane % 4 == 0);
+    p.b_vec = aligned16(B) && (ldb % 4 == 0) && (b_plane % 4 == 0);
+    dim3 grid(erc_cdiv(N, 32), erc_cdiv(M, BM), split_k);
+    hipLaunchKernelGGL((gemm_f32_kernel<0, 0, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    ERC_LAUNCH_CHECK("gemm_f32_planes");
     return ERC_OK;
 }
 

@@ -264,18 +264,30 @@ __global__ __launch_bounds__(256) void cross_apply_kernel(const float* __restric
         if (lane + 64 * u < FD) o[lane + 64 * u] += acc.v[u];
 }
 
-// dCR[b][m*M+n][p] += dhi[(m,p), :] . h[(n,p), :]   (directional)
+// dCR[b][m*M+n][p] += sum over planes of dhi_pl[(m,p), :] . h_pl[(n,p), :]   (directional); planes = the layers whose
+// contributions only meet in this sum (one launch for all of them)
 __global__ __launch_bounds__(256) void cross_grad_kernel(const float* __restrict__ dhi, int ldd, const float* __restrict__ h,
                                                          int ldh, const int32_t* __restrict__ node_dlg,
                                                          const int32_t* __restrict__ node_off, int M, int N, int P,
-                                                         float* __restrict__ dCR) {
+                                                         float* __restrict__ dCR, int planes, int64_t d_plane, int64_t h_plane) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= M * N) return;
     const int m = r / N, i = r % N, b = node_dlg[i], p = i - node_off[b];
-    const L4 g = ld4(dhi + (int64_t)r * ldd, lane);
     for (int n = 0; n < M; ++n) {
         if (n == m) continue;
-        const float d = wave_sum(dt4(g, ld4(h + ((int64_t)n * N + i) * ldh, lane)));
+        float acc = 0.f;
+        for (int pl0 = 0; pl0 < planes; pl0 += 4) {      // 4 planes (8 row loads) in flight
+            L4 g[4], hh[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pl = min(pl0 + u, planes - 1);
+                g[u] = ld4(dhi + (int64_t)pl * d_plane + (int64_t)r * ldd, lane);
+                hh[u] = ld4(h + (int64_t)pl * h_plane + ((int64_t)n * N + i) * ldh, lane);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += (pl0 + u < planes) ? dt4(g[u], hh[u]) : 0.f;
+        }
+        const float d = wave_sum(acc);
         if (lane == 0) dCR[((int64_t)b * M * M + m * M + n) * P + p] += d;
     }
 }
@@ -440,9 +452,11 @@ extern "C" int erc_mm_cross_apply(const float* CR, const float* h, int ldh, cons
     return ERC_OK;
 }
 extern "C" int erc_mm_cross_grad(const float* dhi, int ldd, const float* h, int ldh, const int32_t* node_dlg,
-                                 const int32_t* node_off, int M, int N, int P, float* dCR, void* stream) {
-    ERC_REQUIRE(dhi && h && node_dlg && node_off && dCR && M >= 2 && N > 0, "mm_cross_grad: bad arguments");
-    hipLaunchKernelGGL(cross_grad_kernel, NODEG(M * N), dhi, ldd, h, ldh, node_dlg, node_off, M, N, P, dCR);
+                                 const int32_t* node_off, int M, int N, int P, float* dCR, int planes, int64_t d_plane,
+                                 int64_t h_plane, void* stream) {
+    ERC_REQUIRE(dhi && h && node_dlg && node_off && dCR && M >= 2 && N > 0 && planes >= 1, "mm_cross_grad: bad arguments");
+    hipLaunchKernelGGL(cross_grad_kernel, NODEG(M * N), dhi, ldd, h, ldh, node_dlg, node_off, M, N, P, dCR, planes, d_plane,
+                       h_plane);
     ERC_LAUNCH_CHECK("mm_cross_grad");
     return ERC_OK;
 }

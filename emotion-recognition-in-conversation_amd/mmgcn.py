@@ -23,6 +23,7 @@ from .engine import FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear
 from .rnn import BiLSTM2, lstm_groups
 
 FD, NLAYERS, LAMDA, ALPHA, DROP = 200, 64, 0.5, 0.1, 0.4
+KSPLIT = 16      # parts of the layer-plane sums in the backward (adjacency / h0 gradients); 8 .. 32 measured alike
 _KEY = {"a": "audio_feature", "v": "visual_feature", "t": "text_feature"}
 _LIN = {"a": "linear_a", "v": "linear_v", "t": "linear_l"}
 
@@ -141,7 +142,8 @@ class MMGCNModule(nn.Module):
                   CCOS=f32(B, Mo * Mo, P), DEG=f32(R3), H0=f32(R3, FD), Gt=f32(R3, FD),
                   HI=f32(NLAYERS + 1, R3, 2 * FD), HD=f32(NLAYERS + 2, R3, FD), FE=f32(N, Mo * 2 * FD), logits=f32(N, C),
                   stats=torch.zeros(256, dtype=torch.float32, device=device), dlogits=f32(N, C), dFE=f32(N, Mo * 2 * FD), dXD=f32(R3, FD), DH=f32(R3, FD),
-                  dG=f32(NLAYERS + 1, R3, FD), dHIH0=f32(R3, 2 * FD), dH0=f32(R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
+                  dG=f32(NLAYERS + 1, R3, FD), dHIa=f32(NLAYERS + 1, R3, FD), dH0=f32(R3, FD),
+                  dADJs=f32(KSPLIT, B * Mo, P, P), dH0s=f32(KSPLIT + 1, R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
                   Gb=f32(B * Mo, P, P), GC=f32(B, Mo * Mo, P), dXH=f32(R3, FD), dX=f32(R3, FD),
                   dLIN={m: f32(TB, FD) for m in self.order}, dLL=f32(TB, FD))
         dmax = max(self.dims[m] for m in self.order)
@@ -250,24 +252,38 @@ class MMGCNModule(nn.Module):
                      defer=True)
         DH = ws["DH"]
         capi.mm_regroup_bwd(ws["dFE"], ws["FE"], Mo, N, ks, ws["dXD"], DH)
-        dHIH0 = ws["dHIH0"]               # [dhi | dh0] rows, pitch 2 FD: one product per layer accumulates into both halves
-        dHI, dH0 = dHIH0, dHIH0[:, FD:]
-        dHIH0.zero_(), ws["dADJ"].zero_(), ws["dCR"].zero_()
+        # Per layer only what the NEXT layer's gradient needs stays on the dependency chain: dG_l, dhi_l = its residual
+        # part + dG_l W_l[:FD]^T, and DH = A^T dhi_l.  Everything that only meets in a sum over the layers -- the
+        # adjacency gradient sum_l dhi_l h_l^T, its cross-modal entries, the h0 gradient sum_l dG_l W_l[FD:]^T and the
+        # weight gradients -- is computed after the loop, one launch each over all 64 layer planes.
+        dHIa, dH0 = ws["dHIa"], ws["dH0"]
+        dH0e = ws["dH0s"][KSPLIT]          # elementwise residual contributions to dh0: the last slab of the dh0 sum
+        dH0e.zero_(), ws["dCR"].zero_()
         for l in range(NLAYERS, 0, -1):
             Wn = gn + "convs.%d.weight" % (l - 1)
             W = fp.w(Wn)
-            dG = ws["dG"][l]     # kept per layer: the 128 weight-gradient products run as one launch at the end
-            capi.gcnii_combine_bwd(DH, HD[l + 1], n_el, self.theta(l), ALPHA, ks, 0, dG, dHI, dH0, F=FD, ld_d=2 * FD)
-            capi.gemm_f32(dG, FD, 0, None, W, FD, 0, None, dHIH0, 2 * FD, R3, 2 * FD, FD, accumulate=1)   # [dhi|dh0] += dG W^T
+            dG, dhi = ws["dG"][l], dHIa[l]
+            capi.gcnii_combine_bwd(DH, HD[l + 1], n_el, self.theta(l), ALPHA, ks, 0, dG, dhi, dH0e, F=FD, ld_d=FD)
+            capi.gemm_f32(dG, FD, 0, None, W, FD, 0, None, dhi, FD, R3, FD, FD, accumulate=1)          # dhi += dG W[:FD]^T
             matmul_wgrad_io(pl, HI[l], 2 * FD, dG, FD, 2 * FD, FD, R3, off[Wn], None, defer=True)        # dW = [hi|h0]^T dG
-            capi.gemm_grouped(1, dHI, 2 * FD, HD[l], FD, ws["dADJ"], P, FD, ws["node_off"], B, Mo, N, T, P, accumulate=1)
-            capi.mm_cross_grad(dHI, 2 * FD, HD[l], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"])
-            capi.gemm_grouped(0, ws["ADJ"], P, dHI, 2 * FD, DH, FD, FD, ws["node_off"], B, Mo, N, T, P, cross=ws["CR"])
+            capi.gemm_grouped(0, ws["ADJ"], P, dhi, FD, DH, FD, FD, ws["node_off"], B, Mo, N, T, P, cross=ws["CR"])
+        # the sums over the layer planes, cut into KSPLIT parts each (slabs, reduced in order)
+        plane, n_adj = R3 * FD, B * Mo * P * P
+        capi.gemm_grouped(1, dHIa[1], FD, HD[1], FD, ws["dADJs"], P, FD, ws["node_off"], B, Mo, N, T, P, planes=NLAYERS,
+                          a_plane=plane, b_plane=plane, split=KSPLIT, c_slab=n_adj)
+        capi.slab_reduce(ws["dADJs"], KSPLIT, n_adj, None, P, 0, ws["dADJ"], n_adj)
+        capi.mm_cross_grad(dHIa[1], FD, HD[1], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"], planes=NLAYERS,
+                           d_plane=plane, h_plane=plane)
+        w_stride = off[gn + "convs.1.weight"] - off[gn + "convs.0.weight"]
+        assert all(off[gn + "convs.%d.weight" % i] == off[gn + "convs.0.weight"] + i * w_stride for i in range(NLAYERS))
+        W_bot = fp.data[off[gn + "convs.0.weight"] + FD * FD:]                                        # rows FD.. of layer 1's weight
+        capi.gemm_f32_planes(ws["dG"][1], FD, plane, W_bot, FD, w_stride, ws["dH0s"], FD, R3, FD, FD, NLAYERS,
+                             split_k=KSPLIT, c_slab=n_el)
+        capi.slab_reduce(ws["dH0s"], KSPLIT + 1, n_el, None, FD, 0, dH0, n_el)
         # input layer: HD[1] = dropout(H0), H0 = relu(fc0(XD))
-        ws["dH0"].copy_(dH0)              # contiguous copy of the accumulated residual gradient for the elementwise tail
-        capi.axpy_mask(DH, HD[1] if p > 0 else None, n_el, ks, 1, ws["dH0"])
+        capi.axpy_mask(DH, HD[1] if p > 0 else None, n_el, ks, 1, dH0)
         dG0 = ws["dG"][0]
-        capi.gcnii_combine_bwd(ws["dH0"], ws["H0"], n_el, 0.0, 0.0, 1.0, 1, dG0, None, None)
+        capi.gcnii_combine_bwd(dH0, ws["H0"], n_el, 0.0, 0.0, 1.0, 1, dG0, None, None)
         capi.gemm_f32(dG0, FD, 0, None, fp.w(gn + "fcs.0.weight"), FD, 1, None, ws["dXD"], FD, R3, FD, FD, accumulate=1)
         linear_wgrad(pl, dG0, FD, XD, FD, None, FD, FD, R3, off[gn + "fcs.0.weight"], off[gn + "fcs.0.bias"], defer=True)
         dX = ws["dX"]

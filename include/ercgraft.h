@@ -491,12 +491,24 @@ int erc_csr_sum(const float* x, int ldx, int F, int N, const int32_t* ptr, const
  * form 1: Blk[L,L] (+)= A_nodes[L,K] B_nodes[L,K]^T (cosine blocks of mmgcn_models.py:604-608, and dAdj).
  * cross (form 0, optional): the cross-modal entries [B][M*M][P] of the adjacency; their contribution
  * C[(m,t),:] += sum_{n != m} cross[b][m*M+n][t] * B_nodes[(n,t),:] is added in the epilogue (what
- * erc_mm_cross_apply does as a launch of its own). */
+ * erc_mm_cross_apply does as a launch of its own). *
+ * planes > 1 (form 1 and erc_mm_cross_grad, erc_gemm_f32_planes): the contraction also runs over `planes` operand planes
+ * (plane p of A at A + p * a_plane elements, of B at B + p * b_plane): sum_p A_p B_p^T in one launch.  MMGCN's backward
+ * uses it for the 64 per-layer contributions to the adjacency gradient (mmgcn_models.py:373-394 under autograd) and to
+ * the gradient of h0, which only meet in a sum and therefore need not sit on the per-layer dependency chain.
+ * split > 1 (form 1): the contraction range is cut into `split` parts, part s stores into slab C + s * c_slab
+ * (reduced in slab order by erc_slab_reduce). */
 int erc_gemm_f32_grouped(int form, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                          int N_or_K, const int32_t* node_off, int n_dialogues, int n_mod, int n_nodes,
                          int max_len, int pitch, int accumulate, int act, const float* aux, int ldaux,
                          float act_scale,
-                         const float* cross, void* stream);
+                         const float* cross, int planes, int64_t a_plane, int64_t b_plane, int split, int64_t c_slab,
+                         void* stream);
+/* C[M,N] (+)= sum_p A_p[M,K] B_p[N,K]^T over `planes` planes (row-major operands, K contiguous); split_k > 1 writes
+ * partial slabs of c_slab floats each (reduced by erc_slab_reduce) instead of C. */
+int erc_gemm_f32_planes(const float* A, int lda, int64_t a_plane, const float* B, int ldb, int64_t b_plane, float* C,
+                        int ldc, int M, int N, int K, int planes, int split_k, int64_t c_slab, int accumulate,
+                        void* stream);
 /* node tables from text_length and the time-major one-hot qmask [T,B,S] (element (t,b,c) at t*q_st + b*q_sb + c) */
 int erc_mm_meta(const int64_t* lengths, const float* qmask, int64_t q_st, int64_t q_sb, int n_speakers, int B,
                 int32_t* node_off, int32_t* node_row, int32_t* node_dlg, int32_t* node_spk, void* stream);
@@ -517,7 +529,8 @@ int erc_mm_adj_finish_bwd(const float* COS, const float* CCOS, const float* DEG,
 int erc_mm_cross_apply(const float* CR, const float* h, int ldh, const int32_t* node_dlg, const int32_t* node_off,
                        int M, int N, int P, float* out, int ldo, void* stream);
 int erc_mm_cross_grad(const float* dhi, int ldd, const float* h, int ldh, const int32_t* node_dlg,
-                      const int32_t* node_off, int M, int N, int P, float* dCR, void* stream);
+                      const int32_t* node_off, int M, int N, int P, float* dCR, int planes, int64_t d_plane,
+                      int64_t h_plane, void* stream);
 /* GCNII layer tail (mmgcn_models.py:27-39,385-388): hd = dropout(relu(theta*G + (1-theta)((1-alpha) hi + alpha h0)));
  * hi == NULL: hd = dropout(relu(G)) (the input layer fcs[0]).  Backward: dG, dhi (written), dh0 (accumulated). */
 int erc_gcnii_combine_fwd(const float* G, const float* hi, const float* h0, int64_t n, float theta, float alpha,
