@@ -123,6 +123,25 @@ __global__ __launch_bounds__(256) void rgcn_mean_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------- TransformerConv, heads=1
+// CH (<= 16) per-lane partial dot products -> every lane gets all CH wave totals: one 16-value butterfly (17 shuffles)
+// and CH lane reads instead of CH full wave reductions (6 shuffles each).
+__device__ __forceinline__ void wave_sums_ch(const float (&part)[16], float (&tot)[CH], int lane) {
+    static_assert(CH <= 16, "one butterfly");
+    float b[8], c[4], d[2];
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (h5 ? part[8 + j] : part[j]) + __shfl_xor(h5 ? part[j] : part[8 + j], 32, 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = (h4 ? b[4 + j] : b[j]) + __shfl_xor(h4 ? b[j] : b[4 + j], 16, 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) d[j] = (h3 ? c[2 + j] : c[j]) + __shfl_xor(h3 ? c[j] : c[2 + j], 8, 64);
+    float e = (h2 ? d[1] : d[0]) + __shfl_xor(h2 ? d[0] : d[1], 4, 64);
+    e += __shfl_xor(e, 2, 64);
+    e += __shfl_xor(e, 1, 64);      // lane l: total of entry ((l>>5)&1)*8 + ((l>>4)&1)*4 + ((l>>3)&1)*2 + ((l>>2)&1)
+#pragma unroll
+    for (int u = 0; u < CH; ++u) tot[u] = __shfl(e, ((u >> 3) & 1) * 32 + ((u >> 2) & 1) * 16 + ((u >> 1) & 1) * 8 + (u & 1) * 4, 64);
+}
+
 __global__ __launch_bounds__(256) void tconv_fwd_kernel(const float* __restrict__ qkvs, int ld, int F, int N,
                                                         float scale, const int32_t* __restrict__ in_ptr,
                                                         const int32_t* __restrict__ in_src, float* __restrict__ out,
@@ -150,10 +169,13 @@ __global__ __launch_bounds__(256) void tconv_fwd_kernel(const float* __restrict_
             k[u] = ldrow(qkvs + F, sj, ld, c0, c1);
             v[u] = ldrow(qkvs + 2 * F, sj, ld, c0, c1);
         }
-        float sc[CH];
+        float sc[CH], part[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part[u] = u < CH ? q0 * k[u < CH ? u : 0].a + q1 * k[u < CH ? u : 0].b : 0.f;
+        wave_sums_ch(part, sc, lane);
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            sc[u] = wave_sum(q0 * k[u].a + q1 * k[u].b) * scale;
+            sc[u] *= scale;
             if (u < nwin) mx = fmaxf(mx, sc[u]);
         }
 #pragma unroll
@@ -268,10 +290,12 @@ __global__ __launch_bounds__(256) void tconv_bwd_target_kernel(const float* __re
             v[u] = ldrow(qkvs + 2 * F, sj, ld, c0, c1);
             kk[u] = ldrow(qkvs + F, sj, ld, c0, c1);
         }
-        float da[CH], al[CH], t = 0.f;
+        float da[CH], al[CH], part[16], t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part[u] = u < CH ? g0 * v[u < CH ? u : 0].a + g1 * v[u < CH ? u : 0].b : 0.f;
+        wave_sums_ch(part, da, lane);
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            da[u] = wave_sum(g0 * v[u].a + g1 * v[u].b);
             al[u] = u < nwin ? __shfl(my_al, u, 64) : 0.f;
             t += al[u] * da[u];
         }
