@@ -20,11 +20,12 @@ struct Lane4 {
 };
 
 __device__ __forceinline__ Lane4 load4(const float* row, int F, int lane) {
-    Lane4 r;
+    Lane4 r;   // unconditional (clamped) loads, masked by multiplication: a guarded load is a branch + a wait
 #pragma unroll
-    for (int u = 0; u < 4; ++u) r.v[u] = lane + 64 * u < F ? row[lane + 64 * u] : 0.f;
+    for (int u = 0; u < 4; ++u) r.v[u] = row[min(lane + 64 * u, F - 1)] * (lane + 64 * u < F ? 1.f : 0.f);
     return r;
 }
+constexpr int EB = 8;   // edges per load batch: the rows of 8 edges are requested before the first is used
 __device__ __forceinline__ float dot4(const Lane4& a, const Lane4& b) {
     return a.v[0] * b.v[0] + a.v[1] * b.v[1] + a.v[2] * b.v[2] + a.v[3] * b.v[3];
 }
@@ -49,11 +50,20 @@ __global__ __launch_bounds__(256) void edge_att_fwd_kernel(const float* __restri
     const int e0 = out_ptr[j], e1 = out_ptr[j + 1];
     const int head = min(e1 - e0, 64);  // lane l keeps the score of out-edge l (window graphs: degree <= 21)
     float mx = -INFINITY, mine = -INFINITY;
-    for (int e = e0; e < e1; ++e) {
-        const float s = wave_sum(dot4(load4(att + (int64_t)out_dst[e] * lda, F, lane), xj));
-        mx = fmaxf(mx, s);
-        if (e - e0 == lane) mine = s;
+    const int my_dst = out_dst[e0 + min(lane, max(head - 1, 0))];
+    for (int base = 0; base < head; base += EB) {       // the first 64 out-edges, 8 attention rows in flight
+        Lane4 a[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) a[u] = load4(att + (int64_t)__shfl(my_dst, min(base + u, head - 1), 64) * lda, F, lane);
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            const float s = wave_sum(dot4(a[u], xj));
+            if (base + u < head) mx = fmaxf(mx, s);
+            if (base + u == lane) mine = s;
+        }
     }
+    for (int e = e0 + 64; e < e1; ++e)  // degree > 64: the maximum over the rest
+        mx = fmaxf(mx, wave_sum(dot4(load4(att + (int64_t)out_dst[e] * lda, F, lane), xj)));
     const float pexp = lane < head ? expf(mine - mx) : 0.f;
     float den = wave_sum(pexp);
     for (int e = e0 + 64; e < e1; ++e)  // degree > 64: recompute
@@ -80,13 +90,23 @@ __global__ __launch_bounds__(256) void edge_att_bwd_source_kernel(const float* _
     for (int e = e0 + lane; e < e1; e += 64) t += norm[out_eid[e]] * dnorm[out_eid[e]];
     t = wave_sum(t);
     Lane4 acc = {{0.f, 0.f, 0.f, 0.f}};
-    for (int e = e0; e < e1; ++e) {
-        const int id = out_eid[e];
-        const float ds = norm[id] * (dnorm[id] - t);
-        if (lane == 0) dscore[id] = ds;
-        const Lane4 a = load4(att + (int64_t)out_dst[e] * lda, F, lane);
+    for (int w0 = e0; w0 < e1; w0 += 64) {      // lane-parallel edge metadata, then 8 attention rows per batch
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int id = out_eid[el], my_dst = out_dst[el];
+        const float my_ds = lane < nwin ? norm[id] * (dnorm[id] - t) : 0.f;
+        if (lane < nwin) dscore[id] = my_ds;
+        for (int base = 0; base < nwin; base += EB) {
+            Lane4 a[EB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc.v[u] += ds * a.v[u];
+            for (int u = 0; u < EB; ++u) a[u] = load4(att + (int64_t)__shfl(my_dst, min(base + u, nwin - 1), 64) * lda, F, lane);
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const float ds = __shfl(my_ds, min(base + u, 63), 64) * (base + u < nwin ? 1.f : 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc.v[q] += ds * a[u].v[q];
+            }
+        }
     }
     float* d = dx + (int64_t)j * lddx;
 #pragma unroll
@@ -103,11 +123,23 @@ __global__ __launch_bounds__(256) void edge_att_bwd_target_kernel(const float* _
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (k >= N) return;
     Lane4 acc = {{0.f, 0.f, 0.f, 0.f}};
-    for (int e = in_ptr[k]; e < in_ptr[k + 1]; ++e) {
-        const float ds = dscore[e];
-        const Lane4 xs = load4(x + (int64_t)in_src[e] * ldx, F, lane);
+    const int e0 = in_ptr[k], e1 = in_ptr[k + 1];
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_src = in_src[el];
+        const float my_ds = lane < nwin ? dscore[el] : 0.f;
+        for (int base = 0; base < nwin; base += EB) {
+            Lane4 xs[EB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc.v[u] += ds * xs.v[u];
+            for (int u = 0; u < EB; ++u) xs[u] = load4(x + (int64_t)__shfl(my_src, min(base + u, nwin - 1), 64) * ldx, F, lane);
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const float ds = __shfl(my_ds, min(base + u, 63), 64) * (base + u < nwin ? 1.f : 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc.v[q] += ds * xs[u].v[q];
+            }
+        }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -350,10 +382,21 @@ __global__ __launch_bounds__(256) void csr_sum_kernel(const float* __restrict__ 
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= N) return;
     Lane4 acc = {{0.f, 0.f, 0.f, 0.f}};
-    for (int e = ptr[i]; e < ptr[i + 1]; ++e) {
-        const Lane4 v = load4(x + (int64_t)idx[e] * ldx, F, lane);
+    const int e0 = ptr[i], e1 = ptr[i + 1];
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int my_idx = idx[w0 + min(lane, nwin - 1)];
+        for (int base = 0; base < nwin; base += EB) {
+            Lane4 v[EB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc.v[u] += v.v[u];
+            for (int u = 0; u < EB; ++u) v[u] = load4(x + (int64_t)__shfl(my_idx, min(base + u, nwin - 1), 64) * ldx, F, lane);
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const float m = base + u < nwin ? 1.f : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc.v[q] += m * v[u].v[q];
+            }
+        }
     }
     float* o = out + (int64_t)i * ldo;
 #pragma unroll
