@@ -88,7 +88,8 @@ _SIGS = {
     "erc_gemm_f32_planes": (C.c_int, [_vp, _i, _i64, _vp, _i, _i64, _vp, _i, _i, _i, _i, _i, _i, _i64, _i, _vp]),
     "erc_mm_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_mm_flatten": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
-    "erc_mm_emb_grad": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "erc_mm_emb_grad": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "erc_mm_emb_grad_ws_floats": (_i64, [_i]),
     "erc_mm_row_normalize": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
     "erc_mm_row_normalize_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp]),
     "erc_mm_adj_finish": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -384,8 +385,12 @@ def mm_flatten(src, lds, row_map, emb, spk, N, dst, ldd):
     _call("erc_mm_flatten", src, lds, row_map, emb, spk, N, dst, ldd)
 
 
-def mm_emb_grad(dl, ld, spk, N, S, demb):
-    _call("erc_mm_emb_grad", dl, ld, spk, N, S, demb)
+def mm_emb_grad_ws_floats(S):
+    return int(lib().erc_mm_emb_grad_ws_floats(S))
+
+
+def mm_emb_grad(dl, ld, spk, N, S, demb, ws):
+    _call("erc_mm_emb_grad", dl, ld, spk, N, S, demb, ws)
 
 
 def mm_row_normalize(x, R, xhat, inv):

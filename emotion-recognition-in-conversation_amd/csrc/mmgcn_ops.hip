@@ -74,15 +74,15 @@ __global__ __launch_bounds__(256) void flatten_kernel(const float* __restrict__ 
     for (int c = lane; c < FD; c += 64) dst[(int64_t)i * ldd + c] = s[c] + (e ? e[c] : 0.f);
 }
 
-// demb[s, :] = sum_{i: spk[i]==s} dl[i, :]   (one workgroup per speaker, fixed order).  1024 threads = 4 row
-// partitions x 256 columns; rows are read 8 at a time unconditionally and masked by multiplication (a guarded load per
-// row made this a chain of N dependent round trips: 152 us at N = 1040).
-__global__ __launch_bounds__(1024) void emb_grad_kernel(const float* __restrict__ dl, int ld, const int32_t* __restrict__ spk,
-                                                        int N, float* __restrict__ demb) {
-    __shared__ float sh[4][256];
-    const int s = blockIdx.x, c = threadIdx.x & 255, part = threadIdx.x >> 8;
+// demb[s, :] = sum_{i: spk[i]==s} dl[i, :], fixed order, two stages: EG_CH row chunks per speaker into ws, then their sum.
+// Rows are read 8 at a time unconditionally and masked by multiplication.  (One workgroup per speaker walked all N rows
+// on 2 of the 256 CUs: 69 us at N = 920; a guarded load per row before that: 152 us.)
+constexpr int EG_CH = 32;
+__global__ __launch_bounds__(256) void emb_grad_part_kernel(const float* __restrict__ dl, int ld, const int32_t* __restrict__ spk,
+                                                             int N, float* __restrict__ part) {
+    const int s = blockIdx.x, ch = blockIdx.y, c = threadIdx.x;
     const int cc = min(c, FD - 1);
-    const int per = (N + 3) / 4, lo = part * per, hi = min(N, lo + per);
+    const int per = (N + EG_CH - 1) / EG_CH, lo = ch * per, hi = min(N, lo + per);
     float acc = 0.f;
     for (int i0 = lo; i0 < hi; i0 += 8) {
         float v[8], m[8];
@@ -95,9 +95,18 @@ __global__ __launch_bounds__(1024) void emb_grad_kernel(const float* __restrict_
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc += v[u] * m[u];
     }
-    sh[part][c] = acc;
-    __syncthreads();
-    if (part == 0 && c < FD) demb[s * FD + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+    if (c < FD) part[((int64_t)s * EG_CH + ch) * FD + c] = acc;
+}
+__global__ __launch_bounds__(256) void emb_grad_sum_kernel(const float* __restrict__ part, float* __restrict__ demb) {
+    const int s = blockIdx.x, c = threadIdx.x;
+    if (c >= FD) return;
+    float v[EG_CH];
+#pragma unroll
+    for (int ch = 0; ch < EG_CH; ++ch) v[ch] = part[((int64_t)s * EG_CH + ch) * FD + c];
+    float acc = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < EG_CH; ++ch) acc += v[ch];
+    demb[s * FD + c] = acc;
 }
 
 // xhat = x / |x| ; inv = 1/|x|
@@ -406,9 +415,12 @@ extern "C" int erc_mm_flatten(const float* src, int lds, const int32_t* row_map,
     ERC_LAUNCH_CHECK("mm_flatten");
     return ERC_OK;
 }
-extern "C" int erc_mm_emb_grad(const float* dl, int ld, const int32_t* spk, int N, int n_speakers, float* demb, void* stream) {
-    ERC_REQUIRE(dl && spk && demb && N > 0 && n_speakers > 0, "mm_emb_grad: bad arguments");
-    hipLaunchKernelGGL(emb_grad_kernel, dim3(n_speakers), dim3(1024), 0, (hipStream_t)stream, dl, ld, spk, N, demb);
+extern "C" int64_t erc_mm_emb_grad_ws_floats(int n_speakers) { return (int64_t)n_speakers * EG_CH * FD; }
+extern "C" int erc_mm_emb_grad(const float* dl, int ld, const int32_t* spk, int N, int n_speakers, float* demb, float* ws,
+                               void* stream) {
+    ERC_REQUIRE(dl && spk && demb && ws && N > 0 && n_speakers > 0, "mm_emb_grad: bad arguments");
+    hipLaunchKernelGGL(emb_grad_part_kernel, dim3(n_speakers, EG_CH), dim3(256), 0, (hipStream_t)stream, dl, ld, spk, N, ws);
+    hipLaunchKernelGGL(emb_grad_sum_kernel, dim3(n_speakers), dim3(256), 0, (hipStream_t)stream, ws, demb);
     ERC_LAUNCH_CHECK("mm_emb_grad");
     return ERC_OK;
 }

@@ -143,7 +143,8 @@ class MMGCNModule(nn.Module):
                   HI=f32(NLAYERS + 1, R3, 2 * FD), HD=f32(NLAYERS + 2, R3, FD), FE=f32(N, Mo * 2 * FD), logits=f32(N, C),
                   stats=torch.zeros(256, dtype=torch.float32, device=device), dlogits=f32(N, C), dFE=f32(N, Mo * 2 * FD), dXD=f32(R3, FD), DH=f32(R3, FD),
                   dG=f32(NLAYERS + 1, R3, FD), dHIa=f32(NLAYERS + 1, R3, FD), dH0=f32(R3, FD),
-                  dADJs=f32(KSPLIT, B * Mo, P, P), dH0s=f32(KSPLIT + 1, R3, FD), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
+                  dADJs=f32(KSPLIT, B * Mo, P, P), dH0s=f32(KSPLIT + 1, R3, FD),
+                  emb_ws=f32(capi.mm_emb_grad_ws_floats(self.n_speakers)), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
                   Gb=f32(B * Mo, P, P), GC=f32(B, Mo * Mo, P), dXH=f32(R3, FD), dX=f32(R3, FD),
                   dLIN={m: f32(TB, FD) for m in self.order}, dLL=f32(TB, FD))
         dmax = max(self.dims[m] for m in self.order)
@@ -302,7 +303,8 @@ class MMGCNModule(nn.Module):
             capi.gather_rows(dm, FD, ws["node_row"], N, FD, dpad, FD, scatter=1)
             dlin = dpad
             if m == "t":
-                capi.mm_emb_grad(dm, FD, ws["node_spk"], N, self.n_speakers, fp.g("graph_model.speaker_embeddings.weight"))
+                capi.mm_emb_grad(dm, FD, ws["node_spk"], N, self.n_speakers, fp.g("graph_model.speaker_embeddings.weight"),
+                                 ws["emb_ws"])
                 self.lstm.backward(pl, dpad, FD, dx=ws["dLL"], lddx=FD)
                 dlin = ws["dLL"]
             x = feats[m].reshape(TB, self.dims[m])

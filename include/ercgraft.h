@@ -515,7 +515,9 @@ int erc_mm_meta(const int64_t* lengths, const float* qmask, int64_t q_st, int64_
 /* simple_batch_graphify (mmgcn_utils.py:5-21) [+ speaker embedding add, mmgcn_models.py:540-545]; F = 200 */
 int erc_mm_flatten(const float* src, int lds, const int32_t* row_map, const float* emb, const int32_t* spk, int N,
                    float* dst, int ldd, void* stream);
-int erc_mm_emb_grad(const float* dl, int ld, const int32_t* spk, int N, int n_speakers, float* demb, void* stream);
+int64_t erc_mm_emb_grad_ws_floats(int n_speakers);   /* floats of `ws` below */
+int erc_mm_emb_grad(const float* dl, int ld, const int32_t* spk, int N, int n_speakers, float* demb, float* ws,
+                    void* stream);
 int erc_mm_row_normalize(const float* x, int R, float* xhat, float* inv, void* stream);
 int erc_mm_row_normalize_bwd(const float* xhat, const float* inv, const float* dxhat, int R, float* dx, void* stream);
 /* COS blocks (raw cosines, form-1 grouped GEMM of xhat) -> sim = 1 - acos(0.99999 cos)/pi, cross-modal
