@@ -57,11 +57,20 @@ __global__ __launch_bounds__(NTH) void lstm_fwd_kernel(LstmP p) {
     if (p.Hdrop && p.drop_p > 0.f) roff = p.rng[0], rseed = p.rng[1] ^ p.rng_stream;
     const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     __syncthreads();
+    // the hoisted gate pre-activation of step s + 1 is requested while step s runs: its (L2) latency was the longest
+    // item on the per-step critical path
+    const int gcol = d * G4 + min(tid, G4 - 1);
+    float gx_next = L > 0 ? p.GX[row_of(p, b, d == 0 ? 0 : L - 1) * p.ldgx + gcol] : 0.f;
     for (int s = 0; s < L; ++s) {
         const int t = d == 0 ? s : L - 1 - s;
         const int64_t row = row_of(p, b, t);
+        const float gx = gx_next;
+        {
+            const int sn = min(s + 1, L - 1);
+            gx_next = p.GX[row_of(p, b, d == 0 ? sn : L - 1 - sn) * p.ldgx + gcol];
+        }
         if (tid < G4) {
-            float a = p.GX[row * p.ldgx + d * G4 + tid] + bhh;
+            float a = gx + bhh;
 #pragma unroll
             for (int k = 0; k < H; ++k) a += w[k] * s_h[k];
             const float act = (tid >= 2 * H && tid < 3 * H) ? tanhf(a) : sigm(a);
@@ -118,24 +127,40 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_kernel(LstmP p) {
     if (dropped) roff = p.rng[0], rseed = p.rng[1] ^ p.rng_stream;
     const float keep_scale = dropped ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     __syncthreads();
+    // operands of a step (upstream gradient, the four gates, cell state and previous cell state): requested one step
+    // ahead, unconditionally (clamped rows), consumed from registers
+    struct StepIn { float g, gi, gf, gg, go, c, cprev; };
+    const int hc = min(tid, H - 1);
+    auto fetch = [&](int s) {
+        StepIn r;
+        const int sc = max(s, 0);
+        const int t = d == 0 ? sc : L - 1 - sc;
+        const int64_t row = row_of(p, b, t);
+        r.g = p.dHout[row * p.lddh + d * H + hc];
+        const float* gt = p.gates + row * 2 * G4 + d * G4;
+        r.gi = gt[hc], r.gf = gt[H + hc], r.gg = gt[2 * H + hc], r.go = gt[3 * H + hc];
+        r.c = p.Cst[row * 2 * H + d * H + hc];
+        const int sp = max(sc - 1, 0);
+        const int tp = d == 0 ? sp : L - 1 - sp;
+        r.cprev = p.Cst[row_of(p, b, tp) * 2 * H + d * H + hc] * (sc > 0 ? 1.f : 0.f);
+        return r;
+    };
+    StepIn nxt = fetch(L - 1);
     for (int s = L - 1; s >= 0; --s) {
         const int t = d == 0 ? s : L - 1 - s;
         const int64_t row = row_of(p, b, t);
+        const StepIn cur = nxt;
+        nxt = fetch(s - 1);
         if (tid < H) {
-            float g = p.dHout[row * p.lddh + d * H + tid];
+            float g = cur.g;
             if (dropped) {
                 const float u = erc_uniform(rseed, roff, (uint64_t)row * 2 * H + d * H + tid);
                 g = u >= p.drop_p ? g * keep_scale : 0.f;
             }
             const float dh = g + s_dh[tid];
-            const float* gt = p.gates + row * 2 * G4 + d * G4;
-            const float gi = gt[tid], gf = gt[H + tid], gg = gt[2 * H + tid], go = gt[3 * H + tid];
-            const float c = p.Cst[row * 2 * H + d * H + tid];
-            float cprev = 0.f;
-            if (s > 0) {
-                const int tp = d == 0 ? s - 1 : L - s;
-                cprev = p.Cst[row_of(p, b, tp) * 2 * H + d * H + tid];
-            }
+            const float gi = cur.gi, gf = cur.gf, gg = cur.gg, go = cur.go;
+            const float c = cur.c;
+            const float cprev = cur.cprev;
             const float tc = tanhf(c);
             const float dc = s_dc[tid] + dh * go * (1.f - tc * tc);
             const float dpi = dc * gg * gi * (1.f - gi);
