@@ -98,7 +98,7 @@ def test_cluster_scan_equals_single_workgroup_scan(monkeypatch):
     dims = dict(a=30, t=60, v=34)
     batch = make_batch(6, dims, n_speakers=3, n_classes=5, min_len=2, max_len=37, seed=4, speaker_onehot=True, force_max=True)
     res = {}
-    for P in (1, 4, 8):
+    for P in (1, 4, 8, 16):
         monkeypatch.setenv("ERC_DAG_CLUSTER", str(P))
         torch.manual_seed(9)
         m = DAGERCModule(emb_dim=sum(dims.values()), dropout=0.0, n_classes=5, gnn_layers=2).finalize(DEV)
@@ -108,7 +108,7 @@ def test_cluster_scan_equals_single_workgroup_scan(monkeypatch):
         assert ws["cluster"] == min(P, capi.dag_cluster_size(6))
         m.check_cluster()
         res[P] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone())
-    for P in (4, 8):
+    for P in (4, 8, 16):
         assert abs(res[P][0] - res[1][0]) < 1e-6
         assert float((res[P][1] - res[1][1]).abs().max()) <= 2e-6 * max(1.0, float(res[1][1].abs().max()))
         assert float((res[P][2] - res[1][2]).abs().max()) <= 1e-6 * max(1.0, float(res[1][2].abs().max()))

@@ -331,3 +331,12 @@ def test_chained_training_is_reproducible_and_learns():
     # the trained encoder weights reach the state dict under the reference's names
     sd = tr.model.state_dict()
     assert "rnn.0.layers.0.self_attn.in_proj_weight" in sd
+
+
+def test_training_attention_rejects_long_sequences():
+    """The matrix-core attention holds one sequence per workgroup (S <= 128): longer ones are refused, not truncated."""
+    from erc_amd import capi
+    qkv = torch.zeros(2 * 130, 3 * 24, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(2 * 130, 24, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(capi.ErcGraftError):
+        capi.enc_attention_train(qkv, 2, 130, 24, 6, None, 0.0, None, 0, out)
