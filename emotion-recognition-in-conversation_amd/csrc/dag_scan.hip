@@ -438,6 +438,7 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
     const int T = p.T, P = cl.P;
     __shared__ __attribute__((aligned(16))) float v_m[320], v_h[320], v_x[320], gates[2 * G3], s_alpha[MAX_T];
     __shared__ float s_ks[MAX_T];            // key scores of the steps done so far (one sc1 load per step keeps it current)
+    __shared__ float s_rl[2 * HID + 8];      // the relation row of the previous step, as it arrives from the exchange
     __shared__ int s_spk[MAX_T], s_pred[MAX_T];
     for (int t = tid; t < T; t += CNT) s_spk[t] = p.spk[(int64_t)b * T + t], s_pred[t] = p.pred[(int64_t)b * T + t];
     const float* w_q = p.w_lin;
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
         wait_tagged<2>(xr, idx, tag, v, cl.err);
         float* rrow = p.R + ((int64_t)b * T + j) * 2 * HID;
         rrow[tid] = v[0];
-        if (tid + CNT < 2 * HID) rrow[tid + CNT] = v[1];
+        s_rl[tid] = v[0];
+        if (tid + CNT < 2 * HID) rrow[tid + CNT] = v[1], s_rl[tid + CNT] = v[1];
         if (tid + CNT == 2 * HID) {
             s_ks[j] = v[1];
             if (mem == 0) p.ks[(int64_t)b * T + j] = v[1];
@@ -475,6 +477,22 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
             const float* gi = p.GI + row * 2 * G3;
 #pragma unroll
             for (int u = 0; u < 6; ++u) gi_r[u] = gi[u * HID + tid];
+        }
+        // the window's OLDER relation rows (steps < i - 1: stored by this member itself in earlier steps) are requested
+        // before the wait for the exchange of step i - 1; that newest row is then taken from LDS (s_rl)
+        float rv_pre[8];
+        {
+            const int pr0 = i > 0 ? s_pred[i] : 0;
+            const int lo0 = pr0 > 0 ? pr0 : 0, nold0 = i > 0 ? i - 1 - lo0 : 0, si0 = s_spk[i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                // slots past the window read a read-only address instead: touching a row of R BEFORE it is written
+                // would leave a stale line in this CU's L1 for the later, legitimate read
+                const int tj = lo0 + min(u, max(nold0 - 1, 0));
+                const float* src = u < nold0 ? p.R + ((int64_t)b * T + tj) * 2 * HID + (s_spk[tj] == si0 ? 0 : HID) + min(tid, HID - 1)
+                                             : p.GI + row * 2 * G3;
+                rv_pre[u] = *src;
+            }
         }
         if (i > 0) take_row(i - 1);
         __syncthreads();
@@ -510,17 +528,21 @@ __global__ __launch_bounds__(CNT) void dag_scan_fwd_cluster_kernel(DagFwd p, Dag
             __syncthreads();
             if (tid < HID) {
                 const int si = s_spk[i];
+                const int nold = n - 1;                  // rows lo .. i - 2; row i - 1 comes from s_rl
                 float m = 0.f;
-                for (int j0 = 0; j0 < n; j0 += 8) {      // 8 predecessor rows in flight
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m += (u < nold ? s_alpha[u] : 0.f) * rv_pre[u];
+                for (int j0 = 8; j0 < nold; j0 += 8) {   // longer windows: 8 more rows in flight
                     float rv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int tj = lo + min(j0 + u, n - 1);
+                        const int tj = lo + min(j0 + u, nold - 1);
                         rv[u] = p.R[((int64_t)b * T + tj) * 2 * HID + (s_spk[tj] == si ? 0 : HID) + tid];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) m += (j0 + u < n ? s_alpha[j0 + u] : 0.f) * rv[u];
+                    for (int u = 0; u < 8; ++u) m += (j0 + u < nold ? s_alpha[j0 + u] : 0.f) * rv[u];
                 }
+                m += s_alpha[n - 1] * s_rl[(s_spk[i - 1] == si ? 0 : HID) + tid];
                 v_m[tid] = m;
                 if (mem == 0) p.Mseq[row * HID + tid] = m;
             }
