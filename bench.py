@@ -211,7 +211,7 @@ def main():
         total_utt = float(cnt.item())
     else:
         total_utt = float(n_utt)
-    stats = trainer.model._ws[next(iter(trainer.model._ws))]["stats"].cpu().tolist()
+    stats = trainer.model._last_ws["stats"].cpu().tolist()
 
     # ---------------------------------------------------------------- dominant kernel, HIP events on its stream
     roof = None

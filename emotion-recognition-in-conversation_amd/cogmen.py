@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from . import capi
-from .engine import FlatParams, FusedAdam, GemmPlanner, SideStream, all_reduce_grads, linear_fwd, linear_wgrad, \
+from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, SideStream, all_reduce_grads, linear_fwd, linear_wgrad, \
     matmul_wgrad_io
 
 F_HID = 100
@@ -92,7 +92,7 @@ class COGMENModule(nn.Module):
         self.drop_p = 0.5
         self.fuse_head = True   # training path: csrc/head.hip instead of separate BN / Linear / CE launches
         self.flat = None
-        self._ws = {}
+        self._ws = WorkspaceCache()
         self._seed = seed
 
     # ------------------------------------------------------------------ setup
@@ -133,11 +133,15 @@ class COGMENModule(nn.Module):
         self.w1_shadow = w.to(torch.bfloat16).contiguous()
         optim.shadow = (self.w1_shadow, self.flat.offsets["rnn.1.weight"], w.numel())
 
+    @property
+    def _last_ws(self):
+        """workspace of the most recent forward (tests / bench read results out of it)"""
+        return self._ws.last
+
     def _workspace(self, B, T, N, device):
-        key = (B, T, N)
-        ws = self._ws.get(key)
-        if ws is not None:
-            return ws
+        return self._ws.get((B, T, N), lambda: self._make_workspace(B, T, N, device))
+
+    def _make_workspace(self, B, T, N, device):
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
         E = N * (WP + WF + 1)
@@ -158,14 +162,15 @@ class COGMENModule(nn.Module):
         slab = 16 * N * F + 8 * (F * D + 9 * F * F + 4 * F * F + 2 * F * F) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
-        self._ws[key] = ws
         return ws
 
     # ---------------------------------------------------------------- forward
-    def _shape(self, input_tensor, text_length, label):
+    def _shape(self, input_tensor, text_length, label, n_nodes=None):
         B, T = input_tensor.shape[0], input_tensor.shape[1]
         if label is not None:
             N = int(label.shape[0])          # label is [N]: no device sync needed
+        elif n_nodes is not None:
+            N = int(n_nodes)                 # host-side count stashed by prepare_batch: no device sync either
         else:
             N = int(text_length.sum().item())
         return B, T, N
@@ -215,7 +220,7 @@ class COGMENModule(nn.Module):
     def forward(self, input_tensor, speaker_tensor, text_length, *args, label=None, **kwargs):
         if self.flat is None:
             raise capi.ErcGraftError("call COGMENModule.finalize(device) before forward")
-        B, T, N = self._shape(input_tensor, text_length, label)
+        B, T, N = self._shape(input_tensor, text_length, label, kwargs.get("n_nodes"))
         ws = self._forward_impl(input_tensor, speaker_tensor, text_length, B, T, N, self.training)
         return ws["logits"], ws["H0"]
 
@@ -298,7 +303,7 @@ class COGMENModule(nn.Module):
         self.gcn.bn.num_batches_tracked.fill_(int(optimizer_steps))
 
     def last_graph(self, B, T, N):
-        return self._ws[(B, T, N)]["g"]
+        return self._workspace(B, T, N, self.flat.device)["g"]
 
     def dominant_kernel_probe(self, batch, reps=200):
         """Time the HBM-dominant kernel of the step -- the input projection H0 = X[node_row] W1^T, the only
@@ -402,6 +407,9 @@ class COGMENTrainer:
 
     def prepare_batch(self, batch):
         out = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        tl = batch.get("text_length")
+        if "n_nodes" not in out and torch.is_tensor(tl) and not tl.is_cuda:
+            out["n_nodes"] = int(tl.sum())      # host tensor: no device sync when a batch carries no labels
         if self.model.compute == "bf16":
             out["input_tensor"] = out["input_tensor"].to(torch.bfloat16)
         return out

@@ -17,7 +17,7 @@ import torch
 from torch import nn
 
 from . import capi
-from .engine import FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad
+from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad
 
 HID = 300
 
@@ -55,7 +55,7 @@ class DAGERCModule(nn.Module):
                                      nn.Dropout(dropout), nn.Linear(HID, n_classes))
         self.attentive_node_features = _Attentive(in_dim)
         self.flat = None
-        self._ws = {}
+        self._ws = WorkspaceCache()
         self._seed = seed
 
     # ------------------------------------------------------------------ setup
@@ -83,11 +83,15 @@ class DAGERCModule(nn.Module):
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
         return self
 
+    @property
+    def _last_ws(self):
+        """workspace of the most recent forward (tests / bench read results out of it)"""
+        return self._ws.last
+
     def _workspace(self, B, T, N, device):
-        key = (B, T, N)
-        ws = self._ws.get(key)
-        if ws is not None:
-            return ws
+        return self._ws.get((B, T, N), lambda: self._make_workspace(B, T, N, device))
+
+    def _make_workspace(self, B, T, N, device):
         BT, L, C, D = B * T, self.gnn_layers, self.n_classes, self.emb_dim
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
@@ -113,7 +117,6 @@ class DAGERCModule(nn.Module):
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
-        self._ws[key] = ws
         return ws
 
     def check_cluster(self):
@@ -125,9 +128,9 @@ class DAGERCModule(nn.Module):
                 raise capi.ErcGraftError("DAG-ERC cluster scan timed out waiting for a member workgroup (B,T,N=%s); "
                                          "rerun with ERC_DAG_CLUSTER=1" % (key,))
 
-    def _shape(self, input_tensor, text_length, label):
+    def _shape(self, input_tensor, text_length, label, n_nodes=None):
         B, T = input_tensor.shape[0], input_tensor.shape[1]
-        N = int(label.shape[0]) if label is not None else int(text_length.sum().item())
+        N = int(label.shape[0]) if label is not None else (int(n_nodes) if n_nodes is not None else int(text_length.sum().item()))
         return B, T, N
 
     def _layer_w(self, l):
@@ -190,7 +193,7 @@ class DAGERCModule(nn.Module):
     def forward(self, input_tensor, text_length, speaker_tensor, label=None, **kwargs):
         if self.flat is None:
             raise capi.ErcGraftError("call DAGERCModule.finalize(device) before forward")
-        B, T, N = self._shape(input_tensor, text_length, label)
+        B, T, N = self._shape(input_tensor, text_length, label, kwargs.get("n_nodes"))
         ws = self._forward_impl(input_tensor, speaker_tensor, text_length, B, T, N, self.training)
         return ws["logits"].view(B, T, self.n_classes), None
 
@@ -266,6 +269,9 @@ class DAGERCTrainer:
 
     def prepare_batch(self, batch):
         out = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        tl = batch.get("text_length")
+        if "n_nodes" not in out and torch.is_tensor(tl) and not tl.is_cuda:
+            out["n_nodes"] = int(tl.sum())      # host tensor: no device sync when a batch carries no labels
         if self.model.compute == "bf16":
             out["input_tensor"] = out["input_tensor"].to(torch.bfloat16)
         return out

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from . import capi
-from .engine import FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
+from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
     matmul_wgrad_io
 from .rnn import BiLSTM2, lstm_groups
 
@@ -86,7 +86,7 @@ class DGCNModule(nn.Module):
         self.edge_att = _EdgeAtt(hidden_size)
         self.gcn = _GCN(hidden_size, H1, H1, n_speakers)
         self.clf = _Classifier(hidden_size + H1, 100, n_classes, dropout)
-        self.flat, self._ws, self._seed = None, {}, seed
+        self.flat, self._ws, self._seed = None, WorkspaceCache(), seed
 
     def live_groups(self):
         g, c = self.gcn, self.clf
@@ -107,11 +107,15 @@ class DGCNModule(nn.Module):
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
         return self
 
+    @property
+    def _last_ws(self):
+        """workspace of the most recent forward (tests / bench read results out of it)"""
+        return self._ws.last
+
     def _workspace(self, B, T, N, device):
-        key = (B, T, N)
-        ws = self._ws.get(key)
-        if ws is not None:
-            return ws
+        return self._ws.get((B, T, N), lambda: self._make_workspace(B, T, N, device))
+
+    def _make_workspace(self, B, T, N, device):
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
         w = (self.wp if self.wp >= 0 else T) + (self.wf if self.wf >= 0 else T) + 1
@@ -129,12 +133,11 @@ class DGCNModule(nn.Module):
             8 * (G_DIM * G_DIM + 300 * 100) + (1 << 21)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
-        self._ws[key] = ws
         return ws
 
-    def _shape(self, x, lens, label):
+    def _shape(self, x, lens, label, n_nodes=None):
         B, T = x.shape[0], x.shape[1]
-        N = int(label.shape[0]) if label is not None else int(lens.sum().item())
+        N = int(label.shape[0]) if label is not None else (int(n_nodes) if n_nodes is not None else int(lens.sum().item()))
         return B, T, N
 
     def _forward_impl(self, x, spk, lens, B, T, N, training):
@@ -178,7 +181,7 @@ class DGCNModule(nn.Module):
     def forward(self, input_tensor, speaker_tensor, text_length, label=None, **kwargs):
         if self.flat is None:
             raise capi.ErcGraftError("call DGCNModule.finalize(device) before forward")
-        B, T, N = self._shape(input_tensor, text_length, label)
+        B, T, N = self._shape(input_tensor, text_length, label, kwargs.get("n_nodes"))
         ws = self._forward_impl(input_tensor, speaker_tensor, text_length, B, T, N, self.training)
         return ws["logits"], ws["Xc"][:, G_DIM:]
 
@@ -259,6 +262,9 @@ class DGCNTrainer:
 
     def prepare_batch(self, batch):
         out = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        tl = batch.get("text_length")
+        if "n_nodes" not in out and torch.is_tensor(tl) and not tl.is_cuda:
+            out["n_nodes"] = int(tl.sum())      # host tensor: no device sync when a batch carries no labels
         if self.model.compute == "bf16":
             out["input_tensor"] = out["input_tensor"].to(torch.bfloat16)
         return out

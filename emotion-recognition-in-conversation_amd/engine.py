@@ -13,7 +13,6 @@
   gradient all-reduce over RCCL).
 """
 import math
-
 import os
 
 import torch
@@ -21,6 +20,47 @@ import torch
 from . import capi
 
 ALIGN = 64  # floats: every group starts on a 256-byte boundary
+
+
+class WorkspaceCache:
+    """Per-module workspace sets keyed by batch shape, least-recently-used eviction.  In the real training loop
+    (shuffled batches, smaller last batch: mmbase.py:468) the number of valid utterances N changes almost every step;
+    an unbounded ``dict`` of (B, T, N) -> workspace would grow by hundreds of MB per new shape (DAG-ERC: ~350 MB).
+    ``maxsize`` shapes stay resident (env ERC_WS_CACHE); a HIP graph captured over a workspace pins it (``pin``)."""
+
+    def __init__(self, maxsize=None):
+        import collections
+        self.maxsize = int(os.environ.get("ERC_WS_CACHE", 4)) if maxsize is None else maxsize
+        self._d = collections.OrderedDict()
+        self._pinned = set()
+        self.last = None
+
+    def get(self, key, make):
+        ws = self._d.get(key)
+        if ws is None:
+            ws = make()
+            self._d[key] = ws
+            while len(self._d) - len(self._pinned) > self.maxsize:
+                victim = next((k for k in self._d if k not in self._pinned and k != key), None)
+                if victim is None:
+                    break
+                del self._d[victim]
+        else:
+            self._d.move_to_end(key)
+        self.last = ws
+        return ws
+
+    def pin(self, key):
+        self._pinned.add(key)
+
+    def values(self):
+        return list(self._d.values())
+
+    def items(self):
+        return list(self._d.items())
+
+    def __len__(self):
+        return len(self._d)
 
 
 class FlatParams:

@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import capi
-from .engine import FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
+from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
     matmul_wgrad_io
 from .rnn import BiLSTM2, lstm_groups
 
@@ -103,7 +103,7 @@ class MMGCNModule(nn.Module):
         self.gatedatt = _Holder(gated)
         self.smax_fc = nn.Linear(2 * FD * len(modals), n_classes)
         self.drop_p = DROP
-        self.flat, self._ws, self._seed = None, {}, seed
+        self.flat, self._ws, self._seed = None, WorkspaceCache(), seed
 
     def live_groups(self):
         groups = []
@@ -127,11 +127,15 @@ class MMGCNModule(nn.Module):
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
         return self
 
+    @property
+    def _last_ws(self):
+        """workspace of the most recent forward (tests / bench read results out of it)"""
+        return self._ws.last
+
     def _workspace(self, B, T, N, device):
-        key = (B, T, N)
-        ws = self._ws.get(key)
-        if ws is not None:
-            return ws
+        return self._ws.get((B, T, N), lambda: self._make_workspace(B, T, N, device))
+
+    def _make_workspace(self, B, T, N, device):
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
         Mo, C = len(self.order), self.n_classes
@@ -153,12 +157,11 @@ class MMGCNModule(nn.Module):
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["planner"].MAX_SPLIT = 8      # 128 weight-gradient GEMMs per step: keep their slab sets small
         ws["jobs"] = None
-        self._ws[key] = ws
         return ws
 
-    def _shape(self, batch_feat, lens, label):
+    def _shape(self, batch_feat, lens, label, n_nodes=None):
         T, B = batch_feat.shape[0], batch_feat.shape[1]
-        N = int(label.shape[0]) if label is not None else int(lens.sum().item())
+        N = int(label.shape[0]) if label is not None else (int(n_nodes) if n_nodes is not None else int(lens.sum().item()))
         return B, T, N
 
     @staticmethod
@@ -229,7 +232,7 @@ class MMGCNModule(nn.Module):
         if self.flat is None:
             raise capi.ErcGraftError("call MMGCNModule.finalize(device) before forward")
         feats = self._feats(dict(text_feature=text_feature, audio_feature=audio_feature, visual_feature=visual_feature))
-        B, T, N = self._shape(feats[self.order[0]], text_length, label)
+        B, T, N = self._shape(feats[self.order[0]], text_length, label, kwargs.get("n_nodes"))
         ws = self._forward_impl(feats, speaker_tensor, text_length, B, T, N, self.training)
         return ws["logits"], None
 
@@ -332,7 +335,11 @@ class MMGCNTrainer:
         return self.model(**batch)[0]
 
     def prepare_batch(self, batch):
-        return {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        out = {k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        tl = batch.get("text_length")
+        if "n_nodes" not in out and torch.is_tensor(tl) and not tl.is_cuda:
+            out["n_nodes"] = int(tl.sum())      # host tensor: no device sync when a batch carries no labels
+        return out
 
     def train_step(self, batch):
         self.model.train()

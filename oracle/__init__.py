@@ -16,10 +16,14 @@ Every function cites the reference file:line it follows.
 Pinning status (see DESIGN.md "Oracle"):
   * graph construction (window edges / relation ids / DAG adjacency / speaker
     mask), ERCCollate batch layout, DAG-ERC end-to-end logits+grads, MMGCN
-    graph model, DialogueGCN EdgeAtt / vendored RGCNConv / classifier, the
-    vendored encoder layer: PINNED by golden vectors produced by importing the
-    reference's own modules in the build container
-    (``tests/golden/make_golden.py``, fixtures committed as ``.npz``).
+    end-to-end logits+grads, DialogueGCN EdgeAtt / batch_graphify / vendored
+    RGCNConv / SeqContext / Classifier, the vendored encoder layer
+    (contrib/nn.py:206-305, two layers, with and without key-padding mask):
+    PINNED by golden vectors produced by importing the reference's own modules
+    in the build container (``tests/golden/make_golden.py`` -- one ``gen_*``
+    per item above -- fixtures committed as ``.npz``; the CPU tests
+    ``tests/test_oracle_*.py`` / ``test_host_layout.py`` hold the oracle to
+    them).
   * torch_geometric ``RGCNConv`` (mean), ``TransformerConv`` (heads=1) and
     ``GraphConv`` are third-party, unpinned (``requirements.txt:12``) and not
     installed: restated here from their published formulae ->

@@ -321,8 +321,77 @@ def gen_mmgcn(ref):
              **grad_digest([(n, q.grad) for n, q in model.named_parameters()]))
 
 
+def gen_encoder(ref):
+    """The vendored encoder layer (contrib/nn.py:206-305 over its MultiheadAttention :24-203), two layers called one
+    after the other as cogmen.py:99-101 stacks them (not through nn.TransformerEncoder, see module docstring), eval
+    mode (dropout off), with and without a key-padding mask: outputs + gradients of a weighted output sum."""
+    cn = importlib.import_module("contrib.nn")
+    g = torch.Generator().manual_seed(41)
+    for tag, B, T, D, nhead, masked in (("d24", 3, 13, 24, 6, False), ("d24_mask", 3, 13, 24, 6, True),
+                                        ("d48_h8", 2, 9, 48, 8, True), ("d712", 2, 20, 712, 8, True),
+                                        ("d712_nomask", 2, 20, 712, 8, False), ("d1380", 1, 16, 1380, 6, False)):
+        class Stack(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.layers = torch.nn.ModuleList([cn.TransformerEncoderLayer(d_model=D, nhead=nhead, dropout=0.5,
+                                                                              batch_first=True) for _ in range(2)])
+        enc = Stack()
+        fill_params(enc, 43)
+        with torch.no_grad():          # LayerNorm gains around one (the filler gives +-0.1)
+            for lyr in enc.layers:
+                lyr.norm1.weight.add_(1.0), lyr.norm2.weight.add_(1.0)
+        enc.eval()
+        x = torch.randn(B, T, D, generator=g).requires_grad_()
+        lengths = torch.randint(1, T + 1, (B,), generator=g)
+        lengths[0] = T
+        pad = (torch.arange(T)[None, :] >= lengths[:, None]) if masked else None
+        h = x
+        for lyr in enc.layers:
+            h = lyr(h, src_key_padding_mask=pad)
+        valid = ~pad if masked else torch.ones(B, T, dtype=torch.bool)
+        w = torch.randn(B, T, D, generator=g) * valid[..., None]
+        (h * w).sum().backward()
+        save("encoder_" + tag, param_seed=43, nhead=nhead, x=x.detach().numpy(), lengths=lengths.numpy(),
+             masked=np.array(masked), out=h.detach().numpy(), w=w.numpy(), dx=x.grad.numpy(),
+             **grad_digest([(n, q.grad) for n, q in enc.named_parameters()]))
+
+
+def gen_dgcn_leaves(ref):
+    """DialogueGCN leaf modules that run from the reference's own file: SeqContext (packed 2-layer BiLSTM,
+    dgcn_models.py:10-33) and Classifier (dgcn_models.py:155-170), eval mode, outputs + gradients."""
+    dm = importlib.import_module("track_mm.dgcn_models")
+    g = torch.Generator().manual_seed(51)
+    for tag, D, lens in (("d30", 30, [5, 12, 1, 9]), ("d1242", 1242, [7, 33, 2, 16])):
+        B, T = len(lens), max(lens)
+        lengths = torch.tensor(lens)
+        x = torch.randn(B, T, D, generator=g) * 0.5
+        for b, L in enumerate(lens):
+            x[b, L:] = 0
+        x.requires_grad_()
+        rnn = dm.SeqContext(D, 200)
+        fill_params(rnn, 53)
+        rnn.eval()
+        out = rnn(lengths, x)
+        w = torch.randn(out.shape, generator=g)
+        (out * w).sum().backward()
+        save("seqcontext_" + tag, param_seed=53, x=x.detach().numpy(), lengths=lengths.numpy(), out=out.detach().numpy(),
+             w=w.numpy(), dx=x.grad.numpy(), **grad_digest([("rnn." + n, q.grad) for n, q in rnn.named_parameters()]))
+    for tag, C, N in (("c6", 6, 37), ("c7", 7, 11)):
+        clf = dm.Classifier(300, 100, C, 0.4)
+        fill_params(clf, 57)
+        clf.eval()
+        h = torch.randn(N, 300, generator=g).requires_grad_()
+        logits = clf(h, None)
+        w = torch.randn(logits.shape, generator=g)
+        (logits * w).sum().backward()
+        none = [n for n, q in clf.named_parameters() if q.grad is None]
+        save("classifier_" + tag, param_seed=57, n_classes=C, h=h.detach().numpy(), logits=logits.detach().numpy(),
+             w=w.numpy(), dh=h.grad.numpy(), grad_none=np.array(none),
+             **grad_digest([("clf." + n, q.grad) for n, q in clf.named_parameters()]))
+
+
 GENERATORS = {"collate": gen_collate, "window_graph": gen_window_graph, "dagerc": gen_dagerc, "dgcn": gen_dgcn,
-              "mmgcn": gen_mmgcn}
+              "mmgcn": gen_mmgcn, "encoder": gen_encoder, "dgcn_leaves": gen_dgcn_leaves}
 
 
 def main():

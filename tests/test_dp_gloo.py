@@ -66,3 +66,63 @@ def test_flat_gradient_all_reduce_world2():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def _loop_worker(rank, world, port, n_dialogs, batch_size, q):
+    """The sharding / step-count logic of trainer.run with an odd dialogue count: every rank must issue the same number
+    of all-reduces per epoch (one per batch) or the job hangs."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from erc_amd.trainer import ListDataset, shard_dialogues
+    from torch.utils.data import DataLoader
+    dialogs = [{"id": i} for i in range(n_dialogs)]
+    mine = shard_dialogues(dialogs, rank, world)
+    loader = DataLoader(ListDataset(mine), batch_size=batch_size, shuffle=True, collate_fn=lambda s: [d for d, in s],
+                        generator=torch.Generator().manual_seed(rank))
+    steps, seen = 0, []
+    for batch in loader:                       # one gradient exchange per batch, as trainer.run does
+        t = torch.ones(3)
+        dist.all_reduce(t)
+        assert float(t[0]) == world
+        steps += 1
+        seen += [d["id"] for d in batch]
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([steps]))
+    q.put((rank, steps, [int(c) for c in counts], sorted(seen)))
+    dist.destroy_process_group()
+
+
+def test_sharded_epoch_runs_equal_steps_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n, bs, world = 259, 43, 2                   # dialogs[rank::world] gave 130 / 129 dialogues -> 4 vs 3 steps
+    procs = [ctx.Process(target=_loop_worker, args=(r, world, _free_port_shared(), n, bs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res[0][1] == res[1][1] == 4 and res[0][2] == res[1][2] == [4, 4]
+    covered = set(res[0][3]) | set(res[1][3])
+    assert covered == set(range(n))             # nothing dropped; exactly one dialogue is seen twice (the wrap)
+    assert len(res[0][3]) == len(res[1][3]) == 130
+
+
+_PORT = []
+
+
+def _free_port_shared():
+    if not _PORT:
+        _PORT.append(_free_port())
+    return _PORT[0]
+
+
+def test_shard_dialogues_properties():
+    from erc_amd.trainer import shard_dialogues
+    for n in (0, 1, 5, 120, 259):
+        for world in (1, 2, 3, 8):
+            shards = [shard_dialogues(list(range(n)), r, world) for r in range(world)]
+            assert len({len(s) for s in shards}) == 1
+            if n:
+                assert set().union(*map(set, shards)) == set(range(n))
+                assert sum(map(len, shards)) - n < world

@@ -51,6 +51,15 @@ def test_cogmen_bf16_feature_mode():
     assert res["grad_err"] < 2e-2, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:8]
 
 
+def test_cogmen_bf16_feature_mode_full_config2():
+    """The same check at the BENCHED shape: BASELINE.json configs[1], B=32, T=110, D=1380 (d_a=100 d_t=768 d_v=512),
+    bf16 feature block -- the persistent projection kernel (M >= 1024) and the gathered bf16 weight-gradient path."""
+    res = run_cogmen_parity(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=16),
+                            compute="bf16")
+    assert res["logit_err"] < 1e-3, res
+    assert res["grad_err"] < 2e-2, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:8]
+
+
 def test_cogmen_train_step_matches_torch_adam():
     """three full train steps (dropout off) == oracle + torch.optim.Adam on the same batches."""
     from oracle.cogmen import COGMENOracle, cogmen_train_step

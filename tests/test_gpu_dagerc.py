@@ -27,7 +27,7 @@ def test_dag_structure_bit_exact_vs_reference(golden, name):
     model.eval()
     model(**to_device(batch, DEV))
     B, T = batch["input_tensor"].shape[:2]
-    ws = model._ws[(B, T, int(batch["label"].shape[0]))]
+    ws = model._last_ws
     spk, pred = ws["spk"].cpu().numpy(), ws["pred"].cpu().numpy()
     adj = np.zeros((B, T, T), dtype=np.float32)
     for b in range(B):
@@ -46,7 +46,7 @@ def test_dagerc_matches_reference_golden(golden, name):
     model.train()
     stats = model.loss_and_grads(to_device(batch, DEV)).cpu()
     B, T = batch["input_tensor"].shape[:2]
-    logits = model._ws[(B, T, int(batch["label"].shape[0]))]["logits"].view(B, T, -1).cpu()
+    logits = model._last_ws["logits"].view(B, T, -1).cpu()
     assert float((logits - torch.from_numpy(fx["logits"])).abs().max()) < 1e-4
     assert abs(float(stats[0]) - float(fx["loss"])) < 1e-5
     worst = check_grad_digest(fx, [(n, model.flat.g(n)) for n in model.flat.params], tol=2e-3)
@@ -77,7 +77,7 @@ def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C):
     want, _ = ref(**batch)
     stats = mine.loss_and_grads(to_device(batch, DEV)).cpu()
     T = batch["input_tensor"].shape[1]
-    got = mine._ws[(B, T, int(batch["label"].shape[0]))]["logits"].view(B, T, -1).cpu()
+    got = mine._last_ws["logits"].view(B, T, -1).cpu()
     valid = batch["attention_mask"].bool()
     assert float((got[valid] - want.detach()[valid]).abs().max()) < 1e-4
     assert float((got - want.detach()).abs().max()) < 1e-4              # padded rows too (finite garbage, same garbage)
@@ -104,7 +104,7 @@ def test_cluster_scan_equals_single_workgroup_scan(monkeypatch):
         m = DAGERCModule(emb_dim=sum(dims.values()), dropout=0.0, n_classes=5, gnn_layers=2).finalize(DEV)
         m.train()
         stats = m.loss_and_grads(to_device(batch, DEV)).cpu()
-        ws = next(iter(m._ws.values()))
+        ws = m._last_ws
         assert ws["cluster"] == min(P, capi.dag_cluster_size(6))
         m.check_cluster()
         res[P] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone())
@@ -135,3 +135,44 @@ def test_dagerc_train_step_clip_adamw():
     refp = dict(ref.named_parameters())
     for n in tr.model.flat.params:
         assert float((tr.model.flat.w(n).cpu() - refp[n].detach()).abs().max()) < 2e-4, n
+
+
+@pytest.mark.parametrize("B,lens,dims,S,C", [(4, (5, 40), dict(a=100, t=100, v=512), 2, 6)])
+def test_dagerc_bf16_feature_mode_vs_rounded_oracle(B, lens, dims, S, C):
+    """``--compute=bf16`` (what bench.py --module dagerc --dtype bf16 runs): the feature block is stored in bf16; the two
+    weights that multiply it (fc1.weight, the raw-feature columns of out_mlp.0.weight) are rounded to bf16 while staged.
+    The oracle gets the SAME rounded operands; left over: accumulation order and the bf16 rounding of the upstream
+    gradient inside those two weight-gradient products.  Logits within 1e-3, gradients within 2 % of their scale
+    (3 % for the two bf16-side weight gradients) -- tolerances of the MODE; fp32 parity (1e-4) is tested above."""
+    from oracle.dagerc import DAGERCOracle, dagerc_loss
+    from erc_amd.dagerc import DAGERCModule, HID
+    batch = make_batch(B, dims, n_speakers=S, n_classes=C, min_len=lens[0], max_len=lens[1], seed=18,
+                       speaker_onehot=True, force_max=True)
+    D = sum(dims.values())
+    torch.manual_seed(6)
+    ref = DAGERCOracle(emb_dim=D, dropout=0.0, n_classes=C, gnn_layers=4)
+    W5 = HID * 5
+    with torch.no_grad():
+        ref.fc1.weight.copy_(ref.fc1.weight.to(torch.bfloat16).float())
+        w0 = ref.out_mlp[0].weight
+        w0[:, W5:] = w0[:, W5:].to(torch.bfloat16).float()
+    mine = DAGERCModule(emb_dim=D, dropout=0.0, n_classes=C, gnn_layers=4, compute="bf16")
+    mine.load_state_dict(ref.state_dict())
+    mine.finalize(DEV)
+    dbatch = to_device(batch, DEV)
+    dbatch["input_tensor"] = dbatch["input_tensor"].to(torch.bfloat16)
+    batch = dict(batch, input_tensor=batch["input_tensor"].to(torch.bfloat16).float())
+    ref.train(), mine.train()
+    loss, _ = dagerc_loss(ref, batch)
+    loss.backward()
+    want, _ = ref(**batch)
+    stats = mine.loss_and_grads(dbatch).cpu()
+    T = batch["input_tensor"].shape[1]
+    got = mine._last_ws["logits"].view(B, T, -1).cpu()
+    assert float((got - want.detach()).abs().max()) < 1e-3
+    assert abs(float(stats[0]) - float(loss)) < 1e-3
+    refp = dict(ref.named_parameters())
+    errs = {n: rel_err(mine.flat.g(n).cpu(), refp[n].grad) for n in mine.flat.params}
+    for n, e in errs.items():
+        assert e < (3e-2 if n in ("fc1.weight", "out_mlp.0.weight") else 2e-2), sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    mine.check_cluster()

@@ -86,16 +86,27 @@ def _pair(case, compute="f32"):
     return ref, mine
 
 
+MELD = dict(a=300, t=600, v=342)      # meld-mmgcn-7 (mmbase.py:80-88)
+
+
 @pytest.mark.parametrize("case", [
     dict(B=4, lens=(2, 14), dims=dict(a=10, t=14, v=12), S=2, C=6, seed=1, weights=True),
-    dict(B=6, lens=(1, 33), dims=dict(a=300, t=600, v=342), S=9, C=7, seed=2, weights=False),   # MELD dims, D=1242, R=162
+    dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=2, weights=False),                        # MELD dims, D=1242, R=162
     dict(B=8, lens=(20, 60), dims=dict(a=100, t=100, v=512), S=2, C=6, seed=3, weights=True),   # IEMOCAP dims
-], ids=["tiny", "meld-1242", "iemocap-712"])
+    # BASELINE.json configs[4]: the modality ablation of scripts/baseline.py:27-58 (mmbase.py:31,408-415) at MELD dims:
+    # D = 300 / 600 / 342 / 900 -- other vector-width / alignment paths of the input GEMMs than atv's 1242
+    dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=12, weights=False, modality="a"),
+    dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=13, weights=False, modality="t"),
+    dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=14, weights=False, modality="v"),
+    dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=15, weights=False, modality="at"),
+], ids=["tiny", "meld-1242", "iemocap-712", "meld-a-300", "meld-t-600", "meld-v-342", "meld-at-900"])
 def test_dgcn_module_parity_vs_oracle(case):
     from oracle.dgcn import IEMOCAP6_WEIGHTS
+    modality = case.get("modality", "atv")
     batch = make_batch(case["B"], case["dims"], n_speakers=case["S"], n_classes=case["C"], min_len=case["lens"][0],
-                       max_len=case["lens"][1], seed=case["seed"], force_max=True)
-    case = dict(case, D=sum(case["dims"].values()))
+                       max_len=case["lens"][1], seed=case["seed"], force_max=True, modality=modality)
+    case = dict(case, D=sum(case["dims"][m] for m in modality))
+    assert batch["input_tensor"].shape[2] == case["D"]
     ref, mine = _pair(case)
     w = torch.tensor(IEMOCAP6_WEIGHTS) if case["weights"] else None
     dbatch = to_device(batch, DEV)
@@ -131,3 +142,74 @@ def test_dgcn_train_steps_with_dropout_run():
     batch = make_batch(8, p.dims(), n_speakers=9, n_classes=7, min_len=1, max_len=33, seed=4)
     losses = [float(tr.train_step(tr.prepare_batch(batch)).cpu()[0]) for _ in range(4)]
     assert all(math.isfinite(l) for l in losses) and losses[-1] < losses[0] + 0.5
+
+
+@pytest.mark.parametrize("modality", ["atv", "a", "v"])
+def test_dgcn_bf16_feature_mode_vs_rounded_oracle(modality):
+    """``--compute=bf16`` (what bench.py --module dgcn --dtype bf16 runs): the feature block is stored in bf16 and the
+    layer-0 input weights of the BiLSTM are rounded to bf16 while they are staged.  The oracle is fed the SAME rounded
+    operands, so what is left is accumulation order plus the bf16 rounding of the gate gradients inside the
+    weight_ih_l0 weight-gradient product (8 significant bits): logits within 1e-3, gradients within 2 % of their scale
+    (weight_ih_l0 itself: 3 %).  Tolerances stated here are those of the MODE, not of fp32 parity (1e-4, test above)."""
+    D = sum(MELD[m] for m in modality)
+    case = dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=21, D=D)
+    batch = make_batch(6, MELD, n_speakers=9, n_classes=7, min_len=1, max_len=33, seed=21, force_max=True, modality=modality)
+    ref, mine = _pair(case, compute="bf16")
+    with torch.no_grad():
+        for n in ("weight_ih_l0", "weight_ih_l0_reverse"):
+            w = getattr(ref.rnn.rnn, n)
+            w.copy_(w.to(torch.bfloat16).float())
+            mine.flat.w("rnn.rnn." + n).copy_(w.to(DEV))
+    dbatch = to_device(batch, DEV)
+    dbatch["input_tensor"] = dbatch["input_tensor"].to(torch.bfloat16)
+    batch = dict(batch, input_tensor=batch["input_tensor"].to(torch.bfloat16).float())
+    ref.eval(), mine.eval()
+    with torch.no_grad():
+        want, _ = ref(**batch)
+    got, _ = mine(**dbatch)
+    assert float((got.cpu() - want).abs().max()) < 1e-3
+    ref.train(), mine.train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    ref.rnn.rnn.dropout = 0.0
+    mine.drop_p, mine.lstm.drop_p = 0.0, 0.0
+    logits, _ = ref(**batch)
+    loss = F.cross_entropy(logits, batch["label"])
+    loss.backward()
+    stats = mine.loss_and_grads(dbatch, None).cpu()
+    assert abs(float(stats[0]) - float(loss.detach())) < 1e-3
+    refp = dict(ref.named_parameters())
+    errs = {n: rel_err(mine.flat.g(n).cpu(), refp[n].grad) for n in mine.flat.params}
+    for n, e in errs.items():
+        assert e < (3e-2 if "weight_ih_l0" in n else 2e-2), sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
+@pytest.mark.parametrize("name", ["classifier_c6", "classifier_c7"])
+def test_classifier_ops_vs_reference_golden(golden, name):
+    """The classifier's launch sequence (DGCNModule: Linear+ReLU -> Linear, and its backward) against the REFERENCE's
+    own dgcn_models.Classifier (golden vectors; eval mode: dropout off)."""
+    from erc_amd import capi
+    fx = golden(name)
+    C, N = int(fx["n_classes"]), fx["h"].shape[0]
+    clf = torch.nn.Module()
+    clf.emotion_att = torch.nn.Module(); clf.emotion_att.lin = torch.nn.Linear(300, 300)
+    clf.lin1, clf.lin2 = torch.nn.Linear(300, 100), torch.nn.Linear(100, C)
+    fill_params(clf, int(fx["param_seed"]))
+    W1, b1, W2, b2 = [t.detach().to(DEV) for t in (clf.lin1.weight, clf.lin1.bias, clf.lin2.weight, clf.lin2.bias)]
+    h = torch.from_numpy(fx["h"]).to(DEV)
+    Z, logits = torch.zeros(N, 100, device=DEV), torch.zeros(N, C, device=DEV)
+    capi.gemm_f32(h, 300, 0, None, W1, 300, 0, None, Z, 100, N, 100, 300, bias=b1, act=1)
+    capi.gemm_f32(Z, 100, 0, None, W2, 100, 0, None, logits, C, N, C, 100, bias=b2)
+    np.testing.assert_allclose(logits.cpu().numpy(), fx["logits"], atol=2e-5, rtol=1e-5)
+    dl = torch.from_numpy(fx["w"]).to(DEV)
+    dZ, dh = torch.zeros(N, 100, device=DEV), torch.zeros(N, 300, device=DEV)
+    capi.gemm_f32(dl, C, 0, None, W2, 100, 1, None, dZ, 100, N, 100, C, act=2, aux=Z, ldaux=100, act_scale=1.0)
+    capi.gemm_f32(dZ, 100, 0, None, W1, 300, 1, None, dh, 300, N, 300, 100)
+    np.testing.assert_allclose(dh.cpu().numpy(), fx["dh"], atol=2e-5, rtol=1e-4)
+    dW1, db1 = torch.zeros(100, 300, device=DEV), torch.zeros(100, device=DEV)
+    dW2, db2 = torch.zeros(C, 100, device=DEV), torch.zeros(C, device=DEV)
+    capi.gemm_f32(dZ, 100, 1, None, h, 300, 1, None, dW1, 300, 100, 300, N, ones_col=1, bias_out=db1)
+    capi.gemm_f32(dl, C, 1, None, Z, 100, 1, None, dW2, 100, C, 100, N, ones_col=1, bias_out=db2)
+    check_grad_digest(fx, [("clf.lin1.weight", dW1), ("clf.lin1.bias", db1), ("clf.lin2.weight", dW2),
+                           ("clf.lin2.bias", db2)], tol=1e-4)

@@ -33,6 +33,35 @@ def test_encoder_block_matches_torch(B, T, D):
     assert blk.flops(B, T) > 0
 
 
+@pytest.mark.parametrize("name", ["encoder_d24", "encoder_d712_nomask", "encoder_d1380"])
+def test_encoder_block_vs_reference_layers(golden, name):
+    """K9 against the REFERENCE's own contrib/nn.py:206-305 layers (golden vectors written by
+    tests/golden/make_golden.py gen_encoder: two layers, eval mode, no padding mask -- what cogmen.py:146 runs).
+    (a) vs the fp32 fixture: bf16 operands bound the error to the mode's quantisation -- mean |err| < 4e-3, 99.9th
+        percentile < 3e-2 on O(1) LayerNorm outputs;
+    (b) vs oracle/encoder.py (itself pinned to the same fixture at 3e-5 on the CPU) fed the SAME bf16 roundings the
+        kernels apply: what is left is accumulation order and single-ulp rounding flips -- mean |err| < 1e-3.
+    A wrong head split / q-k-v layout moves individual outputs by O(1): mean |err| would be ~0.5, far outside both."""
+    from erc_amd.encoder import EncoderBlock
+    from oracle.encoder import encoder, round_bf16
+    from tests.test_oracle_encoder import encoder_from_fixture
+    fx = golden(name)
+    x = torch.from_numpy(fx["x"])
+    B, T, D = x.shape
+    enc = encoder_from_fixture(fx, D)
+    blk = EncoderBlock(enc, DEV)
+    got = blk.forward(x.to(DEV)).cpu().clone()
+    want = torch.from_numpy(fx["out"])
+    e = (got - want).abs().flatten()
+    print(name, "vs reference fp32: mean %.2e p99.9 %.2e max %.2e" % (float(e.mean()), float(e.quantile(0.999)), float(e.max())))
+    assert float(e.mean()) < 4e-3 and float(e.quantile(0.999)) < 3e-2 and float(e.max()) < 8e-2
+    with torch.no_grad():
+        rounded = encoder(x, enc, None, rnd=round_bf16)
+    r = (got - rounded).abs().flatten()
+    print(name, "vs bf16-rounded oracle: mean %.2e p99.9 %.2e max %.2e" % (float(r.mean()), float(r.quantile(0.999)), float(r.max())))
+    assert float(r.mean()) < 1e-3 and float(r.quantile(0.999)) < 1.5e-2
+
+
 def test_faithful_mode_changes_cost_not_results():
     """--faithful_dead_encoder runs the dead encoder every step and discards its output: losses are bit-identical to the
     default mode (the live path does not read anything the encoder writes)."""

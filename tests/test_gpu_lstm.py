@@ -4,7 +4,7 @@ import pytest
 import torch
 from torch.nn.utils.rnn import pack_padded_sequence, pad_packed_sequence
 
-from tests.util_cases import rel_err
+from tests.util_cases import check_grad_digest, fill_params, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -105,3 +105,31 @@ def test_interlayer_dropout_is_consistent_between_forward_and_backward():
     want.backward(gout)
     run.backward(pl, gout.to(DEV).view(B * T, 200), 200)
     assert rel_err(ws["dH0d"].cpu().view(B, T, 200), inp.grad) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["seqcontext_d30", "seqcontext_d1242"])
+def test_packed_bilstm_vs_reference_seqcontext(golden, name):
+    """lstm.hip (packed run) against the REFERENCE's own SeqContext (track_mm/dgcn_models.py:10-33; golden vectors
+    written by tests/golden/make_golden.py gen_dgcn_leaves): outputs, input gradient, every weight gradient."""
+    fx = golden(name)
+    x, lens = torch.from_numpy(fx["x"]), torch.from_numpy(fx["lengths"])
+    B, T, D = x.shape
+    holder = torch.nn.Module()
+    holder.rnn = torch.nn.LSTM(D, 100, dropout=0.4, bidirectional=True, num_layers=2, batch_first=True)
+    fill_params(holder, int(fx["param_seed"]))          # names "rnn.<param>", as the generator's SeqContext
+    run, flat, pl = _runner(holder.rnn, D)
+    out = torch.zeros(B * T, 200, device=DEV)
+    run.forward(pl, x.to(DEV).view(B * T, D), D, B * T, B, T, T, 1, lens.to(DEV), False, None, out, 200)
+    got = out.cpu().view(B, T, 200)
+    want = torch.from_numpy(fx["out"])                  # pad_packed_sequence: zeros behind each dialogue's length
+    assert float((got - want).abs().max()) < 2e-5
+    gout = torch.from_numpy(fx["w"]).clone()
+    for b in range(B):
+        gout[b, lens[b]:] = 0                           # padded outputs are constants: no gradient flows through them
+    dx = torch.zeros(B * T, D, device=DEV)
+    run.backward(pl, gout.to(DEV).view(B * T, 200), 200, dx=dx, lddx=D)
+    want_dx = torch.from_numpy(fx["dx"])
+    assert rel_err(dx.cpu().view(B, T, D), want_dx) < 1e-3
+    from erc_amd import capi
+    capi.slab_reduce_batched(pl.ws, flat.grad, pl.job_table(), len(pl.jobs), pl.max_numel)
+    check_grad_digest(fx, [("rnn." + n, flat.g("rnn." + n)) for n, _ in holder.rnn.named_parameters()], tol=1e-3)

@@ -7,6 +7,40 @@ from torch import nn
 
 from oracle.cogmen import COGMENOracle, pick_heads
 from oracle.encoder import encoder, round_bf16
+from tests.util_cases import check_grad_digest, fill_params
+
+
+def encoder_from_fixture(fx, D):
+    """torch.nn.TransformerEncoder carrying the parameters the fixture's generator gave the reference's vendored
+    layers (tests/golden/make_golden.py gen_encoder: same names, same filler, LayerNorm gains + 1)."""
+    layer = nn.TransformerEncoderLayer(d_model=D, nhead=int(fx["nhead"]), dropout=0.5, batch_first=True)
+    enc = nn.TransformerEncoder(layer, num_layers=2, enable_nested_tensor=False).eval()
+    fill_params(enc, int(fx["param_seed"]))
+    with torch.no_grad():
+        for lyr in enc.layers:
+            lyr.norm1.weight.add_(1.0), lyr.norm2.weight.add_(1.0)
+    return enc
+
+
+@pytest.mark.parametrize("name", ["encoder_d24", "encoder_d24_mask", "encoder_d48_h8", "encoder_d712",
+                                  "encoder_d712_nomask", "encoder_d1380"])
+def test_functional_encoder_equals_reference_layers(golden, name):
+    """oracle/encoder.py against the REFERENCE's own contrib/nn.py:206-305 layers (golden vectors): outputs on the
+    valid positions, input gradient, every parameter gradient."""
+    fx = golden(name)
+    x = torch.from_numpy(fx["x"]).requires_grad_()
+    B, T, D = x.shape
+    enc = encoder_from_fixture(fx, D)
+    lengths = torch.from_numpy(fx["lengths"])
+    pad = (torch.arange(T)[None, :] >= lengths[:, None]) if bool(fx["masked"]) else None
+    valid = ~pad if pad is not None else torch.ones(B, T, dtype=torch.bool)
+    got = encoder(x, enc, pad)
+    want = torch.from_numpy(fx["out"])
+    assert float((got - want)[valid].abs().max()) < 3e-5
+    (got * torch.from_numpy(fx["w"])).sum().backward()
+    dx = torch.from_numpy(fx["dx"])
+    assert float((x.grad - dx).abs().max()) < 1e-4 * max(1.0, float(dx.abs().max()))
+    check_grad_digest(fx, [(n, p.grad) for n, p in enc.named_parameters()], tol=2e-4)
 
 
 @pytest.mark.parametrize("B,T,D,masked", [(3, 13, 24, True), (2, 20, 712, True), (2, 9, 48, False)])
