@@ -26,6 +26,108 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2_f32: exact fp32, = the fp32 vector rate (same guide)
+MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16
+
+
+def step_work(module, params, host_batch, features_bf16):
+    """Algorithmic work of ONE training step (fwd + bwd + update, live path only): SURVEY.md 8(d) per-utterance table x
+    the units of this batch.  Returns (bytes, flops, note).  COGMEN / MMGCN / DialogueGCN count the N valid utterances;
+    DAG-ERC counts all B*T padded positions for the FLOPs (the reference runs the recurrence over the padded length,
+    dagerc.py:167-189) and the valid ones for the bytes."""
+    N = int(host_batch["label"].shape[0])
+    D = params.hidden_all
+    if module == "cogmen":
+        row = D * (2 if features_bf16 else 4)
+        per_utt = 2 * row + 4800 + 180                 # feature row read in fwd and in wgrad; 12 x 100-wide fp32; edges
+        live = 100 * D + 100 + 90100 + 40400 + 200 + 10100 + 101 * params.n_classes
+        return per_utt * N + live * 16, 1.4e6 * N * (D / 1380.0 * 0.59 + 0.41), "N=%d utterances; 10.5 KB + 1.4 MFLOP per utterance at D=1380, %.2f MB of parameters + Adam state" % (N, live * 16 / 1e6)
+    if module == "dagerc":
+        B, T = host_batch["input_tensor"].shape[:2]
+        live = 6427510 if D == 1380 else 6026710 if D == 712 else (300 * D + 300 + 4 * (4 * 541800 + 180000 + 601) + 300 * (1500 + D) + 300 + 90300 + 301 * params.n_classes)
+        flops_pos = 3.0 * (2 * D * 300 + 4 * 2.55e6 + 2 * (1500 + D) * 300 + 2 * 300 * 300)
+        return (2 * D * (2 if features_bf16 else 4) + 48000) * N + live * 16, flops_pos * B * T, \
+            "%d padded positions x %.1f MFLOP, %d valid utterances x 53.6 KB, %.1f MB of parameters + Adam state" % (
+                B * T, flops_pos / 1e6, N, live * 16 / 1e6)
+    if module == "mmgcn":
+        live = 5927606
+        return (1380 * 4 + 460000) * N + live * 16, 111e6 * N, \
+            "N=%d utterances x (477 KB with the 64 per-layer activations stored for the backward, 111 MFLOP)" % N
+    live = 2030000    # dgcn, MELD atv
+    lstm_act = (2 * 800 + 2 * 200 + 2 * 200) * 4 * 2
+    fl = 3.0 * (2 * 2 * 4 * 100 * (D + 100) + 2 * 2 * 4 * 100 * 300 + 88e3 + 0.84e6 + 62e3)
+    return (2 * D * (2 if features_bf16 else 4) + lstm_act + 420) * N + live * 16, fl * N, \
+        "N=%d utterances x (%.1f KB, %.1f MFLOP)" % (N, (2 * D * 4 + lstm_act + 420) / 1e3, fl / 1e6)
+
+
+# entry points whose kernels can dominate a step, per module, with their algorithmic FLOPs per launch
+def _probe_candidates(module, params, host_batch, trainer):
+    lens = host_batch["text_length"].tolist()
+    N = sum(lens)
+    if module == "cogmen":
+        pl = trainer.model._last_ws["planner"]
+        fl = sum(2.0 * M * Nn * K for (_, _, _, _, _, _, M, Nn, K, _, _, _) in pl.deferred)
+        return {"erc_wgrad_table": ("wgrad_table_kernel (every weight gradient of the step, one launch)", fl, "mfma")}
+    if module == "dagerc":
+        B, T = host_batch["input_tensor"].shape[:2]
+        per = 2.0 * 300 * (1800 + 600 + 1)
+        return {"erc_dag_scan_fwd": ("DAG-ERC forward scan (one layer)", per * B * T, "mfma"),
+                "erc_dag_scan_bwd": ("DAG-ERC backward scan (one layer)", per * B * T, "mfma"),
+                "erc_dag_rec_fwd": ("dag_rec_fwd_kernel (weight-stationary forward recurrence, one layer)", per * B * T, "mfma"),
+                "erc_dag_rec_bwd": ("dag_rec_bwd_kernel (weight-stationary backward recurrence, one layer)", per * B * T, "mfma")}
+    if module == "mmgcn":
+        Mo = len(params.modality)
+        fl = sum(Mo * 2.0 * L * L * 200 for L in lens)
+        return {"erc_gemm_f32_grouped": ("gemm_f32_grouped_kernel<0> (A.h of one GCNII layer, per-dialogue blocks)", fl, "mfma"),
+                "erc_gcnii_chain_fwd": ("gcnii_chain_fwd_kernel (64 GCNII layers, one launch)", 64 * (fl + 3 * N * 2.0 * 400 * 200), "mfma"),
+                "erc_gcnii_chain_bwd": ("gcnii_chain_bwd_kernel (64 GCNII layers backward, one launch)", 64 * (fl + 3 * N * 2.0 * 2 * 400 * 200), "mfma")}
+    per = 2 * 2.0 * 100 * 400
+    return {"erc_lstm_scan_fwd": ("lstm_fwd_kernel (BiLSTM recurrence, one layer)", per * N, "mfma"),
+            "erc_lstm_scan_bwd": ("lstm_bwd_kernel (BiLSTM recurrence backward, one layer)", per * N, "mfma")}
+
+
+def time_replays(entries, reps):
+    """Average duration of `reps` back-to-back launches (captured once, replayed as one HIP graph -- eager ctypes calls
+    would time the interpreter) between one HIP event pair on the launching stream."""
+    from erc_amd import capi
+    for e in entries:
+        capi.replay(e)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            for e in entries:
+                capi.replay(e)
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def dominant_kernel(module, params, host_batch, batch, trainer, reps):
+    """Record one eager step, replay each candidate entry point on its own with the step's operands, and name the one
+    with the largest share of the step (average launch duration x launches per step)."""
+    from erc_amd import capi
+    capi.start_recording()
+    trainer.train_step(batch)
+    rec = capi.stop_recording()
+    torch.cuda.synchronize()
+    cands = _probe_candidates(module, params, host_batch, trainer)
+    best = None
+    for name, (label, flops, bound) in cands.items():
+        calls = [e for e in rec if e[0] == name]
+        if not calls:
+            continue
+        us = time_replays([calls[0]], max(10, reps // (10 if module in ("dagerc", "mmgcn") else 1)))
+        share = us * len(calls)
+        if best is None or share > best["share_us"]:
+            best = {"entry": name, "kernel": label, "avg_us": us, "launches_per_step": len(calls), "share_us": share,
+                    "flops": flops, "bound": bound}
+    return best
 
 
 def synthetic_batch(params, B, T, seed):
@@ -213,21 +315,46 @@ def main():
         total_utt = float(n_utt)
     stats = trainer.model._last_ws["stats"].cpu().tolist()
 
-    # ---------------------------------------------------------------- dominant kernel, HIP events on its stream
+    # ---------------------------------------------------------------- roofline: dominant kernel (HIP events) + whole step
     roof = None
-    if rank == 0 and args.module == "cogmen":
-        roof = trainer.model.dominant_kernel_probe(batch, reps=args.kernel_reps)
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        sb, sf, note = step_work(args.module, params, host_batch, args.dtype == "bf16")
+        # the probe runs one extra (eager) training step: on one rank only when there is no collective to join
+        dom = dominant_kernel(args.module, params, host_batch, batch, trainer, args.kernel_reps) if world == 1 else None
+        tag = "r02_%s_b%d_%s" % (args.module, args.batch, args.dtype)
         traffic, tsrc = None, None
-        pmc = os.path.join(REPO, "profiles", "r01_cogmen_b32_%s_pmc.json" % args.dtype)
-        if args.batch == 32 and args.max_len == 110 and os.path.exists(pmc):
-            # HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-            # same command (tools/pmc_summary.py; gfx950 correction: read bytes = 2 x FETCH_SIZE)
+        pmc = os.path.join(REPO, "profiles", tag + "_pmc.json")
+        if os.path.exists(pmc):
+            # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+            # this same command (tools/pmc_summary.py; gfx950 correction: read bytes = 2 x FETCH_SIZE)
             with open(pmc) as fh:
-                rec = json.load(fh)
-            traffic, tsrc = rec.get("hbm_bytes_per_launch"), os.path.relpath(pmc, REPO)
-        roof = {"bound": "hbm", "kernel": roof["kernel"], "achieved": roof["gbs"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": roof["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                "algorithmic_bytes": roof["bytes"], "avg_us": roof["us"], "launches_timed": args.kernel_reps}
+                prec = json.load(fh)
+            if dom is not None and prec.get("kernel_substring", "") in dom["kernel"]:
+                traffic, tsrc = prec.get("hbm_bytes_per_launch"), os.path.relpath(pmc, REPO)
+        roof = {"bound": "mfma", "kernel": dom["kernel"] if dom else None,
+                "achieved": dom["flops"] / dom["avg_us"] * 1e-6 if dom else None, "peak": MFMA_F32_PEAK_TFS,
+                "unit": "TFLOP/s", "frac": dom["flops"] / dom["avg_us"] * 1e-6 / MFMA_F32_PEAK_TFS if dom else None,
+                "traffic": traffic, "traffic_source": tsrc,
+                "peak_note": "fp32 matrix-core peak (v_mfma_f32_16x16x4_f32): every product of the step except the bf16 "
+                             "input projection is exact fp32",
+                "algorithmic_flops_per_launch": dom["flops"] if dom else None, "avg_us": dom["avg_us"] if dom else None,
+                "launches_per_step": dom["launches_per_step"] if dom else None,
+                "share_of_step": dom["share_us"] / (ms_step * 1e3) if dom else None,
+                "step": {"algorithmic_bytes": sb, "algorithmic_flops": sf, "work": note, "ms": ms_step,
+                         "hbm_GBs": sb / ms_step * 1e-6, "hbm_frac": sb / ms_step * 1e-6 / HBM_PEAK_GBS,
+                         "TFLOPs": sf / ms_step * 1e-9, "mfma_f32_frac": sf / ms_step * 1e-9 / MFMA_F32_PEAK_TFS,
+                         "mfma_bf16_frac": sf / ms_step * 1e-9 / MFMA_BF16_PEAK_TFS}}
+        if args.module == "cogmen":
+            pr = trainer.model.dominant_kernel_probe(batch, reps=args.kernel_reps)
+            ptraffic = None
+            ppmc = os.path.join(REPO, "profiles", tag + "_projection_pmc.json")
+            if os.path.exists(ppmc):
+                with open(ppmc) as fh:
+                    ptraffic = json.load(fh).get("hbm_bytes_per_launch")
+            roof["projection"] = {"bound": "hbm", "kernel": pr["kernel"], "achieved": pr["gbs"], "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": pr["gbs"] / HBM_PEAK_GBS, "traffic": ptraffic,
+                                  "algorithmic_bytes": pr["bytes"], "avg_us": pr["us"]}
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None

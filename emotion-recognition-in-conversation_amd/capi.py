@@ -114,6 +114,27 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)
 _lib = None
+_raw = None
+_record = None     # list of (entry point, argument tuple) while a recording is active (bench.py kernel probes)
+
+
+def start_recording():
+    """Record every C-ABI call (name + raw arguments) until stop_recording(): bench.py replays single entry points with
+    the exact operands a training step gave them, to time the step's dominant kernel on its own."""
+    global _record
+    _record = []
+
+
+def stop_recording():
+    global _record
+    rec, _record = _record, None
+    return rec
+
+
+def replay(entry):
+    """Re-issue a recorded call on the CURRENT stream (the stream handle is every launching entry point's last argument)."""
+    name, args = entry
+    _check(getattr(_raw, name)(*(args[:-1] + (stream(),))), name)
 
 
 class ErcGraftError(RuntimeError):
@@ -138,13 +159,24 @@ def lib():
             raise ErcGraftError(
                 "libercgraft.so not found at %s: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU / PyTorch fallback for the hot path)" % LIB_PATH)
+        global _raw
         handle = C.CDLL(LIB_PATH)
+
+        class _Recording:          # same attribute surface as the CDLL handle; one global test per call when idle
+            pass
+        rec = _Recording()
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)  # AttributeError = symbol missing: fail loudly
             fn.restype, fn.argtypes = res, args
+
+            def call(*a, _fn=fn, _name=name):
+                if _record is not None:
+                    _record.append((_name, a))
+                return _fn(*a)
+            setattr(rec, name, call)
         if handle.erc_abi_version() != 1:
             raise ErcGraftError("libercgraft ABI version mismatch")
-        _lib = handle
+        _raw, _lib = handle, rec
     return _lib
 
 
