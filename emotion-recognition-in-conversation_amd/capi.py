@@ -67,7 +67,7 @@ _SIGS = {
     "erc_head_ce_stats_floats": (C.c_int64, [_i]),
     "erc_head_ce": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _i64, _i64,
-                                _vp]),
+                                _vp, _vp]),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
     "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
@@ -110,6 +110,13 @@ _SIGS = {
     "erc_dag_scan_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                    _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "erc_dag_cluster_scratch_floats": (C.c_int64, [_i, _i]),
+    "erc_dag_rec_config": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_dag_rec_scratch_bytes": (C.c_int64, [_i, _i, _i]),
+    "erc_dag_rec_set_stamps": (C.c_int, [_vp]),
+    "erc_dag_rec_fwd": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
+                                  _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_dag_rec_bwd": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i,
+                                  _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -298,14 +305,47 @@ def cross_entropy(logits, ld, Cn, n_rows, row_map, labels, weight, grad_scale, d
 
 
 def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_norm, gnorm, state, shadow=None,
-              shadow_off=0, shadow_n=0):
+              shadow_off=0, shadow_n=0, skip_flag=None):
     _check(lib().erc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale,
-                               clip_norm, ptr(gnorm), ptr(state), ptr(shadow), shadow_off, shadow_n, stream()),
-           "erc_adam_step")
+                               clip_norm, ptr(gnorm), ptr(state), ptr(shadow), shadow_off, shadow_n, ptr(skip_flag),
+                               stream()), "erc_adam_step")
 
 
 def grad_norm(g, n, grad_scale, gnorm, ws):
     _check(lib().erc_grad_norm(ptr(g), n, grad_scale, ptr(gnorm), ptr(ws), stream()), "erc_grad_norm")
+
+
+def dag_rec_config(B, T, epc_hint=0, dg_hint=0):
+    """(epc, dg, groups_per_launch) for the weight-stationary DAG-ERC recurrence on the current device."""
+    out = (C.c_int * 3)()
+    _check(lib().erc_dag_rec_config(B, T, epc_hint, dg_hint, C.addressof(out), C.addressof(out) + 4, C.addressof(out) + 8),
+           "erc_dag_rec_config")
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def dag_rec_set_stamps(t):
+    _check(lib().erc_dag_rec_set_stamps(ptr(t)), "erc_dag_rec_set_stamps")
+
+
+def dag_rec_scratch_bytes(B, epc, dg):
+    return int(lib().erc_dag_rec_scratch_bytes(B, epc, dg))
+
+
+def dag_rec_fwd(Hl, ldh, GI, ldgi, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_k, pred, spk, B, T, H1, ldo, Mseq, GH, R, ks, alpha,
+                cfg, state, scratch):
+    _dev(Hl, GI, H1)
+    _check(lib().erc_dag_rec_fwd(ptr(Hl), ldh, ptr(GI), ldgi, ptr(W_hh_c), ptr(b_hh_c), ptr(W_ih_p), ptr(b_ih_p), ptr(Wr),
+                                 ptr(w_k), ptr(pred), ptr(spk), B, T, ptr(H1), ldo, ptr(Mseq), ptr(GH), ptr(R), ptr(ks),
+                                 ptr(alpha), cfg[0], cfg[1], cfg[2], ptr(state), ptr(scratch), stream()), "erc_dag_rec_fwd")
+
+
+def dag_rec_bwd(Hl, ldh, GI, ldgi, GH, Mseq, R, alpha, W_hh_c, W_ih_p, Wr, w_k, pred, spk, B, T, dH1, ldd, dHl, lddl, DGI,
+                lddgi, DGH, dR, dks, cfg, state, scratch):
+    _dev(Hl, GI, dH1)
+    _check(lib().erc_dag_rec_bwd(ptr(Hl), ldh, ptr(GI), ldgi, ptr(GH), ptr(Mseq), ptr(R), ptr(alpha), ptr(W_hh_c),
+                                 ptr(W_ih_p), ptr(Wr), ptr(w_k), ptr(pred), ptr(spk), B, T, ptr(dH1), ldd, ptr(dHl), lddl,
+                                 ptr(DGI), lddgi, ptr(DGH), ptr(dR), ptr(dks), cfg[0], cfg[1], cfg[2], ptr(state),
+                                 ptr(scratch), stream()), "erc_dag_rec_bwd")
 
 
 def dag_meta(speaker_onehot, speaker_ids, sb, st, S, lengths, B, T, spk, pred, node_off, node_row):

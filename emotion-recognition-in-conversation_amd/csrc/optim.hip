@@ -27,7 +27,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float grad_scale, float clip_norm,
                                                    const float* __restrict__ gnorm, int64_t* state,
                                                    unsigned short* __restrict__ shadow, int64_t shadow_off,
-                                                   int64_t shadow_n) {
+                                                   int64_t shadow_n, const int32_t* __restrict__ skip_flag) {
+    // a producer of this step's gradients (the DAG-ERC recurrence kernels) flagged an exchange timeout: the
+    // gradients are invalid -- leave parameters, moments and the step counter untouched (checked on the device, no sync)
+    if (skip_flag && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     // first quad of this thread: requested before the (dependent, transcendental) bias-correction math
     const int64_t nq = n >> 2;
     const int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -144,7 +147,7 @@ extern "C" int erc_clock_probe(uint64_t* out, int iters, void* stream) {
 extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
                              float clip_norm, const float* gnorm, int64_t* state, void* bf16_shadow,
-                             int64_t shadow_off, int64_t shadow_n, void* stream) {
+                             int64_t shadow_off, int64_t shadow_n, const int32_t* skip_flag, void* stream) {
     ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
     ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
     ERC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: 16-byte alignment");
@@ -153,7 +156,8 @@ extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64
     if (grid > 512) grid = 512;  // one arrival atomic per block on a single word: keep the count low
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                       decoupled, grad_scale, clip_norm, gnorm, state, (unsigned short*)bf16_shadow, shadow_off, shadow_n);
+                       decoupled, grad_scale, clip_norm, gnorm, state, (unsigned short*)bf16_shadow, shadow_off, shadow_n,
+                       skip_flag);
     ERC_LAUNCH_CHECK("adam_step");
     return ERC_OK;
 }

@@ -6,9 +6,12 @@ keys (including the never-trained ``fcs.*`` and
 ``forward(**batch) -> (logits [B,T,C] padded, None)`` contract; the harness masks
 with ``attention_mask`` exactly as for the reference (dagerc.py:225).
 
-Per layer: one hoisted GEMM for the input-side gates of ``grus_c`` and the
-hidden-side gates of ``grus_p`` over all B*T rows, then the persistent
-per-dialogue scan kernel (csrc/dag_scan.hip).  The five hidden states
+Per layer: one hoisted GEMM for the input-side gates of ``grus_c``, the
+hidden-side gates of ``grus_p`` and the attention's query score over all B*T
+rows (stacked weight [W_ih_c ; W_hh_p ; w_q]), then the weight-stationary
+recurrence kernel (csrc/dag_rec.hip: groups of dialogues as the MFMA M
+dimension, each workgroup keeps its slice of the recurrent weights in
+registers for all T steps).  The five hidden states
 H0..H4 are written straight into one [B*T, 1500] buffer, so the
 ``torch.cat`` of dagerc.py:190-192 never happens: the head's first Linear is
 two GEMMs (hidden block, raw-feature block) summed by the slab reducer.
@@ -20,6 +23,7 @@ from . import capi
 from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad
 
 HID = 300
+LDG = 6 * HID + 4      # row pitch of the hoisted gate block: 1800 gate columns + the query-score column (+ pad to 16 bytes)
 
 
 class _Gather(nn.Module):
@@ -64,12 +68,15 @@ class DAGERCModule(nn.Module):
         for l in range(self.gnn_layers):
             c, p, g = self.grus_c[l], self.grus_p[l], self.gather[l]
             groups += [
-                [("grus_c.%d.weight_ih" % l, c.weight_ih), ("grus_p.%d.weight_hh" % l, p.weight_hh)],   # hoisted
-                [("grus_c.%d.bias_ih" % l, c.bias_ih), ("grus_p.%d.bias_hh" % l, p.bias_hh)],
+                # hoisted: ONE [1802, 300] operand -- rows 0..1799 the two gate matrices, row 1800 w_q, row 1801 w_k (the
+                # [1, 600] gather.linear.weight is two 300-rows back to back); the bias group lines up with rows 0..1800
+                [("grus_c.%d.weight_ih" % l, c.weight_ih), ("grus_p.%d.weight_hh" % l, p.weight_hh),
+                 ("gather.%d.linear.weight" % l, g.linear.weight)],
+                [("grus_c.%d.bias_ih" % l, c.bias_ih), ("grus_p.%d.bias_hh" % l, p.bias_hh),
+                 ("gather.%d.linear.bias" % l, g.linear.bias)],
                 [("grus_c.%d.weight_hh" % l, c.weight_hh), ("grus_p.%d.weight_ih" % l, p.weight_ih)],   # sequential
                 [("grus_c.%d.bias_hh" % l, c.bias_hh), ("grus_p.%d.bias_ih" % l, p.bias_ih)],
                 [("gather.%d.Wr0.weight" % l, g.Wr0.weight), ("gather.%d.Wr1.weight" % l, g.Wr1.weight)],
-                [("gather.%d.linear.weight" % l, g.linear.weight), ("gather.%d.linear.bias" % l, g.linear.bias)],
             ]
         m = self.out_mlp
         groups += [[("out_mlp.0.weight", m[0].weight)], [("out_mlp.0.bias", m[0].bias)],
@@ -81,6 +88,9 @@ class DAGERCModule(nn.Module):
         self.to(device)
         self.flat = FlatParams(self.live_groups(), device)
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
+        # [0] error flag of the recurrence kernels (an exchange timed out: the optimizer skips the step on the device),
+        # then one launch epoch per dialogue group; shared by every workspace so that the flag has ONE address
+        self.rec_state = torch.zeros(1 + 4096, dtype=torch.int32, device=device)
         return self
 
     @property
@@ -98,35 +108,37 @@ class DAGERCModule(nn.Module):
         ws = dict(
             spk=i32(B, T), pred=i32(B, T), node_off=i32(B + 1), node_row=i32(max(N, 1)),
             Hall=f32(BT, HID * (L + 1)), dHall=f32(BT, HID * (L + 1)),
-            GI=[f32(BT, 6 * HID) for _ in range(L)], GH=[f32(BT, 6 * HID) for _ in range(L)],
+            GI=[f32(BT, LDG) for _ in range(L)], GH=[f32(BT, 6 * HID) for _ in range(L)],
             Mseq=[f32(BT, HID) for _ in range(L)], R=[f32(BT, 2 * HID) for _ in range(L)],
-            ks=[f32(BT) for _ in range(L)], alpha=[f32(B, T, T) for _ in range(L)],
+            ks=[f32(BT) for _ in range(L)], alpha=[torch.zeros(B, T, T, dtype=torch.float32, device=device) for _ in range(L)],
             Y1=f32(BT, HID), Y2=f32(BT, HID), logits=f32(BT, C), dlogits=f32(BT, C), dY2=f32(BT, HID),
-            dY1=f32(BT, HID), DGI=[f32(BT, 6 * HID) for _ in range(L)], DGH=[f32(BT, 6 * HID) for _ in range(L)],
+            dY1=f32(BT, HID), DGI=[f32(BT, LDG) for _ in range(L)], DGH=[f32(BT, 6 * HID) for _ in range(L)],
             # dR | dks per layer (kept until the batched weight-gradient launch at the end of the step)
-            zero=torch.zeros(L, BT * (2 * HID + 1), dtype=torch.float32, device=device),
+            dR=[f32(BT, 2 * HID) for _ in range(L)], dks=[f32(BT) for _ in range(L)],
             stats=torch.zeros(256, dtype=torch.float32, device=device),
         )
-        # P workgroups per dialogue in the recurrence kernels (csrc/dag_scan.hip, cluster mode); ERC_DAG_CLUSTER overrides
+        # (elements per workgroup, dialogues per group, groups per launch) of the recurrence kernels, from the device's CU
+        # count and the occupancy query (csrc/dag_rec.hip); ERC_DAG_EPC / ERC_DAG_DG force a configuration (tuning, tests)
         import os
-        ws["cluster"] = min(int(os.environ.get("ERC_DAG_CLUSTER", capi.dag_cluster_size(B))), capi.dag_cluster_size(B))
-        ws["cl_state"] = i32(2 * B + 1)
-        ws["cl_scratch"] = torch.zeros(capi.dag_cluster_scratch_floats(B, T), dtype=torch.float32, device=device)
-        ws["dR"] = [ws["zero"][l, :BT * 2 * HID].view(BT, 2 * HID) for l in range(L)]
-        ws["dks"] = [ws["zero"][l, BT * 2 * HID:] for l in range(L)]
+        if B > 4096:
+            raise capi.ErcGraftError("DAG-ERC: more than 4096 dialogues per batch")
+        ws["cfg"] = capi.dag_rec_config(B, T, int(os.environ.get("ERC_DAG_EPC", 0)), int(os.environ.get("ERC_DAG_DG", 0)))
+        ws["rec_scratch"] = torch.zeros(capi.dag_rec_scratch_bytes(B, ws["cfg"][0], ws["cfg"][1]) // 8 + 1, dtype=torch.int64,
+                                        device=device)
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
         return ws
 
     def check_cluster(self):
-        """Raise if a cluster-mode recurrence kernel flagged a wait that ran into its bound (its workgroups were not all
-        resident at once, e.g. another process shares the GPU): the results of that step are invalid.  Costs one
-        device->host copy per workspace, so it is called at epoch boundaries / in tests, not per step."""
-        for key, ws in self._ws.items():
-            if int(ws["cl_state"][0].item()) != 0:
-                raise capi.ErcGraftError("DAG-ERC cluster scan timed out waiting for a member workgroup (B,T,N=%s); "
-                                         "rerun with ERC_DAG_CLUSTER=1" % (key,))
+        """Raise if a recurrence kernel flagged an exchange wait that ran into its bound (its workgroups were not all
+        resident at once, e.g. another process holds CUs).  The affected optimizer steps were already skipped ON THE
+        DEVICE (FusedAdam.skip_flag = this flag); this host-side check (one device->host copy) reports it -- the trainer
+        calls it after the training loop and after the evaluation loop of every epoch."""
+        if int(self.rec_state[0].item()) != 0:
+            self.rec_state[0] = 0
+            raise capi.ErcGraftError("DAG-ERC recurrence: an exchange between the workgroups of a dialogue group timed out; "
+                                     "the optimizer steps of the affected batches were skipped")
 
     def _shape(self, input_tensor, text_length, label, n_nodes=None):
         B, T = input_tensor.shape[0], input_tensor.shape[1]
@@ -138,7 +150,7 @@ class DAGERCModule(nn.Module):
         return dict(Whoist=fp.w("grus_c.%d.weight_ih" % l), bhoist=fp.w("grus_c.%d.bias_ih" % l),
                     W_hh_c=fp.w("grus_c.%d.weight_hh" % l), b_hh_c=fp.w("grus_c.%d.bias_hh" % l),
                     W_ih_p=fp.w("grus_p.%d.weight_ih" % l), b_ih_p=fp.w("grus_p.%d.bias_ih" % l),
-                    Wr=fp.w("gather.%d.Wr0.weight" % l), w_lin=fp.w("gather.%d.linear.weight" % l))
+                    Wr=fp.w("gather.%d.Wr0.weight" % l), w_k=fp.w("gather.%d.linear.weight" % l).view(-1)[HID:])
 
     # ---------------------------------------------------------------- forward
     def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training):
@@ -163,11 +175,11 @@ class DAGERCModule(nn.Module):
         for l in range(L):
             w = self._layer_w(l)
             Hl, H1 = Hall[:, HID * l:], Hall[:, HID * (l + 1):]
-            linear_fwd(pl, Hl, W5, None, w["Whoist"], w["bhoist"], ws["GI"][l], 6 * HID, BT, 6 * HID, HID)
-            capi.dag_scan_fwd(Hl, W5, ws["GI"][l], w["W_hh_c"], w["b_hh_c"], w["W_ih_p"], w["b_ih_p"], w["Wr"],
-                              w["w_lin"], ws["pred"], ws["spk"], B, T, H1, W5, ws["Mseq"][l], ws["GH"][l], ws["R"][l],
-                              ws["ks"][l], ws["alpha"][l], cluster=ws["cluster"], cl_state=ws["cl_state"],
-                              cl_scratch=ws["cl_scratch"])
+            # gates of both cells' hoisted sides and the query score w_q.H_l + b: one GEMM, N = 1801
+            linear_fwd(pl, Hl, W5, None, w["Whoist"], w["bhoist"], ws["GI"][l], LDG, BT, 6 * HID + 1, HID)
+            capi.dag_rec_fwd(Hl, W5, ws["GI"][l], LDG, w["W_hh_c"], w["b_hh_c"], w["W_ih_p"], w["b_ih_p"], w["Wr"], w["w_k"],
+                             ws["pred"], ws["spk"], B, T, H1, W5, ws["Mseq"][l], ws["GH"][l], ws["R"][l], ws["ks"][l],
+                             ws["alpha"][l], ws["cfg"], self.rec_state, ws["rec_scratch"])
         # head: Y1 = relu([Hall | x] W0^T + b0) as two GEMMs into one slab set
         W0 = fp.w("out_mlp.0.weight")
         Sa = pl.split_for(BT, HID, W5)
@@ -226,22 +238,25 @@ class DAGERCModule(nn.Module):
                             ld_w=self.in_dim, force_slab=x_bf16)
         linear_wgrad(pl, ws["dY1"], HID, x, D, None, HID, D, BT, None, off["out_mlp.0.bias"], x_bf16=x_bf16,
                      slab=slab, col_off=W5)
-        ws["zero"].zero_()
         for l in range(L - 1, -1, -1):
             w = self._layer_w(l)
             Hl, H1 = ws["Hall"][:, HID * l:], ws["Hall"][:, HID * (l + 1):]
             dHl, dH1 = ws["dHall"][:, HID * l:], ws["dHall"][:, HID * (l + 1):]
-            dlin = pl.take(B * (2 * HID + 1))
-            capi.dag_scan_bwd(Hl, W5, ws["GI"][l], ws["GH"][l], ws["Mseq"][l], ws["R"][l], ws["alpha"][l], H1, W5,
-                              w["W_hh_c"], w["W_ih_p"], w["Wr"], w["w_lin"], ws["pred"], ws["spk"], B, T, dH1, W5,
-                              dHl, W5, ws["DGI"][l], ws["DGH"][l], ws["dR"][l], ws["dks"][l], pl.ws[dlin:],
-                              cluster=ws["cluster"], cl_state=ws["cl_state"], cl_scratch=ws["cl_scratch"])
-            pl.add_job(dlin, 2 * HID + 1, B, 2 * HID + 1, off["gather.%d.linear.weight" % l])
-            # dH_l += DGI [W_ih_c ; W_hh_p]; on layer 0 the same launch applies the relu mask of fc1
-            capi.gemm_f32(ws["DGI"][l], 6 * HID, 0, None, w["Whoist"], HID, 1, None, dHl, W5, BT, HID, 6 * HID,
+            capi.dag_rec_bwd(Hl, W5, ws["GI"][l], LDG, ws["GH"][l], ws["Mseq"][l], ws["R"][l], ws["alpha"][l], w["W_hh_c"],
+                             w["W_ih_p"], w["Wr"], w["w_k"], ws["pred"], ws["spk"], B, T, dH1, W5, dHl, W5, ws["DGI"][l], LDG,
+                             ws["DGH"][l], ws["dR"][l], ws["dks"][l], ws["cfg"], self.rec_state, ws["rec_scratch"])
+            # dH_l += DGI [W_ih_c ; W_hh_p ; w_q] (column 1800 of DGI is d(query score)); on layer 0 the same launch
+            # applies the relu mask of fc1
+            capi.gemm_f32(ws["DGI"][l], LDG, 0, None, w["Whoist"], HID, 1, None, dHl, W5, BT, HID, 6 * HID + 1,
                           accumulate=1, act=2 if l == 0 else 0, aux=Hl if l == 0 else None, ldaux=W5, act_scale=1.0)
-            linear_wgrad(pl, ws["DGI"][l], 6 * HID, Hl, W5, None, 6 * HID, HID, BT, off["grus_c.%d.weight_ih" % l],
+            # d[W_ih_c ; W_hh_p] and their biases (1800 rows: 16-byte operand loads); the two halves of gather.linear:
+            # dw_q = DGI[:, 1800]^T H_l (+ its bias), dw_k = dks^T H1 -- one-row products of the same batched launch
+            linear_wgrad(pl, ws["DGI"][l], LDG, Hl, W5, None, 6 * HID, HID, BT, off["grus_c.%d.weight_ih" % l],
                          off["grus_c.%d.bias_ih" % l], defer=True)
+            linear_wgrad(pl, ws["DGI"][l][:, 6 * HID:], LDG, Hl, W5, None, 1, HID, BT, off["gather.%d.linear.weight" % l],
+                         off["gather.%d.linear.bias" % l], defer=True)
+            linear_wgrad(pl, ws["dks"][l], 1, H1, W5, None, 1, HID, BT, off["gather.%d.linear.weight" % l] + HID, None,
+                         defer=True)
             linear_wgrad(pl, ws["DGH"][l], 6 * HID, ws["Mseq"][l], HID, None, 6 * HID, HID, BT,
                          off["grus_c.%d.weight_hh" % l], off["grus_c.%d.bias_hh" % l], defer=True)
             linear_wgrad(pl, ws["dR"][l], 2 * HID, H1, W5, None, 2 * HID, HID, BT, off["gather.%d.Wr0.weight" % l], None, defer=True)
@@ -263,6 +278,7 @@ class DAGERCTrainer:
         self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.get("weight_decay", 1e-2),
                                decoupled=(o.name == "AdamW"), clip_norm=5.0, seed=params.seed)
         self.model.rng_state = self.optim.rng_state
+        self.optim.skip_flag = self.model.rec_state      # [0]: a recurrence exchange timed out -> the update is skipped
 
     def to_logits(self, batch):
         return self.model(**batch)[0]

@@ -309,6 +309,7 @@ class FusedAdam:
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.norm_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.shadow = None   # (bf16 tensor, offset, numel): kept in sync with the fp32 master weights by the step
+        self.skip_flag = None  # device int32: non-zero = this step's gradients are invalid, the kernel skips the update
 
     @property
     def rng_state(self):
@@ -321,7 +322,7 @@ class FusedAdam:
         capi.adam_step(f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, self.lr, self.betas[0], self.betas[1],
                        self.eps, self.weight_decay, self.decoupled, grad_scale, self.clip_norm,
                        self.gnorm if self.clip_norm > 0 else None, self.state,
-                       *(self.shadow if self.shadow is not None else (None, 0, 0)))
+                       *(self.shadow if self.shadow is not None else (None, 0, 0)), skip_flag=self.skip_flag)
 
 
 def all_reduce_grads(flat, always=False):

@@ -174,6 +174,8 @@ def run(trainer_cls, params_cls, argv=None):
                 logits = logits[batch["attention_mask"].bool().to(logits.device)]
             pred.extend(logits.argmax(-1).cpu().tolist())
             true.extend(batch["label"].tolist())
+        if hasattr(trainer.model, "check_cluster"):
+            trainer.model.check_cluster()      # a timeout inside to_logits would make the metrics below meaningless
         if rank == 0:
             rep = classification_report(true, pred, params.n_classes)
             for k in ("acc", "wa", "f1", "mif1", "maf1", "pre", "rec"):

@@ -351,11 +351,14 @@ int erc_head_ce(const float* Z, int ldz, int F, int C, int n_rows, const float* 
  *   grad_scale multiplies g first (1/world_size after a sum all-reduce).
  *   bf16_shadow (optional): the updated p[shadow_off, shadow_off+shadow_n) is also written as bf16 -- the weight
  *   operand of erc_gemm_bf16a_stream stays in sync without a conversion launch.
+ *   skip_flag (optional): device int32; when non-zero at launch time the whole update is skipped (parameters, moments
+ *   and the step counter stay as they are): the DAG-ERC recurrence kernels raise it when an exchange timed out, i.e.
+ *   when this step's gradients are invalid -- the step fails on the device, no host synchronisation.
  */
 int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
                   float grad_scale, float clip_norm, const float* gnorm, int64_t* state,
-                  void* bf16_shadow, int64_t shadow_off, int64_t shadow_n, void* stream);
+                  void* bf16_shadow, int64_t shadow_off, int64_t shadow_n, const int32_t* skip_flag, void* stream);
 /* diagnostic: out[0] = shader cycles, out[1] = 10-ns ticks of a fixed dependent-MFMA loop (bench.py --clock_probe) */
 int erc_clock_probe(uint64_t* out, int iters, void* stream);
 /* gnorm[0] = ||g * grad_scale||_2 ; ws >= 1024 floats */
@@ -406,6 +409,41 @@ int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
  * d[Wr0;Wr1] = dR^T H1, dH_l += DGI [W_ih_c;W_hh_p]); accumulates dR [B*T,600] / dks [B*T] (caller zero-fills),
  * ADDS the direct gradient wrt H_l into dHl, and writes the per-dialogue partial gradient of gather.linear
  * to dlin [B,601]. */
+/* ------------------------------------------------------------------------
+ * K6, second generation: the same recurrence (dagerc.py:167-189, dagerc_models.py:326-365) weight-stationary with the
+ * batch of dialogues as the MFMA M dimension (csrc/dag_rec.hip).  A group of `dg` dialogues is advanced by 300 / epc
+ * workgroups; workgroup c keeps the weight rows / columns of its hidden elements [c epc, (c+1) epc) in registers for all
+ * T steps and the groups' 300-vectors are exchanged as tagged 8-byte records (two exchanges per step and direction).
+ *   erc_dag_rec_config: picks (epc, dg, groups_per_launch) for B dialogues of padded length T from the device's CU count
+ *     and the occupancy query of BOTH kernels, so that every workgroup of a launch is resident (hints > 0 force a value);
+ *     when the device cannot hold all groups at once the entry points below issue several launches.
+ *   GI [B*T, ldgi >= 1801]: columns [0,1800) the hoisted gate pre-activations as for erc_dag_scan_fwd, column 1800 the
+ *     hoisted query score w_q.H_l[t] + b (gather.linear): one GEMM with the stacked weight
+ *     [W_ih(grus_c) ; W_hh(grus_p) ; w_q] by the caller.  w_k [300] = the key half of gather.linear.weight.
+ *   DGI [B*T, lddgi >= 1801] (backward, written): columns [0,1800) as for erc_dag_scan_bwd, column 1800 d(query score):
+ *     dH_l += DGI [W_ih_c ; W_hh_p ; w_q] and d[W_ih_c ; W_hh_p ; w_q] = DGI^T H_l are single GEMMs; dw_k = dks^T H1.
+ *   dR [B*T,600] / dks [B*T]: written (final values; no zero-fill needed).
+ *   state: int32 [1 + ceil(B / dg)], zero-filled ONCE by the caller: [0] is raised when a poll ran into its bound (results
+ *     invalid; pass it to erc_adam_step as skip_flag), then one launch epoch per group.
+ *   scratch: erc_dag_rec_scratch_bytes(B, epc, dg) bytes, 8-byte aligned, zero-filled ONCE (exchange records).
+ * T <= 1022 and the per-workgroup LDS (histories of the slice: grows with dg * T) <= 160 KB. */
+int erc_dag_rec_config(int B, int T, int epc_hint, int dg_hint, int* epc, int* dg, int* groups_per_launch);
+int64_t erc_dag_rec_scratch_bytes(int B, int epc, int dg);
+/* diagnostic: while set, the recurrence kernels store shader-clock stamps of workgroup 0 per step and phase into
+ * stamps[T][2][8] (tools/dag_stamps.py); NULL (the default) switches it off. */
+int erc_dag_rec_set_stamps(uint64_t* stamps);
+int erc_dag_rec_fwd(const float* Hl, int ldh, const float* GI, int ldgi,
+                    const float* W_hh_c, const float* b_hh_c, const float* W_ih_p, const float* b_ih_p,
+                    const float* Wr, const float* w_k, const int32_t* pred, const int32_t* spk, int B, int T,
+                    float* H1, int ldo, float* Mseq, float* GH, float* R, float* ks, float* alpha,
+                    int epc, int dg, int groups_per_launch, int32_t* state, void* scratch, void* stream);
+int erc_dag_rec_bwd(const float* Hl, int ldh, const float* GI, int ldgi, const float* GH, const float* Mseq,
+                    const float* R, const float* alpha, const float* W_hh_c, const float* W_ih_p, const float* Wr,
+                    const float* w_k, const int32_t* pred, const int32_t* spk, int B, int T,
+                    const float* dH1, int ldd, float* dHl, int lddl, float* DGI, int lddgi, float* DGH,
+                    float* dR, float* dks, int epc, int dg, int groups_per_launch, int32_t* state, void* scratch,
+                    void* stream);
+
 /* (cluster / cl_state / cl_scratch as in erc_dag_scan_fwd) */
 int64_t erc_dag_cluster_scratch_floats(int B, int T);
 int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,

@@ -88,30 +88,57 @@ def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C):
     mine.check_cluster()      # no member of a cluster-mode recurrence kernel timed out
 
 
-def test_cluster_scan_equals_single_workgroup_scan(monkeypatch):
-    """The recurrence kernels in cluster mode (P workgroups per dialogue) against one workgroup per dialogue: hidden
-    states equal up to the association order inside a row's dot product (the cluster kernels fetch the 44-float row
-    tails four rows per instruction, so a tail lands in a different lane of the butterfly sum), gradients up to the
-    order of the cross-member partial sums."""
-    from erc_amd import capi
+def test_recurrence_configurations_agree(monkeypatch):
+    """The weight-stationary recurrence kernels under different partitions -- elements per workgroup (EPC: 5 / 4 / 2 ->
+    60 / 75 / 150 workgroups per group) and dialogues per group (DG: the MFMA M rows in use; a ragged last group;
+    several launches when the groups do not fit the device at once): hidden states and gradients equal up to the
+    association order of the cross-workgroup partial sums."""
     from erc_amd.dagerc import DAGERCModule
     dims = dict(a=30, t=60, v=34)
     batch = make_batch(6, dims, n_speakers=3, n_classes=5, min_len=2, max_len=37, seed=4, speaker_onehot=True, force_max=True)
     res = {}
-    for P in (1, 4, 8, 16):
-        monkeypatch.setenv("ERC_DAG_CLUSTER", str(P))
+    configs = [(0, 0), (5, 1), (5, 4), (4, 3), (4, 6), (2, 6), (2, 16), (5, 16)]
+    for epc, dg in configs:
+        monkeypatch.setenv("ERC_DAG_EPC", str(epc))
+        monkeypatch.setenv("ERC_DAG_DG", str(dg))
         torch.manual_seed(9)
         m = DAGERCModule(emb_dim=sum(dims.values()), dropout=0.0, n_classes=5, gnn_layers=2).finalize(DEV)
         m.train()
         stats = m.loss_and_grads(to_device(batch, DEV)).cpu()
         ws = m._last_ws
-        assert ws["cluster"] == min(P, capi.dag_cluster_size(6))
+        if epc:
+            assert ws["cfg"][:2] == (epc, dg)
         m.check_cluster()
-        res[P] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone())
-    for P in (4, 8, 16):
-        assert abs(res[P][0] - res[1][0]) < 1e-6
-        assert float((res[P][1] - res[1][1]).abs().max()) <= 2e-6 * max(1.0, float(res[1][1].abs().max()))
-        assert float((res[P][2] - res[1][2]).abs().max()) <= 1e-6 * max(1.0, float(res[1][2].abs().max()))
+        res[(epc, dg)] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone(), ws["cfg"])
+    base = res[configs[0]]
+    print("default configuration (epc, dg, groups per launch):", base[3])
+    for key in configs[1:]:
+        assert abs(res[key][0] - base[0]) < 1e-6, key
+        assert float((res[key][1] - base[1]).abs().max()) <= 2e-6 * max(1.0, float(base[1].abs().max())), key
+        assert float((res[key][2] - base[2]).abs().max()) <= 2e-6 * max(1.0, float(base[2].abs().max())), key
+
+
+def test_recurrence_timeout_fails_the_step_on_the_device():
+    """A raised error flag (what a recurrence kernel sets when an exchange wait runs into its bound) makes the optimizer
+    kernel skip the update -- parameters, moments and the step counter untouched, no host synchronisation involved -- and
+    check_cluster() reports it."""
+    from erc_amd import capi
+    from erc_amd.dagerc import DAGERCTrainer
+    from erc_amd.params import ERCParams
+    p = ERCParams().from_args(["--dataset=iemocap-cogmen-6", "--modality=a"])
+    p.speaker_onehot, p.dropout = True, 0.0
+    tr = DAGERCTrainer(p, DEV)
+    batch = tr.prepare_batch(make_batch(3, p.dims(), n_classes=6, min_len=2, max_len=9, seed=3, modality="a", speaker_onehot=True))
+    tr.train_step(batch)
+    before, step = tr.model.flat.data.clone(), int(tr.optim.state[0])
+    assert step == 1
+    tr.model.rec_state[0] = 1
+    tr.train_step(batch)
+    assert torch.equal(tr.model.flat.data, before) and int(tr.optim.state[0]) == step
+    with pytest.raises(capi.ErcGraftError):
+        tr.model.check_cluster()
+    tr.train_step(batch)                                   # flag cleared by check_cluster: training continues
+    assert not torch.equal(tr.model.flat.data, before) and int(tr.optim.state[0]) == step + 1
 
 
 def test_dagerc_train_step_clip_adamw():
