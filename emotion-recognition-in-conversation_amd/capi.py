@@ -110,13 +110,12 @@ _SIGS = {
     "erc_dag_scan_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
                                    _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "erc_dag_cluster_scratch_floats": (C.c_int64, [_i, _i]),
-    "erc_dag_rec_config": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _vp]),
-    "erc_dag_rec_scratch_bytes": (C.c_int64, [_i, _i, _i]),
+    "erc_dag_rec_config": (C.c_int, [_i, _i, _i, _i, _i, _i, _i, _vp]),
+    "erc_dag_rec_scratch_bytes": (C.c_int64, [_i, _i, _i, _vp]),
     "erc_dag_rec_set_stamps": (C.c_int, [_vp]),
-    "erc_dag_rec_fwd": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
-                                  _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_dag_rec_fwd": (C.c_int, [_vp, _i, _i] + [_vp] * 8 + [_vp, _vp, _i, _i, _vp, _i, _vp, _i] + [_vp] * 5 + [_vp, _vp, _vp, _vp]),
     "erc_dag_rec_bwd": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i,
-                                  _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+                                  _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -315,28 +314,37 @@ def grad_norm(g, n, grad_scale, gnorm, ws):
     _check(lib().erc_grad_norm(ptr(g), n, grad_scale, ptr(gnorm), ptr(ws), stream()), "erc_grad_norm")
 
 
-def dag_rec_config(B, T, epc_hint=0, dg_hint=0):
-    """(epc, dg, groups_per_launch) for the weight-stationary DAG-ERC recurrence on the current device."""
-    out = (C.c_int * 3)()
-    _check(lib().erc_dag_rec_config(B, T, epc_hint, dg_hint, C.addressof(out), C.addressof(out) + 4, C.addressof(out) + 8),
-           "erc_dag_rec_config")
-    return int(out[0]), int(out[1]), int(out[2])
+def dag_rec_config(direction, B, T, n_layers, epc_hint=0, dg_hint=0, lpl_hint=0):
+    """cfg = (epc, dg, groups per launch, layers per launch) of the weight-stationary DAG-ERC recurrence (0 forward,
+    1 backward) on the current device, as a ctypes int array the launch wrappers take."""
+    cfg = (C.c_int * 4)()
+    _check(lib().erc_dag_rec_config(direction, B, T, n_layers, epc_hint, dg_hint, lpl_hint, C.addressof(cfg)), "erc_dag_rec_config")
+    return cfg
 
 
 def dag_rec_set_stamps(t):
     _check(lib().erc_dag_rec_set_stamps(ptr(t)), "erc_dag_rec_set_stamps")
 
 
-def dag_rec_scratch_bytes(B, epc, dg):
-    return int(lib().erc_dag_rec_scratch_bytes(B, epc, dg))
+def dag_rec_scratch_bytes(direction, B, T, cfg):
+    return int(lib().erc_dag_rec_scratch_bytes(direction, B, T, C.addressof(cfg)))
 
 
-def dag_rec_fwd(Hl, ldh, GI, ldgi, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_k, pred, spk, B, T, H1, ldo, Mseq, GH, R, ks, alpha,
-                cfg, state, scratch):
-    _dev(Hl, GI, H1)
-    _check(lib().erc_dag_rec_fwd(ptr(Hl), ldh, ptr(GI), ldgi, ptr(W_hh_c), ptr(b_hh_c), ptr(W_ih_p), ptr(b_ih_p), ptr(Wr),
-                                 ptr(w_k), ptr(pred), ptr(spk), B, T, ptr(H1), ldo, ptr(Mseq), ptr(GH), ptr(R), ptr(ks),
-                                 ptr(alpha), cfg[0], cfg[1], cfg[2], ptr(state), ptr(scratch), stream()), "erc_dag_rec_fwd")
+def ptr_table(tensors):
+    """host array of device pointers (one per layer) for the per-layer operands of erc_dag_rec_fwd"""
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def dag_rec_fwd(H0, ldh0, n_layers, tables, pred, spk, B, T, ldo, ldgi, cfg, state, scratch):
+    """tables: dict of ptr_table()s -- Wh bh W_hh_c b_hh_c W_ih_p b_ih_p Wr w_k | H1 GI Mseq GH R ks alpha"""
+    _dev(H0)
+    t = tables
+    _check(lib().erc_dag_rec_fwd(ptr(H0), ldh0, n_layers, C.addressof(t["Wh"]), C.addressof(t["bh"]), C.addressof(t["W_hh_c"]),
+                                 C.addressof(t["b_hh_c"]), C.addressof(t["W_ih_p"]), C.addressof(t["b_ih_p"]),
+                                 C.addressof(t["Wr"]), C.addressof(t["w_k"]), ptr(pred), ptr(spk), B, T,
+                                 C.addressof(t["H1"]), ldo, C.addressof(t["GI"]), ldgi, C.addressof(t["Mseq"]),
+                                 C.addressof(t["GH"]), C.addressof(t["R"]), C.addressof(t["ks"]), C.addressof(t["alpha"]),
+                                 C.addressof(cfg), ptr(state), ptr(scratch), stream()), "erc_dag_rec_fwd")
 
 
 def dag_rec_bwd(Hl, ldh, GI, ldgi, GH, Mseq, R, alpha, W_hh_c, W_ih_p, Wr, w_k, pred, spk, B, T, dH1, ldd, dHl, lddl, DGI,
@@ -344,7 +352,7 @@ def dag_rec_bwd(Hl, ldh, GI, ldgi, GH, Mseq, R, alpha, W_hh_c, W_ih_p, Wr, w_k, 
     _dev(Hl, GI, dH1)
     _check(lib().erc_dag_rec_bwd(ptr(Hl), ldh, ptr(GI), ldgi, ptr(GH), ptr(Mseq), ptr(R), ptr(alpha), ptr(W_hh_c),
                                  ptr(W_ih_p), ptr(Wr), ptr(w_k), ptr(pred), ptr(spk), B, T, ptr(dH1), ldd, ptr(dHl), lddl,
-                                 ptr(DGI), lddgi, ptr(DGH), ptr(dR), ptr(dks), cfg[0], cfg[1], cfg[2], ptr(state),
+                                 ptr(DGI), lddgi, ptr(DGH), ptr(dR), ptr(dks), C.addressof(cfg), ptr(state),
                                  ptr(scratch), stream()), "erc_dag_rec_bwd")
 
 

@@ -82,7 +82,8 @@ __device__ __forceinline__ float settle(const u64* p, u64 v, unsigned tag, int& 
 
 // The A operand of a matrix wavefront for an all-gathered [dialogue][300] vector set: lane l holds
 // x[m = l & 15][k = 4 s + (l >> 4)] for its k-steps s = wave + 7 q; record (k, m) lives at k * 16 + m = 64 s + l.
-__device__ __forceinline__ void poll_operand(const u64* x, int wave, int lane, int ndlg, unsigned tag, float (&a)[NQ], int* err) {
+template <int NWV, int NQT>
+__device__ __forceinline__ void poll_operand(const u64* x, int wave, int lane, int ndlg, unsigned tag, float (&a)[NQT], int* err) {
     // What an exchange costs is set by the CONSUMER CU's own memory queue (MI355X_MICROARCH.md, handoff-1to1 by streaming
     // waves on the endpoint: 1.0 us idle, 2.3 - 2.8 us with 8 waves streaming): with all 77 record loads of the 7 matrix
     // wavefronts in flight and re-issued while waiting, an all-gather took 4.6 us.  So a wavefront first polls ONE
@@ -106,15 +107,15 @@ __device__ __forceinline__ void poll_operand(const u64* x, int wave, int lane, i
         }
         a[0] = __builtin_bit_cast(float, (unsigned)v0);
     }
-    u64 v[NQ];
+    u64 v[NQT];
 #pragma unroll
-    for (int q = 1; q < NQ; ++q) {
-        const int s = wave + NMW * q;
+    for (int q = 1; q < NQT; ++q) {
+        const int s = wave + NWV * q;
         v[q] = (u64)tag << 32;                     // no record for this lane / k-step: a zero operand
         if (mv && s < KS) v[q] = ld64(x + 64 * s + lane);
     }
 #pragma unroll
-    for (int q = 1; q < NQ; ++q) a[q] = settle(x + 64 * (wave + NMW * q) + lane, v[q], tag, spins, err);
+    for (int q = 1; q < NQT; ++q) a[q] = settle(x + 64 * (wave + NWV * q) + lane, v[q], tag, spins, err);
 }
 
 __device__ __forceinline__ void store_tile(float* dst, const f32x4& acc, int lane) {
@@ -130,42 +131,59 @@ __device__ __forceinline__ const float* gate_row(const float* W_hh_c, const floa
 }
 
 // ----------------------------------------------------------------------------------------------- forward
+// The forward runs the LAYERS as a pipeline: layer l needs, at its step i, only h^{(l-1)}_{i+1} of the layer below, so
+// the (up to) 4 layers of a launch run concurrently on their own workgroups, each about two steps behind the one below;
+// 4 x 110 dependent steps become 110 + 6.  What used to be the hoisted GEMM of a layer (the input-side gates of cell C,
+// the hidden-side gates of cell P and the attention's query score: [W_ih_c ; W_hh_p ; w_q] H_l) is a third stationary
+// product of the layer's workgroups, fed by the records the layer below publishes anyway (its per-step all-gather of h
+// is a RING over the steps, never overwritten inside a launch, so a consumer may lag); it is computed one step ahead
+// and sits in the shadow of the layer's own all-gather of h.
+constexpr int ML = 4;           // layers per launch (pipeline depth)
+constexpr int FMW = 6;          // forward: matrix wavefronts 0..5, elementwise wavefronts 6 and 7 (8 dialogues each)
+constexpr int FNQ = 13;         // k-steps per forward matrix wavefront (ceil(75 / 6))
+
+struct FwdLayer {
+    const float *Wh, *bh;                              // hoisted [1801(+1), 300] = W_ih(grus_c) ; W_hh(grus_p) ; w_q, and its biases [1801]
+    const float *W_hh_c, *b_hh_c, *W_ih_p, *b_ih_p;    // sequential [900,300], [900]
+    const float *Wr, *w_k;                             // [600,300] = Wr0 ; Wr1, [300]
+    float *H1, *GI, *Mseq, *GH, *R, *ks, *alpha;       // outputs / saved for the backward
+};
+
 struct RecFwd {
-    const float* Hl; int ldh;          // layer input [B*T, >= 300]
-    const float* GI; int ldgi;         // hoisted [B*T, >= 1801]: cell C input-side gates | cell P hidden-side gates | w_q.H_l + b
-    const float *W_hh_c, *b_hh_c, *W_ih_p, *b_ih_p;   // [900,300], [900]
-    const float* Wr;                   // [600,300] = Wr0 ; Wr1
-    const float* w_k;                  // [300]
+    const float* H0; int ldh0;         // input of the launch's first layer [B*T, >= 300] (complete before the launch)
+    FwdLayer ly[ML];
+    int ldo, ldgi;                     // row pitch of H1 (>= 300) and of GI (>= 1801)
     const int32_t *pred, *spk;         // [B*T]
-    float* H1; int ldo;                // layer output
-    float *Mseq, *GH, *R, *ks, *alpha; // saved for the backward: [B*T,300], [B*T,1800], [B*T,600], [B*T], [B,T,T]
-    int B, T, DG, g0;                  // dialogues per group, first group of this launch
-    u64 *xm, *xh;                      // [groups][300][16] all-gather records
+    int B, T, DG, g0, nl;              // dialogues per group, first group of this launch, layers of this launch
+    u64 *xm;                           // [groups][ML][300][16]     all-gather records of M (reused every step)
+    u64 *xh;                           // [groups][ML][T][300][16]  all-gather records of h, one set per step (ring)
     int *epoch, *err;                  // [groups], [1]
     u64* stamps;                       // diagnostic (NULL in production): [T][2][8] shader-clock stamps of workgroup 0
 };
 
-// diagnostic phase stamps of workgroup 0 (matrix wavefront 0 -> row 0, elementwise wavefront -> row 1)
+// diagnostic phase stamps of workgroup 0 (matrix wavefront 0 -> row 0, last elementwise wavefront -> row 1)
 #define REC_STAMP(slot)                                                                                        \
     do {                                                                                                       \
-        if (p.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == EWW))                            \
-            p.stamps[((int64_t)i * 2 + (wave == EWW ? 1 : 0)) * 8 + (slot)] = __builtin_amdgcn_s_memtime();   \
+        if (p.stamps && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7))                              \
+            p.stamps[((int64_t)i * 2 + (wave == 7 ? 1 : 0)) * 8 + (slot)] = __builtin_amdgcn_s_memtime();      \
     } while (0)
 
 template <int EPC>
 __global__ __launch_bounds__(NTH) void dag_rec_fwd_kernel(RecFwd p) {
-    constexpr int NTG = (6 * EPC + 15) / 16;            // 16-column tiles of this slice's gate rows
+    constexpr int NTG = (6 * EPC + 15) / 16;            // 16-column tiles of this slice's sequential gate rows
+    constexpr int NTH2 = (6 * EPC + 1 + 15) / 16;       // ... of its hoisted rows (+ the query-score column)
     constexpr int NSL = HID / EPC;
-    constexpr int MAXP = (MAXDG * EPC + 63) / 64;       // passes of the elementwise wavefront over its items
-    static_assert(HID % EPC == 0 && 2 * EPC + 1 <= 16, "slice width");
+    static_assert(HID % EPC == 0 && 2 * EPC + 1 <= 16 && EPC <= 8, "slice width");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = p.g0 + blockIdx.x / NSL, c = blockIdx.x % NSL;
+    const int c = blockIdx.x % NSL, l = (blockIdx.x / NSL) % p.nl, grp = p.g0 + blockIdx.x / (NSL * p.nl);
     const int DG = p.DG, T = p.T;
     const int b0 = grp * DG, ndlg = min(DG, p.B - b0);
-    float* part_g = smem;                               // [NMW][NTG][16][PST]
-    float* part_r = part_g + NMW * NTG * 16 * PST;      // [NMW][16][PST]
-    float* rhist = part_r + NMW * 16 * PST;             // [T][DG][2 EPC]  this slice's relation rows of the steps so far
+    const FwdLayer& L = p.ly[l];
+    float* part_g = smem;                               // [FMW][NTG][16][PST]
+    float* part_h = part_g + FMW * NTG * 16 * PST;      // [FMW][NTH2][16][PST]
+    float* part_r = part_h + FMW * NTH2 * 16 * PST;     // [FMW][16][PST]
+    float* rhist = part_r + FMW * 16 * PST;             // [T][DG][2 EPC]  this slice's relation rows of the steps so far
     float* kshist = rhist + T * DG * 2 * EPC;           // [T][DG]         key scores
     int* s_spk = reinterpret_cast<int*>(kshist + T * DG);   // [DG][T]
     int* s_pred = s_spk + DG * T;
@@ -173,155 +191,199 @@ __global__ __launch_bounds__(NTH) void dag_rec_fwd_kernel(RecFwd p) {
         s_spk[x] = p.spk[(int64_t)b0 * T + x];
         s_pred[x] = p.pred[(int64_t)b0 * T + x];
     }
-    const unsigned ep = (unsigned)p.epoch[grp] + 1u;     // every member reads it before any member can finish
-    u64* const xm = p.xm + (int64_t)grp * XG;
-    u64* const xh = p.xh + (int64_t)grp * XG;
+    // the last layer's slice 0 advances the epoch when it is done: by then every workgroup of the group has read it
+    const unsigned ep = (unsigned)p.epoch[grp] + 1u;
+    u64* const xm = p.xm + ((int64_t)grp * ML + l) * XG;
+    u64* const xh = p.xh + ((int64_t)grp * ML + l) * T * XG;            // this layer's ring
+    const u64* const xlow = xh - (int64_t)T * XG;                       // the ring of the layer below (l > 0)
 
     // ---- stationary weights of the matrix wavefronts
-    float wg[NTG][NQ], wr[NQ];
+    float wg[NTG][FNQ], wh[NTH2][FNQ], wr[FNQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int s = wave + NMW * q, kc = min(4 * s + (lane >> 4), HID - 1);
-        const float kv = (wave < NMW && s < KS) ? 1.f : 0.f;
+    for (int q = 0; q < FNQ; ++q) {
+        const int s = wave + FMW * q, kc = min(4 * s + (lane >> 4), HID - 1);
+        const float kv = (wave < FMW && s < KS) ? 1.f : 0.f;
 #pragma unroll
         for (int t = 0; t < NTG; ++t) {
             const int j = 16 * t + (lane & 15), jc = min(j, 6 * EPC - 1);
-            const float v = gate_row(p.W_hh_c, p.W_ih_p, jc / EPC, c * EPC + jc % EPC)[kc];
-            wg[t][q] = v * (j < 6 * EPC ? kv : 0.f);
+            wg[t][q] = gate_row(L.W_hh_c, L.W_ih_p, jc / EPC, c * EPC + jc % EPC)[kc] * (j < 6 * EPC ? kv : 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < NTH2; ++t) {
+            const int j = 16 * t + (lane & 15), jc = min(j, 6 * EPC);
+            const int row = jc < 6 * EPC ? (jc / EPC) * HID + c * EPC + jc % EPC : 6 * HID;     // gate rows, then w_q
+            wh[t][q] = L.Wh[(int64_t)row * HID + kc] * (j <= 6 * EPC ? kv : 0.f);
         }
         const int j = lane & 15, jc = min(j, 2 * EPC - 1);
-        const float vr = p.Wr[(int64_t)((jc / EPC) * HID + c * EPC + jc % EPC) * HID + kc];
-        const float vk = p.w_k[kc];
-        wr[q] = (j < 2 * EPC ? vr : (j == 2 * EPC ? vk : 0.f)) * kv;
+        const float vr = L.Wr[(int64_t)((jc / EPC) * HID + c * EPC + jc % EPC) * HID + kc];
+        wr[q] = (j < 2 * EPC ? vr : (j == 2 * EPC ? L.w_k[kc] : 0.f)) * kv;
     }
-    // ---- items of the elementwise wavefront: (dialogue m, element el) -> it = el * ndlg + m
-    bool iv[MAXP];
-    int im[MAXP], iel[MAXP];
-    float bias[MAXP][6], mcur[MAXP];
+    // ---- items of the elementwise wavefronts: wavefront 6 + w owns dialogues [8 w, 8 w + 8), lane = el * 8 + (m & 7)
+    const int el = lane >> 3, m = 8 * (wave - FMW) + (lane & 7), e = c * EPC + min(el, EPC - 1);
+    const bool iv = wave >= FMW && el < EPC && m < ndlg;
+    const int mc = iv ? m : 0;
+    float bias[6], bhv[6], gi[6], mcur = 0.f, xcur = 0.f, qnext = 0.f;    // M_0 = 0 (dagerc.py:168-174)
 #pragma unroll
-    for (int r = 0; r < MAXP; ++r) {
-        const int it = lane + 64 * r;
-        iv[r] = wave == EWW && it < ndlg * EPC;
-        const int itc = iv[r] ? it : 0;
-        iel[r] = itc / ndlg, im[r] = itc % ndlg;
-        const int e = c * EPC + iel[r];
-#pragma unroll
-        for (int g = 0; g < 6; ++g) bias[r][g] = g < 3 ? p.b_hh_c[g * HID + e] : p.b_ih_p[(g - 3) * HID + e];
-        mcur[r] = 0.f;                                   // M_0 = 0 (dagerc.py:168-174)
+    for (int g = 0; g < 6; ++g) {
+        bias[g] = g < 3 ? L.b_hh_c[g * HID + e] : L.b_ih_p[(g - 3) * HID + e];
+        bhv[g] = L.bh[g * HID + e];
+        gi[g] = 0.f;
     }
+    const float bq = L.bh[6 * HID];
     __syncthreads();
+
+    // the operand of the hoisted product of step i: row i of the layer below (a plain matrix for the first layer)
+    auto lower_operand = [&](int i, float (&a)[FNQ]) {
+        if (l == 0) {
+            const bool mv = (lane & 15) < ndlg;
+            const float* row = p.H0 + ((int64_t)(b0 + min(lane & 15, ndlg - 1)) * T + i) * p.ldh0;
+#pragma unroll
+            for (int q = 0; q < FNQ; ++q) {
+                const int s = wave + FMW * q;
+                a[q] = row[min(4 * s + (lane >> 4), HID - 1)] * ((mv && s < KS) ? 1.f : 0.f);
+            }
+        } else {
+            poll_operand<FMW, FNQ>(xlow + (int64_t)i * XG, wave, lane, ndlg, ep * 1024u + (unsigned)i + 1u, a, p.err);
+        }
+    };
+    auto hoisted_product = [&](int i) {               // matrix wavefronts: partial tiles of [W_ih_c ; W_hh_p ; w_q] h^{(l-1)}_i
+        float a[FNQ];
+        lower_operand(i, a);
+        f32x4 acc[NTH2];
+#pragma unroll
+        for (int t = 0; t < NTH2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < FNQ; ++q)
+#pragma unroll
+            for (int t = 0; t < NTH2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wh[t][q], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTH2; ++t) store_tile(part_h + (wave * NTH2 + t) * 16 * PST, acc[t], lane);
+    };
+    auto hoisted_reduce = [&](int i) {                // elementwise wavefronts: gates of step i (+ bias), query score, x
+        if (!iv) return;
+        const int64_t row = (int64_t)(b0 + m) * T + i;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int j = g * EPC + el;
+            float s = bhv[g];
+#pragma unroll
+            for (int w = 0; w < FMW; ++w) s += part_h[((w * NTH2 + (j >> 4)) * 16 + m) * PST + (j & 15)];
+            gi[g] = s;
+            L.GI[row * p.ldgi + g * HID + e] = s;
+        }
+        {
+            constexpr int j = 6 * EPC;
+            float s = bq;
+#pragma unroll
+            for (int w = 0; w < FMW; ++w) s += part_h[((w * NTH2 + (j >> 4)) * 16 + m) * PST + (j & 15)];
+            qnext = s;
+            if (c == 0 && el == 0) L.GI[row * p.ldgi + 6 * HID] = s;
+        }
+        if (l == 0) {
+            xcur = p.H0[row * p.ldh0 + e];
+        } else {      // the record was consumed by the matrix wavefronts before the barrier: it is there
+            const u64* rp = xlow + (int64_t)i * XG + e * XROW + m;
+            int spins = 0;
+            xcur = settle(rp, ld64(rp), ep * 1024u + (unsigned)i + 1u, spins, p.err);
+        }
+    };
+
+    // ---- prologue: the hoisted product of step 0
+    if (wave < FMW) hoisted_product(0);
+    __syncthreads();
+    hoisted_reduce(0);
 
     for (int i = 0; i < T; ++i) {
         const unsigned tag = ep * 1024u + (unsigned)i + 1u;
-        float gi[MAXP][6], xv[MAXP], qn[MAXP];
         REC_STAMP(0);
-        if (wave < NMW) {
+        if (wave < FMW) {
             // ---- gates = [W_hh_c ; W_ih_p][rows of E_c] . M_i
             f32x4 acc[NTG];
 #pragma unroll
             for (int t = 0; t < NTG; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (i > 0) {
-                float a[NQ];
-                poll_operand(xm, wave, lane, ndlg, tag, a, p.err);
+                float a[FNQ];
+                poll_operand<FMW, FNQ>(xm, wave, lane, ndlg, tag, a, p.err);
                 REC_STAMP(1);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
+                for (int q = 0; q < FNQ; ++q)
 #pragma unroll
                     for (int t = 0; t < NTG; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wg[t][q], acc[t], 0, 0, 0);
             }
 #pragma unroll
             for (int t = 0; t < NTG; ++t) store_tile(part_g + (wave * NTG + t) * 16 * PST, acc[t], lane);
-        } else {
-            // hoisted operands of this step (requested before the barrier)
-#pragma unroll
-            for (int r = 0; r < MAXP; ++r) {
-                const int64_t row = (int64_t)(b0 + im[r]) * T + i;
-                const int e = c * EPC + iel[r];
-#pragma unroll
-                for (int g = 0; g < 6; ++g) gi[r][g] = p.GI[row * p.ldgi + g * HID + e];
-                xv[r] = p.Hl[row * p.ldh + e];
-                qn[r] = p.GI[(row + (i + 1 < T ? 1 : 0)) * p.ldgi + 6 * HID];     // query score of step i + 1
-            }
         }
         REC_STAMP(2);
         __syncthreads();
         REC_STAMP(3);
-        if (wave < NMW) {
-            // ---- R_i = Wr[rows of E_c] . h_i and ks_i = w_k . h_i
-            float a[NQ];
-            poll_operand(xh, wave, lane, ndlg, tag, a, p.err);
+        if (wave < FMW) {
+            // ---- the hoisted product of step i + 1 (its operand is normally there already: the layer below runs ahead) ...
+            if (i + 1 < T) hoisted_product(i + 1);
+            // ---- ... then R_i = Wr[rows of E_c] . h_i and ks_i = w_k . h_i
+            float a[FNQ];
+            poll_operand<FMW, FNQ>(xh + (int64_t)i * XG, wave, lane, ndlg, tag, a, p.err);
             REC_STAMP(4);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wr[q], acc, 0, 0, 0);
+            for (int q = 0; q < FNQ; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wr[q], acc, 0, 0, 0);
             store_tile(part_r + wave * 16 * PST, acc, lane);
-        } else {
+        } else if (iv) {
             // ---- the two GRU cells of this slice's elements (dagerc.py:175-186), h_i = C + P
+            const int64_t row = (int64_t)(b0 + m) * T + i;
+            float gh[6];
 #pragma unroll
-            for (int r = 0; r < MAXP; ++r) {
-                if (!iv[r]) continue;
-                const int m = im[r], el = iel[r], e = c * EPC + el;
-                const int64_t row = (int64_t)(b0 + m) * T + i;
-                float gh[6];
+            for (int g = 0; g < 6; ++g) {
+                const int j = g * EPC + el;
+                float s = bias[g];
 #pragma unroll
-                for (int g = 0; g < 6; ++g) {
-                    const int j = g * EPC + el;
-                    float s = bias[r][g];
-#pragma unroll
-                    for (int w = 0; w < NMW; ++w) s += part_g[((w * NTG + (j >> 4)) * 16 + m) * PST + (j & 15)];
-                    gh[g] = s;
-                }
-                float rr = sigm(gi[r][0] + gh[0]);
-                float zz = sigm(gi[r][1] + gh[1]);
-                float nn = tanhf(gi[r][2] + rr * gh[2]);
-                const float cc = (1.f - zz) * nn + zz * mcur[r];          // cell C: x = H_l[i], h = M_i
-                rr = sigm(gh[3] + gi[r][3]);
-                zz = sigm(gh[4] + gi[r][4]);
-                nn = tanhf(gh[5] + rr * gi[r][5]);
-                const float pp = (1.f - zz) * nn + zz * xv[r];            // cell P: x = M_i, h = H_l[i]
-                const float h1 = cc + pp;
-                st_tag(xh + e * XROW + m, h1, tag);
-                REC_STAMP(4);
-                p.H1[row * p.ldo + e] = h1;
-                p.Mseq[row * HID + e] = mcur[r];
-#pragma unroll
-                for (int g = 0; g < 6; ++g) p.GH[row * 6 * HID + g * HID + e] = gh[g];
+                for (int w = 0; w < FMW; ++w) s += part_g[((w * NTG + (j >> 4)) * 16 + m) * PST + (j & 15)];
+                gh[g] = s;
             }
+            float rr = sigm(gi[0] + gh[0]);
+            float zz = sigm(gi[1] + gh[1]);
+            float nn = tanhf(gi[2] + rr * gh[2]);
+            const float cc = (1.f - zz) * nn + zz * mcur;               // cell C: x = H_l[i], h = M_i
+            rr = sigm(gh[3] + gi[3]);
+            zz = sigm(gh[4] + gi[4]);
+            nn = tanhf(gh[5] + rr * gi[5]);
+            const float pp = (1.f - zz) * nn + zz * xcur;               // cell P: x = M_i, h = H_l[i]
+            const float h1 = cc + pp;
+            st_tag(xh + (int64_t)i * XG + e * XROW + m, h1, tag);
+            REC_STAMP(4);
+            L.H1[row * p.ldo + e] = h1;
+            L.Mseq[row * HID + e] = mcur;
+#pragma unroll
+            for (int g = 0; g < 6; ++g) L.GH[row * 6 * HID + g * HID + e] = gh[g];
         }
         REC_STAMP(5);
         __syncthreads();
         REC_STAMP(6);
-        if (wave == EWW) {
-#pragma unroll
-            for (int r = 0; r < MAXP; ++r) {
-                if (!iv[r]) continue;
-                const int m = im[r], el = iel[r], e = c * EPC + el;
+        if (wave >= FMW) {
+            if (iv) {
                 const int64_t row = (int64_t)(b0 + m) * T + i;
                 float r0 = 0.f, r1 = 0.f, kk = 0.f;
 #pragma unroll
-                for (int w = 0; w < NMW; ++w) {
+                for (int w = 0; w < FMW; ++w) {
                     const float* pr = part_r + (w * 16 + m) * PST;
                     r0 += pr[el], r1 += pr[EPC + el], kk += pr[2 * EPC];
                 }
                 rhist[(i * DG + m) * 2 * EPC + el] = r0;
                 rhist[(i * DG + m) * 2 * EPC + EPC + el] = r1;
-                p.R[row * 2 * HID + e] = r0;
-                p.R[row * 2 * HID + HID + e] = r1;
+                L.R[row * 2 * HID + e] = r0;
+                L.R[row * 2 * HID + HID + e] = r1;
                 if (el == 0) {
                     kshist[i * DG + m] = kk;
-                    if (c == 0) p.ks[row] = kk;
+                    if (c == 0) L.ks[row] = kk;
                 }
             }
-            // ---- attention of step i + 1 over its DAG predecessors [max(pred, 0), i] (dagerc_models.py:326-365)
             if (i + 1 < T) {
-                const int ii = i + 1;
-                const unsigned tagn = tag + 1u;
-#pragma unroll
-                for (int r = 0; r < MAXP; ++r) {
-                    if (!iv[r]) continue;
-                    const int m = im[r], el = iel[r], e = c * EPC + el;
-                    const int pr = s_pred[m * T + ii], lo = pr > 0 ? pr : 0, si = s_spk[m * T + ii];
-                    const float qs = qn[r];
+                hoisted_reduce(i + 1);
+                // ---- attention of step i + 1 over its DAG predecessors [max(pred, 0), i] (dagerc_models.py:326-365);
+                //      every dialogue's items live in ONE wavefront, so the histories need no workgroup barrier
+                if (iv) {
+                    const int ii = i + 1;
+                    const int pr = s_pred[mc * T + ii], lo = pr > 0 ? pr : 0, si = s_spk[mc * T + ii];
+                    const float qs = qnext;
                     float mx = -INFINITY;
                     for (int j = lo; j <= i; ++j) mx = fmaxf(mx, qs + kshist[j * DG + m]);
                     float den = 0.f;
@@ -329,20 +391,20 @@ __global__ __launch_bounds__(NTH) void dag_rec_fwd_kernel(RecFwd p) {
                     const float inv = 1.0f / den;
                     float macc = 0.f;
                     const bool sv = c == 0 && el == 0;
-                    float* arow = p.alpha + ((int64_t)(b0 + m) * T + ii) * T;
+                    float* arow = L.alpha + ((int64_t)(b0 + m) * T + ii) * T;
                     for (int j = lo; j <= i; ++j) {
                         const float al = expf(qs + kshist[j * DG + m] - mx) * inv;
                         macc += al * rhist[(j * DG + m) * 2 * EPC + (s_spk[m * T + j] == si ? 0 : EPC) + el];
                         if (sv) arow[j] = al;
                     }
-                    mcur[r] = macc;
-                    st_tag(xm + e * XROW + m, macc, tagn);
+                    mcur = macc;
+                    st_tag(xm + e * XROW + m, macc, tag + 1u);
                 }
             }
             REC_STAMP(7);
         }
     }
-    if (c == 0 && tid == 0) p.epoch[grp] = (int)ep;
+    if (l == p.nl - 1 && c == 0 && tid == 0) p.epoch[grp] = (int)ep;
 }
 
 // ----------------------------------------------------------------------------------------------- backward
@@ -553,7 +615,7 @@ __global__ __launch_bounds__(NTH) void dag_rec_bwd_kernel(RecBwd p) {
             }
         } else {
             float a[NQ];
-            poll_operand(xm, wave, lane, ndlg, tag, a, p.err);
+            poll_operand<NMW, NQ>(xm, wave, lane, ndlg, tag, a, p.err);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -633,16 +695,15 @@ __global__ __launch_bounds__(NTH) void dag_rec_bwd_kernel(RecBwd p) {
 
 // ----------------------------------------------------------------------------------------------- host side
 int lds_fwd(int epc, int dg, int T) {
-    const int ntg = (6 * epc + 15) / 16;
-    return 4 * (NMW * ntg * 16 * PST + NMW * 16 * PST + T * dg * 2 * epc + T * dg + 2 * dg * T);
+    const int ntg = (6 * epc + 15) / 16, nth2 = (6 * epc + 1 + 15) / 16;
+    return 4 * (FMW * (ntg + nth2 + 1) * 16 * PST + T * dg * 2 * epc + T * dg + 2 * dg * T);
 }
 int lds_bwd(int epc, int dg, int T) {
     const int nkg = (6 * epc + 3) / 4;
     return 4 * (16 * (4 * nkg + 1) + NTH + NMW * 16 * PST + 16 * DMP + T * dg * (3 * epc + 1) + dg * T + 2 * dg * T);
 }
 
-template <int EPC>
-int capacity(int dg, int T) {      // workgroups of BOTH kernels that the device holds at once
+int device_cus() {
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -650,51 +711,66 @@ int capacity(int dg, int T) {      // workgroups of BOTH kernels that the device
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
         cus = prop.multiProcessorCount;
     }
-    const int lf = lds_fwd(EPC, dg, T), lb = lds_bwd(EPC, dg, T);
-    if (lf > 160 * 1024 || lb > 160 * 1024) return 0;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(dag_rec_fwd_kernel<EPC>), hipFuncAttributeMaxDynamicSharedMemorySize, lf) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dag_rec_bwd_kernel<EPC>), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess)
-        return -1;
-    int nf = 0, nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nf, dag_rec_fwd_kernel<EPC>, NTH, lf) != hipSuccess) return -1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dag_rec_bwd_kernel<EPC>, NTH, lb) != hipSuccess) return -1;
-    // one workgroup per CU is what the exchange latency is tuned for; never count more than the query admits
-    return cus * (nf < nb ? (nf < 1 ? nf : 1) : (nb < 1 ? nb : 1));
+    return cus;
 }
 
-int capacity_of(int epc, int dg, int T) {
+// workgroups of a kernel that the device holds at once (one per CU is what the exchange latency is tuned for; never more
+// than the occupancy query admits); also raises the kernel's dynamic-LDS limit to what the launch will ask for
+template <typename K>
+int capacity(K kernel, int lds) {
+    const int cus = device_cus();
+    if (cus < 0) return -1;
+    if (lds > 160 * 1024) return 0;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NTH, lds) != hipSuccess) return -1;
+    return cus * (n < 1 ? n : 1);
+}
+
+int capacity_of(int dir, int epc, int dg, int T) {
+    const int lds = dir ? lds_bwd(epc, dg, T) : lds_fwd(epc, dg, T);
     switch (epc) {
-        case 2: return capacity<2>(dg, T);
-        case 4: return capacity<4>(dg, T);
-        case 5: return capacity<5>(dg, T);
+        case 2: return dir ? capacity(dag_rec_bwd_kernel<2>, lds) : capacity(dag_rec_fwd_kernel<2>, lds);
+        case 4: return dir ? capacity(dag_rec_bwd_kernel<4>, lds) : capacity(dag_rec_fwd_kernel<4>, lds);
+        case 5: return dir ? capacity(dag_rec_bwd_kernel<5>, lds) : capacity(dag_rec_fwd_kernel<5>, lds);
         default: return 0;
     }
 }
 
+bool cfg_ok(const int* cfg) {
+    return cfg && (cfg[0] == 2 || cfg[0] == 4 || cfg[0] == 5) && cfg[1] >= 1 && cfg[1] <= MAXDG && cfg[2] >= 1 && cfg[3] >= 1 && cfg[3] <= ML;
+}
+
 }  // namespace
 
-extern "C" int erc_dag_rec_config(int B, int T, int epc_hint, int dg_hint, int* epc_out, int* dg_out, int* groups_per_launch) {
-    ERC_REQUIRE(B > 0 && T > 0 && T < 1023 && epc_out && dg_out && groups_per_launch, "dag_rec_config: B=%d T=%d", B, T);
+// cfg[4] = {elements per workgroup, dialogues per group, groups per launch, layers per launch}
+extern "C" int erc_dag_rec_config(int dir, int B, int T, int n_layers, int epc_hint, int dg_hint, int lpl_hint, int* cfg) {
+    ERC_REQUIRE(B > 0 && T > 0 && T < 1023 && n_layers > 0 && cfg, "dag_rec_config: B=%d T=%d layers=%d", B, T, n_layers);
     const int cand[3] = {5, 4, 2};
-    int best_epc = 0, best_dg = 0, best_gpl = 0;
+    double best = 1e30;
+    cfg[0] = 0;
     for (int ci = 0; ci < 3; ++ci) {
-        const int epc = cand[ci];
+        const int epc = cand[ci], P = HID / epc;
         if (epc_hint > 0 && epc != epc_hint) continue;
-        const int P = HID / epc;
-        // dialogues per group: the smallest DG whose groups all fit into one launch (LDS grows with DG)
         for (int dg = (dg_hint > 0 ? dg_hint : 1); dg <= (dg_hint > 0 ? dg_hint : MAXDG); ++dg) {
-            const int cap = capacity_of(epc, dg, T);
+            const int cap = capacity_of(dir, epc, dg, T);
             ERC_REQUIRE(cap >= 0, "dag_rec_config: device query failed (no GPU?)");
-            const int gpl = cap / P, groups = erc_cdiv(B, dg);
-            if (gpl < 1) continue;
-            if (groups <= gpl || dg == MAXDG || dg_hint > 0) {
-                if (!best_epc || dg < best_dg) best_epc = epc, best_dg = dg, best_gpl = gpl < groups ? gpl : groups;
-                break;
+            const int groups = erc_cdiv(B, dg);
+            const int lmax = dir ? 1 : (n_layers < ML ? n_layers : ML);      // only the forward pipelines the layers
+            for (int lpl = (lpl_hint > 0 ? lpl_hint : 1); lpl <= (lpl_hint > 0 ? lpl_hint : lmax); ++lpl) {
+                if (lpl > lmax) break;
+                int gpl = cap / (lpl * P);
+                if (gpl < 1) continue;
+                if (gpl > groups) gpl = groups;
+                // dependent steps of all launches; a mild preference for fewer dialogues per group (shorter elementwise
+                // phases, smaller records) and for more elements per workgroup (fewer members per exchange)
+                const double steps = (double)erc_cdiv(groups, gpl) * erc_cdiv(n_layers, lpl) * (T + 2 * (lpl - 1));
+                const double cost = steps * (1.0 + 0.01 * dg + 0.02 * ci);
+                if (cost < best) best = cost, cfg[0] = epc, cfg[1] = dg, cfg[2] = gpl, cfg[3] = lpl;
             }
         }
     }
-    ERC_REQUIRE(best_epc, "dag_rec_config: no configuration fits this device (B=%d T=%d: LDS per workgroup or CU count)", B, T);
-    *epc_out = best_epc, *dg_out = best_dg, *groups_per_launch = best_gpl;
+    ERC_REQUIRE(cfg[0], "dag_rec_config: no configuration fits this device (B=%d T=%d: LDS per workgroup or CU count)", B, T);
     return ERC_OK;
 }
 
@@ -706,44 +782,64 @@ extern "C" int erc_dag_rec_set_stamps(uint64_t* stamps) {
     return ERC_OK;
 }
 
-// scratch (bytes): all-gather records xm | xh [groups][300][16] u64, reduce-scatter records xd [groups][P][P][DG][EPC] u64
-extern "C" int64_t erc_dag_rec_scratch_bytes(int B, int epc, int dg) {
-    if (B <= 0 || epc <= 0 || dg <= 0 || HID % epc) return -1;
-    const int64_t groups = erc_cdiv(B, dg), P = HID / epc;
-    return 8 * (2 * groups * XG + groups * P * P * dg * epc);
+// scratch (bytes).  forward: all-gather records of M [groups][4][300][16] and the per-step rings of h
+// [groups][4][T][300][16]; backward: all-gather records of dM [groups][300][16], reduce-scatter records
+// [groups][P][P][dg][epc] (8 bytes each)
+extern "C" int64_t erc_dag_rec_scratch_bytes(int dir, int B, int T, const int* cfg) {
+    if (B <= 0 || T <= 0 || !cfg_ok(cfg)) return -1;
+    const int64_t groups = erc_cdiv(B, cfg[1]), P = HID / cfg[0];
+    return dir ? 8 * (groups * XG + groups * P * P * cfg[1] * cfg[0]) : 8 * (groups * ML * XG * (1 + (int64_t)T));
 }
 
-#define REC_DISPATCH(KERNEL, ARGS, LDS)                                                                                  \
-    switch (epc) {                                                                                                       \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(ng * (HID / 2)), dim3(NTH), LDS, st, ARGS); break;                    \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3(ng * (HID / 4)), dim3(NTH), LDS, st, ARGS); break;                    \
-        case 5: hipLaunchKernelGGL(KERNEL<5>, dim3(ng * (HID / 5)), dim3(NTH), LDS, st, ARGS); break;                    \
+#define REC_DISPATCH(KERNEL, ARGS, LDS, WGS)                                                                    \
+    switch (cfg[0]) {                                                                                           \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3((WGS) * (HID / 2)), dim3(NTH), LDS, st, ARGS); break;        \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3((WGS) * (HID / 4)), dim3(NTH), LDS, st, ARGS); break;        \
+        case 5: hipLaunchKernelGGL(KERNEL<5>, dim3((WGS) * (HID / 5)), dim3(NTH), LDS, st, ARGS); break;        \
     }
 
-extern "C" int erc_dag_rec_fwd(const float* Hl, int ldh, const float* GI, int ldgi, const float* W_hh_c, const float* b_hh_c,
-                               const float* W_ih_p, const float* b_ih_p, const float* Wr, const float* w_k,
-                               const int32_t* pred, const int32_t* spk, int B, int T, float* H1, int ldo, float* Mseq,
-                               float* GH, float* R, float* ks, float* alpha, int epc, int dg, int groups_per_launch,
-                               int32_t* state, void* scratch, void* stream) {
-    ERC_REQUIRE(Hl && GI && W_hh_c && b_hh_c && W_ih_p && b_ih_p && Wr && w_k && pred && spk && H1 && Mseq && GH && R && ks &&
-                    alpha && state && scratch,
+extern "C" int erc_dag_rec_fwd(const float* H0, int ldh0, int n_layers, const float* const* Wh, const float* const* bh,
+                               const float* const* W_hh_c, const float* const* b_hh_c, const float* const* W_ih_p,
+                               const float* const* b_ih_p, const float* const* Wr, const float* const* w_k,
+                               const int32_t* pred, const int32_t* spk, int B, int T, float* const* H1, int ldo,
+                               float* const* GI, int ldgi, float* const* Mseq, float* const* GH, float* const* R,
+                               float* const* ks, float* const* alpha, const int* cfg, int32_t* state, void* scratch,
+                               void* stream) {
+    ERC_REQUIRE(H0 && Wh && bh && W_hh_c && b_hh_c && W_ih_p && b_ih_p && Wr && w_k && pred && spk && H1 && GI && Mseq && GH &&
+                    R && ks && alpha && state && scratch,
                 "dag_rec_fwd: null pointer");
-    ERC_REQUIRE(B > 0 && T > 0 && T < 1023 && ldh >= HID && ldo >= HID && ldgi > 6 * HID, "dag_rec_fwd: bad sizes B=%d T=%d", B, T);
-    ERC_REQUIRE((epc == 2 || epc == 4 || epc == 5) && dg >= 1 && dg <= MAXDG && groups_per_launch >= 1 &&
-                    ((uintptr_t)scratch & 7) == 0,
-                "dag_rec_fwd: epc=%d dg=%d groups_per_launch=%d (use erc_dag_rec_config)", epc, dg, groups_per_launch);
-    const int lds = lds_fwd(epc, dg, T);
+    ERC_REQUIRE(B > 0 && T > 0 && T < 1023 && n_layers > 0 && ldh0 >= HID && ldo >= HID && ldgi > 6 * HID,
+                "dag_rec_fwd: bad sizes B=%d T=%d layers=%d", B, T, n_layers);
+    ERC_REQUIRE(cfg_ok(cfg) && ((uintptr_t)scratch & 7) == 0, "dag_rec_fwd: bad configuration (use erc_dag_rec_config)");
+    const int dg = cfg[1], gpl = cfg[2], lpl = cfg[3];
+    const int lds = lds_fwd(cfg[0], dg, T);
     ERC_REQUIRE(lds <= 160 * 1024, "dag_rec_fwd: T=%d with %d dialogues per group needs %d bytes of LDS", T, dg, lds);
+    for (int l = 0; l < n_layers; ++l)
+        ERC_REQUIRE(Wh[l] && bh[l] && W_hh_c[l] && b_hh_c[l] && W_ih_p[l] && b_ih_p[l] && Wr[l] && w_k[l] && H1[l] && GI[l] &&
+                        Mseq[l] && GH[l] && R[l] && ks[l] && alpha[l],
+                    "dag_rec_fwd: null pointer in the tables of layer %d", l);
     const int groups = erc_cdiv(B, dg);
     u64* xm = reinterpret_cast<u64*>(scratch);
-    u64* xh = xm + (int64_t)groups * XG;
+    u64* xh = xm + (int64_t)groups * ML * XG;
     hipStream_t st = (hipStream_t)stream;
-    for (int g0 = 0; g0 < groups; g0 += groups_per_launch) {
-        const int ng = groups - g0 < groups_per_launch ? groups - g0 : groups_per_launch;
-        RecFwd p{Hl, ldh, GI, ldgi, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_k, pred, spk, H1, ldo, Mseq, GH, R, ks, alpha,
-                 B, T, dg, g0, xm, xh, state + 1, state, g_stamps};
-        REC_DISPATCH(dag_rec_fwd_kernel, p, lds)
-        ERC_LAUNCH_CHECK("dag_rec_fwd");
+    for (int l0 = 0; l0 < n_layers; l0 += lpl) {
+        const int nl = n_layers - l0 < lpl ? n_layers - l0 : lpl;
+        for (int g0 = 0; g0 < groups; g0 += gpl) {
+            const int ng = groups - g0 < gpl ? groups - g0 : gpl;
+            RecFwd p;
+            p.H0 = l0 == 0 ? H0 : H1[l0 - 1];           // a later chunk reads the previous chunk's output as a plain matrix
+            p.ldh0 = l0 == 0 ? ldh0 : ldo;
+            for (int l = 0; l < nl; ++l)
+                p.ly[l] = FwdLayer{Wh[l0 + l], bh[l0 + l], W_hh_c[l0 + l], b_hh_c[l0 + l], W_ih_p[l0 + l], b_ih_p[l0 + l],
+                                   Wr[l0 + l], w_k[l0 + l], H1[l0 + l], GI[l0 + l], Mseq[l0 + l], GH[l0 + l], R[l0 + l],
+                                   ks[l0 + l], alpha[l0 + l]};
+            for (int l = nl; l < ML; ++l) p.ly[l] = p.ly[0];
+            p.ldo = ldo, p.ldgi = ldgi, p.pred = pred, p.spk = spk;
+            p.B = B, p.T = T, p.DG = dg, p.g0 = g0, p.nl = nl;
+            p.xm = xm, p.xh = xh, p.epoch = state + 1, p.err = state, p.stamps = g_stamps;
+            REC_DISPATCH(dag_rec_fwd_kernel, p, lds, ng * nl)
+            ERC_LAUNCH_CHECK("dag_rec_fwd");
+        }
     }
     return ERC_OK;
 }
@@ -752,25 +848,24 @@ extern "C" int erc_dag_rec_bwd(const float* Hl, int ldh, const float* GI, int ld
                                const float* R, const float* alpha, const float* W_hh_c, const float* W_ih_p, const float* Wr,
                                const float* w_k, const int32_t* pred, const int32_t* spk, int B, int T, const float* dH1,
                                int ldd, float* dHl, int lddl, float* DGI, int lddgi, float* DGH, float* dR, float* dks,
-                               int epc, int dg, int groups_per_launch, int32_t* state, void* scratch, void* stream) {
+                               const int* cfg, int32_t* state, void* scratch, void* stream) {
     ERC_REQUIRE(Hl && GI && GH && Mseq && R && alpha && W_hh_c && W_ih_p && Wr && w_k && pred && spk && dH1 && dHl && DGI &&
                     DGH && dR && dks && state && scratch,
                 "dag_rec_bwd: null pointer");
     ERC_REQUIRE(B > 0 && T > 0 && T < 1023 && ldh >= HID && ldgi > 6 * HID && lddgi > 6 * HID, "dag_rec_bwd: bad sizes B=%d T=%d", B, T);
-    ERC_REQUIRE((epc == 2 || epc == 4 || epc == 5) && dg >= 1 && dg <= MAXDG && groups_per_launch >= 1 &&
-                    ((uintptr_t)scratch & 7) == 0,
-                "dag_rec_bwd: epc=%d dg=%d groups_per_launch=%d (use erc_dag_rec_config)", epc, dg, groups_per_launch);
-    const int lds = lds_bwd(epc, dg, T);
+    ERC_REQUIRE(cfg_ok(cfg) && ((uintptr_t)scratch & 7) == 0, "dag_rec_bwd: bad configuration (use erc_dag_rec_config)");
+    const int dg = cfg[1], gpl = cfg[2];
+    const int lds = lds_bwd(cfg[0], dg, T);
     ERC_REQUIRE(lds <= 160 * 1024, "dag_rec_bwd: T=%d with %d dialogues per group needs %d bytes of LDS", T, dg, lds);
     const int groups = erc_cdiv(B, dg);
     u64* xm = reinterpret_cast<u64*>(scratch);
-    u64* xd = xm + 2 * (int64_t)groups * XG;
+    u64* xd = xm + (int64_t)groups * XG;
     hipStream_t st = (hipStream_t)stream;
-    for (int g0 = 0; g0 < groups; g0 += groups_per_launch) {
-        const int ng = groups - g0 < groups_per_launch ? groups - g0 : groups_per_launch;
+    for (int g0 = 0; g0 < groups; g0 += gpl) {
+        const int ng = groups - g0 < gpl ? groups - g0 : gpl;
         RecBwd p{Hl, ldh, GI, ldgi, GH, Mseq, R, alpha, W_hh_c, W_ih_p, Wr, w_k, pred, spk, dH1, ldd, dHl, lddl, DGI, lddgi,
                  DGH, dR, dks, B, T, dg, g0, xd, xm, state + 1, state, g_stamps};
-        REC_DISPATCH(dag_rec_bwd_kernel, p, lds)
+        REC_DISPATCH(dag_rec_bwd_kernel, p, lds, ng)
         ERC_LAUNCH_CHECK("dag_rec_bwd");
     }
     return ERC_OK;

@@ -117,14 +117,24 @@ class DAGERCModule(nn.Module):
             dR=[f32(BT, 2 * HID) for _ in range(L)], dks=[f32(BT) for _ in range(L)],
             stats=torch.zeros(256, dtype=torch.float32, device=device),
         )
-        # (elements per workgroup, dialogues per group, groups per launch) of the recurrence kernels, from the device's CU
-        # count and the occupancy query (csrc/dag_rec.hip); ERC_DAG_EPC / ERC_DAG_DG force a configuration (tuning, tests)
+        # cfg = (elements per workgroup, dialogues per group, groups per launch, layers per launch) of the recurrence
+        # kernels per direction, from the device's CU count and the occupancy query (csrc/dag_rec.hip);
+        # ERC_DAG_EPC / ERC_DAG_DG / ERC_DAG_LPL force a forward configuration, ERC_DAG_BEPC / ERC_DAG_BDG a backward one
         import os
         if B > 4096:
             raise capi.ErcGraftError("DAG-ERC: more than 4096 dialogues per batch")
-        ws["cfg"] = capi.dag_rec_config(B, T, int(os.environ.get("ERC_DAG_EPC", 0)), int(os.environ.get("ERC_DAG_DG", 0)))
-        ws["rec_scratch"] = torch.zeros(capi.dag_rec_scratch_bytes(B, ws["cfg"][0], ws["cfg"][1]) // 8 + 1, dtype=torch.int64,
-                                        device=device)
+        env = lambda k: int(os.environ.get(k, 0))
+        ws["cfg_f"] = capi.dag_rec_config(0, B, T, L, env("ERC_DAG_EPC"), env("ERC_DAG_DG"), env("ERC_DAG_LPL"))
+        ws["cfg_b"] = capi.dag_rec_config(1, B, T, L, env("ERC_DAG_BEPC"), env("ERC_DAG_BDG"))
+        ws["cfg"] = (tuple(ws["cfg_f"]), tuple(ws["cfg_b"]))
+        i64 = lambda n: torch.zeros(n // 8 + 1, dtype=torch.int64, device=device)
+        ws["scratch_f"] = i64(capi.dag_rec_scratch_bytes(0, B, T, ws["cfg_f"]))
+        ws["scratch_b"] = i64(capi.dag_rec_scratch_bytes(1, B, T, ws["cfg_b"]))
+        W5 = HID * (L + 1)
+        lw = [self._layer_w(l) for l in range(L)]
+        ws["tables"] = {k: capi.ptr_table([w[k] for w in lw]) for k in ("Wh", "bh", "W_hh_c", "b_hh_c", "W_ih_p", "b_ih_p", "Wr", "w_k")}
+        ws["tables"].update(H1=capi.ptr_table([ws["Hall"][:, HID * (l + 1):] for l in range(L)]),
+                            **{k: capi.ptr_table(ws[k]) for k in ("GI", "Mseq", "GH", "R", "ks", "alpha")})
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
@@ -147,7 +157,7 @@ class DAGERCModule(nn.Module):
 
     def _layer_w(self, l):
         fp = self.flat
-        return dict(Whoist=fp.w("grus_c.%d.weight_ih" % l), bhoist=fp.w("grus_c.%d.bias_ih" % l),
+        return dict(Wh=fp.w("grus_c.%d.weight_ih" % l), bh=fp.w("grus_c.%d.bias_ih" % l),
                     W_hh_c=fp.w("grus_c.%d.weight_hh" % l), b_hh_c=fp.w("grus_c.%d.bias_hh" % l),
                     W_ih_p=fp.w("grus_p.%d.weight_ih" % l), b_ih_p=fp.w("grus_p.%d.bias_ih" % l),
                     Wr=fp.w("gather.%d.Wr0.weight" % l), w_k=fp.w("gather.%d.linear.weight" % l).view(-1)[HID:])
@@ -172,14 +182,10 @@ class DAGERCModule(nn.Module):
         Hall = ws["Hall"]
         # H0 = relu(fc1(x)) over ALL B*T rows, padded ones included (dagerc.py:164)
         linear_fwd(pl, x, D, None, fp.w("fc1.weight"), fp.w("fc1.bias"), Hall, W5, BT, HID, D, act=1, x_bf16=x_bf16)
-        for l in range(L):
-            w = self._layer_w(l)
-            Hl, H1 = Hall[:, HID * l:], Hall[:, HID * (l + 1):]
-            # gates of both cells' hoisted sides and the query score w_q.H_l + b: one GEMM, N = 1801
-            linear_fwd(pl, Hl, W5, None, w["Whoist"], w["bhoist"], ws["GI"][l], LDG, BT, 6 * HID + 1, HID)
-            capi.dag_rec_fwd(Hl, W5, ws["GI"][l], LDG, w["W_hh_c"], w["b_hh_c"], w["W_ih_p"], w["b_ih_p"], w["Wr"], w["w_k"],
-                             ws["pred"], ws["spk"], B, T, H1, W5, ws["Mseq"][l], ws["GH"][l], ws["R"][l], ws["ks"][l],
-                             ws["alpha"][l], ws["cfg"], self.rec_state, ws["rec_scratch"])
+        # all layers in one pipelined launch (csrc/dag_rec.hip): the hoisted products (gates of both cells' hoisted sides,
+        # query score) are computed -- and saved to GI -- by the recurrence's own workgroups
+        capi.dag_rec_fwd(Hall, W5, L, ws["tables"], ws["pred"], ws["spk"], B, T, W5, LDG, ws["cfg_f"], self.rec_state,
+                         ws["scratch_f"])
         # head: Y1 = relu([Hall | x] W0^T + b0) as two GEMMs into one slab set
         W0 = fp.w("out_mlp.0.weight")
         Sa = pl.split_for(BT, HID, W5)
@@ -244,10 +250,10 @@ class DAGERCModule(nn.Module):
             dHl, dH1 = ws["dHall"][:, HID * l:], ws["dHall"][:, HID * (l + 1):]
             capi.dag_rec_bwd(Hl, W5, ws["GI"][l], LDG, ws["GH"][l], ws["Mseq"][l], ws["R"][l], ws["alpha"][l], w["W_hh_c"],
                              w["W_ih_p"], w["Wr"], w["w_k"], ws["pred"], ws["spk"], B, T, dH1, W5, dHl, W5, ws["DGI"][l], LDG,
-                             ws["DGH"][l], ws["dR"][l], ws["dks"][l], ws["cfg"], self.rec_state, ws["rec_scratch"])
+                             ws["DGH"][l], ws["dR"][l], ws["dks"][l], ws["cfg_b"], self.rec_state, ws["scratch_b"])
             # dH_l += DGI [W_ih_c ; W_hh_p ; w_q] (column 1800 of DGI is d(query score)); on layer 0 the same launch
             # applies the relu mask of fc1
-            capi.gemm_f32(ws["DGI"][l], LDG, 0, None, w["Whoist"], HID, 1, None, dHl, W5, BT, HID, 6 * HID + 1,
+            capi.gemm_f32(ws["DGI"][l], LDG, 0, None, w["Wh"], HID, 1, None, dHl, W5, BT, HID, 6 * HID + 1,
                           accumulate=1, act=2 if l == 0 else 0, aux=Hl if l == 0 else None, ldaux=W5, act_scale=1.0)
             # d[W_ih_c ; W_hh_p] and their biases (1800 rows: 16-byte operand loads); the two halves of gather.linear:
             # dw_q = DGI[:, 1800]^T H_l (+ its bias), dw_k = dks^T H1 -- one-row products of the same batched launch

@@ -414,35 +414,42 @@ int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
  * batch of dialogues as the MFMA M dimension (csrc/dag_rec.hip).  A group of `dg` dialogues is advanced by 300 / epc
  * workgroups; workgroup c keeps the weight rows / columns of its hidden elements [c epc, (c+1) epc) in registers for all
  * T steps and the groups' 300-vectors are exchanged as tagged 8-byte records (two exchanges per step and direction).
- *   erc_dag_rec_config: picks (epc, dg, groups_per_launch) for B dialogues of padded length T from the device's CU count
- *     and the occupancy query of BOTH kernels, so that every workgroup of a launch is resident (hints > 0 force a value);
- *     when the device cannot hold all groups at once the entry points below issue several launches.
- *   GI [B*T, ldgi >= 1801]: columns [0,1800) the hoisted gate pre-activations as for erc_dag_scan_fwd, column 1800 the
- *     hoisted query score w_q.H_l[t] + b (gather.linear): one GEMM with the stacked weight
- *     [W_ih(grus_c) ; W_hh(grus_p) ; w_q] by the caller.  w_k [300] = the key half of gather.linear.weight.
- *   DGI [B*T, lddgi >= 1801] (backward, written): columns [0,1800) as for erc_dag_scan_bwd, column 1800 d(query score):
- *     dH_l += DGI [W_ih_c ; W_hh_p ; w_q] and d[W_ih_c ; W_hh_p ; w_q] = DGI^T H_l are single GEMMs; dw_k = dks^T H1.
- *   dR [B*T,600] / dks [B*T]: written (final values; no zero-fill needed).
+ *   erc_dag_rec_config(dir, ...): picks cfg[4] = {epc, dg, groups per launch, layers per launch} for direction dir
+ *     (0 forward, 1 backward), B dialogues of padded length T and n_layers layers from the device's CU count and the
+ *     occupancy query of the kernel, so that every workgroup of a launch is resident (hints > 0 force a value); when the
+ *     device cannot hold everything at once the entry points below issue several launches.
+ *   FORWARD: the layers of a launch run as a PIPELINE (layer l needs at its step t only h^{(l-1)}_{t+1}), each on its
+ *     own workgroups: L x T dependent steps become T + 2 (L - 1).  The former hoisted GEMM of a layer -- GI = [W_ih(grus_c)
+ *     H_l + b | W_hh(grus_p) H_l + b | w_q.H_l + b_lin] -- is computed by the layer's workgroups from the records the layer
+ *     below publishes and SAVED to GI [B*T, ldgi >= 1801] (columns [0,1800) gate pre-activations, column 1800 the query
+ *     score).  Per-layer operands are passed as host arrays of n_layers device pointers:
+ *       Wh [1801(+),300] = W_ih(grus_c) ; W_hh(grus_p) ; w_q (row 1800), bh [1801] its biases (gather.linear.bias last),
+ *       W_hh_c / b_hh_c = grus_c.weight_hh / bias_hh, W_ih_p / b_ih_p = grus_p.weight_ih / bias_ih, Wr = [Wr0 ; Wr1],
+ *       w_k [300] = the key half of gather.linear.weight;  outputs H1 (row pitch ldo), GI, Mseq, GH, R, ks, alpha as for
+ *       erc_dag_scan_fwd.  H0 [B*T, ldh0 >= 300] is the input of layer 0 (relu(fc1 x)).
+ *   BACKWARD (one layer per call, layers not pipelined yet): DGI [B*T, lddgi >= 1801] (written): columns [0,1800) as for
+ *     erc_dag_scan_bwd, column 1800 d(query score): dH_l += DGI [W_ih_c ; W_hh_p ; w_q] and d[W_ih_c ; W_hh_p ; w_q] =
+ *     DGI^T H_l are single GEMMs; dw_k = dks^T H1.  dR [B*T,600] / dks [B*T]: written (final values; no zero-fill needed).
  *   state: int32 [1 + ceil(B / dg)], zero-filled ONCE by the caller: [0] is raised when a poll ran into its bound (results
- *     invalid; pass it to erc_adam_step as skip_flag), then one launch epoch per group.
- *   scratch: erc_dag_rec_scratch_bytes(B, epc, dg) bytes, 8-byte aligned, zero-filled ONCE (exchange records).
+ *     invalid; pass it to erc_adam_step as skip_flag), then one launch epoch per group (shared by both directions).
+ *   scratch: erc_dag_rec_scratch_bytes(dir, B, T, cfg) bytes per direction, 8-byte aligned, zero-filled ONCE.
  * T <= 1022 and the per-workgroup LDS (histories of the slice: grows with dg * T) <= 160 KB. */
-int erc_dag_rec_config(int B, int T, int epc_hint, int dg_hint, int* epc, int* dg, int* groups_per_launch);
-int64_t erc_dag_rec_scratch_bytes(int B, int epc, int dg);
+int erc_dag_rec_config(int dir, int B, int T, int n_layers, int epc_hint, int dg_hint, int lpl_hint, int* cfg);
+int64_t erc_dag_rec_scratch_bytes(int dir, int B, int T, const int* cfg);
 /* diagnostic: while set, the recurrence kernels store shader-clock stamps of workgroup 0 per step and phase into
  * stamps[T][2][8] (tools/dag_stamps.py); NULL (the default) switches it off. */
 int erc_dag_rec_set_stamps(uint64_t* stamps);
-int erc_dag_rec_fwd(const float* Hl, int ldh, const float* GI, int ldgi,
-                    const float* W_hh_c, const float* b_hh_c, const float* W_ih_p, const float* b_ih_p,
-                    const float* Wr, const float* w_k, const int32_t* pred, const int32_t* spk, int B, int T,
-                    float* H1, int ldo, float* Mseq, float* GH, float* R, float* ks, float* alpha,
-                    int epc, int dg, int groups_per_launch, int32_t* state, void* scratch, void* stream);
+int erc_dag_rec_fwd(const float* H0, int ldh0, int n_layers, const float* const* Wh, const float* const* bh,
+                    const float* const* W_hh_c, const float* const* b_hh_c, const float* const* W_ih_p,
+                    const float* const* b_ih_p, const float* const* Wr, const float* const* w_k,
+                    const int32_t* pred, const int32_t* spk, int B, int T, float* const* H1, int ldo,
+                    float* const* GI, int ldgi, float* const* Mseq, float* const* GH, float* const* R,
+                    float* const* ks, float* const* alpha, const int* cfg, int32_t* state, void* scratch, void* stream);
 int erc_dag_rec_bwd(const float* Hl, int ldh, const float* GI, int ldgi, const float* GH, const float* Mseq,
                     const float* R, const float* alpha, const float* W_hh_c, const float* W_ih_p, const float* Wr,
                     const float* w_k, const int32_t* pred, const int32_t* spk, int B, int T,
                     const float* dH1, int ldd, float* dHl, int lddl, float* DGI, int lddgi, float* DGH,
-                    float* dR, float* dks, int epc, int dg, int groups_per_launch, int32_t* state, void* scratch,
-                    void* stream);
+                    float* dR, float* dks, const int* cfg, int32_t* state, void* scratch, void* stream);
 
 /* (cluster / cl_state / cl_scratch as in erc_dag_scan_fwd) */
 int64_t erc_dag_cluster_scratch_floats(int B, int T);

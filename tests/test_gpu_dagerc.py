@@ -90,28 +90,31 @@ def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C):
 
 def test_recurrence_configurations_agree(monkeypatch):
     """The weight-stationary recurrence kernels under different partitions -- elements per workgroup (EPC: 5 / 4 / 2 ->
-    60 / 75 / 150 workgroups per group) and dialogues per group (DG: the MFMA M rows in use; a ragged last group;
-    several launches when the groups do not fit the device at once): hidden states and gradients equal up to the
-    association order of the cross-workgroup partial sums."""
+    60 / 75 / 150 workgroups per group and layer), dialogues per group (DG: the MFMA M rows in use; a ragged last group;
+    several launches when the groups do not fit the device at once) and, in the forward, layers per launch (the layer
+    pipeline: 1 = one layer per launch, 3 = layers {0,1,2} then {3}, 4 = all four concurrently): hidden states and
+    gradients equal up to the association order of the cross-workgroup / cross-wavefront partial sums."""
     from erc_amd.dagerc import DAGERCModule
     dims = dict(a=30, t=60, v=34)
     batch = make_batch(6, dims, n_speakers=3, n_classes=5, min_len=2, max_len=37, seed=4, speaker_onehot=True, force_max=True)
     res = {}
-    configs = [(0, 0), (5, 1), (5, 4), (4, 3), (4, 6), (2, 6), (2, 16), (5, 16)]
-    for epc, dg in configs:
-        monkeypatch.setenv("ERC_DAG_EPC", str(epc))
-        monkeypatch.setenv("ERC_DAG_DG", str(dg))
+    # (forward epc, dg, layers per launch | backward epc, dg); 0 = let erc_dag_rec_config choose
+    configs = [(0, 0, 0, 0, 0), (5, 1, 1, 5, 1), (5, 4, 4, 5, 4), (4, 3, 3, 4, 3), (4, 6, 2, 4, 6), (2, 6, 1, 2, 6),
+               (2, 16, 1, 2, 16), (5, 16, 4, 5, 16), (5, 6, 2, 5, 2)]
+    for cf in configs:
+        for k, v in zip(("ERC_DAG_EPC", "ERC_DAG_DG", "ERC_DAG_LPL", "ERC_DAG_BEPC", "ERC_DAG_BDG"), cf):
+            monkeypatch.setenv(k, str(v))
         torch.manual_seed(9)
-        m = DAGERCModule(emb_dim=sum(dims.values()), dropout=0.0, n_classes=5, gnn_layers=2).finalize(DEV)
+        m = DAGERCModule(emb_dim=sum(dims.values()), dropout=0.0, n_classes=5, gnn_layers=4).finalize(DEV)
         m.train()
         stats = m.loss_and_grads(to_device(batch, DEV)).cpu()
         ws = m._last_ws
-        if epc:
-            assert ws["cfg"][:2] == (epc, dg)
+        if cf[0]:
+            assert ws["cfg"][0][:2] == cf[:2] and ws["cfg"][0][3] == cf[2] and ws["cfg"][1][:2] == cf[3:], ws["cfg"]
         m.check_cluster()
-        res[(epc, dg)] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone(), ws["cfg"])
+        res[cf] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone(), ws["cfg"])
     base = res[configs[0]]
-    print("default configuration (epc, dg, groups per launch):", base[3])
+    print("default configuration (epc, dg, groups per launch, layers per launch) forward | backward:", base[3])
     for key in configs[1:]:
         assert abs(res[key][0] - base[0]) < 1e-6, key
         assert float((res[key][1] - base[1]).abs().max()) <= 2e-6 * max(1.0, float(base[1].abs().max())), key

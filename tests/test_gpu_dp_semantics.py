@@ -97,7 +97,11 @@ def test_dagerc_two_shards_clip_on_averaged_gradient():
     assert abs(float(opt.gnorm.cpu()) - norm) < 1e-3 * norm      # the norm of the AVERAGED gradient
     refp = dict(ref.named_parameters())
     for n in mine.flat.params:
-        # one AdamW step moves every element by about lr = 1e-3 (m / sqrt(v) = +-1 on the first step, whatever the
-        # gradient's size): elements whose gradient is at rounding-noise level may differ by a fraction of lr
-        assert float((mine.flat.w(n).cpu() - refp[n].detach()).abs().max()) < 1e-4, n
+        # the first AdamW step moves every element by lr * g / (|g| + eps'): where |g| is at rounding-noise level the
+        # step's SIZE is noise on both sides, so parameters are compared where the gradient is well above that level
+        g = refp[n].grad
+        sure = g.abs() > 1e-3 * g.abs().max()
+        d = (mine.flat.w(n).cpu() - refp[n].detach()).abs()
+        assert float(d[sure].max()) < 2e-5, n
+        assert float(d.max()) < 2.1e-3, n            # nowhere more than the two opposite full steps
     mine.check_cluster()

@@ -16,10 +16,13 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--epc", type=int, default=0), ap.add_argument("--dg", type=int, default=0)
+    ap.add_argument("--lpl", type=int, default=0)
+    ap.add_argument("--bepc", type=int, default=0), ap.add_argument("--bdg", type=int, default=0)
     ap.add_argument("--batch", type=int, default=16)
     a = ap.parse_args()
-    if a.epc:
-        os.environ["ERC_DAG_EPC"], os.environ["ERC_DAG_DG"] = str(a.epc), str(a.dg)
+    for k, v in (("ERC_DAG_EPC", a.epc), ("ERC_DAG_DG", a.dg), ("ERC_DAG_LPL", a.lpl), ("ERC_DAG_BEPC", a.bepc), ("ERC_DAG_BDG", a.bdg)):
+        if v:
+            os.environ[k] = str(v)
     from bench import synthetic_batch
     from erc_amd import capi
     import track_mm.dagerc as plugin
@@ -30,14 +33,14 @@ def main():
         tr.train_step(batch)
     T = 110
     names = {"erc_dag_rec_fwd": ["start", "polled M", "gates done", "barrier A", "polled h | h published", "R done | saves done",
-                                 "barrier B", "tail done (EW)"],
+                                 "barrier B", "tail done (EW)"],     # workgroup 0 = layer 0, slice 0
              "erc_dag_rec_bwd": ["start", "E1 done", "M1+publish done", "partials summed", "E2 | Y done", "barrier 3", "dots done",
                                  "E3 done (EW)"]}
     capi.start_recording()
     tr.train_step(batch)
     rec = capi.stop_recording()
     torch.cuda.synchronize()
-    print("config (epc, dg, groups per launch):", tr.model._last_ws["cfg"])
+    print("config (epc, dg, groups per launch, layers per launch) forward | backward:", tr.model._last_ws["cfg"])
     for entry in ("erc_dag_rec_fwd", "erc_dag_rec_bwd"):
         call = [e for e in rec if e[0] == entry][0]
         st = torch.zeros(T, 2, 8, dtype=torch.int64, device="cuda:0")
