@@ -11,7 +11,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libercgraft.so")
+LIB_PATH = os.environ.get("ERC_LIB_PATH") or os.path.join(_HERE, "lib", "libercgraft.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -114,8 +114,9 @@ _SIGS = {
     "erc_dag_rec_scratch_bytes": (C.c_int64, [_i, _i, _i, _vp]),
     "erc_dag_rec_set_stamps": (C.c_int, [_vp]),
     "erc_dag_rec_fwd": (C.c_int, [_vp, _i, _i] + [_vp] * 8 + [_vp, _vp, _i, _i, _vp, _i, _vp, _i] + [_vp] * 5 + [_vp, _vp, _vp, _vp]),
-    "erc_dag_rec_bwd": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i,
-                                  _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "erc_dag_rec_bwd": (C.c_int, [_i, _vp, _i, _vp, _i] + [_vp] * 9 + [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp]),
+    "erc_dag_attn_sums": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -347,13 +348,20 @@ def dag_rec_fwd(H0, ldh0, n_layers, tables, pred, spk, B, T, ldo, ldgi, cfg, sta
                                  C.addressof(cfg), ptr(state), ptr(scratch), stream()), "erc_dag_rec_fwd")
 
 
-def dag_rec_bwd(Hl, ldh, GI, ldgi, GH, Mseq, R, alpha, W_hh_c, W_ih_p, Wr, w_k, pred, spk, B, T, dH1, ldd, dHl, lddl, DGI,
-                lddgi, DGH, dR, dks, cfg, state, scratch):
-    _dev(Hl, GI, dH1)
-    _check(lib().erc_dag_rec_bwd(ptr(Hl), ldh, ptr(GI), ldgi, ptr(GH), ptr(Mseq), ptr(R), ptr(alpha), ptr(W_hh_c),
-                                 ptr(W_ih_p), ptr(Wr), ptr(w_k), ptr(pred), ptr(spk), B, T, ptr(dH1), ldd, ptr(dHl), lddl,
-                                 ptr(DGI), lddgi, ptr(DGH), ptr(dR), ptr(dks), C.addressof(cfg), ptr(state),
-                                 ptr(scratch), stream()), "erc_dag_rec_bwd")
+def dag_rec_bwd(n_layers, tables, ldh, ldgi, pred, spk, B, T, dHall, ldd, lddgi, cfg, state, scratch):
+    """tables: ptr_table()s -- Hl GI GH Mseq R alpha Wh W_hh_c W_ih_p Wr w_k | DGI DGH dM dks"""
+    _dev(dHall)
+    t = tables
+    _check(lib().erc_dag_rec_bwd(n_layers, C.addressof(t["Hl"]), ldh, C.addressof(t["GI"]), ldgi, C.addressof(t["GH"]),
+                                 C.addressof(t["Mseq"]), C.addressof(t["R"]), C.addressof(t["alpha"]), C.addressof(t["Wh"]),
+                                 C.addressof(t["W_hh_c"]), C.addressof(t["W_ih_p"]), C.addressof(t["Wr"]),
+                                 C.addressof(t["w_k"]), ptr(pred), ptr(spk), B, T, ptr(dHall), ldd, C.addressof(t["DGI"]),
+                                 lddgi, C.addressof(t["DGH"]), C.addressof(t["dM"]), C.addressof(t["dks"]),
+                                 C.addressof(cfg), ptr(state), ptr(scratch), stream()), "erc_dag_rec_bwd")
+
+
+def dag_attn_sums(alpha, H1, ldo, pred, spk, B, T, A):
+    _check(lib().erc_dag_attn_sums(ptr(alpha), ptr(H1), ldo, ptr(pred), ptr(spk), B, T, ptr(A), stream()), "erc_dag_attn_sums")
 
 
 def dag_meta(speaker_onehot, speaker_ids, sb, st, S, lengths, B, T, spk, pred, node_off, node_row):

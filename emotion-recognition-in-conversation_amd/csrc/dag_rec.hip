@@ -57,6 +57,7 @@ constexpr int SPIN_LIMIT = 4000000;
 
 typedef unsigned long long u64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ u64 ld64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -408,19 +409,39 @@ __global__ __launch_bounds__(NTH) void dag_rec_fwd_kernel(RecFwd p) {
 }
 
 // ----------------------------------------------------------------------------------------------- backward
+// The backward pipelines the layers the same way, top layer first: layer l needs at its step i the complete gradient
+// wrt h^{(l)}_i = (the head's part, a plain matrix) + (the input gradient of layer l + 1 at step i), and layer l + 1 knows
+// its input gradient dH^{(l+1)}_i = z_p . g_i + [W_ih_c ; W_hh_p ; w_q]^T [dgates_i ; dqs_i] one step after it has processed
+// step i.  That second term -- the former "dH_l += DGI Wh" GEMM -- is a second transposed product of the layer's
+// workgroups; its partial vectors travel in the same reduce-scatter records as the partial dM, one step late.
+// Per step: E1 (GRU cells backward) -> M1 (both transposed products, all 8 wavefronts) -> reduce-scatter -> E2 (dM of the
+// slice; input gradient of the step before -> ring of the layer below / the dHall block) -> all-gather dM -> M2 (Y =
+// Wr[:, E_c]^T dM; dalpha dots) -> E3 (softmax backward, accumulations for the earlier steps).
+// The relation-weight gradient needs no accumulator in here: d[Wr0 ; Wr1] = sum_j dR_j h_j^T with dR_j = sum_i alpha_ij dM_i
+// equals sum_i dM_i (sum_j alpha_ij h_j)^T, so the kernel saves dM and the caller multiplies it with the attention-weighted
+// sums of the hidden states (erc_dag_attn_sums, a forward quantity).
+constexpr int BTW = 3;          // column tiles of the transposed products per wavefront (all 8 wavefronts: 24 >= 19)
+
+struct BwdLayer {
+    const float* Hl;                                   // the layer's input [B*T, >= 300] (row pitch ldh)
+    const float *GI, *GH, *Mseq, *R, *alpha;           // saved by the forward
+    const float *Wh, *W_hh_c, *W_ih_p, *Wr, *w_k;
+    const float* dHead;                                // [B*T, >= 300] (row pitch ldd): the part of dL/dh^{(l)} that does not
+                                                       // come through the layer above inside this launch
+    float *DGI, *DGH, *dM, *dks;                       // written: [B*T, lddgi], [B*T,1800], [B*T,300], [B*T]
+};
+
 struct RecBwd {
-    const float* Hl; int ldh;
-    const float* GI; int ldgi;
-    const float *GH, *Mseq, *R, *alpha;
-    const float *W_hh_c, *W_ih_p, *Wr, *w_k;
+    BwdLayer ly[ML];                   // ly[0] = the LOWEST layer of the launch
+    int ldh, ldgi, ldd, lddgi;
+    float* dLow;                       // [B*T, >= 300] (row pitch ldd): += the input gradient of the launch's lowest layer
+    int relu_low;                      // the lowest layer is layer 0 of the model: apply fc1's relu mask (Hl > 0) to dLow
     const int32_t *pred, *spk;
-    const float* dH1; int ldd;          // complete gradient wrt the layer outputs
-    float* dHl; int lddl;               // += the direct gradient wrt H_l (z_p * g)
-    float* DGI; int lddgi;              // [B*T, >= 1801] written: hoisted-side gate gradients | d(query score)
-    float* DGH;                         // [B*T, 1800] written: sequential-side gate gradients
-    float *dR, *dks;                    // [B*T,600], [B*T] written
-    int B, T, DG, g0;
-    u64 *xd, *xm;                       // [groups][P consumers][P producers][ndlg][EPC] ; [groups][300][16]
+    int B, T, DG, g0, nl;
+    u64 *xd;                           // [groups][ML][2][P consumers][P producers][ndlg][EPC] 16-byte records {partial dM, tag,
+                                       // partial input gradient, tag}, two sets used by the parity of the step
+    u64 *xm;                           // [groups][ML][300][16]     all-gather records of dM
+    u64 *xu;                           // [groups][ML][T][300][16]  rings: complete input gradient of layer l per step
     int *epoch, *err;
     u64* stamps;
 };
@@ -428,269 +449,388 @@ struct RecBwd {
 template <int EPC>
 __global__ __launch_bounds__(NTH) void dag_rec_bwd_kernel(RecBwd p) {
     constexpr int NSL = HID / EPC;
-    constexpr int NKG = (6 * EPC + 3) / 4;              // k-steps of the transposed gate product (this slice's rows)
-    constexpr int VP = 4 * NKG + 1;
-    constexpr int MAXP = (MAXDG * EPC + 63) / 64;
+    constexpr int NKG = (6 * EPC + 3) / 4;              // k-steps of the transposed sequential-side product (this slice's rows)
+    constexpr int NKH = (6 * EPC + 1 + 3) / 4;          // ... of the hoisted-side product (+ the w_q row, slice 0 only)
+    constexpr int VP = 4 * NKG + 1, VPH = 4 * NKH + 1;
+    constexpr int SP = 16 * NT19 + 1;                   // row pitch of the staged partial vectors
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = p.g0 + blockIdx.x / NSL, c = blockIdx.x % NSL;
+    const int c = blockIdx.x % NSL, l = (blockIdx.x / NSL) % p.nl, grp = p.g0 + blockIdx.x / (NSL * p.nl);
     const int DG = p.DG, T = p.T;
     const int b0 = grp * DG, ndlg = min(DG, p.B - b0);
-    float* vin = smem;                                  // [16][VP]   sequential-side gate gradients of this slice
-    float* red = vin + 16 * VP;                         // [NTH]
-    float* part_y = red + NTH;                          // [NMW][16][PST]
-    float* dmfull = part_y + NMW * 16 * PST;            // [16][DMP]  the gathered dM_i
-    float* gacc = dmfull + 16 * DMP;                    // [T][DG][EPC]    sum_i alpha_ij (Wr_sel^T dM_i)[E_c]
-    float* dracc = gacc + T * DG * EPC;                 // [T][DG][2 EPC]  dR
-    float* dks_s = dracc + T * DG * 2 * EPC;            // [DG][T]
-    float* dal = dks_s + DG * T;                        // [DG][T]         dalpha of the current step's window
+    const BwdLayer& L = p.ly[l];
+    const bool top = l == p.nl - 1, low = l == 0;
+    float* vin = smem;                                  // [16][VP]      sequential-side gate gradients of this slice, step i
+    float* vinh = vin + 16 * VP;                        // [2][16][VPH]  hoisted-side gate gradients + d(query score), by parity
+    float* reda = vinh + 2 * 16 * VPH;                  // [NTH]
+    float* redb = reda + NTH;                           // [NTH]
+    float* part_y = redb + NTH;                         // [FMW][16][PST]
+    float* dmfull = part_y + FMW * 16 * PST;            // [16][DMP]     the gathered dM_i
+    float* stage = dmfull + 16 * DMP;                   // [2][16][SP]   both partial vectors of a step, [dialogue][k]
+    float* gacc = stage + 2 * 16 * SP;                  // [T][DG][EPC]  sum_i alpha_ij (Wr_sel^T dM_i)[E_c]
+    float* dks_s = gacc + T * DG * EPC;                 // [DG][T]
+    float* dal = dks_s + DG * T;                        // [DG][T]       dalpha of the current step's window
     int* s_spk = reinterpret_cast<int*>(dal + DG * T);
     int* s_pred = s_spk + DG * T;
     for (int x = tid; x < ndlg * T; x += NTH) {
         s_spk[x] = p.spk[(int64_t)b0 * T + x];
         s_pred[x] = p.pred[(int64_t)b0 * T + x];
     }
-    for (int x = tid; x < 16 * VP; x += NTH) vin[x] = 0.f;
-    for (int x = tid; x < T * DG * (3 * EPC + 1); x += NTH) gacc[x] = 0.f;      // gacc | dracc | dks_s are contiguous
+    for (int x = tid; x < 16 * VP + 2 * 16 * VPH; x += NTH) vin[x] = 0.f;       // vin | vinh are contiguous
+    for (int x = tid; x < T * DG * (EPC + 1); x += NTH) gacc[x] = 0.f;          // gacc | dks_s are contiguous
     const unsigned ep = (unsigned)p.epoch[grp] + 1u;
-    u64* const xm = p.xm + (int64_t)grp * XG;
-    const int IT = ndlg * EPC;                            // records per producer block
-    u64* const xd = p.xd + (int64_t)grp * NSL * NSL * DG * EPC;
+    const int64_t gl = (int64_t)grp * ML + l;
+    u64* const xm = p.xm + gl * XG;
+    u64* const xu = p.xu + gl * T * XG;                                  // this layer's ring (published when l > 0)
+    const u64* const xup = xu + (int64_t)T * XG;                         // the ring of the layer above (read when !top)
+    const int IT = ndlg * EPC;                                           // records per producer block
+    // the reduce-scatter records of this (group, layer): two sets of NSL * NSL * IT 16-byte records; stores and loads
+    // are 16-byte write-through / L1-bypassing buffer accesses (aux 16 = sc1), the descriptor built from uniform values
+    const int64_t xd_set = (int64_t)NSL * NSL * DG * EPC * 2;            // u64 per set
+    u64* const xdbase = p.xd + gl * 2 * xd_set;
+    // (readfirstlane returns a SIGNED int: widen through uint32_t, or a low word >= 2^31 smears ones over the high word)
+    const uint64_t xd_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)xdbase);
+    const uint64_t xd_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)xdbase >> 32));
+    const __amdgpu_buffer_rsrc_t xdr =
+        __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>((xd_hi << 32) | xd_lo), 0, (int)(2 * xd_set * 8), 0x00020000);
 
-    // ---- stationary weights
-    float wgT[TPW][NKG], wrY[NQ];
+    // ---- stationary weights: the transposed products use all 8 wavefronts (column tiles wave + 8 u), Y the first 6
+    float wgT[BTW][NKG], whT[BTW][NKH], wrY[FNQ];
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        const int t = wave + NMW * u, k = 16 * t + (lane & 15), kc = min(k, HID - 1);
-        const float kv = (wave < NMW && t < NT19 && k < HID) ? 1.f : 0.f;
+    for (int u = 0; u < BTW; ++u) {
+        const int t = wave + 8 * u, k = 16 * t + (lane & 15), kc = min(k, HID - 1);
+        const float kv = (t < NT19 && k < HID) ? 1.f : 0.f;
 #pragma unroll
         for (int s = 0; s < NKG; ++s) {
             const int n = 4 * s + (lane >> 4), nc = min(n, 6 * EPC - 1);
-            const float v = gate_row(p.W_hh_c, p.W_ih_p, nc / EPC, c * EPC + nc % EPC)[kc];
-            wgT[u][s] = v * (n < 6 * EPC ? kv : 0.f);
+            wgT[u][s] = gate_row(L.W_hh_c, L.W_ih_p, nc / EPC, c * EPC + nc % EPC)[kc] * (n < 6 * EPC ? kv : 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < NKH; ++s) {
+            const int n = 4 * s + (lane >> 4), nc = min(n, 6 * EPC);
+            const int row = nc < 6 * EPC ? (nc / EPC) * HID + c * EPC + nc % EPC : 6 * HID;
+            const float on = n < 6 * EPC ? kv : ((n == 6 * EPC && c == 0) ? kv : 0.f);      // the w_q row counts once: slice 0
+            whT[u][s] = L.Wh[(int64_t)row * HID + kc] * on;
         }
     }
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int s = wave + NMW * q, ec = min(4 * s + (lane >> 4), HID - 1);
+    for (int q = 0; q < FNQ; ++q) {
+        const int s = wave + FMW * q, ec = min(4 * s + (lane >> 4), HID - 1);
         const int j = lane & 15, jc = min(j, 2 * EPC - 1);
-        const float v = p.Wr[(int64_t)((jc / EPC) * HID + ec) * HID + c * EPC + jc % EPC];
-        wrY[q] = v * ((wave < NMW && s < KS && j < 2 * EPC) ? 1.f : 0.f);
+        const float v = L.Wr[(int64_t)((jc / EPC) * HID + ec) * HID + c * EPC + jc % EPC];
+        wrY[q] = v * ((wave < FMW && s < KS && j < 2 * EPC) ? 1.f : 0.f);
     }
-    bool iv[MAXP];
-    int im[MAXP], iel[MAXP];
-    float wk_e[MAXP], dmdir[MAXP];
-#pragma unroll
-    for (int r = 0; r < MAXP; ++r) {
-        const int it = lane + 64 * r;
-        iv[r] = wave == EWW && it < IT;
-        const int itc = iv[r] ? it : 0;
-        iel[r] = itc / ndlg, im[r] = itc % ndlg;
-        wk_e[r] = p.w_k[c * EPC + iel[r]];
-        dmdir[r] = 0.f;
-    }
+    // ---- items of the elementwise wavefronts (as in the forward): wavefront 6 + w owns dialogues [8 w, 8 w + 8)
+    const int el = lane >> 3, m = 8 * (wave - FMW) + (lane & 7), e = c * EPC + min(el, EPC - 1);
+    const bool iv = wave >= FMW && el < EPC && m < ndlg;
+    const int mc = iv ? m : 0;
+    const float wk_e = L.w_k[e];
+    float dmdir = 0.f, dirh_prev = 0.f, dirh_cur = 0.f;   // z_c g (into M_i) ; z_p g (into H_l) of step i + 1 / of step i
     __syncthreads();
+
+    // both transposed products of a step, all 8 wavefronts: partial dM_i (valid when do_a) and the partial input gradient
+    // of step i + 1 (valid when do_b), published as two tagged records per (consumer slice, dialogue, element)
+    auto transposed_products = [&](int i, bool do_a, bool do_b, unsigned tag, int set) {
+        const float* vh = vinh + ((i + 1) & 1) * 16 * VPH;
+        float a[NKG], b[NKH];
+#pragma unroll
+        for (int s = 0; s < NKG; ++s) a[s] = vin[(lane & 15) * VP + 4 * s + (lane >> 4)];
+#pragma unroll
+        for (int s = 0; s < NKH; ++s) b[s] = vh[(lane & 15) * VPH + 4 * s + (lane >> 4)];
+#pragma unroll
+        for (int u = 0; u < BTW; ++u) {
+            f32x4 acca = {0.f, 0.f, 0.f, 0.f}, accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NKG; ++s) acca = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wgT[u][s], acca, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < NKH; ++s) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s], whT[u][s], accb, 0, 0, 0);
+            const int t = wave + 8 * u;
+            if (t < NT19) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    stage[(4 * (lane >> 4) + r) * SP + 16 * t + (lane & 15)] = acca[r];
+                    stage[(16 + 4 * (lane >> 4) + r) * SP + 16 * t + (lane & 15)] = accb[r];
+                }
+            }
+        }
+        __syncthreads();
+        // publish: record x = (consumer slice, dialogue, element) in consumer-major order -> every consumer's block of
+        // this producer is one contiguous run of IT 16-byte records
+        const unsigned ta = do_a ? tag : 0u, tb = do_b ? tag : 0u;
+        for (int x = tid; x < NSL * IT; x += NTH) {
+            const int cc = x / IT, o = x - cc * IT, mm = o / EPC, k = cc * EPC + (o - mm * EPC);
+            u32x4 v;
+            v.x = __builtin_bit_cast(unsigned, stage[mm * SP + k]), v.y = ta;
+            v.z = __builtin_bit_cast(unsigned, stage[(16 + mm) * SP + k]), v.w = tb;
+            __builtin_amdgcn_raw_buffer_store_b128(v, xdr, (int)((set * xd_set + ((int64_t)(cc * NSL + c) * IT + o) * 2) * 8), 0, 16);
+        }
+    };
+    // every thread sums its share of the P partial blocks addressed to this slice, in producer order
+    auto gather_partials = [&](bool do_a, bool do_b, unsigned tag, int set) {
+        const int S = (NTH / IT) * IT, total = NSL * IT;
+        const u64* blka = xdbase + set * xd_set + (int64_t)c * NSL * IT * 2;
+        const u64* blkb = blka + 1;
+        float suma = 0.f, sumb = 0.f;
+        if (tid < S) {
+            int spins = 0;
+            if (tid < total) {   // sentinel: wait for this thread's first record before requesting the others (see poll_operand)
+                const u64* sp = do_a ? blka + 2 * tid : blkb + 2 * tid;
+                u64 v0 = ld64(sp);
+                while ((unsigned)(v0 >> 32) != tag) {
+                    if (++spins > SPIN_LIMIT) {
+                        set_err(p.err);
+                        break;
+                    }
+                    if ((spins & 255) == 0 && ld_err(p.err)) break;
+                    __builtin_amdgcn_s_sleep(POLL_SLEEP);
+                    v0 = ld64(sp);
+                }
+            }
+            for (int x0 = tid; x0 < total; x0 += 4 * S) {
+                u64 va[4], vb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = x0 + u * S;
+                    va[u] = vb[u] = (u64)tag << 32;
+                    if (x < total && do_a) va[u] = ld64(blka + 2 * x);
+                    if (x < total && do_b) vb[u] = ld64(blkb + 2 * x);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = min(x0 + u * S, total - 1);
+                    suma += settle(blka + 2 * x, va[u], tag, spins, p.err);
+                    sumb += settle(blkb + 2 * x, vb[u], tag, spins, p.err);
+                }
+            }
+        }
+        reda[tid] = suma, redb[tid] = sumb;
+    };
+    // the complete input gradient of step j for this slice: to the ring of the layer below, or (lowest layer of the
+    // launch) added to the dHall block, through fc1's relu mask on layer 0 of the model
+    auto emit_input_gradient = [&](int j, unsigned tagj) {
+        if (!iv) return;
+        const int S = (NTH / IT) * IT;
+        float v = dirh_prev;
+        for (int x = m * EPC + el; x < S; x += IT) v += redb[x];
+        const int64_t row = (int64_t)(b0 + m) * T + j;
+        if (!low) {
+            st_tag(xu + (int64_t)j * XG + e * XROW + m, v, tagj);
+        } else {
+            float* dst = p.dLow + row * p.ldd + e;
+            const float keep = (!p.relu_low || L.Hl[row * p.ldh + e] > 0.f) ? 1.f : 0.f;
+            *dst = (*dst + v) * keep;
+        }
+    };
 
     for (int i = T - 1; i >= 0; --i) {
         const unsigned tag = ep * 1024u + (unsigned)i + 1u;
         REC_STAMP(0);
         // ---- E1: total gradient wrt h_i for this slice, GRU cells backward (elementwise)
-        if (wave == EWW) {
+        if (iv) {
+            const int64_t row = (int64_t)(b0 + m) * T + i;
+            const float* gi = L.GI + row * p.ldgi;
+            const float* gh = L.GH + row * 6 * HID;
+            float giv[6], ghv[6];
 #pragma unroll
-            for (int r = 0; r < MAXP; ++r) {
-                if (!iv[r]) continue;
-                const int m = im[r], el = iel[r], e = c * EPC + el;
-                const int64_t row = (int64_t)(b0 + m) * T + i;
-                const float* gi = p.GI + row * p.ldgi;
-                const float* gh = p.GH + row * 6 * HID;
-                float giv[6], ghv[6];
-#pragma unroll
-                for (int g = 0; g < 6; ++g) giv[g] = gi[g * HID + e], ghv[g] = gh[g * HID + e];
-                const float mi = p.Mseq[row * HID + e], xi = p.Hl[row * p.ldh + e];
-                const float g = p.dH1[row * p.ldd + e] + gacc[(i * DG + m) * EPC + el] + wk_e[r] * dks_s[m * T + i];
-                float* dgi = p.DGI + row * p.lddgi;
-                float* dgh = p.DGH + row * 6 * HID;
-                float* vrow = vin + m * VP;
-                {   // cell C: x = H_l[i] (hoisted side), h = M_i (sequential side)
-                    const float rr = sigm(giv[0] + ghv[0]), zz = sigm(giv[1] + ghv[1]);
-                    const float nn = tanhf(giv[2] + rr * ghv[2]);
-                    const float dn = g * (1.f - zz) * (1.f - nn * nn);
-                    const float dz = g * (mi - nn) * zz * (1.f - zz);
-                    const float dr = dn * ghv[2] * rr * (1.f - rr);
-                    dgi[e] = dr, dgi[HID + e] = dz, dgi[2 * HID + e] = dn;
-                    dgh[e] = dr, dgh[HID + e] = dz, dgh[2 * HID + e] = dn * rr;
-                    vrow[el] = dr, vrow[EPC + el] = dz, vrow[2 * EPC + el] = dn * rr;
-                    dmdir[r] = g * zz;                                    // direct path into M_i
+            for (int g = 0; g < 6; ++g) giv[g] = gi[g * HID + e], ghv[g] = gh[g * HID + e];
+            const float mi = L.Mseq[row * HID + e], xi = L.Hl[row * p.ldh + e];
+            float g = L.dHead[row * p.ldd + e] + gacc[(i * DG + m) * EPC + el] + wk_e * dks_s[m * T + i];
+            if (!top) {      // + the input gradient of the layer above at this step (it runs about two steps ahead)
+                const u64* rp = xup + (int64_t)i * XG + e * XROW + m;
+                int spins = 0;
+                u64 v0 = ld64(rp);
+                while ((unsigned)(v0 >> 32) != tag) {
+                    if (++spins > SPIN_LIMIT) {
+                        set_err(p.err);
+                        break;
+                    }
+                    if ((spins & 255) == 0 && ld_err(p.err)) break;
+                    __builtin_amdgcn_s_sleep(POLL_SLEEP);
+                    v0 = ld64(rp);
                 }
-                {   // cell P: x = M_i (sequential side), h = H_l[i] (hoisted side)
-                    const float rr = sigm(ghv[3] + giv[3]), zz = sigm(ghv[4] + giv[4]);
-                    const float nn = tanhf(ghv[5] + rr * giv[5]);
-                    const float dn = g * (1.f - zz) * (1.f - nn * nn);
-                    const float dz = g * (xi - nn) * zz * (1.f - zz);
-                    const float dr = dn * giv[5] * rr * (1.f - rr);
-                    dgh[3 * HID + e] = dr, dgh[4 * HID + e] = dz, dgh[5 * HID + e] = dn;
-                    dgi[3 * HID + e] = dr, dgi[4 * HID + e] = dz, dgi[5 * HID + e] = dn * rr;
-                    vrow[3 * EPC + el] = dr, vrow[4 * EPC + el] = dz, vrow[5 * EPC + el] = dn;
-                    p.dHl[row * p.lddl + e] += g * zz;                    // direct path into H_l[i]
-                }
-                if (i == 0 && c == 0 && el == 0) dgi[6 * HID] = 0.f;      // step 0 has no attention: d(query score) = 0
+                g += __builtin_bit_cast(float, (unsigned)v0);
+            }
+            float* dgi = L.DGI + row * p.lddgi;
+            float* dgh = L.DGH + row * 6 * HID;
+            float* vrow = vin + m * VP;
+            float* vhrow = vinh + ((i & 1) * 16 + m) * VPH;
+            {   // cell C: x = H_l[i] (hoisted side), h = M_i (sequential side)
+                const float rr = sigm(giv[0] + ghv[0]), zz = sigm(giv[1] + ghv[1]);
+                const float nn = tanhf(giv[2] + rr * ghv[2]);
+                const float dn = g * (1.f - zz) * (1.f - nn * nn);
+                const float dz = g * (mi - nn) * zz * (1.f - zz);
+                const float dr = dn * ghv[2] * rr * (1.f - rr);
+                dgi[e] = dr, dgi[HID + e] = dz, dgi[2 * HID + e] = dn;
+                dgh[e] = dr, dgh[HID + e] = dz, dgh[2 * HID + e] = dn * rr;
+                vrow[el] = dr, vrow[EPC + el] = dz, vrow[2 * EPC + el] = dn * rr;
+                vhrow[el] = dr, vhrow[EPC + el] = dz, vhrow[2 * EPC + el] = dn;
+                dmdir = g * zz;                                        // direct path into M_i
+            }
+            {   // cell P: x = M_i (sequential side), h = H_l[i] (hoisted side)
+                const float rr = sigm(ghv[3] + giv[3]), zz = sigm(ghv[4] + giv[4]);
+                const float nn = tanhf(ghv[5] + rr * giv[5]);
+                const float dn = g * (1.f - zz) * (1.f - nn * nn);
+                const float dz = g * (xi - nn) * zz * (1.f - zz);
+                const float dr = dn * giv[5] * rr * (1.f - rr);
+                dgh[3 * HID + e] = dr, dgh[4 * HID + e] = dz, dgh[5 * HID + e] = dn;
+                dgi[3 * HID + e] = dr, dgi[4 * HID + e] = dz, dgi[5 * HID + e] = dn * rr;
+                vrow[3 * EPC + el] = dr, vrow[4 * EPC + el] = dz, vrow[5 * EPC + el] = dn;
+                vhrow[3 * EPC + el] = dr, vhrow[4 * EPC + el] = dz, vhrow[5 * EPC + el] = dn * rr;
+                dirh_cur = g * zz;                                     // direct path into H_l[i]
+            }
+            if (i == 0 && el == 0) {      // step 0 has no attention: d(query score) = 0
+                vhrow[6 * EPC] = 0.f;
+                if (c == 0) dgi[6 * HID] = 0.f;
             }
         }
-        if (i == 0) break;                                                // M_0 = 0 has no producers
         REC_STAMP(1);
         __syncthreads();
-        // ---- M1: partial dM_i = Wg[rows of E_c]^T dgates, one partial FULL vector per dialogue -> reduce-scatter
-        if (wave < NMW) {
-            float a[NKG];
-#pragma unroll
-            for (int s = 0; s < NKG; ++s) a[s] = vin[(lane & 15) * VP + 4 * s + (lane >> 4)];
-            f32x4 acc[TPW];
-#pragma unroll
-            for (int u = 0; u < TPW; ++u) {
-                acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < NKG; ++s) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wgT[u][s], acc[u], 0, 0, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < TPW; ++u) {
-                const int k = 16 * (wave + NMW * u) + (lane & 15);
-                const int cc = k / EPC, el2 = k % EPC;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int mm = 4 * (lane >> 4) + r;
-                    if (wave + NMW * u < NT19 && k < HID && mm < ndlg)
-                        st_tag(xd + ((int64_t)(cc * NSL + c) * ndlg + mm) * EPC + el2, acc[u][r], tag);
-                }
-            }
-        }
+        // ---- M1: partial dM_i = Wg[rows of E_c]^T dgates_i and the partial input gradient of step i + 1
+        const bool do_a = i > 0, do_b = i + 1 < T;       // M_0 = 0 has no producers; step T - 1 has no later step
+        transposed_products(i, do_a, do_b, tag, i & 1);
         REC_STAMP(2);
-        {   // every thread sums its share of the P partial blocks addressed to this slice, in producer order
-            const int S = (NTH / IT) * IT, total = NSL * IT;
-            const u64* blk = xd + (int64_t)c * NSL * IT;
-            float sum = 0.f;
-            if (tid < S) {
-                int spins = 0;
-                if (tid < total) {   // sentinel: wait for this thread's first record before requesting the others (see poll_operand)
-                    u64 v0 = ld64(blk + tid);
-                    while ((unsigned)(v0 >> 32) != tag) {
-                        if (++spins > SPIN_LIMIT) {
-                            set_err(p.err);
-                            break;
-                        }
-                        if ((spins & 255) == 0 && ld_err(p.err)) break;
-                        __builtin_amdgcn_s_sleep(POLL_SLEEP);
-                        v0 = ld64(blk + tid);
-                    }
-                }
-                for (int x0 = tid; x0 < total; x0 += 4 * S) {
-                    u64 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int x = x0 + u * S;
-                        v[u] = (u64)tag << 32;
-                        if (x < total) v[u] = ld64(blk + x);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) sum += settle(blk + min(x0 + u * S, total - 1), v[u], tag, spins, p.err);
-                }
-            }
-            red[tid] = sum;
-        }
+        gather_partials(do_a, do_b, tag, i & 1);
         REC_STAMP(3);
         __syncthreads();
-        // ---- E2 / M2: dM_i of this slice -> all-gather; Y_i = Wr[:, E_c]^T dM_i
-        if (wave == EWW) {
-            const int S = (NTH / IT) * IT;
-#pragma unroll
-            for (int r = 0; r < MAXP; ++r) {
-                if (!iv[r]) continue;
-                const int m = im[r], el = iel[r], e = c * EPC + el;
-                float dm = dmdir[r];
-                for (int x = m * EPC + el; x < S; x += IT) dm += red[x];
-                st_tag(xm + e * XROW + m, dm, tag);
-                const int pr = s_pred[m * T + i], lo = pr > 0 ? pr : 0, si = s_spk[m * T + i];
-                const float* arow = p.alpha + ((int64_t)(b0 + m) * T + i) * T;
-                for (int j = lo; j < i; ++j)                               // dV_j = alpha_ij dM_i into the slot that was read
-                    dracc[(j * DG + m) * 2 * EPC + (s_spk[m * T + j] == si ? 0 : EPC) + el] += arow[j] * dm;
+        // ---- E2 / M2: dM_i of this slice -> all-gather; the input gradient of step i + 1 goes out; Y_i = Wr[:, E_c]^T dM_i
+        if (wave >= FMW) {
+            if (iv) {
+                float dm = 0.f;                                         // M_0 = 0: no dM for step 0
+                if (do_a) {
+                    const int S = (NTH / IT) * IT;
+                    dm = dmdir;
+                    for (int x = m * EPC + el; x < S; x += IT) dm += reda[x];
+                    st_tag(xm + e * XROW + m, dm, tag);
+                }
+                L.dM[((int64_t)(b0 + m) * T + i) * HID + e] = dm;
             }
-        } else {
-            float a[NQ];
-            poll_operand<NMW, NQ>(xm, wave, lane, ndlg, tag, a, p.err);
+            if (do_b) emit_input_gradient(i + 1, tag + 1u);
+            dirh_prev = dirh_cur;
+        } else if (do_a) {
+            float a[FNQ];
+            poll_operand<FMW, FNQ>(xm, wave, lane, ndlg, tag, a, p.err);
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int s = wave + NMW * q;
+            for (int q = 0; q < FNQ; ++q) {
+                const int s = wave + FMW * q;
                 if (s < KS) dmfull[(lane & 15) * DMP + 4 * s + (lane >> 4)] = a[q];
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wrY[q], acc, 0, 0, 0);
             }
             store_tile(part_y + wave * 16 * PST, acc, lane);
         }
         REC_STAMP(4);
+        if (i == 0) break;
         __syncthreads();
         REC_STAMP(5);
-        // ---- dalpha_ij = dM_i . V_j over the window (V_j = the relation row of j that step i read)
-        if (wave < NMW) {
+        // ---- dalpha_ij = dM_i . V_j over the window (V_j = the relation row of j that step i read): all 8 wavefronts,
+        //      four (dialogue, j) pairs per batch so that their 20 row loads are in flight together
+        {
             int nmax = 0;
-            for (int m = 0; m < ndlg; ++m) {
-                const int pr = s_pred[m * T + i];
+            for (int mm = 0; mm < ndlg; ++mm) {
+                const int pr = s_pred[mm * T + i];
                 nmax = max(nmax, i - (pr > 0 ? pr : 0));
             }
-            for (int d = wave; d < ndlg * nmax; d += NMW) {
-                const int m = d % ndlg, jj = d / ndlg;
-                const int pr = s_pred[m * T + i], lo = pr > 0 ? pr : 0;
-                if (jj >= i - lo) continue;
-                const int j = lo + jj;
-                const float* v = p.R + ((int64_t)(b0 + m) * T + j) * 2 * HID + (s_spk[m * T + j] == s_spk[m * T + i] ? 0 : HID);
-                float s = 0.f;
+            const int npair = ndlg * nmax;
+            for (int d0 = 4 * wave; d0 < npair; d0 += 32) {
+                float vv[4][5];
+                int pm[4], pj[4];
+                bool ok[4];
 #pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    const int k = lane + 64 * r, kc = min(k, HID - 1);
-                    s += v[kc] * dmfull[m * DMP + kc] * (k < HID ? 1.f : 0.f);
+                for (int u = 0; u < 4; ++u) {
+                    const int d = min(d0 + u, npair - 1), mm = d % ndlg, jj = d / ndlg;
+                    const int pr = s_pred[mm * T + i], lo = pr > 0 ? pr : 0;
+                    ok[u] = d0 + u < npair && jj < i - lo;
+                    const int j = ok[u] ? lo + jj : lo;
+                    pm[u] = mm, pj[u] = jj;
+                    const float* v = L.R + ((int64_t)(b0 + mm) * T + j) * 2 * HID + (s_spk[mm * T + j] == s_spk[mm * T + i] ? 0 : HID);
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) vv[u][r] = v[min(lane + 64 * r, HID - 1)];
                 }
-                s = wave_sum(s);
-                if (lane == 0) dal[m * T + jj] = s;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        const int k = lane + 64 * r;
+                        s += vv[u][r] * dmfull[pm[u] * DMP + min(k, HID - 1)] * (k < HID ? 1.f : 0.f);
+                    }
+                    s = wave_sum(s);
+                    if (lane == 0 && ok[u]) dal[pm[u] * T + pj[u]] = s;
+                }
             }
         }
         REC_STAMP(6);
         __syncthreads();
         // ---- E3: softmax backward, accumulations for the earlier steps
-        if (wave == EWW) {
+        if (iv) {
+            float y0 = 0.f, y1 = 0.f;
 #pragma unroll
-            for (int r = 0; r < MAXP; ++r) {
-                if (!iv[r]) continue;
-                const int m = im[r], el = iel[r];
-                float y0 = 0.f, y1 = 0.f;
-#pragma unroll
-                for (int w = 0; w < NMW; ++w) {
-                    const float* py = part_y + (w * 16 + m) * PST;
-                    y0 += py[el], y1 += py[EPC + el];
-                }
-                const int pr = s_pred[m * T + i], lo = pr > 0 ? pr : 0, si = s_spk[m * T + i], n = i - lo;
-                const float* arow = p.alpha + ((int64_t)(b0 + m) * T + i) * T + lo;
-                float t = 0.f;
-                for (int jj = 0; jj < n; ++jj) t += arow[jj] * dal[m * T + jj];
-                float dq = 0.f;
-                for (int jj = 0; jj < n; ++jj) {
-                    const int j = lo + jj;
-                    const float al = arow[jj];
-                    const float ds = al * (dal[m * T + jj] - t);
-                    dq += ds;
-                    if (el == 0) dks_s[m * T + j] += ds;
-                    gacc[(j * DG + m) * EPC + el] += al * (s_spk[m * T + j] == si ? y0 : y1);
-                }
-                if (el == 0 && c == 0) p.DGI[((int64_t)(b0 + m) * T + i) * p.lddgi + 6 * HID] = dq;
+            for (int w = 0; w < FMW; ++w) {
+                const float* py = part_y + (w * 16 + m) * PST;
+                y0 += py[el], y1 += py[EPC + el];
+            }
+            const int pr = s_pred[m * T + i], lo = pr > 0 ? pr : 0, si = s_spk[m * T + i], n = i - lo;
+            const float* arow = L.alpha + ((int64_t)(b0 + m) * T + i) * T + lo;
+            float t = 0.f;
+            for (int jj = 0; jj < n; ++jj) t += arow[jj] * dal[m * T + jj];
+            float dq = 0.f;
+            for (int jj = 0; jj < n; ++jj) {
+                const int j = lo + jj;
+                const float al = arow[jj];
+                const float ds = al * (dal[m * T + jj] - t);
+                dq += ds;
+                if (el == 0) dks_s[m * T + j] += ds;
+                gacc[(j * DG + m) * EPC + el] += al * (s_spk[m * T + j] == si ? y0 : y1);
+            }
+            if (el == 0) {
+                vinh[((i & 1) * 16 + m) * VPH + 6 * EPC] = dq;          // d(query score) joins the hoisted-side row of step i
+                if (c == 0) L.DGI[((int64_t)(b0 + m) * T + i) * p.lddgi + 6 * HID] = dq;
             }
         }
         REC_STAMP(7);
     }
+    // ---- flush: the input gradient of step 0 (one more round of the second transposed product).  It travels in the
+    //      record set of parity 1: round 0 published set 0 without a dM all-gather behind it (M_0 has none), so a fast
+    //      member could overwrite a round-0 record that a slow one has not read yet; set 1 was last used in round 1,
+    //      which the all-gather of dM_1 closed for every member.
     __syncthreads();
-    for (int x = tid; x < T * ndlg * 2 * EPC; x += NTH) {
-        const int el2 = x % (2 * EPC), m = (x / (2 * EPC)) % ndlg, j = x / (2 * EPC * ndlg);
-        p.dR[((int64_t)(b0 + m) * T + j) * 2 * HID + (el2 / EPC) * HID + c * EPC + el2 % EPC] = dracc[(j * DG + m) * 2 * EPC + el2];
+    {
+        const unsigned tagf = ep * 1024u + (unsigned)T + 2u;
+        transposed_products(-1, false, true, tagf, 1);
+        gather_partials(false, true, tagf, 1);
+        __syncthreads();
+        if (wave >= FMW) emit_input_gradient(0, ep * 1024u + 1u);
     }
-    if (c == 0)
-        for (int x = tid; x < T * ndlg; x += NTH) p.dks[(int64_t)(b0 + x / T) * T + x % T] = dks_s[x];
-    if (c == 0 && tid == 0) p.epoch[grp] = (int)ep;
+    if (iv && el == 0 && c == 0)
+        for (int j = 0; j < T; ++j) L.dks[(int64_t)(b0 + m) * T + j] = dks_s[m * T + j];
+    if (low && c == 0 && tid == 0) p.epoch[grp] = (int)ep;
+}
+
+// dR_j = sum_i alpha_ij dM_i never has to exist: d[Wr0 ; Wr1] = sum_i dM_i (A_i)^T with the attention-weighted sums
+// A_i[sel] = sum_{j in window(i), speaker relation sel} alpha_ij h_j -- a forward quantity, one workgroup per row.
+__global__ __launch_bounds__(64) void dag_attn_sums_kernel(const float* __restrict__ alpha, const float* __restrict__ H1, int ldo,
+                                                           const int32_t* __restrict__ pred, const int32_t* __restrict__ spk,
+                                                           int T, float* __restrict__ A) {
+    const int64_t row = blockIdx.x;
+    const int i = (int)(row % T), lane = threadIdx.x;
+    const int64_t base = row - i;
+    const int pr = pred[row], lo = pr > 0 ? pr : 0, si = spk[row];
+    float acc[2][5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) acc[0][r] = acc[1][r] = 0.f;
+    for (int j = lo; j < i; ++j) {
+        const float al = alpha[row * T + j];
+        const float a0 = spk[base + j] == si ? al : 0.f, a1 = al - a0;
+        const float* h = H1 + (base + j) * ldo;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const float hv = h[min(lane + 64 * r, HID - 1)];
+            acc[0][r] += a0 * hv, acc[1][r] += a1 * hv;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        if (lane + 64 * r < HID) A[row * 2 * HID + lane + 64 * r] = acc[0][r], A[row * 2 * HID + HID + lane + 64 * r] = acc[1][r];
 }
 
 // ----------------------------------------------------------------------------------------------- host side
@@ -699,8 +839,9 @@ int lds_fwd(int epc, int dg, int T) {
     return 4 * (FMW * (ntg + nth2 + 1) * 16 * PST + T * dg * 2 * epc + T * dg + 2 * dg * T);
 }
 int lds_bwd(int epc, int dg, int T) {
-    const int nkg = (6 * epc + 3) / 4;
-    return 4 * (16 * (4 * nkg + 1) + NTH + NMW * 16 * PST + 16 * DMP + T * dg * (3 * epc + 1) + dg * T + 2 * dg * T);
+    const int nkg = (6 * epc + 3) / 4, nkh = (6 * epc + 1 + 3) / 4;
+    return 4 * (16 * (4 * nkg + 1) + 2 * 16 * (4 * nkh + 1) + 2 * NTH + FMW * 16 * PST + 16 * DMP + 2 * 16 * (16 * NT19 + 1) +
+                T * dg * (epc + 1) + dg * T + 2 * dg * T);
 }
 
 int device_cus() {
@@ -714,14 +855,38 @@ int device_cus() {
     return cus;
 }
 
+// The kernels use more than 64 KB of dynamic LDS: the per-kernel limit must be raised first, and only ever RAISED (the
+// configuration search probes candidates with smaller needs after the one it finally picks; a limit left at the last
+// candidate's value made launches of the chosen configuration run with too little LDS).
+template <typename K>
+bool ensure_lds(K kernel, int lds) {
+    // keyed by the kernel's address: every EPC instantiation has the same function-pointer TYPE
+    static const void* known[16];
+    static int granted[16];
+    static int n_known = 0;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    int slot = -1;
+    for (int i = 0; i < n_known; ++i)
+        if (known[i] == key) slot = i;
+    if (slot < 0) {
+        if (n_known == 16) return false;
+        slot = n_known++;
+        known[slot] = key, granted[slot] = 64 * 1024;
+    }
+    if (lds <= granted[slot]) return true;
+    if (hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return false;
+    granted[slot] = lds;
+    return true;
+}
+
 // workgroups of a kernel that the device holds at once (one per CU is what the exchange latency is tuned for; never more
-// than the occupancy query admits); also raises the kernel's dynamic-LDS limit to what the launch will ask for
+// than the occupancy query admits)
 template <typename K>
 int capacity(K kernel, int lds) {
     const int cus = device_cus();
     if (cus < 0) return -1;
     if (lds > 160 * 1024) return 0;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
+    if (!ensure_lds(kernel, lds)) return -1;
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, NTH, lds) != hipSuccess) return -1;
     return cus * (n < 1 ? n : 1);
@@ -756,7 +921,7 @@ extern "C" int erc_dag_rec_config(int dir, int B, int T, int n_layers, int epc_h
             const int cap = capacity_of(dir, epc, dg, T);
             ERC_REQUIRE(cap >= 0, "dag_rec_config: device query failed (no GPU?)");
             const int groups = erc_cdiv(B, dg);
-            const int lmax = dir ? 1 : (n_layers < ML ? n_layers : ML);      // only the forward pipelines the layers
+            const int lmax = n_layers < ML ? n_layers : ML;                  // both directions pipeline the layers
             for (int lpl = (lpl_hint > 0 ? lpl_hint : 1); lpl <= (lpl_hint > 0 ? lpl_hint : lmax); ++lpl) {
                 if (lpl > lmax) break;
                 int gpl = cap / (lpl * P);
@@ -783,19 +948,20 @@ extern "C" int erc_dag_rec_set_stamps(uint64_t* stamps) {
 }
 
 // scratch (bytes).  forward: all-gather records of M [groups][4][300][16] and the per-step rings of h
-// [groups][4][T][300][16]; backward: all-gather records of dM [groups][300][16], reduce-scatter records
-// [groups][P][P][dg][epc] (8 bytes each)
+// [groups][4][T][300][16]; backward: all-gather records of dM and the per-step rings of the input gradients (same
+// shapes), two sets of reduce-scatter records [groups][4][P][P][dg][epc] (16 bytes each)
 extern "C" int64_t erc_dag_rec_scratch_bytes(int dir, int B, int T, const int* cfg) {
     if (B <= 0 || T <= 0 || !cfg_ok(cfg)) return -1;
     const int64_t groups = erc_cdiv(B, cfg[1]), P = HID / cfg[0];
-    return dir ? 8 * (groups * XG + groups * P * P * cfg[1] * cfg[0]) : 8 * (groups * ML * XG * (1 + (int64_t)T));
+    const int64_t rings = 8 * (groups * ML * XG * (1 + (int64_t)T));
+    return dir ? rings + 8 * 4 * groups * ML * P * P * cfg[1] * cfg[0] : rings;      // two sets of 16-byte records
 }
 
 #define REC_DISPATCH(KERNEL, ARGS, LDS, WGS)                                                                    \
     switch (cfg[0]) {                                                                                           \
-        case 2: hipLaunchKernelGGL(KERNEL<2>, dim3((WGS) * (HID / 2)), dim3(NTH), LDS, st, ARGS); break;        \
-        case 4: hipLaunchKernelGGL(KERNEL<4>, dim3((WGS) * (HID / 4)), dim3(NTH), LDS, st, ARGS); break;        \
-        case 5: hipLaunchKernelGGL(KERNEL<5>, dim3((WGS) * (HID / 5)), dim3(NTH), LDS, st, ARGS); break;        \
+        case 2: ensure_lds(KERNEL<2>, LDS); hipLaunchKernelGGL(KERNEL<2>, dim3((WGS) * (HID / 2)), dim3(NTH), LDS, st, ARGS); break; \
+        case 4: ensure_lds(KERNEL<4>, LDS); hipLaunchKernelGGL(KERNEL<4>, dim3((WGS) * (HID / 4)), dim3(NTH), LDS, st, ARGS); break; \
+        case 5: ensure_lds(KERNEL<5>, LDS); hipLaunchKernelGGL(KERNEL<5>, dim3((WGS) * (HID / 5)), dim3(NTH), LDS, st, ARGS); break; \
     }
 
 extern "C" int erc_dag_rec_fwd(const float* H0, int ldh0, int n_layers, const float* const* Wh, const float* const* bh,
@@ -844,29 +1010,58 @@ extern "C" int erc_dag_rec_fwd(const float* H0, int ldh0, int n_layers, const fl
     return ERC_OK;
 }
 
-extern "C" int erc_dag_rec_bwd(const float* Hl, int ldh, const float* GI, int ldgi, const float* GH, const float* Mseq,
-                               const float* R, const float* alpha, const float* W_hh_c, const float* W_ih_p, const float* Wr,
-                               const float* w_k, const int32_t* pred, const int32_t* spk, int B, int T, const float* dH1,
-                               int ldd, float* dHl, int lddl, float* DGI, int lddgi, float* DGH, float* dR, float* dks,
+extern "C" int erc_dag_rec_bwd(int n_layers, const float* const* Hl, int ldh, const float* const* GI, int ldgi,
+                               const float* const* GH, const float* const* Mseq, const float* const* R,
+                               const float* const* alpha, const float* const* Wh, const float* const* W_hh_c,
+                               const float* const* W_ih_p, const float* const* Wr, const float* const* w_k,
+                               const int32_t* pred, const int32_t* spk, int B, int T, float* dHall, int ldd,
+                               float* const* DGI, int lddgi, float* const* DGH, float* const* dM, float* const* dks,
                                const int* cfg, int32_t* state, void* scratch, void* stream) {
-    ERC_REQUIRE(Hl && GI && GH && Mseq && R && alpha && W_hh_c && W_ih_p && Wr && w_k && pred && spk && dH1 && dHl && DGI &&
-                    DGH && dR && dks && state && scratch,
+    ERC_REQUIRE(Hl && GI && GH && Mseq && R && alpha && Wh && W_hh_c && W_ih_p && Wr && w_k && pred && spk && dHall && DGI && DGH &&
+                    dM && dks && state && scratch,
                 "dag_rec_bwd: null pointer");
-    ERC_REQUIRE(B > 0 && T > 0 && T < 1023 && ldh >= HID && ldgi > 6 * HID && lddgi > 6 * HID, "dag_rec_bwd: bad sizes B=%d T=%d", B, T);
+    ERC_REQUIRE(B > 0 && T > 0 && T < 1021 && n_layers > 0 && ldh >= HID && ldgi > 6 * HID && lddgi > 6 * HID &&
+                    ldd >= HID * (n_layers + 1),
+                "dag_rec_bwd: bad sizes B=%d T=%d layers=%d", B, T, n_layers);
     ERC_REQUIRE(cfg_ok(cfg) && ((uintptr_t)scratch & 7) == 0, "dag_rec_bwd: bad configuration (use erc_dag_rec_config)");
-    const int dg = cfg[1], gpl = cfg[2];
+    const int dg = cfg[1], gpl = cfg[2], lpl = cfg[3];
     const int lds = lds_bwd(cfg[0], dg, T);
     ERC_REQUIRE(lds <= 160 * 1024, "dag_rec_bwd: T=%d with %d dialogues per group needs %d bytes of LDS", T, dg, lds);
+    for (int l = 0; l < n_layers; ++l)
+        ERC_REQUIRE(Hl[l] && GI[l] && GH[l] && Mseq[l] && R[l] && alpha[l] && Wh[l] && W_hh_c[l] && W_ih_p[l] && Wr[l] && w_k[l] &&
+                        DGI[l] && DGH[l] && dM[l] && dks[l],
+                    "dag_rec_bwd: null pointer in the tables of layer %d", l);
     const int groups = erc_cdiv(B, dg);
+    const int64_t P = HID / cfg[0];
     u64* xm = reinterpret_cast<u64*>(scratch);
-    u64* xd = xm + (int64_t)groups * XG;
+    u64* xu = xm + (int64_t)groups * ML * XG;
+    u64* xd = xu + (int64_t)groups * ML * T * XG;
     hipStream_t st = (hipStream_t)stream;
-    for (int g0 = 0; g0 < groups; g0 += gpl) {
-        const int ng = groups - g0 < gpl ? groups - g0 : gpl;
-        RecBwd p{Hl, ldh, GI, ldgi, GH, Mseq, R, alpha, W_hh_c, W_ih_p, Wr, w_k, pred, spk, dH1, ldd, dHl, lddl, DGI, lddgi,
-                 DGH, dR, dks, B, T, dg, g0, xd, xm, state + 1, state, g_stamps};
-        REC_DISPATCH(dag_rec_bwd_kernel, p, lds, ng)
-        ERC_LAUNCH_CHECK("dag_rec_bwd");
+    for (int hi = n_layers; hi > 0; hi -= lpl) {          // chunks of layers, top chunk first
+        const int l0 = hi - lpl > 0 ? hi - lpl : 0, nl = hi - l0;
+        for (int g0 = 0; g0 < groups; g0 += gpl) {
+            const int ng = groups - g0 < gpl ? groups - g0 : gpl;
+            RecBwd p;
+            for (int l = 0; l < nl; ++l)
+                p.ly[l] = BwdLayer{Hl[l0 + l], GI[l0 + l], GH[l0 + l], Mseq[l0 + l], R[l0 + l], alpha[l0 + l], Wh[l0 + l],
+                                   W_hh_c[l0 + l], W_ih_p[l0 + l], Wr[l0 + l], w_k[l0 + l], dHall + (int64_t)HID * (l0 + l + 1),
+                                   DGI[l0 + l], DGH[l0 + l], dM[l0 + l], dks[l0 + l]};
+            for (int l = nl; l < ML; ++l) p.ly[l] = p.ly[0];
+            p.ldh = ldh, p.ldgi = ldgi, p.ldd = ldd, p.lddgi = lddgi;
+            p.dLow = dHall + (int64_t)HID * l0, p.relu_low = l0 == 0;
+            p.pred = pred, p.spk = spk, p.B = B, p.T = T, p.DG = dg, p.g0 = g0, p.nl = nl;
+            p.xd = xd, p.xm = xm, p.xu = xu, p.epoch = state + 1, p.err = state, p.stamps = g_stamps;
+            REC_DISPATCH(dag_rec_bwd_kernel, p, lds, ng * nl)
+            ERC_LAUNCH_CHECK("dag_rec_bwd");
+        }
     }
+    return ERC_OK;
+}
+
+extern "C" int erc_dag_attn_sums(const float* alpha, const float* H1, int ldo, const int32_t* pred, const int32_t* spk, int B,
+                                 int T, float* A, void* stream) {
+    ERC_REQUIRE(alpha && H1 && pred && spk && A && B > 0 && T > 0 && ldo >= HID, "dag_attn_sums: bad arguments");
+    hipLaunchKernelGGL(dag_attn_sums_kernel, dim3(B * T), dim3(64), 0, (hipStream_t)stream, alpha, H1, ldo, pred, spk, T, A);
+    ERC_LAUNCH_CHECK("dag_attn_sums");
     return ERC_OK;
 }

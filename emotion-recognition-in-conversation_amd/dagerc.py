@@ -113,8 +113,8 @@ class DAGERCModule(nn.Module):
             ks=[f32(BT) for _ in range(L)], alpha=[torch.zeros(B, T, T, dtype=torch.float32, device=device) for _ in range(L)],
             Y1=f32(BT, HID), Y2=f32(BT, HID), logits=f32(BT, C), dlogits=f32(BT, C), dY2=f32(BT, HID),
             dY1=f32(BT, HID), DGI=[f32(BT, LDG) for _ in range(L)], DGH=[f32(BT, 6 * HID) for _ in range(L)],
-            # dR | dks per layer (kept until the batched weight-gradient launch at the end of the step)
-            dR=[f32(BT, 2 * HID) for _ in range(L)], dks=[f32(BT) for _ in range(L)],
+            # dM | dks | attention-weighted sums per layer (kept until the batched weight-gradient launch at the end of the step)
+            dM=[f32(BT, HID) for _ in range(L)], dks=[f32(BT) for _ in range(L)], A=[f32(BT, 2 * HID) for _ in range(L)],
             stats=torch.zeros(256, dtype=torch.float32, device=device),
         )
         # cfg = (elements per workgroup, dialogues per group, groups per launch, layers per launch) of the recurrence
@@ -125,7 +125,7 @@ class DAGERCModule(nn.Module):
             raise capi.ErcGraftError("DAG-ERC: more than 4096 dialogues per batch")
         env = lambda k: int(os.environ.get(k, 0))
         ws["cfg_f"] = capi.dag_rec_config(0, B, T, L, env("ERC_DAG_EPC"), env("ERC_DAG_DG"), env("ERC_DAG_LPL"))
-        ws["cfg_b"] = capi.dag_rec_config(1, B, T, L, env("ERC_DAG_BEPC"), env("ERC_DAG_BDG"))
+        ws["cfg_b"] = capi.dag_rec_config(1, B, T, L, env("ERC_DAG_BEPC"), env("ERC_DAG_BDG"), env("ERC_DAG_BLPL"))
         ws["cfg"] = (tuple(ws["cfg_f"]), tuple(ws["cfg_b"]))
         i64 = lambda n: torch.zeros(n // 8 + 1, dtype=torch.int64, device=device)
         ws["scratch_f"] = i64(capi.dag_rec_scratch_bytes(0, B, T, ws["cfg_f"]))
@@ -134,7 +134,8 @@ class DAGERCModule(nn.Module):
         lw = [self._layer_w(l) for l in range(L)]
         ws["tables"] = {k: capi.ptr_table([w[k] for w in lw]) for k in ("Wh", "bh", "W_hh_c", "b_hh_c", "W_ih_p", "b_ih_p", "Wr", "w_k")}
         ws["tables"].update(H1=capi.ptr_table([ws["Hall"][:, HID * (l + 1):] for l in range(L)]),
-                            **{k: capi.ptr_table(ws[k]) for k in ("GI", "Mseq", "GH", "R", "ks", "alpha")})
+                            Hl=capi.ptr_table([ws["Hall"][:, HID * l:] for l in range(L)]),
+                            **{k: capi.ptr_table(ws[k]) for k in ("GI", "Mseq", "GH", "R", "ks", "alpha", "DGI", "DGH", "dM", "dks")})
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
@@ -244,17 +245,12 @@ class DAGERCModule(nn.Module):
                             ld_w=self.in_dim, force_slab=x_bf16)
         linear_wgrad(pl, ws["dY1"], HID, x, D, None, HID, D, BT, None, off["out_mlp.0.bias"], x_bf16=x_bf16,
                      slab=slab, col_off=W5)
-        for l in range(L - 1, -1, -1):
-            w = self._layer_w(l)
+        # all layers in one pipelined launch, top layer first (csrc/dag_rec.hip): leaves the gate gradients, dM and dks of
+        # every layer and the complete gradient wrt H_0 (through fc1's relu mask) in block 0 of dHall
+        capi.dag_rec_bwd(L, ws["tables"], W5, LDG, ws["pred"], ws["spk"], B, T, ws["dHall"], W5, LDG, ws["cfg_b"],
+                         self.rec_state, ws["scratch_b"])
+        for l in range(L):
             Hl, H1 = ws["Hall"][:, HID * l:], ws["Hall"][:, HID * (l + 1):]
-            dHl, dH1 = ws["dHall"][:, HID * l:], ws["dHall"][:, HID * (l + 1):]
-            capi.dag_rec_bwd(Hl, W5, ws["GI"][l], LDG, ws["GH"][l], ws["Mseq"][l], ws["R"][l], ws["alpha"][l], w["W_hh_c"],
-                             w["W_ih_p"], w["Wr"], w["w_k"], ws["pred"], ws["spk"], B, T, dH1, W5, dHl, W5, ws["DGI"][l], LDG,
-                             ws["DGH"][l], ws["dR"][l], ws["dks"][l], ws["cfg_b"], self.rec_state, ws["scratch_b"])
-            # dH_l += DGI [W_ih_c ; W_hh_p ; w_q] (column 1800 of DGI is d(query score)); on layer 0 the same launch
-            # applies the relu mask of fc1
-            capi.gemm_f32(ws["DGI"][l], LDG, 0, None, w["Wh"], HID, 1, None, dHl, W5, BT, HID, 6 * HID + 1,
-                          accumulate=1, act=2 if l == 0 else 0, aux=Hl if l == 0 else None, ldaux=W5, act_scale=1.0)
             # d[W_ih_c ; W_hh_p] and their biases (1800 rows: 16-byte operand loads); the two halves of gather.linear:
             # dw_q = DGI[:, 1800]^T H_l (+ its bias), dw_k = dks^T H1 -- one-row products of the same batched launch
             linear_wgrad(pl, ws["DGI"][l], LDG, Hl, W5, None, 6 * HID, HID, BT, off["grus_c.%d.weight_ih" % l],
@@ -265,7 +261,12 @@ class DAGERCModule(nn.Module):
                          defer=True)
             linear_wgrad(pl, ws["DGH"][l], 6 * HID, ws["Mseq"][l], HID, None, 6 * HID, HID, BT,
                          off["grus_c.%d.weight_hh" % l], off["grus_c.%d.bias_hh" % l], defer=True)
-            linear_wgrad(pl, ws["dR"][l], 2 * HID, H1, W5, None, 2 * HID, HID, BT, off["gather.%d.Wr0.weight" % l], None, defer=True)
+            # d[Wr0 ; Wr1] = sum_j dR_j h_j^T = sum_i dM_i A_i^T with the attention-weighted sums A (a forward quantity)
+            capi.dag_attn_sums(ws["alpha"][l], H1, W5, ws["pred"], ws["spk"], B, T, ws["A"][l])
+            linear_wgrad(pl, ws["dM"][l], HID, ws["A"][l], 2 * HID, None, HID, HID, BT, off["gather.%d.Wr0.weight" % l], None,
+                         defer=True)
+            linear_wgrad(pl, ws["dM"][l], HID, ws["A"][l][:, HID:], 2 * HID, None, HID, HID, BT,
+                         off["gather.%d.Wr1.weight" % l], None, defer=True)
         linear_wgrad(pl, ws["dHall"], W5, x, D, None, HID, D, BT, off["fc1.weight"], off["fc1.bias"], x_bf16=x_bf16)
         pl.reduce_into(ws, fp.grad)
         return ws["stats"]

@@ -427,9 +427,13 @@ int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
  *       W_hh_c / b_hh_c = grus_c.weight_hh / bias_hh, W_ih_p / b_ih_p = grus_p.weight_ih / bias_ih, Wr = [Wr0 ; Wr1],
  *       w_k [300] = the key half of gather.linear.weight;  outputs H1 (row pitch ldo), GI, Mseq, GH, R, ks, alpha as for
  *       erc_dag_scan_fwd.  H0 [B*T, ldh0 >= 300] is the input of layer 0 (relu(fc1 x)).
- *   BACKWARD (one layer per call, layers not pipelined yet): DGI [B*T, lddgi >= 1801] (written): columns [0,1800) as for
- *     erc_dag_scan_bwd, column 1800 d(query score): dH_l += DGI [W_ih_c ; W_hh_p ; w_q] and d[W_ih_c ; W_hh_p ; w_q] =
- *     DGI^T H_l are single GEMMs; dw_k = dks^T H1.  dR [B*T,600] / dks [B*T]: written (final values; no zero-fill needed).
+ *   BACKWARD: the same pipeline, top layer first.  dHall [B*T, ldd >= 300 (n_layers + 1)] holds on entry the head's part
+ *     of dL/d[H_0 | H_1 | .. | H_L] (block l+1 = the outputs of layer l) and receives in block 0 the complete gradient wrt
+ *     H_0 through fc1's relu mask (H_0 > 0); the input gradient of a layer -- z_p g + [W_ih_c ; W_hh_p ; w_q]^T [dgates ;
+ *     dqs], the former "dH_l += DGI Wh" GEMM -- is computed by the layer's workgroups and handed to the layer below per step.
+ *     Written per layer: DGI [B*T, lddgi >= 1801] (columns [0,1800) hoisted-side gate gradients, column 1800 d(query
+ *     score): d[W_ih_c ; W_hh_p ; w_q] = DGI^T H_l), DGH [B*T,1800] (d[W_hh_c ; W_ih_p] = DGH^T Mseq), dM [B*T,300]
+ *     (d[Wr0 ; Wr1] = dM^T A with A from erc_dag_attn_sums), dks [B*T] (dw_k = dks^T H1).  Hl[l] = the input of layer l.
  *   state: int32 [1 + ceil(B / dg)], zero-filled ONCE by the caller: [0] is raised when a poll ran into its bound (results
  *     invalid; pass it to erc_adam_step as skip_flag), then one launch epoch per group (shared by both directions).
  *   scratch: erc_dag_rec_scratch_bytes(dir, B, T, cfg) bytes per direction, 8-byte aligned, zero-filled ONCE.
@@ -445,11 +449,16 @@ int erc_dag_rec_fwd(const float* H0, int ldh0, int n_layers, const float* const*
                     const int32_t* pred, const int32_t* spk, int B, int T, float* const* H1, int ldo,
                     float* const* GI, int ldgi, float* const* Mseq, float* const* GH, float* const* R,
                     float* const* ks, float* const* alpha, const int* cfg, int32_t* state, void* scratch, void* stream);
-int erc_dag_rec_bwd(const float* Hl, int ldh, const float* GI, int ldgi, const float* GH, const float* Mseq,
-                    const float* R, const float* alpha, const float* W_hh_c, const float* W_ih_p, const float* Wr,
-                    const float* w_k, const int32_t* pred, const int32_t* spk, int B, int T,
-                    const float* dH1, int ldd, float* dHl, int lddl, float* DGI, int lddgi, float* DGH,
-                    float* dR, float* dks, const int* cfg, int32_t* state, void* scratch, void* stream);
+int erc_dag_rec_bwd(int n_layers, const float* const* Hl, int ldh, const float* const* GI, int ldgi,
+                    const float* const* GH, const float* const* Mseq, const float* const* R, const float* const* alpha,
+                    const float* const* Wh, const float* const* W_hh_c, const float* const* W_ih_p,
+                    const float* const* Wr, const float* const* w_k, const int32_t* pred, const int32_t* spk, int B, int T,
+                    float* dHall, int ldd, float* const* DGI, int lddgi, float* const* DGH, float* const* dM,
+                    float* const* dks, const int* cfg, int32_t* state, void* scratch, void* stream);
+/* A[i, sel*300 + k] = sum_{j in window(i), relation sel} alpha[i,j] H1[j,k]  (sel 0: same speaker): the attention-weighted
+ * sums of the hidden states, [B*T, 600].  d[Wr0 ; Wr1] = dM^T A (dagerc_models.py:356-358 under autograd). */
+int erc_dag_attn_sums(const float* alpha, const float* H1, int ldo, const int32_t* pred, const int32_t* spk, int B, int T,
+                      float* A, void* stream);
 
 /* (cluster / cl_state / cl_scratch as in erc_dag_scan_fwd) */
 int64_t erc_dag_cluster_scratch_floats(int B, int T);

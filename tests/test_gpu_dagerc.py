@@ -98,11 +98,11 @@ def test_recurrence_configurations_agree(monkeypatch):
     dims = dict(a=30, t=60, v=34)
     batch = make_batch(6, dims, n_speakers=3, n_classes=5, min_len=2, max_len=37, seed=4, speaker_onehot=True, force_max=True)
     res = {}
-    # (forward epc, dg, layers per launch | backward epc, dg); 0 = let erc_dag_rec_config choose
-    configs = [(0, 0, 0, 0, 0), (5, 1, 1, 5, 1), (5, 4, 4, 5, 4), (4, 3, 3, 4, 3), (4, 6, 2, 4, 6), (2, 6, 1, 2, 6),
-               (2, 16, 1, 2, 16), (5, 16, 4, 5, 16), (5, 6, 2, 5, 2)]
+    # (forward epc, dg, layers per launch | backward epc, dg, layers per launch); 0 = let erc_dag_rec_config choose
+    configs = [(0, 0, 0, 0, 0, 0), (5, 1, 1, 5, 1, 1), (5, 4, 4, 5, 4, 4), (4, 3, 3, 4, 3, 3), (4, 6, 2, 4, 6, 2),
+               (2, 6, 1, 2, 6, 1), (2, 16, 1, 2, 16, 1), (5, 16, 4, 5, 16, 4), (5, 6, 2, 5, 2, 3)]
     for cf in configs:
-        for k, v in zip(("ERC_DAG_EPC", "ERC_DAG_DG", "ERC_DAG_LPL", "ERC_DAG_BEPC", "ERC_DAG_BDG"), cf):
+        for k, v in zip(("ERC_DAG_EPC", "ERC_DAG_DG", "ERC_DAG_LPL", "ERC_DAG_BEPC", "ERC_DAG_BDG", "ERC_DAG_BLPL"), cf):
             monkeypatch.setenv(k, str(v))
         torch.manual_seed(9)
         m = DAGERCModule(emb_dim=sum(dims.values()), dropout=0.0, n_classes=5, gnn_layers=4).finalize(DEV)
@@ -110,7 +110,8 @@ def test_recurrence_configurations_agree(monkeypatch):
         stats = m.loss_and_grads(to_device(batch, DEV)).cpu()
         ws = m._last_ws
         if cf[0]:
-            assert ws["cfg"][0][:2] == cf[:2] and ws["cfg"][0][3] == cf[2] and ws["cfg"][1][:2] == cf[3:], ws["cfg"]
+            assert ws["cfg"][0][:2] == cf[:2] and ws["cfg"][0][3] == cf[2], ws["cfg"]
+            assert ws["cfg"][1][:2] == cf[3:5] and ws["cfg"][1][3] == cf[5], ws["cfg"]
         m.check_cluster()
         res[cf] = (float(stats[0]), ws["Hall"].cpu().clone(), m.flat.grad.cpu().clone(), ws["cfg"])
     base = res[configs[0]]

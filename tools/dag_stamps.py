@@ -18,9 +18,10 @@ def main():
     ap.add_argument("--epc", type=int, default=0), ap.add_argument("--dg", type=int, default=0)
     ap.add_argument("--lpl", type=int, default=0)
     ap.add_argument("--bepc", type=int, default=0), ap.add_argument("--bdg", type=int, default=0)
+    ap.add_argument("--blpl", type=int, default=0)
     ap.add_argument("--batch", type=int, default=16)
     a = ap.parse_args()
-    for k, v in (("ERC_DAG_EPC", a.epc), ("ERC_DAG_DG", a.dg), ("ERC_DAG_LPL", a.lpl), ("ERC_DAG_BEPC", a.bepc), ("ERC_DAG_BDG", a.bdg)):
+    for k, v in (("ERC_DAG_EPC", a.epc), ("ERC_DAG_DG", a.dg), ("ERC_DAG_LPL", a.lpl), ("ERC_DAG_BEPC", a.bepc), ("ERC_DAG_BDG", a.bdg), ("ERC_DAG_BLPL", a.blpl)):
         if v:
             os.environ[k] = str(v)
     from bench import synthetic_batch
@@ -35,7 +36,7 @@ def main():
     names = {"erc_dag_rec_fwd": ["start", "polled M", "gates done", "barrier A", "polled h | h published", "R done | saves done",
                                  "barrier B", "tail done (EW)"],     # workgroup 0 = layer 0, slice 0
              "erc_dag_rec_bwd": ["start", "E1 done", "M1+publish done", "partials summed", "E2 | Y done", "barrier 3", "dots done",
-                                 "E3 done (EW)"]}
+                                 "E3 done (EW)"]}      # workgroup 0 = the launch's lowest layer, slice 0
     capi.start_recording()
     tr.train_step(batch)
     rec = capi.stop_recording()
