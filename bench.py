@@ -71,10 +71,14 @@ def _probe_candidates(module, params, host_batch, trainer):
     if module == "dagerc":
         B, T = host_batch["input_tensor"].shape[:2]
         per = 2.0 * 300 * (1800 + 600 + 1)
-        return {"erc_dag_scan_fwd": ("DAG-ERC forward scan (one layer)", per * B * T, "mfma"),
-                "erc_dag_scan_bwd": ("DAG-ERC backward scan (one layer)", per * B * T, "mfma"),
-                "erc_dag_rec_fwd": ("dag_rec_fwd_kernel (weight-stationary forward recurrence, one layer)", per * B * T, "mfma"),
-                "erc_dag_rec_bwd": ("dag_rec_bwd_kernel (weight-stationary backward recurrence, one layer)", per * B * T, "mfma")}
+        L = params.get("gnn_layers", 4)
+        # per position and layer: hoisted [1801 x 300] + sequential [1800 x 300] + relations [601 x 300] products, forward;
+        # the backward runs the three transposed products (the weight-gradient GEMMs are separate launches)
+        per = 2.0 * 300 * (1801 + 1800 + 601)
+        return {"erc_dag_rec_fwd": ("dag_rec_fwd_kernel (weight-stationary forward recurrence, all %d layers pipelined)" % L,
+                                    per * B * T * L, "mfma"),
+                "erc_dag_rec_bwd": ("dag_rec_bwd_kernel (weight-stationary backward recurrence, all %d layers pipelined)" % L,
+                                    per * B * T * L, "mfma")}
     if module == "mmgcn":
         Mo = len(params.modality)
         fl = sum(Mo * 2.0 * L * L * 200 for L in lens)

@@ -104,12 +104,6 @@ _SIGS = {
     "erc_mm_regroup_bwd": (C.c_int, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "erc_axpy_mask": (C.c_int, [_vp, _vp, _i64, _f, _i, _vp, _vp]),
     "erc_dag_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "erc_dag_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp,
-                                   _vp, _vp, _vp, _i, _vp, _vp, _vp]),
-    "erc_dag_cluster_size": (C.c_int, [_i]),
-    "erc_dag_scan_bwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
-                                   _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
-    "erc_dag_cluster_scratch_floats": (C.c_int64, [_i, _i]),
     "erc_dag_rec_config": (C.c_int, [_i, _i, _i, _i, _i, _i, _i, _vp]),
     "erc_dag_rec_scratch_bytes": (C.c_int64, [_i, _i, _i, _vp]),
     "erc_dag_rec_set_stamps": (C.c_int, [_vp]),
@@ -367,31 +361,6 @@ def dag_attn_sums(alpha, H1, ldo, pred, spk, B, T, A):
 def dag_meta(speaker_onehot, speaker_ids, sb, st, S, lengths, B, T, spk, pred, node_off, node_row):
     _check(lib().erc_dag_meta(ptr(speaker_onehot), ptr(speaker_ids), sb, st, S, ptr(lengths), B, T, ptr(spk),
                               ptr(pred), ptr(node_off), ptr(node_row), stream()), "erc_dag_meta")
-
-
-def dag_cluster_size(B):
-    return int(lib().erc_dag_cluster_size(B))
-
-
-def dag_scan_fwd(Hl, ldh, GI, W_hh_c, b_hh_c, W_ih_p, b_ih_p, Wr, w_lin, pred, spk, B, T, H1, ldo, Mseq, GH, R, ks,
-                 alpha, cluster=1, cl_state=None, cl_scratch=None):
-    _check(lib().erc_dag_scan_fwd(ptr(Hl), ldh, ptr(GI), ptr(W_hh_c), ptr(b_hh_c), ptr(W_ih_p), ptr(b_ih_p), ptr(Wr),
-                                  ptr(w_lin), ptr(pred), ptr(spk), B, T, ptr(H1), ldo, ptr(Mseq), ptr(GH), ptr(R),
-                                  ptr(ks), ptr(alpha), cluster, ptr(cl_state), ptr(cl_scratch), stream()),
-           "erc_dag_scan_fwd")
-
-
-def dag_cluster_scratch_floats(B, T):
-    return int(lib().erc_dag_cluster_scratch_floats(B, T))
-
-
-def dag_scan_bwd(Hl, ldh, GI, GH, Mseq, R, alpha, H1, ldo, W_hh_c, W_ih_p, Wr, w_lin, pred, spk, B, T, dH1, ldd, dHl,
-                 lddl, DGI, DGH, dR, dks, dlin, cluster=1, cl_state=None, cl_scratch=None):
-    _check(lib().erc_dag_scan_bwd(ptr(Hl), ldh, ptr(GI), ptr(GH), ptr(Mseq), ptr(R), ptr(alpha), ptr(H1), ldo,
-                                  ptr(W_hh_c), ptr(W_ih_p), ptr(Wr), ptr(w_lin), ptr(pred), ptr(spk), B, T, ptr(dH1),
-                                  ldd, ptr(dHl), lddl, ptr(DGI), ptr(DGH), ptr(dR), ptr(dks), ptr(dlin), cluster,
-                                  ptr(cl_state), ptr(cl_scratch), stream()),
-           "erc_dag_scan_bwd")
 
 
 def lstm_scan_fwd(GX, ldgx, W_hh, b_hh, lengths, node_off, sb, st, B, T, Hout, ldh, Hdrop, ldhd, drop_p, rng,

@@ -1,7 +1,7 @@
 // K6 (second generation): the DAG-ERC directed-acyclic recurrence (track_mm/dagerc.py:167-189,
 // track_mm/dagerc_models.py:326-365) weight-stationary, with the batch of dialogues as the MFMA M dimension.
 //
-// The first-generation scan (dag_scan.hip) gave every dialogue its own cluster of workgroups and re-streamed the
+// The first-generation scan (round 1) gave every dialogue its own cluster of workgroups and re-streamed the
 // 2.9 MB of recurrent fp32 weights from L2 at every one of the 110 steps: 41 GB of L2 traffic per training step for
 // 11.6 MB of weights.  Here a GROUP of DG <= 16 dialogues is advanced together by P = 300 / EPC workgroups (one per CU).
 // Workgroup c owns the hidden ELEMENTS E_c = [c EPC, (c+1) EPC) of every 300-vector of the recurrence and keeps, for its
@@ -130,6 +130,56 @@ __device__ __forceinline__ const float* gate_row(const float* W_hh_c, const floa
     // cell C then of cell P
     return gate < 3 ? W_hh_c + (int64_t)(gate * HID + e) * HID : W_ih_p + (int64_t)((gate - 3) * HID + e) * HID;
 }
+
+constexpr int MAX_T = 1022;
+
+// ----------------------------------------------------------------------------- meta
+// speaker ids, DAG predecessor, valid-row map.  One workgroup per dialogue.
+__global__ __launch_bounds__(256) void dag_meta_kernel(const float* __restrict__ onehot, const int64_t* __restrict__ ids,
+                                                       int64_t sb, int64_t st, int S, const int64_t* __restrict__ lengths,
+                                                       int B, int T, int32_t* __restrict__ spk, int32_t* __restrict__ pred,
+                                                       int32_t* __restrict__ node_off, int32_t* __restrict__ node_row) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_spk[1024];
+    __shared__ int red[256];
+    int acc = 0;
+    for (int i = tid; i < b; i += 256) acc += (int)lengths[i];
+    red[tid] = acc;
+    for (int t = tid; t < T; t += 256) {
+        int s = 0;
+        if (onehot) {  // argmax of the one-hot row (first maximum, like torch.argmax)
+            const float* row = onehot + (int64_t)b * sb + (int64_t)t * st;
+            float best = row[0];
+            for (int c = 1; c < S; ++c)
+                if (row[c] > best) best = row[c], s = c;
+        } else {
+            s = (int)ids[(int64_t)b * sb + (int64_t)t * st];
+        }
+        s_spk[t] = s;
+        spk[b * T + t] = s;
+    }
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    const int noff = red[0], L = (int)lengths[b];
+    if (tid == 0) {
+        node_off[b] = noff;
+        if (b == B - 1) node_off[B] = noff + L;
+    }
+    for (int t = tid; t < T; t += 256) {
+        int p = -1;
+        for (int j = t - 1; j >= 0; --j)
+            if (s_spk[j] == s_spk[t]) {
+                p = j;
+                break;
+            }
+        pred[b * T + t] = p;
+        if (t < L) node_row[noff + t] = b * T + t;
+    }
+}
+
 
 // ----------------------------------------------------------------------------------------------- forward
 // The forward runs the LAYERS as a pipeline: layer l needs, at its step i, only h^{(l-1)}_{i+1} of the layer below, so
@@ -907,6 +957,19 @@ bool cfg_ok(const int* cfg) {
 }
 
 }  // namespace
+
+extern "C" int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_t spk_sb, int64_t spk_st,
+                            int n_speakers, const int64_t* lengths, int B, int T, int32_t* spk, int32_t* pred,
+                            int32_t* node_off, int32_t* node_row, void* stream) {
+    ERC_REQUIRE((speaker_onehot != nullptr) != (speaker_ids != nullptr), "dag_meta: give one-hot OR ids");
+    ERC_REQUIRE(lengths && spk && pred && node_off && node_row, "dag_meta: null pointer");
+    ERC_REQUIRE(B > 0 && T > 0 && T <= MAX_T && n_speakers > 0, "dag_meta: B=%d T=%d (T <= %d)", B, T, MAX_T);
+    hipLaunchKernelGGL(dag_meta_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, speaker_onehot, speaker_ids, spk_sb,
+                       spk_st, n_speakers, lengths, B, T, spk, pred, node_off, node_row);
+    ERC_LAUNCH_CHECK("dag_meta");
+    return ERC_OK;
+}
+
 
 // cfg[4] = {elements per workgroup, dialogues per group, groups per launch, layers per launch}
 extern "C" int erc_dag_rec_config(int dir, int B, int T, int n_layers, int epc_hint, int dg_hint, int lpl_hint, int* cfg) {

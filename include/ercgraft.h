@@ -381,36 +381,11 @@ int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_
                  int n_speakers, const int64_t* lengths, int B, int T,
                  int32_t* spk, int32_t* pred, int32_t* node_off, int32_t* node_row, void* stream);
 
-/* One layer of the recurrence (dagerc.py:167-189), hidden size 300, one
- * persistent workgroup per dialogue, steps t = 0..T-1:
+/* ------------------------------------------------------------------------
+ * K6: the recurrence (dagerc.py:167-189, dagerc_models.py:326-365), hidden size 300, per layer and step t:
  *   M_t  = sum_{j in [max(pred,0), t-1]} softmax_j(w_q.H_l[t] + w_k.h_j + b) * (same speaker ? Wr0 h_j : Wr1 h_j)
  *   h_t  = GRUCell_c(x = H_l[t], h = M_t) + GRUCell_p(x = M_t, h = H_l[t])
- * GI [B*T,1800] holds the hoisted gate pre-activations
- *   [W_ih(grus_c) H_l + b_ih(grus_c) | W_hh(grus_p) H_l + b_hh(grus_p)]  (one GEMM by the caller);
- * W_hh_c/b_hh_c = grus_c.weight_hh/bias_hh, W_ih_p/b_ih_p = grus_p.weight_ih/bias_ih, Wr = [Wr0;Wr1] [600,300],
- * w_lin [601] = gather.linear.weight (w_q | w_k) followed by its bias.
- * Saved for the backward: Mseq [B*T,300], GH [B*T,1800] (sequential gate pre-activations),
- * R [B*T,600] (Wr0 h | Wr1 h), ks [B*T] (w_k.h), alpha [B,T,T].
- * cluster = P > 1: P cooperating workgroups per dialogue (each streams 1/P of the weight rows per step; results
- * exchanged through GH / R / ks with write-through stores and a per-dialogue arrival counter).  P <= 8 and
- * B * P <= 224 (all workgroups must be resident at once: erc_dag_cluster_size(B) gives the largest legal P);
- * cl_state: 2 B + 1 int32 -- [0] is set to 1 if a member timed out waiting (the result is then invalid), then B
- * arrival counters and B launch epochs; cl_scratch: erc_dag_cluster_scratch_floats(B, T) floats, 8-byte aligned (tagged
- * exchange records, private accumulator copies of the backward).  The caller zero-fills both ONCE and may check cl_state[0]
- * after a step.  cluster <= 1: one workgroup per dialogue. */
-int erc_dag_cluster_size(int B);
-int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
-                     const float* W_hh_c, const float* b_hh_c, const float* W_ih_p, const float* b_ih_p,
-                     const float* Wr, const float* w_lin, const int32_t* pred, const int32_t* spk, int B, int T,
-                     float* H1, int ldo, float* Mseq, float* GH, float* R, float* ks, float* alpha,
-                     int cluster, int32_t* cl_state, float* cl_scratch, void* stream);
-/* Reverse scan.  dH1 = complete gradient wrt the layer outputs.  Writes the gate gradients DGI / DGH
- * [B*T,1800] (weight gradients are then plain GEMMs: d[W_ih_c;W_hh_p] = DGI^T H_l, d[W_hh_c;W_ih_p] = DGH^T Mseq,
- * d[Wr0;Wr1] = dR^T H1, dH_l += DGI [W_ih_c;W_hh_p]); accumulates dR [B*T,600] / dks [B*T] (caller zero-fills),
- * ADDS the direct gradient wrt H_l into dHl, and writes the per-dialogue partial gradient of gather.linear
- * to dlin [B,601]. */
-/* ------------------------------------------------------------------------
- * K6, second generation: the same recurrence (dagerc.py:167-189, dagerc_models.py:326-365) weight-stationary with the
+ * weight-stationary with the
  * batch of dialogues as the MFMA M dimension (csrc/dag_rec.hip).  A group of `dg` dialogues is advanced by 300 / epc
  * workgroups; workgroup c keeps the weight rows / columns of its hidden elements [c epc, (c+1) epc) in registers for all
  * T steps and the groups' 300-vectors are exchanged as tagged 8-byte records (two exchanges per step and direction).
@@ -425,8 +400,8 @@ int erc_dag_scan_fwd(const float* Hl, int ldh, const float* GI,
  *     score).  Per-layer operands are passed as host arrays of n_layers device pointers:
  *       Wh [1801(+),300] = W_ih(grus_c) ; W_hh(grus_p) ; w_q (row 1800), bh [1801] its biases (gather.linear.bias last),
  *       W_hh_c / b_hh_c = grus_c.weight_hh / bias_hh, W_ih_p / b_ih_p = grus_p.weight_ih / bias_ih, Wr = [Wr0 ; Wr1],
- *       w_k [300] = the key half of gather.linear.weight;  outputs H1 (row pitch ldo), GI, Mseq, GH, R, ks, alpha as for
- *       erc_dag_scan_fwd.  H0 [B*T, ldh0 >= 300] is the input of layer 0 (relu(fc1 x)).
+ *       w_k [300] = the key half of gather.linear.weight;  outputs H1 (row pitch ldo) and, saved for the backward, GI, Mseq [B*T,300], GH [B*T,1800] (sequential gate
+ *       pre-activations), R [B*T,600] (Wr0 h | Wr1 h), ks [B*T] (w_k.h), alpha [B,T,T].  H0 [B*T, ldh0 >= 300] is the input of layer 0 (relu(fc1 x)).
  *   BACKWARD: the same pipeline, top layer first.  dHall [B*T, ldd >= 300 (n_layers + 1)] holds on entry the head's part
  *     of dL/d[H_0 | H_1 | .. | H_L] (block l+1 = the outputs of layer l) and receives in block 0 the complete gradient wrt
  *     H_0 through fc1's relu mask (H_0 > 0); the input gradient of a layer -- z_p g + [W_ih_c ; W_hh_p ; w_q]^T [dgates ;
@@ -460,15 +435,7 @@ int erc_dag_rec_bwd(int n_layers, const float* const* Hl, int ldh, const float* 
 int erc_dag_attn_sums(const float* alpha, const float* H1, int ldo, const int32_t* pred, const int32_t* spk, int B, int T,
                       float* A, void* stream);
 
-/* (cluster / cl_state / cl_scratch as in erc_dag_scan_fwd) */
-int64_t erc_dag_cluster_scratch_floats(int B, int T);
-int erc_dag_scan_bwd(const float* Hl, int ldh, const float* GI, const float* GH, const float* Mseq,
-                     const float* R, const float* alpha, const float* H1, int ldo,
-                     const float* W_hh_c, const float* W_ih_p, const float* Wr, const float* w_lin,
-                     const int32_t* pred, const int32_t* spk, int B, int T,
-                     const float* dH1, int ldd, float* dHl, int lddl,
-                     float* DGI, float* DGH, float* dR, float* dks, float* dlin,
-                     int cluster, int32_t* cl_state, float* cl_scratch, void* stream);
+
 
 /* ------------------------------------------------------------------------
  * (Bi)LSTM recurrence, hidden 100 per direction, torch.nn.LSTM semantics (gate order i|f|g|o):

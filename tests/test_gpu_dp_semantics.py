@@ -100,6 +100,9 @@ def test_dagerc_two_shards_clip_on_averaged_gradient():
         # the first AdamW step moves every element by lr * g / (|g| + eps'): where |g| is at rounding-noise level the
         # step's SIZE is noise on both sides, so parameters are compared where the gradient is well above that level
         g = refp[n].grad
+        if n.endswith("linear.bias") and n.startswith("gather."):
+            assert float(g.abs().max()) < 1e-6      # softmax is shift invariant: this gradient is mathematically zero
+            continue
         sure = g.abs() > 1e-3 * g.abs().max()
         d = (mine.flat.w(n).cpu() - refp[n].detach()).abs()
         assert float(d[sure].max()) < 2e-5, n

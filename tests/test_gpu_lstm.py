@@ -132,4 +132,5 @@ def test_packed_bilstm_vs_reference_seqcontext(golden, name):
     assert rel_err(dx.cpu().view(B, T, D), want_dx) < 1e-3
     from erc_amd import capi
     capi.slab_reduce_batched(pl.ws, flat.grad, pl.job_table(), len(pl.jobs), pl.max_numel)
-    check_grad_digest(fx, [("rnn." + n, flat.g("rnn." + n)) for n, _ in holder.rnn.named_parameters()], tol=1e-3)
+    # the generator's names: "rnn." + SeqContext.named_parameters() = "rnn.rnn.<param>"
+    check_grad_digest(fx, [("rnn.rnn." + n, flat.g("rnn." + n)) for n, _ in holder.rnn.named_parameters()], tol=1e-3)
