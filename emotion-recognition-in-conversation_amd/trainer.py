@@ -113,6 +113,75 @@ def make_loaders(params, rank=0, world=1, device=None):
     return tl, el
 
 
+class FixedBatches:
+    """``--fixed_batches``: the training batches are collated once and kept on the device; an epoch visits them in a
+    freshly shuffled ORDER.  Batch shapes then repeat every epoch, so every step after the first epoch is one HIP-graph
+    replay with no host-side collate and no host-to-device copy.  (Opt-in: the reference reshuffles the dialogues
+    themselves every epoch.)"""
+
+    def __init__(self, loader, trainer, seed):
+        self.batches = [(int(b["label"].shape[0]), trainer.prepare_batch(b)) for b in loader]
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for i in torch.randperm(len(self.batches), generator=self.gen).tolist():
+            yield i, self.batches[i]
+
+
+class StepGraphs:
+    """One captured HIP graph of the whole training step per batch shape (B, T, N), least-recently-used eviction.  The
+    FIRST step of a shape runs eagerly -- it is a real training step and allocates that shape's workspace -- and is then
+    captured (capture records, it does not execute); later steps of the shape copy the batch into the graph's static
+    input buffers and replay.  Losses are therefore identical to the eager loop."""
+
+    def __init__(self, trainer, maxsize=16):
+        import collections
+        self.trainer, self.maxsize = trainer, maxsize
+        self.cache = collections.OrderedDict()
+        self.replays = self.eager = 0
+
+    @staticmethod
+    def shape_key(batch):
+        return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v)) + \
+            tuple((k, v) for k, v in sorted(batch.items()) if isinstance(v, int))
+
+    def step(self, batch, key=None, resident=False):
+        """``resident``: ``batch`` lives in fixed device buffers of its own (FixedBatches) -- the graph binds to them."""
+        key = (key, ) if key is not None else self.shape_key(batch)
+        ent = self.cache.get(key)
+        if ent is not None:
+            static, graph, out = ent[:3]
+            self.cache.move_to_end(key)
+            if not resident:
+                for k, v in batch.items():
+                    if torch.is_tensor(v):
+                        static[k].copy_(v, non_blocking=True)
+            graph.replay()
+            self.replays += 1
+            return out
+        stats = self.trainer.train_step(batch)                # the real step of this shape's first occurrence
+        self.eager += 1
+        static = batch if resident else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        try:
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.trainer.train_step(static)
+        except Exception as exc:                               # a step that cannot be captured stays eager
+            print(json.dumps({"graph_replay": "capture failed, staying eager", "error": str(exc)[:200]}), file=sys.stderr)
+            self.step = lambda b, key=None, resident=False: self.trainer.train_step(b)
+            return stats
+        # the graph holds raw pointers into this shape's workspace: keep the workspace object alive with the graph, whatever
+        # the module's own LRU cache does with it (evaluation batches of other shapes come in between)
+        self.cache[key] = (static, graph, out, getattr(self.trainer.model, "_last_ws", None))
+        while len(self.cache) > self.maxsize:
+            self.cache.popitem(last=False)
+        return stats
+
+
 def classification_report(true, pred, n_classes):
     """The metric set of mmbase.py:259-275."""
     from sklearn import metrics
@@ -150,21 +219,33 @@ def run(trainer_cls, params_cls, argv=None):
         checkpoint.load(trainer, params.load)
     train_loader, test_loader = make_loaders(params, rank, world, device)
     best = {}
+    # one captured graph per batch shape; with gradient exchange (world > 1) the step stays eager: the all-reduce is
+    # issued from the host between backward and optimizer
+    graphs = StepGraphs(trainer) if (params.get("graph_replay", True) and world == 1) else None
+    fixed = FixedBatches(train_loader, trainer, params.seed + rank) if params.get("fixed_batches", False) else None
+    n_steps = len(fixed) if fixed is not None else len(train_loader)
+    ring = torch.zeros(max(1, n_steps), 4, dtype=torch.float32, device=device)    # per-step {loss, #correct, ...}: read once per epoch
     for epoch in range(params.epoch):
         trainer.model.train()
-        t0, n_utt, last = time.perf_counter(), 0, None
-        for i, batch in enumerate(train_loader):
-            dev_batch = trainer.prepare_batch(batch)
-            stats = trainer.train_step(dev_batch)
-            n_utt += int(batch["label"].shape[0])
-            if rank == 0 and params.log_every and (i + 1) % params.log_every == 0:
-                s = stats.tolist()  # one device->host sync per logged step
-                last = {"epoch": epoch, "step": i, "Lall": s[0], "Acc": s[1] / max(1, batch["label"].shape[0])}
-                print(json.dumps(last), flush=True)
+        t0, n_utt, counts = time.perf_counter(), 0, []
+        for i, item in enumerate(fixed if fixed is not None else train_loader):
+            if fixed is not None:
+                bid, (n_b, dev_batch) = item
+            else:
+                bid, n_b, dev_batch = None, int(item["label"].shape[0]), trainer.prepare_batch(item)
+            stats = graphs.step(dev_batch, key=bid, resident=fixed is not None) if graphs is not None else trainer.train_step(dev_batch)
+            ring[i].copy_(stats[:4], non_blocking=True)          # no device->host synchronisation inside the epoch
+            n_utt += n_b
+            counts.append(n_b)
         torch.cuda.synchronize()
         if hasattr(trainer.model, "check_cluster"):
             trainer.model.check_cluster()
         dt = time.perf_counter() - t0
+        if rank == 0 and params.log_every:
+            rows = ring[:len(counts)].cpu().tolist()
+            for i, (row, n_b) in enumerate(zip(rows, counts)):
+                if (i + 1) % params.log_every == 0:
+                    print(json.dumps({"epoch": epoch, "step": i, "Lall": row[0], "Acc": row[1] / max(1, n_b)}), flush=True)
         # test after every epoch (mmbase.py:136,180-201)
         trainer.model.eval()
         true, pred = [], []
@@ -181,7 +262,8 @@ def run(trainer_cls, params_cls, argv=None):
             for k in ("acc", "wa", "f1", "mif1", "maf1", "pre", "rec"):
                 best[k] = max(best.get(k, 0.0), rep[k])
             print(json.dumps({"epoch": epoch, "train_utt_per_s": n_utt / dt, "test": {k: rep[k] for k in rep if k != "cm"},
-                              "best": best}), flush=True)
+                              "best": best, "graph_replays": graphs.replays if graphs else 0,
+                              "eager_steps": graphs.eager if graphs else len(counts)}), flush=True)
     if params.get("save") and rank == 0:
         from . import checkpoint
         checkpoint.save(trainer, params.save)

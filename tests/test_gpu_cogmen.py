@@ -260,3 +260,28 @@ def test_checkpoint_envelope_round_trip_with_reference_style_trainer(tmp_path):
     l_hip2 = float(tr.train_step(tr.prepare_batch(batches[3])).cpu()[0])
     assert abs(l_hip2 - float(l_ref2)) < 2e-5
     close(tr, ref2, 1e-4)
+
+
+def test_training_loop_graph_replay_equals_eager():
+    """trainer.run (what ``train_mm.py --module=cogmen`` executes): with ``--fixed_batches`` the batches repeat every epoch,
+    so from epoch 1 on every step is a replay of the shape's captured HIP graph.  Per-step losses must be IDENTICAL to the
+    same loop run eagerly (``--graph_replay=False``): the first occurrence of a shape runs eagerly and is then captured
+    (capture records, it does not execute), the dropout RNG offset and the optimizer step live on the device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for tag, extra in (("graph", []), ("eager", ["--graph_replay=False"])):
+        res = subprocess.run([sys.executable, "train_mm.py", "--module=cogmen", "--dataset=iemocap-cogmen-6", "--epoch=3",
+                              "--n_train=20", "--n_test=6", "--train.batch_size=8", "--test.batch_size=8", "--fixed_batches",
+                              "--compute=bf16"] + extra, cwd=repo, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+        runs[tag] = ([l["Lall"] for l in lines if "Lall" in l], [l for l in lines if "test" in l])
+    assert len(runs["graph"][0]) == 9 and runs["graph"][0] == runs["eager"][0]
+    ep = runs["graph"][1]
+    assert ep[0]["graph_replays"] == 0 and ep[0]["eager_steps"] == 3          # epoch 0: every shape is new
+    assert ep[2]["graph_replays"] == 6 and ep[2]["eager_steps"] == 3          # epochs 1, 2: replays only
+    assert runs["eager"][1][2]["graph_replays"] == 0
