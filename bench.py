@@ -274,11 +274,15 @@ def main():
             return out
         step = GraphedStep(step_fn) if use_graph else step_fn
     else:
-        # forward+backward in one graph; the RCCL all-reduce and the optimizer stay eager (2 launches)
+        # N > 1: the WHOLE step -- forward, backward, the RCCL sum all-reduce of the flat gradient buffer and the
+        # optimizer -- is one captured HIP graph (RCCL collectives are capturable: the all-reduce becomes a graph node
+        # behind the last weight-gradient kernel); ERC_DP_EAGER=1 keeps the exchange and the optimizer outside the graph
+        # (the round-1 structure) for comparison
         trainer.model.train()
         cw = getattr(trainer, "class_weight", None)
         dead_encoder = getattr(trainer, "encoder", None)            # --faithful_dead_encoder
         trained_encoder = getattr(trainer.model, "enc_train", None)  # --chained_encoder
+        dp_eager = os.environ.get("ERC_DP_EAGER", "0") == "1"
 
         def fb():
             if dead_encoder is not None:
@@ -286,14 +290,25 @@ def main():
             if args.module in ("cogmen", "dgcn"):
                 return trainer.model.loss_and_grads(batch, cw)
             return trainer.model.loss_and_grads(batch)
-        fb_g = GraphedStep(fb) if use_graph else fb
 
-        def step():
-            out = fb_g()
+        def exchange_and_update():
             trainer.optim.step(grad_scale=all_reduce_grads(trainer.model.flat, always=args.rehearse_dp))
             if trained_encoder is not None:
                 trained_encoder.refresh_shadows()      # bf16 copies of the encoder weights follow the fp32 masters
-            return out
+
+        if dp_eager or not use_graph:
+            fb_g = GraphedStep(fb) if use_graph else fb
+
+            def step():
+                out = fb_g()
+                exchange_and_update()
+                return out
+        else:
+            def whole():
+                out = fb()
+                exchange_and_update()
+                return out
+            step = GraphedStep(whole)
 
     def barrier():
         if dp:
@@ -398,6 +413,7 @@ def main():
                                        params.hidden_visual, params.hidden_all, params.n_classes),
                        "utterances_per_step_per_gpu": n_utt, "global_batch_dialogues": args.batch * world,
                        "parallelism": "dp%d" % world, "hip_graph": use_graph,
+                       "dp_exchange": ("none" if not dp else ("eager after the graph" if os.environ.get("ERC_DP_EAGER", "0") == "1" or not use_graph else "captured in the step graph")),
                        "features_dtype": args.dtype, "loss": stats[0],
                        "faithful_dead_encoder": bool(args.faithful_dead_encoder and args.module == "cogmen"),
                        "chained_encoder": bool(args.chained_encoder and args.module == "cogmen")},
