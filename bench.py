@@ -66,7 +66,7 @@ def _probe_candidates(module, params, host_batch, trainer):
     N = sum(lens)
     if module == "cogmen":
         pl = trainer.model._last_ws["planner"]
-        fl = sum(2.0 * M * Nn * K for (_, _, _, _, _, _, M, Nn, K, _, _, _) in pl.deferred)
+        fl = sum(2.0 * d[6] * d[7] * d[8] for d in pl.deferred)
         return {"erc_wgrad_table": ("wgrad_table_kernel (every weight gradient of the step, one launch)", fl, "mfma")}
     if module == "dagerc":
         B, T = host_batch["input_tensor"].shape[:2]

@@ -103,6 +103,14 @@ _SIGS = {
     "erc_mm_regroup_fwd": (C.c_int, [_vp, _vp, _i, _i, _f, _vp, C.c_uint64, _vp, _vp]),
     "erc_mm_regroup_bwd": (C.c_int, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     "erc_axpy_mask": (C.c_int, [_vp, _vp, _i64, _f, _i, _vp, _vp]),
+    "erc_test_poison_lds": (C.c_int, [_vp, _vp]),
+    "erc_gcnii_chain_set_stamps": (C.c_int, [_vp]),
+    "erc_gcnii_chain_prep": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
+    "erc_gcnii_chain_config": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_gcnii_chain_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i, _vp, _vp,
+                                      _f, _vp, C.c_uint64, _vp]),
+    "erc_gcnii_chain_bwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp,
+                                      _vp, _f, _vp]),
     "erc_dag_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_dag_rec_config": (C.c_int, [_i, _i, _i, _i, _i, _i, _i, _vp]),
     "erc_dag_rec_scratch_bytes": (C.c_int64, [_i, _i, _i, _vp]),
@@ -309,6 +317,30 @@ def grad_norm(g, n, grad_scale, gnorm, ws):
     _check(lib().erc_grad_norm(ptr(g), n, grad_scale, ptr(gnorm), ptr(ws), stream()), "erc_grad_norm")
 
 
+def gcnii_chain_prep(W, w_stride, lamda, alpha, VT, V, U):
+    _check(lib().erc_gcnii_chain_prep(ptr(W), w_stride, lamda, alpha, ptr(VT), ptr(V), ptr(U), stream()), "erc_gcnii_chain_prep")
+
+
+def gcnii_chain_config(B, T, Mo, P):
+    out = (C.c_int * 3)()
+    _check(lib().erc_gcnii_chain_config(B, T, Mo, P, C.addressof(out), C.addressof(out) + 4, C.addressof(out) + 8),
+           "erc_gcnii_chain_config")
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def gcnii_chain_fwd(ADJ, P, CR, node_off, N, Mo, B, T, cfg, VT, Call, ldc, HD, hd_plane, ZS, lds, ZX, state, drop_p, rng,
+                    rng_stream0):
+    _check(lib().erc_gcnii_chain_fwd(ptr(ADJ), P, ptr(CR), ptr(node_off), N, Mo, B, T, cfg[0], cfg[1], cfg[2], ptr(VT), ptr(Call),
+                                     ldc, ptr(HD), hd_plane, ptr(ZS), lds, ptr(ZX), ptr(state), drop_p, ptr(rng), rng_stream0,
+                                     stream()), "erc_gcnii_chain_fwd")
+
+
+def gcnii_chain_bwd(ADJ, P, CR, node_off, N, Mo, B, T, cfg, V, HD, hd_plane, dHin, dHout, DG, DZ, lds, ZX, state, drop_p):
+    _check(lib().erc_gcnii_chain_bwd(ptr(ADJ), P, ptr(CR), ptr(node_off), N, Mo, B, T, cfg[0], cfg[1], cfg[2], ptr(V), ptr(HD),
+                                     hd_plane, ptr(dHin), ptr(dHout), ptr(DG), ptr(DZ), lds, ptr(ZX), ptr(state), drop_p,
+                                     stream()), "erc_gcnii_chain_bwd")
+
+
 def dag_rec_config(direction, B, T, n_layers, epc_hint=0, dg_hint=0, lpl_hint=0):
     """cfg = (epc, dg, groups per launch, layers per launch) of the weight-stationary DAG-ERC recurrence (0 forward,
     1 backward) on the current device, as a ctypes int array the launch wrappers take."""
@@ -432,6 +464,15 @@ def gemm_f32_planes(A, lda, a_plane, B, ldb, b_plane, Cm, ldc, M, N, K, planes, 
 
 def _call(name, *args):
     _check(getattr(lib(), name)(*[ptr(a) if torch.is_tensor(a) or a is None else a for a in args], stream()), name)
+
+
+def gcnii_chain_set_stamps(stamps):
+    _check(lib().erc_gcnii_chain_set_stamps(ptr(stamps)), "erc_gcnii_chain_set_stamps")
+
+
+def poison_lds():
+    """Test support: NaN bit patterns into the LDS of every CU (see include/ercgraft.h)."""
+    _check(lib().erc_test_poison_lds(None, stream()), "erc_test_poison_lds")
 
 
 def mm_meta(lengths, qmask, q_st, q_sb, S, B, node_off, node_row, node_dlg, node_spk):

@@ -103,7 +103,29 @@ __global__ __launch_bounds__(256) void window_graph_kernel(
     }
 }
 
+// test support: leave NaN bit patterns in the LDS of every CU, so that a kernel which reads LDS it did not write
+// (e.g. the masked tail rows of an MFMA operand: 0 * NaN = NaN) fails its parity test on every run, not on some boxes
+__global__ __launch_bounds__(256) void lds_poison_kernel(int words, int* sink) {
+    extern __shared__ int lds_words[];
+    for (int x = threadIdx.x; x < words; x += 256) lds_words[x] = -1;
+    __syncthreads();
+    if (sink && lds_words[(threadIdx.x * 97) % words] == 0) sink[0] = 1;    // keeps the stores alive
+}
+
 }  // namespace
+
+extern "C" int erc_test_poison_lds(int32_t* sink, void* stream) {
+    const int bytes = 160 * 1024;
+    static bool raised = false;
+    if (!raised) {
+        ERC_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        bytes) == hipSuccess, "test_poison_lds: LDS limit");
+        raised = true;
+    }
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), bytes, (hipStream_t)stream, bytes / 4, sink);
+    ERC_LAUNCH_CHECK("test_poison_lds");
+    return ERC_OK;
+}
 
 extern "C" int erc_window_graph_build(const int64_t* lengths, const int64_t* speakers, int64_t spk_sb, int64_t spk_st,
                                       int B, int T, int wp, int wf, int n_speakers, int n_cap, int e_cap,

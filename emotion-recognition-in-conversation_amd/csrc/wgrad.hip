@@ -34,7 +34,7 @@ constexpr int WG_IDX_CAP = 2048;   // k per split (row-gather stage in LDS)
 constexpr int WG_SLAB = 4096 + 64; // floats per partial tile: 64 x 64 + one bias strip
 constexpr int WG_MAX_DESC = 32;
 
-struct WgDesc {  // 96 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQQQQ14i")
+struct WgDesc {  // 104 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQQQQ14if4x")
     const float* A;
     const void* B;
     float* C;
@@ -42,6 +42,7 @@ struct WgDesc {  // 96 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQQ
     const int32_t* b_gather;  // row of B for every k, or null
     int lda, ldb, ldc, M, N, K;
     int ones, b_bf16, splits, tiles_n, item_base, n_items, tile_base, vec;  // vec: bit0 A, bit1 B, bit2 C 16-byte ok
+    float scale;              // the product is stored as scale * A^T B (GCNII: dW_l = theta_l dV_l); bias strips are not scaled
 };
 
 // Cross-workgroup hand-off of the partial tiles WITHOUT fences (an agent-scope release/acquire fence pair costs
@@ -186,7 +187,8 @@ __device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, flo
     float* const slab = slabs + (int64_t)(d.item_base + local) * WG_SLAB;
     const bool direct = d.splits == 1;
     const bool cvec = d.vec & 4;
-    auto store_c = [&](const int f4, const int h, const float4 v) {
+    auto store_c = [&](const int f4, const int h, const float4 v0) {
+        const float4 v = make_float4(v0.x * d.scale, v0.y * d.scale, v0.z * d.scale, v0.w * d.scale);
         const int ilq = f4 >> 6, ln = f4 & 63;
         const int i = 2 * h + (ilq >> 2), q = ilq & 3;
         const int m = m0 + 4 * (4 * (ln >> 4) + q) + i, n = n0 + 4 * (ln & 15);

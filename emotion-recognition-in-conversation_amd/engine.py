@@ -126,9 +126,9 @@ class GemmPlanner:
         self.max_numel = 0
         self.deferred = []     # (A, lda, B, ldb, C, ldc, M, N, K, ones, bias_out): one batched launch at the end
 
-    def defer(self, A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather=None):
-        """C[M,N] = A[K,M]^T B[gather(K),N] (+ bias strip); B may be the bf16 feature block."""
-        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather))
+    def defer(self, A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather=None, scale=1.0):
+        """C[M,N] = scale * A[K,M]^T B[gather(K),N] (+ bias strip); B may be the bf16 feature block."""
+        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather, float(scale)))
 
     WG_STEPS = 64   # k-steps (4 k each) per work item: 16 per wavefront (measured best of 48..128 on COGMEN B=32)
 
@@ -139,13 +139,13 @@ class GemmPlanner:
         if not self.deferred:
             return
         import struct
-        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, g.data_ptr() if g is not None else 0)
-                    for a, _, b, _, c, _, M, N, K, _, _, g in self.deferred)
+        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, g.data_ptr() if g is not None else 0, sc)
+                    for a, _, b, _, c, _, M, N, K, _, _, g, sc in self.deferred)
         if cache.get("wgrad_key") != key:
             cap = capi.wgrad_max_k_per_split()
             raw, items, tiles, bases = [], 0, 0, []
             steps = int(os.environ.get("ERC_WG_STEPS", self.WG_STEPS))
-            for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g in self.deferred:
+            for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g, sc in self.deferred:
                 bf16 = b.dtype == torch.bfloat16
                 if a.dtype != torch.float32 or c.dtype != torch.float32 or (not bf16 and b.dtype != torch.float32):
                     raise capi.ErcGraftError("wgrad table: operand dtypes %s %s %s" % (a.dtype, b.dtype, c.dtype))
@@ -161,10 +161,10 @@ class GemmPlanner:
                     | (2 if (N % 4 == 0 and ldb % 4 == 0 and b.data_ptr() % (8 if bf16 else 16) == 0) else 0) \
                     | (4 if (N % 4 == 0 and ldc % 4 == 0 and c.data_ptr() % 16 == 0) else 0)
                 n_it = tm * tn * splits
-                raw.append(struct.pack("<QQQQQ14i", a.data_ptr(), b.data_ptr(), c.data_ptr(),
+                raw.append(struct.pack("<QQQQQ14if4x", a.data_ptr(), b.data_ptr(), c.data_ptr(),
                                        bo.data_ptr() if bo is not None else 0, g.data_ptr() if g is not None else 0,
                                        lda, ldb, ldc, M, N, K, ones if bo is not None else 0, int(bf16), splits, tn,
-                                       items, n_it, tiles, vec))
+                                       items, n_it, tiles, vec, sc))
                 bases.append(items)
                 items += n_it
                 tiles += tm * tn
@@ -274,14 +274,14 @@ def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off
     return slab
 
 
-def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off, defer=False):
+def matmul_wgrad_io(pl, x, ldx, dy, lddy, n_in, n_out, n_rows, w_off, b_off, defer=False, scale=1.0):
     """dW[n_in,n_out] = x^T dy and db[n_out] = colsum(dy) for [in,out]-stored weights (PyG RGCNConv, GCNII)."""
     want_b = b_off is not None
     S = pl.split_for(n_in + 1, n_out, n_rows, min_chunks=2)
     if (S == 1 or defer) and pl.grad is not None:
         if defer:
             pl.defer(x, ldx, dy, lddy, pl.grad[w_off:], n_out, n_in, n_out, n_rows, 2 if want_b else 0,
-                     pl.grad[b_off:] if want_b else None)
+                     pl.grad[b_off:] if want_b else None, scale=scale)
         else:
             capi.gemm_f32(x, ldx, 1, None, dy, lddy, 1, None, pl.grad[w_off:], n_out, n_in, n_out, n_rows,
                           ones_col=2 if want_b else 0, bias_out=pl.grad[b_off:] if want_b else None)

@@ -151,6 +151,17 @@ class MMGCNModule(nn.Module):
                   emb_ws=f32(capi.mm_emb_grad_ws_floats(self.n_speakers)), dADJ=f32(B * Mo, P, P), dCR=f32(B, Mo * Mo, P),
                   Gb=f32(B * Mo, P, P), GC=f32(B, Mo * Mo, P), dXH=f32(R3, FD), dX=f32(R3, FD),
                   dLIN={m: f32(TB, FD) for m in self.order}, dLL=f32(TB, FD))
+        import os
+        ws["chain"] = os.environ.get("ERC_MM_CHAIN", "1") != "0" and T <= 128 and NLAYERS == 64 and FD == 200
+        if ws["chain"]:
+            # K8 (csrc/gcnii_chain.hip): the 64 layers in one persistent launch per direction
+            LDS = NLAYERS * FD
+            ws["chain_cfg"] = capi.gcnii_chain_config(B, T, Mo, P)
+            ws["VT"], ws["V"] = f32(NLAYERS + 1, FD, 208), f32(NLAYERS + 1, FD, 208)
+            ws["U"], ws["Call"] = f32(FD, LDS), f32(R3, LDS)
+            ws["ZS"], ws["DGl"], ws["DZl"] = f32(R3, LDS), f32(R3, LDS), f32(R3, LDS)
+            ws["ZX"], ws["DH1"] = f32(2, R3, FD), f32(R3, FD)
+            ws["chain_state"] = i32(1 + B + B * Mo * ws["chain_cfg"][0])
         dmax = max(self.dims[m] for m in self.order)
         slab = 4 * TB * 800 + 8 * (800 * FD + 2 * 400 * 100 * 2) + 8 * FD * dmax * 3 + NLAYERS * 2 * 8 * FD * FD + \
             8 * FD * FD + 8 * self.n_classes * Mo * 2 * FD + 8 * R3 * FD + (1 << 21)
@@ -205,19 +216,31 @@ class MMGCNModule(nn.Module):
         if p > 0:
             capi.dropout_fwd(X, n_el, p, rng, 1000, XD)
         gn = "graph_model.graph_net."
-        linear_fwd(pl, XD, FD, None, fp.w(gn + "fcs.0.weight"), fp.w(gn + "fcs.0.bias"), ws["H0"], FD, R3, FD, FD, act=1)
         HD, HI = ws["HD"], ws["HI"]
+        # h0 = relu(fc0 x); the chain's first plane is dropout(h0): without dropout the product writes it in place
+        H0 = ws["H0"] if p > 0 else HD[1]
+        linear_fwd(pl, XD, FD, None, fp.w(gn + "fcs.0.weight"), fp.w(gn + "fcs.0.bias"), H0, FD, R3, FD, FD, act=1)
         if p > 0:
-            capi.dropout_fwd(ws["H0"], n_el, p, rng, 1001, HD[1])
+            capi.dropout_fwd(H0, n_el, p, rng, 1001, HD[1])
+        ws["_H0"] = H0
+        if ws["chain"]:
+            # K8: V_l / U_l from the layer weights, c_l = h0 U_l for all 64 layers as ONE product, then the whole chain in one
+            # persistent launch (adjacency rows resident in LDS; csrc/gcnii_chain.hip)
+            Wn0 = gn + "convs.0.weight"
+            w_stride = fp.offsets[gn + "convs.1.weight"] - fp.offsets[Wn0]
+            LDS = NLAYERS * FD
+            capi.gcnii_chain_prep(fp.w(Wn0), w_stride, LAMDA, ALPHA, ws["VT"], ws["V"], ws["U"])
+            capi.gemm_f32(H0, FD, 0, None, ws["U"], LDS, 1, None, ws["Call"], LDS, R3, LDS, FD)
+            capi.gcnii_chain_fwd(ws["ADJ"], P, ws["CR"], ws["node_off"], N, Mo, B, T, ws["chain_cfg"], ws["VT"], ws["Call"], LDS,
+                                 HD, R3 * FD, ws["ZS"], LDS, ws["ZX"], ws["chain_state"], p, rng, 2000)
         else:
-            HD[1].copy_(ws["H0"])
-        # every layer's input rows are [hi_l | h0] (pitch 2 FD): h0 is copied next to the 64 hi slots once per step, so that
-        # [hi | h0] W is ONE product per layer, with the GCNII tail (residual mix, relu, dropout) in its epilogue
-        HI[1:, :, FD:] = ws["H0"]
-        for l in range(1, NLAYERS + 1):
-            W = fp.w(gn + "convs.%d.weight" % (l - 1))
-            capi.gemm_grouped(0, ws["ADJ"], P, HD[l], FD, HI[l], 2 * FD, FD, ws["node_off"], B, Mo, N, T, P, cross=ws["CR"])
-            capi.gcnii_layer_fwd(HI[l], 2 * FD, W, FD, self.theta(l), ALPHA, p, rng, 2000 + l, HD[l + 1], FD, R3, FD)
+            # every layer's input rows are [hi_l | h0] (pitch 2 FD): h0 is copied next to the 64 hi slots once per step, so that
+            # [hi | h0] W is ONE product per layer, with the GCNII tail (residual mix, relu, dropout) in its epilogue
+            HI[1:, :, FD:] = H0
+            for l in range(1, NLAYERS + 1):
+                W = fp.w(gn + "convs.%d.weight" % (l - 1))
+                capi.gemm_grouped(0, ws["ADJ"], P, HD[l], FD, HI[l], 2 * FD, FD, ws["node_off"], B, Mo, N, T, P, cross=ws["CR"])
+                capi.gcnii_layer_fwd(HI[l], 2 * FD, W, FD, self.theta(l), ALPHA, p, rng, 2000 + l, HD[l + 1], FD, R3, FD)
         capi.mm_regroup_fwd(XD, HD[NLAYERS + 1], Mo, N, p, rng, 3000, ws["FE"])
         linear_fwd(pl, ws["FE"], Mo * 2 * FD, None, fp.w("smax_fc.weight"), fp.w("smax_fc.bias"), ws["logits"], C, N, C,
                    Mo * 2 * FD)
@@ -236,26 +259,13 @@ class MMGCNModule(nn.Module):
         ws = self._forward_impl(feats, speaker_tensor, text_length, B, T, N, self.training)
         return ws["logits"], None
 
-    # --------------------------------------------------------------- training
-    def loss_and_grads(self, batch):
-        feats = self._feats(batch)
-        qmask, lens, ys = batch["speaker_tensor"], batch["text_length"], batch["label"]
-        B, T, N = self._shape(feats[self.order[0]], lens, ys)
-        ws = self._forward_impl(feats, qmask, lens, B, T, N, self.training)
-        fp, pl, off = self.flat, ws["planner"], self.flat.offsets
-        Mo, C, TB, P = len(self.order), self.n_classes, T * B, ws["P"]
+    def _legacy_chain_backward(self, ws, pl, DH, B, T, N, p, ks):
+        """Round-1 form of the chain's backward (ERC_MM_CHAIN=0): launches per layer."""
+        fp, off = self.flat, self.flat.offsets
+        Mo, P = len(self.order), ws["P"]
         R3, n_el = Mo * N, Mo * N * FD
-        p, XD = ws["_p"], ws["_XD"]
-        ks = 1.0 / (1.0 - p)
         HD, HI = ws["HD"], ws["HI"]
         gn = "graph_model.graph_net."
-        capi.cross_entropy(ws["logits"], C, C, N, None, ys, None, 1.0, ws["dlogits"], C, ws["stats"])
-        FW = Mo * 2 * FD
-        capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("smax_fc.weight"), FW, 1, None, ws["dFE"], FW, N, FW, C)
-        linear_wgrad(pl, ws["dlogits"], C, ws["FE"], FW, None, C, FW, N, off["smax_fc.weight"], off["smax_fc.bias"],
-                     defer=True)
-        DH = ws["DH"]
-        capi.mm_regroup_bwd(ws["dFE"], ws["FE"], Mo, N, ks, ws["dXD"], DH)
         # Per layer only what the NEXT layer's gradient needs stays on the dependency chain: dG_l, dhi_l = its residual
         # part + dG_l W_l[:FD]^T, and DH = A^T dhi_l.  Everything that only meets in a sum over the layers -- the
         # adjacency gradient sum_l dhi_l h_l^T, its cross-modal entries, the h0 gradient sum_l dG_l W_l[FD:]^T and the
@@ -284,10 +294,59 @@ class MMGCNModule(nn.Module):
         capi.gemm_f32_planes(ws["dG"][1], FD, plane, W_bot, FD, w_stride, ws["dH0s"], FD, R3, FD, FD, NLAYERS,
                              split_k=KSPLIT, c_slab=n_el)
         capi.slab_reduce(ws["dH0s"], KSPLIT + 1, n_el, None, FD, 0, dH0, n_el)
+        return DH, dH0
+
+    # --------------------------------------------------------------- training
+    def loss_and_grads(self, batch):
+        feats = self._feats(batch)
+        qmask, lens, ys = batch["speaker_tensor"], batch["text_length"], batch["label"]
+        B, T, N = self._shape(feats[self.order[0]], lens, ys)
+        ws = self._forward_impl(feats, qmask, lens, B, T, N, self.training)
+        fp, pl, off = self.flat, ws["planner"], self.flat.offsets
+        Mo, C, TB, P = len(self.order), self.n_classes, T * B, ws["P"]
+        R3, n_el = Mo * N, Mo * N * FD
+        p, XD = ws["_p"], ws["_XD"]
+        ks = 1.0 / (1.0 - p)
+        HD, HI = ws["HD"], ws["HI"]
+        gn = "graph_model.graph_net."
+        capi.cross_entropy(ws["logits"], C, C, N, None, ys, None, 1.0, ws["dlogits"], C, ws["stats"])
+        FW = Mo * 2 * FD
+        capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("smax_fc.weight"), FW, 1, None, ws["dFE"], FW, N, FW, C)
+        linear_wgrad(pl, ws["dlogits"], C, ws["FE"], FW, None, C, FW, N, off["smax_fc.weight"], off["smax_fc.bias"],
+                     defer=True)
+        DH = ws["DH"]
+        capi.mm_regroup_bwd(ws["dFE"], ws["FE"], Mo, N, ks, ws["dXD"], DH)
+        if ws["chain"]:
+            # K8 backward: one persistent launch leaves dg_l (= d out_l) and dz_l (= A dg_l) of every layer and the gradient wrt
+            # the chain's input; what only meets in sums over the layers follows as batched products
+            LDS = NLAYERS * FD
+            plane, n_adj = R3 * FD, B * Mo * P * P
+            dH0 = ws["dH0"]
+            ws["dCR"].zero_()
+            capi.gcnii_chain_bwd(ws["ADJ"], P, ws["CR"], ws["node_off"], N, Mo, B, T, ws["chain_cfg"], ws["V"], HD, plane, DH,
+                                 ws["DH1"], ws["DGl"], ws["DZl"], LDS, ws["ZX"], ws["chain_state"], p)
+            for l in range(1, NLAYERS + 1):
+                Wn = gn + "convs.%d.weight" % (l - 1)
+                th = self.theta(l)
+                # dW_l[:200] = theta_l h_l^T dz_l ; dW_l[200:] = theta_l h0^T dg_l  (V_l, U_l are theta_l W + multiples of I)
+                matmul_wgrad_io(pl, HD[l], FD, ws["DZl"][:, (l - 1) * FD:], LDS, FD, FD, R3, off[Wn], None, defer=True, scale=th)
+                matmul_wgrad_io(pl, ws["_H0"], FD, ws["DGl"][:, (l - 1) * FD:], LDS, FD, FD, R3, off[Wn] + FD * FD, None,
+                                defer=True, scale=th)
+            # dA = sum_l dg_l z_l^T on the block structure (and its cross-modal entries)
+            capi.gemm_grouped(1, ws["DGl"], LDS, ws["ZS"], LDS, ws["dADJs"], P, FD, ws["node_off"], B, Mo, N, T, P, planes=NLAYERS,
+                              a_plane=FD, b_plane=FD, split=KSPLIT, c_slab=n_adj)
+            capi.slab_reduce(ws["dADJs"], KSPLIT, n_adj, None, P, 0, ws["dADJ"], n_adj)
+            capi.mm_cross_grad(ws["DGl"], LDS, ws["ZS"], LDS, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"], planes=NLAYERS,
+                               d_plane=FD, h_plane=FD)
+            # dh0 = sum_l dg_l U_l^T = DG U^T: one product with K = 64 * 200
+            linear_fwd(pl, ws["DGl"], LDS, None, ws["U"], None, dH0, FD, R3, FD, LDS)
+            DH = ws["DH1"]
+        else:
+            DH, dH0 = self._legacy_chain_backward(ws, pl, DH, B, T, N, p, ks)
         # input layer: HD[1] = dropout(H0), H0 = relu(fc0(XD))
         capi.axpy_mask(DH, HD[1] if p > 0 else None, n_el, ks, 1, dH0)
         dG0 = ws["dG"][0]
-        capi.gcnii_combine_bwd(dH0, ws["H0"], n_el, 0.0, 0.0, 1.0, 1, dG0, None, None)
+        capi.gcnii_combine_bwd(dH0, ws["_H0"], n_el, 0.0, 0.0, 1.0, 1, dG0, None, None)
         capi.gemm_f32(dG0, FD, 0, None, fp.w(gn + "fcs.0.weight"), FD, 1, None, ws["dXD"], FD, R3, FD, FD, accumulate=1)
         linear_wgrad(pl, dG0, FD, XD, FD, None, FD, FD, R3, off[gn + "fcs.0.weight"], off[gn + "fcs.0.bias"], defer=True)
         dX = ws["dX"]

@@ -365,6 +365,36 @@ int erc_clock_probe(uint64_t* out, int iters, void* stream);
 int erc_grad_norm(const float* g, int64_t n, float grad_scale, float* gnorm, float* ws, void* stream);
 
 /* ------------------------------------------------------------------------
+ * K8  MMGCN's 64-layer GCNII chain (mmgcn_models.py:373-394, GraphConvolution.forward :27-39; nlayers 64, nhidden 200,
+ * lamda 0.5, alpha 0.1, variant) as one persistent launch per direction (csrc/gcnii_chain.hip).
+ *   out_l = theta_l [A h_l | h0] W_l + (1 - theta_l)((1 - alpha) A h_l + alpha h0) is re-associated to A (h_l V_l) + h0 U_l with
+ *   V_l = theta_l W_l[:200] + (1 - theta_l)(1 - alpha) I, U_l = theta_l W_l[200:] + (1 - theta_l) alpha I, theta_l = ln(lamda / l + 1).
+ *   erc_gcnii_chain_prep: W = convs.0.weight, layer l at W + l * w_stride ([400,200] each) -> VT [65][200][208] (row n,
+ *     contiguous k; zero-filled once by the caller, the last plane is padding), V [65][200][208] (row k, contiguous n),
+ *     U [200][64*200] (layer l at column l * 200).  The caller computes Call = H0 U ([Mo*N][64*200]) with one GEMM.
+ *   erc_gcnii_chain_config: parts per (dialogue, modality) block, rows per workgroup (<= 32) and dialogues per launch so that
+ *     every workgroup of a dialogue is resident (occupancy query); T <= 128.
+ *   erc_gcnii_chain_fwd: HD planes [66][Mo*N][200] (plane stride hd_plane): plane 1 = dropout(relu(fc0 x)) on entry, planes
+ *     2..65 written (plane l+1 = dropout(relu(out_l)), dropout stream rng_stream0 + l as erc_gcnii_layer_fwd); ZS [Mo*N][lds]
+ *     receives z_l = h_l V_l at column (l-1)*200.  ADJ / CR / node_off as erc_gemm_f32_grouped.
+ *   erc_gcnii_chain_bwd: dHin = gradient wrt plane 65, dHout = gradient wrt plane 1; saves dg_l = d out_l -> DG and
+ *     dz_l = A dg_l -> DZ (same layout as ZS).  Left to the caller (they only meet in sums over the layers):
+ *     dW_l[:200] = theta_l HD_l^T dz_l, dW_l[200:] = theta_l H0^T dg_l, dH0 = DG U^T, dADJ = sum_l dg_l z_l^T (blocks, cross).
+ *   ZX: exchange buffer [2][Mo*N][200]; state: int32 [1 + B + B*Mo*parts], zero-filled once ([0] error flag, epochs, flags). */
+int erc_gcnii_chain_prep(const float* W, int64_t w_stride, float lamda, float alpha, float* VT, float* V, float* U, void* stream);
+int erc_gcnii_chain_config(int B, int T, int Mo, int P, int* parts, int* rows, int* dialogues_per_launch);
+int erc_gcnii_chain_fwd(const float* ADJ, int P, const float* CR, const int32_t* node_off, int N, int Mo, int B, int T,
+                        int parts, int rows, int dialogues_per_launch, const float* VT, const float* Call, int ldc,
+                        float* HD, int64_t hd_plane, float* ZS, int lds, float* ZX, int32_t* state, float drop_p,
+                        const uint64_t* rng_state, uint64_t rng_stream0, void* stream);
+int erc_gcnii_chain_bwd(const float* ADJ, int P, const float* CR, const int32_t* node_off, int N, int Mo, int B, int T,
+                        int parts, int rows, int dialogues_per_launch, const float* V, const float* HD, int64_t hd_plane,
+                        const float* dHin, float* dHout, float* DG, float* DZ, int lds, float* ZX, int32_t* state,
+                        float drop_p, void* stream);
+/* diagnostic: phase stamps (s_memtime) of workgroup 0 of the following launches, [64][16] uint64; NULL switches them off */
+int erc_gcnii_chain_set_stamps(uint64_t* stamps);
+
+/* ------------------------------------------------------------------------
  * K6  DAG-ERC (track_mm/dagerc.py:109-189, track_mm/dagerc_models.py:312-365).
  *
  * erc_dag_meta: speaker ids (argmax of the one-hot speaker tensor, or integer
@@ -578,6 +608,11 @@ int erc_mm_regroup_bwd(const float* dFE, const float* FE, int M, int N, float ke
                        void* stream);
 /* y (+)= scale * x, optionally masked by mask != 0 */
 int erc_axpy_mask(const float* x, const float* mask, int64_t n, float scale, int accumulate, float* y, void* stream);
+
+
+/* Test support (not part of the data path): fills the LDS of every CU with NaN bit patterns, so that a persistent
+ * kernel that reads LDS it did not initialise fails its parity test deterministically.  sink: one int32, may be NULL. */
+int erc_test_poison_lds(int32_t* sink, void* stream);
 
 #ifdef __cplusplus
 }

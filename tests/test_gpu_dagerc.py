@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.util_cases import check_grad_digest, fill_params, make_batch, rel_err, to_device
+from tests.util_cases import poison_lds_before, check_grad_digest, fill_params, make_batch, rel_err, to_device
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -58,7 +58,7 @@ def test_dagerc_matches_reference_golden(golden, name):
 
 @pytest.mark.parametrize("B,lens,dims,S,C", [(16, (20, 110), dict(a=100, t=100, v=512), 2, 6),
                                              (5, (1, 40), dict(a=30, t=60, v=34), 9, 7)])
-def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C):
+def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C, monkeypatch):
     """BASELINE config-4 shape (B=16, T=110, D=712) and a multi-speaker ragged case vs the (reference-pinned) oracle."""
     from oracle.dagerc import DAGERCOracle, dagerc_loss
     from erc_amd.dagerc import DAGERCModule
@@ -75,6 +75,7 @@ def test_dagerc_parity_vs_oracle_large(B, lens, dims, S, C):
     loss, _ = dagerc_loss(ref, batch)
     loss.backward()
     want, _ = ref(**batch)
+    poison_lds_before(monkeypatch, "dag_rec_fwd", "dag_rec_bwd")       # uninitialised LDS shows up as NaN, on every box
     stats = mine.loss_and_grads(to_device(batch, DEV)).cpu()
     T = batch["input_tensor"].shape[1]
     got = mine._last_ws["logits"].view(B, T, -1).cpu()

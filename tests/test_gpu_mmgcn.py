@@ -5,7 +5,7 @@ import pytest
 import torch
 from torch.nn import functional as F
 
-from tests.util_cases import check_grad_digest, fill_params, make_batch, rel_err, to_device
+from tests.util_cases import poison_lds_before, check_grad_digest, fill_params, make_batch, rel_err, to_device
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -58,7 +58,7 @@ def test_mmgcn_matches_reference_golden(golden, name):
 
 @pytest.mark.parametrize("B,lens,dims,S,C,mods", [(16, (20, 110), dict(a=100, t=768, v=512), 2, 6, "atv"),
                                                   (5, (1, 30), dict(a=30, t=60, v=34), 9, 7, "at")])
-def test_mmgcn_parity_vs_oracle_large(B, lens, dims, S, C, mods):
+def test_mmgcn_parity_vs_oracle_large(B, lens, dims, S, C, mods, monkeypatch):
     """BASELINE config-3 shape (iemocap-cogmen-sbert-6 atv, B=16, T=110) and a ragged two-modality MELD-like case."""
     from oracle.mmgcn import MMGCNOracle
     from erc_amd.mmgcn import MMGCNModule
@@ -76,6 +76,7 @@ def test_mmgcn_parity_vs_oracle_large(B, lens, dims, S, C, mods):
     logits, _ = ref(**batch)
     loss = F.cross_entropy(logits, batch["label"])
     loss.backward()
+    poison_lds_before(monkeypatch, "gcnii_chain_fwd", "gcnii_chain_bwd")       # uninitialised LDS shows up as NaN, on every box
     stats = mine.loss_and_grads(to_device(batch, DEV)).cpu()
     T = batch["speaker_tensor"].shape[0]
     got = mine._last_ws["logits"].cpu()

@@ -139,3 +139,17 @@ def check_grad_digest(fix, named_grads, tol, seed=0, keep=512):
         worst = max(worst, e)
     assert seen > 0
     return worst
+
+
+def poison_lds_before(monkeypatch, *entry_points):
+    """Wrap capi entry points so that every CU's LDS holds NaN bit patterns when their kernel starts: a persistent kernel
+    that reads LDS it never wrote (masked operand tails, pad rows) then fails its parity test on every box."""
+    from erc_amd import capi
+
+    def wrap(fn):
+        def inner(*a, **k):
+            capi.poison_lds()
+            return fn(*a, **k)
+        return inner
+    for name in entry_points:
+        monkeypatch.setattr(capi, name, wrap(getattr(capi, name)))
