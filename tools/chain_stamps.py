@@ -29,11 +29,11 @@ def main():
     tr.train_step(batch)
     rec = capi.stop_recording()
     torch.cuda.synchronize()
-    print("config (parts, rows, dialogues per launch):", tr.model._last_ws["chain_cfg"])
-    names = {"erc_gcnii_chain_fwd": {1: "row-local product h V", 2: "z -> LDS", 3: "publish + drain", 4: "flag + wait", 5: "gather + cross",
-                                     6: "block product A z", 7: "epilogue", 8: "plane store issued"},
-             "erc_gcnii_chain_bwd": {2: "dg = dh . mask -> LDS", 3: "publish + drain", 4: "flag + wait", 5: "gather + cross",
-                                     6: "block product A dg", 7: "dz -> LDS, saved", 8: "row-local product dz V^T"}}
+    print("config (flag pitch, grid cap, dialogues per launch):", tr.model._last_ws["chain_cfg"])
+    names = {"erc_gcnii_chain_fwd": {1: "row-local product h V", 2: "z -> exchange, LDS, save", 3: "drain", 4: "flag + wait",
+                                     5: "gather + cross", 6: "block product A z (+ V_l+1 requests)", 7: "epilogue"},
+             "erc_gcnii_chain_bwd": {2: "dg = dh . mask -> exchange", 3: "drain", 4: "flag + wait", 5: "gather + cross",
+                                     6: "block product A dg (+ V_l requests)", 7: "dz -> LDS", 8: "dz saved, row-local dz V^T"}}
     for entry in names:
         call = [e for e in rec if e[0] == entry][0]
         st = torch.zeros(64, 16, dtype=torch.int64, device="cuda:0")
@@ -51,12 +51,15 @@ def main():
         us_per_tick = ms * 1e3 / 64 / ticks_per_layer           # calibrated on the launch itself
         print("== %s: %.3f ms, %.2f us / layer (workgroup 0: dialogue 0, modality 0, part 0)" % (entry, ms, ms * 1e3 / 64))
         prev = 0
+        sub = {9: "   gather requests issued", 10: "   gathered rows in LDS"}
+        for k in (9, 10):
+            print("   %-36s +%5.2f us after the wait" % (sub[k], float((s[layers, k] - s[layers, 4]).mean()) * us_per_tick))
         for k in sorted(names[entry]):
             d = float((s[layers, k] - s[layers, prev]).mean()) * us_per_tick
-            print("   %-28s %6.2f us" % (names[entry][k], d))
+            print("   %-40s %6.2f us" % (names[entry][k], d))
             prev = k
         nxt = float((s[[l + 1 for l in layers], 0] - s[layers, prev]).mean()) * us_per_tick
-        print("   %-28s %6.2f us" % ("to the next layer's start", nxt))
+        print("   %-40s %6.2f us" % ("to the next layer's start", nxt))
 
 
 if __name__ == "__main__":
