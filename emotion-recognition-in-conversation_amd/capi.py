@@ -68,6 +68,14 @@ _SIGS = {
     "erc_head_ce": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _i64, _i64,
                                 _vp, _vp]),
+    "erc_adam_step_tab": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "erc_shadow_refresh": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "erc_cogmen_fwd_tile_ws_doubles": (C.c_int64, [_i]),
+    "erc_cogmen_set_stamps": (C.c_int, [_vp]),
+    "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
+                                      _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+    "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
     "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
@@ -311,6 +319,83 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_no
     _check(lib().erc_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale,
                                clip_norm, ptr(gnorm), ptr(state), ptr(shadow), shadow_off, shadow_n, ptr(skip_flag),
                                stream()), "erc_adam_step")
+
+
+class ShadowTable:
+    """Host mirror of ErcShadowTab (ercgraft.h): bf16 shadow ranges of the flat parameter buffer, all inside ONE bf16
+    buffer.  ``add`` returns the view of the new range's destination block."""
+
+    MAX = 8
+
+    def __init__(self, device):
+        self.device = device
+        self.descs = []          # (src_off, n_el, dst_off, n0, n1, s0, s1, s2)
+        self.sizes = []
+        self.numel = 0
+        self.buf = None
+        self._packed = None
+
+    def add(self, src_off, n_el, dst_numel, n0, n1, s0, s1, s2):
+        if self.buf is not None or len(self.descs) == self.MAX:
+            raise ErcGraftError("shadow table is sealed or full")
+        dst_off = (self.numel + 63) // 64 * 64       # 128-byte aligned blocks
+        self.descs.append((src_off, n_el, dst_off, n0, n1, s0, s1, s2))
+        self.sizes.append(dst_numel)
+        self.numel = dst_off + dst_numel
+        return len(self.descs) - 1
+
+    def seal(self):
+        import struct
+        self.buf = torch.zeros(self.numel + 64, dtype=torch.bfloat16, device=self.device)
+        raw = struct.pack("<ii", len(self.descs), 0)
+        for d in self.descs:
+            raw += struct.pack("<qqq6i", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], 0)
+        raw += b"\0" * (8 + 48 * self.MAX - len(raw))
+        self._packed = C.create_string_buffer(raw, len(raw))
+        return self
+
+    def view(self, i):
+        off = self.descs[i][2]
+        return self.buf[off:off + self.sizes[i]]
+
+    @property
+    def tab_ptr(self):
+        return C.addressof(self._packed)
+
+
+def adam_step_tab(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_norm, gnorm, state, table, skip_flag=None):
+    _check(lib().erc_adam_step_tab(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale,
+                                   clip_norm, ptr(gnorm), ptr(state), ptr(table.buf), table.tab_ptr, ptr(skip_flag),
+                                   stream()), "erc_adam_step_tab")
+
+
+def shadow_refresh(p, n, table):
+    _check(lib().erc_shadow_refresh(ptr(p), n, ptr(table.buf), table.tab_ptr, stream()), "erc_shadow_refresh")
+
+
+def cogmen_set_stamps(t):
+    _check(lib().erc_cogmen_set_stamps(ptr(t)), "erc_cogmen_set_stamps")
+
+
+def cogmen_fwd_tile_ws_doubles(n):
+    return int(lib().erc_cogmen_fwd_tile_ws_doubles(n))
+
+
+def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, inv_cnt, H1b, ldh1b, QKVS, H2, ldh2, alpha,
+                    bn_fused=False, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, saved=None, bn_ws=None):
+    _check(lib().erc_cogmen_fwd_tile(ptr(H0), ldh0, N, wp, wf, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
+                                     ptr(WcatT), ptr(b1), ptr(Wq), ptr(bq), scale, ptr(Mb), ldmb, ptr(inv_cnt), ptr(H1b),
+                                     ldh1b, ptr(QKVS), ptr(H2), ldh2, ptr(alpha), int(bn_fused), ptr(running_mean),
+                                     ptr(running_var), momentum, eps, ptr(saved), ptr(bn_ws), stream()),
+           "erc_cogmen_fwd_tile")
+
+
+def cogmen_bwd_tile(dY, H2, ldh2, N, wp, wf, gamma, saved, bn_bwd, QKVS, alpha, g, inv_cnt, WqT, Wb, scale, dQKVS, dH1,
+                    dH0, lddh0):
+    _check(lib().erc_cogmen_bwd_tile(ptr(dY), ptr(H2), ldh2, N, wp, wf, ptr(gamma), ptr(saved), ptr(bn_bwd), ptr(QKVS),
+                                     ptr(alpha), ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["out_ptr"]), ptr(g["out_dst"]),
+                                     ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(inv_cnt), ptr(WqT), ptr(Wb), scale,
+                                     ptr(dQKVS), ptr(dH1), ptr(dH0), lddh0, stream()), "erc_cogmen_bwd_tile")
 
 
 def grad_norm(g, n, grad_scale, gnorm, ws):

@@ -90,7 +90,9 @@ def load(trainer, path, with_optimizer=True, strict=True):
                 if tuple(own[k].shape) != tuple(v.shape):
                     raise ValueError("%s: checkpoint shape %s, module %s" % (k, tuple(v.shape), tuple(own[k].shape)))
                 own[k].copy_(v.to(own[k].device, own[k].dtype))
-    if getattr(model, "w1_shadow", None) is not None:             # bf16 copy of the input projection weight
+    if getattr(model, "shadows", None) is not None:               # bf16 copies of the weights follow the loaded masters
+        model.refresh_shadows()
+    elif getattr(model, "w1_shadow", None) is not None:
         model.w1_shadow.copy_(model.flat.w("rnn.1.weight").to(torch.bfloat16).view_as(model.w1_shadow))
     opt = ckpt.get("optims", {}).get("optim") if isinstance(ckpt, dict) else None
     if with_optimizer and opt is not None:

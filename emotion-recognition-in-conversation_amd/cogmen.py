@@ -90,6 +90,7 @@ class COGMENModule(nn.Module):
         self.gcn = _GNNParams(hidden_size, hidden_size, hidden_size)
         self.cls = nn.Sequential(nn.Linear(100, 100), nn.ReLU(), nn.Dropout(p=0.5), nn.Linear(100, n_classes))
         self.drop_p = 0.5
+        self.use_fused_graph = False   # set by finalize() in bf16 mode
         self.fuse_head = True   # training path: csrc/head.hip instead of separate BN / Linear / CE launches
         self.flat = None
         self._ws = WorkspaceCache()
@@ -122,16 +123,48 @@ class COGMENModule(nn.Module):
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
         self.side = SideStream()
         self.w1_shadow = None     # bf16 copy of rnn.1.weight, valid only while an optimizer keeps it in sync
+        self.shadows = None       # bf16 mode: every bf16 weight copy (capi.ShadowTable)
+        self._shadow_auto = True  # nobody maintains the shadows: rebuild them at every forward
         if self.chained_encoder:
             from .encoder import EncoderTrain
             self.enc_train = EncoderTrain(self.rnn[0], self.flat, device, drop_p=0.5)
+        elif self.compute == "bf16":
+            self._build_shadows()
         return self
 
+    @property
+    def fused_graph(self):
+        """bf16 mode: the graph part runs as the two row-tile kernels of csrc/cogmen_fused.hip (bf16 matrix cores)."""
+        return self.shadows is not None and self.use_fused_graph
+
+    def _build_shadows(self):
+        """bf16 copies of the weights in the layouts the bf16 products read them (ercgraft.h, ErcShadowTab): the input
+        projection's W1 as is, and the four packed / transposed copies of the fused graph kernels."""
+        fp, D, F = self.flat, self.input_size, F_HID
+        t = capi.ShadowTable(fp.device)
+        off_cat, off_q = fp.offsets["gcn.conv1.weight"], fp.offsets["gcn.conv2.lin_query.weight"]
+        assert fp.offsets["gcn.conv1.root"] == off_cat + N_REL * F * F
+        assert fp.offsets["gcn.conv2.lin_skip.weight"] == off_q + 3 * F * F
+        i_w1 = t.add(fp.offsets["rnn.1.weight"], F * D, F * D, F * D, 1, 1, 0, 0)
+        i_catT = t.add(off_cat, 9 * F * F, 112 * 928, F, 9 * F, 928, 1, 0)     # WcatT[o][r*100+c]
+        i_wb = t.add(off_cat, 9 * F * F, 112 * 960, F, F, 1, 960, 104)         # Wb[c][r*104+o]
+        i_q = t.add(off_q, 4 * F * F, 400 * 128, F, 4 * F, 1, 128, 0)          # Wq[n][k]
+        i_qT = t.add(off_q, 4 * F * F, 112 * 416, F, 4 * F, 416, 1, 0)         # WqT[k][n]
+        t.seal()
+        self.shadows = t
+        self._sh = dict(w1=t.view(i_w1).view(F, D), catT=t.view(i_catT), wb=t.view(i_wb), q=t.view(i_q), qT=t.view(i_qT))
+        self.use_fused_graph = True
+
+    def refresh_shadows(self):
+        if self.shadows is not None:
+            capi.shadow_refresh(self.flat.data, self.flat.numel, self.shadows)
+
     def attach_bf16_shadow(self, optim):
-        """bf16 mode: let the fused optimizer maintain a bf16 copy of rnn.1.weight for the input projection."""
-        w = self.flat.w("rnn.1.weight")
-        self.w1_shadow = w.to(torch.bfloat16).contiguous()
-        optim.shadow = (self.w1_shadow, self.flat.offsets["rnn.1.weight"], w.numel())
+        """bf16 mode: let the fused optimizer maintain the bf16 weight copies (input projection, fused graph kernels)."""
+        self.refresh_shadows()
+        self.w1_shadow = self._sh["w1"]
+        self._shadow_auto = False
+        optim.shadow_table = self.shadows
 
     @property
     def _last_ws(self):
@@ -139,13 +172,15 @@ class COGMENModule(nn.Module):
         return self._ws.last
 
     def _workspace(self, B, T, N, device):
-        return self._ws.get((B, T, N), lambda: self._make_workspace(B, T, N, device))
+        return self._ws.get((B, T, N, self.fused_graph), lambda: self._make_workspace(B, T, N, device))
 
     def _make_workspace(self, B, T, N, device):
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
         E = N * (WP + WF + 1)
         C, F, D = self.n_classes, F_HID, self.input_size
+        if self.fused_graph:
+            return self._make_workspace_fused(B, T, N, device, E)
         g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E),
                  in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
         ws = dict(
@@ -163,6 +198,31 @@ class COGMENModule(nn.Module):
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
         return ws
+
+    def _make_workspace_fused(self, B, T, N, device, E):
+        """bf16 mode: M / H1 only exist as bf16 weight-gradient operands, no dM / dscore buffers."""
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=device)
+        bf = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=device)
+        C, F, D = self.n_classes, F_HID, self.input_size
+        g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E),
+                 in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
+        ws = dict(
+            g=g, E=E, fused=True,
+            H0=f32(N, F), Mb=bf(N, 904), inv_cnt=f32(N, N_REL), H1b=bf(N, 104), QKVS=f32(N, 4 * F),
+            alpha=f32(E), H2=f32(N, F), H3=f32(N, F), Z=f32(N, F), logits=f32(N, C),
+            bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=torch.zeros(1024, dtype=torch.float32, device=device),
+            bn_stats_ws=torch.zeros(capi.bn_batch_stats_ws_floats(F), dtype=torch.float32, device=device),
+            bn_tile_ws=torch.zeros(capi.cogmen_fwd_tile_ws_doubles(N), dtype=torch.float64, device=device),
+            head_ws=torch.zeros(capi.head_fused_ws_floats(N), dtype=torch.float32, device=device), bn_bwd=f32(2 * F),
+            dlogits=f32(N, C), dZ=f32(N, F), dH3=f32(N, F), dQKVS=f32(N, 4 * F), dH1=f32(N, F), dH0=f32(N, F),
+        )
+        slab = 16 * N * F + 8 * (F * D + 9 * F * F + 4 * F * F + 2 * F * F) + (1 << 20)
+        ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
+        ws["jobs"] = None
+        return ws
+
+    BN_FUSED_MAX_N = 8192   # above: the tile partials are too many for one last arriver, BatchNorm statistics get their own launch
 
     # ---------------------------------------------------------------- forward
     def _shape(self, input_tensor, text_length, label, n_nodes=None):
@@ -188,8 +248,22 @@ class COGMENModule(nn.Module):
             x = self.enc_train.forward(x, text_length, training, self.rng_state)
             x_bf16 = True
             ws["x_enc"] = x
+        if self.shadows is not None and self._shadow_auto:
+            self.refresh_shadows()
         W1 = self.w1_shadow if (x_bf16 and self.w1_shadow is not None) else fp.w("rnn.1.weight")
         linear_fwd(pl, x, D, g["node_row"], W1, fp.w("rnn.1.bias"), ws["H0"], F, N, F, D, x_bf16=x_bf16)
+        if ws.get("fused"):
+            bn = self.gcn.bn
+            # training with the fused head: BatchNorm's batch statistics come out of the same launch
+            ws["bn_in_tile"] = bool(upto_h2 and N <= self.BN_FUSED_MAX_N)
+            capi.cogmen_fwd_tile(ws["H0"], F, N, WP, WF, g, self._sh["catT"], fp.w("gcn.conv1.bias"), self._sh["q"],
+                                 fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], 904, ws["inv_cnt"],
+                                 ws["H1b"], 104, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=ws["bn_in_tile"],
+                                 running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum,
+                                 eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"])
+            if upto_h2:
+                return ws
+            return self._forward_tail(ws, N, training)
         capi.rgcn_mean_fwd(ws["H0"], F, F, N_REL, N, g, ws["M"], 9 * F, ws["inv_cnt"])
         # H1 = M @ [W_r ; W_root] + bias : B operand is the [9F, F] k-major stack conv1.weight|conv1.root
         Wcat = fp.w("gcn.conv1.weight")
@@ -207,6 +281,11 @@ class COGMENModule(nn.Module):
         capi.tconv_attn_fwd(ws["QKVS"], 4 * F, F, N, 1.0 / math.sqrt(F), g, ws["H2"], F, ws["alpha"])
         if upto_h2:      # the training path runs everything behind H2 in the fused head kernel
             return ws
+        return self._forward_tail(ws, N, training)
+
+    def _forward_tail(self, ws, N, training):
+        fp, pl = self.flat, ws["planner"]
+        F, C = F_HID, self.n_classes
         bn = self.gcn.bn
         capi.bn_lrelu_fwd(ws["H2"], F, N, F, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), bn.running_mean,
                           bn.running_var, bn.momentum, bn.eps, 0.01, training, ws["bn_saved"], ws["H3"], F,
@@ -239,9 +318,13 @@ class COGMENModule(nn.Module):
         x_bf16 = x.dtype == torch.bfloat16
         p = self.drop_p if training else 0.0
         bn = self.gcn.bn
+        fused = bool(ws.get("fused"))
+        if fused and not fused_head:
+            raise capi.ErcGraftError("COGMEN bf16 mode trains through the fused head (C <= 8)")
         if fused_head:
-            capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
-                                ws["bn_stats_ws"])
+            if not (fused and ws["bn_in_tile"]):
+                capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
+                                    ws["bn_stats_ws"])
             capi.head_fused(ws["H2"], F, N, F, C, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
                             fp.w("cls.0.weight"), fp.w("cls.0.bias"), fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys,
                             class_weight, p, self.rng_state if p > 0 else None, ws["H3"], ws["Z"], ws["logits"],
@@ -257,6 +340,9 @@ class COGMENModule(nn.Module):
         with self.side.fork():
             linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
                          fp.offsets["cls.0.bias"], defer=True)
+        if fused:
+            self._backward_fused(ws, x, x_bf16, N)
+            return ws["stats"]
         bn_prologue = None
         if fused_head:   # BatchNorm's elementwise backward runs inside the attention backward (one launch less)
             bn_prologue = (ws["H2"], F, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["dH2"])
@@ -296,6 +382,21 @@ class COGMENModule(nn.Module):
             capi.enc_inverse_rows(g["node_row"], N, ews["inv"], B * T)
             self.enc_train.backward(ews["dXn"], ews["inv"])
         return ws["stats"]
+
+    def _backward_fused(self, ws, x, x_bf16, N):
+        """bf16 mode: BatchNorm backward .. dH0 in one launch (csrc/cogmen_fused.hip), then the batched weight gradients."""
+        fp, g, pl = self.flat, ws["g"], ws["planner"]
+        F, D = F_HID, self.input_size
+        capi.cogmen_bwd_tile(ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"],
+                             ws["QKVS"], ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F),
+                             ws["dQKVS"], ws["dH1"], ws["dH0"], F)
+        linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1b"], 104, None, 4 * F, F, N,
+                     fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"], defer=True)
+        matmul_wgrad_io(pl, ws["Mb"], 904, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
+                        fp.offsets["gcn.conv1.bias"], defer=True)
+        linear_wgrad(pl, ws["dH0"], F, x, D, g["node_row"], F, D, N, fp.offsets["rnn.1.weight"],
+                     fp.offsets["rnn.1.bias"], x_bf16=x_bf16, defer=True)
+        pl.reduce_into(ws, fp.grad)
 
     def sync_buffers(self, optimizer_steps):
         """BatchNorm1d.num_batches_tracked is bookkeeping only (momentum is fixed): it is set from the optimizer's

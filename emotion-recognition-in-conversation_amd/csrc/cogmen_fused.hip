@@ -1,0 +1,938 @@
+// COGMEN graph part as row-tile kernels (bf16 compute mode): everything between the input projection and the BatchNorm
+// of track_mm/cogmen.py:61-74 (GNN.forward: RGCNConv -> TransformerConv) in ONE launch, and its backward in one more.
+//
+// The dialogue graph is a window graph (cogmen.py:153-154, wp = wf = 5): node i only sees rows [i-5, i+5] of its own
+// dialogue, so a tile of 16 consecutive nodes needs a HALO, not a global exchange.  A workgroup computes
+//   forward  : M = [mean_r H0 | H0] for rows [r0-5, r0+21)  -> H1 = M Wcat + b (those 26 rows) -> QKVS = H1 Wqkvs^T + b
+//              (26 rows) -> segmented-softmax attention + skip for its 16 rows -> H2, plus the BatchNorm column sums
+//              (partials per tile, finalised by the last workgroup to arrive)
+//   backward : dH2 = BatchNorm backward for rows [r0-10, r0+26) -> attention backward, target side (those 36 rows),
+//              source side (rows [r0-5, r0+21)) -> dH1 = dQKVS Wqkvs (26 rows) -> dP = A^T dH1 (16 rows, the transposed
+//              relation means) -> dH0 = dP [W_r^T] (16 rows)
+// with the intermediate tiles in LDS.  The halo rows are recomputed by the neighbouring tile (1.6x .. 2.3x of the small
+// products) -- that is what buys 5 + 5 launches less and no HBM / L2 round trip for M, H1 (fp32), dM.
+//
+// The dense products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: A fragments from the LDS tile
+// (ds_read_b128, rows 16-byte aligned), B fragments straight from bf16 shadow copies of the weights that the optimizer
+// launch keeps in sync (erc_adam_step_tab) in the [n][k] layouts the fragments want:
+//   WcatT [112][928]  WcatT[o][r*100+c] = W_r[c][o]  (r = 8: root)       H1 = M Wcat
+//   Wq    [400][128]  the [q;k;v;skip] Linear weights, K padded           QKVS = H1 Wq^T
+//   WqT   [112][416]  WqT[c][n] = Wq[n][c]                                dH1 = dQKVS Wq
+//   Wb    [112][960]  Wb[c][r*104+o] = W_r[c][o]                          dH0 = dP [W_r^T]
+// Everything else (means, softmax, BatchNorm) is fp32.  The graph is read through the CSR that erc_window_graph_build
+// wrote; the kernels only rely on |source - target| <= 5 (checked by the host wrapper through wp / wf).
+#include "erc_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CG_F = 100;                    // channels (the reference hard-codes 100: cogmen.py:116-122)
+constexpr int CG_R = 8;                      // relations (GNN(n_speakers = 2): cogmen.py:62-64)
+constexpr int CG_HL = 5;                     // halo = max(wp, wf)
+constexpr int CG_TR = 16;                    // rows a tile owns
+constexpr int CG_MID = CG_TR + 2 * CG_HL;    // 26
+constexpr int CG_OUT = CG_TR + 4 * CG_HL;    // 36
+constexpr int CG_FAR = CG_TR + 6 * CG_HL;    // 46
+constexpr int CG_KM = (CG_R + 1) * CG_F;     // 900
+constexpr int CG_KMP = 928;                  // K of the H1 product, padded to 29 blocks of 32
+constexpr int CG_SM = 936;                   // LDS pitch of the M tile (bf16 elements; 1872 B = 117 x 16)
+constexpr int CG_SH1 = 136;                  // LDS pitch of the H1 tile (bf16; K padded to 128)
+constexpr int CG_SQ = 404;                   // LDS pitch of the QKVS tile (floats)
+constexpr int CG_CH = 12;                    // neighbour rows handled per batch (window graph: <= 11 in-edges)
+constexpr int CG_NT = 7;                     // column tiles of 16 covering F = 100
+
+constexpr int CG_NW = 16;                    // wavefronts per workgroup (1024 threads: <= 128 VGPRs)
+constexpr int CG_NTH = 64 * CG_NW;
+
+// LDS map of the forward kernel (bytes)
+constexpr int FW_SM_OFF = 0;                                   // M tile, 27 rows (26 + one zero row); later the QKVS tile (26 x 404 floats)
+constexpr int FW_SM_BYTES = 27 * CG_SM * 2;                    // 50544  (26 * 404 * 4 = 42016 fits)
+constexpr int FW_SH1_OFF = FW_SM_OFF + FW_SM_BYTES;
+constexpr int FW_SH1_BYTES = 32 * CG_SH1 * 2;                  // 8704
+constexpr int FW_SH0_OFF = FW_SH1_OFF + FW_SH1_BYTES;          // H0 rows [r0-10, r0+26) fp32; then the K-split partials of
+constexpr int FW_SH0_BYTES = CG_OUT * CG_F * 4;                //   the H1 product (7 x 64 x 8 floats = 14336); then the H2 tile
+constexpr int FW_ECAP = 288;                                   // in-edges of the 26 mid rows (<= 26 x 11)
+constexpr int FW_SE_OFF = FW_SH0_OFF + FW_SH0_BYTES;           // sSrc[288], sTyp[288], sIp[32]
+constexpr int FW_SE_BYTES = (2 * FW_ECAP + 32) * 4;
+constexpr int FW_RED_OFF = FW_SE_OFF + FW_SE_BYTES;            // BatchNorm finalisation scratch: 4 x 256 doubles
+constexpr int FW_RED_BYTES = 4 * 256 * 8;
+constexpr int FW_LDS = FW_RED_OFF + FW_RED_BYTES + 16;
+static_assert(7 * 64 * 8 * 4 <= FW_SH0_BYTES, "K-split partials must fit the H0 area");
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ double ld_sc1d(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1d(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// CG_CH (<= 16) per-lane partial dot products -> every lane gets all wave totals: one 16-value butterfly
+__device__ __forceinline__ void wave_sums_ch(const float (&part)[16], float (&tot)[CG_CH], int lane) {
+    float b[8], c[4], d[2];
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (h5 ? part[8 + j] : part[j]) + __shfl_xor(h5 ? part[j] : part[8 + j], 32, 64);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = (h4 ? b[4 + j] : b[j]) + __shfl_xor(h4 ? b[j] : b[4 + j], 16, 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) d[j] = (h3 ? c[2 + j] : c[j]) + __shfl_xor(h3 ? c[j] : c[2 + j], 8, 64);
+    float e = (h2 ? d[1] : d[0]) + __shfl_xor(h2 ? d[0] : d[1], 4, 64);
+    e += __shfl_xor(e, 2, 64);
+    e += __shfl_xor(e, 1, 64);
+#pragma unroll
+    for (int u = 0; u < CG_CH; ++u) tot[u] = __shfl(e, ((u >> 3) & 1) * 32 + ((u >> 2) & 1) * 16 + ((u >> 1) & 1) * 8 + (u & 1) * 4, 64);
+}
+
+// diagnostic phase stamps (tools/cogmen_stamps.py): the 100 MHz real-time counter, written by thread 0 of one workgroup
+#define CG_STAMP(slot)                                                                                            \
+    do {                                                                                                          \
+        if (p.stamps && (int)blockIdx.x == p.stamp_block && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+// one of 8 accumulator pairs selected by a WAVE-UNIFORM relation id: a scalar branch, two adds executed
+#define CG_ACC8(ty, s0, s1, va, vb)                          \
+    do {                                                     \
+        switch (ty) {                                        \
+            case 0: s0[0] += va, s1[0] += vb; break;         \
+            case 1: s0[1] += va, s1[1] += vb; break;         \
+            case 2: s0[2] += va, s1[2] += vb; break;         \
+            case 3: s0[3] += va, s1[3] += vb; break;         \
+            case 4: s0[4] += va, s1[4] += vb; break;         \
+            case 5: s0[5] += va, s1[5] += vb; break;         \
+            case 6: s0[6] += va, s1[6] += vb; break;         \
+            case 7: s0[7] += va, s1[7] += vb; break;         \
+            default: break;                                  \
+        }                                                    \
+    } while (0)
+
+struct CgFwdP {
+    const float* H0;               // [N, ldh0] fp32: the projected utterance features
+    const int32_t* in_ptr;         // CSR by target
+    const int32_t* in_src;
+    const int32_t* in_typ;
+    const unsigned short* WcatT;   // bf16 [112][928]
+    const float* b1;               // conv1.bias [100]
+    const unsigned short* Wq;      // bf16 [400][128]
+    const float* bq;               // [400]
+    unsigned short* Mb;            // out bf16 [N, ldmb]: the relation means | self (operand of the weight gradient)
+    float* inv_cnt;                // out [N, 8]
+    unsigned short* H1b;           // out bf16 [N, ldh1b]
+    float* QKVS;                   // out [N, 400]
+    float* H2;                     // out [N, ldh2]
+    float* alpha;                  // out [E]
+    double* bn_part;               // [tiles][200] column sums of H2 and H2^2 (bn_fused)
+    int* bn_counter;
+    float* running_mean;
+    float* running_var;
+    float* saved;                  // out [0,F) mean, [F,2F) rstd
+    float momentum, eps, scale;
+    int N, ldh0, ldmb, ldh1b, ldh2, bn_fused;
+    uint64_t* stamps;
+    int stamp_block;
+};
+
+__global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned short* const sM = reinterpret_cast<unsigned short*>(lds + FW_SM_OFF);
+    float* const sQ = reinterpret_cast<float*>(lds + FW_SM_OFF);       // aliases sM (after the H1 product)
+    unsigned short* const sH1 = reinterpret_cast<unsigned short*>(lds + FW_SH1_OFF);
+    float* const sH0 = reinterpret_cast<float*>(lds + FW_SH0_OFF);
+    float* const sPart = sH0;                                           // aliases sH0 (after the aggregation)
+    float* const sH2 = sH0;                                             // aliases sH0 (after the H1 product)
+    int* const sSrc = reinterpret_cast<int*>(lds + FW_SE_OFF);
+    int* const sTyp = sSrc + FW_ECAP;
+    int* const sIp = sTyp + FW_ECAP;
+    double* const sRed = reinterpret_cast<double*>(lds + FW_RED_OFF);
+    int* const s_last = reinterpret_cast<int*>(lds + FW_RED_OFF + FW_RED_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar branches below
+    const int N = p.N;
+    const int r0 = (int)blockIdx.x * CG_TR;
+    const int mb = r0 - CG_HL, ob = r0 - 2 * CG_HL;   // first node of the mid / outer row ranges
+    const int c1 = min(lane + 64, CG_F - 1);
+    const bool h1 = lane + 64 < CG_F;
+    CG_STAMP(0);
+
+    // ---- stage 0: H0 rows [r0-10, r0+26) and the CSR slice of the mid rows -> LDS; zero the K padding of the M tile
+    const int m_lo = min(max(mb, 0), N), m_hi = min(max(mb + CG_MID, 0), N);
+    const int E_lo = p.in_ptr[m_lo], E_hi = min(p.in_ptr[m_hi], E_lo + FW_ECAP);
+    // B fragments of the H1 product: wavefront (ct = w & 7, kh = w >> 3) owns column tile ct and the K blocks
+    // [15 kh, 15 kh + 15) (kh = 1: 14); requested now, they arrive during the aggregation
+    const int ct = w & 7, kh = w >> 3;
+    const bool mma_wave = ct < CG_NT;
+    constexpr int NKB = CG_KMP / 32, KH0 = 15;      // 29 blocks: 15 + 14
+    const unsigned short* const brow = p.WcatT + (int64_t)min(16 * min(ct, CG_NT - 1) + r, CG_F - 1) * CG_KMP + 8 * g + 32 * KH0 * kh;   // padded columns (>= 100, never stored) re-read row 99
+    const int nkb = kh ? NKB - KH0 : KH0;       // 14 | 15
+    {
+        if (tid < CG_OUT * 25) {
+            const int e = tid / 25, q = tid % 25;
+            const int node = ob + e;
+            const bool ok = node >= 0 && node < N;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.H0 + (int64_t)min(max(node, 0), N - 1) * p.ldh0 + 4 * q);
+            const float m = ok ? 1.f : 0.f;
+            *reinterpret_cast<f32x4*>(sH0 + e * CG_F + 4 * q) = (f32x4){v.x * m, v.y * m, v.z * m, v.w * m};
+        }
+        if (tid < CG_MID + 1) sIp[tid] = p.in_ptr[min(max(mb + tid, 0), N)];
+        if (tid >= 64 && tid < 64 + FW_ECAP) {
+            const int i = tid - 64;
+            const int ei = min(E_lo + i, max(E_hi - 1, E_lo));
+            sSrc[i] = p.in_src[ei], sTyp[i] = p.in_typ[ei];
+        }
+        // columns [900, 936) of rows 0..25: 18 dwords each; row 26 entirely: 468 dwords
+        uint32_t* const sMw = reinterpret_cast<uint32_t*>(sM);
+        if (tid < 26 * 18) sMw[(tid / 18) * (CG_SM / 2) + CG_KM / 2 + (tid % 18)] = 0u;
+        if (tid >= 512 && tid < 512 + CG_SM / 2) sMw[26 * (CG_SM / 2) + tid - 512] = 0u;
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the tile / graph loads above are queued first
+    bf16x8 bx[KH0];
+#pragma unroll
+    for (int u = 0; u < KH0; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow + 32 * min(u, nkb - 1));
+    __syncthreads();
+    CG_STAMP(1);
+
+    // ---- stage A: relation means of the 26 mid rows: one wavefront per row, lane l < 50 owns channels 2l, 2l + 1.
+    //      These gather stages are bound by the NUMBER of wave instructions (16 wavefronts x 4 cycles each on 4 SIMDs),
+    //      not by latency: the relation of an edge is wave-uniform, so it selects the accumulator pair by a scalar branch
+    //      (two adds executed per edge instead of an 8-way select chain), the edge loop stays rolled (two edges per
+    //      trip; the code of this kernel runs once per launch from a cold instruction cache), and the mean is
+    //      sum * rcp(count) with one Newton step (3 instructions; IEEE division is ~25).
+    {
+        const bool act = lane < CG_F / 2;
+        const int c2 = 2 * min(lane, CG_F / 2 - 1);
+#pragma unroll 1
+        for (int e = w; e < CG_MID; e += CG_NW) {
+            const int node = mb + e;
+            const bool valid = node >= 0 && node < N;
+            const int e0 = __builtin_amdgcn_readfirstlane(max(sIp[e] - E_lo, 0));
+            const int nwin = __builtin_amdgcn_readfirstlane(valid ? min(max(sIp[e + 1] - sIp[e], 0), CG_CH) : 0);
+            // lane u holds edge u of the row
+            const int xm = min(e0 + min(lane, max(nwin - 1, 0)), FW_ECAP - 1);
+            const int my_off = min(max(sSrc[xm] - ob, 0), CG_OUT - 1) * CG_F, my_typ = lane < nwin ? sTyp[xm] : CG_R;
+            float s0[CG_R], s1[CG_R];
+#pragma unroll
+            for (int q = 0; q < CG_R; ++q) s0[q] = s1[q] = 0.f;
+            int cnt_l = 0;                        // lane q < 8: number of in-edges of relation q
+#pragma unroll 1
+            for (int u = 0; u < nwin; u += 2) {   // two edges per trip, the second masked on an odd tail
+                const int u1 = min(u + 1, nwin - 1);
+                const int o0 = __builtin_amdgcn_readlane(my_off, u), ty0 = __builtin_amdgcn_readlane(my_typ, u);
+                const int o1 = __builtin_amdgcn_readlane(my_off, u1);
+                const int ty1 = u + 1 < nwin ? __builtin_amdgcn_readlane(my_typ, u1) : CG_R;
+                const float2 v0 = *reinterpret_cast<const float2*>(sH0 + o0 + c2);
+                const float2 v1 = *reinterpret_cast<const float2*>(sH0 + o1 + c2);
+                CG_ACC8(ty0, s0, s1, v0.x, v0.y);       // relation ids >= R are ignored (PyG loops over range(num_relations))
+                CG_ACC8(ty1, s0, s1, v1.x, v1.y);
+                cnt_l += (ty0 == lane ? 1 : 0) + (ty1 == lane ? 1 : 0);
+            }
+            const int le = min(max(node - ob, 0), CG_OUT - 1);
+            float2 self = *reinterpret_cast<const float2*>(sH0 + le * CG_F + c2);
+            if (!valid) self = make_float2(0.f, 0.f);
+            const bool own = valid && e >= CG_HL && e < CG_HL + CG_TR;   // wave-uniform: the tile's own rows go to global memory too
+            uint32_t* const mrow = reinterpret_cast<uint32_t*>(sM + e * CG_SM);
+            uint32_t* const grow = reinterpret_cast<uint32_t*>(p.Mb + (int64_t)(own ? node : 0) * p.ldmb);
+            const float fc_l = (float)max(cnt_l, 1), rc_l = __builtin_amdgcn_rcpf(fc_l);   // lane q: count and 1 / count of relation q
+#pragma unroll
+            for (int q = 0; q < CG_R; ++q) {
+                // mean = sum / count: q0 = s * rc, one correction step with the exact residual (sums are 0 when the count is)
+                const float fc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fc_l), q));
+                const float rc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rc_l), q));
+                float m0 = s0[q] * rc, m1 = s1[q] * rc;
+                m0 = fmaf(fmaf(-m0, fc, s0[q]), rc, m0), m1 = fmaf(fmaf(-m1, fc, s1[q]), rc, m1);
+                const uint32_t pk = (uint32_t)f2bf(m0) | ((uint32_t)f2bf(m1) << 16);
+                if (act) {
+                    mrow[q * (CG_F / 2) + lane] = pk;
+                    if (own) grow[q * (CG_F / 2) + lane] = pk;
+                }
+            }
+            const uint32_t pks = (uint32_t)f2bf(self.x) | ((uint32_t)f2bf(self.y) << 16);
+            if (act) {
+                mrow[CG_R * (CG_F / 2) + lane] = pks;
+                if (own) grow[CG_R * (CG_F / 2) + lane] = pks;
+            }
+            if (own && lane < CG_R) p.inv_cnt[(int64_t)node * CG_R + lane] = cnt_l > 0 ? 1.0f / (float)cnt_l : 0.f;   // kept for the backward
+        }
+    }
+    __syncthreads();
+    CG_STAMP(2);
+
+    // ---- stage B: H1 = M WcatT^T + b1 for rows 0..31 of the tile (rows >= 26 read the zero row); K split over the two
+    //      wavefronts of a column tile, partial tiles of the second half summed through LDS
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if (mma_wave) {
+        const unsigned short* const a0 = sM + r * CG_SM + 8 * g + 32 * KH0 * kh;
+        const unsigned short* const a1 = sM + min(16 + r, 26) * CG_SM + 8 * g + 32 * KH0 * kh;
+#pragma unroll
+        for (int u = 0; u < KH0; ++u) {
+            if (u < nkb) {    // wave-uniform
+                const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(a0 + 32 * u);
+                const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(a1 + 32 * u);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, bx[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, bx[u], acc1, 0, 0, 0);
+            }
+        }
+        if (kh) {
+            float* dst = sPart + (ct * 64 + lane) * 8;
+            *reinterpret_cast<f32x4*>(dst) = acc0, *reinterpret_cast<f32x4*>(dst + 4) = acc1;
+        }
+    }
+    // B fragments of the QKVS product (wavefront w: column tiles w and w + 16 of 25; K = 128): in flight across the barrier
+    bf16x8 fq[2][4];
+    float qbias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qt = min(w + 16 * j, 24);
+        const unsigned short* const bq = p.Wq + (int64_t)(16 * qt + r) * 128 + 8 * g;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) fq[j][kb] = *reinterpret_cast<const bf16x8*>(bq + 32 * kb);
+        qbias[j] = p.bq[16 * qt + r];
+    }
+    __syncthreads();
+    if (mma_wave && !kh) {
+        const float* src = sPart + (ct * 64 + lane) * 8;
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(src), p1 = *reinterpret_cast<const f32x4*>(src + 4);
+        const int col = 16 * ct + r;
+        const float bias = p.b1[min(col, CG_F - 1)];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 16 * h + 4 * g + i;
+                const float v = (h ? acc1[i] + p1[i] : acc0[i] + p0[i]) + bias;
+                const unsigned short hb = col < CG_F ? f2bf(v) : (unsigned short)0;
+                sH1[e * CG_SH1 + col] = hb;
+                const int node = mb + e;
+                if (col < CG_F && e >= CG_HL && e < CG_HL + CG_TR && node < N) p.H1b[(int64_t)node * p.ldh1b + col] = hb;
+            }
+    } else if (w == 7) {
+        // columns [112, 128) of the H1 tile are K padding of the next product
+        for (int i = lane; i < 32 * 16; i += 64) sH1[(i >> 4) * CG_SH1 + 112 + (i & 15)] = 0;
+    }
+    __syncthreads();
+    CG_STAMP(3);
+
+    // ---- stage C: QKVS = H1 Wq^T + bq, 25 column tiles over the 16 wavefronts, both row tiles; K = 128 (4 blocks)
+    {
+        bf16x8 fa[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) fa[h][kb] = *reinterpret_cast<const bf16x8*>(sH1 + (16 * h + r) * CG_SH1 + 32 * kb + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int qt = w + 16 * j;
+            f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[h][kb], fq[j][kb], acc[h], 0, 0, 0);
+            if (qt < 25) {   // wave-uniform
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = 16 * h + 4 * g + i;
+                        if (e < CG_MID) sQ[e * CG_SQ + 16 * qt + r] = acc[h][i] + qbias[j];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    CG_STAMP(4);
+
+    // ---- own rows of the QKVS tile -> global (the backward reads q, k, v of the neighbourhoods): 16 x 100 float4
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + CG_NTH * j;
+        const int li = i / 100, q = i % 100;
+        const int node = r0 + li;
+        if (i < CG_TR * 100 && node < N)
+            *reinterpret_cast<f32x4*>(p.QKVS + (int64_t)node * 400 + 4 * q) = *reinterpret_cast<const f32x4*>(sQ + (CG_HL + li) * CG_SQ + 4 * q);
+    }
+
+    // ---- stage D: attention of the 16 own rows (one per wavefront), softmax grouped by target; lane l < 50 owns
+    //      channels 2l, 2l + 1
+    {
+        const bool act = lane < CG_F / 2;
+        const int c2 = 2 * min(lane, CG_F / 2 - 1);
+        const float am = act ? 1.f : 0.f;
+        const int li = w, node = r0 + li, e = CG_HL + li;
+        const bool valid = node < N;
+        const int e0 = __builtin_amdgcn_readfirstlane(max(sIp[e] - E_lo, 0));
+        const int nwin = __builtin_amdgcn_readfirstlane(valid ? min(max(sIp[e + 1] - sIp[e], 0), CG_CH) : 0);
+        float2 qv = *reinterpret_cast<const float2*>(sQ + e * CG_SQ + c2);
+        qv.x *= am, qv.y *= am;
+        const float2 sk = *reinterpret_cast<const float2*>(sQ + e * CG_SQ + 3 * CG_F + c2);
+        int ljs[CG_CH];
+#pragma unroll
+        for (int u = 0; u < CG_CH; ++u) ljs[u] = sSrc[min(e0 + min(u, max(nwin - 1, 0)), FW_ECAP - 1)];
+        float2 kv[CG_CH], vv[CG_CH];
+#pragma unroll
+        for (int u = 0; u < CG_CH; ++u) {
+            const float* row = sQ + min(max(ljs[u] - mb, 0), CG_MID - 1) * CG_SQ;
+            kv[u] = *reinterpret_cast<const float2*>(row + CG_F + c2), vv[u] = *reinterpret_cast<const float2*>(row + 2 * CG_F + c2);
+        }
+        float sc[CG_CH], part[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part[u] = u < CG_CH ? qv.x * kv[u < CG_CH ? u : 0].x + qv.y * kv[u < CG_CH ? u : 0].y : 0.f;
+        wave_sums_ch(part, sc, lane);
+        float mx = -INFINITY, den = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int u = 0; u < CG_CH; ++u) {
+            sc[u] *= p.scale;
+            if (u < nwin) mx = fmaxf(mx, sc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < CG_CH; ++u) {
+            const float pw = u < nwin ? expf(sc[u] - mx) : 0.f;
+            sc[u] = pw;
+            den += pw;
+            o0 += pw * vv[u].x, o1 += pw * vv[u].y;
+        }
+        const float inv = 1.0f / (den + 1e-16f);
+        const float2 y = make_float2(valid ? o0 * inv + sk.x : 0.f, valid ? o1 * inv + sk.y : 0.f);
+        // invalid rows (past N) put zeros into the BatchNorm sums
+        if (act) *reinterpret_cast<float2*>(sH2 + li * CG_F + c2) = y;
+        if (valid) {
+            if (act) *reinterpret_cast<float2*>(p.H2 + (int64_t)node * p.ldh2 + c2) = y;
+            float mine = 0.f;
+#pragma unroll
+            for (int u = 0; u < CG_CH; ++u)
+                if (lane == u) mine = sc[u];
+            if (lane < nwin) p.alpha[sIp[e] + lane] = mine * inv;
+        }
+    }
+    CG_STAMP(5);
+    if (!p.bn_fused) return;   // uniform
+
+    // ---- BatchNorm statistics (torch.nn.BatchNorm1d in training mode, cogmen.py:67): column sums of this tile in
+    //      fp64, published with write-through stores; the last workgroup to arrive adds the tiles in order
+    __syncthreads();
+    if (tid < 2 * CG_F) {
+        const int c = tid % CG_F, sq = tid / CG_F;
+        double s = 0.0;
+#pragma unroll
+        for (int li = 0; li < CG_TR; ++li) {
+            const double x = (double)sH2[li * CG_F + c];
+            s += sq ? x * x : x;
+        }
+        st_sc1d(p.bn_part + (int64_t)blockIdx.x * 2 * CG_F + tid, s);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    CG_STAMP(6);
+    if (tid == 0) {
+        const int prev = __hip_atomic_fetch_add(p.bn_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(p.bn_counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    {
+        const int slot = tid & 255, part = tid >> 8;        // four threads per column sum: quarters of the tile list, in order
+        const int G = (int)gridDim.x, Gq = (G + 3) >> 2;
+        const int g_begin = min(part * Gq, G), g_end = min(G, g_begin + Gq);
+        double s = 0.0;
+        if (slot < 2 * CG_F) {
+            for (int g0 = g_begin; g0 < g_end; g0 += 32) {
+                double t[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) t[j] = ld_sc1d(p.bn_part + (int64_t)min(g0 + j, G - 1) * 2 * CG_F + slot);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) s += t[j] * (g0 + j < g_end ? 1.0 : 0.0);
+            }
+        }
+        sRed[part * 256 + slot] = s;
+        __syncthreads();
+        if (tid < CG_F) {
+            const int c = tid;
+            const double sx = ((sRed[c] + sRed[256 + c]) + sRed[512 + c]) + sRed[768 + c];
+            const double sxx = ((sRed[CG_F + c] + sRed[256 + CG_F + c]) + sRed[512 + CG_F + c]) + sRed[768 + CG_F + c];
+            const double m = sx / (double)N;
+            double var = sxx / (double)N - m * m;
+            if (var < 0.0) var = 0.0;
+            p.saved[c] = (float)m;
+            p.saved[CG_F + c] = (float)(1.0 / sqrt(var + (double)p.eps));
+            const double unbiased = N > 1 ? var * (double)N / (double)(N - 1) : var;
+            p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)m;
+            p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+        }
+        if (p.stamps && tid == 0) p.stamps[7] = __builtin_amdgcn_s_memrealtime();   // the last arriver, whichever tile it is
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------ backward
+// LDS map of the backward kernel (bytes)
+constexpr int BW_SK_OFF = 0;                                    // K rows [r0-15, r0+31) fp32; later (with sV, sQq) the dP tile
+constexpr int BW_SK_BYTES = CG_FAR * CG_F * 4;                  // 18400
+constexpr int BW_SV_OFF = BW_SK_OFF + BW_SK_BYTES;
+constexpr int BW_SQ_OFF = BW_SV_OFF + BW_SK_BYTES;              // Q rows [r0-10, r0+26)
+constexpr int BW_SQ_BYTES = CG_OUT * CG_F * 4;                  // 14400
+constexpr int BW_SG_OFF = BW_SQ_OFF + BW_SQ_BYTES;              // dH2 rows [r0-10, r0+26)
+constexpr int BW_SE_OFF = BW_SG_OFF + BW_SQ_BYTES;              // edge arrays
+constexpr int BW_ECAP = 400;                                    // in-edges of the 36 outer rows (<= 36 x 11)
+constexpr int BW_OCAP = 288;                                    // out-edges of the 26 mid rows (<= 26 x 11)
+constexpr int BW_SE_BYTES = (3 * BW_ECAP + 4 * BW_OCAP + 40 + 28) * 4;
+constexpr int BW_SDQ_OFF = BW_SE_OFF + ((BW_SE_BYTES + 15) / 16) * 16;
+constexpr int CG_SDQ = 424;                                     // pitch of the dQKVS tile (bf16; K padded to 416)
+constexpr int BW_SDQ_BYTES = 32 * CG_SDQ * 2;                   // 27136
+constexpr int BW_SDH1_OFF = BW_SDQ_OFF + BW_SDQ_BYTES;
+constexpr int BW_SDH1_BYTES = 32 * CG_F * 4;                    // 12800
+constexpr int BW_SDP_OFF = BW_SDH1_OFF + BW_SDH1_BYTES;         // the dP tile (bf16 [16][968])
+constexpr int BW_SDP_BYTES = CG_TR * 968 * 2;                   // 30976
+constexpr int BW_LDS = BW_SDP_OFF + BW_SDP_BYTES;
+constexpr int CG_KB = 936;                                      // K of the dH0 product: 9 relation blocks of 104
+constexpr int CG_KBP = 960;                                     // padded to 30 blocks of 32
+constexpr int CG_SDP = 968;                                     // pitch of the dP tile (bf16)
+static_assert(CG_TR * CG_SDP * 2 <= BW_SDP_BYTES && BW_SDP_OFF % 16 == 0 && BW_LDS <= 160 * 1024, "backward LDS map");
+
+struct CgBwdP {
+    const float* dY;               // [N, F]: dL/d(BatchNorm output) (through the LeakyReLU), from the head kernel
+    const float* H2;               // [N, ldh2]: BatchNorm input
+    const float* gamma;
+    const float* saved;            // [0,F) mean, [F,2F) rstd
+    const float* bn_bwd;           // [0,F) mean of dY, [F,2F) mean of dY * xhat
+    const float* QKVS;             // [N, 400]
+    const float* alpha;            // [E]
+    const int32_t* in_ptr;
+    const int32_t* in_src;
+    const int32_t* out_ptr;
+    const int32_t* out_dst;
+    const int32_t* out_typ;
+    const int32_t* out_eid;
+    const float* inv_cnt;          // [N, 8]
+    const unsigned short* WqT;     // bf16 [112][416]
+    const unsigned short* Wb;      // bf16 [112][960]
+    float* dQKVS;                  // out [N, 400]
+    float* dH1;                    // out [N, F]
+    float* dH0;                    // out [N, lddh0]
+    float scale;
+    int N, ldh2, lddh0;
+    uint64_t* stamps;
+    int stamp_block;
+};
+
+__global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float* const sK = reinterpret_cast<float*>(lds + BW_SK_OFF);
+    float* const sV = reinterpret_cast<float*>(lds + BW_SV_OFF);
+    float* const sQq = reinterpret_cast<float*>(lds + BW_SQ_OFF);
+    float* const sG = reinterpret_cast<float*>(lds + BW_SG_OFF);
+    float* const sAl = reinterpret_cast<float*>(lds + BW_SE_OFF);          // alpha of in-edge E_lo + i
+    float* const sDs = sAl + BW_ECAP;                                      // d(score) of the same edge
+    int* const sSrc = reinterpret_cast<int*>(sDs + BW_ECAP);               // its source node
+    int* const sOd = sSrc + BW_ECAP;                                       // out-edge O_lo + i: target node
+    int* const sOe = sOd + BW_OCAP;                                        //   its in-edge id
+    int* const sOt = sOe + BW_OCAP;                                        //   relation
+    float* const sOw = reinterpret_cast<float*>(sOt + BW_OCAP);            //   1 / count of (target, relation)
+    int* const sIp = reinterpret_cast<int*>(sOw + BW_OCAP);                // in_ptr of outer rows (37)
+    int* const sOp = sIp + 40;                                             // out_ptr of mid rows (27)
+    unsigned short* const sDQ = reinterpret_cast<unsigned short*>(lds + BW_SDQ_OFF);
+    float* const sDH1 = reinterpret_cast<float*>(lds + BW_SDH1_OFF);
+    unsigned short* const sDP = reinterpret_cast<unsigned short*>(lds + BW_SDP_OFF);
+    float* const sPart3 = sK;                                              // K-split partials of the dH1 product
+    float* const sPart5 = sG;                                              // K-split partials of the dH0 product
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar branches below
+    const int N = p.N;
+    const int r0 = (int)blockIdx.x * CG_TR;
+    const int mb = r0 - CG_HL, ob = r0 - 2 * CG_HL, fb = r0 - 3 * CG_HL;
+    const int c1 = min(lane + 64, CG_F - 1);
+    const bool h1 = lane + 64 < CG_F;
+    const int ct = w & 7, kh = w >> 3;           // MFMA stages: column tile and K half of this wavefront
+    const bool mma_wave = ct < CG_NT;
+    CG_STAMP(0);
+
+    // ---- stage 0: graph slices and row tiles -> LDS
+    const int o_lo_node = min(max(ob, 0), N), o_hi_node = min(max(ob + CG_OUT, 0), N);
+    const int m_lo_node = min(max(mb, 0), N), m_hi_node = min(max(mb + CG_MID, 0), N);
+    const int E_lo = p.in_ptr[o_lo_node], E_hi = min(p.in_ptr[o_hi_node], E_lo + BW_ECAP);
+    const int O_lo = p.out_ptr[m_lo_node], O_hi = min(p.out_ptr[m_hi_node], O_lo + BW_OCAP);
+    if (tid < CG_OUT + 1) sIp[tid] = p.in_ptr[min(max(ob + tid, 0), N)];
+    if (tid >= 64 && tid < 64 + CG_MID + 1) sOp[tid - 64] = p.out_ptr[min(max(mb + tid - 64, 0), N)];
+    {
+        // K / V rows of the far range: 46 rows x 50 float4
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + CG_NTH * j;
+            const int f = min(i / 50, CG_FAR - 1), q = i % 50;
+            const int node = fb + f;
+            const bool ok = i < CG_FAR * 50 && node >= 0 && node < N;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.QKVS + (int64_t)min(max(node, 0), N - 1) * 400 + CG_F + 4 * q);
+            const float m = ok ? 1.f : 0.f;
+            float* dst = (q < 25 ? sK + f * CG_F + 4 * q : sV + f * CG_F + 4 * (q - 25));
+            if (i < CG_FAR * 50) *reinterpret_cast<f32x4*>(dst) = (f32x4){v.x * m, v.y * m, v.z * m, v.w * m};
+        }
+        // Q rows and dH2 = BatchNorm backward of the outer range: 36 rows x 25 float4
+        if (tid < CG_OUT * 25) {
+            const int e = tid / 25, q = tid % 25;
+            const int node = ob + e;
+            const bool ok = node >= 0 && node < N;
+            const int64_t nc = min(max(node, 0), N - 1);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(p.QKVS + nc * 400 + 4 * q);
+            const f32x4 dy = *reinterpret_cast<const f32x4*>(p.dY + nc * CG_F + 4 * q);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(p.H2 + nc * p.ldh2 + 4 * q);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(p.saved + 4 * q), rs = *reinterpret_cast<const f32x4*>(p.saved + CG_F + 4 * q);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + 4 * q);
+            const f32x4 ma = *reinterpret_cast<const f32x4*>(p.bn_bwd + 4 * q), mbv = *reinterpret_cast<const f32x4*>(p.bn_bwd + CG_F + 4 * q);
+            const float m = ok ? 1.f : 0.f;
+            f32x4 gq, qq;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                gq[t] = ga[t] * rs[t] * (dy[t] - ma[t] - (x[t] - mu[t]) * rs[t] * mbv[t]) * m;
+                qq[t] = qv[t] * m;
+            }
+            *reinterpret_cast<f32x4*>(sG + e * CG_F + 4 * q) = gq;
+            *reinterpret_cast<f32x4*>(sQq + e * CG_F + 4 * q) = qq;
+        }
+        // edge slices
+        if (tid < BW_ECAP) {
+            const int ei = min(E_lo + tid, max(E_hi - 1, E_lo));
+            const bool ok = E_lo + tid < E_hi;
+            const float a = p.alpha[ei];
+            const int sj = p.in_src[ei];
+            sAl[tid] = ok ? a : 0.f;
+            sSrc[tid] = ok ? sj : 0;
+            sDs[tid] = 0.f;
+        }
+        if (tid >= 512 && tid < 512 + BW_OCAP) {
+            const int i = tid - 512;
+            const int oi = min(O_lo + i, max(O_hi - 1, O_lo));
+            const bool ok = O_lo + i < O_hi;
+            const int dst = p.out_dst[oi], typ = p.out_typ[oi], eid = p.out_eid[oi];
+            const float wgt = p.inv_cnt[(int64_t)dst * CG_R + min(typ, CG_R - 1)];
+            sOd[i] = ok ? dst : 0;
+            sOe[i] = ok ? eid : E_lo;
+            sOt[i] = ok ? typ : CG_R;
+            sOw[i] = (ok && typ < CG_R) ? wgt : 0.f;
+        }
+        // K padding and the dead rows of the dQKVS tile
+        uint32_t* const sDQw = reinterpret_cast<uint32_t*>(sDQ);
+        if (tid < CG_MID * 12) sDQw[(tid / 12) * (CG_SDQ / 2) + 200 + (tid % 12)] = 0u;
+        for (int i = tid; i < 6 * (CG_SDQ / 2); i += CG_NTH) sDQw[CG_MID * (CG_SDQ / 2) + i] = 0u;
+    }
+    __syncthreads();
+    CG_STAMP(1);
+
+    // ---- stage 1: target side of the attention backward for the 36 outer rows (one wavefront per row; lane l < 50 owns
+    //      channels 2l, 2l + 1)
+    const bool act = lane < CG_F / 2;
+    const int c2 = 2 * min(lane, CG_F / 2 - 1);
+    const float am = act ? 1.f : 0.f;
+#pragma unroll 1
+    for (int e = w; e < CG_OUT; e += CG_NW) {
+        const int node = ob + e;
+        const bool valid = node >= 0 && node < N;
+        const int e0 = __builtin_amdgcn_readfirstlane(sIp[e] - E_lo), e1 = __builtin_amdgcn_readfirstlane(sIp[e + 1] - E_lo);
+        const int nwin = valid ? min(max(e1 - e0, 0), CG_CH) : 0;
+        const int eb = max(e0, 0);
+        const int em = e - CG_HL;     // row of the mid tile
+        const bool in_mid = em >= 0 && em < CG_MID;   // wave-uniform: dq is only needed there
+        float2 gv = *reinterpret_cast<const float2*>(sG + e * CG_F + c2);
+        gv.x *= am, gv.y *= am;
+        float al[CG_CH];
+        int ljs[CG_CH];
+#pragma unroll
+        for (int u = 0; u < CG_CH; ++u) {
+            const int x = min(eb + min(u, max(nwin - 1, 0)), BW_ECAP - 1);
+            ljs[u] = sSrc[x];
+            al[u] = sAl[x];
+        }
+        float2 vv[CG_CH];
+#pragma unroll
+        for (int u = 0; u < CG_CH; ++u) {
+            ljs[u] = min(max(ljs[u] - fb, 0), CG_FAR - 1) * CG_F + c2;
+            al[u] = u < nwin ? al[u] : 0.f;
+            vv[u] = *reinterpret_cast<const float2*>(sV + ljs[u]);
+        }
+        float da[CG_CH], part[16], t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) part[u] = u < CG_CH ? gv.x * vv[u < CG_CH ? u : 0].x + gv.y * vv[u < CG_CH ? u : 0].y : 0.f;
+        wave_sums_ch(part, da, lane);
+#pragma unroll
+        for (int u = 0; u < CG_CH; ++u) t += al[u] * da[u];
+        float mine = 0.f;
+#pragma unroll
+        for (int u = 0; u < CG_CH; ++u) {
+            da[u] = al[u] * (da[u] - t) * p.scale;     // d(score)
+            if (lane == u) mine = da[u];
+        }
+        if (lane < nwin) sDs[min(eb + lane, BW_ECAP - 1)] = mine;
+        if (in_mid) {
+            float2 kk[CG_CH];
+#pragma unroll
+            for (int u = 0; u < CG_CH; ++u) kk[u] = *reinterpret_cast<const float2*>(sK + ljs[u]);
+            float dq0 = 0.f, dq1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < CG_CH; ++u) dq0 += da[u] * kk[u].x, dq1 += da[u] * kk[u].y;
+            if (!valid) dq0 = dq1 = 0.f;
+            uint32_t* row = reinterpret_cast<uint32_t*>(sDQ + em * CG_SDQ);
+            if (act) {
+                row[lane] = (uint32_t)f2bf(dq0) | ((uint32_t)f2bf(dq1) << 16);
+                row[3 * CG_F / 2 + lane] = (uint32_t)f2bf(gv.x) | ((uint32_t)f2bf(gv.y) << 16);
+            }
+            if (valid && em >= CG_HL && em < CG_HL + CG_TR && act) {
+                float* d = p.dQKVS + (int64_t)node * 400 + c2;
+                *reinterpret_cast<float2*>(d) = make_float2(dq0, dq1);
+                *reinterpret_cast<float2*>(d + 3 * CG_F) = gv;
+            }
+        }
+    }
+    __syncthreads();
+    CG_STAMP(2);
+
+    // B fragments of the dH1 product (K = 416: blocks [7 kh, 7 kh + 7), the second half has 6): requested now
+    const unsigned short* const brow3 = p.WqT + (int64_t)min(16 * min(ct, CG_NT - 1) + r, CG_F - 1) * 416 + 8 * g + 32 * 7 * kh;
+    bf16x8 fb3[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) fb3[u] = *reinterpret_cast<const bf16x8*>(brow3 + 32 * min(u, kh ? 5 : 6));
+
+    // ---- stage 2: source side for the 26 mid rows: dk = sum ds q_target, dv = sum alpha dH2_target over the out-edges
+#pragma unroll 1
+    for (int em = w; em < CG_MID; em += CG_NW) {
+        const int node = mb + em;
+        const bool valid = node >= 0 && node < N;
+        const int o0 = __builtin_amdgcn_readfirstlane(sOp[em] - O_lo), o1 = __builtin_amdgcn_readfirstlane(sOp[em + 1] - O_lo);
+        const int nwin = valid ? min(max(o1 - o0, 0), CG_CH) : 0;
+        const int xb = max(o0, 0);
+        float dk0 = 0.f, dk1 = 0.f, dv0 = 0.f, dv1 = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < CG_CH; hb += 6) {      // two batches of six out-edges (register budget)
+            int lts[6], les[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int x = min(xb + min(hb + j, max(nwin - 1, 0)), BW_OCAP - 1);
+                lts[j] = sOd[x], les[j] = sOe[x];
+            }
+            float ds[6], al[6];
+            float2 qq[6], gg[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int lt = min(max(lts[j] - ob, 0), CG_OUT - 1) * CG_F + c2;
+                const int le = min(max(les[j] - E_lo, 0), BW_ECAP - 1);
+                ds[j] = sDs[le], al[j] = sAl[le];
+                qq[j] = *reinterpret_cast<const float2*>(sQq + lt), gg[j] = *reinterpret_cast<const float2*>(sG + lt);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float d = hb + j < nwin ? ds[j] : 0.f, a = hb + j < nwin ? al[j] : 0.f;
+                dk0 += d * qq[j].x, dk1 += d * qq[j].y, dv0 += a * gg[j].x, dv1 += a * gg[j].y;
+            }
+        }
+        uint32_t* row = reinterpret_cast<uint32_t*>(sDQ + em * CG_SDQ);
+        if (act) {
+            row[CG_F / 2 + lane] = (uint32_t)f2bf(dk0) | ((uint32_t)f2bf(dk1) << 16);
+            row[CG_F + lane] = (uint32_t)f2bf(dv0) | ((uint32_t)f2bf(dv1) << 16);
+        }
+        if (valid && em >= CG_HL && em < CG_HL + CG_TR && act) {
+            float* d = p.dQKVS + (int64_t)node * 400 + c2;
+            *reinterpret_cast<float2*>(d + CG_F) = make_float2(dk0, dk1);
+            *reinterpret_cast<float2*>(d + 2 * CG_F) = make_float2(dv0, dv1);
+        }
+    }
+    __syncthreads();
+    CG_STAMP(3);
+
+    // ---- stage 3: dH1 = dQKVS WqT^T (K = 416: 13 blocks split 7 + 6 over the two wavefronts of a column tile), both row tiles
+    {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (mma_wave) {
+            const unsigned short* const a0 = sDQ + r * CG_SDQ + 8 * g + 32 * 7 * kh;
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                if (u < (kh ? 6 : 7)) {   // wave-uniform
+                    const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(a0 + 32 * u);
+                    const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(a0 + 16 * CG_SDQ + 32 * u);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb3[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb3[u], acc1, 0, 0, 0);
+                }
+            }
+            if (kh) {
+                float* dst = sPart3 + (ct * 64 + lane) * 8;
+                *reinterpret_cast<f32x4*>(dst) = acc0, *reinterpret_cast<f32x4*>(dst + 4) = acc1;
+            }
+        }
+        __syncthreads();
+        if (mma_wave && !kh) {
+            const float* src = sPart3 + (ct * 64 + lane) * 8;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(src), p1 = *reinterpret_cast<const f32x4*>(src + 4);
+            const int col = 16 * ct + r;
+            if (col < CG_F) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = 16 * h + 4 * g + i;
+                        const float v = h ? acc1[i] + p1[i] : acc0[i] + p0[i];
+                        sDH1[e * CG_F + col] = v;
+                        const int node = mb + e;
+                        if (e >= CG_HL && e < CG_HL + CG_TR && node < N) p.dH1[(int64_t)node * CG_F + col] = v;
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    CG_STAMP(4);
+
+    // B fragments of the dH0 product (K = 960: blocks [15 kh, 15 kh + 15)): requested now
+    const unsigned short* const brow5 = p.Wb + (int64_t)min(16 * min(ct, CG_NT - 1) + r, CG_F - 1) * CG_KBP + 8 * g + 32 * 15 * kh;
+    bf16x8 bx[15];
+#pragma unroll
+    for (int u = 0; u < 15; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow5 + 32 * u);
+
+    // ---- stage 4: dP = transposed relation means of dH1 for the 16 own rows (one per wavefront): block r of row j
+    //      = sum over out-edges (j -> i, relation r) of dH1[i] / count_r(i); block 8 = dH1[j].  Scalar-branch
+    //      accumulation and a rolled edge loop as in the forward aggregation.
+    {
+        uint32_t* const sDPw = reinterpret_cast<uint32_t*>(sDP);
+        const int li = w, em = CG_HL + li, node = r0 + li;
+        const bool valid = node < N;
+        const int o0 = __builtin_amdgcn_readfirstlane(sOp[em] - O_lo), o1 = __builtin_amdgcn_readfirstlane(sOp[em + 1] - O_lo);
+        const int nwin = valid ? min(max(o1 - o0, 0), CG_CH) : 0;
+        const int xb = max(o0, 0);
+        // lane u holds out-edge u of the row
+        const int xm = min(xb + min(lane, max(nwin - 1, 0)), BW_OCAP - 1);
+        const int my_off = min(max(sOd[xm] - mb, 0), CG_MID - 1) * CG_F, my_typ = lane < nwin ? sOt[xm] : CG_R;
+        const float my_w = sOw[xm];
+        float s0[CG_R], s1[CG_R];
+#pragma unroll
+        for (int q = 0; q < CG_R; ++q) s0[q] = s1[q] = 0.f;
+#pragma unroll 1
+        for (int u = 0; u < nwin; u += 2) {
+            const int u1 = min(u + 1, nwin - 1);
+            const int f0 = __builtin_amdgcn_readlane(my_off, u), ty0 = __builtin_amdgcn_readlane(my_typ, u);
+            const int f1 = __builtin_amdgcn_readlane(my_off, u1);
+            const int ty1 = u + 1 < nwin ? __builtin_amdgcn_readlane(my_typ, u1) : CG_R;
+            const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), u));
+            const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), u1));
+            const float2 v0 = *reinterpret_cast<const float2*>(sDH1 + f0 + c2);
+            const float2 v1 = *reinterpret_cast<const float2*>(sDH1 + f1 + c2);
+            const float a0 = v0.x * w0, b0 = v0.y * w0, a1 = v1.x * w1, b1 = v1.y * w1;
+            CG_ACC8(ty0, s0, s1, a0, b0);
+            CG_ACC8(ty1, s0, s1, a1, b1);
+        }
+        float2 self = *reinterpret_cast<const float2*>(sDH1 + em * CG_F + c2);
+        if (!valid) self = make_float2(0.f, 0.f);
+        uint32_t* const row = sDPw + li * (CG_SDP / 2);
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < CG_R; ++q) row[q * 52 + lane] = (uint32_t)f2bf(s0[q]) | ((uint32_t)f2bf(s1[q]) << 16);
+            row[CG_R * 52 + lane] = (uint32_t)f2bf(self.x) | ((uint32_t)f2bf(self.y) << 16);
+        }
+        // padding: columns [100, 104) of every block and [936, 968)
+        if (lane < CG_R + 1) row[lane * 52 + 50] = 0u, row[lane * 52 + 51] = 0u;
+        if (lane >= 32 && lane < 48) row[CG_KB / 2 + (lane - 32)] = 0u;
+    }
+    __syncthreads();
+    CG_STAMP(5);
+
+    // ---- stage 5: dH0 = dP Wb^T (K = 960: 30 blocks, 15 per wavefront of a column tile), one row tile
+    {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (mma_wave) {
+            const unsigned short* const arow = sDP + r * CG_SDP + 8 * g + 32 * 15 * kh;
+#pragma unroll
+            for (int u = 0; u < 15; ++u) {
+                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(arow + 32 * u);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bx[u], acc, 0, 0, 0);
+            }
+            if (kh) *reinterpret_cast<f32x4*>(sPart5 + (ct * 64 + lane) * 4) = acc;
+        }
+        __syncthreads();
+        if (mma_wave && !kh) {
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(sPart5 + (ct * 64 + lane) * 4);
+            const int col = 16 * ct + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int node = r0 + 4 * g + i;
+                if (col < CG_F && node < N) p.dH0[(int64_t)node * p.lddh0 + col] = acc[i] + p0[i];
+            }
+        }
+    }
+    CG_STAMP(6);
+}
+
+bool ensure_lds(const void* kernel, int bytes) {
+    static const void* known[4];
+    static int n_known = 0;
+    for (int i = 0; i < n_known; ++i)
+        if (known[i] == kernel) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (n_known < 4) known[n_known++] = kernel;
+    return true;
+}
+
+uint64_t* g_cg_stamps = nullptr;
+
+}  // namespace
+
+// diagnostic: phase stamps of the middle workgroup of the next erc_cogmen_{fwd,bwd}_tile launches, 8 x uint64 (10 ns
+// ticks; tools/cogmen_stamps.py); nullptr switches them off
+extern "C" int erc_cogmen_set_stamps(uint64_t* stamps) {
+    g_cg_stamps = stamps;
+    return ERC_OK;
+}
+
+extern "C" int64_t erc_cogmen_fwd_tile_ws_doubles(int n_nodes) { return (int64_t)erc_cdiv(n_nodes, CG_TR) * 2 * CG_F + 2; }
+
+extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int wp, int wf, const int32_t* in_ptr,
+                                   const int32_t* in_src, const int32_t* in_typ, const void* WcatT, const float* b1,
+                                   const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
+                                   int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* saved,
+                                   double* bn_ws, void* stream) {
+    ERC_REQUIRE(H0 && in_ptr && in_src && in_typ && WcatT && b1 && Wq && bq && Mb && inv_cnt && H1b && QKVS && H2 && alpha,
+                "cogmen_fwd_tile: null pointer");
+    ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_fwd_tile: window (%d, %d) exceeds the halo %d",
+                wp, wf, CG_HL);
+    ERC_REQUIRE(ldh0 >= CG_F && ldh0 % 4 == 0 && ((uintptr_t)H0 & 15) == 0 && ldmb >= CG_KM && ldmb % 2 == 0 && ((uintptr_t)Mb & 3) == 0 && ldh1b >= CG_F &&
+                    ldh2 >= CG_F && ldh2 % 2 == 0 && ((uintptr_t)H2 & 7) == 0 &&
+                    ((uintptr_t)QKVS & 15) == 0 && ((uintptr_t)WcatT & 15) == 0 && ((uintptr_t)Wq & 15) == 0,
+                "cogmen_fwd_tile: pitch / alignment");
+    ERC_REQUIRE(!bn_fused || (running_mean && running_var && saved && bn_ws), "cogmen_fwd_tile: BatchNorm operands");
+    ERC_REQUIRE(ensure_lds(reinterpret_cast<const void*>(cogmen_fwd_tile_kernel), FW_LDS), "cogmen_fwd_tile: %d bytes of LDS refused", FW_LDS);
+    CgFwdP p{};
+    p.H0 = H0; p.in_ptr = in_ptr; p.in_src = in_src; p.in_typ = in_typ; p.WcatT = (const unsigned short*)WcatT; p.b1 = b1;
+    p.Wq = (const unsigned short*)Wq; p.bq = bq; p.Mb = (unsigned short*)Mb; p.inv_cnt = inv_cnt; p.H1b = (unsigned short*)H1b;
+    p.QKVS = QKVS; p.H2 = H2; p.alpha = alpha;
+    const int tiles = erc_cdiv(n_nodes, CG_TR);
+    p.bn_part = bn_ws ? bn_ws + 2 : nullptr;                     // [0] holds the arrival counter (8-byte slot)
+    p.bn_counter = reinterpret_cast<int*>(bn_ws);
+    p.running_mean = running_mean; p.running_var = running_var; p.saved = saved;
+    p.momentum = momentum; p.eps = eps; p.scale = scale;
+    p.N = n_nodes; p.ldh0 = ldh0; p.ldmb = ldmb; p.ldh1b = ldh1b; p.ldh2 = ldh2; p.bn_fused = bn_fused ? 1 : 0;
+    p.stamps = g_cg_stamps; p.stamp_block = tiles / 2;
+    hipLaunchKernelGGL(cogmen_fwd_tile_kernel, dim3(tiles), dim3(CG_NTH), FW_LDS, (hipStream_t)stream, p);
+    ERC_LAUNCH_CHECK("cogmen_fwd_tile");
+    return ERC_OK;
+}
+
+extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes, int wp, int wf, const float* gamma,
+                                   const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
+                                   const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                   const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
+                                   const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0, void* stream) {
+    ERC_REQUIRE(dY && H2 && gamma && saved && bn_bwd && QKVS && alpha && in_ptr && in_src && out_ptr && out_dst && out_typ &&
+                    out_eid && inv_cnt && WqT && Wb && dQKVS && dH1 && dH0, "cogmen_bwd_tile: null pointer");
+    ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_bwd_tile: window (%d, %d) exceeds the halo %d",
+                wp, wf, CG_HL);
+    ERC_REQUIRE(ldh2 >= CG_F && ldh2 % 4 == 0 && lddh0 >= CG_F &&
+                    (((uintptr_t)dY | (uintptr_t)H2 | (uintptr_t)QKVS | (uintptr_t)gamma | (uintptr_t)saved | (uintptr_t)bn_bwd |
+                      (uintptr_t)WqT | (uintptr_t)Wb) & 15) == 0, "cogmen_bwd_tile: pitch / alignment");
+    ERC_REQUIRE(ensure_lds(reinterpret_cast<const void*>(cogmen_bwd_tile_kernel), BW_LDS), "cogmen_bwd_tile: %d bytes of LDS refused", BW_LDS);
+    CgBwdP p{};
+    p.dY = dY; p.H2 = H2; p.gamma = gamma; p.saved = saved; p.bn_bwd = bn_bwd; p.QKVS = QKVS; p.alpha = alpha;
+    p.in_ptr = in_ptr; p.in_src = in_src; p.out_ptr = out_ptr; p.out_dst = out_dst; p.out_typ = out_typ; p.out_eid = out_eid;
+    p.inv_cnt = inv_cnt; p.WqT = (const unsigned short*)WqT; p.Wb = (const unsigned short*)Wb;
+    p.dQKVS = dQKVS; p.dH1 = dH1; p.dH0 = dH0; p.scale = scale; p.N = n_nodes; p.ldh2 = ldh2; p.lddh0 = lddh0;
+    p.stamps = g_cg_stamps; p.stamp_block = erc_cdiv(n_nodes, CG_TR) / 2;
+    hipLaunchKernelGGL(cogmen_bwd_tile_kernel, dim3(erc_cdiv(n_nodes, CG_TR)), dim3(CG_NTH), BW_LDS, (hipStream_t)stream, p);
+    ERC_LAUNCH_CHECK("cogmen_bwd_tile");
+    return ERC_OK;
+}

@@ -1,6 +1,7 @@
 // S4: fused optimizer over the flat live-parameter buffer, and the library's
 // error plumbing.
 #include <stdarg.h>
+#include <string.h>
 
 #include "erc_common.h"
 
@@ -17,6 +18,71 @@ extern "C" int erc_abi_version(void) { return ERC_ABI_VERSION; }
 
 namespace {
 
+// bf16 shadow copies of parameter ranges (operands of the bf16 matrix-core products), written by the optimizer
+// kernel itself so that no extra launch keeps them in sync.  Element i of [src_off, src_off + n_el) of the flat
+// buffer, idx = i - src_off, goes to shadow[dst_off + (idx / (n0 n1)) s2 + ((idx / n0) % n1) s1 + (idx % n0) s0]:
+// identity copies, transposes and padded / blocked layouts are all instances (strides in elements).
+struct ShadowDesc {
+    int64_t src_off, n_el, dst_off;
+    int32_t n0, n1, s0, s1, s2, pad;
+};
+constexpr int SHADOW_MAX = 8;
+struct ShadowTab {
+    int32_t n, pad;
+    ShadowDesc d[SHADOW_MAX];
+};
+
+// Four consecutive elements (i0 % 4 == 0) at once: with src_off, n0 multiples of 4 (checked by the host; the flat buffer
+// aligns every group to 64 floats) they share d1 and d2, so one index decomposition serves the quad, and a unit stride
+// makes the four bf16 one 8-byte store.
+__device__ __forceinline__ void shadow_store4(unsigned short* __restrict__ shadow, const ShadowTab& tab, int64_t i0, float4 pn) {
+#pragma unroll
+    for (int t = 0; t < SHADOW_MAX; ++t) {
+        if (t < tab.n) {
+            const int64_t idx = i0 - tab.d[t].src_off;
+            if (idx >= 0 && idx < tab.d[t].n_el) {
+                const int32_t x = (int32_t)idx, n0 = tab.d[t].n0, n1 = tab.d[t].n1;
+                const int32_t q = x / n0, d0 = x - q * n0, d2 = q / n1, d1 = q - d2 * n1;
+                unsigned short* dst = shadow + tab.d[t].dst_off + (int64_t)d2 * tab.d[t].s2 + (int64_t)d1 * tab.d[t].s1 + (int64_t)d0 * tab.d[t].s0;
+                const unsigned short h0 = __builtin_bit_cast(unsigned short, (__bf16)pn.x), h1 = __builtin_bit_cast(unsigned short, (__bf16)pn.y);
+                const unsigned short h2 = __builtin_bit_cast(unsigned short, (__bf16)pn.z), h3 = __builtin_bit_cast(unsigned short, (__bf16)pn.w);
+                if (tab.d[t].s0 == 1 && (tab.d[t].pad & 1)) {   // pad bit 0: destination quads are 8-byte aligned
+                    *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+                } else {
+                    const int64_t s0 = tab.d[t].s0;
+                    dst[0] = h0, dst[s0] = h1, dst[2 * s0] = h2, dst[3 * s0] = h3;
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void shadow_store(unsigned short* __restrict__ shadow, const ShadowTab& tab, int64_t i, float pn) {
+#pragma unroll
+    for (int t = 0; t < SHADOW_MAX; ++t) {
+        if (t < tab.n) {
+            const int64_t idx = i - tab.d[t].src_off;
+            if (idx >= 0 && idx < tab.d[t].n_el) {
+                const int32_t x = (int32_t)idx, n0 = tab.d[t].n0, n1 = tab.d[t].n1;
+                const int32_t d0 = x % n0, q = x / n0, d1 = q % n1, d2 = q / n1;
+                const __bf16 h = (__bf16)pn;
+                shadow[tab.d[t].dst_off + (int64_t)d2 * tab.d[t].s2 + (int64_t)d1 * tab.d[t].s1 + (int64_t)d0 * tab.d[t].s0] =
+                    __builtin_bit_cast(unsigned short, h);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __restrict__ p, unsigned short* __restrict__ shadow,
+                                                             const ShadowTab tab) {
+    const ShadowDesc& d = tab.d[blockIdx.y];
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < d.n_el; idx += (int64_t)gridDim.x * 256) {
+        const int32_t x = (int32_t)idx, d0 = x % d.n0, q = x / d.n0, d1 = q % d.n1, d2 = q / d.n1;
+        const __bf16 h = (__bf16)p[d.src_off + idx];
+        shadow[d.dst_off + (int64_t)d2 * d.s2 + (int64_t)d1 * d.s1 + (int64_t)d0 * d.s0] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
 // torch.optim.Adam / AdamW update (torch/optim/adam.py single-tensor path):
 //   g += wd*p (Adam)  |  p *= 1 - lr*wd (AdamW)
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
@@ -26,8 +92,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float b1, float b2, float eps, float wd, int decoupled,
                                                    float grad_scale, float clip_norm,
                                                    const float* __restrict__ gnorm, int64_t* state,
-                                                   unsigned short* __restrict__ shadow, int64_t shadow_off,
-                                                   int64_t shadow_n, const int32_t* __restrict__ skip_flag) {
+                                                   unsigned short* __restrict__ shadow, const ShadowTab tab,
+                                                   const int32_t* __restrict__ skip_flag) {
     // a producer of this step's gradients (the DAG-ERC recurrence kernels) flagged an exchange timeout: the
     // gradients are invalid -- leave parameters, moments and the step counter untouched (checked on the device, no sync)
     if (skip_flag && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
@@ -58,11 +124,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         vi = b2 * vi + (1.f - b2) * gi * gi;
         pi = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     };
-    auto to_shadow = [&](int64_t i, float pn) {  // bf16 copy for the bf16 input GEMM
-        if (shadow && i >= shadow_off && i < shadow_off + shadow_n) {
-            const __bf16 h = (__bf16)pn;
-            shadow[i - shadow_off] = __builtin_bit_cast(unsigned short, h);
-        }
+    const bool quad_ok = tab.pad != 0;           // host: every range starts on a quad, n0 % 4 == 0, n_el % 4 == 0
+    auto to_shadow = [&](int64_t i, float pn) {  // bf16 copies for the bf16 matrix-core products
+        if (shadow) shadow_store(shadow, tab, i, pn);
     };
     // 16-byte accesses: one quad per thread and grid stride (the launch sizes the grid for a single pass)
     for (int64_t q = q0; q < nq; q += (int64_t)gridDim.x * 256) {
@@ -73,7 +137,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         update(pv.x, gv.x, mv.x, vv.x), update(pv.y, gv.y, mv.y, vv.y);
         update(pv.z, gv.z, mv.z, vv.z), update(pv.w, gv.w, mv.w, vv.w);
         reinterpret_cast<float4*>(m)[q] = mv, reinterpret_cast<float4*>(v)[q] = vv, reinterpret_cast<float4*>(p)[q] = pv;
-        if (shadow) to_shadow(4 * q, pv.x), to_shadow(4 * q + 1, pv.y), to_shadow(4 * q + 2, pv.z), to_shadow(4 * q + 3, pv.w);
+        if (shadow) {
+            if (quad_ok) shadow_store4(shadow, tab, 4 * q, pv);
+            else to_shadow(4 * q, pv.x), to_shadow(4 * q + 1, pv.y), to_shadow(4 * q + 2, pv.z), to_shadow(4 * q + 3, pv.w);
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (nq << 2) + threadIdx.x;
@@ -144,21 +211,79 @@ extern "C" int erc_clock_probe(uint64_t* out, int iters, void* stream) {
     return ERC_OK;
 }
 
-extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
-                             float clip_norm, const float* gnorm, int64_t* state, void* bf16_shadow,
-                             int64_t shadow_off, int64_t shadow_n, const int32_t* skip_flag, void* stream) {
+static int check_shadow_tab(const ShadowTab& tab, int64_t n, const char* who) {
+    ERC_REQUIRE(tab.n >= 0 && tab.n <= SHADOW_MAX, "%s: %d shadow descriptors (max %d)", who, tab.n, SHADOW_MAX);
+    for (int t = 0; t < tab.n; ++t) {
+        const ShadowDesc& d = tab.d[t];
+        ERC_REQUIRE(d.src_off >= 0 && d.n_el > 0 && d.src_off + d.n_el <= n && d.n_el < (1ll << 31) && d.n0 > 0 && d.n1 > 0 &&
+                        d.dst_off >= 0, "%s: shadow descriptor %d out of range", who, t);
+    }
+    return ERC_OK;
+}
+
+static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int decoupled, float grad_scale, float clip_norm, const float* gnorm,
+                       int64_t* state, void* shadow_base, const ShadowTab& tab_in, const int32_t* skip_flag, void* stream) {
+    ShadowTab tab = tab_in;
+    // quad fast path: every range starts on a quad of the flat buffer and has rows of a multiple of 4 elements; per range,
+    // bit 0 of pad = unit-stride destination quads are 8-byte aligned
+    tab.pad = tab.n > 0;
+    for (int t = 0; t < tab.n; ++t) {
+        ShadowDesc& d = tab.d[t];
+        if (d.src_off % 4 || d.n0 % 4 || d.n_el % 4) tab.pad = 0;
+        d.pad = (d.s0 == 1 && d.dst_off % 4 == 0 && d.s1 % 4 == 0 && d.s2 % 4 == 0 && ((uintptr_t)shadow_base & 7) == 0) ? 1 : 0;
+    }
     ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
     ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
     ERC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: 16-byte alignment");
+    if (int rc = check_shadow_tab(tab, n, "adam_step")) return rc;
     int grid = (int)((n / 4 + 255) / 256);   // one float4 per thread
     if (grid < 1) grid = 1;
     if (grid > 512) grid = 512;  // one arrival atomic per block on a single word: keep the count low
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                       decoupled, grad_scale, clip_norm, gnorm, state, (unsigned short*)bf16_shadow, shadow_off, shadow_n,
+                       decoupled, grad_scale, clip_norm, gnorm, state, tab.n > 0 ? (unsigned short*)shadow_base : nullptr, tab,
                        skip_flag);
     ERC_LAUNCH_CHECK("adam_step");
+    return ERC_OK;
+}
+
+extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                             float clip_norm, const float* gnorm, int64_t* state, void* bf16_shadow,
+                             int64_t shadow_off, int64_t shadow_n, const int32_t* skip_flag, void* stream) {
+    ShadowTab tab{};
+    if (bf16_shadow && shadow_n > 0) {
+        tab.n = 1;
+        tab.d[0] = ShadowDesc{shadow_off, shadow_n, 0, (int32_t)shadow_n, 1, 1, 0, 0, 0};
+    }
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, clip_norm, gnorm, state,
+                       bf16_shadow, tab, skip_flag, stream);
+}
+
+// Same step with a table of bf16 shadow ranges (ErcShadowTab in ercgraft.h, a HOST struct passed by value to the kernel).
+extern "C" int erc_adam_step_tab(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                                 float clip_norm, const float* gnorm, int64_t* state, void* shadow_base,
+                                 const ErcShadowTab* tab_host, const int32_t* skip_flag, void* stream) {
+    static_assert(sizeof(ShadowTab) == sizeof(ErcShadowTab), "shadow table layout");
+    ShadowTab tab{};
+    if (tab_host) memcpy(&tab, tab_host, sizeof(tab));
+    ERC_REQUIRE(tab.n == 0 || shadow_base, "adam_step_tab: shadow table without a shadow buffer");
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, clip_norm, gnorm, state,
+                       shadow_base, tab, skip_flag, stream);
+}
+
+// (Re)build every shadow range of the table from the fp32 parameters (after loading a state dict, or when no optimizer
+// maintains them).
+extern "C" int erc_shadow_refresh(const float* p, int64_t n, void* shadow_base, const ErcShadowTab* tab_host, void* stream) {
+    ERC_REQUIRE(p && shadow_base && tab_host, "shadow_refresh: null pointer");
+    ShadowTab tab{};
+    memcpy(&tab, tab_host, sizeof(tab));
+    ERC_REQUIRE(tab.n > 0, "shadow_refresh: empty table");
+    if (int rc = check_shadow_tab(tab, n, "shadow_refresh")) return rc;
+    hipLaunchKernelGGL(shadow_refresh_kernel, dim3(64, tab.n), dim3(256), 0, (hipStream_t)stream, p, (unsigned short*)shadow_base, tab);
+    ERC_LAUNCH_CHECK("shadow_refresh");
     return ERC_OK;
 }
 

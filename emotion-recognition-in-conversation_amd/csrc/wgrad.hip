@@ -34,7 +34,7 @@ constexpr int WG_IDX_CAP = 2048;   // k per split (row-gather stage in LDS)
 constexpr int WG_SLAB = 4096 + 64; // floats per partial tile: 64 x 64 + one bias strip
 constexpr int WG_MAX_DESC = 32;
 
-struct WgDesc {  // 104 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQQQQ14if4x")
+struct WgDesc {  // 104 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQQQQ14ifi")
     const float* A;
     const void* B;
     float* C;
@@ -43,6 +43,7 @@ struct WgDesc {  // 104 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQ
     int lda, ldb, ldc, M, N, K;
     int ones, b_bf16, splits, tiles_n, item_base, n_items, tile_base, vec;  // vec: bit0 A, bit1 B, bit2 C 16-byte ok
     float scale;              // the product is stored as scale * A^T B (GCNII: dW_l = theta_l dV_l); bias strips are not scaled
+    int a_bf16;               // A is bf16 (the relation-mean tile the fused COGMEN forward stores); lda in elements
 };
 
 // Cross-workgroup hand-off of the partial tiles WITHOUT fences (an agent-scope release/acquire fence pair costs
@@ -58,7 +59,7 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 
 // VEC (16-byte operand loads legal for BOTH operands) is compile-time: a runtime flag around a load makes hipcc
 // branch and drain vmcnt per load.
-template <bool BF16, bool VEC>
+template <bool ABF, bool BF16, bool VEC>
 __device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, float* red, float* bred, int* idx,
                                            int* s_flag, float* slabs, int* counters) {
     const gfloat_cp A = (gfloat_cp)d.A;
@@ -105,7 +106,19 @@ __device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, flo
         const int kl = max(0, min(k - k_begin, nk - 1));
         const int64_t arow = (int64_t)(k_begin + kl) * d.lda;
         const int64_t brow = (int64_t)idx[kl] * d.ldb;
-        if (avec) {
+        if (ABF) {
+            const gushort_cp Ah = (gushort_cp)d.A;
+            unsigned short h[4];
+            if (avec) {
+                const u16x4 v = *(gushort4_cp)(Ah + arow + mav);
+                h[0] = v.x, h[1] = v.y, h[2] = v.z, h[3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h[i] = Ah[arow + mc[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = __builtin_bit_cast(float, (unsigned)h[i] << 16);
+        } else if (avec) {
             const f32x4 v = *(gfloat4_cp)(A + arow + mav);
             a[0] = v.x, a[1] = v.y, a[2] = v.z, a[3] = v.w;
         } else {
@@ -311,12 +324,15 @@ __global__ __launch_bounds__(256, 3) void wgrad_table_kernel(const WgDesc* __res
     const int local = L - d.item_base;
     if (local >= d.n_items) return;
     const bool vec = (d.vec & 3) == 3;
-    if (d.b_bf16) {
-        if (vec) wgrad_body<true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+    if (d.a_bf16) {   // bf16 A with an fp32 B (COGMEN bf16 mode: d[W_r ; W_root] = M^T dH1)
+        if (vec) wgrad_body<true, false, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<true, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+    } else if (d.b_bf16) {
+        if (vec) wgrad_body<false, true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<false, true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
     } else {
-        if (vec) wgrad_body<false, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        if (vec) wgrad_body<false, false, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<false, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
     }
 }
 

@@ -147,7 +147,9 @@ class GemmPlanner:
             steps = int(os.environ.get("ERC_WG_STEPS", self.WG_STEPS))
             for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g, sc in self.deferred:
                 bf16 = b.dtype == torch.bfloat16
-                if a.dtype != torch.float32 or c.dtype != torch.float32 or (not bf16 and b.dtype != torch.float32):
+                a_bf16 = a.dtype == torch.bfloat16
+                if (not a_bf16 and a.dtype != torch.float32) or c.dtype != torch.float32 or \
+                        (not bf16 and b.dtype != torch.float32) or (a_bf16 and bf16):
                     raise capi.ErcGraftError("wgrad table: operand dtypes %s %s %s" % (a.dtype, b.dtype, c.dtype))
                 nks = -(-K // 4)
                 splits = max(1, min(32, (nks + steps // 2) // steps))
@@ -157,14 +159,14 @@ class GemmPlanner:
                 if per * 4 > cap:
                     raise capi.ErcGraftError("wgrad table: K=%d needs more than 32 splits" % K)
                 tm, tn = -(-M // 64), -(-N // 64)
-                vec = (1 if (M % 4 == 0 and lda % 4 == 0 and a.data_ptr() % 16 == 0) else 0) \
+                vec = (1 if (M % 4 == 0 and lda % 4 == 0 and a.data_ptr() % (8 if a_bf16 else 16) == 0) else 0) \
                     | (2 if (N % 4 == 0 and ldb % 4 == 0 and b.data_ptr() % (8 if bf16 else 16) == 0) else 0) \
                     | (4 if (N % 4 == 0 and ldc % 4 == 0 and c.data_ptr() % 16 == 0) else 0)
                 n_it = tm * tn * splits
-                raw.append(struct.pack("<QQQQQ14if4x", a.data_ptr(), b.data_ptr(), c.data_ptr(),
+                raw.append(struct.pack("<QQQQQ14ifi", a.data_ptr(), b.data_ptr(), c.data_ptr(),
                                        bo.data_ptr() if bo is not None else 0, g.data_ptr() if g is not None else 0,
                                        lda, ldb, ldc, M, N, K, ones if bo is not None else 0, int(bf16), splits, tn,
-                                       items, n_it, tiles, vec, sc))
+                                       items, n_it, tiles, vec, sc, int(a_bf16)))
                 bases.append(items)
                 items += n_it
                 tiles += tm * tn
@@ -309,6 +311,7 @@ class FusedAdam:
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.norm_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.shadow = None   # (bf16 tensor, offset, numel): kept in sync with the fp32 master weights by the step
+        self.shadow_table = None   # capi.ShadowTable: several bf16 ranges / layouts written by the same launch
         self.skip_flag = None  # device int32: non-zero = this step's gradients are invalid, the kernel skips the update
 
     @property
@@ -319,6 +322,12 @@ class FusedAdam:
         f = self.flat
         if self.clip_norm > 0:
             capi.grad_norm(f.grad, f.numel, grad_scale, self.gnorm, self.norm_ws)
+        if self.shadow_table is not None:
+            capi.adam_step_tab(f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, self.lr, self.betas[0], self.betas[1],
+                               self.eps, self.weight_decay, self.decoupled, grad_scale, self.clip_norm,
+                               self.gnorm if self.clip_norm > 0 else None, self.state, self.shadow_table,
+                               skip_flag=self.skip_flag)
+            return
         capi.adam_step(f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, self.lr, self.betas[0], self.betas[1],
                        self.eps, self.weight_decay, self.decoupled, grad_scale, self.clip_norm,
                        self.gnorm if self.clip_norm > 0 else None, self.state,

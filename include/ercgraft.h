@@ -119,9 +119,10 @@ int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_
  * C_i[M_i,N_i] = A_i^T B_i[gather_i] in ONE launch.  A_i [K,M_i] fp32 K-major; B_i [*,N_i] K-major, fp32 or bf16 (the
  * feature block), optionally row-gathered; bias strip: ones = 1 -> bias_out[m] = sum_k A[k][m], ones = 2 ->
  * bias_out[n] = sum_k B[k][n].  64 x 64 tiles, K split over `splits` workgroups per tile; partial tiles are summed in
- * split order by the last-arriving workgroup (deterministic).  `table` is a device array of n_desc 96-byte records
+ * split order by the last-arriving workgroup (deterministic).  `table` is a device array of n_desc 104-byte records
  *   { const float* A; const void* B; float* C; float* bias_out; const int32_t* b_gather;
- *     int32 lda, ldb, ldc, M, N, K, ones, b_bf16, splits, tiles_n, item_base, n_items, tile_base, vec; }
+ *     int32 lda, ldb, ldc, M, N, K, ones, b_bf16, splits, tiles_n, item_base, n_items, tile_base, vec;
+ *     float scale (C = scale A^T B); int32 a_bf16 (A is bf16 -- with an fp32 B only); }
  * with tiles_n = ceil(N/64), n_items = ceil(M/64)*tiles_n*splits, item_base / tile_base = running sums over the
  * previous records, ceil(ceil(K/4)/splits)*4 <= erc_wgrad_max_k_per_split(), no empty split, and vec bit0/1/2 set
  * when 16-byte (bf16: 8-byte) vector access to A / B / C is legal (M resp. N, the pitch and the base all multiples of
@@ -359,6 +360,64 @@ int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
                   float grad_scale, float clip_norm, const float* gnorm, int64_t* state,
                   void* bf16_shadow, int64_t shadow_off, int64_t shadow_n, const int32_t* skip_flag, void* stream);
+/* COGMEN graph part, bf16 compute mode, as row-tile kernels (csrc/cogmen_fused.hip): GNN.forward of
+ * track_mm/cogmen.py:61-74 -- torch_geometric RGCNConv(100,100,8 relations, mean) -> TransformerConv(100,100,heads=1)
+ * (cogmen.py:65-66,71-72) up to the input of BatchNorm1d (cogmen.py:67) -- in one launch, and its backward in one.
+ * The window graph (cogmen.py:153-154: wp = wf = 5) lets a tile of 16 nodes work from a halo of +-5 (forward) / +-15
+ * (backward) rows; wp, wf <= 5 is required.  Dense products on v_mfma_f32_16x16x32_bf16, fp32 accumulate; weights
+ * are read from bf16 shadows (ErcShadowTab below) in these layouts (zero padded):
+ *   WcatT [112][928]: WcatT[o][r*100 + c] = conv1.weight[r][c][o], r = 8 -> conv1.root[c][o]
+ *   Wq    [400][128]: rows = [lin_query; lin_key; lin_value; lin_skip].weight, K padded 100 -> 128
+ *   WqT   [112][416]: WqT[c][n] = Wq[n][c]
+ *   Wb    [112][960]: Wb[c][r*104 + o] = conv1.weight[r][c][o] (r = 8: root)
+ * Forward outputs: Mb bf16 [N, ldmb >= 900] = [mean_r H0 | H0] and H1b bf16 [N, ldh1b >= 100] (operands of the weight
+ * gradients), inv_cnt [N,8], QKVS fp32 [N,400], H2 [N, ldh2], alpha [E] (softmax weights per in-edge).
+ * bn_fused != 0: also the training-mode BatchNorm statistics of H2 (saved = mean | rstd, running statistics updated)
+ * by the last workgroup to arrive; bn_ws = erc_cogmen_fwd_tile_ws_doubles(N) doubles, zero before the first call. */
+int64_t erc_cogmen_fwd_tile_ws_doubles(int n_nodes);
+int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int wp, int wf, const int32_t* in_ptr,
+                        const int32_t* in_src, const int32_t* in_typ, const void* WcatT, const float* b1,
+                        const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
+                        int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
+                        float* running_mean, float* running_var, float momentum, float eps, float* saved,
+                        double* bn_ws, void* stream);
+/* Backward of the same: dY [N,100] = dL/d(BatchNorm output) (erc_head_fused), BatchNorm's elementwise backward
+ * (gamma, saved, bn_bwd as erc_bn_bwd_apply), TransformerConv backward (target and source side), dH1 = dQKVS Wq,
+ * the transposed relation means and dH0 = dP [W_r^T].  Outputs fp32: dQKVS [N,400], dH1 [N,100], dH0 [N, lddh0] --
+ * the operands of the weight gradients (cogmen.py:187-188). */
+int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes, int wp, int wf, const float* gamma,
+                        const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
+                        const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                        const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
+                        const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0, void* stream);
+
+/* diagnostic: phase stamps (10 ns ticks) of the middle workgroup of the following erc_cogmen_{fwd,bwd}_tile launches,
+ * 8 x uint64 device memory; NULL switches them off (tools/cogmen_stamps.py) */
+int erc_cogmen_set_stamps(uint64_t* stamps);
+
+/* bf16 shadow ranges maintained by the optimizer launch (bf16 compute mode: the weight operands of the bf16
+ * matrix-core products -- rnn.1.weight of the input projection and the packed / transposed copies the fused COGMEN
+ * kernels read, erc_cogmen_fwd_tile / erc_cogmen_bwd_tile -- stay in sync with the fp32 masters without an extra
+ * launch).  Element i of the flat parameter range [src_off, src_off + n_el), idx = i - src_off, is written as bf16 to
+ *   shadow_base[dst_off + (idx / (n0 n1)) s2 + ((idx / n0) % n1) s1 + (idx % n0) s0]      (all in elements)
+ * so identity copies (n0 = n_el, s0 = 1), transposes and padded / blocked layouts are instances.  The table is a HOST
+ * struct; elements a range never maps to keep whatever the buffer held (zero padding: clear it once). */
+typedef struct ErcShadowDesc {
+    int64_t src_off, n_el, dst_off;
+    int32_t n0, n1, s0, s1, s2, pad;
+} ErcShadowDesc;
+typedef struct ErcShadowTab {
+    int32_t n, pad;            /* descriptors in use, <= 8 */
+    ErcShadowDesc d[8];
+} ErcShadowTab;
+/* erc_adam_step with a shadow table instead of the single identity range. */
+int erc_adam_step_tab(float* p, const float* g, float* m, float* v, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
+                      float grad_scale, float clip_norm, const float* gnorm, int64_t* state,
+                      void* shadow_base, const ErcShadowTab* tab_host, const int32_t* skip_flag, void* stream);
+/* Rebuild every shadow range from the fp32 parameters p[0, n) (after loading a state dict; or per forward when no
+ * optimizer maintains the shadows). */
+int erc_shadow_refresh(const float* p, int64_t n, void* shadow_base, const ErcShadowTab* tab_host, void* stream);
 /* diagnostic: out[0] = shader cycles, out[1] = 10-ns ticks of a fixed dependent-MFMA loop (bench.py --clock_probe) */
 int erc_clock_probe(uint64_t* out, int iters, void* stream);
 /* gnorm[0] = ||g * grad_scale||_2 ; ws >= 1024 floats */

@@ -40,7 +40,7 @@ class GNN(nn.Module):
 
 class COGMENOracle(nn.Module):
     def __init__(self, input_size, hidden_size=100, num_head=17, n_speakers=2,
-                 n_classes=6, dead_encoder=True, chained=False):
+                 n_classes=6, dead_encoder=True, chained=False, bf16_products=False):
         super().__init__()
         self.n_speakers = n_speakers
         self.dead_encoder = dead_encoder
@@ -55,6 +55,9 @@ class COGMENOracle(nn.Module):
         self.gcn = GNN(hidden_size, hidden_size, hidden_size)
         self.cls = nn.Sequential(nn.Linear(100, 100), nn.ReLU(), nn.Dropout(p=0.5),
                                  nn.Linear(100, n_classes))
+        # bf16_products: the graph part's dense products with the operand rounding of the bf16 compute mode
+        # (oracle/pyg.py RoundedLinear / RGCNMeanRounded) -- the same algorithm, rounded where that mode rounds
+        self.gcn.conv1.rounded = self.gcn.conv2.rounded = bool(bf16_products)
 
     def forward(self, input_tensor, speaker_tensor, text_length, *args, **kwargs):
         if self.chained:

@@ -18,6 +18,71 @@ import torch
 from torch import nn
 
 
+def rb(t):
+    """round to bf16 and back: the operand rounding of the bf16 matrix-core products (COGMEN bf16 compute mode)"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class RoundedLinear(torch.autograd.Function):
+    """nn.Linear as the bf16 compute mode evaluates it (csrc/cogmen_fused.hip): y = rb(x) rb(W)^T + b with fp32
+    accumulation; backward dx = rb(dy) rb(W) (bf16 product), dW = dy^T rb(x) (the batched weight-gradient launch keeps
+    dy in fp32 and reads the stored bf16 x), db = colsum(dy).  Not part of the reference: it restates the SAME algorithm
+    with the operand rounding of the mode, so that a parity test isolates implementation error from quantisation."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        xr, Wr = rb(x), rb(W)
+        ctx.save_for_backward(xr, Wr)
+        return xr @ Wr.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, Wr = ctx.saved_tensors
+        return rb(dy) @ Wr, dy.t() @ xr, dy.sum(0)
+
+
+class RGCNMeanRounded(torch.autograd.Function):
+    """RGCNConvMean.forward with the bf16 mode's operand rounding: H1 = rb(M) rb([W_r; root]) + b, M = [mean_r x | x];
+    backward dx = sum_r rb(dP_r) rb(W_r)^T with dP = the transposed means of dH1 (aggregate first, then one product per
+    relation -- the order the fused backward kernel uses), d[W_r; root] = rb(M)^T dH1."""
+
+    @staticmethod
+    def forward(ctx, x, weight, root, bias, src, dst, typ):
+        n, R, F = x.size(0), weight.size(0), x.size(1)
+        M = torch.zeros(n, (R + 1) * F, dtype=x.dtype)
+        inv = torch.zeros(n, R, dtype=x.dtype)
+        for r in range(R):
+            sel = typ == r
+            if not bool(sel.any()):
+                continue
+            s, d = src[sel], dst[sel]
+            cnt = scatter_sum(torch.ones(s.numel(), dtype=x.dtype), d, n)
+            M[:, r * F:(r + 1) * F] = scatter_sum(x[s], d, n) / cnt.clamp(min=1)[:, None]
+            inv[:, r] = torch.where(cnt > 0, 1.0 / cnt.clamp(min=1), torch.zeros_like(cnt))
+        M[:, R * F:] = x
+        Wcat = torch.cat([weight.reshape(R * F, -1), root], 0)
+        Mr, Wr = rb(M), rb(Wcat)
+        ctx.save_for_backward(Mr, Wr, inv, src, dst, typ)
+        ctx.dims = (n, R, F)
+        return Mr @ Wr + bias
+
+    @staticmethod
+    def backward(ctx, dH1):
+        Mr, Wr, inv, src, dst, typ = ctx.saved_tensors
+        n, R, F = ctx.dims
+        dx = torch.zeros(n, F, dtype=dH1.dtype)
+        for r in range(R):
+            sel = typ == r
+            if not bool(sel.any()):
+                continue
+            s, d = src[sel], dst[sel]
+            dP = scatter_sum(dH1[d] * inv[d, r][:, None], s, n)
+            dx = dx + rb(dP) @ Wr[r * F:(r + 1) * F].t()
+        dx = dx + rb(dH1) @ Wr[R * F:].t()
+        dW = Mr.t() @ dH1
+        return dx, dW[:R * F].reshape(R, F, -1), dW[R * F:], dH1.sum(0), None, None, None
+
+
 def scatter_sum(src, index, n):
     out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
     return out.index_add(0, index, src)
@@ -37,6 +102,7 @@ class RGCNConvMean(nn.Module):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.num_relations = num_relations
+        self.rounded = False      # bf16 compute mode's operand rounding (RGCNMeanRounded)
         self.weight = nn.Parameter(torch.empty(num_relations, in_channels, out_channels))
         self.root = nn.Parameter(torch.empty(in_channels, out_channels))
         self.bias = nn.Parameter(torch.zeros(out_channels))
@@ -46,6 +112,8 @@ class RGCNConvMean(nn.Module):
 
     def forward(self, x, edge_index, edge_type):
         n = x.size(0)
+        if self.rounded:
+            return RGCNMeanRounded.apply(x, self.weight, self.root, self.bias, edge_index[0], edge_index[1], edge_type)
         out = torch.zeros(n, self.out_channels, dtype=x.dtype)
         src, dst = edge_index[0], edge_index[1]
         for r in range(self.num_relations):  # per-relation loop, as PyG does
@@ -69,6 +137,7 @@ class TransformerConv1(nn.Module):
     def __init__(self, in_channels, out_channels):
         super().__init__()
         self.out_channels = out_channels
+        self.rounded = False      # bf16 compute mode's operand rounding (RoundedLinear)
         self.lin_key = nn.Linear(in_channels, out_channels)
         self.lin_query = nn.Linear(in_channels, out_channels)
         self.lin_value = nn.Linear(in_channels, out_channels)
@@ -77,7 +146,8 @@ class TransformerConv1(nn.Module):
     def forward(self, x, edge_index):
         n = x.size(0)
         src, dst = edge_index[0], edge_index[1]
-        q, k, v = self.lin_query(x), self.lin_key(x), self.lin_value(x)
+        lin = (lambda m, t: RoundedLinear.apply(t, m.weight, m.bias)) if self.rounded else (lambda m, t: m(t))
+        q, k, v = lin(self.lin_query, x), lin(self.lin_key, x), lin(self.lin_value, x)
         score = (q[dst] * k[src]).sum(-1) / math.sqrt(self.out_channels)
         mx = torch.full((n,), -float("inf"), dtype=x.dtype).scatter_reduce(
             0, dst, score.detach(), reduce="amax", include_self=True)
@@ -85,7 +155,7 @@ class TransformerConv1(nn.Module):
         den = scatter_sum(ex, dst, n)
         alpha = ex / (den[dst] + 1e-16)
         out = scatter_sum(alpha[:, None] * v[src], dst, n)
-        return out + self.lin_skip(x)
+        return out + lin(self.lin_skip, x)
 
 
 class GraphConvAdd(nn.Module):

@@ -40,15 +40,20 @@ def test_cogmen_config2_shape_parity():
 
 
 def test_cogmen_bf16_feature_mode():
-    """bf16 storage of the feature block (config 2's throughput mode).  The oracle is fed the same
-    bf16-rounded features and rnn.1.weight, so what is left is accumulation order (fp32 accumulate on both
-    sides) plus the bf16 rounding of dH0 inside the rnn.1 weight-gradient GEMM (8 significant bits):
-    logits within 1e-3, gradients within 2 % of their scale.  Versus the unrounded fp32 oracle the mode
-    itself moves O(1) logits by up to ~3e-2 -- that is quantisation, not implementation, error."""
+    """bf16 compute mode (config 2's throughput mode): bf16 feature block, bf16 matrix-core products in the input
+    projection and the graph part (csrc/cogmen_fused.hip).  The oracle is fed the same bf16-rounded features and
+    weights and rounds the same product operands (oracle/pyg.py RoundedLinear / RGCNMeanRounded), so what is left is
+    fp32 accumulation order -- and its second-order effect: an fp32 difference in a value that sits on a bf16 rounding
+    boundary rounds the other way (measured at config 2: 0.1 % of the H1 entries, one bf16 step each), which moves
+    single logits by up to ~1e-3 and single gradient entries by ~1 % of the tensor's scale (0.5 % norm-wise).
+    tests/test_gpu_cogmen_fused.py pins every intermediate of the two fused kernels at fp32 tolerance.
+    Versus the unrounded fp32 oracle the mode itself moves O(1) logits by up to ~3e-2: quantisation, not
+    implementation, error."""
     res = run_cogmen_parity(cogmen_case(B=8, min_len=20, max_len=60, dims=dict(a=100, t=768, v=512), seed=6),
                             compute="bf16")
     assert res["logit_err"] < 1e-3, res
-    assert res["grad_err"] < 2e-2, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:8]
+    assert res["grad_err"] < 4e-2, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:8]
+    assert res["grad_norm_err"] < 1.5e-2, res["grad_norm_err"]
 
 
 def test_cogmen_bf16_feature_mode_full_config2():
@@ -57,7 +62,84 @@ def test_cogmen_bf16_feature_mode_full_config2():
     res = run_cogmen_parity(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=16),
                             compute="bf16")
     assert res["logit_err"] < 1e-3, res
+    assert res["grad_err"] < 4e-2, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:8]
+    assert res["grad_norm_err"] < 1.5e-2, res["grad_norm_err"]
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=4, min_len=3, max_len=14, dims=dict(a=12, t=20, v=16), seed=3),
+    dict(B=3, min_len=1, max_len=1, dims=dict(a=4, t=4, v=4), seed=4),          # one-utterance dialogues: self loops only
+    dict(B=9, min_len=1, max_len=30, dims=dict(a=100, t=100, v=512), seed=5),   # ragged, tiles straddle dialogues
+    dict(B=2, min_len=16, max_len=16, dims=dict(a=12, t=20, v=16), seed=8),     # dialogue length == tile height
+    dict(B=5, min_len=33, max_len=47, dims=dict(a=12, t=20, v=16), seed=9),
+], ids=["tiny", "one-utt", "ragged", "len16", "mid"])
+def test_cogmen_bf16_fused_graph_kernels(case, monkeypatch):
+    """bf16 compute mode runs the graph part as the two row-tile kernels of csrc/cogmen_fused.hip (halo tiles, bf16
+    matrix cores).  Checked against the oracle with the same operand rounding (oracle/pyg.py RoundedLinear /
+    RGCNMeanRounded) on shapes that exercise the tile / halo / dialogue-boundary logic; LDS is poisoned with NaN
+    patterns before both kernels so that a read of an unwritten pad shows."""
+    from tests.util_cases import poison_lds_before
+    poison_lds_before(monkeypatch, "cogmen_fwd_tile", "cogmen_bwd_tile")
+    # (one-utterance dialogues: conv1.bias is a constant shift in front of BatchNorm only up to the bf16 rounding of H1)
+    res = run_cogmen_parity(cogmen_case(**case), compute="bf16",
+                            zero_grad=("gcn.conv1.bias",) if case["max_len"] == 1 else (), zero_tol=2e-2)
+    assert res["logit_err"] < 1e-3, res
+    assert res["loss_err"] < 1e-4, res
     assert res["grad_err"] < 2e-2, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:8]
+    assert res["bn_mean_err"] < 1e-4 and res["bn_var_err"] < 1e-4, res
+
+
+def test_cogmen_bf16_fused_equals_unfused_bf16_storage_mode():
+    """The fused graph kernels against the SAME module with them switched off (fp32 kernels on the bf16 feature block):
+    the two differ only by the bf16 rounding of the graph part's product operands."""
+    from erc_amd.cogmen import COGMENModule
+    case = cogmen_case(B=8, min_len=20, max_len=60, dims=dict(a=100, t=768, v=512), seed=6)
+    torch.manual_seed(2)
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(5)
+        m = COGMENModule(case["D"], 100, 17, 2, 6, compute="bf16").finalize("cuda:0")
+        m.use_fused_graph = fused
+        m.train()
+        m.drop_p = 0.0
+        b = to_device(case["batch"], "cuda:0")
+        b["input_tensor"] = b["input_tensor"].to(torch.bfloat16)
+        stats = m.loss_and_grads(b).cpu()
+        outs.append((float(stats[0]), m.flat.grad.clone(), m._last_ws["H2"].clone()))
+    assert abs(outs[0][0] - outs[1][0]) < 2e-2
+    assert float((outs[0][2] - outs[1][2]).abs().max()) < 5e-2
+    g0, g1 = outs[0][1], outs[1][1]
+    assert float((g0 - g1).norm() / g1.norm()) < 0.12    # quantisation of the mode (a sanity bound, not parity)
+
+
+def test_bf16_shadow_table_tracks_master_weights():
+    """Every bf16 weight copy of the bf16 mode (ErcShadowTab: W1, WcatT, Wb, Wq, WqT) is written by the optimizer launch
+    and stays bit-identical to packing the rounded fp32 masters."""
+    from erc_amd.cogmen import COGMENTrainer
+    from erc_amd.params import ERCParams
+    p = ERCParams().from_args(["--dataset=iemocap-cogmen-sbert-6", "--compute=bf16", "--optim.lr=0.01"])
+    tr = COGMENTrainer(p, "cuda:0")
+    m = tr.model
+    assert m.shadows is not None and not m._shadow_auto
+    case = cogmen_case(B=6, min_len=5, max_len=25, dims=dict(a=100, t=768, v=512), seed=2)
+    b = tr.prepare_batch(case["batch"])
+    for _ in range(3):
+        tr.train_step(b)
+    after_steps = m.shadows.buf.clone()
+    m.refresh_shadows()
+    assert torch.equal(after_steps.view(torch.int16), m.shadows.buf.view(torch.int16))
+    F = 100
+    wcat = torch.cat([m.flat.w("gcn.conv1.weight").reshape(8 * F, F), m.flat.w("gcn.conv1.root")], 0).to(torch.bfloat16)
+    catT = m._sh["catT"].view(112, 928)
+    assert torch.equal(catT[:F, :900].view(torch.int16), wcat.t().contiguous().view(torch.int16))
+    assert float(catT[F:].float().abs().max()) == 0 and float(catT[:, 900:].float().abs().max()) == 0
+    wb = m._sh["wb"].view(112, 960)
+    for r in (0, 3, 8):
+        blk = wcat[r * F:(r + 1) * F]                     # W_r [c][o]
+        assert torch.equal(wb[:F, r * 104:r * 104 + F].contiguous().view(torch.int16), blk.contiguous().view(torch.int16))
+    wq = torch.cat([m.flat.w("gcn.conv2.lin_%s.weight" % n) for n in ("query", "key", "value", "skip")], 0).to(torch.bfloat16)
+    assert torch.equal(m._sh["q"].view(400, 128)[:, :F].contiguous().view(torch.int16), wq.contiguous().view(torch.int16))
+    assert torch.equal(m._sh["qT"].view(112, 416)[:F, :400].contiguous().view(torch.int16), wq.t().contiguous().view(torch.int16))
 
 
 def test_cogmen_train_step_matches_torch_adam():
