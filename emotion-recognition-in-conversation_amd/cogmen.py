@@ -91,6 +91,7 @@ class COGMENModule(nn.Module):
         self.cls = nn.Sequential(nn.Linear(100, 100), nn.ReLU(), nn.Dropout(p=0.5), nn.Linear(100, n_classes))
         self.drop_p = 0.5
         self.use_fused_graph = False   # set by finalize() in bf16 mode
+        self.wgrad_bf16 = True         # bf16 mode: the graph part's and the projection's weight gradients on bf16 matrix cores
         self.fuse_head = True   # training path: csrc/head.hip instead of separate BN / Linear / CE launches
         self.flat = None
         self._ws = WorkspaceCache()
@@ -390,12 +391,14 @@ class COGMENModule(nn.Module):
         capi.cogmen_bwd_tile(ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"],
                              ws["QKVS"], ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F),
                              ws["dQKVS"], ws["dH1"], ws["dH0"], F)
+        pl.mma_bf16 = self.wgrad_bf16     # these three products on bf16 matrix cores (the head's stay fp32)
         linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1b"], 104, None, 4 * F, F, N,
                      fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"], defer=True)
         matmul_wgrad_io(pl, ws["Mb"], 904, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
                         fp.offsets["gcn.conv1.bias"], defer=True)
         linear_wgrad(pl, ws["dH0"], F, x, D, g["node_row"], F, D, N, fp.offsets["rnn.1.weight"],
                      fp.offsets["rnn.1.bias"], x_bf16=x_bf16, defer=True)
+        pl.mma_bf16 = False
         pl.reduce_into(ws, fp.grad)
 
     def sync_buffers(self, optimizer_steps):

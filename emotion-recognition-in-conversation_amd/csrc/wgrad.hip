@@ -20,6 +20,8 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // Pointers read from the descriptor table are generic to the compiler: without the explicit global address space it
 // emits flat_load, which also counts on lgkmcnt and so serialises with the LDS reads of the gather stage.
 #define ERC_GLOBAL __attribute__((address_space(1)))
@@ -34,7 +36,7 @@ constexpr int WG_IDX_CAP = 2048;   // k per split (row-gather stage in LDS)
 constexpr int WG_SLAB = 4096 + 64; // floats per partial tile: 64 x 64 + one bias strip
 constexpr int WG_MAX_DESC = 32;
 
-struct WgDesc {  // 104 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQQQQ14ifi")
+struct WgDesc {  // 112 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQQQQ14ifii4x")
     const float* A;
     const void* B;
     float* C;
@@ -44,6 +46,7 @@ struct WgDesc {  // 104 bytes; mirrored by engine.GemmPlanner.flush_wgrads ("<QQ
     int ones, b_bf16, splits, tiles_n, item_base, n_items, tile_base, vec;  // vec: bit0 A, bit1 B, bit2 C 16-byte ok
     float scale;              // the product is stored as scale * A^T B (GCNII: dW_l = theta_l dV_l); bias strips are not scaled
     int a_bf16;               // A is bf16 (the relation-mean tile the fused COGMEN forward stores); lda in elements
+    int mma_bf16;             // bf16 compute mode: both operands rounded to bf16, v_mfma_f32_16x16x32_bf16 (fp32 accumulate; bias strips stay fp32 sums)
 };
 
 // Cross-workgroup hand-off of the partial tiles WITHOUT fences (an agent-scope release/acquire fence pair costs
@@ -59,7 +62,17 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 
 // VEC (16-byte operand loads legal for BOTH operands) is compile-time: a runtime flag around a load makes hipcc
 // branch and drain vmcnt per load.
-template <bool ABF, bool BF16, bool VEC>
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// MB: bf16 matrix cores.  v_mfma_f32_16x16x32_bf16 sums over 32 (g, slot) pairs, 8 slots per lane; the load pattern
+// stays the one above (one 16-byte load = four neighbouring output rows for ONE k), so a lane fills its 8 slots from 8
+// consecutive k-steps of its wavefront -- slot j of lane (r, g) holds k-step j's k = 4 ks + g for both operands, which is
+// all the instruction needs (any assignment of k to slots works as long as A and B agree).  16 MFMAs of 16 cycles per 8
+// k-steps instead of 128 of 32 cycles; the accumulator layout, and with it the whole epilogue, is unchanged.
+template <bool ABF, bool BF16, bool VEC, bool MB>
 __device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, float* red, float* bred, int* idx,
                                            int* s_flag, float* slabs, int* counters) {
     const gfloat_cp A = (gfloat_cp)d.A;
@@ -162,7 +175,49 @@ __device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, flo
     // wavefront w takes k-steps ks_begin + w + 4 s; batches of WG_U steps, the next batch's loads issued before
     // the current batch's MFMAs
     const int ns = (max(0, ks_end - ks_begin) + 3) >> 2;
-    if (ns > 0) {
+    if (MB) {
+        // groups of 8 steps = one MFMA per (i, j); loaded four steps at a time (the second half's loads are in flight
+        // while the first half is rounded and packed)
+        for (int s0 = 0; s0 < ns; s0 += 8) {
+            float xa[4][4], xb[4][4], xk[4], ya[4][4], yb[4][4], yk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load(ks_begin + w + 4 * (s0 + u), xa[u], xb[u], xk[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load(ks_begin + w + 4 * (s0 + 4 + u), ya[u], yb[u], yk[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 fa[4], fb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xa[u][i] *= xk[u], xb[u][i] *= xk[u];
+                    bsa[i] += xa[u][i], bsb[i] += xb[u][i];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i][0] = pack_bf16x2(xa[0][i], xa[1][i]), fa[i][1] = pack_bf16x2(xa[2][i], xa[3][i]);
+                fb[i][0] = pack_bf16x2(xb[0][i], xb[1][i]), fb[i][1] = pack_bf16x2(xb[2][i], xb[3][i]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ya[u][i] *= yk[u], yb[u][i] *= yk[u];
+                    bsa[i] += ya[u][i], bsb[i] += yb[u][i];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i][2] = pack_bf16x2(ya[0][i], ya[1][i]), fa[i][3] = pack_bf16x2(ya[2][i], ya[3][i]);
+                fb[i][2] = pack_bf16x2(yb[0][i], yb[1][i]), fb[i][3] = pack_bf16x2(yb[2][i], yb[3][i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                        acc[i][j], 0, 0, 0);
+        }
+    } else if (ns > 0) {
         // software pipeline without a conditional around any load (hipcc drains vmcnt at the end of a conditional
         // block that holds loads): batch b+1 is loaded unconditionally, batch b multiplied, registers rotated
         float xa[WG_U][4], xb[WG_U][4], xk[WG_U];
@@ -324,15 +379,19 @@ __global__ __launch_bounds__(256, 3) void wgrad_table_kernel(const WgDesc* __res
     const int local = L - d.item_base;
     if (local >= d.n_items) return;
     const bool vec = (d.vec & 3) == 3;
-    if (d.a_bf16) {   // bf16 A with an fp32 B (COGMEN bf16 mode: d[W_r ; W_root] = M^T dH1)
-        if (vec) wgrad_body<true, false, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<true, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+    if (d.mma_bf16) {   // bf16 matrix cores (COGMEN bf16 compute mode); vector access is a host contract there
+        if (d.a_bf16) wgrad_body<true, false, true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else if (d.b_bf16) wgrad_body<false, true, true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<false, false, true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+    } else if (d.a_bf16) {   // bf16 A with an fp32 B (COGMEN bf16 mode: d[W_r ; W_root] = M^T dH1)
+        if (vec) wgrad_body<true, false, true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<true, false, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
     } else if (d.b_bf16) {
-        if (vec) wgrad_body<false, true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<false, true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        if (vec) wgrad_body<false, true, true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<false, true, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
     } else {
-        if (vec) wgrad_body<false, false, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<false, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        if (vec) wgrad_body<false, false, true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        else wgrad_body<false, false, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
     }
 }
 

@@ -126,9 +126,12 @@ class GemmPlanner:
         self.max_numel = 0
         self.deferred = []     # (A, lda, B, ldb, C, ldc, M, N, K, ones, bias_out): one batched launch at the end
 
-    def defer(self, A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather=None, scale=1.0):
+    mma_bf16 = False   # bf16 compute mode: deferred weight gradients on bf16 matrix cores (operands rounded, fp32 accumulate)
+
+    def defer(self, A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather=None, scale=1.0, mma_bf16=None):
         """C[M,N] = scale * A[K,M]^T B[gather(K),N] (+ bias strip); B may be the bf16 feature block."""
-        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather, float(scale)))
+        mb = self.mma_bf16 if mma_bf16 is None else mma_bf16
+        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather, float(scale), bool(mb)))
 
     WG_STEPS = 64   # k-steps (4 k each) per work item: 16 per wavefront (measured best of 48..128 on COGMEN B=32)
 
@@ -139,13 +142,13 @@ class GemmPlanner:
         if not self.deferred:
             return
         import struct
-        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, g.data_ptr() if g is not None else 0, sc)
-                    for a, _, b, _, c, _, M, N, K, _, _, g, sc in self.deferred)
+        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, g.data_ptr() if g is not None else 0, sc, mb)
+                    for a, _, b, _, c, _, M, N, K, _, _, g, sc, mb in self.deferred)
         if cache.get("wgrad_key") != key:
             cap = capi.wgrad_max_k_per_split()
             raw, items, tiles, bases = [], 0, 0, []
             steps = int(os.environ.get("ERC_WG_STEPS", self.WG_STEPS))
-            for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g, sc in self.deferred:
+            for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g, sc, mb in self.deferred:
                 bf16 = b.dtype == torch.bfloat16
                 a_bf16 = a.dtype == torch.bfloat16
                 if (not a_bf16 and a.dtype != torch.float32) or c.dtype != torch.float32 or \
@@ -163,10 +166,12 @@ class GemmPlanner:
                     | (2 if (N % 4 == 0 and ldb % 4 == 0 and b.data_ptr() % (8 if bf16 else 16) == 0) else 0) \
                     | (4 if (N % 4 == 0 and ldc % 4 == 0 and c.data_ptr() % 16 == 0) else 0)
                 n_it = tm * tn * splits
-                raw.append(struct.pack("<QQQQQ14ifi", a.data_ptr(), b.data_ptr(), c.data_ptr(),
+                if mb and (vec & 3) != 3:
+                    mb = False      # the bf16 matrix-core path needs vector access to both operands
+                raw.append(struct.pack("<QQQQQ14ifii4x", a.data_ptr(), b.data_ptr(), c.data_ptr(),
                                        bo.data_ptr() if bo is not None else 0, g.data_ptr() if g is not None else 0,
                                        lda, ldb, ldc, M, N, K, ones if bo is not None else 0, int(bf16), splits, tn,
-                                       items, n_it, tiles, vec, sc, int(a_bf16)))
+                                       items, n_it, tiles, vec, sc, int(a_bf16), int(mb)))
                 bases.append(items)
                 items += n_it
                 tiles += tm * tn

@@ -25,8 +25,8 @@ def rb(t):
 
 class RoundedLinear(torch.autograd.Function):
     """nn.Linear as the bf16 compute mode evaluates it (csrc/cogmen_fused.hip): y = rb(x) rb(W)^T + b with fp32
-    accumulation; backward dx = rb(dy) rb(W) (bf16 product), dW = dy^T rb(x) (the batched weight-gradient launch keeps
-    dy in fp32 and reads the stored bf16 x), db = colsum(dy).  Not part of the reference: it restates the SAME algorithm
+    accumulation; backward dx = rb(dy) rb(W) (bf16 product), dW = rb(dy)^T rb(x) (the batched weight-gradient launch
+    runs on bf16 matrix cores in this mode: both operands rounded, fp32 accumulate), db = colsum(dy) in fp32.  Not part of the reference: it restates the SAME algorithm
     with the operand rounding of the mode, so that a parity test isolates implementation error from quantisation."""
 
     @staticmethod
@@ -38,13 +38,14 @@ class RoundedLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xr, Wr = ctx.saved_tensors
-        return rb(dy) @ Wr, dy.t() @ xr, dy.sum(0)
+        dyr = rb(dy)
+        return dyr @ Wr, dyr.t() @ xr, dy.sum(0)
 
 
 class RGCNMeanRounded(torch.autograd.Function):
     """RGCNConvMean.forward with the bf16 mode's operand rounding: H1 = rb(M) rb([W_r; root]) + b, M = [mean_r x | x];
     backward dx = sum_r rb(dP_r) rb(W_r)^T with dP = the transposed means of dH1 (aggregate first, then one product per
-    relation -- the order the fused backward kernel uses), d[W_r; root] = rb(M)^T dH1."""
+    relation -- the order the fused backward kernel uses), d[W_r; root] = rb(M)^T rb(dH1)."""
 
     @staticmethod
     def forward(ctx, x, weight, root, bias, src, dst, typ):
@@ -79,7 +80,7 @@ class RGCNMeanRounded(torch.autograd.Function):
             dP = scatter_sum(dH1[d] * inv[d, r][:, None], s, n)
             dx = dx + rb(dP) @ Wr[r * F:(r + 1) * F].t()
         dx = dx + rb(dH1) @ Wr[R * F:].t()
-        dW = Mr.t() @ dH1
+        dW = Mr.t() @ rb(dH1)
         return dx, dW[:R * F].reshape(R, F, -1), dW[R * F:], dH1.sum(0), None, None, None
 
 
