@@ -323,23 +323,25 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_no
 
 class ShadowTable:
     """Host mirror of ErcShadowTab (ercgraft.h): bf16 shadow ranges of the flat parameter buffer, all inside ONE bf16
-    buffer.  ``add`` returns the view of the new range's destination block."""
+    buffer.  ``add`` returns the index of the new range (``view(i)`` = its destination block)."""
 
     MAX = 8
 
     def __init__(self, device):
         self.device = device
-        self.descs = []          # (src_off, n_el, dst_off, n0, n1, s0, s1, s2)
+        self.descs = []
         self.sizes = []
         self.numel = 0
         self.buf = None
         self._packed = None
 
-    def add(self, src_off, n_el, dst_numel, n0, n1, s0, s1, s2):
+    def add(self, src_off, n_el, dst_numel, n0, n1, sn, sk, ld, mode):
+        """digits (idx % n0, (idx / n0) % n1, idx / (n0 n1)) -> n = digits . sn, k = digits . sk; mode 0 row-major [n][ld],
+        mode 1 MFMA B-fragment order with ld K blocks."""
         if self.buf is not None or len(self.descs) == self.MAX:
             raise ErcGraftError("shadow table is sealed or full")
         dst_off = (self.numel + 63) // 64 * 64       # 128-byte aligned blocks
-        self.descs.append((src_off, n_el, dst_off, n0, n1, s0, s1, s2))
+        self.descs.append((src_off, n_el, dst_off, n0, n1) + tuple(sn) + tuple(sk) + (ld, mode))
         self.sizes.append(dst_numel)
         self.numel = dst_off + dst_numel
         return len(self.descs) - 1
@@ -349,8 +351,8 @@ class ShadowTable:
         self.buf = torch.zeros(self.numel + 64, dtype=torch.bfloat16, device=self.device)
         raw = struct.pack("<ii", len(self.descs), 0)
         for d in self.descs:
-            raw += struct.pack("<qqq6i", d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], 0)
-        raw += b"\0" * (8 + 48 * self.MAX - len(raw))
+            raw += struct.pack("<qqq10i", *d)
+        raw += b"\0" * (8 + 64 * self.MAX - len(raw))
         self._packed = C.create_string_buffer(raw, len(raw))
         return self
 
@@ -361,6 +363,16 @@ class ShadowTable:
     @property
     def tab_ptr(self):
         return C.addressof(self._packed)
+
+
+def mfma_b_fragment_order(W, n_kblocks):
+    """Reference packing of a logical B operand W [n][k] (torch tensor) into ErcShadowTab mode 1 order (tests)."""
+    n, k = W.shape
+    nt = (n + 15) // 16
+    P = torch.zeros(nt * 16, n_kblocks * 32, dtype=W.dtype, device=W.device)
+    P[:n, :k] = W
+    # [ct][r][kb][g][j] -> [ct][kb][g][r][j]
+    return P.view(nt, 16, n_kblocks, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
 
 
 def adam_step_tab(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_norm, gnorm, state, table, skip_flag=None):

@@ -146,11 +146,12 @@ class COGMENModule(nn.Module):
         off_cat, off_q = fp.offsets["gcn.conv1.weight"], fp.offsets["gcn.conv2.lin_query.weight"]
         assert fp.offsets["gcn.conv1.root"] == off_cat + N_REL * F * F
         assert fp.offsets["gcn.conv2.lin_skip.weight"] == off_q + 3 * F * F
-        i_w1 = t.add(fp.offsets["rnn.1.weight"], F * D, F * D, F * D, 1, 1, 0, 0)
-        i_catT = t.add(off_cat, 9 * F * F, 112 * 928, F, 9 * F, 928, 1, 0)     # WcatT[o][r*100+c]
-        i_wb = t.add(off_cat, 9 * F * F, 112 * 960, F, F, 1, 960, 104)         # Wb[c][r*104+o]
-        i_q = t.add(off_q, 4 * F * F, 400 * 128, F, 4 * F, 1, 128, 0)          # Wq[n][k]
-        i_qT = t.add(off_q, 4 * F * F, 112 * 416, F, 4 * F, 416, 1, 0)         # WqT[k][n]
+        i_w1 = t.add(fp.offsets["rnn.1.weight"], F * D, F * D, D, F, (0, 1, 0), (1, 0, 0), D, 0)            # row-major copy
+        # logical [n][k] operands in MFMA B-fragment order (ercgraft.h, mode 1)
+        i_catT = t.add(off_cat, 9 * F * F, 7 * 29 * 512, F, 9 * F, (1, 0, 0), (0, 1, 0), 29, 1)           # WcatT[o][r*100+c]
+        i_wb = t.add(off_cat, 9 * F * F, 7 * 30 * 512, F, F, (0, 1, 0), (1, 0, 104), 30, 1)               # Wb[c][r*104+o]
+        i_q = t.add(off_q, 4 * F * F, 25 * 4 * 512, F, 4 * F, (0, 1, 0), (1, 0, 0), 4, 1)                 # Wq[n][k]
+        i_qT = t.add(off_q, 4 * F * F, 7 * 13 * 512, F, 4 * F, (1, 0, 0), (0, 1, 0), 13, 1)               # WqT[k][n]
         t.seal()
         self.shadows = t
         self._sh = dict(w1=t.view(i_w1).view(F, D), catT=t.view(i_catT), wb=t.view(i_wb), q=t.view(i_q), qT=t.view(i_qT))

@@ -14,7 +14,9 @@
 //
 // The dense products run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: A fragments from the LDS tile
 // (ds_read_b128, rows 16-byte aligned), B fragments straight from bf16 shadow copies of the weights that the optimizer
-// launch keeps in sync (erc_adam_step_tab) in the [n][k] layouts the fragments want:
+// launch keeps in sync (erc_adam_step_tab), stored in the fragment order of the instruction's B operand (ErcShadowTab
+// mode 1: the 512 elements of a (16-column tile, 32-deep K block) are contiguous, so a wavefront's fragment load is one
+// 1 KB run) -- logical operands [n][k]:
 //   WcatT [112][928]  WcatT[o][r*100+c] = W_r[c][o]  (r = 8: root)       H1 = M Wcat
 //   Wq    [400][128]  the [q;k;v;skip] Linear weights, K padded           QKVS = H1 Wq^T
 //   WqT   [112][416]  WqT[c][n] = Wq[n][c]                                dH1 = dQKVS Wq
@@ -116,9 +118,9 @@ struct CgFwdP {
     const int32_t* in_ptr;         // CSR by target
     const int32_t* in_src;
     const int32_t* in_typ;
-    const unsigned short* WcatT;   // bf16 [112][928]
+    const unsigned short* WcatT;   // bf16, fragment order (7 column tiles x 29 K blocks x 512)
     const float* b1;               // conv1.bias [100]
-    const unsigned short* Wq;      // bf16 [400][128]
+    const unsigned short* Wq;      // bf16, fragment order (25 x 4 x 512)
     const float* bq;               // [400]
     unsigned short* Mb;            // out bf16 [N, ldmb]: the relation means | self (operand of the weight gradient)
     float* inv_cnt;                // out [N, 8]
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     const int ct = w & 7, kh = w >> 3;
     const bool mma_wave = ct < CG_NT;
     constexpr int NKB = CG_KMP / 32, KH0 = 15;      // 29 blocks: 15 + 14
-    const unsigned short* const brow = p.WcatT + (int64_t)min(16 * min(ct, CG_NT - 1) + r, CG_F - 1) * CG_KMP + 8 * g + 32 * KH0 * kh;   // padded columns (>= 100, never stored) re-read row 99
+    const unsigned short* const brow = p.WcatT + ((int64_t)(min(ct, CG_NT - 1) * NKB + KH0 * kh) * 64 + lane) * 8;   // fragment (ct, kb) = 512 contiguous elements
     const int nkb = kh ? NKB - KH0 : KH0;       // 14 | 15
     {
         if (tid < CG_OUT * 25) {
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     __builtin_amdgcn_sched_barrier(0);   // the tile / graph loads above are queued first
     bf16x8 bx[KH0];
 #pragma unroll
-    for (int u = 0; u < KH0; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow + 32 * min(u, nkb - 1));
+    for (int u = 0; u < KH0; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow + 512 * min(u, nkb - 1));
     __syncthreads();
     CG_STAMP(1);
 
@@ -287,9 +289,9 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int qt = min(w + 16 * j, 24);
-        const unsigned short* const bq = p.Wq + (int64_t)(16 * qt + r) * 128 + 8 * g;
+        const unsigned short* const bq = p.Wq + ((int64_t)qt * 4 * 64 + lane) * 8;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) fq[j][kb] = *reinterpret_cast<const bf16x8*>(bq + 32 * kb);
+        for (int kb = 0; kb < 4; ++kb) fq[j][kb] = *reinterpret_cast<const bf16x8*>(bq + 512 * kb);
         qbias[j] = p.bq[16 * qt + r];
     }
     __syncthreads();
@@ -507,8 +509,8 @@ struct CgBwdP {
     const int32_t* out_typ;
     const int32_t* out_eid;
     const float* inv_cnt;          // [N, 8]
-    const unsigned short* WqT;     // bf16 [112][416]
-    const unsigned short* Wb;      // bf16 [112][960]
+    const unsigned short* WqT;     // bf16, fragment order (7 x 13 x 512)
+    const unsigned short* Wb;      // bf16, fragment order (7 x 30 x 512)
     float* dQKVS;                  // out [N, 400]
     float* dH1;                    // out [N, F]
     float* dH0;                    // out [N, lddh0]
@@ -688,10 +690,10 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     CG_STAMP(2);
 
     // B fragments of the dH1 product (K = 416: blocks [7 kh, 7 kh + 7), the second half has 6): requested now
-    const unsigned short* const brow3 = p.WqT + (int64_t)min(16 * min(ct, CG_NT - 1) + r, CG_F - 1) * 416 + 8 * g + 32 * 7 * kh;
+    const unsigned short* const brow3 = p.WqT + ((int64_t)(min(ct, CG_NT - 1) * 13 + 7 * kh) * 64 + lane) * 8;
     bf16x8 fb3[7];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) fb3[u] = *reinterpret_cast<const bf16x8*>(brow3 + 32 * min(u, kh ? 5 : 6));
+    for (int u = 0; u < 7; ++u) fb3[u] = *reinterpret_cast<const bf16x8*>(brow3 + 512 * min(u, kh ? 5 : 6));
 
     // ---- stage 2: source side for the 26 mid rows: dk = sum ds q_target, dv = sum alpha dH2_target over the out-edges
 #pragma unroll 1
@@ -781,10 +783,10 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     CG_STAMP(4);
 
     // B fragments of the dH0 product (K = 960: blocks [15 kh, 15 kh + 15)): requested now
-    const unsigned short* const brow5 = p.Wb + (int64_t)min(16 * min(ct, CG_NT - 1) + r, CG_F - 1) * CG_KBP + 8 * g + 32 * 15 * kh;
+    const unsigned short* const brow5 = p.Wb + ((int64_t)(min(ct, CG_NT - 1) * 30 + 15 * kh) * 64 + lane) * 8;
     bf16x8 bx[15];
 #pragma unroll
-    for (int u = 0; u < 15; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow5 + 32 * u);
+    for (int u = 0; u < 15; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow5 + 512 * u);
 
     // ---- stage 4: dP = transposed relation means of dH1 for the 16 own rows (one per wavefront): block r of row j
     //      = sum over out-edges (j -> i, relation r) of dH1[i] / count_r(i); block 8 = dH1[j].  Scalar-branch

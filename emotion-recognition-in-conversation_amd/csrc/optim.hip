@@ -20,37 +20,55 @@ namespace {
 
 // bf16 shadow copies of parameter ranges (operands of the bf16 matrix-core products), written by the optimizer
 // kernel itself so that no extra launch keeps them in sync.  Element i of [src_off, src_off + n_el) of the flat
-// buffer, idx = i - src_off, goes to shadow[dst_off + (idx / (n0 n1)) s2 + ((idx / n0) % n1) s1 + (idx % n0) s0]:
-// identity copies, transposes and padded / blocked layouts are all instances (strides in elements).
+// buffer, idx = i - src_off, is split into digits d0 = idx % n0, d1 = (idx / n0) % n1, d2 = idx / (n0 n1); the digits
+// give the element's coordinates in the LOGICAL B operand of its product, n = sum d_i sn_i (output column) and
+// k = sum d_i sk_i (reduction index), and the layout places it:
+//   mode 0: shadow[dst_off + n * ld + k]                                   (row-major [n][k]: identity copies)
+//   mode 1: the fragment order of v_mfma_f32_16x16x32_bf16's B operand, ld = number of 32-deep K blocks: the 512
+//           elements of (column tile n / 16, K block k / 32) are contiguous, lane (r = n % 16, g = (k % 32) / 8) at
+//           [(g * 16 + r) * 8, +8) -- a wavefront's fragment load is ONE contiguous 1 KB run (8 full cache lines;
+//           the row-major layout cost 16 half-used lines per load and the L1 miss path, not bytes, set the time).
 struct ShadowDesc {
     int64_t src_off, n_el, dst_off;
-    int32_t n0, n1, s0, s1, s2, pad;
+    int32_t n0, n1, sn0, sn1, sn2, sk0, sk1, sk2, ld, mode;
 };
 constexpr int SHADOW_MAX = 8;
 struct ShadowTab {
-    int32_t n, pad;
+    int32_t n, flags;
     ShadowDesc d[SHADOW_MAX];
 };
 
+__device__ __forceinline__ int64_t shadow_dst(const ShadowDesc& d, int32_t n, int32_t k) {
+    if (d.mode == 0) return d.dst_off + (int64_t)n * d.ld + k;
+    return d.dst_off + ((((int64_t)(n >> 4) * d.ld + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) << 3) + (k & 7);
+}
+__device__ __forceinline__ unsigned short f2bf_u16(float f) {
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
 // Four consecutive elements (i0 % 4 == 0) at once: with src_off, n0 multiples of 4 (checked by the host; the flat buffer
-// aligns every group to 64 floats) they share d1 and d2, so one index decomposition serves the quad, and a unit stride
-// makes the four bf16 one 8-byte store.
+// aligns every group to 64 floats) they share d1 and d2, so one index decomposition serves the quad, and when they run
+// along k (sn0 = 0, sk0 = 1, k % 4 == 0) the four bf16 are one 8-byte store in either layout.
 __device__ __forceinline__ void shadow_store4(unsigned short* __restrict__ shadow, const ShadowTab& tab, int64_t i0, float4 pn) {
 #pragma unroll
     for (int t = 0; t < SHADOW_MAX; ++t) {
         if (t < tab.n) {
-            const int64_t idx = i0 - tab.d[t].src_off;
-            if (idx >= 0 && idx < tab.d[t].n_el) {
-                const int32_t x = (int32_t)idx, n0 = tab.d[t].n0, n1 = tab.d[t].n1;
-                const int32_t q = x / n0, d0 = x - q * n0, d2 = q / n1, d1 = q - d2 * n1;
-                unsigned short* dst = shadow + tab.d[t].dst_off + (int64_t)d2 * tab.d[t].s2 + (int64_t)d1 * tab.d[t].s1 + (int64_t)d0 * tab.d[t].s0;
-                const unsigned short h0 = __builtin_bit_cast(unsigned short, (__bf16)pn.x), h1 = __builtin_bit_cast(unsigned short, (__bf16)pn.y);
-                const unsigned short h2 = __builtin_bit_cast(unsigned short, (__bf16)pn.z), h3 = __builtin_bit_cast(unsigned short, (__bf16)pn.w);
-                if (tab.d[t].s0 == 1 && (tab.d[t].pad & 1)) {   // pad bit 0: destination quads are 8-byte aligned
-                    *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+            const ShadowDesc& d = tab.d[t];
+            const int64_t idx = i0 - d.src_off;
+            if (idx >= 0 && idx < d.n_el) {
+                const int32_t x = (int32_t)idx;
+                const int32_t q = x / d.n0, d0 = x - q * d.n0, d2 = q / d.n1, d1 = q - d2 * d.n1;
+                const int32_t n = d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, k = d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2;
+                const unsigned short h0 = f2bf_u16(pn.x), h1 = f2bf_u16(pn.y), h2 = f2bf_u16(pn.z), h3 = f2bf_u16(pn.w);
+                if (d.sn0 == 0 && d.sk0 == 1 && (tab.flags & (2 << t))) {   // flag: k % 4 == 0 and 8-byte aligned destinations
+                    *reinterpret_cast<uint2*>(shadow + shadow_dst(d, n, k)) =
+                        make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
                 } else {
-                    const int64_t s0 = tab.d[t].s0;
-                    dst[0] = h0, dst[s0] = h1, dst[2 * s0] = h2, dst[3 * s0] = h3;
+                    shadow[shadow_dst(d, n, k)] = h0;
+                    shadow[shadow_dst(d, n + d.sn0, k + d.sk0)] = h1;
+                    shadow[shadow_dst(d, n + 2 * d.sn0, k + 2 * d.sk0)] = h2;
+                    shadow[shadow_dst(d, n + 3 * d.sn0, k + 3 * d.sk0)] = h3;
                 }
             }
         }
@@ -61,13 +79,12 @@ __device__ __forceinline__ void shadow_store(unsigned short* __restrict__ shadow
 #pragma unroll
     for (int t = 0; t < SHADOW_MAX; ++t) {
         if (t < tab.n) {
-            const int64_t idx = i - tab.d[t].src_off;
-            if (idx >= 0 && idx < tab.d[t].n_el) {
-                const int32_t x = (int32_t)idx, n0 = tab.d[t].n0, n1 = tab.d[t].n1;
-                const int32_t d0 = x % n0, q = x / n0, d1 = q % n1, d2 = q / n1;
-                const __bf16 h = (__bf16)pn;
-                shadow[tab.d[t].dst_off + (int64_t)d2 * tab.d[t].s2 + (int64_t)d1 * tab.d[t].s1 + (int64_t)d0 * tab.d[t].s0] =
-                    __builtin_bit_cast(unsigned short, h);
+            const ShadowDesc& d = tab.d[t];
+            const int64_t idx = i - d.src_off;
+            if (idx >= 0 && idx < d.n_el) {
+                const int32_t x = (int32_t)idx;
+                const int32_t q = x / d.n0, d0 = x - q * d.n0, d2 = q / d.n1, d1 = q - d2 * d.n1;
+                shadow[shadow_dst(d, d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2)] = f2bf_u16(pn);
             }
         }
     }
@@ -77,9 +94,9 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __rest
                                                              const ShadowTab tab) {
     const ShadowDesc& d = tab.d[blockIdx.y];
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < d.n_el; idx += (int64_t)gridDim.x * 256) {
-        const int32_t x = (int32_t)idx, d0 = x % d.n0, q = x / d.n0, d1 = q % d.n1, d2 = q / d.n1;
-        const __bf16 h = (__bf16)p[d.src_off + idx];
-        shadow[d.dst_off + (int64_t)d2 * d.s2 + (int64_t)d1 * d.s1 + (int64_t)d0 * d.s0] = __builtin_bit_cast(unsigned short, h);
+        const int32_t x = (int32_t)idx;
+        const int32_t q = x / d.n0, d0 = x - q * d.n0, d2 = q / d.n1, d1 = q - d2 * d.n1;
+        shadow[shadow_dst(d, d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2)] = f2bf_u16(p[d.src_off + idx]);
     }
 }
 
@@ -124,7 +141,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         vi = b2 * vi + (1.f - b2) * gi * gi;
         pi = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     };
-    const bool quad_ok = tab.pad != 0;           // host: every range starts on a quad, n0 % 4 == 0, n_el % 4 == 0
+    const bool quad_ok = tab.flags & 1;          // host: every range starts on a quad, n0 % 4 == 0, n_el % 4 == 0
     auto to_shadow = [&](int64_t i, float pn) {  // bf16 copies for the bf16 matrix-core products
         if (shadow) shadow_store(shadow, tab, i, pn);
     };
@@ -216,7 +233,8 @@ static int check_shadow_tab(const ShadowTab& tab, int64_t n, const char* who) {
     for (int t = 0; t < tab.n; ++t) {
         const ShadowDesc& d = tab.d[t];
         ERC_REQUIRE(d.src_off >= 0 && d.n_el > 0 && d.src_off + d.n_el <= n && d.n_el < (1ll << 31) && d.n0 > 0 && d.n1 > 0 &&
-                        d.dst_off >= 0, "%s: shadow descriptor %d out of range", who, t);
+                        d.dst_off >= 0 && d.ld > 0 && (d.mode == 0 || d.mode == 1) && d.sn0 >= 0 && d.sn1 >= 0 && d.sn2 >= 0 &&
+                        d.sk0 >= 0 && d.sk1 >= 0 && d.sk2 >= 0, "%s: shadow descriptor %d out of range", who, t);
     }
     return ERC_OK;
 }
@@ -225,13 +243,15 @@ static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, 
                        float weight_decay, int decoupled, float grad_scale, float clip_norm, const float* gnorm,
                        int64_t* state, void* shadow_base, const ShadowTab& tab_in, const int32_t* skip_flag, void* stream) {
     ShadowTab tab = tab_in;
-    // quad fast path: every range starts on a quad of the flat buffer and has rows of a multiple of 4 elements; per range,
-    // bit 0 of pad = unit-stride destination quads are 8-byte aligned
-    tab.pad = tab.n > 0;
+    // quad fast path (flags bit 0): every range starts on a quad of the flat buffer and has rows of a multiple of 4
+    // elements; bit 1 + t: range t runs along k with k % 4 == 0 for every quad and 8-byte aligned destinations
+    tab.flags = tab.n > 0;
     for (int t = 0; t < tab.n; ++t) {
-        ShadowDesc& d = tab.d[t];
-        if (d.src_off % 4 || d.n0 % 4 || d.n_el % 4) tab.pad = 0;
-        d.pad = (d.s0 == 1 && d.dst_off % 4 == 0 && d.s1 % 4 == 0 && d.s2 % 4 == 0 && ((uintptr_t)shadow_base & 7) == 0) ? 1 : 0;
+        const ShadowDesc& d = tab.d[t];
+        if (d.src_off % 4 || d.n0 % 4 || d.n_el % 4) tab.flags &= ~1;
+        const bool kq = d.sn0 == 0 && d.sk0 == 1 && d.sk1 % 4 == 0 && d.sk2 % 4 == 0 && d.dst_off % 4 == 0 &&
+                        (d.mode == 1 || d.ld % 4 == 0) && ((uintptr_t)shadow_base & 7) == 0;
+        if (kq) tab.flags |= 2 << t;
     }
     ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
     ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
@@ -255,7 +275,7 @@ extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64
     ShadowTab tab{};
     if (bf16_shadow && shadow_n > 0) {
         tab.n = 1;
-        tab.d[0] = ShadowDesc{shadow_off, shadow_n, 0, (int32_t)shadow_n, 1, 1, 0, 0, 0};
+        tab.d[0] = ShadowDesc{shadow_off, shadow_n, 0, (int32_t)shadow_n, 1, 0, 0, 0, 1, 0, 0, (int32_t)shadow_n, 0};   // identity: k = idx
     }
     return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, clip_norm, gnorm, state,
                        bf16_shadow, tab, skip_flag, stream);

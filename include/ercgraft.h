@@ -365,11 +365,11 @@ int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
  * (cogmen.py:65-66,71-72) up to the input of BatchNorm1d (cogmen.py:67) -- in one launch, and its backward in one.
  * The window graph (cogmen.py:153-154: wp = wf = 5) lets a tile of 16 nodes work from a halo of +-5 (forward) / +-15
  * (backward) rows; wp, wf <= 5 is required.  Dense products on v_mfma_f32_16x16x32_bf16, fp32 accumulate; weights
- * are read from bf16 shadows (ErcShadowTab below) in these layouts (zero padded):
- *   WcatT [112][928]: WcatT[o][r*100 + c] = conv1.weight[r][c][o], r = 8 -> conv1.root[c][o]
- *   Wq    [400][128]: rows = [lin_query; lin_key; lin_value; lin_skip].weight, K padded 100 -> 128
- *   WqT   [112][416]: WqT[c][n] = Wq[n][c]
- *   Wb    [112][960]: Wb[c][r*104 + o] = conv1.weight[r][c][o] (r = 8: root)
+ * are read from bf16 shadows (ErcShadowTab below, mode 1 = MFMA fragment order) of these logical [n][k] operands (zero padded):
+ *   WcatT [112][928 = 29 K blocks]: WcatT[o][r*100 + c] = conv1.weight[r][c][o], r = 8 -> conv1.root[c][o]
+ *   Wq    [400][128 =  4 K blocks]: rows = [lin_query; lin_key; lin_value; lin_skip].weight
+ *   WqT   [112][416 = 13 K blocks]: WqT[c][n] = Wq[n][c]
+ *   Wb    [112][960 = 30 K blocks]: Wb[c][r*104 + o] = conv1.weight[r][c][o] (r = 8: root)
  * Forward outputs: Mb bf16 [N, ldmb >= 900] = [mean_r H0 | H0] and H1b bf16 [N, ldh1b >= 100] (operands of the weight
  * gradients), inv_cnt [N,8], QKVS fp32 [N,400], H2 [N, ldh2], alpha [E] (softmax weights per in-edge).
  * bn_fused != 0: also the training-mode BatchNorm statistics of H2 (saved = mean | rstd, running statistics updated)
@@ -396,18 +396,23 @@ int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes,
 int erc_cogmen_set_stamps(uint64_t* stamps);
 
 /* bf16 shadow ranges maintained by the optimizer launch (bf16 compute mode: the weight operands of the bf16
- * matrix-core products -- rnn.1.weight of the input projection and the packed / transposed copies the fused COGMEN
- * kernels read, erc_cogmen_fwd_tile / erc_cogmen_bwd_tile -- stay in sync with the fp32 masters without an extra
- * launch).  Element i of the flat parameter range [src_off, src_off + n_el), idx = i - src_off, is written as bf16 to
- *   shadow_base[dst_off + (idx / (n0 n1)) s2 + ((idx / n0) % n1) s1 + (idx % n0) s0]      (all in elements)
- * so identity copies (n0 = n_el, s0 = 1), transposes and padded / blocked layouts are instances.  The table is a HOST
- * struct; elements a range never maps to keep whatever the buffer held (zero padding: clear it once). */
+ * matrix-core products -- rnn.1.weight of the input projection and the packed copies the fused COGMEN kernels read,
+ * erc_cogmen_fwd_tile / erc_cogmen_bwd_tile -- stay in sync with the fp32 masters without an extra launch).
+ * Element i of the flat parameter range [src_off, src_off + n_el), idx = i - src_off, is split into digits
+ *   d0 = idx % n0, d1 = (idx / n0) % n1, d2 = idx / (n0 n1)
+ * which give its coordinates in the LOGICAL B operand of its product, n = d0 sn0 + d1 sn1 + d2 sn2 (output column)
+ * and k = d0 sk0 + d1 sk1 + d2 sk2 (reduction index); it is written as bf16 to
+ *   mode 0: shadow_base[dst_off + n * ld + k]                                  (row-major [n][k]; identity copies)
+ *   mode 1: shadow_base[dst_off + (((n / 16) * ld + k / 32) * 64 + ((k % 32) / 8) * 16 + n % 16) * 8 + k % 8]
+ *           = the fragment order of v_mfma_f32_16x16x32_bf16's B operand, ld = number of 32-deep K blocks: a
+ *           wavefront's fragment of (column tile, K block) is one contiguous 1 KB run.
+ * The table is a HOST struct; elements no range maps to keep whatever the buffer held (zero padding: clear it once). */
 typedef struct ErcShadowDesc {
     int64_t src_off, n_el, dst_off;
-    int32_t n0, n1, s0, s1, s2, pad;
+    int32_t n0, n1, sn0, sn1, sn2, sk0, sk1, sk2, ld, mode;
 } ErcShadowDesc;
 typedef struct ErcShadowTab {
-    int32_t n, pad;            /* descriptors in use, <= 8 */
+    int32_t n, flags;          /* descriptors in use, <= 8; flags: set by the library */
     ErcShadowDesc d[8];
 } ErcShadowTab;
 /* erc_adam_step with a shadow table instead of the single identity range. */

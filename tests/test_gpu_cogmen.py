@@ -128,18 +128,19 @@ def test_bf16_shadow_table_tracks_master_weights():
     after_steps = m.shadows.buf.clone()
     m.refresh_shadows()
     assert torch.equal(after_steps.view(torch.int16), m.shadows.buf.view(torch.int16))
+    from erc_amd.capi import mfma_b_fragment_order as frag
     F = 100
+    eq = lambda got, want: torch.equal(got.view(torch.int16), want.contiguous().view(torch.int16))
     wcat = torch.cat([m.flat.w("gcn.conv1.weight").reshape(8 * F, F), m.flat.w("gcn.conv1.root")], 0).to(torch.bfloat16)
-    catT = m._sh["catT"].view(112, 928)
-    assert torch.equal(catT[:F, :900].view(torch.int16), wcat.t().contiguous().view(torch.int16))
-    assert float(catT[F:].float().abs().max()) == 0 and float(catT[:, 900:].float().abs().max()) == 0
-    wb = m._sh["wb"].view(112, 960)
-    for r in (0, 3, 8):
-        blk = wcat[r * F:(r + 1) * F]                     # W_r [c][o]
-        assert torch.equal(wb[:F, r * 104:r * 104 + F].contiguous().view(torch.int16), blk.contiguous().view(torch.int16))
+    assert eq(m._sh["catT"], frag(wcat.t(), 29))                       # WcatT[o][r*100+c]
+    wb = torch.zeros(F, 960, dtype=torch.bfloat16, device=wcat.device)   # Wb[c][r*104+o] = W_r[c][o]
+    for r in range(9):
+        wb[:, r * 104:r * 104 + F] = wcat[r * F:(r + 1) * F]
+    assert eq(m._sh["wb"], frag(wb, 30))
     wq = torch.cat([m.flat.w("gcn.conv2.lin_%s.weight" % n) for n in ("query", "key", "value", "skip")], 0).to(torch.bfloat16)
-    assert torch.equal(m._sh["q"].view(400, 128)[:, :F].contiguous().view(torch.int16), wq.contiguous().view(torch.int16))
-    assert torch.equal(m._sh["qT"].view(112, 416)[:F, :400].contiguous().view(torch.int16), wq.t().contiguous().view(torch.int16))
+    assert eq(m._sh["q"], frag(wq, 4))
+    assert eq(m._sh["qT"], frag(wq.t(), 13))
+    assert eq(m._sh["w1"], m.flat.w("rnn.1.weight").to(torch.bfloat16))
 
 
 def test_cogmen_train_step_matches_torch_adam():
