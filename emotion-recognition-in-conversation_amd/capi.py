@@ -48,6 +48,8 @@ _SIGS = {
     "erc_head_fused_ws_floats": (C.c_int64, [_i]),
     "erc_head_fused": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "erc_head_fused_bn": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp]),
     "erc_bn_bwd_apply": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_wgrad_max_k_per_split": (C.c_int, []),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
@@ -666,6 +668,14 @@ def head_fused(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3,
                H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws):
     _call("erc_head_fused", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
           float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws)
+
+
+def head_fused_bn(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
+                  H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, running_mean,
+                  running_var, momentum, eps):
+    _call("erc_head_fused_bn", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
+          float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles,
+          running_mean, running_var, float(momentum), float(eps))
 
 
 def bn_bwd_apply(x, ldx, N, F, gamma, saved, bn_bwd, dY, lddy, dx, lddx):

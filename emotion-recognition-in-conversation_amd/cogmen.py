@@ -257,10 +257,10 @@ class COGMENModule(nn.Module):
         if ws.get("fused"):
             bn = self.gcn.bn
             # training with the fused head: BatchNorm's batch statistics come out of the same launch
-            ws["bn_in_tile"] = bool(upto_h2 and N <= self.BN_FUSED_MAX_N)
+            ws["bn_in_tile"] = bool(upto_h2 and N <= self.BN_FUSED_MAX_N)   # tile sums here, finalised by the head kernel
             capi.cogmen_fwd_tile(ws["H0"], F, N, WP, WF, g, self._sh["catT"], fp.w("gcn.conv1.bias"), self._sh["q"],
                                  fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], 904, ws["inv_cnt"],
-                                 ws["H1b"], 104, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=ws["bn_in_tile"],
+                                 ws["H1b"], 104, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=2 if ws["bn_in_tile"] else 0,
                                  running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum,
                                  eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"])
             if upto_h2:
@@ -324,14 +324,19 @@ class COGMENModule(nn.Module):
         if fused and not fused_head:
             raise capi.ErcGraftError("COGMEN bf16 mode trains through the fused head (C <= 8)")
         if fused_head:
-            if not (fused and ws["bn_in_tile"]):
+            head_args = (ws["H2"], F, N, F, C, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
+                         fp.w("cls.0.weight"), fp.w("cls.0.bias"), fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys,
+                         class_weight, p, self.rng_state if p > 0 else None, ws["H3"], ws["Z"], ws["logits"],
+                         ws["dlogits"], ws["dZ"], ws["dH3"], ws["bn_bwd"], fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"),
+                         ws["stats"], ws["head_ws"])
+            if fused and ws["bn_in_tile"]:
+                # BatchNorm's batch statistics: per-tile sums from the forward tile kernel, added up by every head workgroup
+                capi.head_fused_bn(*head_args, ws["bn_tile_ws"][2:].view(torch.float32), -(-N // 16), bn.running_mean,
+                                   bn.running_var, bn.momentum, bn.eps)
+            else:
                 capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
                                     ws["bn_stats_ws"])
-            capi.head_fused(ws["H2"], F, N, F, C, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
-                            fp.w("cls.0.weight"), fp.w("cls.0.bias"), fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys,
-                            class_weight, p, self.rng_state if p > 0 else None, ws["H3"], ws["Z"], ws["logits"],
-                            ws["dlogits"], ws["dZ"], ws["dH3"], ws["bn_bwd"], fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"),
-                            ws["stats"], ws["head_ws"])
+                capi.head_fused(*head_args)
         else:
             capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
             capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,

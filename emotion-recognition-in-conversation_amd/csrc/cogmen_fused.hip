@@ -423,7 +423,15 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
             const double x = (double)sH2[li * CG_F + c];
             s += sq ? x * x : x;
         }
-        st_sc1d(p.bn_part + (int64_t)blockIdx.x * 2 * CG_F + tid, s);
+        if (p.bn_fused == 2) {   // the head kernel adds the tiles (erc_head_fused_bn): plain stores, no arrival
+            reinterpret_cast<float*>(p.bn_part)[(int64_t)blockIdx.x * 2 * CG_F + tid] = (float)s;
+        } else {
+            st_sc1d(p.bn_part + (int64_t)blockIdx.x * 2 * CG_F + tid, s);
+        }
+    }
+    if (p.bn_fused == 2) {
+        CG_STAMP(6);
+        return;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -897,7 +905,8 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
                     ldh2 >= CG_F && ldh2 % 2 == 0 && ((uintptr_t)H2 & 7) == 0 &&
                     ((uintptr_t)QKVS & 15) == 0 && ((uintptr_t)WcatT & 15) == 0 && ((uintptr_t)Wq & 15) == 0,
                 "cogmen_fwd_tile: pitch / alignment");
-    ERC_REQUIRE(!bn_fused || (running_mean && running_var && saved && bn_ws), "cogmen_fwd_tile: BatchNorm operands");
+    ERC_REQUIRE(bn_fused >= 0 && bn_fused <= 2 && (bn_fused != 1 || (running_mean && running_var && saved)) && (!bn_fused || bn_ws),
+                "cogmen_fwd_tile: BatchNorm operands");
     ERC_REQUIRE(ensure_lds(reinterpret_cast<const void*>(cogmen_fwd_tile_kernel), FW_LDS), "cogmen_fwd_tile: %d bytes of LDS refused", FW_LDS);
     CgFwdP p{};
     p.H0 = H0; p.in_ptr = in_ptr; p.in_src = in_src; p.in_typ = in_typ; p.WcatT = (const unsigned short*)WcatT; p.b1 = b1;
@@ -908,7 +917,7 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
     p.bn_counter = reinterpret_cast<int*>(bn_ws);
     p.running_mean = running_mean; p.running_var = running_var; p.saved = saved;
     p.momentum = momentum; p.eps = eps; p.scale = scale;
-    p.N = n_nodes; p.ldh0 = ldh0; p.ldmb = ldmb; p.ldh1b = ldh1b; p.ldh2 = ldh2; p.bn_fused = bn_fused ? 1 : 0;
+    p.N = n_nodes; p.ldh0 = ldh0; p.ldmb = ldmb; p.ldh1b = ldh1b; p.ldh2 = ldh2; p.bn_fused = bn_fused;
     p.stamps = g_cg_stamps; p.stamp_block = tiles / 2;
     hipLaunchKernelGGL(cogmen_fwd_tile_kernel, dim3(tiles), dim3(CG_NTH), FW_LDS, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("cogmen_fwd_tile");

@@ -137,6 +137,13 @@ struct HeadP {
     float* stats;
     float slope, drop_p;
     int ldh, N, F, C;
+    // BNP: the batch statistics are finalised here from per-tile column sums (erc_cogmen_fwd_tile, bn mode 2)
+    const float* bn_part;    // [bn_tiles][2F]: sum x | sum x^2 of 16 rows each
+    float* saved_out;        // [2F] mean | rstd, written by workgroup 0 (the backward reads it)
+    float* running_mean;
+    float* running_var;
+    float momentum, eps;
+    int bn_tiles;
 };
 
 // DPP lane exchanges inside a row of 16 lanes (VALU, no LDS traffic)
@@ -164,6 +171,7 @@ __device__ __forceinline__ float row8_min(float v) {
 
 // Workgroup = 8 wavefronts = 32 rows: wavefront w works on row tile rt = w >> 2 (16 rows) and column tiles
 // nt = 2 (w & 3), 2 (w & 3) + 1 of the 7; the class-space quantities (8 wide) are exchanged through LDS.
+template <bool BNP>
 __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     __shared__ __attribute__((aligned(16))) float sW[HF_MAXF * HF_S];  // W0, row pitch HF_S
     __shared__ __attribute__((aligned(16))) float sT[2][16 * HF_ST];    // dZ row tiles (transposition between the MFMA products); sT[0] first holds sLg
@@ -176,6 +184,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     const int r = lane & 15, g = lane >> 4;
     const int F = p.F, C = p.C, N = p.N;
     float* const sLg = &sT[0][0];  // [rt][cq][16 rows][8 classes] partial logits, dead before sT is written
+    __shared__ __attribute__((aligned(16))) float sSaved[2 * HF_MAXF];
 
     // ---- stage W0 (F x F) into LDS: F*F/4 <= 2500 float4 over 512 threads, all loads in flight
     {
@@ -188,6 +197,52 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
             const int row = i / per_row, q = i - row * per_row;
             v[j] = *reinterpret_cast<const f32x4*>(p.W0 + (int64_t)row * F + 4 * q);
             dst[j] = row * HF_S + 4 * q;
+        }
+        // ---- BNP: training-mode BatchNorm statistics (torch.nn.BatchNorm1d, cogmen.py:67) from the per-tile column
+        //      sums the forward tile kernel left behind: every workgroup adds the tiles in order (fp64) -- no last
+        //      arriver, no extra launch; workgroup 0 publishes mean | rstd and updates the running statistics.
+        //      Thread (pair = tid % 128 < F, part = tid / 128) takes two columns and a quarter of the tile list: one
+        //      batch of 8-byte loads, in flight together with the W0 loads above.
+        if (BNP) {
+            double* const sBn = reinterpret_cast<double*>(&sT[0][0]);   // [4][2][128] doubles = 8 KB of the tile area
+            const int pair = tid & 127, part = tid >> 7;
+            const int G = p.bn_tiles, Gq = (G + 3) >> 2;
+            const int g_begin = min(part * Gq, G), g_end = min(G, g_begin + Gq);
+            double ax = 0.0, ay = 0.0;
+            if (pair < F) {
+                for (int g0 = g_begin; g0 < g_end; g0 += 32) {
+                    float2 t[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) t[j] = *reinterpret_cast<const float2*>(p.bn_part + (int64_t)min(g0 + j, G - 1) * 2 * F + 2 * pair);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        const double mk = g0 + j < g_end ? 1.0 : 0.0;
+                        ax += (double)t[j].x * mk, ay += (double)t[j].y * mk;
+                    }
+                }
+            }
+            sBn[(part * 2 + 0) * 128 + pair] = ax, sBn[(part * 2 + 1) * 128 + pair] = ay;
+            __syncthreads();
+            if (tid < F) {
+                // column c: sum x = slot c, sum x^2 = slot F + c of the 2F slots; slot s lives in pair s / 2, component s % 2
+                auto slot_sum = [&](int sl) {
+                    const int pr = sl >> 1, cm = sl & 1;
+                    return ((sBn[(0 * 2 + cm) * 128 + pr] + sBn[(1 * 2 + cm) * 128 + pr]) + sBn[(2 * 2 + cm) * 128 + pr]) + sBn[(3 * 2 + cm) * 128 + pr];
+                };
+                const double sx = slot_sum(tid), sxx = slot_sum(F + tid);
+                const double m = sx / (double)N;
+                double var = sxx / (double)N - m * m;
+                if (var < 0.0) var = 0.0;
+                const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+                sSaved[tid] = mean, sSaved[F + tid] = rstd;
+                if (blockIdx.x == 0) {
+                    p.saved_out[tid] = mean, p.saved_out[F + tid] = rstd;
+                    const double unbiased = N > 1 ? var * (double)N / (double)(N - 1) : var;
+                    p.running_mean[tid] = (1.f - p.momentum) * p.running_mean[tid] + p.momentum * mean;
+                    p.running_var[tid] = (1.f - p.momentum) * p.running_var[tid] + p.momentum * (float)unbiased;
+                }
+            }
+            __syncthreads();
         }
 #pragma unroll
         for (int j = 0; j < 5; ++j)
@@ -221,7 +276,8 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         const int k0c = kv ? k0 : 0;
         const float km = kv ? 1.f : 0.f;
         const f32x4 x = *reinterpret_cast<const f32x4*>(p.H2 + (int64_t)mrc * p.ldh + k0c);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.saved + k0c), rs = *reinterpret_cast<const f32x4*>(p.saved + F + k0c);
+        const f32x4 mu = BNP ? *reinterpret_cast<const f32x4*>(sSaved + k0c) : *reinterpret_cast<const f32x4*>(p.saved + k0c);
+        const f32x4 rs = BNP ? *reinterpret_cast<const f32x4*>(sSaved + F + k0c) : *reinterpret_cast<const f32x4*>(p.saved + F + k0c);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + k0c), be = *reinterpret_cast<const f32x4*>(p.beta + k0c);
         f32x4 h;
 #pragma unroll
@@ -246,7 +302,8 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         const int col = 16 * (2 * cq + jn) + r;
         colc[jn] = min(col, F - 1);
         cm[jn] = col < F ? 1.f : 0.f;
-        mu6[jn] = p.saved[colc[jn]], rs6[jn] = p.saved[F + colc[jn]], ga6[jn] = p.gamma[colc[jn]], be6[jn] = p.beta[colc[jn]];
+        mu6[jn] = BNP ? sSaved[colc[jn]] : p.saved[colc[jn]], rs6[jn] = BNP ? sSaved[F + colc[jn]] : p.saved[F + colc[jn]];
+        ga6[jn] = p.gamma[colc[jn]], be6[jn] = p.beta[colc[jn]];
         b0c[jn] = p.b0[colc[jn]];
 #pragma unroll
         for (int q = 0; q < 4; ++q) x6[jn][q] = p.H2[(int64_t)min(m0 + 4 * g + q, N - 1) * p.ldh + colc[jn]];
@@ -500,30 +557,63 @@ extern "C" int erc_bn_batch_stats(const float* x, int ldx, int N, int F, float* 
 
 extern "C" int64_t erc_head_fused_ws_floats(int n_rows) { return (int64_t)erc_cdiv(n_rows, 32) * HF_PART + 16; }
 
-extern "C" int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
-                              const float* saved, float slope, const float* W0, const float* b0, const float* W3,
-                              const float* b3, const int64_t* labels, const float* weight, float drop_p,
-                              const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
-                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* stream) {
-    ERC_REQUIRE(H2 && gamma && beta && saved && W0 && b0 && W3 && b3 && labels && H3 && Z && logits && dlogits && dZ && dY &&
+static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
+                             const float* saved, float slope, const float* W0, const float* b0, const float* W3,
+                             const float* b3, const int64_t* labels, const float* weight, float drop_p,
+                             const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
+                             float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
+                             const float* bn_part, int bn_tiles, float* saved_out, float* running_mean, float* running_var,
+                             float momentum, float eps, void* stream) {
+    ERC_REQUIRE(H2 && gamma && beta && (saved || bn_part) && W0 && b0 && W3 && b3 && labels && H3 && Z && logits && dlogits && dZ && dY &&
                     bn_bwd && dgamma && dbeta && stats && ws,
                 "head_fused: null pointer");
     ERC_REQUIRE(n_rows > 0 && F >= 4 && F <= HF_MAXF && F % 4 == 0 && C > 0 && C <= HF_MAXC && ldh >= F && ldh % 4 == 0,
                 "head_fused: n_rows=%d F=%d C=%d ldh=%d unsupported (F <= %d, F %% 4 == 0, C <= %d)", n_rows, F, C, ldh,
                 HF_MAXF, HF_MAXC);
-    ERC_REQUIRE(al16(H2) && al16(gamma) && al16(beta) && al16(saved) && al16(W0) && al16(H3), "head_fused: 16-byte alignment");
+    ERC_REQUIRE(al16(H2) && al16(gamma) && al16(beta) && (!saved || al16(saved)) && al16(W0) && al16(H3), "head_fused: 16-byte alignment");
     ERC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state), "head_fused: drop_p=%f", (double)drop_p);
+    ERC_REQUIRE(!bn_part || (bn_tiles > 0 && saved_out && running_mean && running_var), "head_fused: BatchNorm partials operands");
     HeadP p{};
     p.H2 = H2, p.gamma = gamma, p.beta = beta, p.saved = saved, p.W0 = W0, p.b0 = b0, p.W3 = W3, p.b3 = b3;
     p.labels = labels, p.weight = weight, p.rng = rng_state, p.H3 = H3, p.Z = Z, p.logits = logits, p.dlogits = dlogits;
     p.dZ = dZ, p.dY = dY, p.bn_bwd = bn_bwd, p.dgamma = dgamma, p.dbeta = dbeta, p.stats = stats;
     p.slope = slope, p.drop_p = drop_p, p.ldh = ldh, p.N = n_rows, p.F = F, p.C = C;
+    p.bn_part = bn_part, p.bn_tiles = bn_tiles, p.saved_out = saved_out, p.running_mean = running_mean, p.running_var = running_var;
+    p.momentum = momentum, p.eps = eps;
     const int grid = erc_cdiv(n_rows, 32);
     p.part = ws;
     p.counter = reinterpret_cast<int*>(ws + (int64_t)grid * HF_PART);
-    hipLaunchKernelGGL(head_fused_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    if (bn_part) hipLaunchKernelGGL(head_fused_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(head_fused_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("head_fused");
     return ERC_OK;
+}
+
+extern "C" int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
+                              const float* saved, float slope, const float* W0, const float* b0, const float* W3,
+                              const float* b3, const int64_t* labels, const float* weight, float drop_p,
+                              const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
+                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* stream) {
+    ERC_REQUIRE(saved, "head_fused: null pointer");
+    return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
+                             H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, nullptr, 0, nullptr, nullptr,
+                             nullptr, 0.f, 0.f, stream);
+}
+
+// erc_head_fused with BatchNorm's batch statistics finalised inside: bn_part [bn_tiles][2F] = the per-tile column sums
+// (sum x | sum x^2) erc_cogmen_fwd_tile leaves in bn mode 2; saved [2F] (mean | rstd) becomes an OUTPUT, the running
+// statistics are updated (momentum, unbiased variance) as nn.BatchNorm1d does in training mode.
+extern "C" int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
+                                 float* saved, float slope, const float* W0, const float* b0, const float* W3,
+                                 const float* b3, const int64_t* labels, const float* weight, float drop_p,
+                                 const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
+                                 float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
+                                 const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
+                                 float eps, void* stream) {
+    ERC_REQUIRE(bn_part && saved, "head_fused_bn: null pointer");
+    return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, nullptr, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
+                             H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, saved,
+                             running_mean, running_var, momentum, eps, stream);
 }
 
 extern "C" int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,

@@ -328,6 +328,18 @@ int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const flo
                    const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                    float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* stream);
 
+/* erc_head_fused with BatchNorm's batch statistics finalised inside (training mode of nn.BatchNorm1d, cogmen.py:67):
+ * bn_part [bn_tiles][2F] floats = per-tile column sums (sum x | sum x^2) from erc_cogmen_fwd_tile (bn_fused = 2);
+ * every workgroup adds the tiles in order, workgroup 0 writes saved [2F] = mean | rstd (an OUTPUT here) and updates
+ * running_mean / running_var (momentum, unbiased variance). */
+int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
+                      float* saved, float slope, const float* W0, const float* b0, const float* W3,
+                      const float* b3, const int64_t* labels, const float* weight, float drop_p,
+                      const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
+                      float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
+                      const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
+                      float eps, void* stream);
+
 /* Elementwise part of BatchNorm1d's backward: dx = gamma * rstd * (dY - bn_bwd[c] - xhat * bn_bwd[F + c]). */
 int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,
                      const float* bn_bwd, const float* dY, int lddy, float* dx, int lddx, void* stream);
@@ -372,8 +384,10 @@ int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
  *   Wb    [112][960 = 30 K blocks]: Wb[c][r*104 + o] = conv1.weight[r][c][o] (r = 8: root)
  * Forward outputs: Mb bf16 [N, ldmb >= 900] = [mean_r H0 | H0] and H1b bf16 [N, ldh1b >= 100] (operands of the weight
  * gradients), inv_cnt [N,8], QKVS fp32 [N,400], H2 [N, ldh2], alpha [E] (softmax weights per in-edge).
- * bn_fused != 0: also the training-mode BatchNorm statistics of H2 (saved = mean | rstd, running statistics updated)
- * by the last workgroup to arrive; bn_ws = erc_cogmen_fwd_tile_ws_doubles(N) doubles, zero before the first call. */
+ * bn_fused = 1: also the training-mode BatchNorm statistics of H2 (saved = mean | rstd, running statistics updated)
+ * by the last workgroup to arrive; bn_fused = 2: only the per-tile column sums, as floats [tiles][200] from bn_ws + 2
+ * doubles on (= the bn_part operand of erc_head_fused_bn, which finalises them without a last arriver);
+ * bn_ws = erc_cogmen_fwd_tile_ws_doubles(N) doubles, zero before the first call. */
 int64_t erc_cogmen_fwd_tile_ws_doubles(int n_nodes);
 int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int wp, int wf, const int32_t* in_ptr,
                         const int32_t* in_src, const int32_t* in_typ, const void* WcatT, const float* b1,
