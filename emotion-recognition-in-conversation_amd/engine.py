@@ -147,7 +147,14 @@ class GemmPlanner:
         if cache.get("wgrad_key") != key:
             cap = capi.wgrad_max_k_per_split()
             raw, items, tiles, bases = [], 0, 0, []
-            steps = int(os.environ.get("ERC_WG_STEPS", self.WG_STEPS))
+            steps = int(os.environ.get("ERC_WG_STEPS", 0))
+            if steps <= 0:
+                # 64 k-steps per item (16 per wavefront) while all items of the launch fit the chip at once (768 workgroup
+                # slots: COGMEN, DialogueGCN); with several rounds of items the per-item overhead (LDS reduce, slab, arrival)
+                # is paid per round, and longer items win (measured: MMGCN 4.68 -> 4.47 ms, DAG-ERC 3.80 -> 3.71 ms at 256)
+                n64 = sum(-(-M // 64) * -(-N // 64) * max(1, min(32, (-(-K // 4) + 32) // 64))
+                          for _, _, _, _, _, _, M, N, K, _, _, _, _, _ in self.deferred)
+                steps = self.WG_STEPS if n64 <= 1152 else 256
             for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g, sc, mb in self.deferred:
                 bf16 = b.dtype == torch.bfloat16
                 a_bf16 = a.dtype == torch.bfloat16
