@@ -21,7 +21,7 @@ def one(pattern):
     hits = glob.glob(pattern)
     if not hits:
         raise SystemExit("no file matches " + pattern)
-    return hits[0]
+    return max(hits, key=os.path.getmtime)     # gpurun merges runs into the same directory: take the newest
 
 
 def avg_counter(path, kernel, counter):
