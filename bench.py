@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--max_len", type=int, default=None)
     ap.add_argument("--dataset", default=None)  # cogmen default: d_t=768 -> D=1380 as BASELINE.json config 2
+    ap.add_argument("--modality", default="atv", help="subset of a / t / v (BASELINE.json configs[4]: DialogueGCN ablation)")
     ap.add_argument("--no_graph", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--kernel_reps", type=int, default=200)
@@ -272,7 +273,7 @@ def main():
         extra = extra + ["--faithful_dead_encoder"]
     if args.chained_encoder and args.module == "cogmen":
         extra = extra + ["--chained_encoder"]
-    params = plugin.ParamsType().from_args(["--dataset=" + args.dataset, "--modality=atv", "--compute=" + args.dtype]
+    params = plugin.ParamsType().from_args(["--dataset=" + args.dataset, "--modality=" + args.modality, "--compute=" + args.dtype]
                                            + extra)
     params.train.batch_size = args.batch
     trainer = getattr(plugin, {"cogmen": "COGMENTrainer", "mmgcn": "MMGCNTrainer", "dagerc": "DAGERCTrainer",
@@ -420,7 +421,7 @@ def main():
         value = total_utt * args.steps / elapsed
         line = {
             "metric": "utterances/sec training step, COGMEN IEMOCAP-6 atv" if args.module == "cogmen" else
-            "utterances/sec training step, %s %s atv" % (args.module, args.dataset), "value": value,
+            "utterances/sec training step, %s %s %s" % (args.module, args.dataset, args.modality), "value": value,
             "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -28,4 +28,10 @@ Pinning status (see DESIGN.md "Oracle"):
     ``GraphConv`` are third-party, unpinned (``requirements.txt:12``) and not
     installed: restated here from their published formulae ->
     "parity unpinned" for those three operators.
+  * COGMEN's bf16 compute mode is checked against the SAME restatement with the
+    operands of the products that mode runs on bf16 matrix cores rounded to
+    bf16 (``pyg.RoundedLinear`` / ``pyg.RGCNMeanRounded``; their hand-written
+    backward formulas equal autograd when the rounding is switched off:
+    ``tests/test_oracle_cogmen_rounded.py``) -- the reference has no bf16 path,
+    so this pins implementation error of the mode, not the mode's quantisation.
 """
