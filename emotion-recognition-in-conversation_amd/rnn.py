@@ -41,7 +41,7 @@ class BiLSTM2:
             f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
             ws = dict(GX=[f32(rows, 8 * H), f32(rows, 8 * H)], gates=[f32(rows, 8 * H), f32(rows, 8 * H)],
                       Cst=[f32(rows, 2 * H), f32(rows, 2 * H)], Hprev=[f32(rows, 2 * H), f32(rows, 2 * H)],
-                      H0=f32(rows, 2 * H), H0d=f32(rows, 2 * H), dGX=f32(rows, 8 * H), dH0d=f32(rows, 2 * H))
+                      H0=f32(rows, 2 * H), H0d=f32(rows, 2 * H), dGX=[f32(rows, 8 * H), f32(rows, 8 * H)], dH0d=f32(rows, 2 * H))
             self._ws[rows] = ws
         return ws
 
@@ -65,28 +65,30 @@ class BiLSTM2:
         dx [rows, d_in] (needed when the LSTM input is itself trainable, MMGCN)."""
         x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16 = self._last
         ws = self._buf(rows, dout.device)
+        # one gate-gradient buffer per layer: every weight gradient of the LSTM then joins the step's ONE batched
+        # weight-gradient launch (erc_wgrad_table) instead of 6 split-K GEMMs + a slab reduce per layer pair
         for k in (1, 0):
+            dGX = ws["dGX"][k]
             if k == 1:
                 capi.lstm_scan_bwd(self._w("weight_hh_l1"), lengths, None, sb, st, B, T, ws["gates"][1], ws["Cst"][1],
-                                   dout, lddo, 0.0, None, 0, ws["dGX"])
+                                   dout, lddo, 0.0, None, 0, dGX)
                 xin, ldin, d_in, bf = ws["H0d"], 2 * H, 2 * H, False
             else:
                 capi.lstm_scan_bwd(self._w("weight_hh_l0"), lengths, None, sb, st, B, T, ws["gates"][0], ws["Cst"][0],
-                                   ws["dH0d"], 2 * H, p, rng, 0x5EED0, ws["dGX"])
+                                   ws["dH0d"], 2 * H, p, rng, 0x5EED0, dGX)
                 xin, ldin, d_in, bf = x, ldx, self.d_in, x_bf16
-            # W_ih (both directions stacked [800, d_in]) and b_ih; b_hh receives the same gradient
-            src_w, S, _ = linear_wgrad(pl, ws["dGX"], 8 * H, xin, ldin, None, 8 * H, d_in, rows,
-                                       self._off("weight_ih_l%d" % k), self._off("bias_ih_l%d" % k), x_bf16=bf,
-                                       force_slab=True)
-            src_b = pl.jobs[-1][0]
-            pl.add_job(src_b, 8 * H, S, 8 * H, self._off("bias_hh_l%d" % k))
-            # W_hh per direction: dGX[:, 400d:]^T Hprev[:, 100d:]
+            # W_ih (both directions stacked [800, d_in]) and b_ih
+            linear_wgrad(pl, dGX, 8 * H, xin, ldin, None, 8 * H, d_in, rows, self._off("weight_ih_l%d" % k),
+                         self._off("bias_ih_l%d" % k), x_bf16=bf, defer=True)
+            # W_hh per direction: dGX[:, 400d:]^T Hprev[:, 100d:]; b_hh receives the same gradient as b_ih = the column
+            # sums of the direction's gate gradients (the bias strip of this product)
             for d in (0, 1):
-                linear_wgrad(pl, ws["dGX"][:, 4 * H * d:], 8 * H, ws["Hprev"][k][:, H * d:], 2 * H, None, 4 * H, H, rows,
-                             self._off("weight_hh_l%d" % k) + d * 4 * H * H, None)
+                linear_wgrad(pl, dGX[:, 4 * H * d:], 8 * H, ws["Hprev"][k][:, H * d:], 2 * H, None, 4 * H, H, rows,
+                             self._off("weight_hh_l%d" % k) + d * 4 * H * H, self._off("bias_hh_l%d" % k) + d * 4 * H,
+                             defer=True)
             if k == 1:   # gradient wrt the (dropped) layer-0 output
-                capi.gemm_f32(ws["dGX"], 8 * H, 0, None, self._w("weight_ih_l1"), 2 * H, 1, None, ws["dH0d"], 2 * H,
+                capi.gemm_f32(dGX, 8 * H, 0, None, self._w("weight_ih_l1"), 2 * H, 1, None, ws["dH0d"], 2 * H,
                               rows, 2 * H, 8 * H)
             elif dx is not None:
-                capi.gemm_f32(ws["dGX"], 8 * H, 0, None, self._w("weight_ih_l0"), self.d_in, 1, None, dx, lddx,
+                capi.gemm_f32(dGX, 8 * H, 0, None, self._w("weight_ih_l0"), self.d_in, 1, None, dx, lddx,
                               rows, self.d_in, 8 * H)
