@@ -264,8 +264,10 @@ def linear_wgrad(pl, dy, lddy, x, ldx, gather, n_out, n_in, n_rows, w_off, b_off
     if slab[0] == "direct":
         _, base, ld_w = slab
         if defer:
+            # a bf16 x operand (the feature block) takes the bf16 matrix-core path: dy is rounded too, as the split-K
+            # bf16 GEMM this product used before did (the bias strip stays an fp32 sum)
             pl.defer(dy, lddy, x, ldx, pl.grad[base + col_off:], ld_w, n_out, n_in, n_rows, 1 if want_b else 0,
-                     pl.grad[b_off:] if want_b else None, gather=gather)
+                     pl.grad[b_off:] if want_b else None, gather=gather, mma_bf16=True if x_bf16 else None)
         elif x_bf16:
             raise capi.ErcGraftError("bf16 column slice into a directly written gradient: pass force_slab=True")
         else:
