@@ -6,9 +6,9 @@
 //   forward  : M = [mean_r H0 | H0] for rows [r0-5, r0+21)  -> H1 = M Wcat + b (those 26 rows) -> QKVS = H1 Wqkvs^T + b
 //              (26 rows) -> segmented-softmax attention + skip for its 16 rows -> H2, plus the BatchNorm column sums
 //              (partials per tile, finalised by the last workgroup to arrive)
-//   backward : dH2 = BatchNorm backward for rows [r0-10, r0+26) -> attention backward, target side (those 36 rows),
-//              source side (rows [r0-5, r0+21)) -> dH1 = dQKVS Wqkvs (26 rows) -> dP = A^T dH1 (16 rows, the transposed
-//              relation means) -> dH0 = dP [W_r^T] (16 rows)
+//   backward : dH2 = BatchNorm backward for rows [r0-10, r0+26) -> attention backward as fp32 band products on the matrix
+//              cores (dA = G V^T on the +-5 band, d(score), dq = DS K, dk = DS^T Q, dv = AL^T G) -> dH1 = dQKVS Wqkvs
+//              (26 rows) -> dP = A^T dH1 (16 rows, the transposed relation means) -> dH0 = dP [W_r^T] (16 rows)
 // with the intermediate tiles in LDS.  The halo rows are recomputed by the neighbouring tile (1.6x .. 2.3x of the small
 // products) -- that is what buys 5 + 5 launches less and no HBM / L2 round trip for M, H1 (fp32), dM.
 //
@@ -477,13 +477,25 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     }
 }
 
+// sum over the 16 lanes of a row (lanes 16 g .. 16 g + 15), in every lane: DPP exchanges, no LDS traffic
+template <int CTRL>
+__device__ __forceinline__ float cg_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float cg_row16_sum(float v) {
+    v += cg_dpp<0xB1>(v), v += cg_dpp<0x4E>(v), v += cg_dpp<0x141>(v), v += cg_dpp<0x140>(v);   // quad xor 1 / xor 2, row_half_mirror, row_mirror
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------------ backward
 // LDS map of the backward kernel (bytes)
-constexpr int BW_SK_OFF = 0;                                    // K rows [r0-15, r0+31) fp32; later (with sV, sQq) the dP tile
-constexpr int BW_SK_BYTES = CG_FAR * CG_F * 4;                  // 18400
+constexpr int BW_ROWS = 48;                                     // the far (46) / outer (36) row tiles padded to three MFMA tiles of 16 (pad rows zero)
+constexpr int BW_SK_OFF = 0;                                    // K rows [r0-15, r0+31) fp32
+constexpr int BW_SK_BYTES = BW_ROWS * CG_F * 4;                 // 19200
 constexpr int BW_SV_OFF = BW_SK_OFF + BW_SK_BYTES;
 constexpr int BW_SQ_OFF = BW_SV_OFF + BW_SK_BYTES;              // Q rows [r0-10, r0+26)
-constexpr int BW_SQ_BYTES = CG_OUT * CG_F * 4;                  // 14400
+constexpr int BW_SQ_BYTES = BW_ROWS * CG_F * 4;                 // 19200
+constexpr int BW_BAND = 68;                                     // pitch of the band matrices [outer row][far column] (68 mod 64 = 4: conflict-free row reads)
 constexpr int BW_SG_OFF = BW_SQ_OFF + BW_SQ_BYTES;              // dH2 rows [r0-10, r0+26)
 constexpr int BW_SE_OFF = BW_SG_OFF + BW_SQ_BYTES;              // edge arrays
 constexpr int BW_ECAP = 400;                                    // in-edges of the 36 outer rows (<= 36 x 11)
@@ -501,6 +513,8 @@ constexpr int CG_KB = 936;                                      // K of the dH0 
 constexpr int CG_KBP = 960;                                     // padded to 30 blocks of 32
 constexpr int CG_SDP = 968;                                     // pitch of the dP tile (bf16)
 static_assert(CG_TR * CG_SDP * 2 <= BW_SDP_BYTES && BW_SDP_OFF % 16 == 0 && BW_LDS <= 160 * 1024, "backward LDS map");
+static_assert(2 * BW_ROWS * BW_BAND * 4 <= BW_SDP_BYTES, "the two band matrices live in the dP tile's area until the dP stage");
+static_assert(3 * 4 * 2 * 64 * 4 * 4 <= BW_SDQ_BYTES, "K-split partials of the band product live in the dQKVS tile's area");
 
 struct CgBwdP {
     const float* dY;               // [N, F]: dL/d(BatchNorm output) (through the LeakyReLU), from the head kernel
@@ -535,11 +549,9 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     float* const sQq = reinterpret_cast<float*>(lds + BW_SQ_OFF);
     float* const sG = reinterpret_cast<float*>(lds + BW_SG_OFF);
     float* const sAl = reinterpret_cast<float*>(lds + BW_SE_OFF);          // alpha of in-edge E_lo + i
-    float* const sDs = sAl + BW_ECAP;                                      // d(score) of the same edge
-    int* const sSrc = reinterpret_cast<int*>(sDs + BW_ECAP);               // its source node
+    int* const sSrc = reinterpret_cast<int*>(sAl + 2 * BW_ECAP);           // its source node
     int* const sOd = sSrc + BW_ECAP;                                       // out-edge O_lo + i: target node
-    int* const sOe = sOd + BW_OCAP;                                        //   its in-edge id
-    int* const sOt = sOe + BW_OCAP;                                        //   relation
+    int* const sOt = sOd + 2 * BW_OCAP;                                    //   relation
     float* const sOw = reinterpret_cast<float*>(sOt + BW_OCAP);            //   1 / count of (target, relation)
     int* const sIp = reinterpret_cast<int*>(sOw + BW_OCAP);                // in_ptr of outer rows (37)
     int* const sOp = sIp + 40;                                             // out_ptr of mid rows (27)
@@ -567,23 +579,25 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     if (tid < CG_OUT + 1) sIp[tid] = p.in_ptr[min(max(ob + tid, 0), N)];
     if (tid >= 64 && tid < 64 + CG_MID + 1) sOp[tid - 64] = p.out_ptr[min(max(mb + tid - 64, 0), N)];
     {
-        // K / V rows of the far range: 46 rows x 50 float4
+        // K / V rows of the far range: 46 (+ 2 zero) rows x 50 float4
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int i = tid + CG_NTH * j;
-            const int f = min(i / 50, CG_FAR - 1), q = i % 50;
+            const int f = min(i / 50, BW_ROWS - 1), q = i % 50;
             const int node = fb + f;
-            const bool ok = i < CG_FAR * 50 && node >= 0 && node < N;
+            const bool ok = f < CG_FAR && node >= 0 && node < N;
             const f32x4 v = *reinterpret_cast<const f32x4*>(p.QKVS + (int64_t)min(max(node, 0), N - 1) * 400 + CG_F + 4 * q);
             const float m = ok ? 1.f : 0.f;
             float* dst = (q < 25 ? sK + f * CG_F + 4 * q : sV + f * CG_F + 4 * (q - 25));
-            if (i < CG_FAR * 50) *reinterpret_cast<f32x4*>(dst) = (f32x4){v.x * m, v.y * m, v.z * m, v.w * m};
+            if (i < BW_ROWS * 50) *reinterpret_cast<f32x4*>(dst) = (f32x4){v.x * m, v.y * m, v.z * m, v.w * m};
         }
-        // Q rows and dH2 = BatchNorm backward of the outer range: 36 rows x 25 float4
-        if (tid < CG_OUT * 25) {
-            const int e = tid / 25, q = tid % 25;
+        // Q rows and dH2 = BatchNorm backward of the outer range: 36 (+ 12 zero) rows x 25 float4
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + CG_NTH * j;
+            const int e = min(i / 25, BW_ROWS - 1), q = i % 25;
             const int node = ob + e;
-            const bool ok = node >= 0 && node < N;
+            const bool ok = e < CG_OUT && node >= 0 && node < N;
             const int64_t nc = min(max(node, 0), N - 1);
             const f32x4 qv = *reinterpret_cast<const f32x4*>(p.QKVS + nc * 400 + 4 * q);
             const f32x4 dy = *reinterpret_cast<const f32x4*>(p.dY + nc * CG_F + 4 * q);
@@ -598,8 +612,10 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                 gq[t] = ga[t] * rs[t] * (dy[t] - ma[t] - (x[t] - mu[t]) * rs[t] * mbv[t]) * m;
                 qq[t] = qv[t] * m;
             }
-            *reinterpret_cast<f32x4*>(sG + e * CG_F + 4 * q) = gq;
-            *reinterpret_cast<f32x4*>(sQq + e * CG_F + 4 * q) = qq;
+            if (i < BW_ROWS * 25) {
+                *reinterpret_cast<f32x4*>(sG + e * CG_F + 4 * q) = gq;
+                *reinterpret_cast<f32x4*>(sQq + e * CG_F + 4 * q) = qq;
+            }
         }
         // edge slices
         if (tid < BW_ECAP) {
@@ -609,92 +625,85 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
             const int sj = p.in_src[ei];
             sAl[tid] = ok ? a : 0.f;
             sSrc[tid] = ok ? sj : 0;
-            sDs[tid] = 0.f;
         }
         if (tid >= 512 && tid < 512 + BW_OCAP) {
             const int i = tid - 512;
             const int oi = min(O_lo + i, max(O_hi - 1, O_lo));
             const bool ok = O_lo + i < O_hi;
-            const int dst = p.out_dst[oi], typ = p.out_typ[oi], eid = p.out_eid[oi];
+            const int dst = p.out_dst[oi], typ = p.out_typ[oi];
             const float wgt = p.inv_cnt[(int64_t)dst * CG_R + min(typ, CG_R - 1)];
             sOd[i] = ok ? dst : 0;
-            sOe[i] = ok ? eid : E_lo;
             sOt[i] = ok ? typ : CG_R;
             sOw[i] = (ok && typ < CG_R) ? wgt : 0.f;
         }
-        // K padding and the dead rows of the dQKVS tile
-        uint32_t* const sDQw = reinterpret_cast<uint32_t*>(sDQ);
-        if (tid < CG_MID * 12) sDQw[(tid / 12) * (CG_SDQ / 2) + 200 + (tid % 12)] = 0u;
-        for (int i = tid; i < 6 * (CG_SDQ / 2); i += CG_NTH) sDQw[CG_MID * (CG_SDQ / 2) + i] = 0u;
     }
     __syncthreads();
     CG_STAMP(1);
 
-    // ---- stage 1: target side of the attention backward for the 36 outer rows (one wavefront per row; lane l < 50 owns
-    //      channels 2l, 2l + 1)
-    const bool act = lane < CG_F / 2;
-    const int c2 = 2 * min(lane, CG_F / 2 - 1);
-    const float am = act ? 1.f : 0.f;
-#pragma unroll 1
-    for (int e = w; e < CG_OUT; e += CG_NW) {
-        const int node = ob + e;
-        const bool valid = node >= 0 && node < N;
-        const int e0 = __builtin_amdgcn_readfirstlane(sIp[e] - E_lo), e1 = __builtin_amdgcn_readfirstlane(sIp[e + 1] - E_lo);
-        const int nwin = valid ? min(max(e1 - e0, 0), CG_CH) : 0;
-        const int eb = max(e0, 0);
-        const int em = e - CG_HL;     // row of the mid tile
-        const bool in_mid = em >= 0 && em < CG_MID;   // wave-uniform: dq is only needed there
-        float2 gv = *reinterpret_cast<const float2*>(sG + e * CG_F + c2);
-        gv.x *= am, gv.y *= am;
-        float al[CG_CH];
-        int ljs[CG_CH];
+    // ---- stages 1 / 2: the attention backward as BAND products on the matrix cores (v_mfma_f32_16x16x4_f32: exact
+    //      fp32, a k-ordered fma chain).  A target only sees sources within +-5 rows, so the (target, source) quantities
+    //      of a 16-target row tile live in two 16-column tiles of the far range:
+    //        dA = G V^T (band)  ->  ds = alpha (dA - sum_s alpha dA) scale  (elementwise on the band, DPP row sums)
+    //        dq = DS K,  dk = DS^T Q,  dv = AL^T G                          (band x row tiles, K = 32 sources / targets)
+    //      One wavefront per graph row with 12-edge gathers cost 9.5 us for these two stages (wave-instruction bound).
+    float* const sDS = reinterpret_cast<float*>(lds + BW_SDP_OFF);            // [48][68] d(score), 0 outside the band
+    float* const sAL = sDS + BW_ROWS * BW_BAND;                               // [48][68] alpha in the same layout
+    float* const sPartA = reinterpret_cast<float*>(lds + BW_SDQ_OFF);         // K-split partials (the dQKVS tile is written later)
+    {
+        // (a) dA: row tile i = w >> 2 (outer rows 16 i ..), K quarter j = w & 3 (25 k-steps as 7 + 7 + 7 + 4), both
+        //     column tiles (far rows 16 i .. 16 i + 31); wavefronts 12..15 zero the band matrices meanwhile
+        const int bi = w >> 2, bj = w & 3;
+        f32x4 dA0 = {0.f, 0.f, 0.f, 0.f}, dA1 = {0.f, 0.f, 0.f, 0.f};
+        if (bi < 3) {
+            const float* const ga = sG + (16 * bi + r) * CG_F + g;
+            const float* const v0 = sV + min(16 * bi + r, BW_ROWS - 1) * CG_F + g;
+            const float* const v1 = sV + min(16 * (bi + 1) + r, BW_ROWS - 1) * CG_F + g;
+            const int ks0 = 7 * bj, ks1 = min(25, ks0 + 7);
 #pragma unroll
-        for (int u = 0; u < CG_CH; ++u) {
-            const int x = min(eb + min(u, max(nwin - 1, 0)), BW_ECAP - 1);
-            ljs[u] = sSrc[x];
-            al[u] = sAl[x];
-        }
-        float2 vv[CG_CH];
-#pragma unroll
-        for (int u = 0; u < CG_CH; ++u) {
-            ljs[u] = min(max(ljs[u] - fb, 0), CG_FAR - 1) * CG_F + c2;
-            al[u] = u < nwin ? al[u] : 0.f;
-            vv[u] = *reinterpret_cast<const float2*>(sV + ljs[u]);
-        }
-        float da[CG_CH], part[16], t = 0.f;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) part[u] = u < CG_CH ? gv.x * vv[u < CG_CH ? u : 0].x + gv.y * vv[u < CG_CH ? u : 0].y : 0.f;
-        wave_sums_ch(part, da, lane);
-#pragma unroll
-        for (int u = 0; u < CG_CH; ++u) t += al[u] * da[u];
-        float mine = 0.f;
-#pragma unroll
-        for (int u = 0; u < CG_CH; ++u) {
-            da[u] = al[u] * (da[u] - t) * p.scale;     // d(score)
-            if (lane == u) mine = da[u];
-        }
-        if (lane < nwin) sDs[min(eb + lane, BW_ECAP - 1)] = mine;
-        if (in_mid) {
-            float2 kk[CG_CH];
-#pragma unroll
-            for (int u = 0; u < CG_CH; ++u) kk[u] = *reinterpret_cast<const float2*>(sK + ljs[u]);
-            float dq0 = 0.f, dq1 = 0.f;
-#pragma unroll
-            for (int u = 0; u < CG_CH; ++u) dq0 += da[u] * kk[u].x, dq1 += da[u] * kk[u].y;
-            if (!valid) dq0 = dq1 = 0.f;
-            uint32_t* row = reinterpret_cast<uint32_t*>(sDQ + em * CG_SDQ);
-            if (act) {
-                row[lane] = (uint32_t)f2bf(dq0) | ((uint32_t)f2bf(dq1) << 16);
-                row[3 * CG_F / 2 + lane] = (uint32_t)f2bf(gv.x) | ((uint32_t)f2bf(gv.y) << 16);
+            for (int u = 0; u < 7; ++u) {
+                const int ks = min(ks0 + u, 24);
+                const float m = ks0 + u < ks1 ? 1.f : 0.f;
+                const float af = ga[4 * ks] * m;
+                dA0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, v0[4 * ks], dA0, 0, 0, 0);
+                dA1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af, v1[4 * ks], dA1, 0, 0, 0);
             }
-            if (valid && em >= CG_HL && em < CG_HL + CG_TR && act) {
-                float* d = p.dQKVS + (int64_t)node * 400 + c2;
-                *reinterpret_cast<float2*>(d) = make_float2(dq0, dq1);
-                *reinterpret_cast<float2*>(d + 3 * CG_F) = gv;
-            }
+            float* dst = sPartA + (((bi * 4 + bj) * 2) * 64 + lane) * 4;
+            *reinterpret_cast<f32x4*>(dst) = dA0, *reinterpret_cast<f32x4*>(dst + 256) = dA1;
+        } else {
+            for (int i = lane + 64 * (w - 12); i < 2 * BW_ROWS * BW_BAND / 4; i += 256) reinterpret_cast<f32x4*>(sDS)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        __syncthreads();
+        // (b) the band elementwise: the four wavefronts of a row tile each take one of the four target rows a lane holds
+        //     (q = K quarter): lane (r, g) -> target 16 i + 4 g + q x sources 16 (i + c) + r (c < 2)
+        if (bi < 3) {
+            const int q = bj;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float* src = sPartA + (((bi * 4 + jj) * 2) * 64 + lane) * 4 + q;
+                a0 += src[0], a1 += src[256];
+            }
+            const int t = 16 * bi + 4 * g + q;                 // outer row
+            const int node_t = ob + t;
+            const bool tv = t < CG_OUT && node_t >= 0 && node_t < N;
+            const int tc = min(t, CG_OUT - 1);
+            const int e0 = min(max(sIp[tc] - E_lo, 0), BW_ECAP - 1);
+            const int cnt = tv ? min(max(sIp[tc + 1] - sIp[tc], 0), CG_CH) : 0;
+            const int lo = sSrc[e0];                           // first source node of the target's in-edges
+            const int o0 = (fb + 16 * bi + r) - lo, o1 = o0 + 16;   // edge position of source column r of the two tiles
+            const bool k0 = o0 >= 0 && o0 < cnt, k1 = o1 >= 0 && o1 < cnt;
+            const float al0 = k0 ? sAl[min(e0 + max(o0, 0), BW_ECAP - 1)] : 0.f;
+            const float al1 = k1 ? sAl[min(e0 + max(o1, 0), BW_ECAP - 1)] : 0.f;
+            const float x0 = k0 ? al0 * a0 : 0.f, x1 = k1 ? al1 * a1 : 0.f;
+            const float tsum = cg_row16_sum(x0 + x1);
+            const float d0 = k0 ? al0 * (a0 - tsum) * p.scale : 0.f, d1 = k1 ? al1 * (a1 - tsum) * p.scale : 0.f;
+            float* drow = sDS + t * BW_BAND + 16 * bi + r;
+            float* arow = sAL + t * BW_BAND + 16 * bi + r;
+            drow[0] = d0, drow[16] = d1;
+            arow[0] = al0, arow[16] = al1;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     CG_STAMP(2);
 
     // B fragments of the dH1 product (K = 416: blocks [7 kh, 7 kh + 7), the second half has 6): requested now
@@ -703,47 +712,57 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
 #pragma unroll
     for (int u = 0; u < 7; ++u) fb3[u] = *reinterpret_cast<const bf16x8*>(brow3 + 512 * min(u, kh ? 5 : 6));
 
-    // ---- stage 2: source side for the 26 mid rows: dk = sum ds q_target, dv = sum alpha dH2_target over the out-edges
+    {
+        // (c) the dQKVS tile [26 mid rows][400] (bf16, the A operand of the dH1 product; own rows also to global memory):
+        //     K padding / dead rows, the skip part (= dH2), then 42 units of 8 MFMAs: dq for outer row tiles 0, 1 (7 column
+        //     tiles each), dk and dv for mid row tiles 0, 1
+        uint32_t* const sDQw = reinterpret_cast<uint32_t*>(sDQ);
+        if (tid < CG_MID * 12) sDQw[(tid / 12) * (CG_SDQ / 2) + 200 + (tid % 12)] = 0u;
+        for (int i = tid; i < 6 * (CG_SDQ / 2); i += CG_NTH) sDQw[CG_MID * (CG_SDQ / 2) + i] = 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + CG_NTH * j;                 // 26 rows x 50 channel pairs
+            const int em = i / 50, cp = i % 50;
+            if (i < CG_MID * 50) {
+                const float2 gv = *reinterpret_cast<const float2*>(sG + (em + CG_HL) * CG_F + 2 * cp);
+                sDQw[em * (CG_SDQ / 2) + 150 + cp] = (uint32_t)f2bf(gv.x) | ((uint32_t)f2bf(gv.y) << 16);
+                const int node = mb + em;
+                if (em >= CG_HL && em < CG_HL + CG_TR && node < N) *reinterpret_cast<float2*>(p.dQKVS + (int64_t)node * 400 + 3 * CG_F + 2 * cp) = gv;
+            }
+        }
 #pragma unroll 1
-    for (int em = w; em < CG_MID; em += CG_NW) {
-        const int node = mb + em;
-        const bool valid = node >= 0 && node < N;
-        const int o0 = __builtin_amdgcn_readfirstlane(sOp[em] - O_lo), o1 = __builtin_amdgcn_readfirstlane(sOp[em + 1] - O_lo);
-        const int nwin = valid ? min(max(o1 - o0, 0), CG_CH) : 0;
-        const int xb = max(o0, 0);
-        float dk0 = 0.f, dk1 = 0.f, dv0 = 0.f, dv1 = 0.f;
+        for (int u = w; u < 42; u += CG_NW) {
+            // unit -> (kind: 0 dq | 1 dk | 2 dv, row tile, column tile)
+            const int kind = u < 14 ? 0 : 1 + (u - 14) / 14, uu = u < 14 ? u : (u - 14) % 14;
+            const int rt = uu / 7, cti = uu % 7;
+            const int col = min(16 * cti + r, CG_F - 1);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (kind == 0) {       // dq[t][c] = sum_s DS[t][s] K[s][c]: t = outer row 16 rt + r, s = far rows 16 rt .. + 31
+                const float* const a = sDS + (16 * rt + r) * BW_BAND + 16 * rt + g;
+                const float* const bq = sK + (16 * rt + g) * CG_F + col;
 #pragma unroll
-        for (int hb = 0; hb < CG_CH; hb += 6) {      // two batches of six out-edges (register budget)
-            int lts[6], les[6];
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * ks], bq[4 * ks * CG_F], acc, 0, 0, 0);   // rows <= 16 + 3 + 28 = 47: inside the padded tile
+            } else {               // dk[i][c] = sum_t DS[t][i] Q[t][c], dv[i][c] = sum_t AL[t][i] G[t][c]: i = mid row 16 rt + r
+                                   // (far column 16 rt + r + 10), t = outer rows 16 rt .. + 31
+                const float* const a = (kind == 1 ? sDS : sAL) + (16 * rt + g) * BW_BAND + 16 * rt + r + 2 * CG_HL;
+                const float* const bq = (kind == 1 ? sQq : sG) + (16 * rt + g) * CG_F + col;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int x = min(xb + min(hb + j, max(nwin - 1, 0)), BW_OCAP - 1);
-                lts[j] = sOd[x], les[j] = sOe[x];
+                for (int ks = 0; ks < 8; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * ks * BW_BAND], bq[4 * ks * CG_F], acc, 0, 0, 0);
             }
-            float ds[6], al[6];
-            float2 qq[6], gg[6];
+            // result rows 4 g + q of the tile, column 16 cti + r: into the dQKVS tile (bf16) and, for own rows, to global
+            const int coff = kind * CG_F;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int lt = min(max(lts[j] - ob, 0), CG_OUT - 1) * CG_F + c2;
-                const int le = min(max(les[j] - E_lo, 0), BW_ECAP - 1);
-                ds[j] = sDs[le], al[j] = sAl[le];
-                qq[j] = *reinterpret_cast<const float2*>(sQq + lt), gg[j] = *reinterpret_cast<const float2*>(sG + lt);
+            for (int q = 0; q < 4; ++q) {
+                const int em = kind == 0 ? 16 * rt + 4 * g + q - CG_HL : 16 * rt + 4 * g + q;   // mid row
+                const int node = mb + em;
+                const bool rowv = em >= 0 && em < CG_MID;
+                if (rowv && 16 * cti + r < CG_F) {
+                    const bool nv = node >= 0 && node < N;
+                    sDQ[em * CG_SDQ + coff + 16 * cti + r] = f2bf(nv ? acc[q] : 0.f);
+                    if (nv && em >= CG_HL && em < CG_HL + CG_TR) p.dQKVS[(int64_t)node * 400 + coff + 16 * cti + r] = acc[q];
+                }
             }
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float d = hb + j < nwin ? ds[j] : 0.f, a = hb + j < nwin ? al[j] : 0.f;
-                dk0 += d * qq[j].x, dk1 += d * qq[j].y, dv0 += a * gg[j].x, dv1 += a * gg[j].y;
-            }
-        }
-        uint32_t* row = reinterpret_cast<uint32_t*>(sDQ + em * CG_SDQ);
-        if (act) {
-            row[CG_F / 2 + lane] = (uint32_t)f2bf(dk0) | ((uint32_t)f2bf(dk1) << 16);
-            row[CG_F + lane] = (uint32_t)f2bf(dv0) | ((uint32_t)f2bf(dv1) << 16);
-        }
-        if (valid && em >= CG_HL && em < CG_HL + CG_TR && act) {
-            float* d = p.dQKVS + (int64_t)node * 400 + c2;
-            *reinterpret_cast<float2*>(d + CG_F) = make_float2(dk0, dk1);
-            *reinterpret_cast<float2*>(d + 2 * CG_F) = make_float2(dv0, dv1);
         }
     }
     __syncthreads();
@@ -800,6 +819,8 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     //      = sum over out-edges (j -> i, relation r) of dH1[i] / count_r(i); block 8 = dH1[j].  Scalar-branch
     //      accumulation and a rolled edge loop as in the forward aggregation.
     {
+        const bool act = lane < CG_F / 2;                 // lane l < 50 owns channels 2l, 2l + 1
+        const int c2 = 2 * min(lane, CG_F / 2 - 1);
         uint32_t* const sDPw = reinterpret_cast<uint32_t*>(sDP);
         const int li = w, em = CG_HL + li, node = r0 + li;
         const bool valid = node < N;

@@ -31,7 +31,7 @@ def main():
     torch.cuda.synchronize()
     names = {"erc_cogmen_fwd_tile": ["H0 rows -> LDS", "relation means", "H1 product", "QKVS product", "QKVS store + attention",
                                      "BatchNorm partials", "(arrival ..) last arriver done"],
-             "erc_cogmen_bwd_tile": ["slices + tiles -> LDS", "target side", "source side", "dH1 product", "dP", "dH0 product"]}
+             "erc_cogmen_bwd_tile": ["slices + tiles -> LDS", "band dA + d(score)", "dq / dk / dv band products", "dH1 product", "dP", "dH0 product"]}
     for entry, labels in names.items():
         call = [e for e in rec if e[0] == entry][0]
         st = torch.zeros(16, dtype=torch.int64, device="cuda:0")
