@@ -75,7 +75,7 @@ _SIGS = {
     "erc_cogmen_fwd_tile_ws_doubles": (C.c_int64, [_i]),
     "erc_cogmen_set_stamps": (C.c_int, [_vp]),
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
-                                      _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
+                                      _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp]),
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
@@ -396,11 +396,13 @@ def cogmen_fwd_tile_ws_doubles(n):
 
 
 def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, inv_cnt, H1b, ldh1b, QKVS, H2, ldh2, alpha,
-                    bn_fused=False, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, saved=None, bn_ws=None):
+                    bn_fused=False, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, saved=None, bn_ws=None,
+                    n_speakers=2):
     _check(lib().erc_cogmen_fwd_tile(ptr(H0), ldh0, N, wp, wf, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
                                      ptr(WcatT), ptr(b1), ptr(Wq), ptr(bq), scale, ptr(Mb), ldmb, ptr(inv_cnt), ptr(H1b),
                                      ldh1b, ptr(QKVS), ptr(H2), ldh2, ptr(alpha), int(bn_fused), ptr(running_mean),
-                                     ptr(running_var), momentum, eps, ptr(saved), ptr(bn_ws), stream()),
+                                     ptr(running_var), momentum, eps, ptr(saved), ptr(bn_ws), ptr(g["node_spk"]), n_speakers,
+                                     stream()),
            "erc_cogmen_fwd_tile")
 
 

@@ -262,7 +262,7 @@ class COGMENModule(nn.Module):
                                  fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], 904, ws["inv_cnt"],
                                  ws["H1b"], 104, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=2 if ws["bn_in_tile"] else 0,
                                  running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum,
-                                 eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"])
+                                 eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=self.n_speakers)
             if upto_h2:
                 return ws
             return self._forward_tail(ws, N, training)

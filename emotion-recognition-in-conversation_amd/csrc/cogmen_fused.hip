@@ -60,7 +60,11 @@ constexpr int FW_SE_OFF = FW_SH0_OFF + FW_SH0_BYTES;           // sSrc[288], sTy
 constexpr int FW_SE_BYTES = (2 * FW_ECAP + 32) * 4;
 constexpr int FW_RED_OFF = FW_SE_OFF + FW_SE_BYTES;            // BatchNorm finalisation scratch: 4 x 256 doubles
 constexpr int FW_RED_BYTES = 4 * 256 * 8;
-constexpr int FW_LDS = FW_RED_OFF + FW_RED_BYTES + 16;
+constexpr int FW_PFX_OFF = FW_RED_OFF + FW_RED_BYTES + 16;     // two-speaker path: exclusive per-speaker prefix sums of the H0 rows
+constexpr int FW_PFX_BYTES = 2 * (CG_OUT + 1) * CG_F * 8;      //   [2][37][100] fp64 = 59200
+constexpr int FW_SPK_OFF = FW_PFX_OFF + FW_PFX_BYTES;          // speakers of the 36 outer rows
+constexpr int FW_LDS = FW_SPK_OFF + 64 * 4;
+static_assert(FW_PFX_OFF % 16 == 0 && FW_LDS <= 160 * 1024, "forward LDS map");
 static_assert(7 * 64 * 8 * 4 <= FW_SH0_BYTES, "K-split partials must fit the H0 area");
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
@@ -128,13 +132,14 @@ struct CgFwdP {
     float* QKVS;                   // out [N, 400]
     float* H2;                     // out [N, ldh2]
     float* alpha;                  // out [E]
+    const int32_t* node_spk;       // speaker of every node; two_spk: all in {0, 1} (n_speakers = 2) -> prefix-sum aggregation
     double* bn_part;               // [tiles][200] column sums of H2 and H2^2 (bn_fused)
     int* bn_counter;
     float* running_mean;
     float* running_var;
     float* saved;                  // out [0,F) mean, [F,2F) rstd
     float momentum, eps, scale;
-    int N, ldh0, ldmb, ldh1b, ldh2, bn_fused;
+    int N, ldh0, ldmb, ldh1b, ldh2, bn_fused, two_spk;
     uint64_t* stamps;
     int stamp_block;
 };
@@ -152,6 +157,8 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     int* const sIp = sTyp + FW_ECAP;
     double* const sRed = reinterpret_cast<double*>(lds + FW_RED_OFF);
     int* const s_last = reinterpret_cast<int*>(lds + FW_RED_OFF + FW_RED_BYTES);
+    double* const sPfx = reinterpret_cast<double*>(lds + FW_PFX_OFF);
+    int* const sSpk = reinterpret_cast<int*>(lds + FW_SPK_OFF);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar branches below
     const int N = p.N;
@@ -186,6 +193,11 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
             const int ei = min(E_lo + i, max(E_hi - 1, E_lo));
             sSrc[i] = p.in_src[ei], sTyp[i] = p.in_typ[ei];
         }
+        if (tid >= 960 && tid < 960 + CG_OUT) {      // speakers of the outer rows (-1: no such node)
+            const int node = ob + tid - 960;
+            const int sp = p.node_spk[min(max(node, 0), N - 1)];
+            sSpk[tid - 960] = (node >= 0 && node < N) ? sp : -1;
+        }
         // columns [900, 936) of rows 0..25: 18 dwords each; row 26 entirely: 468 dwords
         uint32_t* const sMw = reinterpret_cast<uint32_t*>(sM);
         if (tid < 26 * 18) sMw[(tid / 18) * (CG_SM / 2) + CG_KM / 2 + (tid % 18)] = 0u;
@@ -204,6 +216,105 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     //      (two adds executed per edge instead of an 8-way select chain), the edge loop stays rolled (two edges per
     //      trip; the code of this kernel runs once per launch from a cold instruction cache), and the mean is
     //      sum * rcp(count) with one Newton step (3 instructions; IEEE division is ~25).
+    if (p.two_spk) {
+        // Two speakers (the reference's GNN(n_speakers = 2), cogmen.py:62-64): the relation of an edge is
+        // 4 spk(source) + 2 spk(target) + (source < target ? 0 : 1) and the sources of a target are a contiguous run of rows,
+        // so the four non-empty relation sums of a target are DIFFERENCES of per-speaker prefix sums over the tile's rows: a
+        // row costs 6 LDS reads and 4 subtractions per lane instead of an 11-edge gather.  The prefix sums are fp64: the
+        // difference, rounded to fp32, is then the (almost always correctly rounded) window sum whatever the tile's first row
+        // is -- a halo row gets bit-identical means in every tile that recomputes it, which the backward relies on (it reads
+        // the OWNER tile's QKVS).  Scan: 4 segments of 9 rows in parallel (800 threads), then the segment offsets.
+        {
+            double* const sTot = sRed;                        // [4][200] segment totals (the BatchNorm scratch is free here)
+            const int sg = tid / (2 * CG_F), bc = tid % (2 * CG_F), b = bc / CG_F, c = bc % CG_F;
+            double* const pf = sPfx + (b * (CG_OUT + 1) + 9 * sg) * CG_F + c;
+            double acc = 0.0;
+            if (tid < 8 * CG_F) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    pf[i * CG_F] = acc;
+                    acc += sSpk[9 * sg + i] == b ? (double)sH0[(9 * sg + i) * CG_F + c] : 0.0;
+                }
+                sTot[sg * 2 * CG_F + bc] = acc;
+            }
+            __syncthreads();
+            if (tid < 8 * CG_F) {
+                double off = 0.0;
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) off += s2 < sg ? sTot[s2 * 2 * CG_F + bc] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) pf[i * CG_F] += off;
+                if (sg == 3) pf[9 * CG_F] = off + acc;        // entry 36: everything
+            }
+        }
+        __syncthreads();
+        const bool act = lane < CG_F / 2;
+        const int c2 = 2 * min(lane, CG_F / 2 - 1);
+        // speaker masks of the outer rows (bit e: row e has speaker b), wave-uniform
+        const int my_spk = lane < CG_OUT ? sSpk[lane] : -1;
+        const unsigned long long mask0 = __ballot(my_spk == 0), mask1 = __ballot(my_spk == 1);
+#pragma unroll 1
+        for (int e = w; e < CG_MID; e += CG_NW) {
+            const int node = mb + e;
+            const bool valid = node >= 0 && node < N;
+            const int e0 = __builtin_amdgcn_readfirstlane(min(max(sIp[e] - E_lo, 0), FW_ECAP - 1));
+            const int nwin = __builtin_amdgcn_readfirstlane(valid ? min(max(sIp[e + 1] - sIp[e], 0), CG_CH) : 0);
+            const int te = e + CG_HL;                                                        // outer row of the target
+            const int lo = __builtin_amdgcn_readfirstlane(min(max(sSrc[e0] - ob, 0), te));   // first / one-past-last source row
+            const int hi1 = nwin > 0 ? min(lo + nwin, CG_OUT) : lo;
+            const int a = __builtin_amdgcn_readfirstlane(max(sSpk[te], 0));                  // target speaker
+            const int past_hi = min(te, hi1);        // sources [lo, te) are "past" (direction bit 0), [te, hi1) the rest
+            auto range_mask = [](int x0, int x1) -> unsigned long long {   // bits [x0, x1)
+                return x1 > x0 ? ((~0ull >> (64 - (x1 - x0))) << x0) : 0ull;
+            };
+            const unsigned long long mp = range_mask(lo, past_hi), mf = range_mask(max(te, lo), hi1);
+            int cnt[4];   // group 2 b + dir
+            cnt[0] = __popcll(mask0 & mp), cnt[1] = __popcll(mask0 & mf), cnt[2] = __popcll(mask1 & mp), cnt[3] = __popcll(mask1 & mf);
+            const double* const p0 = sPfx + c2, * const p1 = sPfx + (CG_OUT + 1) * CG_F + c2;
+            const double2 a_lo = *reinterpret_cast<const double2*>(p0 + lo * CG_F), a_te = *reinterpret_cast<const double2*>(p0 + past_hi * CG_F);
+            const double2 a_hi = *reinterpret_cast<const double2*>(p0 + hi1 * CG_F);
+            const double2 b_lo = *reinterpret_cast<const double2*>(p1 + lo * CG_F), b_te = *reinterpret_cast<const double2*>(p1 + past_hi * CG_F);
+            const double2 b_hi = *reinterpret_cast<const double2*>(p1 + hi1 * CG_F);
+            float2 sum[4];
+            sum[0] = make_float2((float)(a_te.x - a_lo.x), (float)(a_te.y - a_lo.y)), sum[1] = make_float2((float)(a_hi.x - a_te.x), (float)(a_hi.y - a_te.y));
+            sum[2] = make_float2((float)(b_te.x - b_lo.x), (float)(b_te.y - b_lo.y)), sum[3] = make_float2((float)(b_hi.x - b_te.x), (float)(b_hi.y - b_te.y));
+            const int le = min(max(node - ob, 0), CG_OUT - 1);
+            float2 self = *reinterpret_cast<const float2*>(sH0 + le * CG_F + c2);
+            if (!valid) self = make_float2(0.f, 0.f);
+            uint32_t pk4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float fc = (float)max(cnt[q], 1), rc = __builtin_amdgcn_rcpf(fc);
+                float m0 = sum[q].x * rc, m1 = sum[q].y * rc;
+                m0 = fmaf(fmaf(-m0, fc, sum[q].x), rc, m0), m1 = fmaf(fmaf(-m1, fc, sum[q].y), rc, m1);
+                pk4[q] = cnt[q] > 0 ? ((uint32_t)f2bf(m0) | ((uint32_t)f2bf(m1) << 16)) : 0u;
+            }
+            const uint32_t pks = (uint32_t)f2bf(self.x) | ((uint32_t)f2bf(self.y) << 16);
+            const bool own = valid && e >= CG_HL && e < CG_HL + CG_TR;
+            uint32_t* const mrow = reinterpret_cast<uint32_t*>(sM + e * CG_SM);
+            uint32_t* const grow = reinterpret_cast<uint32_t*>(p.Mb + (int64_t)(own ? node : 0) * p.ldmb);
+            // relation r = 4 b + 2 a + dir: groups (b, dir) = 0..3 land in blocks 2 a + {0, 1, 4, 5}; the other four are empty
+            if (act) {
+#pragma unroll
+                for (int q = 0; q < CG_R; ++q) {
+                    const int grp = (q >> 2) * 2 + (q & 1);            // which group block q would hold
+                    const uint32_t v = ((q >> 1) & 1) == a ? pk4[grp] : 0u;
+                    mrow[q * (CG_F / 2) + lane] = v;
+                    if (own) grow[q * (CG_F / 2) + lane] = v;
+                }
+                mrow[CG_R * (CG_F / 2) + lane] = pks;
+                if (own) grow[CG_R * (CG_F / 2) + lane] = pks;
+            }
+            if (own && lane < CG_R) {
+                const int grp = (lane >> 2) * 2 + (lane & 1);
+                int c = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c = grp == q ? cnt[q] : c;
+                c = ((lane >> 1) & 1) == a ? c : 0;
+                p.inv_cnt[(int64_t)node * CG_R + lane] = c > 0 ? 1.0f / (float)c : 0.f;
+            }
+        }
+    } else
     {
         const bool act = lane < CG_F / 2;
         const int c2 = 2 * min(lane, CG_F / 2 - 1);
@@ -917,8 +1028,8 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
                                    const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
                                    int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
                                    float* running_mean, float* running_var, float momentum, float eps, float* saved,
-                                   double* bn_ws, void* stream) {
-    ERC_REQUIRE(H0 && in_ptr && in_src && in_typ && WcatT && b1 && Wq && bq && Mb && inv_cnt && H1b && QKVS && H2 && alpha,
+                                   double* bn_ws, const int32_t* node_spk, int n_speakers, void* stream) {
+    ERC_REQUIRE(H0 && in_ptr && in_src && in_typ && WcatT && b1 && Wq && bq && Mb && inv_cnt && H1b && QKVS && H2 && alpha && node_spk,
                 "cogmen_fwd_tile: null pointer");
     ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_fwd_tile: window (%d, %d) exceeds the halo %d",
                 wp, wf, CG_HL);
@@ -939,6 +1050,7 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
     p.running_mean = running_mean; p.running_var = running_var; p.saved = saved;
     p.momentum = momentum; p.eps = eps; p.scale = scale;
     p.N = n_nodes; p.ldh0 = ldh0; p.ldmb = ldmb; p.ldh1b = ldh1b; p.ldh2 = ldh2; p.bn_fused = bn_fused;
+    p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0;
     p.stamps = g_cg_stamps; p.stamp_block = tiles / 2;
     hipLaunchKernelGGL(cogmen_fwd_tile_kernel, dim3(tiles), dim3(CG_NTH), FW_LDS, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("cogmen_fwd_tile");

@@ -384,6 +384,9 @@ int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
  *   Wb    [112][960 = 30 K blocks]: Wb[c][r*104 + o] = conv1.weight[r][c][o] (r = 8: root)
  * Forward outputs: Mb bf16 [N, ldmb >= 900] = [mean_r H0 | H0] and H1b bf16 [N, ldh1b >= 100] (operands of the weight
  * gradients), inv_cnt [N,8], QKVS fp32 [N,400], H2 [N, ldh2], alpha [E] (softmax weights per in-edge).
+ * node_spk / n_speakers: erc_window_graph_build's speaker array and the speaker count it was built with; with two speakers
+ * (ids 0 / 1, the reference's GNN(n_speakers = 2)) the relation means are differences of per-speaker prefix sums over
+ * the tile's rows, otherwise an edge-by-edge gather.
  * bn_fused = 1: also the training-mode BatchNorm statistics of H2 (saved = mean | rstd, running statistics updated)
  * by the last workgroup to arrive; bn_fused = 2: only the per-tile column sums, as floats [tiles][200] from bn_ws + 2
  * doubles on (= the bn_part operand of erc_head_fused_bn, which finalises them without a last arriver);
@@ -394,7 +397,7 @@ int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int wp, int wf, 
                         const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
                         int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
                         float* running_mean, float* running_var, float momentum, float eps, float* saved,
-                        double* bn_ws, void* stream);
+                        double* bn_ws, const int32_t* node_spk, int n_speakers, void* stream);
 /* Backward of the same: dY [N,100] = dL/d(BatchNorm output) (erc_head_fused), BatchNorm's elementwise backward
  * (gamma, saved, bn_bwd as erc_bn_bwd_apply), TransformerConv backward (target and source side), dH1 = dQKVS Wq,
  * the transposed relation means and dH0 = dP [W_r^T].  Outputs fp32: dQKVS [N,400], dH1 [N,100], dH0 [N, lddh0] --

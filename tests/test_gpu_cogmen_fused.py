@@ -26,7 +26,8 @@ def bf16_ulp(ref):
     dict(B=32, min_len=20, max_len=110, seed=16),     # the benched shape's node count (~2000)
     dict(B=3, min_len=1, max_len=2, seed=7),
 ], ids=["ragged", "config2", "tiny"])
-def test_fused_kernels_stagewise(case):
+@pytest.mark.parametrize("n_spk", [2, 3], ids=["two-speakers", "edge-gather"])
+def test_fused_kernels_stagewise(case, n_spk):
     from erc_amd import capi
     from erc_amd.cogmen import COGMENModule, WP, WF
     dev = "cuda:0"
@@ -54,14 +55,16 @@ def test_fused_kernels_stagewise(case):
     capi.cogmen_fwd_tile(H0, F, N, WP, WF, g, m._sh["catT"], fp.w("gcn.conv1.bias"), m._sh["q"],
                          fp.w("gcn.conv2.lin_query.bias"), scale, ws["Mb"], 904, ws["inv_cnt"], ws["H1b"], 104, ws["QKVS"],
                          ws["H2"], F, ws["alpha"], bn_fused=True, running_mean=bn.running_mean, running_var=bn.running_var,
-                         momentum=bn.momentum, eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"])
-    # ---- relation means: the fp32 kernel's result rounded to bf16 (the fused kernel divides by rcp + one Newton step:
-    #      an fp32 last-bit difference can only show where the mean sits on a bf16 rounding boundary)
+                         momentum=bn.momentum, eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=n_spk)
+    # ---- relation means: the fp32 kernel's result rounded to bf16.  The fused kernel divides by rcp + one Newton step and,
+    #      with two speakers, takes window sums as differences of per-speaker prefix sums (n_spk = 3 only selects the
+    #      edge-by-edge gather: the graph below is built with two speakers either way): fp32 last-bit differences, which can
+    #      only show where the mean sits on a bf16 rounding boundary
     M_ref, inv_ref = f32(N, 9 * F), f32(N, R)
     capi.rgcn_mean_fwd(H0, F, F, R, N, g, M_ref, 9 * F, inv_ref)
     Mb = ws["Mb"][:, :900].float()
-    assert bool(((Mb - M_ref).abs() <= bf16_ulp(M_ref) * 0.5 + 1e-12).all())
-    assert float((Mb != rb(M_ref)).float().mean()) < 1e-3
+    assert bool(((Mb - M_ref).abs() <= bf16_ulp(M_ref) * 0.51 + 1e-6).all())
+    assert float((Mb != rb(M_ref)).float().mean()) < 2e-3
     assert torch.equal(ws["inv_cnt"], inv_ref)
     # ---- H1 = rb(M) rb(Wcat) + b: within one bf16 step of the float64 product
     Wcat = torch.cat([fp.w("gcn.conv1.weight").reshape(R * F, F), fp.w("gcn.conv1.root")], 0)
