@@ -77,7 +77,7 @@ _SIGS = {
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
                                       _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp]),
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp]),
+                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
     "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
@@ -407,11 +407,12 @@ def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, 
 
 
 def cogmen_bwd_tile(dY, H2, ldh2, N, wp, wf, gamma, saved, bn_bwd, QKVS, alpha, g, inv_cnt, WqT, Wb, scale, dQKVS, dH1,
-                    dH0, lddh0):
+                    dH0, lddh0, n_speakers=2):
     _check(lib().erc_cogmen_bwd_tile(ptr(dY), ptr(H2), ldh2, N, wp, wf, ptr(gamma), ptr(saved), ptr(bn_bwd), ptr(QKVS),
                                      ptr(alpha), ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["out_ptr"]), ptr(g["out_dst"]),
                                      ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(inv_cnt), ptr(WqT), ptr(Wb), scale,
-                                     ptr(dQKVS), ptr(dH1), ptr(dH0), lddh0, stream()), "erc_cogmen_bwd_tile")
+                                     ptr(dQKVS), ptr(dH1), ptr(dH0), lddh0, ptr(g["node_spk"]), n_speakers, stream()),
+           "erc_cogmen_bwd_tile")
 
 
 def grad_norm(g, n, grad_scale, gnorm, ws):

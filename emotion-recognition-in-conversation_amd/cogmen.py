@@ -396,7 +396,7 @@ class COGMENModule(nn.Module):
         F, D = F_HID, self.input_size
         capi.cogmen_bwd_tile(ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"],
                              ws["QKVS"], ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F),
-                             ws["dQKVS"], ws["dH1"], ws["dH0"], F)
+                             ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers)
         pl.mma_bf16 = self.wgrad_bf16     # these three products on bf16 matrix cores (the head's stay fp32)
         linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1b"], 104, None, 4 * F, F, N,
                      fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"], defer=True)

@@ -642,13 +642,14 @@ struct CgBwdP {
     const int32_t* out_typ;
     const int32_t* out_eid;
     const float* inv_cnt;          // [N, 8]
+    const int32_t* node_spk;       // speakers; two_spk: all in {0, 1}
     const unsigned short* WqT;     // bf16, fragment order (7 x 13 x 512)
     const unsigned short* Wb;      // bf16, fragment order (7 x 30 x 512)
     float* dQKVS;                  // out [N, 400]
     float* dH1;                    // out [N, F]
     float* dH0;                    // out [N, lddh0]
     float scale;
-    int N, ldh2, lddh0;
+    int N, ldh2, lddh0, two_spk;
     uint64_t* stamps;
     int stamp_block;
 };
@@ -666,6 +667,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     float* const sOw = reinterpret_cast<float*>(sOt + BW_OCAP);            //   1 / count of (target, relation)
     int* const sIp = reinterpret_cast<int*>(sOw + BW_OCAP);                // in_ptr of outer rows (37)
     int* const sOp = sIp + 40;                                             // out_ptr of mid rows (27)
+    int* const sSpkOwn = reinterpret_cast<int*>(sAl + BW_ECAP);            // speakers of the 16 own rows (the unused d(score) slot)
     unsigned short* const sDQ = reinterpret_cast<unsigned short*>(lds + BW_SDQ_OFF);
     float* const sDH1 = reinterpret_cast<float*>(lds + BW_SDH1_OFF);
     unsigned short* const sDP = reinterpret_cast<unsigned short*>(lds + BW_SDP_OFF);
@@ -689,6 +691,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     const int O_lo = p.out_ptr[m_lo_node], O_hi = min(p.out_ptr[m_hi_node], O_lo + BW_OCAP);
     if (tid < CG_OUT + 1) sIp[tid] = p.in_ptr[min(max(ob + tid, 0), N)];
     if (tid >= 64 && tid < 64 + CG_MID + 1) sOp[tid - 64] = p.out_ptr[min(max(mb + tid - 64, 0), N)];
+    if (tid >= 128 && tid < 128 + CG_TR) sSpkOwn[tid - 128] = p.node_spk[min(r0 + tid - 128, N - 1)];
     {
         // K / V rows of the far range: 46 (+ 2 zero) rows x 50 float4
 #pragma unroll
@@ -823,6 +826,8 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
 #pragma unroll
     for (int u = 0; u < 7; ++u) fb3[u] = *reinterpret_cast<const bf16x8*>(brow3 + 512 * min(u, kh ? 5 : 6));
 
+    const unsigned short* const brow5 = p.Wb + ((int64_t)(min(ct, CG_NT - 1) * 30 + 15 * kh) * 64 + lane) * 8;
+    bf16x8 bx[15];
     {
         // (c) the dQKVS tile [26 mid rows][400] (bf16, the A operand of the dH1 product; own rows also to global memory):
         //     K padding / dead rows, the skip part (= dH2), then 42 units of 8 MFMAs: dq for outer row tiles 0, 1 (7 column
@@ -841,8 +846,14 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                 if (em >= CG_HL && em < CG_HL + CG_TR && node < N) *reinterpret_cast<float2*>(p.dQKVS + (int64_t)node * 400 + 3 * CG_F + 2 * cp) = gv;
             }
         }
-#pragma unroll 1
-        for (int u = w; u < 42; u += CG_NW) {
+        // (the B fragments of the dH0 product, K = 960: blocks [15 kh, 15 kh + 15), are requested five at a time between the
+        //  units: a burst of 15 loads in front of the transposed-means stage stalled it by ~3 us)
+#pragma unroll
+        for (int ui = 0; ui < 3; ++ui) {
+#pragma unroll
+            for (int t5 = 0; t5 < 5; ++t5) bx[5 * ui + t5] = *reinterpret_cast<const bf16x8*>(brow5 + 512 * (5 * ui + t5));
+            const int u = w + CG_NW * ui;
+            if (u >= 42) continue;      // wave-uniform
             // unit -> (kind: 0 dq | 1 dk | 2 dv, row tile, column tile)
             const int kind = u < 14 ? 0 : 1 + (u - 14) / 14, uu = u < 14 ? u : (u - 14) % 14;
             const int rt = uu / 7, cti = uu % 7;
@@ -920,12 +931,6 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     __syncthreads();
     CG_STAMP(4);
 
-    // B fragments of the dH0 product (K = 960: blocks [15 kh, 15 kh + 15)): requested now
-    const unsigned short* const brow5 = p.Wb + ((int64_t)(min(ct, CG_NT - 1) * 30 + 15 * kh) * 64 + lane) * 8;
-    bf16x8 bx[15];
-#pragma unroll
-    for (int u = 0; u < 15; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow5 + 512 * u);
-
     // ---- stage 4: dP = transposed relation means of dH1 for the 16 own rows (one per wavefront): block r of row j
     //      = sum over out-edges (j -> i, relation r) of dH1[i] / count_r(i); block 8 = dH1[j].  Scalar-branch
     //      accumulation and a rolled edge loop as in the forward aggregation.
@@ -945,6 +950,40 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
         float s0[CG_R], s1[CG_R];
 #pragma unroll
         for (int q = 0; q < CG_R; ++q) s0[q] = s1[q] = 0.f;
+        if (p.two_spk) {
+            // two speakers: an out-edge of a source with speaker b has relation 4 b + (2 spk(target) + dir), so only the
+            // four blocks 4 b .. 4 b + 3 of the row are non-empty: all 12 target rows are requested at once and a 4-way
+            // scalar branch picks the accumulator (the rolled two-edges-per-trip loop below pays an LDS round trip per trip)
+            const int b4 = 4 * __builtin_amdgcn_readfirstlane(min(max(sSpkOwn[li], 0), 1));
+            float2 v[CG_CH];
+            float wv[CG_CH];
+            int gid[CG_CH];
+#pragma unroll
+            for (int u = 0; u < CG_CH; ++u) {
+                const int uu = min(u, max(nwin - 1, 0));
+                const int f = __builtin_amdgcn_readlane(my_off, uu);
+                gid[u] = u < nwin ? __builtin_amdgcn_readlane(my_typ, uu) - b4 : -1;
+                wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), uu));
+                v[u] = *reinterpret_cast<const float2*>(sDH1 + f + c2);
+            }
+            float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < CG_CH; ++u) {
+                const float a0 = v[u].x * wv[u], a1 = v[u].y * wv[u];
+                switch (gid[u]) {
+                    case 0: t0[0] += a0, t1[0] += a1; break;
+                    case 1: t0[1] += a0, t1[1] += a1; break;
+                    case 2: t0[2] += a0, t1[2] += a1; break;
+                    case 3: t0[3] += a0, t1[3] += a1; break;
+                    default: break;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CG_R; ++q) {
+                const bool mine = (q & 4) == b4;
+                s0[q] = mine ? t0[q & 3] : 0.f, s1[q] = mine ? t1[q & 3] : 0.f;
+            }
+        } else {
 #pragma unroll 1
         for (int u = 0; u < nwin; u += 2) {
             const int u1 = min(u + 1, nwin - 1);
@@ -958,6 +997,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
             const float a0 = v0.x * w0, b0 = v0.y * w0, a1 = v1.x * w1, b1 = v1.y * w1;
             CG_ACC8(ty0, s0, s1, a0, b0);
             CG_ACC8(ty1, s0, s1, a1, b1);
+        }
         }
         float2 self = *reinterpret_cast<const float2*>(sDH1 + em * CG_F + c2);
         if (!valid) self = make_float2(0.f, 0.f);
@@ -1061,9 +1101,10 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
                                    const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
                                    const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                    const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
-                                   const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0, void* stream) {
+                                   const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0,
+                                   const int32_t* node_spk, int n_speakers, void* stream) {
     ERC_REQUIRE(dY && H2 && gamma && saved && bn_bwd && QKVS && alpha && in_ptr && in_src && out_ptr && out_dst && out_typ &&
-                    out_eid && inv_cnt && WqT && Wb && dQKVS && dH1 && dH0, "cogmen_bwd_tile: null pointer");
+                    out_eid && inv_cnt && WqT && Wb && dQKVS && dH1 && dH0 && node_spk, "cogmen_bwd_tile: null pointer");
     ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_bwd_tile: window (%d, %d) exceeds the halo %d",
                 wp, wf, CG_HL);
     ERC_REQUIRE(ldh2 >= CG_F && ldh2 % 4 == 0 && lddh0 >= CG_F &&
@@ -1075,6 +1116,7 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
     p.in_ptr = in_ptr; p.in_src = in_src; p.out_ptr = out_ptr; p.out_dst = out_dst; p.out_typ = out_typ; p.out_eid = out_eid;
     p.inv_cnt = inv_cnt; p.WqT = (const unsigned short*)WqT; p.Wb = (const unsigned short*)Wb;
     p.dQKVS = dQKVS; p.dH1 = dH1; p.dH0 = dH0; p.scale = scale; p.N = n_nodes; p.ldh2 = ldh2; p.lddh0 = lddh0;
+    p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0;
     p.stamps = g_cg_stamps; p.stamp_block = erc_cdiv(n_nodes, CG_TR) / 2;
     hipLaunchKernelGGL(cogmen_bwd_tile_kernel, dim3(erc_cdiv(n_nodes, CG_TR)), dim3(CG_NTH), BW_LDS, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("cogmen_bwd_tile");

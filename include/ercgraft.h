@@ -406,7 +406,8 @@ int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes,
                         const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                         const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
-                        const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0, void* stream);
+                        const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0,
+                        const int32_t* node_spk, int n_speakers, void* stream);
 
 /* diagnostic: phase stamps (10 ns ticks) of the middle workgroup of the following erc_cogmen_{fwd,bwd}_tile launches,
  * 8 x uint64 device memory; NULL switches them off (tools/cogmen_stamps.py) */

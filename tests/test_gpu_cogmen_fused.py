@@ -96,7 +96,7 @@ def test_fused_kernels_stagewise(case, n_spk):
     gamma = fp.w("gcn.bn.weight")
     capi.poison_lds()
     capi.cogmen_bwd_tile(dY, ws["H2"], F, N, WP, WF, gamma, ws["bn_saved"], bn_bwd, ws["QKVS"], ws["alpha"], g, ws["inv_cnt"],
-                         m._sh["qT"], m._sh["wb"], scale, ws["dQKVS"], ws["dH1"], ws["dH0"], F)
+                         m._sh["qT"], m._sh["wb"], scale, ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=n_spk)
     dH2_ref, dQ_ref, dsc = f32(N, F), f32(N, 4 * F), f32(ws["E"])
     capi.tconv_attn_bwd(ws["QKVS"], 4 * F, F, N, scale, g, ws["alpha"], dY, F, dQ_ref, dsc,
                         bn=(ws["H2"], F, gamma, ws["bn_saved"], bn_bwd, dH2_ref))
