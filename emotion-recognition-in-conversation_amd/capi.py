@@ -74,6 +74,7 @@ _SIGS = {
     "erc_shadow_refresh": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "erc_cogmen_fwd_tile_ws_doubles": (C.c_int64, [_i]),
     "erc_cogmen_set_stamps": (C.c_int, [_vp]),
+    "erc_head_set_stamps": (C.c_int, [_vp]),
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
                                       _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp]),
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -389,6 +390,10 @@ def shadow_refresh(p, n, table):
 
 def cogmen_set_stamps(t):
     _check(lib().erc_cogmen_set_stamps(ptr(t)), "erc_cogmen_set_stamps")
+
+
+def head_set_stamps(t):
+    _check(lib().erc_head_set_stamps(ptr(t)), "erc_head_set_stamps")
 
 
 def cogmen_fwd_tile_ws_doubles(n):

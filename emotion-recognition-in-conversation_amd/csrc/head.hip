@@ -144,7 +144,13 @@ struct HeadP {
     float* running_var;
     float momentum, eps;
     int bn_tiles;
+    uint64_t* stamps;        // diagnostic phase stamps of the middle workgroup (tools/cogmen_stamps.py) or null
 };
+
+#define HF_STAMP(slot)                                                                                              \
+    do {                                                                                                            \
+        if (p.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 // DPP lane exchanges inside a row of 16 lanes (VALU, no LDS traffic)
 template <int CTRL>
@@ -184,6 +190,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     const int r = lane & 15, g = lane >> 4;
     const int F = p.F, C = p.C, N = p.N;
     float* const sLg = &sT[0][0];  // [rt][cq][16 rows][8 classes] partial logits, dead before sT is written
+    HF_STAMP(0);
     __shared__ __attribute__((aligned(16))) float sSaved[2 * HF_MAXF];
 
     // ---- stage W0 (F x F) into LDS: F*F/4 <= 2500 float4 over 512 threads, all loads in flight
@@ -313,6 +320,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     const int cr = r & 7;
     const float b3c = p.b3[min(cr, C - 1)];
     __syncthreads();  // sW, sRed complete
+    HF_STAMP(1);
     double wsum = (double)N;
     if (p.weight) {
         wsum = 0.0;
@@ -366,6 +374,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         if (r < 8) sLg[((rt * 4 + cq) * 16 + 4 * g + q) * 8 + cr] = mine;
     }
     __syncthreads();
+    HF_STAMP(2);
     // ---- P3b: cross entropy with one class per lane (lanes r and r + 8 duplicate); rows 4g + q
     float lsum = 0.f, hsum = 0.f;
     const bool cv = cr < C;
@@ -398,6 +407,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         if (lane == 0) sLoss[rt][0] = lsum, sLoss[rt][1] = hsum;
     }
     __syncthreads();
+    HF_STAMP(3);
 
     // ---- P4: dZ = (dlogits W3) * relu/dropout mask for this wavefront's columns; into the row tile in LDS
     float* const tile = sT[rt];
@@ -422,6 +432,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         }
     }
     __syncthreads();
+    HF_STAMP(4);
 
     // ---- P5: dH3 = dZ W0 : A fragments from the transposed tile, B[k = j][n = i] = W0[j][i] read column-wise from LDS
     float a2[HF_NT][4];
@@ -461,6 +472,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         }
     }
     __syncthreads();
+    HF_STAMP(5);
     float* const rec = p.part + (int64_t)blockIdx.x * HF_PART;
     if (tid < 112) {
         st_sc1(rec + tid, sCol[0][0][tid] + sCol[1][0][tid]);
@@ -470,6 +482,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    HF_STAMP(6);
     if (tid == 0) {
         const int prev = __hip_atomic_fetch_add(p.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev == (int)gridDim.x - 1;
@@ -510,6 +523,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     } else if (tid == F + 1) {
         p.stats[1] = (float)s1;
     }
+    if (p.stamps && tid == 0) p.stamps[7] = __builtin_amdgcn_s_memrealtime();   // the last arriver, whichever workgroup it is
 }
 
 // dx = gamma * rstd * (dY - mean(dY) - xhat * mean(dY * xhat)): the elementwise part of BatchNorm's backward
@@ -557,6 +571,13 @@ extern "C" int erc_bn_batch_stats(const float* x, int ldx, int N, int F, float* 
 
 extern "C" int64_t erc_head_fused_ws_floats(int n_rows) { return (int64_t)erc_cdiv(n_rows, 32) * HF_PART + 16; }
 
+static uint64_t* g_head_stamps = nullptr;
+// diagnostic: 8 x uint64 phase stamps (10 ns ticks) of the following erc_head_fused launches; NULL switches them off
+extern "C" int erc_head_set_stamps(uint64_t* stamps) {
+    g_head_stamps = stamps;
+    return ERC_OK;
+}
+
 static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
                              const float* saved, float slope, const float* W0, const float* b0, const float* W3,
                              const float* b3, const int64_t* labels, const float* weight, float drop_p,
@@ -580,6 +601,7 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     p.slope = slope, p.drop_p = drop_p, p.ldh = ldh, p.N = n_rows, p.F = F, p.C = C;
     p.bn_part = bn_part, p.bn_tiles = bn_tiles, p.saved_out = saved_out, p.running_mean = running_mean, p.running_var = running_var;
     p.momentum = momentum, p.eps = eps;
+    p.stamps = g_head_stamps;
     const int grid = erc_cdiv(n_rows, 32);
     p.part = ws;
     p.counter = reinterpret_cast<int*>(ws + (int64_t)grid * HF_PART);

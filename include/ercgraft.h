@@ -340,6 +340,10 @@ int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const 
                       const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
                       float eps, void* stream);
 
+/* diagnostic: 8 x uint64 phase stamps (10 ns ticks) of the middle workgroup of the following erc_head_fused[_bn] launches;
+ * NULL switches them off (tools/cogmen_stamps.py) */
+int erc_head_set_stamps(uint64_t* stamps);
+
 /* Elementwise part of BatchNorm1d's backward: dx = gamma * rstd * (dY - bn_bwd[c] - xhat * bn_bwd[F + c]). */
 int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,
                      const float* bn_bwd, const float* dY, int lddy, float* dx, int lddx, void* stream);

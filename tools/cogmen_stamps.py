@@ -31,11 +31,13 @@ def main():
     torch.cuda.synchronize()
     names = {"erc_cogmen_fwd_tile": ["H0 rows -> LDS", "relation means", "H1 product", "QKVS product", "QKVS store + attention",
                                      "BatchNorm partials", "(arrival ..) last arriver done"],
+             "erc_head_fused_bn": ["BatchNorm sums + W0 -> LDS + A fragments", "product 1 (Z), partial logits", "cross entropy", "dZ -> LDS",
+                                   "product 2 (dH3), dY, column partials", "partial record + drain", "(arrival ..) last arriver done"],
              "erc_cogmen_bwd_tile": ["slices + tiles -> LDS", "band dA + d(score)", "dq / dk / dv band products", "dH1 product", "dP", "dH0 product"]}
     for entry, labels in names.items():
         call = [e for e in rec if e[0] == entry][0]
         st = torch.zeros(16, dtype=torch.int64, device="cuda:0")
-        capi.cogmen_set_stamps(st)
+        (capi.head_set_stamps if "head" in entry else capi.cogmen_set_stamps)(st)
         acc = torch.zeros(16, dtype=torch.float64)
         reps = 20
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,7 +49,7 @@ def main():
             acc += s - s[0]
         ev1.record()
         torch.cuda.synchronize()
-        capi.cogmen_set_stamps(None)
+        (capi.head_set_stamps if "head" in entry else capi.cogmen_set_stamps)(None)
         acc /= reps
         print("== %s (middle workgroup, 10 ns ticks)" % entry)
         prev = 0.0
