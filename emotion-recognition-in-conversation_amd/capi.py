@@ -49,7 +49,7 @@ _SIGS = {
     "erc_head_fused": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "erc_head_fused_bn": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
-                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _i, _vp]),
     "erc_bn_bwd_apply": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_wgrad_max_k_per_split": (C.c_int, []),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
@@ -78,7 +78,8 @@ _SIGS = {
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
                                       _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp]),
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "erc_head_fused_part_floats": (C.c_int, []),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
     "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
@@ -412,12 +413,13 @@ def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, 
 
 
 def cogmen_bwd_tile(dY, H2, ldh2, N, wp, wf, gamma, saved, bn_bwd, QKVS, alpha, g, inv_cnt, WqT, Wb, scale, dQKVS, dH1,
-                    dH0, lddh0, n_speakers=2):
+                    dH0, lddh0, n_speakers=2, head_part=None, head_parts=0, dgamma=None, dbeta=None, stats=None):
     _check(lib().erc_cogmen_bwd_tile(ptr(dY), ptr(H2), ldh2, N, wp, wf, ptr(gamma), ptr(saved), ptr(bn_bwd), ptr(QKVS),
                                      ptr(alpha), ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["out_ptr"]), ptr(g["out_dst"]),
                                      ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(inv_cnt), ptr(WqT), ptr(Wb), scale,
-                                     ptr(dQKVS), ptr(dH1), ptr(dH0), lddh0, ptr(g["node_spk"]), n_speakers, stream()),
-           "erc_cogmen_bwd_tile")
+                                     ptr(dQKVS), ptr(dH1), ptr(dH0), lddh0, ptr(g["node_spk"]), n_speakers, ptr(head_part),
+                                     head_parts, head_fused_part_floats() if head_part is not None else 0, ptr(dgamma),
+                                     ptr(dbeta), ptr(stats), stream()), "erc_cogmen_bwd_tile")
 
 
 def grad_norm(g, n, grad_scale, gnorm, ws):
@@ -680,10 +682,14 @@ def head_fused(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3,
 
 def head_fused_bn(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                   H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, running_mean,
-                  running_var, momentum, eps):
+                  running_var, momentum, eps, defer_reduce=False):
     _call("erc_head_fused_bn", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
           float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles,
-          running_mean, running_var, float(momentum), float(eps))
+          running_mean, running_var, float(momentum), float(eps), int(defer_reduce))
+
+
+def head_fused_part_floats():
+    return int(lib().erc_head_fused_part_floats())
 
 
 def bn_bwd_apply(x, ldx, N, F, gamma, saved, bn_bwd, dY, lddy, dx, lddx):

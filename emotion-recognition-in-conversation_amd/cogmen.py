@@ -331,12 +331,15 @@ class COGMENModule(nn.Module):
                          ws["stats"], ws["head_ws"])
             if fused and ws["bn_in_tile"]:
                 # BatchNorm's batch statistics: per-tile sums from the forward tile kernel, added up by every head workgroup
+                # ... and the head's own cross-workgroup sums (BatchNorm backward means, loss) are left to the backward tile kernel
                 capi.head_fused_bn(*head_args, ws["bn_tile_ws"][2:].view(torch.float32), -(-N // 16), bn.running_mean,
-                                   bn.running_var, bn.momentum, bn.eps)
+                                   bn.running_var, bn.momentum, bn.eps, defer_reduce=True)
+                ws["head_deferred"] = True
             else:
                 capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
                                     ws["bn_stats_ws"])
                 capi.head_fused(*head_args)
+                ws["head_deferred"] = False
         else:
             capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
             capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
@@ -396,7 +399,9 @@ class COGMENModule(nn.Module):
         F, D = F_HID, self.input_size
         capi.cogmen_bwd_tile(ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"],
                              ws["QKVS"], ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F),
-                             ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers)
+                             ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers,
+                             **(dict(head_part=ws["head_ws"], head_parts=-(-N // 32), dgamma=fp.g("gcn.bn.weight"),
+                                     dbeta=fp.g("gcn.bn.bias"), stats=ws["stats"]) if ws.get("head_deferred") else {}))
         pl.mma_bf16 = self.wgrad_bf16     # these three products on bf16 matrix cores (the head's stay fp32)
         linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1b"], 104, None, 4 * F, F, N,
                      fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"], defer=True)

@@ -643,6 +643,14 @@ struct CgBwdP {
     const int32_t* out_eid;
     const float* inv_cnt;          // [N, 8]
     const int32_t* node_spk;       // speakers; two_spk: all in {0, 1}
+    // head_part != null: the head kernel left its workgroup records un-reduced (erc_head_fused_bn, defer_reduce): every
+    // workgroup here adds them up (same order everywhere) instead of reading bn_bwd; workgroup 0 publishes the results
+    const float* head_part;        // [head_parts][hp_floats]: column sums of dY | of dY * xhat | loss, hits, weight sum
+    float* bn_bwd_out;             // [2F]
+    float* dgamma;
+    float* dbeta;
+    float* stats;
+    int head_parts, hp_floats;
     const unsigned short* WqT;     // bf16, fragment order (7 x 13 x 512)
     const unsigned short* Wb;      // bf16, fragment order (7 x 30 x 512)
     float* dQKVS;                  // out [N, 400]
@@ -692,6 +700,24 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     if (tid < CG_OUT + 1) sIp[tid] = p.in_ptr[min(max(ob + tid, 0), N)];
     if (tid >= 64 && tid < 64 + CG_MID + 1) sOp[tid - 64] = p.out_ptr[min(max(mb + tid - 64, 0), N)];
     if (tid >= 128 && tid < 128 + CG_TR) sSpkOwn[tid - 128] = p.node_spk[min(r0 + tid - 128, N - 1)];
+    double* const sHp = reinterpret_cast<double*>(lds + BW_SDQ_OFF);                  // [4][256] partial sums of the head records
+    float* const sBnB = reinterpret_cast<float*>(lds + BW_SDQ_OFF + 4 * 256 * 8);     // [224] mean dY | mean dY * xhat
+    if (p.head_part) {   // (uniform) the head's workgroup records: slot = tid % 256, a quarter of the record list each
+        const int slot = tid & 255, part = tid >> 8;
+        const int G = p.head_parts, Gq = (G + 3) >> 2;
+        const int g_begin = min(part * Gq, G), g_end = min(G, g_begin + Gq);
+        double acc = 0.0;
+        if (slot < p.hp_floats) {
+            for (int g0 = g_begin; g0 < g_end; g0 += 16) {
+                float t[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t[j] = p.head_part[(int64_t)min(g0 + j, G - 1) * p.hp_floats + slot];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc += (double)t[j] * (g0 + j < g_end ? 1.0 : 0.0);
+            }
+        }
+        sHp[part * 256 + slot] = acc;
+    }
     {
         // K / V rows of the far range: 46 (+ 2 zero) rows x 50 float4
 #pragma unroll
@@ -704,32 +730,6 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
             const float m = ok ? 1.f : 0.f;
             float* dst = (q < 25 ? sK + f * CG_F + 4 * q : sV + f * CG_F + 4 * (q - 25));
             if (i < BW_ROWS * 50) *reinterpret_cast<f32x4*>(dst) = (f32x4){v.x * m, v.y * m, v.z * m, v.w * m};
-        }
-        // Q rows and dH2 = BatchNorm backward of the outer range: 36 (+ 12 zero) rows x 25 float4
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i = tid + CG_NTH * j;
-            const int e = min(i / 25, BW_ROWS - 1), q = i % 25;
-            const int node = ob + e;
-            const bool ok = e < CG_OUT && node >= 0 && node < N;
-            const int64_t nc = min(max(node, 0), N - 1);
-            const f32x4 qv = *reinterpret_cast<const f32x4*>(p.QKVS + nc * 400 + 4 * q);
-            const f32x4 dy = *reinterpret_cast<const f32x4*>(p.dY + nc * CG_F + 4 * q);
-            const f32x4 x = *reinterpret_cast<const f32x4*>(p.H2 + nc * p.ldh2 + 4 * q);
-            const f32x4 mu = *reinterpret_cast<const f32x4*>(p.saved + 4 * q), rs = *reinterpret_cast<const f32x4*>(p.saved + CG_F + 4 * q);
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + 4 * q);
-            const f32x4 ma = *reinterpret_cast<const f32x4*>(p.bn_bwd + 4 * q), mbv = *reinterpret_cast<const f32x4*>(p.bn_bwd + CG_F + 4 * q);
-            const float m = ok ? 1.f : 0.f;
-            f32x4 gq, qq;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                gq[t] = ga[t] * rs[t] * (dy[t] - ma[t] - (x[t] - mu[t]) * rs[t] * mbv[t]) * m;
-                qq[t] = qv[t] * m;
-            }
-            if (i < BW_ROWS * 25) {
-                *reinterpret_cast<f32x4*>(sG + e * CG_F + 4 * q) = gq;
-                *reinterpret_cast<f32x4*>(sQq + e * CG_F + 4 * q) = qq;
-            }
         }
         // edge slices
         if (tid < BW_ECAP) {
@@ -749,6 +749,57 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
             sOd[i] = ok ? dst : 0;
             sOt[i] = ok ? typ : CG_R;
             sOw[i] = (ok && typ < CG_R) ? wgt : 0.f;
+        }
+    }
+    // Q rows and the operands of dH2 (BatchNorm backward) for the outer range: 36 (+ 12 zero) rows x 25 float4, requested
+    // BEFORE the wait for the head records below
+    f32x4 r_q[2], r_dy[2], r_x[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + CG_NTH * j;
+        const int e = min(i / 25, BW_ROWS - 1), q = i % 25;
+        const int64_t nc = min(max(ob + e, 0), N - 1);
+        r_q[j] = *reinterpret_cast<const f32x4*>(p.QKVS + nc * 400 + 4 * q);
+        r_dy[j] = *reinterpret_cast<const f32x4*>(p.dY + nc * CG_F + 4 * q);
+        r_x[j] = *reinterpret_cast<const f32x4*>(p.H2 + nc * p.ldh2 + 4 * q);
+    }
+    if (p.head_part) {
+        __syncthreads();
+        if (tid < 228) {
+            const double sv = ((sHp[tid] + sHp[256 + tid]) + sHp[512 + tid]) + sHp[768 + tid];
+            if (tid < 224) sBnB[tid] = (float)(sv / (double)N);
+            if (blockIdx.x == 0) {   // dbeta = sum dY, dgamma = sum dY * xhat (BatchNorm1d backward), loss / accuracy statistics
+                const int c = tid < 112 ? tid : tid - 112;
+                if (tid < 112 && c < CG_F) p.dbeta[c] = (float)sv, p.bn_bwd_out[c] = (float)(sv / (double)N);
+                if (tid >= 112 && tid < 224 && c < CG_F) p.dgamma[c] = (float)sv, p.bn_bwd_out[CG_F + c] = (float)(sv / (double)N);
+                const double wsum = ((sHp[226] + sHp[256 + 226]) + sHp[512 + 226]) + sHp[768 + 226];
+                const double wmean = wsum / (double)p.head_parts;      // every record carries the same weight sum
+                if (tid == 224) p.stats[0] = (float)(sv / wmean), p.stats[2] = (float)wmean;
+                if (tid == 225) p.stats[1] = (float)sv;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = tid + CG_NTH * j;
+        const int e = min(i / 25, BW_ROWS - 1), q = i % 25;
+        const int node = ob + e;
+        const bool ok = e < CG_OUT && node >= 0 && node < N;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.saved + 4 * q), rs = *reinterpret_cast<const f32x4*>(p.saved + CG_F + 4 * q);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + 4 * q);
+        const f32x4 ma = p.head_part ? *reinterpret_cast<const f32x4*>(sBnB + 4 * q) : *reinterpret_cast<const f32x4*>(p.bn_bwd + 4 * q);
+        const f32x4 mbv = p.head_part ? *reinterpret_cast<const f32x4*>(sBnB + 112 + 4 * q) : *reinterpret_cast<const f32x4*>(p.bn_bwd + CG_F + 4 * q);
+        const float m = ok ? 1.f : 0.f;
+        f32x4 gq, qq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            gq[t] = ga[t] * rs[t] * (r_dy[j][t] - ma[t] - (r_x[j][t] - mu[t]) * rs[t] * mbv[t]) * m;
+            qq[t] = r_q[j][t] * m;
+        }
+        if (i < BW_ROWS * 25) {
+            *reinterpret_cast<f32x4*>(sG + e * CG_F + 4 * q) = gq;
+            *reinterpret_cast<f32x4*>(sQq + e * CG_F + 4 * q) = qq;
         }
     }
     __syncthreads();
@@ -1102,7 +1153,10 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
                                    const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                    const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
                                    const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0,
-                                   const int32_t* node_spk, int n_speakers, void* stream) {
+                                   const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
+                                   int head_part_floats, float* dgamma, float* dbeta, float* stats, void* stream) {
+    ERC_REQUIRE(!head_part || (head_parts > 0 && head_part_floats >= 227 && head_part_floats <= 256 && dgamma && dbeta && stats),
+                "cogmen_bwd_tile: head record operands");
     ERC_REQUIRE(dY && H2 && gamma && saved && bn_bwd && QKVS && alpha && in_ptr && in_src && out_ptr && out_dst && out_typ &&
                     out_eid && inv_cnt && WqT && Wb && dQKVS && dH1 && dH0 && node_spk, "cogmen_bwd_tile: null pointer");
     ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_bwd_tile: window (%d, %d) exceeds the halo %d",
@@ -1117,6 +1171,8 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
     p.inv_cnt = inv_cnt; p.WqT = (const unsigned short*)WqT; p.Wb = (const unsigned short*)Wb;
     p.dQKVS = dQKVS; p.dH1 = dH1; p.dH0 = dH0; p.scale = scale; p.N = n_nodes; p.ldh2 = ldh2; p.lddh0 = lddh0;
     p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0;
+    p.head_part = head_part; p.head_parts = head_parts; p.hp_floats = head_part_floats; p.bn_bwd_out = const_cast<float*>(bn_bwd);
+    p.dgamma = dgamma; p.dbeta = dbeta; p.stats = stats;
     p.stamps = g_cg_stamps; p.stamp_block = erc_cdiv(n_nodes, CG_TR) / 2;
     hipLaunchKernelGGL(cogmen_bwd_tile_kernel, dim3(erc_cdiv(n_nodes, CG_TR)), dim3(CG_NTH), BW_LDS, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("cogmen_bwd_tile");

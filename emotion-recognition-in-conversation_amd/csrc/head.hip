@@ -27,7 +27,7 @@ constexpr int HF_ST = 116;     // pitch of the dZ row tiles: >= 112 (7 full colu
 constexpr int HF_NT = 7;       // column tiles of 16 (F <= 100 -> 7 tiles, the last one partial)
 constexpr int HF_MAXF = 100;
 constexpr int HF_MAXC = 8;
-constexpr int HF_PART = 2 * 112 + 2;  // floats per workgroup partial record
+constexpr int HF_PART = 2 * 112 + 4;  // floats per workgroup partial record: column sums of dY | of dY * xhat | loss part, hits, weight sum, pad
 constexpr int BS_G = 64;       // workgroups of the statistics pass
 
 __device__ __forceinline__ float ld_sc1(const float* p) {
@@ -144,6 +144,7 @@ struct HeadP {
     float* running_var;
     float momentum, eps;
     int bn_tiles;
+    int defer;               // 1: leave the workgroup records for the consumer to add up (erc_cogmen_bwd_tile), no last arriver
     uint64_t* stamps;        // diagnostic phase stamps of the middle workgroup (tools/cogmen_stamps.py) or null
 };
 
@@ -479,7 +480,10 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         st_sc1(rec + 112 + tid, sCol[0][1][tid] + sCol[1][1][tid]);
     } else if (tid < 114) {
         st_sc1(rec + 224 + (tid - 112), sLoss[0][tid - 112] + sLoss[1][tid - 112]);
+    } else if (tid == 114) {
+        st_sc1(rec + 226, (float)wsum);
     }
+    if (p.defer) return;     // (uniform) the records become visible with the end of the kernel; the next kernel adds them up
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     HF_STAMP(6);
@@ -584,7 +588,7 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
                              const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                              const float* bn_part, int bn_tiles, float* saved_out, float* running_mean, float* running_var,
-                             float momentum, float eps, void* stream) {
+                             float momentum, float eps, int defer, void* stream) {
     ERC_REQUIRE(H2 && gamma && beta && (saved || bn_part) && W0 && b0 && W3 && b3 && labels && H3 && Z && logits && dlogits && dZ && dY &&
                     bn_bwd && dgamma && dbeta && stats && ws,
                 "head_fused: null pointer");
@@ -601,6 +605,7 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     p.slope = slope, p.drop_p = drop_p, p.ldh = ldh, p.N = n_rows, p.F = F, p.C = C;
     p.bn_part = bn_part, p.bn_tiles = bn_tiles, p.saved_out = saved_out, p.running_mean = running_mean, p.running_var = running_var;
     p.momentum = momentum, p.eps = eps;
+    p.defer = defer ? 1 : 0;
     p.stamps = g_head_stamps;
     const int grid = erc_cdiv(n_rows, 32);
     p.part = ws;
@@ -619,8 +624,10 @@ extern "C" int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C
     ERC_REQUIRE(saved, "head_fused: null pointer");
     return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                              H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, nullptr, 0, nullptr, nullptr,
-                             nullptr, 0.f, 0.f, stream);
+                             nullptr, 0.f, 0.f, 0, stream);
 }
+
+extern "C" int erc_head_fused_part_floats(void) { return HF_PART; }
 
 // erc_head_fused with BatchNorm's batch statistics finalised inside: bn_part [bn_tiles][2F] = the per-tile column sums
 // (sum x | sum x^2) erc_cogmen_fwd_tile leaves in bn mode 2; saved [2F] (mean | rstd) becomes an OUTPUT, the running
@@ -631,11 +638,11 @@ extern "C" int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, in
                                  const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                                  float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                                  const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
-                                 float eps, void* stream) {
+                                 float eps, int defer_reduce, void* stream) {
     ERC_REQUIRE(bn_part && saved, "head_fused_bn: null pointer");
     return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, nullptr, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                              H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, saved,
-                             running_mean, running_var, momentum, eps, stream);
+                             running_mean, running_var, momentum, eps, defer_reduce, stream);
 }
 
 extern "C" int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,

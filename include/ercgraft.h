@@ -331,14 +331,18 @@ int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const flo
 /* erc_head_fused with BatchNorm's batch statistics finalised inside (training mode of nn.BatchNorm1d, cogmen.py:67):
  * bn_part [bn_tiles][2F] floats = per-tile column sums (sum x | sum x^2) from erc_cogmen_fwd_tile (bn_fused = 2);
  * every workgroup adds the tiles in order, workgroup 0 writes saved [2F] = mean | rstd (an OUTPUT here) and updates
- * running_mean / running_var (momentum, unbiased variance). */
+ * running_mean / running_var (momentum, unbiased variance).  defer_reduce != 0: no last arriver -- bn_bwd, dgamma, dbeta and
+ * stats are NOT written here; the consumer adds the workgroup records of ws itself (erc_cogmen_bwd_tile, head_part). */
 int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const float* gamma, const float* beta,
                       float* saved, float slope, const float* W0, const float* b0, const float* W3,
                       const float* b3, const int64_t* labels, const float* weight, float drop_p,
                       const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                       float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                       const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
-                      float eps, void* stream);
+                      float eps, int defer_reduce, void* stream);
+/* floats per workgroup record of erc_head_fused's workspace: [0,112) column sums of dY, [112,224) of dY * xhat, [224] loss
+ * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / 32) records */
+int erc_head_fused_part_floats(void);
 
 /* diagnostic: 8 x uint64 phase stamps (10 ns ticks) of the middle workgroup of the following erc_head_fused[_bn] launches;
  * NULL switches them off (tools/cogmen_stamps.py) */
@@ -405,13 +409,17 @@ int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int wp, int wf, 
 /* Backward of the same: dY [N,100] = dL/d(BatchNorm output) (erc_head_fused), BatchNorm's elementwise backward
  * (gamma, saved, bn_bwd as erc_bn_bwd_apply), TransformerConv backward (target and source side), dH1 = dQKVS Wq,
  * the transposed relation means and dH0 = dP [W_r^T].  Outputs fp32: dQKVS [N,400], dH1 [N,100], dH0 [N, lddh0] --
- * the operands of the weight gradients (cogmen.py:187-188). */
+ * the operands of the weight gradients (cogmen.py:187-188).
+ * head_part != NULL (with erc_head_fused_bn's defer_reduce): bn_bwd is an OUTPUT -- every workgroup adds the head
+ * kernel's head_parts workgroup records (head_part_floats = erc_head_fused_part_floats() each) itself, in the same order,
+ * and workgroup 0 writes bn_bwd, dgamma (= sum dY * xhat), dbeta (= sum dY) and stats {mean loss, #correct, weight sum}. */
 int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes, int wp, int wf, const float* gamma,
                         const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                         const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
                         const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0,
-                        const int32_t* node_spk, int n_speakers, void* stream);
+                        const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
+                        int head_part_floats, float* dgamma, float* dbeta, float* stats, void* stream);
 
 /* diagnostic: phase stamps (10 ns ticks) of the middle workgroup of the following erc_cogmen_{fwd,bwd}_tile launches,
  * 8 x uint64 device memory; NULL switches them off (tools/cogmen_stamps.py) */
