@@ -94,6 +94,13 @@ _SIGS = {
     "erc_brgcn_bwd_edges": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_brgcn_bwd_source": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_transpose_batched": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
+    "erc_lstm_set_stamps": (C.c_int, [_vp]),
+    "erc_rrgcn_max_relations": (C.c_int, []),
+    "erc_basis_compose": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_basis_decompose": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_rrgcn_agg_fwd": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "erc_rrgcn_bwd_edges": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "erc_rrgcn_bwd_source": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "erc_csr_sum": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "erc_gemm_f32_grouped": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _f,
                                        _vp, _i, _i64, _i64, _i, _i64, _vp]),
@@ -393,6 +400,10 @@ def cogmen_set_stamps(t):
     _check(lib().erc_cogmen_set_stamps(ptr(t)), "erc_cogmen_set_stamps")
 
 
+def lstm_set_stamps(t):
+    _check(lib().erc_lstm_set_stamps(ptr(t)), "erc_lstm_set_stamps")
+
+
 def head_set_stamps(t):
     _check(lib().erc_head_set_stamps(ptr(t)), "erc_head_set_stamps")
 
@@ -548,6 +559,34 @@ def brgcn_bwd_source(dH, lddh, O, N, g, norm, att, nb, U):
     _check(lib().erc_brgcn_bwd_source(ptr(dH), lddh, O, N, ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]),
                                       ptr(g["out_eid"]), ptr(norm), ptr(att), nb, ptr(U), stream()),
            "erc_brgcn_bwd_source")
+
+
+def rrgcn_max_relations():
+    return int(lib().erc_rrgcn_max_relations())
+
+
+def basis_compose(comp, basis, R, nb, F, O, Wr, WrT):
+    _check(lib().erc_basis_compose(ptr(comp), ptr(basis), R, nb, F, O, ptr(Wr), ptr(WrT), stream()), "erc_basis_compose")
+
+
+def basis_decompose(comp, basis, dWr, R, nb, FO, dbasis, dcomp):
+    _check(lib().erc_basis_decompose(ptr(comp), ptr(basis), ptr(dWr), R, nb, FO, ptr(dbasis), ptr(dcomp), stream()),
+           "erc_basis_decompose")
+
+
+def rrgcn_agg_fwd(x, ldx, F, N, R, g, norm, Z):
+    _check(lib().erc_rrgcn_agg_fwd(ptr(x), ldx, F, N, R, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]), ptr(norm),
+                                   ptr(Z), stream()), "erc_rrgcn_agg_fwd")
+
+
+def rrgcn_bwd_edges(x, ldx, F, N, R, g, dZ, dnorm):
+    _check(lib().erc_rrgcn_bwd_edges(ptr(x), ldx, F, N, R, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]), ptr(dZ),
+                                     ptr(dnorm), stream()), "erc_rrgcn_bwd_edges")
+
+
+def rrgcn_bwd_source(dH, lddh, O, N, R, g, norm, U):
+    _check(lib().erc_rrgcn_bwd_source(ptr(dH), lddh, O, N, R, ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]),
+                                      ptr(g["out_eid"]), ptr(norm), ptr(U), stream()), "erc_rrgcn_bwd_source")
 
 
 def transpose_batched(inp, nb, rows, cols, out):

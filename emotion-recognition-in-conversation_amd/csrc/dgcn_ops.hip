@@ -363,6 +363,204 @@ __global__ __launch_bounds__(256) void brgcn_bwd_source_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------ basis RGCN in RELATION space (R <= 8)
+// With few relations (two speakers: R = 2 S^2 = 8 < 30 bases) the layer is cheaper the way models/rgcn.py:300-304 writes
+// it: W_r = sum_b comp[r,b] basis[b] first, then
+//      out_i = sum_r ( sum_{e -> i, type r} norm_e x_src(e) ) W_r + x_i root + bias
+// -- Z is [N, R F] instead of [N, 30 F] (the two GEMMs, the weight gradient and the scatter shrink by 30/R) and the
+// per-edge work is one multiply-add row instead of 30.  comp / basis receive their gradients from dW_r afterwards.
+constexpr int RR = 8;
+
+// Wr[r][k] = sum_b comp[r,b] basis[b][k] (k < F*O, row-major [F,O]); WrT[r][c][f] = Wr[r][f][c]
+__global__ __launch_bounds__(256) void basis_compose_kernel(const float* __restrict__ comp, const float* __restrict__ basis,
+                                                            int R, int F, int O, float* __restrict__ Wr,
+                                                            float* __restrict__ WrT) {
+    __shared__ float s_comp[RR * NB];
+    for (int i = threadIdx.x; i < R * NB; i += 256) s_comp[i] = comp[i];
+    __syncthreads();
+    const int FO = F * O, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= FO) return;
+    float bv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bv[b] = basis[(int64_t)b * FO + k];
+    const int f = k / O, c = k - f * O;
+    for (int r = 0; r < R; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) a += s_comp[r * NB + b] * bv[b];
+        Wr[(int64_t)r * FO + k] = a;
+        WrT[(int64_t)r * FO + (int64_t)c * F + f] = a;
+    }
+}
+
+// blocks [0, nA): dbasis[b][k] = sum_r comp[r,b] dWr[r][k];  blocks nA + (r*NB + b): dcomp[r,b] = <dWr[r], basis[b]>
+__global__ __launch_bounds__(256) void basis_decompose_kernel(const float* __restrict__ comp, const float* __restrict__ basis,
+                                                              const float* __restrict__ dWr, int R, int FO, int nA,
+                                                              float* __restrict__ dbasis, float* __restrict__ dcomp) {
+    __shared__ float s_comp[RR * NB];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < nA) {
+        for (int i = tid; i < R * NB; i += 256) s_comp[i] = comp[i];
+        __syncthreads();
+        const int k = blockIdx.x * 256 + tid;
+        if (k >= FO) return;
+        float g[RR];
+#pragma unroll
+        for (int r = 0; r < RR; ++r) g[r] = r < R ? dWr[(int64_t)r * FO + k] : 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            float a = 0.f;
+#pragma unroll
+            for (int r = 0; r < RR; ++r) a += (r < R ? s_comp[r * NB + b] : 0.f) * g[r];
+            dbasis[(int64_t)b * FO + k] = a;
+        }
+        return;
+    }
+    const int rb = blockIdx.x - nA, r = rb / NB, b = rb - r * NB;
+    const float* gw = dWr + (int64_t)r * FO;
+    const float* bw = basis + (int64_t)b * FO;
+    float a = 0.f;
+    for (int k = tid; k < FO; k += 256) a += gw[k] * bw[k];
+    a = wave_sum(a);
+    if ((tid & 63) == 0) s_red[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) dcomp[rb] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// Z[i, r*F + c] = sum_{e into i, type_e == r} norm_e x[src_e, c]
+__global__ __launch_bounds__(256) void rrgcn_agg_fwd_kernel(const float* __restrict__ x, int ldx, int F, int N, int R,
+                                                            const int32_t* __restrict__ in_ptr,
+                                                            const int32_t* __restrict__ in_src,
+                                                            const int32_t* __restrict__ in_typ,
+                                                            const float* __restrict__ norm, float* __restrict__ Z) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N) return;
+    float acc[RR][4];
+#pragma unroll
+    for (int r = 0; r < RR; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[r][u] = 0.f;
+    const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
+    for (int w0 = e0; w0 < e1; w0 += 64) {      // lane-parallel edge metadata, then 8 source rows per batch
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_src = in_src[el], my_typ = in_typ[el];
+        const float my_n = lane < nwin ? norm[el] : 0.f;
+        for (int base = 0; base < nwin; base += EB) {
+            Lane4 xs[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) xs[u] = load4(x + (int64_t)__shfl(my_src, min(base + u, nwin - 1), 64) * ldx, F, lane);
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int t = __shfl(my_typ, min(base + u, 63), 64);
+                const float ne = __shfl(my_n, min(base + u, 63), 64);      // 0 past the window
+#pragma unroll
+                for (int r = 0; r < RR; ++r) {
+                    const float c = t == r ? ne : 0.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[r][q] += c * xs[u].v[q];
+                }
+            }
+        }
+    }
+    float* z = Z + (int64_t)i * R * F;
+#pragma unroll
+    for (int r = 0; r < RR; ++r)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (r < R && lane + 64 * u < F) z[r * F + lane + 64 * u] = acc[r][u];
+}
+
+// dnorm_e = x[src_e] . dZ[i, type_e, :]  for every edge e into i; 16 edges per butterfly
+__global__ __launch_bounds__(256) void rrgcn_bwd_target_kernel(const float* __restrict__ x, int ldx, int F, int N, int R,
+                                                               const int32_t* __restrict__ in_ptr,
+                                                               const int32_t* __restrict__ in_src,
+                                                               const int32_t* __restrict__ in_typ,
+                                                               const float* __restrict__ dZ, float* __restrict__ dnorm) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N) return;
+    Lane4 dz[RR];
+    const float* z = dZ + (int64_t)i * R * F;
+#pragma unroll
+    for (int r = 0; r < RR; ++r) dz[r] = load4(z + (int64_t)min(r, R - 1) * F, F, lane);
+    const int entry = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_src = in_src[el], my_typ = in_typ[el];
+        for (int base = 0; base < nwin; base += 16) {
+            float part[16];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Lane4 xs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    xs[u] = load4(x + (int64_t)__shfl(my_src, min(base + 8 * h + u, nwin - 1), 64) * ldx, F, lane);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = __shfl(my_typ, min(base + 8 * h + u, 63), 64);
+                    float d = 0.f;
+#pragma unroll
+                    for (int r = 0; r < RR; ++r) d = t == r ? dot4(xs[u], dz[r]) : d;
+                    part[8 * h + u] = d;
+                }
+            }
+            const float tot = butterfly16_sum(part, lane);      // edge base + entry
+            if ((lane & 3) == 0 && base + entry < nwin) dnorm[w0 + base + entry] = tot;
+        }
+    }
+}
+
+// U[j, r*O + c] = sum_{e out of j, type r} norm_e dH[dst_e, c]   (O <= 128)
+__global__ __launch_bounds__(256) void rrgcn_bwd_source_kernel(const float* __restrict__ dH, int lddh, int O, int N, int R,
+                                                               const int32_t* __restrict__ out_ptr,
+                                                               const int32_t* __restrict__ out_dst,
+                                                               const int32_t* __restrict__ out_typ,
+                                                               const int32_t* __restrict__ out_eid,
+                                                               const float* __restrict__ norm, float* __restrict__ U) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j >= N) return;
+    float acc[RR][2];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) acc[r][0] = acc[r][1] = 0.f;
+    const int c0 = min(lane, O - 1), c1 = min(lane + 64, O - 1);
+    const float m0 = lane < O ? 1.f : 0.f, m1 = lane + 64 < O ? 1.f : 0.f;
+    const int e0 = out_ptr[j], e1 = out_ptr[j + 1];
+    for (int w0 = e0; w0 < e1; w0 += 64) {
+        const int nwin = min(64, e1 - w0);
+        const int el = w0 + min(lane, nwin - 1);
+        const int my_dst = out_dst[el], my_typ = out_typ[el];
+        const float my_n = lane < nwin ? norm[out_eid[el]] : 0.f;
+        for (int base = 0; base < nwin; base += EB) {
+            float g0[EB], g1[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const float* g = dH + (int64_t)__shfl(my_dst, min(base + u, nwin - 1), 64) * lddh;
+                g0[u] = g[c0] * m0, g1[u] = g[c1] * m1;
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int t = __shfl(my_typ, min(base + u, 63), 64);
+                const float ne = __shfl(my_n, min(base + u, 63), 64);
+#pragma unroll
+                for (int r = 0; r < RR; ++r) {
+                    const float c = t == r ? ne : 0.f;
+                    acc[r][0] += c * g0[u];
+                    acc[r][1] += c * g1[u];
+                }
+            }
+        }
+    }
+    float* u = U + (int64_t)j * R * O;
+#pragma unroll
+    for (int r = 0; r < RR; ++r) {
+        if (r < R && lane < O) u[r * O + lane] = acc[r][0];
+        if (r < R && lane + 64 < O) u[r * O + lane + 64] = acc[r][1];
+    }
+}
+
 // out[n][c][r] = in[n][r][c]  (basis[b] [F,O] -> [O,F] so that dx = U [N,30*O] x basisT [30*O, F] is one GEMM)
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ in, int nb, int R, int Cc,
                                                                 float* __restrict__ out) {
@@ -474,6 +672,59 @@ extern "C" int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, con
     hipLaunchKernelGGL(brgcn_bwd_source_kernel, NODE_GRID(N), dH, lddh, O, N, out_ptr, out_dst, out_typ, out_eid, norm,
                        att, U);
     ERC_LAUNCH_CHECK("brgcn_bwd_source");
+    return ERC_OK;
+}
+
+extern "C" int erc_rrgcn_max_relations(void) { return RR; }
+
+extern "C" int erc_basis_compose(const float* comp, const float* basis, int R, int num_bases, int F, int O, float* Wr,
+                                 float* WrT, void* stream) {
+    ERC_REQUIRE(comp && basis && Wr && WrT, "basis_compose: null pointer");
+    ERC_REQUIRE(num_bases == NB && R > 0 && R <= RR && F > 0 && O > 0, "basis_compose: R=%d (<= %d) num_bases=%d (built for %d)",
+                R, RR, num_bases, NB);
+    hipLaunchKernelGGL(basis_compose_kernel, dim3(erc_cdiv(F * O, 256)), dim3(256), 0, (hipStream_t)stream, comp, basis, R, F,
+                       O, Wr, WrT);
+    ERC_LAUNCH_CHECK("basis_compose");
+    return ERC_OK;
+}
+
+extern "C" int erc_basis_decompose(const float* comp, const float* basis, const float* dWr, int R, int num_bases, int FO,
+                                   float* dbasis, float* dcomp, void* stream) {
+    ERC_REQUIRE(comp && basis && dWr && dbasis && dcomp, "basis_decompose: null pointer");
+    ERC_REQUIRE(num_bases == NB && R > 0 && R <= RR && FO > 0, "basis_decompose: bad sizes");
+    const int nA = erc_cdiv(FO, 256);
+    hipLaunchKernelGGL(basis_decompose_kernel, dim3(nA + R * NB), dim3(256), 0, (hipStream_t)stream, comp, basis, dWr, R, FO,
+                       nA, dbasis, dcomp);
+    ERC_LAUNCH_CHECK("basis_decompose");
+    return ERC_OK;
+}
+
+extern "C" int erc_rrgcn_agg_fwd(const float* x, int ldx, int F, int N, int R, const int32_t* in_ptr, const int32_t* in_src,
+                                 const int32_t* in_typ, const float* norm, float* Z, void* stream) {
+    ERC_REQUIRE(x && in_ptr && in_src && in_typ && norm && Z, "rrgcn_agg_fwd: null pointer");
+    ERC_REQUIRE(R > 0 && R <= RR && N > 0 && F > 0 && F <= 256, "rrgcn_agg_fwd: R=%d (<= %d) F=%d", R, RR, F);
+    hipLaunchKernelGGL(rrgcn_agg_fwd_kernel, NODE_GRID(N), x, ldx, F, N, R, in_ptr, in_src, in_typ, norm, Z);
+    ERC_LAUNCH_CHECK("rrgcn_agg_fwd");
+    return ERC_OK;
+}
+
+extern "C" int erc_rrgcn_bwd_edges(const float* x, int ldx, int F, int N, int R, const int32_t* in_ptr,
+                                   const int32_t* in_src, const int32_t* in_typ, const float* dZ, float* dnorm,
+                                   void* stream) {
+    ERC_REQUIRE(x && in_ptr && in_src && in_typ && dZ && dnorm, "rrgcn_bwd_edges: null pointer");
+    ERC_REQUIRE(R > 0 && R <= RR && N > 0 && F > 0 && F <= 256, "rrgcn_bwd_edges: bad sizes");
+    hipLaunchKernelGGL(rrgcn_bwd_target_kernel, NODE_GRID(N), x, ldx, F, N, R, in_ptr, in_src, in_typ, dZ, dnorm);
+    ERC_LAUNCH_CHECK("rrgcn_bwd_target");
+    return ERC_OK;
+}
+
+extern "C" int erc_rrgcn_bwd_source(const float* dH, int lddh, int O, int N, int R, const int32_t* out_ptr,
+                                    const int32_t* out_dst, const int32_t* out_typ, const int32_t* out_eid,
+                                    const float* norm, float* U, void* stream) {
+    ERC_REQUIRE(dH && out_ptr && out_dst && out_typ && out_eid && norm && U, "rrgcn_bwd_source: null pointer");
+    ERC_REQUIRE(R > 0 && R <= RR && N > 0 && O > 0 && O <= 128, "rrgcn_bwd_source: bad sizes");
+    hipLaunchKernelGGL(rrgcn_bwd_source_kernel, NODE_GRID(N), dH, lddh, O, N, R, out_ptr, out_dst, out_typ, out_eid, norm, U);
+    ERC_LAUNCH_CHECK("rrgcn_bwd_source");
     return ERC_OK;
 }
 

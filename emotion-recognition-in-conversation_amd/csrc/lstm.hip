@@ -4,9 +4,9 @@
 //
 // One workgroup per (dialogue, direction).  The input-side gate pre-activations GX = x W_ih^T + b_ih are one
 // hoisted GEMM over all rows (both directions: 800 columns); the recurrent matrix W_hh [400,100] of the
-// direction lives in REGISTERS for the whole scan (thread r owns gate row r: 100 VGPRs), h_{t-1} is
+// direction lives in REGISTERS for the whole scan (one gate row per thread: 100 VGPRs), h_{t-1} is
 // broadcast from LDS, so a step costs ~100 LDS broadcasts + 100 FMAs per thread and touches HBM only for the
-// GX row and the saved state.  The backward scan keeps the transposed slices in registers the same way and
+// GX row (requested 4 steps ahead) and the saved state.  The backward scan keeps the transposed slices in registers the same way and
 // leaves all weight gradients to GEMMs over the saved gate gradients.
 #include "erc_common.h"
 
@@ -34,74 +34,163 @@ struct LstmP {
     // backward only
     const float* dHout; int lddh;        // gradient wrt Hout (or wrt Hdrop when drop_p > 0)
     float* dGX;                          // [rows,800] gradient wrt the gate pre-activations (0 on padded rows)
+    unsigned long long* stamps;          // diagnostic (erc_lstm_set_stamps): shader-clock stamps of one step of workgroup (0,0)
 };
+unsigned long long* g_lstm_stamps = nullptr;
+#define LSTM_STAMP(r_, slot)                                                                       \
+    do {                                                                                           \
+        if (r_ == 1 && s0 == SC && p.stamps && tid == 0 && b == 0 && d == 0) {                     \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            p.stamps[slot] = __builtin_readcyclecounter();                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    } while (0)
 
-__device__ __forceinline__ int64_t row_of(const LstmP& p, int b, int t) {
-    return p.node_off ? (int64_t)p.node_off[b] + t : (int64_t)b * p.sb + (int64_t)t * p.st;
+// rows of a dialogue: row(t) = base + t * step
+struct RowMap {
+    int64_t base, step;
+    __device__ __forceinline__ int64_t operator()(int t) const { return base + (int64_t)t * step; }
+};
+__device__ __forceinline__ RowMap rows_of(const LstmP& p, int b) {
+    return p.node_off ? RowMap{(int64_t)p.node_off[b], 1} : RowMap{(int64_t)b * p.sb, p.st};
 }
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+typedef float f2 __attribute__((ext_vector_type(2)));
+// sigmoid / tanh on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each; absolute error < 3e-7):
+// 4 and 6 instructions -- the library expf + IEEE division + tanhf were 90 of the 230 instructions of a step, and the
+// step is bound by instruction issue (two wavefronts per SIMD, finding 26)
+__device__ __forceinline__ float fast_sigm(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * fast_sigm(2.0f * x) - 1.0f; }
 
+// value of lane Q of the caller's quad (lanes 4u .. 4u+3), in every lane of the quad: one DPP move, no LDS
+template <int Q>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), Q * 0x55, 0xF, 0xF, true));
+}
+// Global memory is touched once per SC steps, not per step: the wavefront's memory counter (vmcnt) retires loads and
+// stores in issue order, so a step that stores its results and then needs a prefetched operand waits for its own stores --
+// one L2 round trip (~0.9 us) per step whatever the prefetch distance.  A chunk's operands are requested one chunk ahead
+// and its results are kept in registers until the chunk ends; inside a chunk a step is LDS + ALU only.
+constexpr int SC = 8;
+// Vectors that every thread reads (h_{t-1}: 100 values, the gate gradients: 400) sit in LDS as chunks of 25 values padded
+// to 28 (16-byte rows, chunks 28 banks apart: the distinct addresses of one wavefront read never share a bank).
+constexpr int CHK = 25, CHP = 28;
+constexpr int HP = 4 * CHP;        // hidden state
+constexpr int DPP_ = 16 * CHP;     // gate gradients
+__device__ __forceinline__ int chunk_pos(int k) { return (k / CHK) * CHP + k % CHK; }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// Thread layout of both scans: quad u = tid / 4 (< 100 live) owns hidden unit u, lane q = tid % 4 of the quad its gate q
+// (i|f|g|o).  The four gates of a unit meet through DPP moves inside the quad, the cell state / the recurrent gradients
+// live in registers (the same value in the 4 lanes), and the only LDS traffic is the vector every thread needs from all
+// others -- h_{t-1} forward, the gate gradients backward -- double-buffered, so a step has ONE barrier.
 __global__ __launch_bounds__(NTH) void lstm_fwd_kernel(LstmP p) {
     const int b = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
     const int L = p.lengths ? (int)p.lengths[b] : p.T;
-    __shared__ float s_h[H], s_c[H], s_g[G4];
-    float w[H];
-    if (tid < G4) {
-        const float* src = p.W_hh + ((int64_t)d * G4 + tid) * H;
+    const RowMap rmap = rows_of(p, b);
+    __shared__ __attribute__((aligned(16))) float s_h[2][HP];
+    const int u = tid >> 2, q = tid & 3;
+    const bool live = u < H;
+    const int uc = min(u, H - 1);
+    const int grow = q * H + uc;       // the gate this thread activates: its column of GX / gates
+    // the recurrent product: the quad splits K -- lane q multiplies the unit's FOUR gate rows by h[25q .. 25q+25), 100
+    // weights in registers but 25 LDS values per step instead of 100 (every lane reading the whole vector was 200 KB of
+    // LDS traffic a step), as packed fp32 multiply-adds over the gate pairs (i,f) and (g,o)
+    f2 w01[CHK], w23[CHK];
+    {
+        const float* src = p.W_hh + ((int64_t)d * G4 + uc) * H + q * CHK;
 #pragma unroll
-        for (int k = 0; k < H; ++k) w[k] = src[k];
+        for (int i = 0; i < CHK; ++i) {
+            w01[i] = f2{src[i], src[H * H + i]};
+            w23[i] = f2{src[2 * H * H + i], src[3 * H * H + i]};
+        }
     }
-    const float bhh = tid < G4 ? p.b_hh[d * G4 + tid] : 0.f;
-    if (tid < H) s_h[tid] = 0.f, s_c[tid] = 0.f;
+    const float bhh = p.b_hh[d * G4 + grow];
+    if (tid < HP) s_h[0][tid] = 0.f, s_h[1][tid] = 0.f;
     uint64_t roff = 0, rseed = 0;
-    if (p.Hdrop && p.drop_p > 0.f) roff = p.rng[0], rseed = p.rng[1] ^ p.rng_stream;
+    const bool dropping = p.Hdrop && p.drop_p > 0.f;
+    if (dropping) roff = p.rng[0], rseed = p.rng[1] ^ p.rng_stream;
     const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const float am = q == 2 ? 2.f : 1.f;       // tanh(a) = 2 sigm(2a) - 1: one exponential whatever the gate
+    float c = 0.f, hprev = 0.f;
     __syncthreads();
-    // the hoisted gate pre-activation of step s + 1 is requested while step s runs: its (L2) latency was the longest
-    // item on the per-step critical path
-    const int gcol = d * G4 + min(tid, G4 - 1);
-    float gx_next = L > 0 ? p.GX[row_of(p, b, d == 0 ? 0 : L - 1) * p.ldgx + gcol] : 0.f;
-    for (int s = 0; s < L; ++s) {
-        const int t = d == 0 ? s : L - 1 - s;
-        const int64_t row = row_of(p, b, t);
-        const float gx = gx_next;
-        {
-            const int sn = min(s + 1, L - 1);
-            gx_next = p.GX[row_of(p, b, d == 0 ? sn : L - 1 - sn) * p.ldgx + gcol];
-        }
-        if (tid < G4) {
-            float a = gx + bhh;
+    const int gcol = d * G4 + grow;
+    auto t_of = [&](int s) { return d == 0 ? s : L - 1 - s; };
+    auto gx_of = [&](int s) { return p.GX[rmap(t_of(min(s, L - 1))) * p.ldgx + gcol]; };
+    // the unit's four per-step outputs, one per lane of the quad: c | h_{t-1} | h | dropped h
+    float* const obase = q == 0 ? p.Cst : q == 1 ? p.Hprev : q == 2 ? p.Hout : p.Hdrop;
+    const int64_t opitch = q < 2 ? 2 * H : q == 2 ? p.ldh : p.ldhd;
+    const bool ostore = live && (q < 3 || p.Hdrop);
+    float gx_cur[SC], gx_nxt[SC], o_gate[SC], o_unit[SC];
 #pragma unroll
-            for (int k = 0; k < H; ++k) a += w[k] * s_h[k];
-            const float act = (tid >= 2 * H && tid < 3 * H) ? tanhf(a) : sigm(a);
-            s_g[tid] = act;
-            p.gates[row * 2 * G4 + d * G4 + tid] = act;
-        }
-        __syncthreads();
-        if (tid < H) {
-            const float hprev = s_h[tid];
-            const float c = s_g[H + tid] * s_c[tid] + s_g[tid] * s_g[2 * H + tid];
-            const float h = s_g[3 * H + tid] * tanhf(c);
-            s_c[tid] = c;
-            s_h[tid] = h;
-            p.Cst[row * 2 * H + d * H + tid] = c;
-            p.Hprev[row * 2 * H + d * H + tid] = hprev;
-            p.Hout[row * p.ldh + d * H + tid] = h;
-            if (p.Hdrop) {
-                float hd = h;
-                if (p.drop_p > 0.f) {
-                    const float u = erc_uniform(rseed, roff, (uint64_t)row * 2 * H + d * H + tid);
-                    hd = u >= p.drop_p ? h * keep_scale : 0.f;
+    for (int r = 0; r < SC; ++r) gx_cur[r] = L > 0 ? gx_of(r) : 0.f, gx_nxt[r] = L > 0 ? gx_of(SC + r) : 0.f;
+    for (int s0 = 0; s0 < L; s0 += SC) {
+#pragma unroll
+        for (int r = 0; r < SC; ++r) {
+            const int s = s0 + r;
+            if (s < L) {       // uniform
+                const int cur = s & 1;
+                LSTM_STAMP(r, 0);
+                const float* hv = s_h[cur] + q * CHP;
+                f2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < CHK; ++i) {
+                    const f2 hk = {hv[i], hv[i]};
+                    p01 = __builtin_elementwise_fma(w01[i], hk, p01);
+                    p23 = __builtin_elementwise_fma(w23[i], hk, p23);
                 }
-                p.Hdrop[row * p.ldhd + d * H + tid] = hd;
+                float part[4] = {p01.x, p01.y, p23.x, p23.y};
+                LSTM_STAMP(r, 1);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    part[g] += dpp_mov<0xB1>(part[g]);      // quad lanes xor 1
+                    part[g] += dpp_mov<0x4E>(part[g]);      // quad lanes xor 2
+                }
+                const float a = gx_cur[r] + bhh + (q == 0 ? part[0] : q == 1 ? part[1] : q == 2 ? part[2] : part[3]);
+                const float sg = fast_sigm(am * a);
+                const float act = q == 2 ? 2.f * sg - 1.f : sg;
+                LSTM_STAMP(r, 2);
+                const float gi = quad_bcast<0>(act), gf = quad_bcast<1>(act), gg = quad_bcast<2>(act), go = quad_bcast<3>(act);
+                c = gf * c + gi * gg;
+                const float h = go * fast_tanh(c);
+                o_gate[r] = act;
+                o_unit[r] = q == 0 ? c : q == 1 ? hprev : h;      // lane 3: h, dropped when it is stored
+                if (live && q == 0) s_h[cur ^ 1][chunk_pos(u)] = h;
+                hprev = h;
+                LSTM_STAMP(r, 3);
+                __syncthreads();
+                LSTM_STAMP(r, 4);
             }
         }
-        __syncthreads();
+        // chunk boundary: next chunk's operands (requested a chunk ago) move up, this chunk's results go out, the chunk
+        // after next is requested
+#pragma unroll
+        for (int r = 0; r < SC; ++r) gx_cur[r] = gx_nxt[r];
+#pragma unroll
+        for (int r = 0; r < SC; ++r) {
+            const int s = s0 + r;
+            if (s < L) {
+                const int64_t row = rmap(t_of(s));
+                if (live) p.gates[row * 2 * G4 + gcol] = o_gate[r];
+                float val = o_unit[r];
+                if (dropping) {    // uniform
+                    const float uu = erc_uniform(rseed, roff, (uint64_t)row * 2 * H + d * H + uc);
+                    val = q < 3 ? val : uu >= p.drop_p ? val * keep_scale : 0.f;
+                }
+                if (ostore) obase[row * opitch + d * H + u] = val;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SC; ++r) gx_nxt[r] = gx_of(s0 + 2 * SC + r);
     }
     // padded positions: zero output (pad_packed_sequence) -- only meaningful for padded row addressing
     if (!p.node_off)
         for (int t = L; t < p.T; ++t) {
-            const int64_t row = row_of(p, b, t);
+            const int64_t row = rmap(t);
             if (tid < H) {
                 p.Hout[row * p.ldh + d * H + tid] = 0.f;
                 if (p.Hdrop) p.Hdrop[row * p.ldhd + d * H + tid] = 0.f;
@@ -112,85 +201,128 @@ __global__ __launch_bounds__(NTH) void lstm_fwd_kernel(LstmP p) {
 __global__ __launch_bounds__(NTH) void lstm_bwd_kernel(LstmP p) {
     const int b = blockIdx.x, d = blockIdx.y, tid = threadIdx.x;
     const int L = p.lengths ? (int)p.lengths[b] : p.T;
-    __shared__ float s_dh[H], s_dc[H], s_dp[G4], s_part[4][H];
-    // thread (q,k), q = tid/100 < 4, holds W_hh[100q + j][k], j < 100: its share of (W_hh^T dpre)[k]
-    const int q = tid / H, k = tid % H;
-    float wt[H];
-    if (tid < G4) {
-        const float* src = p.W_hh + ((int64_t)d * G4 + q * H) * H + k;
+    const RowMap rmap = rows_of(p, b);
+    __shared__ __attribute__((aligned(16))) float s_dp[2][DPP_];     // gate gradients of the step, entry q*H + j chunked
+    const int u = tid >> 2, q = tid & 3;
+    const bool live = u < H;
+    const int uc = min(u, H - 1);
+    // the recurrent product (W_hh^T dpre)[u]: a DPP row of 16 lanes = 4 units; lane `part` of the row multiplies entries
+    // [25 part, 25 part + 25) of the 400 gate gradients into each of the row's 4 units (100 weights in registers, 25 LDS
+    // values per step), the row sums by DPP.  The elementwise part keeps the quad layout: unit u = tid / 4 is unit
+    // (tid / 4) % 4 of its own row.
+    const int part = tid & 15, u0 = min(tid >> 4, H / 4 - 1) * 4;
+    f2 wt01[CHK], wt23[CHK];
 #pragma unroll
-        for (int j = 0; j < H; ++j) wt[j] = src[(int64_t)j * H];
+    for (int i = 0; i < CHK; ++i) {
+        const float* src = p.W_hh + ((int64_t)d * G4 + part * CHK + i) * H + u0;
+        wt01[i] = f2{src[0], src[1]};
+        wt23[i] = f2{src[2], src[3]};
     }
-    if (tid < H) s_dh[tid] = 0.f, s_dc[tid] = 0.f;
+    const int myr = (tid >> 2) & 3;
     uint64_t roff = 0, rseed = 0;
     const bool dropped = p.drop_p > 0.f;
     if (dropped) roff = p.rng[0], rseed = p.rng[1] ^ p.rng_stream;
     const float keep_scale = dropped ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-    __syncthreads();
-    // operands of a step (upstream gradient, the four gates, cell state and previous cell state): requested one step
-    // ahead, unconditionally (clamped rows), consumed from registers
-    struct StepIn { float g, gi, gf, gg, go, c, cprev; };
-    const int hc = min(tid, H - 1);
+    auto t_of = [&](int s) { return d == 0 ? s : L - 1 - s; };
+    // operands of a step: upstream gradient, the thread's own gate, the cell state (the previous cell state is the next
+    // step's); clamped rows, a chunk ahead
+    struct StepIn { float g, gq, c; };
     auto fetch = [&](int s) {
         StepIn r;
-        const int sc = max(s, 0);
-        const int t = d == 0 ? sc : L - 1 - sc;
-        const int64_t row = row_of(p, b, t);
-        r.g = p.dHout[row * p.lddh + d * H + hc];
-        const float* gt = p.gates + row * 2 * G4 + d * G4;
-        r.gi = gt[hc], r.gf = gt[H + hc], r.gg = gt[2 * H + hc], r.go = gt[3 * H + hc];
-        r.c = p.Cst[row * 2 * H + d * H + hc];
-        const int sp = max(sc - 1, 0);
-        const int tp = d == 0 ? sp : L - 1 - sp;
-        r.cprev = p.Cst[row_of(p, b, tp) * 2 * H + d * H + hc] * (sc > 0 ? 1.f : 0.f);
+        const int64_t row = rmap(t_of(max(s, 0)));
+        r.g = p.dHout[row * p.lddh + d * H + uc];
+        r.gq = p.gates[row * 2 * G4 + d * G4 + q * H + uc];
+        r.c = p.Cst[row * 2 * H + d * H + uc];
         return r;
     };
-    StepIn nxt = fetch(L - 1);
-    for (int s = L - 1; s >= 0; --s) {
-        const int t = d == 0 ? s : L - 1 - s;
-        const int64_t row = row_of(p, b, t);
-        const StepIn cur = nxt;
-        nxt = fetch(s - 1);
-        if (tid < H) {
-            float g = cur.g;
-            if (dropped) {
-                const float u = erc_uniform(rseed, roff, (uint64_t)row * 2 * H + d * H + tid);
-                g = u >= p.drop_p ? g * keep_scale : 0.f;
-            }
-            const float dh = g + s_dh[tid];
-            const float gi = cur.gi, gf = cur.gf, gg = cur.gg, go = cur.go;
-            const float c = cur.c;
-            const float cprev = cur.cprev;
-            const float tc = tanhf(c);
-            const float dc = s_dc[tid] + dh * go * (1.f - tc * tc);
-            const float dpi = dc * gg * gi * (1.f - gi);
-            const float dpf = dc * cprev * gf * (1.f - gf);
-            const float dpg = dc * gi * (1.f - gg * gg);
-            const float dpo = dh * tc * go * (1.f - go);
-            s_dc[tid] = dc * gf;
-            s_dp[tid] = dpi; s_dp[H + tid] = dpf; s_dp[2 * H + tid] = dpg; s_dp[3 * H + tid] = dpo;
-            float* o = p.dGX + row * 2 * G4 + d * G4;
-            o[tid] = dpi; o[H + tid] = dpf; o[2 * H + tid] = dpg; o[3 * H + tid] = dpo;
-        }
-        __syncthreads();
-        if (tid < G4) {
-            float a = 0.f;
+    StepIn in_cur[SC], in_nxt[SC];
+    float o_dp[SC];
 #pragma unroll
-            for (int j = 0; j < H; ++j) a += wt[j] * s_dp[q * H + j];
-            s_part[q][k] = a;
+    for (int r = 0; r < SC; ++r) {
+        in_cur[r] = L > 0 ? fetch(L - 1 - r) : StepIn{0.f, 0.f, 0.f};
+        in_nxt[r] = L > 0 ? fetch(L - 1 - SC - r) : StepIn{0.f, 0.f, 0.f};
+    }
+    float dh_rec = 0.f, dc_carry = 0.f;
+    for (int s0 = L - 1; s0 >= 0; s0 -= SC) {
+        // everything of a step that does not depend on the recurrent gradients, for the whole chunk: with
+        //   P = o (1 - tanh(c)^2),  K = gate' x (g | c_prev | i | tanh(c)) for this lane's gate,
+        // the dependent chain of a step is dh = g + dh_rec; dc = dc_carry + dh P; dpre = (o-lane ? dh : dc) K; dc_carry = dc f
+        float fP[SC], fK[SC], fF[SC], fG[SC];
+#pragma unroll
+        for (int r = 0; r < SC; ++r) {
+            const int s = max(s0 - r, 0);
+            const StepIn cur = in_cur[r];
+            const float cprev = s > 0 ? (r + 1 < SC ? in_cur[(r + 1) % SC].c : in_nxt[0].c) : 0.f;
+            float g = cur.g;
+            if (dropped) {     // uniform
+                const float uu = erc_uniform(rseed, roff, (uint64_t)rmap(t_of(s)) * 2 * H + d * H + uc);
+                g = uu >= p.drop_p ? g * keep_scale : 0.f;
+            }
+            const float gi = quad_bcast<0>(cur.gq), gf = quad_bcast<1>(cur.gq), gg = quad_bcast<2>(cur.gq),
+                        go = quad_bcast<3>(cur.gq);
+            const float tc = fast_tanh(cur.c);
+            // d pre-activation of this lane's gate: i: dc g i(1-i) | f: dc c' f(1-f) | g: dc i (1-g^2) | o: dh tanh(c) o(1-o)
+            const float der = q == 2 ? 1.f - cur.gq * cur.gq : cur.gq * (1.f - cur.gq);
+            fP[r] = go * (1.f - tc * tc);
+            fK[r] = der * (q == 0 ? gg : q == 1 ? cprev : q == 2 ? gi : tc);
+            fF[r] = gf;
+            fG[r] = g;
         }
-        __syncthreads();
-        if (tid < H) s_dh[tid] = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SC; ++r) {
+            const int s = s0 - r;
+            if (s >= 0) {      // uniform
+                const int buf = s & 1;
+                const float dh = fG[r] + dh_rec;
+                const float dc = dc_carry + dh * fP[r];
+                const float dp = (q == 3 ? dh : dc) * fK[r];
+                dc_carry = dc * fF[r];
+                o_dp[r] = dp;
+                if (live) s_dp[buf][chunk_pos(q * H + u)] = dp;
+                __syncthreads();
+                const float* dv = s_dp[buf] + part * CHP;
+                f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < CHK; ++i) {
+                    const f2 dk = {dv[i], dv[i]};
+                    a01 = __builtin_elementwise_fma(wt01[i], dk, a01);
+                    a23 = __builtin_elementwise_fma(wt23[i], dk, a23);
+                }
+                float acc[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {   // sum over the 16 lanes of the row: quad xor 1 / xor 2, half mirror, mirror
+                    acc[r4] += dpp_mov<0xB1>(acc[r4]);
+                    acc[r4] += dpp_mov<0x4E>(acc[r4]);
+                    acc[r4] += dpp_mov<0x141>(acc[r4]);
+                    acc[r4] += dpp_mov<0x140>(acc[r4]);
+                }
+                dh_rec = myr == 0 ? acc[0] : myr == 1 ? acc[1] : myr == 2 ? acc[2] : acc[3];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < SC; ++r) in_cur[r] = in_nxt[r];
+#pragma unroll
+        for (int r = 0; r < SC; ++r) {
+            const int s = s0 - r;
+            if (s >= 0 && live) p.dGX[rmap(t_of(s)) * 2 * G4 + d * G4 + q * H + u] = o_dp[r];
+        }
+#pragma unroll
+        for (int r = 0; r < SC; ++r) in_nxt[r] = fetch(s0 - 2 * SC - r);
     }
     if (!p.node_off)
         for (int t = L; t < p.T; ++t) {
-            const int64_t row = row_of(p, b, t);
+            const int64_t row = rmap(t);
             if (tid < G4) p.dGX[row * 2 * G4 + d * G4 + tid] = 0.f;
         }
 }
 
 }  // namespace
+
+// diagnostic: shader-clock stamps inside one step of the next forward scans (tools/lstm_bench.py); nullptr = off
+extern "C" int erc_lstm_set_stamps(unsigned long long* stamps) {
+    g_lstm_stamps = stamps;
+    return ERC_OK;
+}
 
 extern "C" int erc_lstm_scan_fwd(const float* GX, int ldgx, const float* W_hh, const float* b_hh,
                                  const int64_t* lengths, const int32_t* node_off, int64_t sb, int64_t st, int B, int T,
@@ -203,6 +335,7 @@ extern "C" int erc_lstm_scan_fwd(const float* GX, int ldgx, const float* W_hh, c
     p.GX = GX; p.ldgx = ldgx; p.W_hh = W_hh; p.b_hh = b_hh; p.lengths = lengths; p.node_off = node_off;
     p.sb = sb; p.st = st; p.B = B; p.T = T; p.Hout = Hout; p.ldh = ldh; p.Hdrop = Hdrop; p.ldhd = ldhd;
     p.drop_p = drop_p; p.rng = rng_state; p.rng_stream = rng_stream; p.gates = gates; p.Cst = Cst; p.Hprev = Hprev;
+    p.stamps = g_lstm_stamps;
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3(B, 2), dim3(NTH), 0, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("lstm_scan_fwd");
     return ERC_OK;

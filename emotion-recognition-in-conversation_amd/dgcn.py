@@ -81,6 +81,9 @@ class DGCNModule(nn.Module):
         self.wp, self.wf = context
         self.n_speakers, self.input_size, self.n_classes, self.compute = n_speakers, input_size, n_classes, compute
         self.R = 2 * n_speakers ** 2
+        # few relations (two speakers: 8 < 30 bases): RGCNConv in relation space, W_r composed first as models/rgcn.py:300-304
+        # does (csrc/dgcn_ops.hip); None = decide in finalize() from the library's limit, True / False = forced (tests)
+        self.relation_space = None
         self.drop_p = float(dropout)
         self.rnn = _SeqContext(input_size, hidden_size, dropout)
         self.edge_att = _EdgeAtt(hidden_size)
@@ -105,6 +108,8 @@ class DGCNModule(nn.Module):
         self.flat = FlatParams(self.live_groups(), device)
         self.lstm = BiLSTM2(self.flat, "rnn.rnn.", self.input_size, drop_p=self.drop_p)
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
+        if self.relation_space is None:
+            self.relation_space = self.R <= capi.rrgcn_max_relations()
         return self
 
     @property
@@ -124,9 +129,10 @@ class DGCNModule(nn.Module):
         g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E),
                  in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
         ws = dict(g=g, E=E, rnn_out=f32(BT, G_DIM), Xc=f32(N, G_DIM + H1), ATT=f32(N, G_DIM), norm=f32(E),
-                  Z=f32(N, NB * G_DIM), Hc=f32(N, H1), AGG=f32(N, H1), Zc=f32(N, 100), logits=f32(N, C), stats=torch.zeros(256, dtype=torch.float32, device=device),
+                  Z=f32(N, self._kb * G_DIM), Hc=f32(N, H1), AGG=f32(N, H1), Zc=f32(N, 100), logits=f32(N, C), stats=torch.zeros(256, dtype=torch.float32, device=device),
                   dlogits=f32(N, C), dZc=f32(N, 100), dXc=f32(N, G_DIM + H1), dAGG=f32(N, H1), dHc=f32(N, H1),
-                  dZ=f32(N, NB * G_DIM), dnorm=f32(E), TT=f32(E, NB), U=f32(N, NB * H1), basisT=f32(NB * H1, G_DIM),
+                  dZ=f32(N, self._kb * G_DIM), dnorm=f32(E), TT=f32(E, NB), U=f32(N, self._kb * H1),
+                  basisT=f32(self._kb * H1, G_DIM), Wr=f32(self._kb * G_DIM, H1), dWr=f32(self._kb * G_DIM, H1),
                   DATT=f32(N, G_DIM), dscore=f32(E), drnn=f32(BT, G_DIM))
         D = self.input_size
         slab = 12 * N * H1 + 4 * BT * 800 + 10 * (800 * D + 800 * 200 + 2 * 400 * 100 * 2) + 4 * NB * G_DIM * H1 + \
@@ -134,6 +140,11 @@ class DGCNModule(nn.Module):
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["jobs"] = None
         return ws
+
+    @property
+    def _kb(self):
+        """blocks of the RGCN aggregate Z: relations (relation space) or bases"""
+        return self.R if self.relation_space else NB
 
     def _shape(self, x, lens, label, n_nodes=None):
         B, T = x.shape[0], x.shape[1]
@@ -156,11 +167,17 @@ class DGCNModule(nn.Module):
         capi.gemm_f32(Xc, XW, 0, None, fp.w("edge_att.weight"), G_DIM, 0, None, ws["ATT"], G_DIM, N, G_DIM, G_DIM)
         capi.edge_att_fwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"])
         # RGCNConv(basis): Z (basis space) -> Z @ basis + x @ root + bias
-        capi.brgcn_agg_fwd(Xc, XW, G_DIM, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["Z"])
-        K1 = NB * G_DIM
+        if self.relation_space:
+            capi.basis_compose(fp.w("gcn.conv1.att"), fp.w("gcn.conv1.basis"), self.R, NB, G_DIM, H1, ws["Wr"], ws["basisT"])
+            capi.rrgcn_agg_fwd(Xc, XW, G_DIM, N, self.R, g, ws["norm"], ws["Z"])
+            Wz = ws["Wr"]
+        else:
+            capi.brgcn_agg_fwd(Xc, XW, G_DIM, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["Z"])
+            Wz = fp.w("gcn.conv1.basis")
+        K1 = self._kb * G_DIM
         S1 = pl.split_for(N, H1, K1)
         src = pl.take((S1 + 1) * N * H1)
-        capi.gemm_f32(ws["Z"], K1, 0, None, fp.w("gcn.conv1.basis"), H1, 1, None, pl.ws[src:], H1, N, H1, K1,
+        capi.gemm_f32(ws["Z"], K1, 0, None, Wz, H1, 1, None, pl.ws[src:], H1, N, H1, K1,
                       split_k=S1, c_slab=N * H1)
         capi.gemm_f32(Xc, XW, 0, None, fp.w("gcn.conv1.root"), H1, 1, None, pl.ws[src + S1 * N * H1:], H1, N, H1, G_DIM)
         capi.slab_reduce(pl.ws[src:], S1 + 1, N * H1, fp.w("gcn.conv1.bias"), H1, 0, ws["Hc"], N * H1)
@@ -210,15 +227,23 @@ class DGCNModule(nn.Module):
         capi.gemm_f32(dG, XW, 0, None, fp.w("gcn.conv2.lin_root.weight"), H1, 1, None, ws["dHc"], H1, N, H1, H1)
         capi.csr_sum(ws["dAGG"], H1, H1, N, g["out_ptr"], g["out_dst"], ws["dHc"], H1, accumulate=1)
         # RGCNConv(basis)
-        K1 = NB * G_DIM
-        capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.basis"), H1, 0, None, ws["dZ"], K1, N, K1, H1)
-        capi.brgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["dZ"], ws["dnorm"],
-                             ws["TT"], fp.g("gcn.conv1.att"))
-        matmul_wgrad_io(pl, ws["Z"], K1, ws["dHc"], H1, K1, H1, N, off["gcn.conv1.basis"], off["gcn.conv1.bias"], defer=True)
+        KB = self._kb
+        K1 = KB * G_DIM
+        if self.relation_space:
+            capi.gemm_f32(ws["dHc"], H1, 0, None, ws["Wr"], H1, 0, None, ws["dZ"], K1, N, K1, H1)
+            capi.rrgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["dZ"], ws["dnorm"])
+            # dW_r = Z^T dHc (+ the bias strip); basis / comp gradients follow from it after the batched launch
+            pl.defer(ws["Z"], K1, ws["dHc"], H1, ws["dWr"], H1, K1, H1, N, 2, pl.grad[off["gcn.conv1.bias"]:])
+            capi.rrgcn_bwd_source(ws["dHc"], H1, H1, N, self.R, g, ws["norm"], ws["U"])
+        else:
+            capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.basis"), H1, 0, None, ws["dZ"], K1, N, K1, H1)
+            capi.brgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["dZ"], ws["dnorm"],
+                                 ws["TT"], fp.g("gcn.conv1.att"))
+            matmul_wgrad_io(pl, ws["Z"], K1, ws["dHc"], H1, K1, H1, N, off["gcn.conv1.basis"], off["gcn.conv1.bias"], defer=True)
+            capi.brgcn_bwd_source(ws["dHc"], H1, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["U"])
+            capi.transpose_batched(fp.w("gcn.conv1.basis"), NB, G_DIM, H1, ws["basisT"])
         matmul_wgrad_io(pl, Xc, XW, ws["dHc"], H1, G_DIM, H1, N, off["gcn.conv1.root"], None, defer=True)
-        capi.brgcn_bwd_source(ws["dHc"], H1, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["U"])
-        capi.transpose_batched(fp.w("gcn.conv1.basis"), NB, G_DIM, H1, ws["basisT"])
-        capi.gemm_f32(ws["U"], NB * H1, 0, None, ws["basisT"], G_DIM, 1, None, dXc, XW, N, G_DIM, NB * H1, accumulate=1)
+        capi.gemm_f32(ws["U"], KB * H1, 0, None, ws["basisT"], G_DIM, 1, None, dXc, XW, N, G_DIM, KB * H1, accumulate=1)
         capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.root"), H1, 0, None, dXc, XW, N, G_DIM, H1, accumulate=1)
         # EdgeAtt
         capi.edge_att_bwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"], ws["dnorm"], dXc, XW, 1, ws["DATT"], G_DIM,
@@ -231,6 +256,9 @@ class DGCNModule(nn.Module):
         capi.gather_rows(dXc, XW, g["node_row"], N, G_DIM, ws["drnn"], G_DIM, scatter=1)
         self.lstm.backward(pl, ws["drnn"], G_DIM)
         pl.reduce_into(ws, fp.grad)
+        if self.relation_space:
+            capi.basis_decompose(fp.w("gcn.conv1.att"), fp.w("gcn.conv1.basis"), ws["dWr"], self.R, NB, G_DIM * H1,
+                                 fp.g("gcn.conv1.basis"), fp.g("gcn.conv1.att"))
         return ws["stats"]
 
 

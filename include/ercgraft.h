@@ -561,6 +561,8 @@ int erc_dag_attn_sums(const float* alpha, const float* H1, int ldo, const int32_
 
 
 
+/* diagnostic: shader-clock stamps (5 x uint64) inside one step of workgroup (0,0) of the next forward scans; NULL = off */
+int erc_lstm_set_stamps(unsigned long long* stamps);
 /* ------------------------------------------------------------------------
  * (Bi)LSTM recurrence, hidden 100 per direction, torch.nn.LSTM semantics (gate order i|f|g|o):
  * DialogueGCN SeqContext (packed; track_mm/dgcn_models.py:10-33) and MMGCN's text branch (unpacked over
@@ -618,6 +620,25 @@ int erc_brgcn_bwd_edges(const float* x, int ldx, int F, int N, int R, const int3
 int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, const int32_t* out_ptr, const int32_t* out_dst,
                          const int32_t* out_typ, const int32_t* out_eid, const float* norm, const float* att,
                          int num_bases, float* U, void* stream);
+/* The same layer in RELATION space, for R <= erc_rrgcn_max_relations() (= 8: two speakers).  models/rgcn.py:300-304 composes
+ * W_r = sum_b comp[r,b] basis[b] and transforms per relation; with R < num_bases that order is also the cheaper one:
+ *   erc_basis_compose:   Wr [R,F,O] and its per-relation transpose WrT [R,O,F]
+ *   erc_rrgcn_agg_fwd:   Z[i, r*F + c] = sum_{e into i, type_e = r} norm_e x[src_e, c];  conv(x) = Z @ Wr.view(RF,O) + ...
+ *   erc_rrgcn_bwd_edges: dnorm[e] = x[src_e] . dZ[i, type_e, :]   from dZ = dOut @ Wr.view(RF,O)^T
+ *   erc_rrgcn_bwd_source: U[j, r*O + c] = sum_{e out of j, type r} norm_e dOut[dst_e, c];  dx = U @ WrT.view(RO,F)
+ *   erc_basis_decompose: dbasis[b] = sum_r comp[r,b] dWr[r], dcomp[r,b] = <dWr[r], basis[b]> from dWr = Z^T dOut [R,F*O]
+ * (fixed summation orders).  Larger R (MELD: 162) keeps the basis-space entry points above. */
+int erc_rrgcn_max_relations(void);
+int erc_basis_compose(const float* comp, const float* basis, int R, int num_bases, int F, int O, float* Wr, float* WrT,
+                      void* stream);
+int erc_basis_decompose(const float* comp, const float* basis, const float* dWr, int R, int num_bases, int FO,
+                        float* dbasis, float* dcomp, void* stream);
+int erc_rrgcn_agg_fwd(const float* x, int ldx, int F, int N, int R, const int32_t* in_ptr, const int32_t* in_src,
+                      const int32_t* in_typ, const float* norm, float* Z, void* stream);
+int erc_rrgcn_bwd_edges(const float* x, int ldx, int F, int N, int R, const int32_t* in_ptr, const int32_t* in_src,
+                        const int32_t* in_typ, const float* dZ, float* dnorm, void* stream);
+int erc_rrgcn_bwd_source(const float* dH, int lddh, int O, int N, int R, const int32_t* out_ptr, const int32_t* out_dst,
+                         const int32_t* out_typ, const int32_t* out_eid, const float* norm, float* U, void* stream);
 /* out[n][c][r] = in[n][r][c] */
 int erc_transpose_batched(const float* in, int nb, int rows, int cols, float* out, void* stream);
 /* out[i,:] (+)= sum_{e in CSR row i} x[idx[e],:]: the neighbour sum of torch_geometric GraphConv(aggr='add')

@@ -75,6 +75,90 @@ def test_edge_att_and_basis_rgcn_vs_reference_golden(golden, name):
                            ("conv1.root", droot), ("conv1.bias", dbias)], tol=2e-3)
 
 
+def test_relation_space_rgcn_vs_reference_golden(golden):
+    """The two-speaker fixture (R = 8 < 30 bases) through the relation-space entry points: W_r composed first, Z [N, 8F],
+    comp / basis gradients from dW_r -- against the same reference outputs as the basis-space path above."""
+    from erc_amd import capi
+    from erc_amd.cogmen import build_graph_tensors
+    fx = golden("dgcn_s2")
+    S, R, NB, Fd, O = 2, 8, 30, 200, 100
+    assert R <= capi.rrgcn_max_relations()
+    lengths, spk = torch.from_numpy(fx["lengths"]).to(DEV), torch.from_numpy(fx["speakers"]).to(DEV)
+    feats = torch.from_numpy(fx["features"])
+    B, T = feats.shape[:2]
+    g, ei, et = build_graph_tensors(lengths, spk, 10, 10, S)
+    N, E = g["counts"].cpu().tolist()
+    att_w = torch.nn.Module(); att_w.weight = torch.nn.Parameter(torch.zeros(Fd, Fd)); fill_params(att_w, int(fx["att_seed"]))
+    conv = torch.nn.Module()
+    conv.basis, conv.att = torch.nn.Parameter(torch.zeros(NB, Fd, O)), torch.nn.Parameter(torch.zeros(R, NB))
+    conv.root, conv.bias = torch.nn.Parameter(torch.zeros(Fd, O)), torch.nn.Parameter(torch.zeros(O))
+    fill_params(conv, int(fx["conv_seed"]))
+    W, basis, comp, root, bias = [t.detach().to(DEV) for t in (att_w.weight, conv.basis, conv.att, conv.root, conv.bias)]
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    x = z(N, Fd)
+    capi.gather_rows(feats.to(DEV).view(B * T, Fd), Fd, g["node_row"], N, Fd, x, Fd)
+    ATT, norm = z(N, Fd), z(E)
+    capi.gemm_f32(x, Fd, 0, None, W, Fd, 0, None, ATT, Fd, N, Fd, Fd)
+    capi.edge_att_fwd(x, Fd, ATT, Fd, Fd, N, g, norm)
+    Wr, WrT = z(R, Fd, O), z(R, O, Fd)
+    capi.basis_compose(comp, basis, R, NB, Fd, O, Wr, WrT)
+    Wr_ref = torch.einsum("rb,bfo->rfo", comp.double(), basis.double())
+    assert float((Wr.double() - Wr_ref).abs().max()) < 1e-6
+    assert torch.equal(WrT, Wr.transpose(1, 2).contiguous())
+    Z = z(N, R * Fd)
+    capi.rrgcn_agg_fwd(x, Fd, Fd, N, R, g, norm, Z)
+    out = z(N, O)
+    capi.gemm_f32(Z, R * Fd, 0, None, Wr, O, 1, None, out, O, N, O, R * Fd, bias=bias)
+    capi.gemm_f32(x, Fd, 0, None, root, O, 1, None, out, O, N, O, Fd, accumulate=1)
+    np.testing.assert_allclose(out.cpu().numpy(), fx["rgcn_out"], atol=1e-4, rtol=1e-4)
+    gout = torch.from_numpy(fx["gout"]).to(DEV)
+    dZ, dnorm = z(N, R * Fd), z(E)
+    capi.gemm_f32(gout, O, 0, None, Wr, O, 0, None, dZ, R * Fd, N, R * Fd, O)
+    capi.rrgcn_bwd_edges(x, Fd, Fd, N, R, g, dZ, dnorm)
+    dWr, dbias = z(R * Fd, O), z(O)
+    capi.gemm_f32(Z, R * Fd, 1, None, gout, O, 1, None, dWr, O, R * Fd, O, N, ones_col=2, bias_out=dbias)
+    dbasis, dcomp = z(NB, Fd, O), z(R, NB)
+    capi.basis_decompose(comp, basis, dWr, R, NB, Fd * O, dbasis, dcomp)
+    droot = z(Fd, O)
+    capi.gemm_f32(x, Fd, 1, None, gout, O, 1, None, droot, O, Fd, O, N)
+    U, dx = z(N, R * O), z(N, Fd)
+    capi.rrgcn_bwd_source(gout, O, O, N, R, g, norm, U)
+    capi.gemm_f32(U, R * O, 0, None, WrT, Fd, 1, None, dx, Fd, N, Fd, R * O)
+    capi.gemm_f32(gout, O, 0, None, root, O, 0, None, dx, Fd, N, Fd, O, accumulate=1)
+    DATT, dscore = z(N, Fd), z(E)
+    capi.edge_att_bwd(x, Fd, ATT, Fd, Fd, N, g, norm, dnorm, dx, Fd, 1, DATT, Fd, dscore)
+    dW = z(Fd, Fd)
+    capi.gemm_f32(DATT, Fd, 1, None, x, Fd, 1, None, dW, Fd, Fd, Fd, N)
+    capi.gemm_f32(DATT, Fd, 0, None, W, Fd, 1, None, dx, Fd, N, Fd, Fd, accumulate=1)
+    dfeat = z(B * T, Fd)
+    capi.gather_rows(dx, Fd, g["node_row"], N, Fd, dfeat, Fd, scatter=1)
+    np.testing.assert_allclose(dfeat.cpu().view(B, T, Fd).numpy(), fx["dfeatures"], atol=2e-4, rtol=2e-3)
+    check_grad_digest(fx, [("edge_att.weight", dW), ("conv1.basis", dbasis), ("conv1.att", dcomp),
+                           ("conv1.root", droot), ("conv1.bias", dbias)], tol=2e-3)
+
+
+def test_dgcn_relation_space_equals_basis_space():
+    """Same module, same batch: RGCNConv in relation space (the default for two speakers) vs basis space."""
+    from erc_amd.dgcn import DGCNModule
+    batch = to_device(make_batch(8, dict(a=100, t=100, v=512), n_speakers=2, n_classes=6, min_len=5, max_len=60, seed=31), DEV)
+    outs = []
+    for rel in (True, False):
+        torch.manual_seed(5)
+        m = DGCNModule(2, input_size=712, hidden_size=200, n_classes=6)
+        m.relation_space = rel
+        m.finalize(DEV)
+        m.train()
+        m.drop_p, m.lstm.drop_p = 0.0, 0.0
+        stats = m.loss_and_grads(batch).clone()
+        outs.append((stats, m._last_ws["logits"].clone(), m.flat.grad.clone(), m))
+    assert outs[0][3].relation_space and not outs[1][3].relation_space
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 2e-5
+    assert abs(float(outs[0][0][0] - outs[1][0][0])) < 1e-5
+    for n in outs[0][3].flat.params:
+        e = rel_err(outs[0][3].flat.g(n), outs[1][3].flat.g(n))
+        assert e < 1e-3, (n, e)
+
+
 def _pair(case, compute="f32"):
     from oracle.dgcn import DGCNOracle
     from erc_amd.dgcn import DGCNModule
