@@ -55,6 +55,9 @@ __device__ __forceinline__ RowMap rows_of(const LstmP& p, int b) {
     return p.node_off ? RowMap{(int64_t)p.node_off[b], 1} : RowMap{(int64_t)b * p.sb, p.st};
 }
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+// barrier that orders LDS traffic only: __syncthreads() would also wait for the LDS-DMA requests in flight (vmcnt)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // sigmoid / tanh on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each; absolute error < 3e-7):
 // 4 and 6 instructions -- the library expf + IEEE division + tanhf were 90 of the 230 instructions of a step, and the
 // step is bound by instruction issue (two wavefronts per SIMD, finding 26)
@@ -116,19 +119,69 @@ __global__ __launch_bounds__(NTH) void lstm_fwd_kernel(LstmP p) {
     if (dropping) roff = p.rng[0], rseed = p.rng[1] ^ p.rng_stream;
     const float keep_scale = p.drop_p > 0.f ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const float am = q == 2 ? 2.f : 1.f;       // tanh(a) = 2 sigm(2a) - 1: one exponential whatever the gate
+    const bool odd = q & 1, hi = q & 2;
     float c = 0.f, hprev = 0.f;
     __syncthreads();
     const int gcol = d * G4 + grow;
     auto t_of = [&](int s) { return d == 0 ? s : L - 1 - s; };
-    auto gx_of = [&](int s) { return p.GX[rmap(t_of(min(s, L - 1))) * p.ldgx + gcol]; };
+    // row of scan step s = row_first + s * dstep: the chunk boundaries are instruction-count bound (a wavefront issues
+    // one instruction per 4 cycles whatever its kind), so addresses are a uniform row pointer + a 32-bit lane offset, or
+    // a per-lane pointer advanced by a per-lane step
+    const int64_t dstep = d == 0 ? rmap.step : -rmap.step;
+    const int64_t row_first = rmap(t_of(0));
     // the unit's four per-step outputs, one per lane of the quad: c | h_{t-1} | h | dropped h
     float* const obase = q == 0 ? p.Cst : q == 1 ? p.Hprev : q == 2 ? p.Hout : p.Hdrop;
     const int64_t opitch = q < 2 ? 2 * H : q == 2 ? p.ldh : p.ldhd;
     const bool ostore = live && (q < 3 || p.Hdrop);
-    float gx_cur[SC], gx_nxt[SC], o_gate[SC], o_unit[SC];
+    float* const uptr0 = obase + row_first * opitch + d * H + uc;
+    const int64_t ustep = dstep * opitch;
+    // A chunk's operands travel global -> LDS directly (LDS-DMA, lane l of a wavefront lands at base + 4 l): requested at
+    // the previous chunk boundary, complete long before the next one, read back by the thread that asked -- no destination
+    // registers, so nothing in the steps can wait for them.  (Prefetching into registers made the steps stall: carried
+    // from boundary to boundary the compiler copies them behind the new requests, and while a request is pending any
+    // packed multiply-add whose unused operand half happens to be the register next to it waits for the request.)
+    __shared__ float s_gx[2][SC][NTH];
+    float gx_cur[SC], o_gate[SC], o_unit[SC];
+    auto request_chunk = [&](int c0, int buf) {
+        float* dst = &s_gx[buf][0][tid & ~63];
 #pragma unroll
-    for (int r = 0; r < SC; ++r) gx_cur[r] = L > 0 ? gx_of(r) : 0.f, gx_nxt[r] = L > 0 ? gx_of(SC + r) : 0.f;
+        for (int r = 0; r < SC; ++r) {
+            const float* grow_p = p.GX + (row_first + (int64_t)min(c0 + r, L - 1) * dstep) * p.ldgx;      // uniform
+            __builtin_amdgcn_global_load_lds(grow_p + gcol, (lds_void*)(dst + r * NTH), 4, 0, 0);
+        }
+    };
+    if (L > 0) request_chunk(0, 0);
+    auto store_chunk = [&](int c0) {
+        float* up = uptr0 + c0 * ustep;
+#pragma unroll
+        for (int r = 0; r < SC; ++r) {
+            const int s = c0 + r;
+            if (s < L) {       // uniform
+                const int64_t row = row_first + (int64_t)s * dstep;
+                float* grow_p = p.gates + row * 2 * G4;      // uniform
+                if (live) grow_p[gcol] = o_gate[r];
+                float val = o_unit[r];
+                if (dropping) {    // uniform
+                    const float uu = erc_uniform(rseed, roff, (uint64_t)row * 2 * H + d * H + uc);
+                    val = q < 3 ? val : uu >= p.drop_p ? val * keep_scale : 0.f;
+                }
+                if (ostore) *up = val;
+            }
+            up += ustep;
+        }
+    };
+    unsigned long long t_c0 = 0, t_r0 = 0;
+    if (p.stamps && tid == 0 && b == 0 && d == 0) t_c0 = __builtin_readcyclecounter(), t_r0 = __builtin_amdgcn_s_memrealtime();
     for (int s0 = 0; s0 < L; s0 += SC) {
+        // chunk boundary: this chunk's operands out of LDS, the previous chunk's results to memory, the next chunk's
+        // operands requested
+        const int cb = (s0 / SC) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // requests and stores of the previous boundary: a chunk old
+#pragma unroll
+        for (int r = 0; r < SC; ++r) gx_cur[r] = s_gx[cb][r][tid];
+        if (s0 > 0) store_chunk(s0 - SC);
+        if (s0 + SC < L) request_chunk(s0 + SC, cb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < SC; ++r) {
             const int s = s0 + r;
@@ -136,21 +189,27 @@ __global__ __launch_bounds__(NTH) void lstm_fwd_kernel(LstmP p) {
                 const int cur = s & 1;
                 LSTM_STAMP(r, 0);
                 const float* hv = s_h[cur] + q * CHP;
-                f2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
+                // two accumulator sets (even / odd k): four independent chains of packed multiply-adds
+                f2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f}, r01 = {0.f, 0.f}, r23 = {0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < CHK; ++i) {
                     const f2 hk = {hv[i], hv[i]};
-                    p01 = __builtin_elementwise_fma(w01[i], hk, p01);
-                    p23 = __builtin_elementwise_fma(w23[i], hk, p23);
+                    if (i & 1) {
+                        r01 = __builtin_elementwise_fma(w01[i], hk, r01);
+                        r23 = __builtin_elementwise_fma(w23[i], hk, r23);
+                    } else {
+                        p01 = __builtin_elementwise_fma(w01[i], hk, p01);
+                        p23 = __builtin_elementwise_fma(w23[i], hk, p23);
+                    }
                 }
-                float part[4] = {p01.x, p01.y, p23.x, p23.y};
+                p01 += r01, p23 += r23;
                 LSTM_STAMP(r, 1);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    part[g] += dpp_mov<0xB1>(part[g]);      // quad lanes xor 1
-                    part[g] += dpp_mov<0x4E>(part[g]);      // quad lanes xor 2
-                }
-                const float a = gx_cur[r] + bhh + (q == 0 ? part[0] : q == 1 ? part[1] : q == 2 ? part[2] : part[3]);
+                // quad transpose-reduce: lane q ends with gate q's sum over the four lanes (3 DPP adds, no branches):
+                // lanes exchange across xor 1 the gate of pair (0,1) / (2,3) they do not keep, then across xor 2
+                const float k0 = odd ? p01.y : p01.x, g0 = odd ? p01.x : p01.y;
+                const float k1 = odd ? p23.y : p23.x, g1 = odd ? p23.x : p23.y;
+                const float e0 = k0 + dpp_mov<0xB1>(g0), e1 = k1 + dpp_mov<0xB1>(g1);
+                const float a = gx_cur[r] + bhh + ((hi ? e1 : e0) + dpp_mov<0x4E>(hi ? e0 : e1));
                 const float sg = fast_sigm(am * a);
                 const float act = q == 2 ? 2.f * sg - 1.f : sg;
                 LSTM_STAMP(r, 2);
@@ -162,31 +221,17 @@ __global__ __launch_bounds__(NTH) void lstm_fwd_kernel(LstmP p) {
                 if (live && q == 0) s_h[cur ^ 1][chunk_pos(u)] = h;
                 hprev = h;
                 LSTM_STAMP(r, 3);
-                __syncthreads();
+                lds_barrier();
                 LSTM_STAMP(r, 4);
             }
         }
-        // chunk boundary: next chunk's operands (requested a chunk ago) move up, this chunk's results go out, the chunk
-        // after next is requested
-#pragma unroll
-        for (int r = 0; r < SC; ++r) gx_cur[r] = gx_nxt[r];
-#pragma unroll
-        for (int r = 0; r < SC; ++r) {
-            const int s = s0 + r;
-            if (s < L) {
-                const int64_t row = rmap(t_of(s));
-                if (live) p.gates[row * 2 * G4 + gcol] = o_gate[r];
-                float val = o_unit[r];
-                if (dropping) {    // uniform
-                    const float uu = erc_uniform(rseed, roff, (uint64_t)row * 2 * H + d * H + uc);
-                    val = q < 3 ? val : uu >= p.drop_p ? val * keep_scale : 0.f;
-                }
-                if (ostore) obase[row * opitch + d * H + u] = val;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < SC; ++r) gx_nxt[r] = gx_of(s0 + 2 * SC + r);
     }
+    if (p.stamps && tid == 0 && b == 0 && d == 0) {
+        p.stamps[5] = __builtin_readcyclecounter() - t_c0;
+        p.stamps[6] = __builtin_amdgcn_s_memrealtime() - t_r0;
+        p.stamps[7] = L;
+    }
+    if (L > 0) store_chunk((L - 1) / SC * SC);
     // padded positions: zero output (pad_packed_sequence) -- only meaningful for padded row addressing
     if (!p.node_off)
         for (int t = L; t < p.T; ++t) {
@@ -226,24 +271,38 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_kernel(LstmP p) {
     auto t_of = [&](int s) { return d == 0 ? s : L - 1 - s; };
     // operands of a step: upstream gradient, the thread's own gate, the cell state (the previous cell state is the next
     // step's); clamped rows, a chunk ahead
-    struct StepIn { float g, gq, c; };
-    auto fetch = [&](int s) {
-        StepIn r;
-        const int64_t row = rmap(t_of(max(s, 0)));
-        r.g = p.dHout[row * p.lddh + d * H + uc];
-        r.gq = p.gates[row * 2 * G4 + d * G4 + q * H + uc];
-        r.c = p.Cst[row * 2 * H + d * H + uc];
-        return r;
-    };
-    StepIn in_cur[SC], in_nxt[SC];
-    float o_dp[SC];
+    struct ChunkIn { float g[SC], gq[SC], c[SC + 1]; };      // steps s0, s0-1, ..; c has one more: c_prev of the last step
+    const int64_t dstep = d == 0 ? rmap.step : -rmap.step;       // row of scan step s = row_first + s * dstep
+    const int64_t row_first = rmap(t_of(0));
+    const int lane_h = d * H + uc, lane_g = d * G4 + q * H + uc;
+    auto load_chunk = [&](int s0, ChunkIn& X) {
 #pragma unroll
-    for (int r = 0; r < SC; ++r) {
-        in_cur[r] = L > 0 ? fetch(L - 1 - r) : StepIn{0.f, 0.f, 0.f};
-        in_nxt[r] = L > 0 ? fetch(L - 1 - SC - r) : StepIn{0.f, 0.f, 0.f};
-    }
+        for (int r = 0; r <= SC; ++r) {
+            const int64_t row = row_first + (int64_t)min(max(s0 - r, 0), max(L - 1, 0)) * dstep;     // uniform
+            if (r < SC) {
+                X.g[r] = (p.dHout + row * p.lddh)[lane_h];
+                X.gq[r] = (p.gates + row * 2 * G4)[lane_g];
+            }
+            X.c[r] = (p.Cst + row * 2 * H)[lane_h];
+        }
+    };
+    auto touch = [&](ChunkIn& X) {
+#pragma unroll
+        for (int r = 0; r <= SC; ++r) {
+            if (r < SC) asm volatile("" : "+v"(X.g[r]), "+v"(X.gq[r]));
+            asm volatile("" : "+v"(X.c[r]));
+        }
+    };
+    float o_dp[SC];
+    auto store_chunk = [&](int s0) {
+#pragma unroll
+        for (int r = 0; r < SC; ++r) {
+            const int s = s0 - r;
+            if (s >= 0 && live) (p.dGX + (row_first + (int64_t)s * dstep) * 2 * G4)[lane_g] = o_dp[r];
+        }
+    };
     float dh_rec = 0.f, dc_carry = 0.f;
-    for (int s0 = L - 1; s0 >= 0; s0 -= SC) {
+    auto steps = [&](int s0, const ChunkIn& X) {
         // everything of a step that does not depend on the recurrent gradients, for the whole chunk: with
         //   P = o (1 - tanh(c)^2),  K = gate' x (g | c_prev | i | tanh(c)) for this lane's gate,
         // the dependent chain of a step is dh = g + dh_rec; dc = dc_carry + dh P; dpre = (o-lane ? dh : dc) K; dc_carry = dc f
@@ -251,18 +310,17 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_kernel(LstmP p) {
 #pragma unroll
         for (int r = 0; r < SC; ++r) {
             const int s = max(s0 - r, 0);
-            const StepIn cur = in_cur[r];
-            const float cprev = s > 0 ? (r + 1 < SC ? in_cur[(r + 1) % SC].c : in_nxt[0].c) : 0.f;
-            float g = cur.g;
+            const float cprev = s > 0 ? X.c[r + 1] : 0.f;
+            float g = X.g[r];
             if (dropped) {     // uniform
                 const float uu = erc_uniform(rseed, roff, (uint64_t)rmap(t_of(s)) * 2 * H + d * H + uc);
                 g = uu >= p.drop_p ? g * keep_scale : 0.f;
             }
-            const float gi = quad_bcast<0>(cur.gq), gf = quad_bcast<1>(cur.gq), gg = quad_bcast<2>(cur.gq),
-                        go = quad_bcast<3>(cur.gq);
-            const float tc = fast_tanh(cur.c);
+            const float gq = X.gq[r];
+            const float gi = quad_bcast<0>(gq), gf = quad_bcast<1>(gq), gg = quad_bcast<2>(gq), go = quad_bcast<3>(gq);
+            const float tc = fast_tanh(X.c[r]);
             // d pre-activation of this lane's gate: i: dc g i(1-i) | f: dc c' f(1-f) | g: dc i (1-g^2) | o: dh tanh(c) o(1-o)
-            const float der = q == 2 ? 1.f - cur.gq * cur.gq : cur.gq * (1.f - cur.gq);
+            const float der = q == 2 ? 1.f - gq * gq : gq * (1.f - gq);
             fP[r] = go * (1.f - tc * tc);
             fK[r] = der * (q == 0 ? gg : q == 1 ? cprev : q == 2 ? gi : tc);
             fF[r] = gf;
@@ -299,16 +357,30 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_kernel(LstmP p) {
                 dh_rec = myr == 0 ? acc[0] : myr == 1 ? acc[1] : myr == 2 ? acc[2] : acc[3];
             }
         }
-#pragma unroll
-        for (int r = 0; r < SC; ++r) in_cur[r] = in_nxt[r];
-#pragma unroll
-        for (int r = 0; r < SC; ++r) {
-            const int s = s0 - r;
-            if (s >= 0 && live) p.dGX[rmap(t_of(s)) * 2 * G4 + d * G4 + q * H + u] = o_dp[r];
+    };
+    ChunkIn inA, inB;
+    if (L > 0) load_chunk(L - 1, inA);
+    for (int s0 = L - 1; s0 >= 0; s0 -= 2 * SC) {
+        __builtin_amdgcn_sched_barrier(0);
+        touch(inA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 < L - 1) store_chunk(s0 + SC);
+        __builtin_amdgcn_sched_barrier(0);
+        load_chunk(s0 - SC, inB);
+        __builtin_amdgcn_sched_barrier(0);
+        steps(s0, inA);
+        if (s0 - SC >= 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            touch(inB);
+            __builtin_amdgcn_sched_barrier(0);
+            store_chunk(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_chunk(s0 - 2 * SC, inA);
+            __builtin_amdgcn_sched_barrier(0);
+            steps(s0 - SC, inB);
         }
-#pragma unroll
-        for (int r = 0; r < SC; ++r) in_nxt[r] = fetch(s0 - 2 * SC - r);
     }
+    if (L > 0) store_chunk(L - 1 - (L - 1) / SC * SC);
     if (!p.node_off)
         for (int t = L; t < p.T; ++t) {
             const int64_t row = rmap(t);

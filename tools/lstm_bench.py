@@ -41,6 +41,8 @@ def run(B, T, packed, reps=50):
     t = stamps.cpu().tolist()
     print("  fwd step stamps (cycles): products %d | reduce + activation %d | cell %d | barrier %d | step %d" % (
         t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[4] - t[0]))
+    print("  scan loop of workgroup (0,0): %d steps, %d cycles in %.2f us -> %.2f GHz, %.0f cycles/step" % (
+        t[7], t[5], t[6] / 100.0, t[5] / (t[6] * 10.0), t[5] / max(t[7], 1)))
     print("B=%d T=%d %s: fwd %.1f us (%.2f us/step)  bwd %.1f us (%.2f us/step)" % (
         B, T, "packed" if packed else "unpacked", out["fwd"], out["fwd"] / T, out["bwd"], out["bwd"] / T))
 
