@@ -112,7 +112,7 @@ _SIGS = {
     "erc_mm_row_normalize": (C.c_int, [_vp, _i, _vp, _vp, _vp]),
     "erc_mm_row_normalize_bwd": (C.c_int, [_vp, _vp, _vp, _i, _vp, _vp]),
     "erc_mm_adj_finish": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "erc_mm_adj_finish_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "erc_mm_adj_finish_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "erc_mm_cross_apply": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "erc_mm_cross_grad": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i64, _i64, _vp]),
     "erc_gcnii_combine_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _f, _f, _f, _vp, C.c_uint64, _vp, _vp]),
@@ -651,8 +651,8 @@ def mm_adj_finish(COS, xhat, node_off, B, M, N, P, ADJ, CR, CCOS, DEG):
     _call("erc_mm_adj_finish", COS, xhat, node_off, B, M, N, P, ADJ, CR, CCOS, DEG)
 
 
-def mm_adj_finish_bwd(COS, CCOS, DEG, dADJ, dCR, node_off, B, M, N, P, G, GC):
-    _call("erc_mm_adj_finish_bwd", COS, CCOS, DEG, dADJ, dCR, node_off, B, M, N, P, G, GC)
+def mm_adj_finish_bwd(COS, CCOS, DEG, dADJ, dCR, node_off, B, M, N, P, G, GC, DD):
+    _call("erc_mm_adj_finish_bwd", COS, CCOS, DEG, dADJ, dCR, node_off, B, M, N, P, G, GC, DD)
 
 
 def mm_cross_apply(CR, h, ldh, node_dlg, node_off, M, N, P, out, ldo):

@@ -141,113 +141,114 @@ __device__ __forceinline__ float dsim_dc(float c) {
     return SHRINK / (PI_F * sqrtf(fmaxf(1.0f - t * t, 1e-12f)));
 }
 
-// One workgroup per dialogue.  COS blocks (raw cosines from the grouped GEMM) -> normalised adjacency blocks ADJ,
-// normalised cross entries CR[b][m*M+n][p] (m != n), degrees DEG[node], raw cross cosines CCOS.
-__global__ __launch_bounds__(1024) void adj_finish_kernel(const float* __restrict__ COS, const float* __restrict__ xhat,
-                                                          const int32_t* __restrict__ node_off, int M, int N, int P,
-                                                          float* __restrict__ ADJ, float* __restrict__ CR,
-                                                          float* __restrict__ CCOS, float* __restrict__ DEG) {
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// COS blocks (raw cosines from the grouped GEMM) -> normalised adjacency blocks ADJ, normalised cross entries
+// CR[b][m*M+n][p] (m != n), degrees DEG[node], raw cross cosines CCOS.  One wavefront per adjacency row (m, p) of a
+// dialogue, two launches: similarities + degrees, then the D^-1/2 . D^-1/2 scaling that needs every degree of the block.
+// (One workgroup per dialogue ran the three phases behind barriers on 32 of the 256 CUs: 91 us; and its backward 84 us.)
+__global__ __launch_bounds__(256) void adj_rows_kernel(const float* __restrict__ COS, const float* __restrict__ xhat,
+                                                       const int32_t* __restrict__ node_off, int M, int N, int P,
+                                                       float* __restrict__ ADJ, float* __restrict__ CCOS,
+                                                       float* __restrict__ DEG) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, it = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int off = node_off[b], L = node_off[b + 1] - off;
-    __shared__ float s_cs[9][MAXP];   // sim of the cross entries
-    __shared__ float s_u[3][MAXP];    // deg^-1/2
-    // cross-modal same-utterance similarities
-    for (int it = wave; it < M * M * L; it += 16) {
-        const int p = it % L, mn = it / L, m = mn / M, n = mn % M;
-        if (m == n) continue;
-        const float c = wave_sum(dt4(ld4(xhat + ((int64_t)m * N + off + p) * FD, lane),
-                                     ld4(xhat + ((int64_t)n * N + off + p) * FD, lane)));
-        if (lane == 0) {
-            s_cs[mn][p] = sim_of(c);
-            CCOS[((int64_t)b * M * M + mn) * P + p] = c;
-        }
+    if (it >= M * L) return;
+    const int m = it / L, p = it % L;
+    // cross-modal same-utterance similarities of this node
+    float cross = 0.f;
+    const L4 mine = ld4(xhat + ((int64_t)m * N + off + p) * FD, lane);
+    for (int n = 0; n < M; ++n) {
+        if (n == m) continue;
+        const float c = wave_sum(dt4(mine, ld4(xhat + ((int64_t)n * N + off + p) * FD, lane)));
+        if (lane == 0) CCOS[((int64_t)b * M * M + m * M + n) * P + p] = c;
+        cross += sim_of(c);
     }
-    __syncthreads();
-    // block similarities (in place into ADJ) and degrees
-    for (int it = wave; it < M * L; it += 16) {
-        const int m = it / L, p = it % L;
-        const float* cr = COS + (((int64_t)b * M + m) * P + p) * P;
-        float* ar = ADJ + (((int64_t)b * M + m) * P + p) * P;
-        float rs = 0.f;
-        for (int q = lane; q < L; q += 64) {
-            const float s = sim_of(cr[q]);
-            ar[q] = s;
-            rs += s;
-        }
-        rs = wave_sum(rs);
-        if (lane == 0) {
-            for (int n = 0; n < M; ++n)
-                if (n != m) rs += s_cs[m * M + n][p];
-            s_u[m][p] = 1.0f / sqrtf(rs);
-            DEG[(int64_t)m * N + off + p] = rs;
-        }
+    const float* cr = COS + (((int64_t)b * M + m) * P + p) * P;
+    float* ar = ADJ + (((int64_t)b * M + m) * P + p) * P;
+    float rs = 0.f;
+    for (int q = lane; q < L; q += 64) {
+        const float s = sim_of(cr[q]);
+        ar[q] = s;
+        rs += s;
     }
-    __syncthreads();
-    for (int it = tid; it < M * L * L; it += 1024) {
-        const int m = it / (L * L), r = it % (L * L), p = r / L, q = r % L;
-        ADJ[(((int64_t)b * M + m) * P + p) * P + q] *= s_u[m][p] * s_u[m][q];
-    }
-    for (int it = tid; it < M * M * L; it += 1024) {
-        const int p = it % L, mn = it / L, m = mn / M, n = mn % M;
-        if (m != n) CR[((int64_t)b * M * M + mn) * P + p] = s_cs[mn][p] * s_u[m][p] * s_u[n][p];
+    rs = wave_sum(rs) + cross;
+    if (lane == 0) DEG[(int64_t)m * N + off + p] = rs;
+}
+
+__global__ __launch_bounds__(256) void adj_scale_kernel(const float* __restrict__ CCOS, const float* __restrict__ DEG,
+                                                        const int32_t* __restrict__ node_off, int M, int N, int P,
+                                                        float* __restrict__ ADJ, float* __restrict__ CR) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int off = node_off[b], L = node_off[b + 1] - off;
+    if (it >= M * L) return;
+    const int m = it / L, p = it % L;
+    const float up = 1.0f / sqrtf(DEG[(int64_t)m * N + off + p]);
+    float* ar = ADJ + (((int64_t)b * M + m) * P + p) * P;
+    for (int q = lane; q < L; q += 64) ar[q] *= up * (1.0f / sqrtf(DEG[(int64_t)m * N + off + q]));
+    if (lane < M && lane != m) {
+        const int64_t i_mn = ((int64_t)b * M * M + m * M + lane) * P + p;
+        CR[i_mn] = sim_of(CCOS[i_mn]) * up * (1.0f / sqrtf(DEG[(int64_t)lane * N + off + p]));
     }
 }
 
 // Backward of adj_finish: from dADJ (blocks) and dCR (directional cross gradients) to
 //   G = dCOS + dCOS^T (blocks, so that dXhat_block = G Xhat is one grouped GEMM) and GC (cross, symmetric per
-//   unordered pair, applied with cross_apply on Xhat).
-__global__ __launch_bounds__(1024) void adj_finish_bwd_kernel(const float* __restrict__ COS, const float* __restrict__ CCOS,
-                                                              const float* __restrict__ DEG,
+//   unordered pair, applied with cross_apply on Xhat).  Same split: per-row degree gradients DD, then the entries.
+__global__ __launch_bounds__(256) void adj_bwd_rows_kernel(const float* __restrict__ COS, const float* __restrict__ CCOS,
+                                                           const float* __restrict__ DEG, const float* __restrict__ dADJ,
+                                                           const float* __restrict__ dCR,
+                                                           const int32_t* __restrict__ node_off, int M, int N, int P,
+                                                           float* __restrict__ DD) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int off = node_off[b], L = node_off[b + 1] - off;
+    if (it >= M * L) return;
+    const int m = it / L, p = it % L;
+    // du_p = sum_q (dA_pq + dA_qp) S_pq u_q  + cross terms;  dd_p = -1/2 du_p d_p^-3/2
+    const int64_t base = ((int64_t)b * M + m) * P;
+    float acc = 0.f;
+    for (int q = lane; q < L; q += 64) {
+        const float s = sim_of(COS[(base + p) * P + q]);
+        acc += (dADJ[(base + p) * P + q] + dADJ[(base + q) * P + p]) * s * (1.0f / sqrtf(DEG[(int64_t)m * N + off + q]));
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        for (int n = 0; n < M; ++n)
+            if (n != m) {
+                const float s = sim_of(CCOS[((int64_t)b * M * M + m * M + n) * P + p]);
+                // entry ((m,p),(n,p)) and entry ((n,p),(m,p)) both carry u^m_p
+                acc += (dCR[((int64_t)b * M * M + m * M + n) * P + p] + dCR[((int64_t)b * M * M + n * M + m) * P + p]) *
+                       s * (1.0f / sqrtf(DEG[(int64_t)n * N + off + p]));
+            }
+        const float u = 1.0f / sqrtf(DEG[(int64_t)m * N + off + p]);
+        DD[(int64_t)m * N + off + p] = -0.5f * acc * u * u * u;
+    }
+}
+
+__global__ __launch_bounds__(256) void adj_bwd_entries_kernel(const float* __restrict__ COS, const float* __restrict__ CCOS,
+                                                              const float* __restrict__ DEG, const float* __restrict__ DD,
                                                               const float* __restrict__ dADJ, const float* __restrict__ dCR,
                                                               const int32_t* __restrict__ node_off, int M, int N, int P,
                                                               float* __restrict__ G, float* __restrict__ GC) {
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, it = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int off = node_off[b], L = node_off[b + 1] - off;
-    __shared__ float s_u[3][MAXP], s_dd[3][MAXP];
-    for (int it = tid; it < M * L; it += 1024) s_u[it / L][it % L] = 1.0f / sqrtf(DEG[(int64_t)(it / L) * N + off + it % L]);
-    __syncthreads();
-    // du_p = sum_q (dA_pq + dA_qp) S_pq u_q  + cross terms;  dd_p = -1/2 du_p d_p^-3/2
-    for (int it = wave; it < M * L; it += 16) {
-        const int m = it / L, p = it % L;
-        const int64_t base = ((int64_t)b * M + m) * P;
-        float acc = 0.f;
-        for (int q = lane; q < L; q += 64) {
-            const float s = sim_of(COS[(base + p) * P + q]);
-            acc += (dADJ[(base + p) * P + q] + dADJ[(base + q) * P + p]) * s * s_u[m][q];
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            for (int n = 0; n < M; ++n)
-                if (n != m) {
-                    const float s = sim_of(CCOS[((int64_t)b * M * M + m * M + n) * P + p]);
-                    // entry ((m,p),(n,p)) and entry ((n,p),(m,p)) both carry u^m_p
-                    acc += (dCR[((int64_t)b * M * M + m * M + n) * P + p] + dCR[((int64_t)b * M * M + n * M + m) * P + p]) *
-                           s * s_u[n][p];
-                }
-            const float u = s_u[m][p];
-            s_dd[m][p] = -0.5f * acc * u * u * u;
-        }
-    }
-    __syncthreads();
+    if (it >= M * L) return;
+    const int m = it / L, p = it % L;
+    const int64_t base = ((int64_t)b * M + m) * P;
+    const float up = 1.0f / sqrtf(DEG[(int64_t)m * N + off + p]), ddp = DD[(int64_t)m * N + off + p];
     // dS_pq = dA_pq u_p u_q + dd_p ; dcos = dS * dsim/dc ; G_pq = dcos_pq + dcos_qp
-    for (int it = tid; it < M * L * L; it += 1024) {
-        const int m = it / (L * L), r = it % (L * L), p = r / L, q = r % L;
-        const int64_t base = ((int64_t)b * M + m) * P;
+    for (int q = lane; q < L; q += 64) {
         const float c = COS[(base + p) * P + q];  // symmetric up to rounding; use the (p,q) entry for both halves
-        const float uu = s_u[m][p] * s_u[m][q];
-        const float dpq = dADJ[(base + p) * P + q] * uu + s_dd[m][p];
-        const float dqp = dADJ[(base + q) * P + p] * uu + s_dd[m][q];
+        const float uu = up * (1.0f / sqrtf(DEG[(int64_t)m * N + off + q]));
+        const float dpq = dADJ[(base + p) * P + q] * uu + ddp;
+        const float dqp = dADJ[(base + q) * P + p] * uu + DD[(int64_t)m * N + off + q];
         G[(base + p) * P + q] = (dpq + dqp) * dsim_dc(c);
     }
-    for (int it = tid; it < M * M * L; it += 1024) {
-        const int p = it % L, mn = it / L, m = mn / M, n = mn % M;
-        if (m == n) continue;
-        const int64_t i_mn = ((int64_t)b * M * M + mn) * P + p, i_nm = ((int64_t)b * M * M + n * M + m) * P + p;
-        const float c = CCOS[i_mn];
-        const float uu = s_u[m][p] * s_u[n][p];
+    if (lane < M && lane != m) {
+        const int n = lane;
+        const int64_t i_mn = ((int64_t)b * M * M + m * M + n) * P + p, i_nm = ((int64_t)b * M * M + n * M + m) * P + p;
+        const float uu = up * (1.0f / sqrtf(DEG[(int64_t)n * N + off + p]));
         // directional entries (m,n) and (n,m) share one cosine: total gradient of that cosine, stored for both
-        const float ds = (dCR[i_mn] * uu + s_dd[m][p]) + (dCR[i_nm] * uu + s_dd[n][p]);
-        GC[i_mn] = ds * dsim_dc(c);
+        const float ds = (dCR[i_mn] * uu + ddp) + (dCR[i_nm] * uu + DD[(int64_t)n * N + off + p]);
+        GC[i_mn] = ds * dsim_dc(CCOS[i_mn]);
     }
 }
 
@@ -441,19 +442,25 @@ extern "C" int erc_mm_adj_finish(const float* COS, const float* xhat, const int3
                                  float* ADJ, float* CR, float* CCOS, float* DEG, void* stream) {
     ERC_REQUIRE(COS && xhat && node_off && ADJ && CR && CCOS && DEG, "mm_adj_finish: null pointer");
     ERC_REQUIRE(B > 0 && M >= 2 && M <= 3 && N > 0 && P > 0 && P <= MAXP, "mm_adj_finish: M=%d P=%d unsupported", M, P);
-    hipLaunchKernelGGL(adj_finish_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, COS, xhat, node_off, M, N, P, ADJ,
-                       CR, CCOS, DEG);
-    ERC_LAUNCH_CHECK("mm_adj_finish");
+    const dim3 grid(erc_cdiv(M * P, 4), B);
+    hipLaunchKernelGGL(adj_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, COS, xhat, node_off, M, N, P, ADJ, CCOS, DEG);
+    ERC_LAUNCH_CHECK("mm_adj_rows");
+    hipLaunchKernelGGL(adj_scale_kernel, grid, dim3(256), 0, (hipStream_t)stream, CCOS, DEG, node_off, M, N, P, ADJ, CR);
+    ERC_LAUNCH_CHECK("mm_adj_scale");
     return ERC_OK;
 }
 extern "C" int erc_mm_adj_finish_bwd(const float* COS, const float* CCOS, const float* DEG, const float* dADJ,
                                      const float* dCR, const int32_t* node_off, int B, int M, int N, int P, float* G,
-                                     float* GC, void* stream) {
-    ERC_REQUIRE(COS && CCOS && DEG && dADJ && dCR && node_off && G && GC, "mm_adj_finish_bwd: null pointer");
+                                     float* GC, float* DD, void* stream) {
+    ERC_REQUIRE(COS && CCOS && DEG && dADJ && dCR && node_off && G && GC && DD, "mm_adj_finish_bwd: null pointer");
     ERC_REQUIRE(B > 0 && M >= 2 && M <= 3 && N > 0 && P > 0 && P <= MAXP, "mm_adj_finish_bwd: bad sizes");
-    hipLaunchKernelGGL(adj_finish_bwd_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, COS, CCOS, DEG, dADJ, dCR,
+    const dim3 grid(erc_cdiv(M * P, 4), B);
+    hipLaunchKernelGGL(adj_bwd_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, COS, CCOS, DEG, dADJ, dCR, node_off, M,
+                       N, P, DD);
+    ERC_LAUNCH_CHECK("mm_adj_bwd_rows");
+    hipLaunchKernelGGL(adj_bwd_entries_kernel, grid, dim3(256), 0, (hipStream_t)stream, COS, CCOS, DEG, DD, dADJ, dCR,
                        node_off, M, N, P, G, GC);
-    ERC_LAUNCH_CHECK("mm_adj_finish_bwd");
+    ERC_LAUNCH_CHECK("mm_adj_bwd_entries");
     return ERC_OK;
 }
 extern "C" int erc_mm_cross_apply(const float* CR, const float* h, int ldh, const int32_t* node_dlg, const int32_t* node_off,

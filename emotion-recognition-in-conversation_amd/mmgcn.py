@@ -143,7 +143,7 @@ class MMGCNModule(nn.Module):
         ws = dict(P=P, node_off=i32(B + 1), node_row=i32(N), node_dlg=i32(N), node_spk=i32(N),
                   LIN={m: f32(TB, FD) for m in self.order}, LO=f32(TB, FD), X=f32(R3, FD), XD=f32(R3, FD),
                   XH=f32(R3, FD), INV=f32(R3), COS=f32(B * Mo, P, P), ADJ=f32(B * Mo, P, P), CR=f32(B, Mo * Mo, P),
-                  CCOS=f32(B, Mo * Mo, P), DEG=f32(R3), H0=f32(R3, FD), Gt=f32(R3, FD),
+                  CCOS=f32(B, Mo * Mo, P), DEG=f32(R3), DDEG=f32(R3), H0=f32(R3, FD), Gt=f32(R3, FD),
                   HI=f32(NLAYERS + 1, R3, 2 * FD), HD=f32(NLAYERS + 2, R3, FD), FE=f32(N, Mo * 2 * FD), logits=f32(N, C),
                   stats=torch.zeros(256, dtype=torch.float32, device=device), dlogits=f32(N, C), dFE=f32(N, Mo * 2 * FD), dXD=f32(R3, FD), DH=f32(R3, FD),
                   dG=f32(NLAYERS + 1, R3, FD), dHIa=f32(NLAYERS + 1, R3, FD), dH0=f32(R3, FD),
@@ -353,7 +353,7 @@ class MMGCNModule(nn.Module):
         capi.axpy_mask(ws["dXD"], XD if p > 0 else None, n_el, ks, 0, dX)
         # through the adjacency into the features
         capi.mm_adj_finish_bwd(ws["COS"], ws["CCOS"], ws["DEG"], ws["dADJ"], ws["dCR"], ws["node_off"], B, Mo, N, P,
-                               ws["Gb"], ws["GC"])
+                               ws["Gb"], ws["GC"], ws["DDEG"])
         capi.gemm_grouped(0, ws["Gb"], P, ws["XH"], FD, ws["dXH"], FD, FD, ws["node_off"], B, Mo, N, T, P)
         capi.mm_cross_apply(ws["GC"], ws["XH"], FD, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dXH"], FD)
         capi.mm_row_normalize_bwd(ws["XH"], ws["INV"], ws["dXH"], R3, dX)

@@ -690,9 +690,11 @@ int erc_mm_row_normalize_bwd(const float* xhat, const float* inv, const float* d
  * same-utterance sims, degrees over the full row, D^-1/2 A D^-1/2 (mmgcn_models.py:604-644). */
 int erc_mm_adj_finish(const float* COS, const float* xhat, const int32_t* node_off, int B, int M, int N, int P,
                       float* ADJ, float* CR, float* CCOS, float* DEG, void* stream);
-/* its backward: G = dCOS + dCOS^T per block (dXhat_block = G Xhat by a form-0 grouped GEMM), GC per cross pair */
+/* its backward: G = dCOS + dCOS^T per block (dXhat_block = G Xhat by a form-0 grouped GEMM), GC per cross pair;
+ * DD [M*N] is scratch (the per-node degree gradients, written by the first of the two launches) */
 int erc_mm_adj_finish_bwd(const float* COS, const float* CCOS, const float* DEG, const float* dADJ, const float* dCR,
-                          const int32_t* node_off, int B, int M, int N, int P, float* G, float* GC, void* stream);
+                          const int32_t* node_off, int B, int M, int N, int P, float* G, float* GC, float* DD,
+                          void* stream);
 /* out[(m,i),:] += sum_{n != m} CR[b][m*M+n][p] h[(n,i),:] ;  dCR[b][m*M+n][p] += dhi[(m,i),:] . h[(n,i),:] */
 int erc_mm_cross_apply(const float* CR, const float* h, int ldh, const int32_t* node_dlg, const int32_t* node_off,
                        int M, int N, int P, float* out, int ldo, void* stream);
