@@ -95,6 +95,8 @@ _SIGS = {
     "erc_brgcn_bwd_source": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_transpose_batched": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "erc_lstm_set_stamps": (C.c_int, [_vp]),
+    "erc_brgcn_fwd_tile_slab_floats": (C.c_int64, [_i]),
+    "erc_brgcn_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_rrgcn_max_relations": (C.c_int, []),
     "erc_basis_compose": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "erc_basis_decompose": (C.c_int, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -559,6 +561,15 @@ def brgcn_bwd_source(dH, lddh, O, N, g, norm, att, nb, U):
     _check(lib().erc_brgcn_bwd_source(ptr(dH), lddh, O, N, ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]),
                                       ptr(g["out_eid"]), ptr(norm), ptr(att), nb, ptr(U), stream()),
            "erc_brgcn_bwd_source")
+
+
+def brgcn_fwd_tile_slab_floats(n):
+    return int(lib().erc_brgcn_fwd_tile_slab_floats(n))
+
+
+def brgcn_fwd_tile(x, ldx, F, O, N, g, norm, att, nb, basis, root, Z, slabs):
+    _check(lib().erc_brgcn_fwd_tile(ptr(x), ldx, F, O, N, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]), ptr(norm),
+                                    ptr(att), nb, ptr(basis), ptr(root), ptr(Z), ptr(slabs), stream()), "erc_brgcn_fwd_tile")
 
 
 def rrgcn_max_relations():

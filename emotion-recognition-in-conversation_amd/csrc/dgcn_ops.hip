@@ -363,6 +363,146 @@ __global__ __launch_bounds__(256) void brgcn_bwd_source_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------ basis RGCN forward as ONE tile launch
+// conv(x) = Z @ basis.view(30F, O) + x @ root + bias with F = 200, O = 100 was four launches: the aggregate (Z = 24 KB per
+// node to HBM), a split-K GEMM with K = 6000 on 16 x 32 wave tiles (4-byte weight-fragment loads), the root GEMM, the slab
+// reduce -- 72 us at N = 700.  Here a workgroup owns 16 nodes x 10 bases (blockIdx.y = basis group; group 2 also carries
+// the root term as an 11th block, Z_root = x): it aggregates its Z blocks into LDS (and to HBM for the weight gradient),
+// multiplies them by its 2000 (2200) rows of basis on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32), K split
+// over the 8 wavefronts, and leaves a [16, 100] partial in slab blockIdx.y; erc_slab_reduce adds the three slabs + bias.
+// Weight fragments are 16-byte loads: a lane's float4 = 4 neighbouring output columns of ONE k, used by 4 MFMAs whose
+// tiles interleave the columns (column 64 h + 4 n + j belongs to MFMA (h, j), lane column n).
+constexpr int TF = 200, TO = 100, TG = 10;      // features, outputs, bases per group
+constexpr int TKP = (TG + 1) * TF + 4;          // LDS row of the Z tile (10 blocks + root block), 16-byte multiple
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void brgcn_fwd_tile_kernel(const float* __restrict__ x, int ldx, int N,
+                                                             const int32_t* __restrict__ in_ptr,
+                                                             const int32_t* __restrict__ in_src,
+                                                             const int32_t* __restrict__ in_typ,
+                                                             const float* __restrict__ norm, const float* __restrict__ attw,
+                                                             const float* __restrict__ basis, const float* __restrict__ root,
+                                                             float* __restrict__ Z, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Zt = smem;                                    // [16][TKP]; later the 8 partial tiles [8][16][128]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i0 = blockIdx.x * 16, g = blockIdx.y;
+    const bool with_root = g == 2;
+    // ---- phase 1: Z[i, b, :] = sum_{e into i} norm_e att[type_e, b] x[src_e, :] for this group's bases, 2 nodes per wavefront
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int li = 2 * w + half, i = i0 + li;
+        float acc[TG][4];
+#pragma unroll
+        for (int b = 0; b < TG; ++b)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[b][u] = 0.f;
+        Lane4 self = {{0.f, 0.f, 0.f, 0.f}};
+        if (i < N) {      // uniform
+            const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
+            for (int w0 = e0; w0 < e1; w0 += 64) {
+                const int nwin = min(64, e1 - w0);
+                const int el = w0 + min(lane, nwin - 1);
+                const int my_src = in_src[el], my_typ = in_typ[el];
+                const float my_n = lane < nwin ? norm[el] : 0.f;
+                for (int base = 0; base < nwin; base += 4) {
+                    Lane4 xs[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) xs[u] = load4(x + (int64_t)__shfl(my_src, min(base + u, nwin - 1), 64) * ldx, TF, lane);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = __builtin_amdgcn_readfirstlane(__shfl(my_typ, min(base + u, 63), 64));
+                        const float ne = __shfl(my_n, min(base + u, 63), 64);      // 0 past the window
+                        const float* ar = attw + (int64_t)t * NB + g * TG;
+#pragma unroll
+                        for (int b = 0; b < TG; ++b) {
+                            const float c = ne * ar[b];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[b][q] += c * xs[u].v[q];
+                        }
+                    }
+                }
+            }
+            if (with_root) self = load4(x + (int64_t)i * ldx, TF, lane);
+        }
+        float* zr = Zt + li * TKP;
+        float* zg = Z + (int64_t)min(i, N - 1) * NB * TF + g * TG * TF;
+#pragma unroll
+        for (int b = 0; b < TG; ++b)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (lane + 64 * u < TF) {
+                    zr[b * TF + lane + 64 * u] = acc[b][u];
+                    if (i < N) zg[b * TF + lane + 64 * u] = acc[b][u];
+                }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (lane + 64 * u < TF) zr[TG * TF + lane + 64 * u] = self.v[u];
+    }
+    __syncthreads();
+    // ---- phase 2: partial[16, 100] = Zt[16, K] @ rows of [basis group ; root], K split over the wavefronts
+    const int nks = (with_root ? (TG + 1) * TF : TG * TF) / 4;          // k-steps of 4
+    const int per = (nks + 7) / 8, ks0 = w * per, ks1 = min(nks, ks0 + per);
+    const int r = lane & 15, kk = lane >> 4;
+    const float* bg = basis + (int64_t)g * TG * TF * TO;
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[h][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int c0 = 4 * r, c1 = 64 + 4 * r;              // the lane's 4 columns in the two column halves
+    const bool v1 = c1 < TO;                             // 64 + 4 r + 3 < 100  <=>  r < 9 (whole float4 inside)
+    const int c1c = v1 ? c1 : 0;
+    constexpr int PB = 4;                                // k-steps of weight fragments in flight
+    for (int ks = ks0; ks < ks1; ks += PB) {
+        float4 b0[PB], b1[PB];
+        float a[PB];
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int k = 4 * min(ks + u, ks1 - 1) + kk;
+            const float* brow = k < TG * TF ? bg + (int64_t)k * TO : root + (int64_t)(k - TG * TF) * TO;
+            b0[u] = *reinterpret_cast<const float4*>(brow + c0);
+            b1[u] = *reinterpret_cast<const float4*>(brow + c1c);
+            a[u] = Zt[r * TKP + k];
+        }
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const float av = ks + u < ks1 ? a[u] : 0.f;
+            const float m1 = v1 ? 1.f : 0.f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[u].y, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[u].z, acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[u].w, acc[0][3], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[u].x * m1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[u].y * m1, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[u].z * m1, acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[u].w * m1, acc[1][3], 0, 0, 0);
+        }
+    }
+    __syncthreads();            // every wavefront is done with the Z tile: its LDS becomes the partial tiles
+    // D of MFMA (h, j): lane holds rows 4 (lane >> 4) + i, i < 4, of tile column n = lane & 15 = output column 64 h + 4 n + j
+    float* red = smem + w * 16 * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(red + (4 * kk + i) * 128 + 64 * h + 4 * r) =
+                float4{acc[h][0][i], acc[h][1][i], acc[h][2][i], acc[h][3][i]};
+    __syncthreads();
+    // ---- phase 3: sum of the 8 partial tiles -> slab g (16 rows x 25 float4)
+    if (tid < 16 * 25) {
+        const int row = tid / 25, c4 = tid % 25;
+        float4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) {
+            const float4 v = *reinterpret_cast<const float4*>(smem + (ww * 16 + row) * 128 + 4 * c4);
+            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+        }
+        if (i0 + row < N)
+            *reinterpret_cast<float4*>(slabs + ((int64_t)g * N + i0 + row) * TO + 4 * c4) = sum;
+    }
+}
+
 // ------------------------------------------------------------------ basis RGCN in RELATION space (R <= 8)
 // With few relations (two speakers: R = 2 S^2 = 8 < 30 bases) the layer is cheaper the way models/rgcn.py:300-304 writes
 // it: W_r = sum_b comp[r,b] basis[b] first, then
@@ -672,6 +812,32 @@ extern "C" int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, con
     hipLaunchKernelGGL(brgcn_bwd_source_kernel, NODE_GRID(N), dH, lddh, O, N, out_ptr, out_dst, out_typ, out_eid, norm,
                        att, U);
     ERC_LAUNCH_CHECK("brgcn_bwd_source");
+    return ERC_OK;
+}
+
+// the three-slab workspace of erc_brgcn_fwd_tile (floats)
+extern "C" int64_t erc_brgcn_fwd_tile_slab_floats(int n_nodes) { return (int64_t)3 * n_nodes * TO; }
+
+extern "C" int erc_brgcn_fwd_tile(const float* x, int ldx, int F, int O, int N, const int32_t* in_ptr, const int32_t* in_src,
+                                  const int32_t* in_typ, const float* norm, const float* att, int num_bases,
+                                  const float* basis, const float* root, float* Z, float* slabs, void* stream) {
+    ERC_REQUIRE(x && in_ptr && in_src && in_typ && norm && att && basis && root && Z && slabs, "brgcn_fwd_tile: null pointer");
+    ERC_REQUIRE(num_bases == NB && F == TF && O == TO && N > 0 && ldx % 4 == 0,
+                "brgcn_fwd_tile: built for %d bases, F = %d, O = %d (got %d, %d, %d)", NB, TF, TO, num_bases, F, O);
+    ERC_REQUIRE(((uintptr_t)basis & 15) == 0 && ((uintptr_t)root & 15) == 0 && ((uintptr_t)slabs & 15) == 0,
+                "brgcn_fwd_tile: basis / root / slabs must be 16-byte aligned");
+    static bool attr_set = false;
+    const int lds = 16 * TKP * (int)sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)brgcn_fwd_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            erc_set_error("brgcn_fwd_tile: cannot reserve %d bytes of LDS", lds);
+            return ERC_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(brgcn_fwd_tile_kernel, dim3(erc_cdiv(N, 16), 3), dim3(512), lds, (hipStream_t)stream, x, ldx, N, in_ptr,
+                       in_src, in_typ, norm, att, basis, root, Z, slabs);
+    ERC_LAUNCH_CHECK("brgcn_fwd_tile");
     return ERC_OK;
 }
 

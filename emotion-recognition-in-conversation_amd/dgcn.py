@@ -84,6 +84,7 @@ class DGCNModule(nn.Module):
         # few relations (two speakers: 8 < 30 bases): RGCNConv in relation space, W_r composed first as models/rgcn.py:300-304
         # does (csrc/dgcn_ops.hip); None = decide in finalize() from the library's limit, True / False = forced (tests)
         self.relation_space = None
+        self.fused_rgcn_fwd = True      # basis space: aggregate + Z @ basis + x @ root as one tile launch (erc_brgcn_fwd_tile)
         self.drop_p = float(dropout)
         self.rnn = _SeqContext(input_size, hidden_size, dropout)
         self.edge_att = _EdgeAtt(hidden_size)
@@ -133,7 +134,8 @@ class DGCNModule(nn.Module):
                   dlogits=f32(N, C), dZc=f32(N, 100), dXc=f32(N, G_DIM + H1), dAGG=f32(N, H1), dHc=f32(N, H1),
                   dZ=f32(N, self._kb * G_DIM), dnorm=f32(E), TT=f32(E, NB), U=f32(N, self._kb * H1),
                   basisT=f32(self._kb * H1, G_DIM), Wr=f32(self._kb * G_DIM, H1), dWr=f32(self._kb * G_DIM, H1),
-                  DATT=f32(N, G_DIM), dscore=f32(E), drnn=f32(BT, G_DIM))
+                  DATT=f32(N, G_DIM), dscore=f32(E), drnn=f32(BT, G_DIM),
+                  rgcn_slabs=f32(capi.brgcn_fwd_tile_slab_floats(N)))
         D = self.input_size
         slab = 12 * N * H1 + 4 * BT * 800 + 10 * (800 * D + 800 * 200 + 2 * 400 * 100 * 2) + 4 * NB * G_DIM * H1 + \
             8 * (G_DIM * G_DIM + 300 * 100) + (1 << 21)
@@ -172,15 +174,22 @@ class DGCNModule(nn.Module):
             capi.rrgcn_agg_fwd(Xc, XW, G_DIM, N, self.R, g, ws["norm"], ws["Z"])
             Wz = ws["Wr"]
         else:
-            capi.brgcn_agg_fwd(Xc, XW, G_DIM, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["Z"])
             Wz = fp.w("gcn.conv1.basis")
-        K1 = self._kb * G_DIM
-        S1 = pl.split_for(N, H1, K1)
-        src = pl.take((S1 + 1) * N * H1)
-        capi.gemm_f32(ws["Z"], K1, 0, None, Wz, H1, 1, None, pl.ws[src:], H1, N, H1, K1,
-                      split_k=S1, c_slab=N * H1)
-        capi.gemm_f32(Xc, XW, 0, None, fp.w("gcn.conv1.root"), H1, 1, None, pl.ws[src + S1 * N * H1:], H1, N, H1, G_DIM)
-        capi.slab_reduce(pl.ws[src:], S1 + 1, N * H1, fp.w("gcn.conv1.bias"), H1, 0, ws["Hc"], N * H1)
+        if self.fused_rgcn_fwd and not self.relation_space:
+            # aggregate + basis product + root product in one tile launch (csrc/dgcn_ops.hip), three partial slabs
+            capi.brgcn_fwd_tile(Xc, XW, G_DIM, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, Wz, fp.w("gcn.conv1.root"),
+                                ws["Z"], ws["rgcn_slabs"])
+            capi.slab_reduce(ws["rgcn_slabs"], 3, N * H1, fp.w("gcn.conv1.bias"), H1, 0, ws["Hc"], N * H1)
+        else:
+            if not self.relation_space:
+                capi.brgcn_agg_fwd(Xc, XW, G_DIM, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["Z"])
+            K1 = self._kb * G_DIM
+            S1 = pl.split_for(N, H1, K1)
+            src = pl.take((S1 + 1) * N * H1)
+            capi.gemm_f32(ws["Z"], K1, 0, None, Wz, H1, 1, None, pl.ws[src:], H1, N, H1, K1,
+                          split_k=S1, c_slab=N * H1)
+            capi.gemm_f32(Xc, XW, 0, None, fp.w("gcn.conv1.root"), H1, 1, None, pl.ws[src + S1 * N * H1:], H1, N, H1, G_DIM)
+            capi.slab_reduce(pl.ws[src:], S1 + 1, N * H1, fp.w("gcn.conv1.bias"), H1, 0, ws["Hc"], N * H1)
         # GraphConv: W_rel * sum_{j->i} h_j + b + W_root h_i, written next to the features
         capi.csr_sum(ws["Hc"], H1, H1, N, g["in_ptr"], g["in_src"], ws["AGG"], H1)
         gout = Xc[:, G_DIM:]

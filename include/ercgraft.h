@@ -620,6 +620,14 @@ int erc_brgcn_bwd_edges(const float* x, int ldx, int F, int N, int R, const int3
 int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, const int32_t* out_ptr, const int32_t* out_dst,
                          const int32_t* out_typ, const int32_t* out_eid, const float* norm, const float* att,
                          int num_bases, float* U, void* stream);
+/* The forward of the layer as ONE tile launch (F = 200, O = 100, 30 bases: dgcn_models.py:41-45): 16 nodes x 10 bases per
+ * workgroup, Z blocks aggregated into LDS (and written to Z [N, 30F] for the weight gradient), multiplied by the basis
+ * rows on the fp32 matrix cores; the root term rides along as an 11th block of basis group 2.  Leaves three partial
+ * [N, O] slabs (erc_brgcn_fwd_tile_slab_floats): conv(x) = erc_slab_reduce(slabs, 3, N*O, bias). */
+int64_t erc_brgcn_fwd_tile_slab_floats(int n_nodes);
+int erc_brgcn_fwd_tile(const float* x, int ldx, int F, int O, int N, const int32_t* in_ptr, const int32_t* in_src,
+                       const int32_t* in_typ, const float* norm, const float* att, int num_bases, const float* basis,
+                       const float* root, float* Z, float* slabs, void* stream);
 /* The same layer in RELATION space, for R <= erc_rrgcn_max_relations() (= 8: two speakers).  models/rgcn.py:300-304 composes
  * W_r = sum_b comp[r,b] basis[b] and transforms per relation; with R < num_bases that order is also the cheaper one:
  *   erc_basis_compose:   Wr [R,F,O] and its per-relation transpose WrT [R,O,F]

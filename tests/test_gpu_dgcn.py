@@ -137,6 +137,46 @@ def test_relation_space_rgcn_vs_reference_golden(golden):
                            ("conv1.root", droot), ("conv1.bias", dbias)], tol=2e-3)
 
 
+@pytest.mark.parametrize("name", ["dgcn_s2", "dgcn_s9"])
+def test_fused_rgcn_forward_tile_vs_unfused_and_reference_golden(golden, name):
+    """erc_brgcn_fwd_tile (aggregate + basis product + root product in one launch, fp32 matrix cores) against the unfused
+    kernels on the reference fixture's graph, and against the fixture's own RGCN output."""
+    from erc_amd import capi
+    from erc_amd.cogmen import build_graph_tensors
+    fx = golden(name)
+    S, R, NB, Fd, O = int(fx["n_speakers"]), 2 * int(fx["n_speakers"]) ** 2, 30, 200, 100
+    lengths, spk = torch.from_numpy(fx["lengths"]).to(DEV), torch.from_numpy(fx["speakers"]).to(DEV)
+    feats = torch.from_numpy(fx["features"])
+    B, T = feats.shape[:2]
+    g, _, _ = build_graph_tensors(lengths, spk, 10, 10, S)
+    N, E = g["counts"].cpu().tolist()
+    att_w = torch.nn.Module(); att_w.weight = torch.nn.Parameter(torch.zeros(Fd, Fd)); fill_params(att_w, int(fx["att_seed"]))
+    conv = torch.nn.Module()
+    conv.basis, conv.att = torch.nn.Parameter(torch.zeros(NB, Fd, O)), torch.nn.Parameter(torch.zeros(R, NB))
+    conv.root, conv.bias = torch.nn.Parameter(torch.zeros(Fd, O)), torch.nn.Parameter(torch.zeros(O))
+    fill_params(conv, int(fx["conv_seed"]))
+    W, basis, attp, root, bias = [t.detach().to(DEV) for t in (att_w.weight, conv.basis, conv.att, conv.root, conv.bias)]
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    XW = Fd + O                                  # the module's row pitch: features next to the graph output
+    xw = z(N, XW)
+    capi.gather_rows(feats.to(DEV).view(B * T, Fd), Fd, g["node_row"], N, Fd, xw, XW)
+    ATT, norm = z(N, Fd), z(E)
+    capi.gemm_f32(xw, XW, 0, None, W, Fd, 0, None, ATT, Fd, N, Fd, Fd)
+    capi.edge_att_fwd(xw, XW, ATT, Fd, Fd, N, g, norm)
+    Z_ref = z(N, NB * Fd)
+    capi.brgcn_agg_fwd(xw, XW, Fd, N, g, norm, attp, NB, Z_ref)
+    out_ref = z(N, O)
+    capi.gemm_f32(Z_ref, NB * Fd, 0, None, basis, O, 1, None, out_ref, O, N, O, NB * Fd, bias=bias)
+    capi.gemm_f32(xw, XW, 0, None, root, O, 1, None, out_ref, O, N, O, Fd, accumulate=1)
+    Zt, slabs, out = torch.full((N, NB * Fd), float("nan"), device=DEV), torch.full((3, N, O), float("nan"), device=DEV), z(N, O)
+    capi.poison_lds()
+    capi.brgcn_fwd_tile(xw, XW, Fd, O, N, g, norm, attp, NB, basis, root, Zt, slabs)
+    capi.slab_reduce(slabs, 3, N * O, bias, O, 0, out, N * O)
+    assert torch.equal(Zt, Z_ref)                # the same per-edge multiply-adds in the same order
+    assert float((out - out_ref).abs().max()) < 2e-5 * max(1.0, float(out_ref.abs().max()))
+    np.testing.assert_allclose(out.cpu().numpy(), fx["rgcn_out"], atol=1e-4, rtol=1e-4)
+
+
 def test_dgcn_relation_space_equals_basis_space():
     """Same module, same batch: RGCNConv in relation space (the default for two speakers) vs basis space."""
     from erc_amd.dgcn import DGCNModule
