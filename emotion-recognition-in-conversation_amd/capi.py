@@ -96,6 +96,8 @@ _SIGS = {
     "erc_transpose_batched": (C.c_int, [_vp, _i, _i, _i, _vp, _vp]),
     "erc_lstm_set_stamps": (C.c_int, [_vp]),
     "erc_brgcn_fwd_tile_slab_floats": (C.c_int64, [_i]),
+    "erc_brgcn_set_stamps": (C.c_int, [_vp]),
+    "erc_brgcn_fwd_tile_slabs": (C.c_int, []),
     "erc_brgcn_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_rrgcn_max_relations": (C.c_int, []),
     "erc_basis_compose": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -561,6 +563,14 @@ def brgcn_bwd_source(dH, lddh, O, N, g, norm, att, nb, U):
     _check(lib().erc_brgcn_bwd_source(ptr(dH), lddh, O, N, ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]),
                                       ptr(g["out_eid"]), ptr(norm), ptr(att), nb, ptr(U), stream()),
            "erc_brgcn_bwd_source")
+
+
+def brgcn_set_stamps(t):
+    _check(lib().erc_brgcn_set_stamps(ptr(t)), "erc_brgcn_set_stamps")
+
+
+def brgcn_fwd_tile_slabs():
+    return int(lib().erc_brgcn_fwd_tile_slabs())
 
 
 def brgcn_fwd_tile_slab_floats(n):

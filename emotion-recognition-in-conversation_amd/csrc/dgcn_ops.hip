@@ -366,15 +366,23 @@ __global__ __launch_bounds__(256) void brgcn_bwd_source_kernel(const float* __re
 // ------------------------------------------------------------------ basis RGCN forward as ONE tile launch
 // conv(x) = Z @ basis.view(30F, O) + x @ root + bias with F = 200, O = 100 was four launches: the aggregate (Z = 24 KB per
 // node to HBM), a split-K GEMM with K = 6000 on 16 x 32 wave tiles (4-byte weight-fragment loads), the root GEMM, the slab
-// reduce -- 72 us at N = 700.  Here a workgroup owns 16 nodes x 10 bases (blockIdx.y = basis group; group 2 also carries
-// the root term as an 11th block, Z_root = x): it aggregates its Z blocks into LDS (and to HBM for the weight gradient),
-// multiplies them by its 2000 (2200) rows of basis on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32), K split
-// over the 8 wavefronts, and leaves a [16, 100] partial in slab blockIdx.y; erc_slab_reduce adds the three slabs + bias.
+// reduce -- 72 us at N = 700.  Here a workgroup owns 16 nodes x 5 bases (blockIdx.y = basis group; the last group also
+// carries the root term as a 6th block, Z_root = x): it aggregates its Z blocks into LDS (and to HBM for the weight
+// gradient), multiplies them by its 1000 (1200) rows of basis on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32),
+// K split over the 8 wavefronts, and leaves a [16, 100] partial in slab blockIdx.y; erc_slab_reduce adds the slabs + bias.
+// (The product is matrix-core bound -- 16 x 128 x 6200 MACs per tile at 256 per cycle and CU -- so the groups are sized to
+// put the layer on the whole chip: 10-basis groups used 132 CUs and took 20 us for it, the aggregate another 23.)
 // Weight fragments are 16-byte loads: a lane's float4 = 4 neighbouring output columns of ONE k, used by 4 MFMAs whose
 // tiles interleave the columns (column 64 h + 4 n + j belongs to MFMA (h, j), lane column n).
-constexpr int TF = 200, TO = 100, TG = 10;      // features, outputs, bases per group
+constexpr int TF = 200, TO = 100, TG = 5, NGRP = NB / TG;      // features, outputs, bases per group, groups
 constexpr int TKP = (TG + 1) * TF + 4;          // LDS row of the Z tile (10 blocks + root block), 16-byte multiple
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+unsigned long long* g_brgcn_stamps = nullptr;      // diagnostic: 100 MHz stamps of one workgroup (erc_brgcn_set_stamps)
+#define BR_STAMP(slot)                                                                                              \
+    do {                                                                                                            \
+        if (stamps && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y - 1 && threadIdx.x == 0)                           \
+            stamps[slot] = __builtin_amdgcn_s_memrealtime();                                                        \
+    } while (0)
 
 __global__ __launch_bounds__(512) void brgcn_fwd_tile_kernel(const float* __restrict__ x, int ldx, int N,
                                                              const int32_t* __restrict__ in_ptr,
@@ -382,64 +390,85 @@ __global__ __launch_bounds__(512) void brgcn_fwd_tile_kernel(const float* __rest
                                                              const int32_t* __restrict__ in_typ,
                                                              const float* __restrict__ norm, const float* __restrict__ attw,
                                                              const float* __restrict__ basis, const float* __restrict__ root,
-                                                             float* __restrict__ Z, float* __restrict__ slabs) {
+                                                             float* __restrict__ Z, float* __restrict__ slabs,
+                                                             unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BR_STAMP(0);
     float* Zt = smem;                                    // [16][TKP]; later the 8 partial tiles [8][16][128]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i0 = blockIdx.x * 16, g = blockIdx.y;
-    const bool with_root = g == 2;
-    // ---- phase 1: Z[i, b, :] = sum_{e into i} norm_e att[type_e, b] x[src_e, :] for this group's bases, 2 nodes per wavefront
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const int li = 2 * w + half, i = i0 + li;
-        float acc[TG][4];
+    const bool with_root = g == NGRP - 1;
+    // ---- phase 1: Z[i, b, :] = sum_{e into i} norm_e att[type_e, b] x[src_e, :] for this group's bases.  A wavefront
+    // advances its two nodes together (8 source rows in flight); an edge's 5 coefficients norm_e att[type_e, b] are computed
+    // by the lane that holds the edge's metadata and read with v_readlane: no memory operation per edge but the source row.
+    {
+        const int liA = 2 * w, liB = 2 * w + 1, iA = i0 + liA, iB = i0 + liB;
+        float accA[TG][4], accB[TG][4];
 #pragma unroll
         for (int b = 0; b < TG; ++b)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[b][u] = 0.f;
-        Lane4 self = {{0.f, 0.f, 0.f, 0.f}};
-        if (i < N) {      // uniform
-            const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
-            for (int w0 = e0; w0 < e1; w0 += 64) {
-                const int nwin = min(64, e1 - w0);
-                const int el = w0 + min(lane, nwin - 1);
-                const int my_src = in_src[el], my_typ = in_typ[el];
-                const float my_n = lane < nwin ? norm[el] : 0.f;
-                for (int base = 0; base < nwin; base += 4) {
-                    Lane4 xs[4];
+            for (int u = 0; u < 4; ++u) accA[b][u] = accB[b][u] = 0.f;
+        int eA0 = 0, eA1 = 0, eB0 = 0, eB1 = 0;
+        if (iA < N) eA0 = in_ptr[iA], eA1 = in_ptr[iA + 1];
+        if (iB < N) eB0 = in_ptr[iB], eB1 = in_ptr[iB + 1];
+        const int dmax = max(eA1 - eA0, eB1 - eB0);
+        auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+        for (int wo = 0; wo < dmax; wo += 64) {
+            const int nA = min(64, max(eA1 - eA0 - wo, 0)), nB = min(64, max(eB1 - eB0 - wo, 0));
+            const int elA = nA > 0 ? eA0 + wo + min(lane, nA - 1) : 0, elB = nB > 0 ? eB0 + wo + min(lane, nB - 1) : 0;
+            const int srcA = in_src[elA], srcB = in_src[elB];
+            const float nrA = lane < nA ? norm[elA] : 0.f, nrB = lane < nB ? norm[elB] : 0.f;
+            const float* arA = attw + (int64_t)in_typ[elA] * NB + g * TG;
+            const float* arB = attw + (int64_t)in_typ[elB] * NB + g * TG;
+            float cfA[TG], cfB[TG];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) xs[u] = load4(x + (int64_t)__shfl(my_src, min(base + u, nwin - 1), 64) * ldx, TF, lane);
+            for (int b = 0; b < TG; ++b) cfA[b] = nrA * arA[b], cfB[b] = nrB * arB[b];
+            const int nmax = max(nA, nB);
+            for (int base = 0; base < nmax; base += 4) {
+                Lane4 xa[4], xb[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int t = __builtin_amdgcn_readfirstlane(__shfl(my_typ, min(base + u, 63), 64));
-                        const float ne = __shfl(my_n, min(base + u, 63), 64);      // 0 past the window
-                        const float* ar = attw + (int64_t)t * NB + g * TG;
+                for (int u = 0; u < 4; ++u) {
+                    const int ja = __builtin_amdgcn_readlane(srcA, min(base + u, max(nA - 1, 0)));
+                    const int jb = __builtin_amdgcn_readlane(srcB, min(base + u, max(nB - 1, 0)));
+                    xa[u] = load4(x + (int64_t)ja * ldx, TF, lane);
+                    xb[u] = load4(x + (int64_t)jb * ldx, TF, lane);
+                }
 #pragma unroll
-                        for (int b = 0; b < TG; ++b) {
-                            const float c = ne * ar[b];
+                for (int u = 0; u < 4; ++u) {
+                    const int l = min(base + u, 63);       // lanes past a node's window hold coefficient 0
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[b][q] += c * xs[u].v[q];
-                        }
+                    for (int b = 0; b < TG; ++b) {
+                        const float ca = rl(cfA[b], l), cb = rl(cfB[b], l);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) accA[b][q] += ca * xa[u].v[q], accB[b][q] += cb * xb[u].v[q];
                     }
                 }
             }
-            if (with_root) self = load4(x + (int64_t)i * ldx, TF, lane);
         }
-        float* zr = Zt + li * TKP;
-        float* zg = Z + (int64_t)min(i, N - 1) * NB * TF + g * TG * TF;
+        Lane4 selfA = {{0.f, 0.f, 0.f, 0.f}}, selfB = {{0.f, 0.f, 0.f, 0.f}};
+        if (with_root && iA < N) selfA = load4(x + (int64_t)iA * ldx, TF, lane);
+        if (with_root && iB < N) selfB = load4(x + (int64_t)iB * ldx, TF, lane);
+        float* zrA = Zt + liA * TKP;
+        float* zrB = Zt + liB * TKP;
+        float* zgA = Z + (int64_t)min(iA, N - 1) * NB * TF + g * TG * TF;
+        float* zgB = Z + (int64_t)min(iB, N - 1) * NB * TF + g * TG * TF;
 #pragma unroll
         for (int b = 0; b < TG; ++b)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (lane + 64 * u < TF) {
-                    zr[b * TF + lane + 64 * u] = acc[b][u];
-                    if (i < N) zg[b * TF + lane + 64 * u] = acc[b][u];
+                    zrA[b * TF + lane + 64 * u] = accA[b][u];
+                    zrB[b * TF + lane + 64 * u] = accB[b][u];
+                    if (iA < N) zgA[b * TF + lane + 64 * u] = accA[b][u];
+                    if (iB < N) zgB[b * TF + lane + 64 * u] = accB[b][u];
                 }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (lane + 64 * u < TF) zr[TG * TF + lane + 64 * u] = self.v[u];
+            if (lane + 64 * u < TF) zrA[TG * TF + lane + 64 * u] = selfA.v[u], zrB[TG * TF + lane + 64 * u] = selfB.v[u];
     }
+    BR_STAMP(1);
     __syncthreads();
+    BR_STAMP(2);
     // ---- phase 2: partial[16, 100] = Zt[16, K] @ rows of [basis group ; root], K split over the wavefronts
     const int nks = (with_root ? (TG + 1) * TF : TG * TF) / 4;          // k-steps of 4
     const int per = (nks + 7) / 8, ks0 = w * per, ks1 = min(nks, ks0 + per);
@@ -453,33 +482,46 @@ __global__ __launch_bounds__(512) void brgcn_fwd_tile_kernel(const float* __rest
     const int c0 = 4 * r, c1 = 64 + 4 * r;              // the lane's 4 columns in the two column halves
     const bool v1 = c1 < TO;                             // 64 + 4 r + 3 < 100  <=>  r < 9 (whole float4 inside)
     const int c1c = v1 ? c1 : 0;
-    constexpr int PB = 4;                                // k-steps of weight fragments in flight
-    for (int ks = ks0; ks < ks1; ks += PB) {
-        float4 b0[PB], b1[PB];
-        float a[PB];
+    constexpr int PB = 8;      // k-steps per batch; two batches in flight (the stream is latency-bound: 63 k-steps per wavefront)
+    struct Batch { float4 b0[PB], b1[PB]; float a[PB]; };
+    auto fetch = [&](int ks, Batch& t) {
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
             const int k = 4 * min(ks + u, ks1 - 1) + kk;
             const float* brow = k < TG * TF ? bg + (int64_t)k * TO : root + (int64_t)(k - TG * TF) * TO;
-            b0[u] = *reinterpret_cast<const float4*>(brow + c0);
-            b1[u] = *reinterpret_cast<const float4*>(brow + c1c);
-            a[u] = Zt[r * TKP + k];
+            t.b0[u] = *reinterpret_cast<const float4*>(brow + c0);
+            t.b1[u] = *reinterpret_cast<const float4*>(brow + c1c);
+            t.a[u] = Zt[r * TKP + k];
         }
+    };
+    const float m1 = v1 ? 1.f : 0.f;
+    auto consume = [&](int ks, const Batch& t) {
 #pragma unroll
         for (int u = 0; u < PB; ++u) {
-            const float av = ks + u < ks1 ? a[u] : 0.f;
-            const float m1 = v1 ? 1.f : 0.f;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[u].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[u].y, acc[0][1], 0, 0, 0);
-            acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[u].z, acc[0][2], 0, 0, 0);
-            acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0[u].w, acc[0][3], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[u].x * m1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[u].y * m1, acc[1][1], 0, 0, 0);
-            acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[u].z * m1, acc[1][2], 0, 0, 0);
-            acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1[u].w * m1, acc[1][3], 0, 0, 0);
+            const float av = ks + u < ks1 ? t.a[u] : 0.f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, t.b0[u].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, t.b0[u].y, acc[0][1], 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, t.b0[u].z, acc[0][2], 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, t.b0[u].w, acc[0][3], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, t.b1[u].x * m1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, t.b1[u].y * m1, acc[1][1], 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, t.b1[u].z * m1, acc[1][2], 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, t.b1[u].w * m1, acc[1][3], 0, 0, 0);
+        }
+    };
+    Batch tA, tB;
+    if (ks0 < ks1) fetch(ks0, tA);
+    for (int ks = ks0; ks < ks1; ks += 2 * PB) {
+        if (ks + PB < ks1) fetch(ks + PB, tB);
+        consume(ks, tA);
+        if (ks + PB < ks1) {
+            if (ks + 2 * PB < ks1) fetch(ks + 2 * PB, tA);
+            consume(ks + PB, tB);
         }
     }
+    BR_STAMP(3);
     __syncthreads();            // every wavefront is done with the Z tile: its LDS becomes the partial tiles
+    BR_STAMP(4);
     // D of MFMA (h, j): lane holds rows 4 (lane >> 4) + i, i < 4, of tile column n = lane & 15 = output column 64 h + 4 n + j
     float* red = smem + w * 16 * 128;
 #pragma unroll
@@ -501,6 +543,7 @@ __global__ __launch_bounds__(512) void brgcn_fwd_tile_kernel(const float* __rest
         if (i0 + row < N)
             *reinterpret_cast<float4*>(slabs + ((int64_t)g * N + i0 + row) * TO + 4 * c4) = sum;
     }
+    BR_STAMP(5);
 }
 
 // ------------------------------------------------------------------ basis RGCN in RELATION space (R <= 8)
@@ -815,8 +858,15 @@ extern "C" int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, con
     return ERC_OK;
 }
 
-// the three-slab workspace of erc_brgcn_fwd_tile (floats)
-extern "C" int64_t erc_brgcn_fwd_tile_slab_floats(int n_nodes) { return (int64_t)3 * n_nodes * TO; }
+// diagnostic: 6 x uint64 phase stamps (10 ns ticks) of the middle tile's workgroup of basis group 2; nullptr = off
+extern "C" int erc_brgcn_set_stamps(unsigned long long* stamps) {
+    g_brgcn_stamps = stamps;
+    return ERC_OK;
+}
+
+// the slab workspace of erc_brgcn_fwd_tile (floats) and its number of slabs
+extern "C" int64_t erc_brgcn_fwd_tile_slab_floats(int n_nodes) { return (int64_t)NGRP * n_nodes * TO; }
+extern "C" int erc_brgcn_fwd_tile_slabs(void) { return NGRP; }
 
 extern "C" int erc_brgcn_fwd_tile(const float* x, int ldx, int F, int O, int N, const int32_t* in_ptr, const int32_t* in_src,
                                   const int32_t* in_typ, const float* norm, const float* att, int num_bases,
@@ -835,8 +885,8 @@ extern "C" int erc_brgcn_fwd_tile(const float* x, int ldx, int F, int O, int N, 
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(brgcn_fwd_tile_kernel, dim3(erc_cdiv(N, 16), 3), dim3(512), lds, (hipStream_t)stream, x, ldx, N, in_ptr,
-                       in_src, in_typ, norm, att, basis, root, Z, slabs);
+    hipLaunchKernelGGL(brgcn_fwd_tile_kernel, dim3(erc_cdiv(N, 16), NGRP), dim3(512), lds, (hipStream_t)stream, x, ldx, N, in_ptr,
+                       in_src, in_typ, norm, att, basis, root, Z, slabs, g_brgcn_stamps);
     ERC_LAUNCH_CHECK("brgcn_fwd_tile");
     return ERC_OK;
 }

@@ -176,10 +176,11 @@ class DGCNModule(nn.Module):
         else:
             Wz = fp.w("gcn.conv1.basis")
         if self.fused_rgcn_fwd and not self.relation_space:
-            # aggregate + basis product + root product in one tile launch (csrc/dgcn_ops.hip), three partial slabs
+            # aggregate + basis product + root product in one tile launch (csrc/dgcn_ops.hip), partial slabs
             capi.brgcn_fwd_tile(Xc, XW, G_DIM, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, Wz, fp.w("gcn.conv1.root"),
                                 ws["Z"], ws["rgcn_slabs"])
-            capi.slab_reduce(ws["rgcn_slabs"], 3, N * H1, fp.w("gcn.conv1.bias"), H1, 0, ws["Hc"], N * H1)
+            capi.slab_reduce(ws["rgcn_slabs"], capi.brgcn_fwd_tile_slabs(), N * H1, fp.w("gcn.conv1.bias"), H1, 0, ws["Hc"],
+                             N * H1)
         else:
             if not self.relation_space:
                 capi.brgcn_agg_fwd(Xc, XW, G_DIM, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["Z"])

@@ -620,11 +620,13 @@ int erc_brgcn_bwd_edges(const float* x, int ldx, int F, int N, int R, const int3
 int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, const int32_t* out_ptr, const int32_t* out_dst,
                          const int32_t* out_typ, const int32_t* out_eid, const float* norm, const float* att,
                          int num_bases, float* U, void* stream);
-/* The forward of the layer as ONE tile launch (F = 200, O = 100, 30 bases: dgcn_models.py:41-45): 16 nodes x 10 bases per
+/* The forward of the layer as ONE tile launch (F = 200, O = 100, 30 bases: dgcn_models.py:41-45): 16 nodes x 5 bases per
  * workgroup, Z blocks aggregated into LDS (and written to Z [N, 30F] for the weight gradient), multiplied by the basis
- * rows on the fp32 matrix cores; the root term rides along as an 11th block of basis group 2.  Leaves three partial
- * [N, O] slabs (erc_brgcn_fwd_tile_slab_floats): conv(x) = erc_slab_reduce(slabs, 3, N*O, bias). */
+ * rows on the fp32 matrix cores; the root term rides along as a 6th block of the last basis group.  Leaves
+ * S = erc_brgcn_fwd_tile_slabs() partial [N, O] slabs: conv(x) = erc_slab_reduce(slabs, S, N*O, bias). */
 int64_t erc_brgcn_fwd_tile_slab_floats(int n_nodes);
+int erc_brgcn_fwd_tile_slabs(void);
+int erc_brgcn_set_stamps(unsigned long long* stamps);   /* diagnostic: 6 x uint64 phase stamps (10 ns ticks); NULL = off */
 int erc_brgcn_fwd_tile(const float* x, int ldx, int F, int O, int N, const int32_t* in_ptr, const int32_t* in_src,
                        const int32_t* in_typ, const float* norm, const float* att, int num_bases, const float* basis,
                        const float* root, float* Z, float* slabs, void* stream);

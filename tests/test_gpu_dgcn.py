@@ -168,10 +168,10 @@ def test_fused_rgcn_forward_tile_vs_unfused_and_reference_golden(golden, name):
     out_ref = z(N, O)
     capi.gemm_f32(Z_ref, NB * Fd, 0, None, basis, O, 1, None, out_ref, O, N, O, NB * Fd, bias=bias)
     capi.gemm_f32(xw, XW, 0, None, root, O, 1, None, out_ref, O, N, O, Fd, accumulate=1)
-    Zt, slabs, out = torch.full((N, NB * Fd), float("nan"), device=DEV), torch.full((3, N, O), float("nan"), device=DEV), z(N, O)
+    Zt, slabs, out = torch.full((N, NB * Fd), float("nan"), device=DEV), torch.full((capi.brgcn_fwd_tile_slabs(), N, O), float("nan"), device=DEV), z(N, O)
     capi.poison_lds()
     capi.brgcn_fwd_tile(xw, XW, Fd, O, N, g, norm, attp, NB, basis, root, Zt, slabs)
-    capi.slab_reduce(slabs, 3, N * O, bias, O, 0, out, N * O)
+    capi.slab_reduce(slabs, capi.brgcn_fwd_tile_slabs(), N * O, bias, O, 0, out, N * O)
     assert torch.equal(Zt, Z_ref)                # the same per-edge multiply-adds in the same order
     assert float((out - out_ref).abs().max()) < 2e-5 * max(1.0, float(out_ref.abs().max()))
     np.testing.assert_allclose(out.cpu().numpy(), fx["rgcn_out"], atol=1e-4, rtol=1e-4)
