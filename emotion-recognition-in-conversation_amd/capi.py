@@ -98,6 +98,7 @@ _SIGS = {
     "erc_brgcn_fwd_tile_slab_floats": (C.c_int64, [_i]),
     "erc_brgcn_set_stamps": (C.c_int, [_vp]),
     "erc_brgcn_fwd_tile_slabs": (C.c_int, []),
+    "erc_brgcn_bwd_source_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "erc_brgcn_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_rrgcn_max_relations": (C.c_int, []),
     "erc_basis_compose": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -567,6 +568,12 @@ def brgcn_bwd_source(dH, lddh, O, N, g, norm, att, nb, U):
 
 def brgcn_set_stamps(t):
     _check(lib().erc_brgcn_set_stamps(ptr(t)), "erc_brgcn_set_stamps")
+
+
+def brgcn_bwd_source_tile(dH, lddh, F, O, N, g, norm, att, nb, basis, root, slabs):
+    _check(lib().erc_brgcn_bwd_source_tile(ptr(dH), lddh, F, O, N, ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]),
+                                           ptr(g["out_eid"]), ptr(norm), ptr(att), nb, ptr(basis), ptr(root), ptr(slabs),
+                                           stream()), "erc_brgcn_bwd_source_tile")
 
 
 def brgcn_fwd_tile_slabs():

@@ -546,6 +546,140 @@ __global__ __launch_bounds__(512) void brgcn_fwd_tile_kernel(const float* __rest
     BR_STAMP(5);
 }
 
+// The node side of the backward the same way: dx[j, :] = sum_b U[j, b, :] basis[b]^T + dOut[j, :] root^T with
+// U[j, b, :] = sum_{e out of j} norm_e att[type_e, b] dOut[dst_e, :].  K = (b, c) runs along the CONTIGUOUS index of
+// basis [30, F, O], so a lane's float4 is 4 consecutive k of one output column f: the matrix core sums over k whatever
+// slot a k sits in, so MFMA step j of a 16-k block takes element j of the float4 on both operands (A rows from LDS the
+// same way) and no transposed copy of basis is needed.
+constexpr int SKB = TG * TO, SKR = SKB + TO;          // k of a group (500), with the root block (600)
+constexpr int SKP = 608 + 4;                           // LDS row: K padded to a multiple of 16 (zeros) + 4
+constexpr int SNT = 13;                                // 16-column tiles over F = 200 (208)
+
+__global__ __launch_bounds__(512) void brgcn_bwd_source_tile_kernel(const float* __restrict__ dH, int lddh, int N,
+                                                                    const int32_t* __restrict__ out_ptr,
+                                                                    const int32_t* __restrict__ out_dst,
+                                                                    const int32_t* __restrict__ out_typ,
+                                                                    const int32_t* __restrict__ out_eid,
+                                                                    const float* __restrict__ norm,
+                                                                    const float* __restrict__ attw,
+                                                                    const float* __restrict__ basis,
+                                                                    const float* __restrict__ root, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ut = smem;                                    // [16][SKP]; later the 8 partial tiles [8][16][208]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * 16, g = blockIdx.y;
+    const bool with_root = g == NGRP - 1;
+    const int c0 = min(lane, TO - 1), c1 = min(lane + 64, TO - 1);
+    const float m0 = lane < TO ? 1.f : 0.f, m1 = lane + 64 < TO ? 1.f : 0.f;
+    // ---- phase 1: the U blocks of this group, two nodes per wavefront advanced together
+    {
+        const int liA = 2 * w, liB = 2 * w + 1, jA = j0 + liA, jB = j0 + liB;
+        float accA[TG][2], accB[TG][2];
+#pragma unroll
+        for (int b = 0; b < TG; ++b) accA[b][0] = accA[b][1] = accB[b][0] = accB[b][1] = 0.f;
+        int eA0 = 0, eA1 = 0, eB0 = 0, eB1 = 0;
+        if (jA < N) eA0 = out_ptr[jA], eA1 = out_ptr[jA + 1];
+        if (jB < N) eB0 = out_ptr[jB], eB1 = out_ptr[jB + 1];
+        const int dmax = max(eA1 - eA0, eB1 - eB0);
+        auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+        for (int wo = 0; wo < dmax; wo += 64) {
+            const int nA = min(64, max(eA1 - eA0 - wo, 0)), nB = min(64, max(eB1 - eB0 - wo, 0));
+            const int elA = nA > 0 ? eA0 + wo + min(lane, nA - 1) : 0, elB = nB > 0 ? eB0 + wo + min(lane, nB - 1) : 0;
+            const int dstA = out_dst[elA], dstB = out_dst[elB];
+            const float nrA = lane < nA ? norm[out_eid[elA]] : 0.f, nrB = lane < nB ? norm[out_eid[elB]] : 0.f;
+            const float* arA = attw + (int64_t)out_typ[elA] * NB + g * TG;
+            const float* arB = attw + (int64_t)out_typ[elB] * NB + g * TG;
+            float cfA[TG], cfB[TG];
+#pragma unroll
+            for (int b = 0; b < TG; ++b) cfA[b] = nrA * arA[b], cfB[b] = nrB * arB[b];
+            const int nmax = max(nA, nB);
+            for (int base = 0; base < nmax; base += 4) {
+                float ga[4][2], gb[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* ra = dH + (int64_t)__builtin_amdgcn_readlane(dstA, min(base + u, max(nA - 1, 0))) * lddh;
+                    const float* rb = dH + (int64_t)__builtin_amdgcn_readlane(dstB, min(base + u, max(nB - 1, 0))) * lddh;
+                    ga[u][0] = ra[c0] * m0, ga[u][1] = ra[c1] * m1;
+                    gb[u][0] = rb[c0] * m0, gb[u][1] = rb[c1] * m1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int l = min(base + u, 63);       // lanes past a node's window hold coefficient 0
+#pragma unroll
+                    for (int b = 0; b < TG; ++b) {
+                        const float ca = rl(cfA[b], l), cb = rl(cfB[b], l);
+                        accA[b][0] += ca * ga[u][0], accA[b][1] += ca * ga[u][1];
+                        accB[b][0] += cb * gb[u][0], accB[b][1] += cb * gb[u][1];
+                    }
+                }
+            }
+        }
+        float* urA = Ut + liA * SKP;
+        float* urB = Ut + liB * SKP;
+#pragma unroll
+        for (int b = 0; b < TG; ++b) {
+            if (lane < TO) urA[b * TO + lane] = accA[b][0], urB[b * TO + lane] = accB[b][0];
+            if (lane + 64 < TO) urA[b * TO + lane + 64] = accA[b][1], urB[b * TO + lane + 64] = accB[b][1];
+        }
+        // root block (last group: the node's own dOut row, else zeros) and the zero padding up to 608
+        const float* sa = dH + (int64_t)min(jA, N - 1) * lddh;
+        const float* sb = dH + (int64_t)min(jB, N - 1) * lddh;
+        const float ka = with_root && jA < N ? 1.f : 0.f, kb = with_root && jB < N ? 1.f : 0.f;
+        if (lane < TO) urA[SKB + lane] = sa[c0] * ka, urB[SKB + lane] = sb[c0] * kb;
+        if (lane + 64 < TO) urA[SKB + lane + 64] = sa[c1] * ka, urB[SKB + lane + 64] = sb[c1] * kb;
+        if (lane < SKP - SKR) urA[SKR + lane] = 0.f, urB[SKR + lane] = 0.f;
+    }
+    __syncthreads();
+    // ---- phase 2: partial[16, 200] = Ut[16, K] @ B, B[k = (b, c)][f] = basis[5 g + b][f][c] (root[f][c] for the 6th block);
+    //      16-k blocks dealt to the wavefronts round-robin
+    const int nblk = (with_root ? SKR + 8 : SKB + 12) / 16;      // 600 -> 38 blocks (608), 500 -> 32 blocks (512)
+    const int r = lane & 15, kk = lane >> 4;
+    const float* bg = basis + (int64_t)g * TG * TF * TO;
+    f32x4_t acc[SNT];
+#pragma unroll
+    for (int t = 0; t < SNT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int blk = w; blk < nblk; blk += 8) {
+        const int k = 16 * blk + 4 * kk;                 // this lane's 4 consecutive k (one basis: 4 | 100)
+        const int kc = min(k, (with_root ? SKR : SKB) - 4);
+        const bool kv = k < (with_root ? SKR : SKB);
+        const float* bcol = kc < SKB ? bg + (int64_t)(kc / TO) * TF * TO + kc % TO : root + (kc - SKB);
+        const float4 av = *reinterpret_cast<const float4*>(Ut + r * SKP + k);      // zeros past K
+        float4 bv[SNT];
+#pragma unroll
+        for (int t = 0; t < SNT; ++t) {
+            const int f = min(16 * t + r, TF - 1);
+            bv[t] = *reinterpret_cast<const float4*>(bcol + (int64_t)f * TO);
+        }
+#pragma unroll
+        for (int t = 0; t < SNT; ++t) {
+            const float mk = kv && 16 * t + r < TF ? 1.f : 0.f;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[t].x * mk, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[t].y * mk, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[t].z * mk, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[t].w * mk, acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // D of tile t: lane holds rows 4 (lane >> 4) + i of column 16 t + (lane & 15)
+    float* red = smem + w * 16 * 208;
+#pragma unroll
+    for (int t = 0; t < SNT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[(4 * kk + i) * 208 + 16 * t + r] = acc[t][i];
+    __syncthreads();
+    // ---- phase 3: sum of the 8 partial tiles -> slab g (16 rows x 50 float4)
+    for (int it = tid; it < 16 * 50; it += 512) {
+        const int row = it / 50, c4 = it % 50;
+        float4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) {
+            const float4 v = *reinterpret_cast<const float4*>(smem + (ww * 16 + row) * 208 + 4 * c4);
+            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+        }
+        if (j0 + row < N) *reinterpret_cast<float4*>(slabs + ((int64_t)g * N + j0 + row) * TF + 4 * c4) = sum;
+    }
+}
+
 // ------------------------------------------------------------------ basis RGCN in RELATION space (R <= 8)
 // With few relations (two speakers: R = 2 S^2 = 8 < 30 bases) the layer is cheaper the way models/rgcn.py:300-304 writes
 // it: W_r = sum_b comp[r,b] basis[b] first, then
@@ -888,6 +1022,32 @@ extern "C" int erc_brgcn_fwd_tile(const float* x, int ldx, int F, int O, int N, 
     hipLaunchKernelGGL(brgcn_fwd_tile_kernel, dim3(erc_cdiv(N, 16), NGRP), dim3(512), lds, (hipStream_t)stream, x, ldx, N, in_ptr,
                        in_src, in_typ, norm, att, basis, root, Z, slabs, g_brgcn_stamps);
     ERC_LAUNCH_CHECK("brgcn_fwd_tile");
+    return ERC_OK;
+}
+
+extern "C" int erc_brgcn_bwd_source_tile(const float* dH, int lddh, int F, int O, int N, const int32_t* out_ptr,
+                                         const int32_t* out_dst, const int32_t* out_typ, const int32_t* out_eid,
+                                         const float* norm, const float* att, int num_bases, const float* basis,
+                                         const float* root, float* slabs, void* stream) {
+    ERC_REQUIRE(dH && out_ptr && out_dst && out_typ && out_eid && norm && att && basis && root && slabs,
+                "brgcn_bwd_source_tile: null pointer");
+    ERC_REQUIRE(num_bases == NB && F == TF && O == TO && N > 0, "brgcn_bwd_source_tile: built for %d bases, F = %d, O = %d",
+                NB, TF, TO);
+    ERC_REQUIRE(((uintptr_t)basis & 15) == 0 && ((uintptr_t)root & 15) == 0 && ((uintptr_t)slabs & 15) == 0,
+                "brgcn_bwd_source_tile: basis / root / slabs must be 16-byte aligned");
+    static bool attr_set = false;
+    const int lds = 8 * 16 * 208 * (int)sizeof(float);       // the partial tiles (106 KB) outsize the U tile (39 KB)
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)brgcn_bwd_source_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            erc_set_error("brgcn_bwd_source_tile: cannot reserve %d bytes of LDS", lds);
+            return ERC_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(brgcn_bwd_source_tile_kernel, dim3(erc_cdiv(N, 16), NGRP), dim3(512), lds, (hipStream_t)stream, dH, lddh,
+                       N, out_ptr, out_dst, out_typ, out_eid, norm, att, basis, root, slabs);
+    ERC_LAUNCH_CHECK("brgcn_bwd_source_tile");
     return ERC_OK;
 }
 

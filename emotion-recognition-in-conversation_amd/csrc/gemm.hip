@@ -507,10 +507,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         for (int s = 0; s < S; ++s) v += slabs[(int64_t)s * stride + i];
         if (bias) v += bias[i % n_cols];
         if (act == 1) v = fmaxf(v, 0.f);
-        if (ld_out > 0)
-            out[(i / n_cols) * ld_out + i % n_cols] = v;
-        else
-            out[i] = v;
+        const int64_t o = ld_out > 0 ? (i / n_cols) * ld_out + i % n_cols : i;
+        out[o] = act == 4 ? out[o] + v : v;      // act 4: accumulate into out
     }
 }
 

@@ -84,7 +84,9 @@ class DGCNModule(nn.Module):
         # few relations (two speakers: 8 < 30 bases): RGCNConv in relation space, W_r composed first as models/rgcn.py:300-304
         # does (csrc/dgcn_ops.hip); None = decide in finalize() from the library's limit, True / False = forced (tests)
         self.relation_space = None
-        self.fused_rgcn_fwd = True      # basis space: aggregate + Z @ basis + x @ root as one tile launch (erc_brgcn_fwd_tile)
+        # basis space: aggregate + Z @ basis + x @ root as one tile launch (erc_brgcn_fwd_tile), and the node side of the
+        # backward likewise (erc_brgcn_bwd_source_tile); False = the separate kernels + GEMMs (tests compare the two)
+        self.fused_rgcn_fwd = True
         self.drop_p = float(dropout)
         self.rnn = _SeqContext(input_size, hidden_size, dropout)
         self.edge_att = _EdgeAtt(hidden_size)
@@ -135,7 +137,7 @@ class DGCNModule(nn.Module):
                   dZ=f32(N, self._kb * G_DIM), dnorm=f32(E), TT=f32(E, NB), U=f32(N, self._kb * H1),
                   basisT=f32(self._kb * H1, G_DIM), Wr=f32(self._kb * G_DIM, H1), dWr=f32(self._kb * G_DIM, H1),
                   DATT=f32(N, G_DIM), dscore=f32(E), drnn=f32(BT, G_DIM),
-                  rgcn_slabs=f32(capi.brgcn_fwd_tile_slab_floats(N)))
+                  rgcn_slabs=f32(capi.brgcn_fwd_tile_slab_floats(N)), rgcn_dslabs=f32(capi.brgcn_fwd_tile_slabs() * N * G_DIM))
         D = self.input_size
         slab = 12 * N * H1 + 4 * BT * 800 + 10 * (800 * D + 800 * 200 + 2 * 400 * 100 * 2) + 4 * NB * G_DIM * H1 + \
             8 * (G_DIM * G_DIM + 300 * 100) + (1 << 21)
@@ -250,11 +252,18 @@ class DGCNModule(nn.Module):
             capi.brgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["dZ"], ws["dnorm"],
                                  ws["TT"], fp.g("gcn.conv1.att"))
             matmul_wgrad_io(pl, ws["Z"], K1, ws["dHc"], H1, K1, H1, N, off["gcn.conv1.basis"], off["gcn.conv1.bias"], defer=True)
-            capi.brgcn_bwd_source(ws["dHc"], H1, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["U"])
-            capi.transpose_batched(fp.w("gcn.conv1.basis"), NB, G_DIM, H1, ws["basisT"])
+            if not self.fused_rgcn_fwd:
+                capi.brgcn_bwd_source(ws["dHc"], H1, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["U"])
+                capi.transpose_batched(fp.w("gcn.conv1.basis"), NB, G_DIM, H1, ws["basisT"])
         matmul_wgrad_io(pl, Xc, XW, ws["dHc"], H1, G_DIM, H1, N, off["gcn.conv1.root"], None, defer=True)
-        capi.gemm_f32(ws["U"], KB * H1, 0, None, ws["basisT"], G_DIM, 1, None, dXc, XW, N, G_DIM, KB * H1, accumulate=1)
-        capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.root"), H1, 0, None, dXc, XW, N, G_DIM, H1, accumulate=1)
+        if self.fused_rgcn_fwd and not self.relation_space:
+            # dXc += sum_b U_b basis_b^T + dHc root^T: one tile launch + the slab sum added into dXc
+            capi.brgcn_bwd_source_tile(ws["dHc"], H1, G_DIM, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB,
+                                       fp.w("gcn.conv1.basis"), fp.w("gcn.conv1.root"), ws["rgcn_dslabs"])
+            capi.slab_reduce(ws["rgcn_dslabs"], capi.brgcn_fwd_tile_slabs(), N * G_DIM, None, G_DIM, 4, dXc, N * G_DIM, ld_out=XW)
+        else:
+            capi.gemm_f32(ws["U"], KB * H1, 0, None, ws["basisT"], G_DIM, 1, None, dXc, XW, N, G_DIM, KB * H1, accumulate=1)
+            capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.root"), H1, 0, None, dXc, XW, N, G_DIM, H1, accumulate=1)
         # EdgeAtt
         capi.edge_att_bwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"], ws["dnorm"], dXc, XW, 1, ws["DATT"], G_DIM,
                           ws["dscore"])

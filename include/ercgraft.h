@@ -155,7 +155,8 @@ int erc_gemm_bf16x(const void* A, int lda, int a_kmajor, const int32_t* a_gather
                    void* stream);
 
 /* out[(i / n_cols)*ld_out + i % n_cols] = act( sum_{s<S} slabs[s*slab_stride + i] + (bias ? bias[i % n_cols] : 0) ),
- * i < numel; ld_out = 0 means contiguous (ld_out = n_cols). */
+ * i < numel; ld_out = 0 means contiguous (ld_out = n_cols).  act: 0 none, 1 relu, 4 = add the sum to out instead of
+ * overwriting it. */
 int erc_slab_reduce(const float* slabs, int S, int64_t slab_stride, const float* bias, int n_cols, int act,
                     float* out, int ld_out, int64_t numel, void* stream);
 
@@ -626,7 +627,15 @@ int erc_brgcn_bwd_source(const float* dH, int lddh, int O, int N, const int32_t*
  * S = erc_brgcn_fwd_tile_slabs() partial [N, O] slabs: conv(x) = erc_slab_reduce(slabs, S, N*O, bias). */
 int64_t erc_brgcn_fwd_tile_slab_floats(int n_nodes);
 int erc_brgcn_fwd_tile_slabs(void);
-int erc_brgcn_set_stamps(unsigned long long* stamps);   /* diagnostic: 6 x uint64 phase stamps (10 ns ticks); NULL = off */
+int erc_brgcn_set_stamps(unsigned long long* stamps);
+/* The node side of the layer's backward as ONE tile launch (replaces erc_brgcn_bwd_source + erc_transpose_batched + the
+ * [N, 30 O] x [30 O, F] GEMM + the root GEMM): per 16 source nodes x 5 bases, U blocks (sum over out-edges of
+ * norm_e att[type_e, b] dOut[dst_e, :]) into LDS, times basis[b]^T on the fp32 matrix cores (weight fragments are 16-byte
+ * loads ALONG k straight from basis [30, F, O] -- no transposed copy), dOut @ root^T as a 6th block of the last group.
+ * Leaves S = erc_brgcn_fwd_tile_slabs() partial [N, F] slabs: dx += erc_slab_reduce(slabs, S, N*F, act = 4). */
+int erc_brgcn_bwd_source_tile(const float* dH, int lddh, int F, int O, int N, const int32_t* out_ptr, const int32_t* out_dst,
+                              const int32_t* out_typ, const int32_t* out_eid, const float* norm, const float* att,
+                              int num_bases, const float* basis, const float* root, float* slabs, void* stream);   /* diagnostic: 6 x uint64 phase stamps (10 ns ticks); NULL = off */
 int erc_brgcn_fwd_tile(const float* x, int ldx, int F, int O, int N, const int32_t* in_ptr, const int32_t* in_src,
                        const int32_t* in_typ, const float* norm, const float* att, int num_bases, const float* basis,
                        const float* root, float* Z, float* slabs, void* stream);

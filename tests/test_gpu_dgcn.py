@@ -175,6 +175,23 @@ def test_fused_rgcn_forward_tile_vs_unfused_and_reference_golden(golden, name):
     assert torch.equal(Zt, Z_ref)                # the same per-edge multiply-adds in the same order
     assert float((out - out_ref).abs().max()) < 2e-5 * max(1.0, float(out_ref.abs().max()))
     np.testing.assert_allclose(out.cpu().numpy(), fx["rgcn_out"], atol=1e-4, rtol=1e-4)
+    # node side of the backward: dx += sum_b U_b basis_b^T + gout root^T, fused vs the separate kernels
+    gout = torch.from_numpy(fx["gout"]).to(DEV)
+    U, basisT = z(N, NB * O), z(NB * O, Fd)
+    dx0 = torch.randn(N, XW, device=DEV)
+    dx_ref = dx0.clone()
+    capi.brgcn_bwd_source(gout, O, O, N, g, norm, attp, NB, U)
+    capi.transpose_batched(basis, NB, Fd, O, basisT)
+    capi.gemm_f32(U, NB * O, 0, None, basisT, Fd, 1, None, dx_ref, XW, N, Fd, NB * O, accumulate=1)
+    capi.gemm_f32(gout, O, 0, None, root, O, 0, None, dx_ref, XW, N, Fd, O, accumulate=1)
+    S = capi.brgcn_fwd_tile_slabs()
+    dslabs, dx = torch.full((S, N, Fd), float("nan"), device=DEV), dx0.clone()
+    capi.poison_lds()
+    capi.brgcn_bwd_source_tile(gout, O, Fd, O, N, g, norm, attp, NB, basis, root, dslabs)
+    capi.slab_reduce(dslabs, S, N * Fd, None, Fd, 4, dx, N * Fd, ld_out=XW)
+    assert torch.equal(dx[:, Fd:], dx0[:, Fd:])           # the columns next to the features are not touched
+    sc = max(1.0, float((dx_ref - dx0).abs().max()))
+    assert float((dx - dx_ref).abs().max()) < 2e-5 * sc, float((dx - dx_ref).abs().max())
 
 
 def test_dgcn_relation_space_equals_basis_space():
