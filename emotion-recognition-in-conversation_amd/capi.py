@@ -98,6 +98,8 @@ _SIGS = {
     "erc_brgcn_fwd_tile_slab_floats": (C.c_int64, [_i]),
     "erc_brgcn_set_stamps": (C.c_int, [_vp]),
     "erc_brgcn_fwd_tile_slabs": (C.c_int, []),
+    "erc_brgcn_bwd_edges_tile": (C.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp,
+                                           C.c_int64, _vp, _vp]),
     "erc_brgcn_bwd_source_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "erc_brgcn_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_rrgcn_max_relations": (C.c_int, []),
@@ -574,6 +576,12 @@ def brgcn_bwd_source_tile(dH, lddh, F, O, N, g, norm, att, nb, basis, root, slab
     _check(lib().erc_brgcn_bwd_source_tile(ptr(dH), lddh, F, O, N, ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_typ"]),
                                            ptr(g["out_eid"]), ptr(norm), ptr(att), nb, ptr(basis), ptr(root), ptr(slabs),
                                            stream()), "erc_brgcn_bwd_source_tile")
+
+
+def brgcn_bwd_edges_tile(x, ldx, F, O, N, R, g, norm, att, nb, basis, dH, lddh, TT, dn_slabs, dn_stride, datt):
+    _check(lib().erc_brgcn_bwd_edges_tile(ptr(x), ldx, F, O, N, R, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
+                                          ptr(g["counts"]), ptr(norm), ptr(att), nb, ptr(basis), ptr(dH), lddh, ptr(TT),
+                                          ptr(dn_slabs), dn_stride, ptr(datt), stream()), "erc_brgcn_bwd_edges_tile")
 
 
 def brgcn_fwd_tile_slabs():

@@ -680,6 +680,125 @@ __global__ __launch_bounds__(512) void brgcn_bwd_source_tile_kernel(const float*
     }
 }
 
+// The edge side of the backward: dZ[i, b, :] = basis[b] dOut[i, :] never goes to HBM.  Per 16 target nodes x 5 bases the
+// workgroup forms its dZ blocks on the matrix cores (K = the 100 outputs, 16-byte weight loads along k as above) into LDS,
+// then every in-edge takes 6 dot products with its source row -- T_e[b] = x_src . dZ[i, b, :] for the group's bases and
+// x_src . (sum_b att[type_e, b] dZ[i, b, :]) = this group's share of d norm_e -- two edges per 16-value butterfly.
+// Outputs: TT[e, 5 g + b] = norm_e T_e[b] (summed per relation by rel_sum_kernel -> d att) and slab g of d norm.
+constexpr int DZP = TG * TF + 4;          // LDS row of the dZ tile
+constexpr int DKB = 7;                    // 16-k blocks over the 100 outputs (112, masked)
+
+__global__ __launch_bounds__(512) void brgcn_bwd_target_tile_kernel(const float* __restrict__ x, int ldx, int N,
+                                                                    const int32_t* __restrict__ in_ptr,
+                                                                    const int32_t* __restrict__ in_src,
+                                                                    const int32_t* __restrict__ in_typ,
+                                                                    const float* __restrict__ norm,
+                                                                    const float* __restrict__ attw,
+                                                                    const float* __restrict__ basis,
+                                                                    const float* __restrict__ dH, int lddh,
+                                                                    float* __restrict__ TT, float* __restrict__ dn_slabs,
+                                                                    int64_t dn_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* dZt = smem;                                   // [16][DZP]
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i0 = blockIdx.x * 16, g = blockIdx.y;
+    const int r = lane & 15, kk = lane >> 4;
+    // ---- phase A: dZ tile [16, 5 x 200] = dOut[16, 100] @ B, B[k = c][n = (b, f)] = basis[5 g + b][f][c]
+    {
+        float4 av[DKB];
+        const float* arow = dH + (int64_t)min(i0 + r, N - 1) * lddh;
+        const float rowok = i0 + r < N ? 1.f : 0.f;
+#pragma unroll
+        for (int blk = 0; blk < DKB; ++blk) {
+            const int k = 16 * blk + 4 * kk;
+            const float4 v = *reinterpret_cast<const float4*>(arow + min(k, TO - 4));
+            const float m = k < TO ? rowok : 0.f;
+            av[blk] = float4{v.x * m, v.y * m, v.z * m, v.w * m};
+        }
+        const float* bg = basis + (int64_t)g * TG * TF * TO;
+        constexpr int NTL = (TG * TF + 15) / 16;        // 63 column tiles (the last one half)
+        for (int t = w; t < NTL; t += 8) {
+            const int col = min(16 * t + r, TG * TF - 1);
+            const float* bcol = bg + (int64_t)col * TO;   // (b, f) -> basis[5 g + b][f][:], rows of 100 are consecutive
+            float4 bv[DKB];
+#pragma unroll
+            for (int blk = 0; blk < DKB; ++blk) bv[blk] = *reinterpret_cast<const float4*>(bcol + min(16 * blk + 4 * kk, TO - 4));
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int blk = 0; blk < DKB; ++blk) {       // A is zero where k >= 100: the clamped B values do not matter
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[blk].x, bv[blk].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[blk].y, bv[blk].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[blk].z, bv[blk].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[blk].w, bv[blk].w, acc, 0, 0, 0);
+            }
+            if (16 * t + r < TG * TF) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dZt[(4 * kk + i) * DZP + 16 * t + r] = acc[i];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase B: per in-edge of the tile's nodes, the 6 dot products with the source row
+    const int entry = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const int eu = entry / 6, ev = entry % 6;            // entries 0..11: edge eu of the pair, value ev (5 = d norm share)
+    auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const int li = 2 * w + half, i = i0 + li;
+        if (i >= N) continue;      // uniform
+        Lane4 dz[TG];
+#pragma unroll
+        for (int b = 0; b < TG; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[b].v[q] = lane + 64 * q < TF ? dZt[li * DZP + b * TF + lane + 64 * q] : 0.f;
+        const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
+        for (int w0 = e0; w0 < e1; w0 += 64) {
+            const int nwin = min(64, e1 - w0);
+            const int el = w0 + min(lane, nwin - 1);
+            const int my_src = in_src[el];
+            const float my_n = lane < nwin ? norm[el] : 0.f;
+            const float* ar = attw + (int64_t)in_typ[el] * NB + g * TG;
+            float at[TG];
+#pragma unroll
+            for (int b = 0; b < TG; ++b) at[b] = ar[b];
+            for (int base = 0; base < nwin; base += 8) {      // 8 source rows in flight = 4 butterflies
+                Lane4 xs[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    xs[u] = load4(x + (int64_t)__builtin_amdgcn_readlane(my_src, min(base + u, nwin - 1)) * ldx, TF, lane);
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    if (base + 2 * pr < nwin) {      // uniform
+                        float part[16];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int l = min(base + 2 * pr + u, 63);
+                            Lane4 comb = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                            for (int b = 0; b < TG; ++b) {
+                                part[6 * u + b] = dot4(xs[2 * pr + u], dz[b]);
+                                const float c = rl(at[b], l);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) comb.v[q] += c * dz[b].v[q];
+                            }
+                            part[6 * u + 5] = dot4(xs[2 * pr + u], comb);
+                        }
+                        part[12] = part[13] = part[14] = part[15] = 0.f;
+                        const float tot = butterfly16_sum(part, lane);
+                        const int eb = base + 2 * pr;
+                        const float n0 = rl(my_n, min(eb, 63)), n1 = rl(my_n, min(eb + 1, 63));
+                        if ((lane & 3) == 0 && entry < 12 && eb + eu < nwin) {
+                            const int64_t e = w0 + eb + eu;
+                            if (ev < TG) TT[e * NB + g * TG + ev] = (eu ? n1 : n0) * tot;
+                            else dn_slabs[(int64_t)g * dn_stride + e] = tot;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ basis RGCN in RELATION space (R <= 8)
 // With few relations (two speakers: R = 2 S^2 = 8 < 30 bases) the layer is cheaper the way models/rgcn.py:300-304 writes
 // it: W_r = sum_b comp[r,b] basis[b] first, then
@@ -1048,6 +1167,34 @@ extern "C" int erc_brgcn_bwd_source_tile(const float* dH, int lddh, int F, int O
     hipLaunchKernelGGL(brgcn_bwd_source_tile_kernel, dim3(erc_cdiv(N, 16), NGRP), dim3(512), lds, (hipStream_t)stream, dH, lddh,
                        N, out_ptr, out_dst, out_typ, out_eid, norm, att, basis, root, slabs);
     ERC_LAUNCH_CHECK("brgcn_bwd_source_tile");
+    return ERC_OK;
+}
+
+extern "C" int erc_brgcn_bwd_edges_tile(const float* x, int ldx, int F, int O, int N, int R, const int32_t* in_ptr,
+                                        const int32_t* in_src, const int32_t* in_typ, const int32_t* counts,
+                                        const float* norm, const float* att, int num_bases, const float* basis,
+                                        const float* dH, int lddh, float* TT, float* dn_slabs, int64_t dn_stride,
+                                        float* datt, void* stream) {
+    ERC_REQUIRE(x && in_ptr && in_src && in_typ && counts && norm && att && basis && dH && TT && dn_slabs && datt,
+                "brgcn_bwd_edges_tile: null pointer");
+    ERC_REQUIRE(num_bases == NB && F == TF && O == TO && N > 0 && R > 0 && lddh % 4 == 0 && dn_stride > 0,
+                "brgcn_bwd_edges_tile: built for %d bases, F = %d, O = %d", NB, TF, TO);
+    ERC_REQUIRE(((uintptr_t)basis & 15) == 0 && ((uintptr_t)dH & 15) == 0, "brgcn_bwd_edges_tile: basis / dOut must be 16-byte aligned");
+    static bool attr_set = false;
+    const int lds = 16 * DZP * (int)sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)brgcn_bwd_target_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess) {
+            erc_set_error("brgcn_bwd_edges_tile: cannot reserve %d bytes of LDS", lds);
+            return ERC_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(brgcn_bwd_target_tile_kernel, dim3(erc_cdiv(N, 16), NGRP), dim3(512), lds, (hipStream_t)stream, x, ldx, N,
+                       in_ptr, in_src, in_typ, norm, att, basis, dH, lddh, TT, dn_slabs, dn_stride);
+    ERC_LAUNCH_CHECK("brgcn_bwd_target_tile");
+    hipLaunchKernelGGL(rel_sum_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, TT, in_typ, counts, datt);
+    ERC_LAUNCH_CHECK("rel_sum");
     return ERC_OK;
 }
 

@@ -137,7 +137,8 @@ class DGCNModule(nn.Module):
                   dZ=f32(N, self._kb * G_DIM), dnorm=f32(E), TT=f32(E, NB), U=f32(N, self._kb * H1),
                   basisT=f32(self._kb * H1, G_DIM), Wr=f32(self._kb * G_DIM, H1), dWr=f32(self._kb * G_DIM, H1),
                   DATT=f32(N, G_DIM), dscore=f32(E), drnn=f32(BT, G_DIM),
-                  rgcn_slabs=f32(capi.brgcn_fwd_tile_slab_floats(N)), rgcn_dslabs=f32(capi.brgcn_fwd_tile_slabs() * N * G_DIM))
+                  rgcn_slabs=f32(capi.brgcn_fwd_tile_slab_floats(N)), rgcn_dslabs=f32(capi.brgcn_fwd_tile_slabs() * N * G_DIM),
+                  dn_slabs=f32(capi.brgcn_fwd_tile_slabs() * E))
         D = self.input_size
         slab = 12 * N * H1 + 4 * BT * 800 + 10 * (800 * D + 800 * 200 + 2 * 400 * 100 * 2) + 4 * NB * G_DIM * H1 + \
             8 * (G_DIM * G_DIM + 300 * 100) + (1 << 21)
@@ -248,9 +249,17 @@ class DGCNModule(nn.Module):
             pl.defer(ws["Z"], K1, ws["dHc"], H1, ws["dWr"], H1, K1, H1, N, 2, pl.grad[off["gcn.conv1.bias"]:])
             capi.rrgcn_bwd_source(ws["dHc"], H1, H1, N, self.R, g, ws["norm"], ws["U"])
         else:
-            capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.basis"), H1, 0, None, ws["dZ"], K1, N, K1, H1)
-            capi.brgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["dZ"], ws["dnorm"],
-                                 ws["TT"], fp.g("gcn.conv1.att"))
+            if self.fused_rgcn_fwd:
+                # dZ stays in LDS: blocks on the matrix cores, 6 dots per in-edge; d norm as partial vectors per basis group
+                E_cap = ws["E"]
+                capi.brgcn_bwd_edges_tile(Xc, XW, G_DIM, H1, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB,
+                                          fp.w("gcn.conv1.basis"), ws["dHc"], H1, ws["TT"], ws["dn_slabs"], E_cap,
+                                          fp.g("gcn.conv1.att"))
+                capi.slab_reduce(ws["dn_slabs"], capi.brgcn_fwd_tile_slabs(), E_cap, None, 0, 0, ws["dnorm"], E_cap)
+            else:
+                capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.basis"), H1, 0, None, ws["dZ"], K1, N, K1, H1)
+                capi.brgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["dZ"], ws["dnorm"],
+                                     ws["TT"], fp.g("gcn.conv1.att"))
             matmul_wgrad_io(pl, ws["Z"], K1, ws["dHc"], H1, K1, H1, N, off["gcn.conv1.basis"], off["gcn.conv1.bias"], defer=True)
             if not self.fused_rgcn_fwd:
                 capi.brgcn_bwd_source(ws["dHc"], H1, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["U"])

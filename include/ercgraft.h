@@ -633,6 +633,14 @@ int erc_brgcn_set_stamps(unsigned long long* stamps);
  * norm_e att[type_e, b] dOut[dst_e, :]) into LDS, times basis[b]^T on the fp32 matrix cores (weight fragments are 16-byte
  * loads ALONG k straight from basis [30, F, O] -- no transposed copy), dOut @ root^T as a 6th block of the last group.
  * Leaves S = erc_brgcn_fwd_tile_slabs() partial [N, F] slabs: dx += erc_slab_reduce(slabs, S, N*F, act = 4). */
+/* The edge side of the backward without dZ in HBM (replaces the [N, O] x [O, 30 F] GEMM + erc_brgcn_bwd_edges): dZ blocks
+ * on the matrix cores into LDS, 6 dot products per in-edge.  TT [E, 30] scratch, datt [R, 30] as erc_brgcn_bwd_edges;
+ * d norm arrives as S = erc_brgcn_fwd_tile_slabs() partial vectors dn_slabs[s * dn_stride + e]:
+ * dnorm = erc_slab_reduce(dn_slabs, S, dn_stride, numel = E). */
+int erc_brgcn_bwd_edges_tile(const float* x, int ldx, int F, int O, int N, int R, const int32_t* in_ptr,
+                             const int32_t* in_src, const int32_t* in_typ, const int32_t* counts, const float* norm,
+                             const float* att, int num_bases, const float* basis, const float* dH, int lddh, float* TT,
+                             float* dn_slabs, int64_t dn_stride, float* datt, void* stream);
 int erc_brgcn_bwd_source_tile(const float* dH, int lddh, int F, int O, int N, const int32_t* out_ptr, const int32_t* out_dst,
                               const int32_t* out_typ, const int32_t* out_eid, const float* norm, const float* att,
                               int num_bases, const float* basis, const float* root, float* slabs, void* stream);   /* diagnostic: 6 x uint64 phase stamps (10 ns ticks); NULL = off */

@@ -189,6 +189,18 @@ def test_fused_rgcn_forward_tile_vs_unfused_and_reference_golden(golden, name):
     capi.poison_lds()
     capi.brgcn_bwd_source_tile(gout, O, Fd, O, N, g, norm, attp, NB, basis, root, dslabs)
     capi.slab_reduce(dslabs, S, N * Fd, None, Fd, 4, dx, N * Fd, ld_out=XW)
+    # edge side of the backward: d norm, TT and d att, fused (dZ in LDS) vs GEMM + erc_brgcn_bwd_edges
+    dZ = z(N, NB * Fd)
+    capi.gemm_f32(gout, O, 0, None, basis, O, 0, None, dZ, NB * Fd, N, NB * Fd, O)
+    dn_ref, TT_ref, datt_ref = z(E), z(E, NB), z(R, NB)
+    capi.brgcn_bwd_edges(xw, XW, Fd, N, R, g, norm, attp, NB, dZ, dn_ref, TT_ref, datt_ref)
+    dn_sl, TTf, dattf, dn = torch.full((S, E), float("nan"), device=DEV), torch.full((E, NB), float("nan"), device=DEV), z(R, NB), z(E)
+    capi.poison_lds()
+    capi.brgcn_bwd_edges_tile(xw, XW, Fd, O, N, R, g, norm, attp, NB, basis, gout, O, TTf, dn_sl, E, dattf)
+    capi.slab_reduce(dn_sl, S, E, None, 0, 0, dn, E)
+    for got, want, what in ((dn, dn_ref, "dnorm"), (TTf, TT_ref, "TT"), (dattf, datt_ref, "datt")):
+        e = float((got - want).abs().max()) / max(1e-6, float(want.abs().max()))
+        assert e < 2e-5, (what, e)
     assert torch.equal(dx[:, Fd:], dx0[:, Fd:])           # the columns next to the features are not touched
     sc = max(1.0, float((dx_ref - dx0).abs().max()))
     assert float((dx - dx_ref).abs().max()) < 2e-5 * sc, float((dx - dx_ref).abs().max())
