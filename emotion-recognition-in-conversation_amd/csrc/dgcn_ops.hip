@@ -697,8 +697,9 @@ __global__ __launch_bounds__(512) void brgcn_bwd_target_tile_kernel(const float*
                                                                     const float* __restrict__ basis,
                                                                     const float* __restrict__ dH, int lddh,
                                                                     float* __restrict__ TT, float* __restrict__ dn_slabs,
-                                                                    int64_t dn_stride) {
+                                                                    int64_t dn_stride, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    BR_STAMP(0);
     float* dZt = smem;                                   // [16][DZP]
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i0 = blockIdx.x * 16, g = blockIdx.y;
@@ -717,12 +718,13 @@ __global__ __launch_bounds__(512) void brgcn_bwd_target_tile_kernel(const float*
         }
         const float* bg = basis + (int64_t)g * TG * TF * TO;
         constexpr int NTL = (TG * TF + 15) / 16;        // 63 column tiles (the last one half)
-        for (int t = w; t < NTL; t += 8) {
-            const int col = min(16 * t + r, TG * TF - 1);
+        auto fetch_b = [&](int t, float4 (&bv)[DKB]) {
+            const int col = min(16 * min(t, NTL - 1) + r, TG * TF - 1);
             const float* bcol = bg + (int64_t)col * TO;   // (b, f) -> basis[5 g + b][f][:], rows of 100 are consecutive
-            float4 bv[DKB];
 #pragma unroll
             for (int blk = 0; blk < DKB; ++blk) bv[blk] = *reinterpret_cast<const float4*>(bcol + min(16 * blk + 4 * kk, TO - 4));
+        };
+        auto tile = [&](int t, const float4 (&bv)[DKB]) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int blk = 0; blk < DKB; ++blk) {       // A is zero where k >= 100: the clamped B values do not matter
@@ -735,60 +737,83 @@ __global__ __launch_bounds__(512) void brgcn_bwd_target_tile_kernel(const float*
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dZt[(4 * kk + i) * DZP + 16 * t + r] = acc[i];
             }
+        };
+        // the weight fragments of the next tile are requested before the current tile's products (two register sets)
+        // (every request is consumed: a request left in flight at the end of the loop would land in registers that
+        // the next phase already uses for something else)
+        float4 bA[DKB], bB[DKB];
+        fetch_b(w, bA);
+        for (int t = w; t < NTL; t += 16) {
+            if (t + 8 < NTL) fetch_b(t + 8, bB);
+            tile(t, bA);
+            if (t + 8 < NTL) {
+                if (t + 16 < NTL) fetch_b(t + 16, bA);
+                tile(t + 8, bB);
+            }
         }
     }
+    BR_STAMP(1);
     __syncthreads();
+    BR_STAMP(2);
     // ---- phase B: per in-edge of the tile's nodes, the 6 dot products with the source row
     const int entry = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
     const int eu = entry / 6, ev = entry % 6;            // entries 0..11: edge eu of the pair, value ev (5 = d norm share)
     auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        const int li = 2 * w + half, i = i0 + li;
-        if (i >= N) continue;      // uniform
-        Lane4 dz[TG];
+    {
+        const int liA = 2 * w, liB = 2 * w + 1, iA = i0 + liA, iB = i0 + liB;
+        Lane4 dzA[TG], dzB[TG];
 #pragma unroll
         for (int b = 0; b < TG; ++b)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dz[b].v[q] = lane + 64 * q < TF ? dZt[li * DZP + b * TF + lane + 64 * q] : 0.f;
-        const int e0 = in_ptr[i], e1 = in_ptr[i + 1];
-        for (int w0 = e0; w0 < e1; w0 += 64) {
-            const int nwin = min(64, e1 - w0);
-            const int el = w0 + min(lane, nwin - 1);
-            const int my_src = in_src[el];
-            const float my_n = lane < nwin ? norm[el] : 0.f;
-            const float* ar = attw + (int64_t)in_typ[el] * NB + g * TG;
-            float at[TG];
+            for (int q = 0; q < 4; ++q) {
+                dzA[b].v[q] = lane + 64 * q < TF ? dZt[liA * DZP + b * TF + lane + 64 * q] : 0.f;
+                dzB[b].v[q] = lane + 64 * q < TF ? dZt[liB * DZP + b * TF + lane + 64 * q] : 0.f;
+            }
+        int eA0 = 0, eA1 = 0, eB0 = 0, eB1 = 0;
+        if (iA < N) eA0 = in_ptr[iA], eA1 = in_ptr[iA + 1];
+        if (iB < N) eB0 = in_ptr[iB], eB1 = in_ptr[iB + 1];
+        const int dmax = max(eA1 - eA0, eB1 - eB0);
+        // one butterfly = one edge of each node: entries 0..5 node A's edge, 6..11 node B's
+        for (int wo = 0; wo < dmax; wo += 64) {
+            const int nA = min(64, max(eA1 - eA0 - wo, 0)), nB = min(64, max(eB1 - eB0 - wo, 0));
+            const int elA = nA > 0 ? eA0 + wo + min(lane, nA - 1) : 0, elB = nB > 0 ? eB0 + wo + min(lane, nB - 1) : 0;
+            const int srcA = in_src[elA], srcB = in_src[elB];
+            const float nrA = lane < nA ? norm[elA] : 0.f, nrB = lane < nB ? norm[elB] : 0.f;
+            const float* arA = attw + (int64_t)in_typ[elA] * NB + g * TG;
+            const float* arB = attw + (int64_t)in_typ[elB] * NB + g * TG;
+            float atA[TG], atB[TG];
 #pragma unroll
-            for (int b = 0; b < TG; ++b) at[b] = ar[b];
-            for (int base = 0; base < nwin; base += 8) {      // 8 source rows in flight = 4 butterflies
-                Lane4 xs[8];
+            for (int b = 0; b < TG; ++b) atA[b] = arA[b], atB[b] = arB[b];
+            const int nmax = max(nA, nB);
+            for (int base = 0; base < nmax; base += 4) {      // 4 + 4 source rows in flight
+                Lane4 xa[4], xb[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    xs[u] = load4(x + (int64_t)__builtin_amdgcn_readlane(my_src, min(base + u, nwin - 1)) * ldx, TF, lane);
+                for (int u = 0; u < 4; ++u) {
+                    xa[u] = load4(x + (int64_t)__builtin_amdgcn_readlane(srcA, min(base + u, max(nA - 1, 0))) * ldx, TF, lane);
+                    xb[u] = load4(x + (int64_t)__builtin_amdgcn_readlane(srcB, min(base + u, max(nB - 1, 0))) * ldx, TF, lane);
+                }
 #pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    if (base + 2 * pr < nwin) {      // uniform
+                for (int u = 0; u < 4; ++u) {
+                    if (base + u < nmax) {      // uniform
+                        const int l = min(base + u, 63);
                         float part[16];
+                        Lane4 cA = {{0.f, 0.f, 0.f, 0.f}}, cB = {{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int l = min(base + 2 * pr + u, 63);
-                            Lane4 comb = {{0.f, 0.f, 0.f, 0.f}};
+                        for (int b = 0; b < TG; ++b) {
+                            part[b] = dot4(xa[u], dzA[b]);
+                            part[6 + b] = dot4(xb[u], dzB[b]);
+                            const float ca = rl(atA[b], l), cb = rl(atB[b], l);
 #pragma unroll
-                            for (int b = 0; b < TG; ++b) {
-                                part[6 * u + b] = dot4(xs[2 * pr + u], dz[b]);
-                                const float c = rl(at[b], l);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) comb.v[q] += c * dz[b].v[q];
-                            }
-                            part[6 * u + 5] = dot4(xs[2 * pr + u], comb);
+                            for (int q = 0; q < 4; ++q) cA.v[q] += ca * dzA[b].v[q], cB.v[q] += cb * dzB[b].v[q];
                         }
+                        part[5] = dot4(xa[u], cA);
+                        part[11] = dot4(xb[u], cB);
                         part[12] = part[13] = part[14] = part[15] = 0.f;
                         const float tot = butterfly16_sum(part, lane);
-                        const int eb = base + 2 * pr;
-                        const float n0 = rl(my_n, min(eb, 63)), n1 = rl(my_n, min(eb + 1, 63));
-                        if ((lane & 3) == 0 && entry < 12 && eb + eu < nwin) {
-                            const int64_t e = w0 + eb + eu;
+                        const float n0 = rl(nrA, l), n1 = rl(nrB, l);
+                        const bool ok = eu == 0 ? base + u < nA : base + u < nB;
+                        if ((lane & 3) == 0 && entry < 12 && ok) {
+                            const int64_t e = (eu == 0 ? eA0 : eB0) + wo + base + u;
                             if (ev < TG) TT[e * NB + g * TG + ev] = (eu ? n1 : n0) * tot;
                             else dn_slabs[(int64_t)g * dn_stride + e] = tot;
                         }
@@ -796,7 +821,9 @@ __global__ __launch_bounds__(512) void brgcn_bwd_target_tile_kernel(const float*
                 }
             }
         }
+        BR_STAMP(3);
     }
+    BR_STAMP(4);
 }
 
 // ------------------------------------------------------------------ basis RGCN in RELATION space (R <= 8)
@@ -1191,7 +1218,7 @@ extern "C" int erc_brgcn_bwd_edges_tile(const float* x, int ldx, int F, int O, i
         attr_set = true;
     }
     hipLaunchKernelGGL(brgcn_bwd_target_tile_kernel, dim3(erc_cdiv(N, 16), NGRP), dim3(512), lds, (hipStream_t)stream, x, ldx, N,
-                       in_ptr, in_src, in_typ, norm, att, basis, dH, lddh, TT, dn_slabs, dn_stride);
+                       in_ptr, in_src, in_typ, norm, att, basis, dH, lddh, TT, dn_slabs, dn_stride, g_brgcn_stamps ? g_brgcn_stamps + 8 : nullptr);
     ERC_LAUNCH_CHECK("brgcn_bwd_target_tile");
     hipLaunchKernelGGL(rel_sum_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, TT, in_typ, counts, datt);
     ERC_LAUNCH_CHECK("rel_sum");

@@ -15,7 +15,7 @@ def main():
     batch = tr.prepare_batch(synthetic_batch(params, 32, 33, seed=1))
     for _ in range(3):
         tr.train_step(batch)
-    st = torch.zeros(8, dtype=torch.int64, device="cuda:0")
+    st = torch.zeros(16, dtype=torch.int64, device="cuda:0")
     capi.brgcn_set_stamps(st)
     tr.train_step(batch)
     torch.cuda.synchronize()
@@ -26,6 +26,9 @@ def main():
     for k, n in enumerate(names):
         print("  %-48s %6.2f us" % (n, (t[k + 1] - t[k]) / 100.0))
     print("  total %.2f us" % ((t[5] - t[0]) / 100.0))
+    print("edge-side backward tile (thread 0 = wavefront 0):")
+    for k, n in enumerate(["dZ blocks (matrix cores)", "barrier", "dots, first node", "dots, second node"]):
+        print("  %-48s %6.2f us" % (n, (t[8 + k + 1] - t[8 + k]) / 100.0))
 
 
 main()
