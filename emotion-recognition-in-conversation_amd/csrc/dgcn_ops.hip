@@ -739,8 +739,8 @@ __global__ __launch_bounds__(512) void brgcn_bwd_target_tile_kernel(const float*
             }
         };
         // the weight fragments of the next tile are requested before the current tile's products (two register sets)
-        // (every request is consumed: a request left in flight at the end of the loop would land in registers that
-        // the next phase already uses for something else)
+        // (every request is consumed: a build that left clamped dummy requests in flight at the end of the loop was not
+        // bit-reproducible, DESIGN.md finding 30)
         float4 bA[DKB], bB[DKB];
         fetch_b(w, bA);
         for (int t = w; t < NTL; t += 16) {

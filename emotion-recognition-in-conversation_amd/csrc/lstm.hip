@@ -366,8 +366,8 @@ __global__ __launch_bounds__(NTH) void lstm_bwd_kernel(LstmP p) {
         __builtin_amdgcn_sched_barrier(0);
         if (s0 < L - 1) store_chunk(s0 + SC);
         __builtin_amdgcn_sched_barrier(0);
-        if (s0 - SC >= 0) load_chunk(s0 - SC, inB);      // only requests that will be consumed: one left in flight at the
-        __builtin_amdgcn_sched_barrier(0);               // end lands in registers the code behind the loop has reused
+        if (s0 - SC >= 0) load_chunk(s0 - SC, inB);      // only requests that will be consumed (DESIGN.md finding 30)
+        __builtin_amdgcn_sched_barrier(0);
         steps(s0, inA);
         if (s0 - SC >= 0) {
             __builtin_amdgcn_sched_barrier(0);

@@ -7,7 +7,7 @@ from erc_amd import capi
 from erc_amd.cogmen import build_graph_tensors
 DEV = "cuda:0"
 torch.manual_seed(0)
-B, T, S, NB, Fd, O = 6, 33, 9, 30, 200, 100
+B, T, S, NB, Fd, O = int(os.environ.get("NB_DLG", "6")), 33, 9, 30, 200, 100
 R = 2 * S * S
 lengths = torch.randint(1, T + 1, (B,))
 spk = torch.randint(0, S, (B, T))
@@ -34,7 +34,7 @@ put("xw", rng.standard_normal(N * XW).astype(np.float32)); put("norm", rng.rando
 put("att", (rng.standard_normal(R * NB) * 0.3).astype(np.float32)); put("basis", (rng.standard_normal(NB * Fd * O) * 0.1).astype(np.float32))
 put("root", (rng.standard_normal(Fd * O) * 0.1).astype(np.float32)); put("gout", (rng.standard_normal(N * O) * 0.1).astype(np.float32))
 ref = None
-for it in range(6):
+for it in range(int(os.environ.get("ITERS", "6"))):
     arena = torch.from_numpy(host.copy()).to(DEV)
     def v(k, *shape):
         o, n = views[k]
