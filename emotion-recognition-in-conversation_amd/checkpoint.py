@@ -50,7 +50,7 @@ def load_optimizer_state_dict(module, optim, sd):
         steps.add(int(float(st["step"])))
     if len(steps) > 1:
         raise ValueError("per-parameter step counts differ (%s): not an Adam state of one training run" % sorted(steps))
-    optim.state[0] = steps.pop() if steps else 0
+    optim.set_step(steps.pop() if steps else 0)
     groups = sd.get("param_groups") or [{}]
     optim.lr = groups[0].get("lr", optim.lr)
     optim.betas = tuple(groups[0].get("betas", optim.betas))

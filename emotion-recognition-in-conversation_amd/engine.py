@@ -321,12 +321,19 @@ class FusedAdam:
         self.weight_decay, self.decoupled, self.clip_norm = weight_decay, decoupled, clip_norm
         dev = flat.device
         # {step, rng offset, rng seed}
-        self.state = torch.tensor([0, 0, seed, 0], dtype=torch.int64, device=dev)
+        # {step, rng offset, rng seed, unused, one private copy of the step count per workgroup of the optimizer launch}
+        self.state = torch.zeros(4 + 512, dtype=torch.int64, device=dev)
+        self.state[2] = seed
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.norm_ws = torch.zeros(1024, dtype=torch.float32, device=dev)
         self.shadow = None   # (bf16 tensor, offset, numel): kept in sync with the fp32 master weights by the step
         self.shadow_table = None   # capi.ShadowTable: several bf16 ranges / layouts written by the same launch
         self.skip_flag = None  # device int32: non-zero = this step's gradients are invalid, the kernel skips the update
+
+    def set_step(self, step):
+        """step count by hand (checkpoint load): state[0] and the workgroups' private copies"""
+        self.state[0] = int(step)
+        self.state[4:] = int(step)
 
     @property
     def rng_state(self):

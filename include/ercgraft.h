@@ -365,8 +365,10 @@ int erc_head_ce(const float* Z, int ldz, int F, int C, int n_rows, const float* 
 /* ------------------------------------------------------------------------
  * S4  optimizer over the flat live-parameter buffer (torch.optim.Adam /
  * AdamW, track_mm/cogmen.py:50,187-189; dagerc.py:39,230-231).
- *   state: device int64 [4] = {step count, RNG offset, RNG seed, arrival counter (0 between calls)}; the
- *   call increments state[0] and state[1] (so state+1 is a valid rng_state).
+ *   state: device int64 [ERC_ADAM_STATE_WORDS = 4 + 512] = {step count, RNG offset, RNG seed, unused, then one private
+ *   copy of the step count per workgroup of the launch (all equal between calls)}; the call increments state[0], state[1]
+ *   (so state+1 is a valid rng_state) and the private copies.  Whoever sets the step count by hand (checkpoint load)
+ *   writes it to state[0] AND to state[4 .. 4+512).
  *   clip_norm > 0: grads are scaled by min(1, clip_norm/(gnorm+1e-6)) where
  *   gnorm[0] was produced by erc_grad_norm (clip_grad_norm_ semantics).
  *   decoupled != 0 -> AdamW (p *= 1 - lr*wd) else L2 (g += wd*p).
@@ -377,6 +379,7 @@ int erc_head_ce(const float* Z, int ldz, int F, int C, int n_rows, const float* 
  *   and the step counter stay as they are): the DAG-ERC recurrence kernels raise it when an exchange timed out, i.e.
  *   when this step's gradients are invalid -- the step fails on the device, no host synchronisation.
  */
+#define ERC_ADAM_STATE_WORDS (4 + 512)
 int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
                   float grad_scale, float clip_norm, const float* gnorm, int64_t* state,

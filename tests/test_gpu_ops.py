@@ -405,7 +405,8 @@ def test_fused_adam_matches_torch(capi, decoupled, wd, clip):
     opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref], lr=1e-3, weight_decay=wd)
     p = p0.clone().to(DEV)
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    state = torch.tensor([0, 0, 1, 0], dtype=torch.int64, device=DEV)
+    state = torch.zeros(4 + 512, dtype=torch.int64, device=DEV)      # ERC_ADAM_STATE_WORDS
+    state[2] = 1
     gnorm, ws = torch.zeros(1, device=DEV), torch.zeros(1024, device=DEV)
     for it in range(4):
         g = torch.randn(n) * (0.01 if it % 2 else 1.0)
@@ -419,7 +420,9 @@ def test_fused_adam_matches_torch(capi, decoupled, wd, clip):
             assert abs(float(gnorm) - float(g.norm())) < 1e-4 * float(g.norm())
         capi.adam_step(p, gd, m, v, n, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, 1.0, clip, gnorm if clip > 0 else None, state)
         _close(p, ref.detach(), 2e-6, 1e-5)
-    assert state.cpu().tolist() == [4, 4, 1, 0]
+    st = state.cpu().tolist()
+    n_wg = (n // 4 + 255) // 256
+    assert st[:4] == [4, 4, 1, 0] and st[4:4 + n_wg] == [4] * n_wg and not any(st[4 + n_wg:])
 
 
 def test_wgrad_table(capi):
