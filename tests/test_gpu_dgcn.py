@@ -240,6 +240,28 @@ def test_dgcn_relation_space_equals_basis_space():
         assert e < 1e-3, (n, e)
 
 
+def test_dgcn_fused_rgcn_equals_separate_kernels():
+    """Same module, same MELD-shaped batch (9 speakers: basis space): the three RGCN tile launches vs the separate kernels."""
+    from erc_amd.dgcn import DGCNModule
+    batch = to_device(make_batch(8, MELD, n_speakers=9, n_classes=7, min_len=1, max_len=33, seed=41, force_max=True), DEV)
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(6)
+        m = DGCNModule(9, input_size=1242, hidden_size=200, n_classes=7)
+        m.fused_rgcn_fwd = fused
+        m.finalize(DEV)
+        assert not m.relation_space
+        m.train()
+        m.drop_p, m.lstm.drop_p = 0.0, 0.0
+        stats = m.loss_and_grads(batch).clone().cpu()
+        outs.append((stats, m._last_ws["logits"].clone().cpu(), m))
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 2e-5
+    assert abs(float(outs[0][0][0] - outs[1][0][0])) < 1e-5
+    for n in outs[0][2].flat.params:
+        e = rel_err(outs[0][2].flat.g(n).cpu(), outs[1][2].flat.g(n).cpu())
+        assert e < 1e-3, (n, e)
+
+
 def _pair(case, compute="f32"):
     from oracle.dgcn import DGCNOracle
     from erc_amd.dgcn import DGCNModule
