@@ -193,7 +193,17 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     float* const sLg = &sT[0][0];  // [rt][cq][16 rows][8 classes] partial logits, dead before sT is written
     HF_STAMP(0);
     __shared__ __attribute__((aligned(16))) float sSaved[2 * HF_MAXF];
+    __shared__ __attribute__((aligned(16))) float sGB[2 * HF_MAXF];      // BNP: gamma | beta, staged with the first loads
 
+    // the H2 rows of the A fragments are requested first: they do not depend on the BatchNorm statistics computed below
+    const int m0 = ((int)blockIdx.x * 2 + rt) * 16;
+    const int mrow = m0 + r, mrc = min(mrow, N - 1);
+    f32x4 xh[HF_NT];
+#pragma unroll
+    for (int kb = 0; kb < HF_NT; ++kb) {
+        const int k0 = 16 * kb + 4 * g;
+        xh[kb] = *reinterpret_cast<const f32x4*>(p.H2 + (int64_t)mrc * p.ldh + (k0 < F ? k0 : 0));
+    }
     // ---- stage W0 (F x F) into LDS: F*F/4 <= 2500 float4 over 512 threads, all loads in flight
     {
         const int nq = F * F / 4, per_row = F / 4;
@@ -212,6 +222,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         //      Thread (pair = tid % 128 < F, part = tid / 128) takes two columns and a quarter of the tile list: one
         //      batch of 8-byte loads, in flight together with the W0 loads above.
         if (BNP) {
+            // gamma / beta -> LDS (visible behind the barriers below): the A fragments then need no global operand but H2
+            if (tid < 2 * (F / 4)) {
+                const int which = tid / (F / 4), q4 = tid - which * (F / 4);
+                *reinterpret_cast<f32x4*>(sGB + which * F + 4 * q4) = *reinterpret_cast<const f32x4*>((which ? p.beta : p.gamma) + 4 * q4);
+            }
             double* const sBn = reinterpret_cast<double*>(&sT[0][0]);   // [4][2][128] doubles = 8 KB of the tile area
             const int pair = tid & 127, part = tid >> 7;
             const int G = p.bn_tiles, Gq = (G + 3) >> 2;
@@ -274,8 +289,6 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     }
 
     // ---- P1: A fragments of H3 = lrelu(bn(H2)); lane (r,g): row m0 + r, k = 16 kb + 4 g + t
-    const int m0 = ((int)blockIdx.x * 2 + rt) * 16;
-    const int mrow = m0 + r, mrc = min(mrow, N - 1);
     float a1[HF_NT][4];
 #pragma unroll
     for (int kb = 0; kb < HF_NT; ++kb) {
@@ -283,10 +296,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         const bool kv = k0 < F;
         const int k0c = kv ? k0 : 0;
         const float km = kv ? 1.f : 0.f;
-        const f32x4 x = *reinterpret_cast<const f32x4*>(p.H2 + (int64_t)mrc * p.ldh + k0c);
+        const f32x4 x = xh[kb];
         const f32x4 mu = BNP ? *reinterpret_cast<const f32x4*>(sSaved + k0c) : *reinterpret_cast<const f32x4*>(p.saved + k0c);
         const f32x4 rs = BNP ? *reinterpret_cast<const f32x4*>(sSaved + F + k0c) : *reinterpret_cast<const f32x4*>(p.saved + F + k0c);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + k0c), be = *reinterpret_cast<const f32x4*>(p.beta + k0c);
+        const f32x4 ga = BNP ? *reinterpret_cast<const f32x4*>(sGB + k0c) : *reinterpret_cast<const f32x4*>(p.gamma + k0c);
+        const f32x4 be = BNP ? *reinterpret_cast<const f32x4*>(sGB + F + k0c) : *reinterpret_cast<const f32x4*>(p.beta + k0c);
         f32x4 h;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
