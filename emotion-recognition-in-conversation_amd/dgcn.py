@@ -84,6 +84,8 @@ class DGCNModule(nn.Module):
         # few relations (two speakers: 8 < 30 bases): RGCNConv in relation space, W_r composed first as models/rgcn.py:300-304
         # does (csrc/dgcn_ops.hip); None = decide in finalize() from the library's limit, True / False = forced (tests)
         self.relation_space = None
+        # the sequence encoder on compact rows (the sum(lengths) valid positions instead of B * T padded ones; rnn.py)
+        self.compact_lstm = True
         # basis space: aggregate + Z @ basis + x @ root as one tile launch (erc_brgcn_fwd_tile), and the node side of the
         # backward likewise (erc_brgcn_bwd_source_tile); False = the separate kernels + GEMMs (tests compare the two)
         self.fused_rgcn_fwd = True
@@ -165,9 +167,14 @@ class DGCNModule(nn.Module):
         x_bf16 = x.dtype == torch.bfloat16
         capi.window_graph_build(lens, spk, spk.stride(0), spk.stride(1), B, T, self.wp, self.wf, self.n_speakers, N,
                                 ws["E"], g)
-        self.lstm.forward(pl, x, D, BT, B, T, T, 1, lens, training, self.rng_state, ws["rnn_out"], G_DIM, x_bf16=x_bf16)
         Xc = ws["Xc"]
-        capi.gather_rows(ws["rnn_out"], G_DIM, g["node_row"], N, G_DIM, Xc, XW)
+        if self.compact_lstm:
+            # the BiLSTM on the N valid positions in node order (row = node_off[b] + t), written next to the graph output
+            self.lstm.forward(pl, x, D, N, B, T, T, 1, lens, training, self.rng_state, Xc, XW, x_bf16=x_bf16,
+                              node_off=g["node_off"], node_row=g["node_row"])
+        else:
+            self.lstm.forward(pl, x, D, BT, B, T, T, 1, lens, training, self.rng_state, ws["rnn_out"], G_DIM, x_bf16=x_bf16)
+            capi.gather_rows(ws["rnn_out"], G_DIM, g["node_row"], N, G_DIM, Xc, XW)
         # EdgeAtt: att = x W^T, softmax over each source's window
         capi.gemm_f32(Xc, XW, 0, None, fp.w("edge_att.weight"), G_DIM, 0, None, ws["ATT"], G_DIM, N, G_DIM, G_DIM)
         capi.edge_att_fwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"])
@@ -280,9 +287,12 @@ class DGCNModule(nn.Module):
         capi.gemm_f32(ws["DATT"], G_DIM, 0, None, fp.w("edge_att.weight"), G_DIM, 1, None, dXc, XW, N, G_DIM, G_DIM,
                       accumulate=1)
         # back to the padded rows and through the BiLSTM
-        ws["drnn"].zero_()
-        capi.gather_rows(dXc, XW, g["node_row"], N, G_DIM, ws["drnn"], G_DIM, scatter=1)
-        self.lstm.backward(pl, ws["drnn"], G_DIM)
+        if self.compact_lstm:
+            self.lstm.backward(pl, dXc, XW)
+        else:
+            ws["drnn"].zero_()
+            capi.gather_rows(dXc, XW, g["node_row"], N, G_DIM, ws["drnn"], G_DIM, scatter=1)
+            self.lstm.backward(pl, ws["drnn"], G_DIM)
         pl.reduce_into(ws, fp.grad)
         if self.relation_space:
             capi.basis_decompose(fp.w("gcn.conv1.att"), fp.w("gcn.conv1.basis"), ws["dWr"], self.R, NB, G_DIM * H1,

@@ -45,40 +45,45 @@ class BiLSTM2:
             self._ws[rows] = ws
         return ws
 
-    def forward(self, pl, x, ldx, rows, B, T, sb, st, lengths, training, rng, out, ldo, x_bf16=False):
-        """x [rows, d_in] (row(b,t) = b*sb + t*st) -> out [rows, 200] (row pitch ldo)."""
+    def forward(self, pl, x, ldx, rows, B, T, sb, st, lengths, training, rng, out, ldo, x_bf16=False, node_off=None,
+                node_row=None):
+        """x [*, d_in] -> out [rows, 200] (row pitch ldo).  Padded rows: row(b,t) = b*sb + t*st of x and of every buffer.
+        Compact rows (``node_off`` [B+1] and ``node_row`` [rows] given, packed sequences only): every buffer holds the
+        ``rows`` = sum(lengths) valid positions in dialogue order (row = node_off[b] + t), x is read through node_row --
+        the input projections, the saved state and the weight gradients shrink from B*T to sum(lengths) rows and the
+        caller needs no gather / scatter between the padded and the node layout (DialogueGCN)."""
         ws = self._buf(rows, out.device)
         p = self.drop_p if training else 0.0
-        linear_fwd(pl, x, ldx, None, self._w("weight_ih_l0"), self._w("bias_ih_l0"), ws["GX"][0], 8 * H, rows, 8 * H,
+        linear_fwd(pl, x, ldx, node_row, self._w("weight_ih_l0"), self._w("bias_ih_l0"), ws["GX"][0], 8 * H, rows, 8 * H,
                    self.d_in, x_bf16=x_bf16)
-        capi.lstm_scan_fwd(ws["GX"][0], 8 * H, self._w("weight_hh_l0"), self._w("bias_hh_l0"), lengths, None, sb, st,
+        capi.lstm_scan_fwd(ws["GX"][0], 8 * H, self._w("weight_hh_l0"), self._w("bias_hh_l0"), lengths, node_off, sb, st,
                            B, T, ws["H0"], 2 * H, ws["H0d"], 2 * H, p, rng, 0x5EED0, ws["gates"][0], ws["Cst"][0],
                            ws["Hprev"][0])
         linear_fwd(pl, ws["H0d"], 2 * H, None, self._w("weight_ih_l1"), self._w("bias_ih_l1"), ws["GX"][1], 8 * H, rows,
                    8 * H, 2 * H)
-        capi.lstm_scan_fwd(ws["GX"][1], 8 * H, self._w("weight_hh_l1"), self._w("bias_hh_l1"), lengths, None, sb, st,
+        capi.lstm_scan_fwd(ws["GX"][1], 8 * H, self._w("weight_hh_l1"), self._w("bias_hh_l1"), lengths, node_off, sb, st,
                            B, T, out, ldo, None, 0, 0.0, None, 0, ws["gates"][1], ws["Cst"][1], ws["Hprev"][1])
-        self._last = (x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16)
+        self._last = (x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16, node_off, node_row)
 
     def backward(self, pl, dout, lddo, dx=None, lddx=0):
         """dout = gradient wrt the layer-1 output.  Registers all weight-gradient jobs; optionally writes
         dx [rows, d_in] (needed when the LSTM input is itself trainable, MMGCN)."""
-        x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16 = self._last
+        x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16, node_off, node_row = self._last
         ws = self._buf(rows, dout.device)
         # one gate-gradient buffer per layer: every weight gradient of the LSTM then joins the step's ONE batched
         # weight-gradient launch (erc_wgrad_table) instead of 6 split-K GEMMs + a slab reduce per layer pair
         for k in (1, 0):
             dGX = ws["dGX"][k]
             if k == 1:
-                capi.lstm_scan_bwd(self._w("weight_hh_l1"), lengths, None, sb, st, B, T, ws["gates"][1], ws["Cst"][1],
+                capi.lstm_scan_bwd(self._w("weight_hh_l1"), lengths, node_off, sb, st, B, T, ws["gates"][1], ws["Cst"][1],
                                    dout, lddo, 0.0, None, 0, dGX)
-                xin, ldin, d_in, bf = ws["H0d"], 2 * H, 2 * H, False
+                xin, ldin, d_in, bf, gat = ws["H0d"], 2 * H, 2 * H, False, None
             else:
-                capi.lstm_scan_bwd(self._w("weight_hh_l0"), lengths, None, sb, st, B, T, ws["gates"][0], ws["Cst"][0],
+                capi.lstm_scan_bwd(self._w("weight_hh_l0"), lengths, node_off, sb, st, B, T, ws["gates"][0], ws["Cst"][0],
                                    ws["dH0d"], 2 * H, p, rng, 0x5EED0, dGX)
-                xin, ldin, d_in, bf = x, ldx, self.d_in, x_bf16
+                xin, ldin, d_in, bf, gat = x, ldx, self.d_in, x_bf16, node_row
             # W_ih (both directions stacked [800, d_in]) and b_ih
-            linear_wgrad(pl, dGX, 8 * H, xin, ldin, None, 8 * H, d_in, rows, self._off("weight_ih_l%d" % k),
+            linear_wgrad(pl, dGX, 8 * H, xin, ldin, gat, 8 * H, d_in, rows, self._off("weight_ih_l%d" % k),
                          self._off("bias_ih_l%d" % k), x_bf16=bf, defer=True)
             # W_hh per direction: dGX[:, 400d:]^T Hprev[:, 100d:]; b_hh receives the same gradient as b_ih = the column
             # sums of the direction's gate gradients (the bias strip of this product)
@@ -90,5 +95,7 @@ class BiLSTM2:
                 capi.gemm_f32(dGX, 8 * H, 0, None, self._w("weight_ih_l1"), 2 * H, 1, None, ws["dH0d"], 2 * H,
                               rows, 2 * H, 8 * H)
             elif dx is not None:
+                if node_row is not None:
+                    raise capi.ErcGraftError("BiLSTM2.backward: dx with compact rows is not built")
                 capi.gemm_f32(dGX, 8 * H, 0, None, self._w("weight_ih_l0"), self.d_in, 1, None, dx, lddx,
                               rows, self.d_in, 8 * H)

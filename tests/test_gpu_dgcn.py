@@ -241,7 +241,8 @@ def test_dgcn_relation_space_equals_basis_space():
 
 
 def test_dgcn_fused_rgcn_equals_separate_kernels():
-    """Same module, same MELD-shaped batch (9 speakers: basis space): the three RGCN tile launches vs the separate kernels."""
+    """Same module, same MELD-shaped batch (9 speakers: basis space): the three RGCN tile launches + the BiLSTM on compact
+    rows vs the separate kernels + the BiLSTM on padded rows."""
     from erc_amd.dgcn import DGCNModule
     batch = to_device(make_batch(8, MELD, n_speakers=9, n_classes=7, min_len=1, max_len=33, seed=41, force_max=True), DEV)
     outs = []
@@ -249,6 +250,7 @@ def test_dgcn_fused_rgcn_equals_separate_kernels():
         torch.manual_seed(6)
         m = DGCNModule(9, input_size=1242, hidden_size=200, n_classes=7)
         m.fused_rgcn_fwd = fused
+        m.compact_lstm = fused          # and the BiLSTM on compact rows vs padded rows + gather / scatter
         m.finalize(DEV)
         assert not m.relation_space
         m.train()
