@@ -218,6 +218,78 @@ def test_fused_rgcn_forward_tile_vs_unfused_and_reference_golden(golden, name):
         assert torch.equal(cpu(a), cpu(b2)), what
 
 
+@pytest.mark.parametrize("S", [2, 9])
+def test_rgcn_kernels_with_windows_wider_than_a_wavefront(S):
+    """Context +-40 over dialogues of up to 110 utterances: in / out degrees up to 81, i.e. more edges per node than the 64
+    lanes that hold a window's metadata -- the second pass of the window loops of the tile kernels (and, for two speakers,
+    of the relation-space kernels) against the separate basis-space kernels."""
+    from erc_amd import capi
+    from erc_amd.cogmen import build_graph_tensors
+    torch.manual_seed(11 + S)
+    B, T, NB, Fd, O = 5, 110, 30, 200, 100
+    R = 2 * S * S
+    lengths = torch.tensor([110, 3, 97, 66, 81], device=DEV)
+    spk = torch.randint(0, S, (B, T), device=DEV)
+    g, _, _ = build_graph_tensors(lengths, spk, 40, 40, S)
+    N, E = g["counts"].cpu().tolist()
+    assert int((g["in_ptr"][1:N + 1] - g["in_ptr"][:N]).max()) > 64
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    XW = Fd + O
+    xw, norm = torch.randn(N, XW, device=DEV), torch.rand(E, device=DEV)
+    comp, basis, root = torch.randn(R, NB, device=DEV) * 0.3, torch.randn(NB, Fd, O, device=DEV) * 0.1, torch.randn(Fd, O, device=DEV) * 0.1
+    bias, gout = torch.randn(O, device=DEV) * 0.1, torch.randn(N, O, device=DEV) * 0.1
+    cpu = lambda t: t.detach().cpu()
+    close = lambda a, b, tol=3e-5: float((cpu(a) - cpu(b)).abs().max()) <= tol * max(1.0, float(cpu(b).abs().max()))
+    # ---- separate basis-space kernels (the reference of this test)
+    Z = z(N, NB * Fd)
+    capi.brgcn_agg_fwd(xw, XW, Fd, N, g, norm, comp, NB, Z)
+    out = z(N, O)
+    capi.gemm_f32(Z, NB * Fd, 0, None, basis, O, 1, None, out, O, N, O, NB * Fd, bias=bias)
+    capi.gemm_f32(xw, XW, 0, None, root, O, 1, None, out, O, N, O, Fd, accumulate=1)
+    dZ = z(N, NB * Fd)
+    capi.gemm_f32(gout, O, 0, None, basis, O, 0, None, dZ, NB * Fd, N, NB * Fd, O)
+    dn, TT, datt = z(E), z(E, NB), z(R, NB)
+    capi.brgcn_bwd_edges(xw, XW, Fd, N, R, g, norm, comp, NB, dZ, dn, TT, datt)
+    U, basisT, dx = z(N, NB * O), z(NB * O, Fd), z(N, Fd)
+    capi.brgcn_bwd_source(gout, O, O, N, g, norm, comp, NB, U)
+    capi.transpose_batched(basis, NB, Fd, O, basisT)
+    capi.gemm_f32(U, NB * O, 0, None, basisT, Fd, 1, None, dx, Fd, N, Fd, NB * O)
+    capi.gemm_f32(gout, O, 0, None, root, O, 0, None, dx, Fd, N, Fd, O, accumulate=1)
+    # ---- tile kernels
+    Sg = capi.brgcn_fwd_tile_slabs()
+    Zt, sl, out_t = z(N, NB * Fd), z(Sg, N, O), z(N, O)
+    capi.poison_lds()
+    capi.brgcn_fwd_tile(xw, XW, Fd, O, N, g, norm, comp, NB, basis, root, Zt, sl)
+    capi.slab_reduce(sl, Sg, N * O, bias, O, 0, out_t, N * O)
+    assert torch.equal(cpu(Zt), cpu(Z)) and close(out_t, out)
+    dsl, dx_t = z(Sg, N, Fd), z(N, Fd)
+    capi.brgcn_bwd_source_tile(gout, O, Fd, O, N, g, norm, comp, NB, basis, root, dsl)
+    capi.slab_reduce(dsl, Sg, N * Fd, None, Fd, 4, dx_t, N * Fd)
+    assert close(dx_t, dx)
+    dnsl, TT_t, datt_t, dn_t = z(Sg, E), z(E, NB), z(R, NB), z(E)
+    capi.brgcn_bwd_edges_tile(xw, XW, Fd, O, N, R, g, norm, comp, NB, basis, gout, O, TT_t, dnsl, E, datt_t)
+    capi.slab_reduce(dnsl, Sg, E, None, 0, 0, dn_t, E)
+    assert close(dn_t, dn) and close(TT_t, TT) and close(datt_t, datt, 1e-4)
+    # ---- relation space (two speakers)
+    if R <= capi.rrgcn_max_relations():
+        Wr, WrT = z(R, Fd, O), z(R, O, Fd)
+        capi.basis_compose(comp, basis, R, NB, Fd, O, Wr, WrT)
+        Zr, out_r = z(N, R * Fd), z(N, O)
+        capi.rrgcn_agg_fwd(xw, XW, Fd, N, R, g, norm, Zr)
+        capi.gemm_f32(Zr, R * Fd, 0, None, Wr, O, 1, None, out_r, O, N, O, R * Fd, bias=bias)
+        capi.gemm_f32(xw, XW, 0, None, root, O, 1, None, out_r, O, N, O, Fd, accumulate=1)
+        assert close(out_r, out, 1e-4)
+        dZr, dn_r = z(N, R * Fd), z(E)
+        capi.gemm_f32(gout, O, 0, None, Wr, O, 0, None, dZr, R * Fd, N, R * Fd, O)
+        capi.rrgcn_bwd_edges(xw, XW, Fd, N, R, g, dZr, dn_r)
+        assert close(dn_r, dn, 1e-4)
+        Ur, dx_r = z(N, R * O), z(N, Fd)
+        capi.rrgcn_bwd_source(gout, O, O, N, R, g, norm, Ur)
+        capi.gemm_f32(Ur, R * O, 0, None, WrT, Fd, 1, None, dx_r, Fd, N, Fd, R * O)
+        capi.gemm_f32(gout, O, 0, None, root, O, 0, None, dx_r, Fd, N, Fd, O, accumulate=1)
+        assert close(dx_r, dx, 1e-4)
+
+
 def test_dgcn_relation_space_equals_basis_space():
     """Same module, same batch: RGCNConv in relation space (the default for two speakers) vs basis space."""
     from erc_amd.dgcn import DGCNModule
