@@ -340,8 +340,9 @@ def _pair(case, compute="f32"):
     from oracle.dgcn import DGCNOracle
     from erc_amd.dgcn import DGCNModule
     torch.manual_seed(case["seed"])
-    ref = DGCNOracle(case["S"], input_size=case["D"], hidden_size=200, n_classes=case["C"])
-    mine = DGCNModule(case["S"], input_size=case["D"], hidden_size=200, n_classes=case["C"], compute=compute)
+    ctx = case.get("context", (10, 10))
+    ref = DGCNOracle(case["S"], input_size=case["D"], hidden_size=200, n_classes=case["C"], context=ctx)
+    mine = DGCNModule(case["S"], input_size=case["D"], hidden_size=200, n_classes=case["C"], compute=compute, context=ctx)
     mine.load_state_dict(ref.state_dict())
     mine.finalize(DEV)
     return ref, mine
@@ -360,7 +361,11 @@ MELD = dict(a=300, t=600, v=342)      # meld-mmgcn-7 (mmbase.py:80-88)
     dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=13, weights=False, modality="t"),
     dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=14, weights=False, modality="v"),
     dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=15, weights=False, modality="at"),
-], ids=["tiny", "meld-1242", "iemocap-712", "meld-a-300", "meld-t-600", "meld-v-342", "meld-at-900"])
+    # context wider than a wavefront has lanes: in / out degrees up to 66 (window loops of the graph kernels take a second pass)
+    dict(B=3, lens=(80, 110), dims=dict(a=10, t=14, v=12), S=2, C=6, seed=22, weights=True, context=(40, 25)),
+    dict(B=3, lens=(80, 110), dims=dict(a=10, t=14, v=12), S=9, C=7, seed=23, weights=False, context=(40, 25)),
+], ids=["tiny", "meld-1242", "iemocap-712", "meld-a-300", "meld-t-600", "meld-v-342", "meld-at-900", "wide-context-s2",
+        "wide-context-s9"])
 def test_dgcn_module_parity_vs_oracle(case):
     from oracle.dgcn import IEMOCAP6_WEIGHTS
     modality = case.get("modality", "atv")
