@@ -19,7 +19,9 @@ def _runner(lstm, d_in):
     return BiLSTM2(flat, "rnn.", d_in, drop_p=0.4), flat, GemmPlanner(DEV, 1 << 24)
 
 
-@pytest.mark.parametrize("B,T,D,lens", [(4, 9, 20, [9, 1, 5, 7]), (32, 33, 1242, None), (3, 110, 712, [110, 20, 64])])
+@pytest.mark.parametrize("B,T,D,lens", [(4, 9, 20, [9, 1, 5, 7]), (32, 33, 1242, None), (3, 110, 712, [110, 20, 64]),
+                                        # lengths around the 8-step chunks of the recurrence kernels
+                                        (9, 25, 36, [25, 8, 16, 17, 15, 24, 1, 2, 9])])
 def test_packed_bilstm_matches_torch(B, T, D, lens):
     torch.manual_seed(B + T)
     lens = torch.tensor(lens) if lens else torch.randint(1, T + 1, (B,))
@@ -41,6 +43,43 @@ def test_packed_bilstm_matches_torch(B, T, D, lens):
     assert float((out.cpu().view(B, T, 200) - want.detach()).abs().max()) < 2e-5
     run.backward(pl, gout.to(DEV).view(B * T, 200), 200)
     from erc_amd import capi
+    capi.slab_reduce_batched(pl.ws, flat.grad, pl.job_table(), len(pl.jobs), pl.max_numel)
+    for name, p in lstm.named_parameters():
+        assert rel_err(flat.g("rnn." + name).cpu(), p.grad) < 1e-3, name
+
+
+@pytest.mark.parametrize("B,T,D", [(6, 20, 36), (32, 33, 1242)])
+def test_packed_bilstm_on_compact_rows_matches_torch(B, T, D):
+    """DialogueGCN layout: every LSTM buffer holds the sum(lengths) valid positions in node order (row = node_off[b] + t),
+    the input is read through the node -> padded-row map, the output lands in a wider block (row pitch 300)."""
+    from erc_amd import capi
+    torch.manual_seed(B * T)
+    lens = torch.randint(1, T + 1, (B,))
+    lens[0], lens[-1] = T, 8
+    x = torch.randn(B, T, D) * 0.5
+    lstm = torch.nn.LSTM(D, 100, dropout=0.4, bidirectional=True, num_layers=2, batch_first=True)
+    lstm.eval()
+    packed = pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False)
+    want, _ = pad_packed_sequence(lstm(packed, None)[0], batch_first=True, total_length=T)
+    gout = torch.randn(B, T, 200)
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    gout = gout * mask[:, :, None]
+    want.backward(gout)
+    N = int(lens.sum())
+    node_off = torch.zeros(B + 1, dtype=torch.int32)
+    node_off[1:] = torch.cumsum(lens, 0)
+    node_row = torch.cat([b * T + torch.arange(int(lens[b])) for b in range(B)]).to(torch.int32)
+    run, flat, pl = _runner(lstm, D)
+    XW = 300
+    out = torch.full((N, XW), 7.0, device=DEV)
+    run.forward(pl, x.to(DEV).view(B * T, D), D, N, B, T, T, 1, lens.to(DEV), False, None, out, XW,
+                node_off=node_off.to(DEV), node_row=node_row.to(DEV))
+    got = out.cpu()
+    assert float((got[:, :200] - want.detach()[mask]).abs().max()) < 2e-5
+    assert bool((got[:, 200:] == 7.0).all())               # the neighbouring columns are not touched
+    dout = torch.zeros(N, XW, device=DEV)
+    dout[:, :200] = gout[mask].to(DEV)
+    run.backward(pl, dout, XW)
     capi.slab_reduce_batched(pl.ws, flat.grad, pl.job_table(), len(pl.jobs), pl.max_numel)
     for name, p in lstm.named_parameters():
         assert rel_err(flat.g("rnn." + name).cpu(), p.grad) < 1e-3, name
