@@ -608,6 +608,22 @@ extern "C" int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const 
     hipStream_t st = (hipStream_t)stream;
     const bool ga = a_gather != nullptr, gb = b_gather != nullptr;
     const bool vec = (a_kmajor || p.a_vec) && (b_kmajor || p.b_vec);
+    // Long K over many rows (MMGCN's dH0 = DG [6 300, 12 800] x U^T [12 800, 200]): with 16 x 32 wave tiles every workgroup
+    // streams 2.4 MB of operands through the ~70 GB/s per-CU L2 path for 0.8 MFLOP x K/16 -- 6.7 GB in all, which is the
+    // launch's 381 us.  32 x 64 wave tiles halve the bytes per flop; these products are long enough that the longer
+    // per-wavefront chain (what made this tile lose on the skinny COGMEN shapes) does not matter.  4 wavefronts (8 spill
+    // 30 VGPRs at this tile); 64 x 64 tiles leave too few workgroups (MMGCN step 4.07 / 4.00 / 4.07 ms for 16x32 / 32x64 / 64x64).
+    static int big_tile = -1;
+    if (big_tile < 0) {
+        const char* e = getenv("ERC_GEMM_BIG_TILE");
+        big_tile = e ? atoi(e) : 1;
+    }
+    if (big_tile && !a_kmajor && !b_kmajor && !ga && !gb && vec && nw == 8 && K >= 4096 && Mlog >= 2048 && Nlog >= 64) {
+        dim3 grid2(erc_cdiv(Nlog, 64), erc_cdiv(Mlog, 32), split_k);
+        hipLaunchKernelGGL((gemm_f32_stream_kernel<0, 0, 4, false, false, true, 2, 4>), grid2, dim3(256), 0, st, p);
+        ERC_LAUNCH_CHECK("gemm_f32_stream");
+        return ERC_OK;
+    }
 #define ERC_SL4(AM, BM_, NW_, GA_, GB_, V_) \
     hipLaunchKernelGGL((gemm_f32_stream_kernel<AM, BM_, NW_, GA_, GB_, V_, 1, 2>), grid, dim3(64 * NW_), 0, st, p)
 #define ERC_SL3(AM, BM_, GA_, GB_, V_)                        \
