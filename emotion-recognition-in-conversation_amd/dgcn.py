@@ -134,7 +134,7 @@ class DGCNModule(nn.Module):
         g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E),
                  in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
         ws = dict(g=g, E=E, rnn_out=f32(BT, G_DIM), Xc=f32(N, G_DIM + H1), ATT=f32(N, G_DIM), norm=f32(E),
-                  Z=f32(N, self._kb * G_DIM), Hc=f32(N, H1), AGG=f32(N, H1), Zc=f32(N, 100), logits=f32(N, C), stats=torch.zeros(256, dtype=torch.float32, device=device),
+                  Z=f32(N, self._kb * G_DIM), Hc=f32(N, H1), AGG=f32(N, H1), Zc=f32(N, 100), logits=f32(N, C), stats=torch.zeros(max(256, capi.head_ce_stats_floats(N)), dtype=torch.float32, device=device),
                   dlogits=f32(N, C), dZc=f32(N, 100), dXc=f32(N, G_DIM + H1), dAGG=f32(N, H1), dHc=f32(N, H1),
                   dZ=f32(N, self._kb * G_DIM), dnorm=f32(E), TT=f32(E, NB), U=f32(N, self._kb * H1),
                   basisT=f32(self._kb * H1, G_DIM), Wr=f32(self._kb * G_DIM, H1), dWr=f32(self._kb * G_DIM, H1),
@@ -158,7 +158,7 @@ class DGCNModule(nn.Module):
         N = int(label.shape[0]) if label is not None else (int(n_nodes) if n_nodes is not None else int(lens.sum().item()))
         return B, T, N
 
-    def _forward_impl(self, x, spk, lens, B, T, N, training):
+    def _forward_impl(self, x, spk, lens, B, T, N, training, with_logits=True):
         fp = self.flat
         ws = self._workspace(B, T, N, x.device)
         g, pl = ws["g"], ws["planner"]
@@ -212,7 +212,8 @@ class DGCNModule(nn.Module):
         p = self.drop_p if training else 0.0
         linear_fwd(pl, Xc, XW, None, fp.w("clf.lin1.weight"), fp.w("clf.lin1.bias"), ws["Zc"], 100, N, 100, XW,
                    act=3 if p > 0 else 1, drop_p=p, rng=self.rng_state)
-        linear_fwd(pl, ws["Zc"], 100, None, fp.w("clf.lin2.weight"), fp.w("clf.lin2.bias"), ws["logits"], C, N, C, 100)
+        if with_logits:      # the training step computes them together with the loss and its gradient (erc_head_ce)
+            linear_fwd(pl, ws["Zc"], 100, None, fp.w("clf.lin2.weight"), fp.w("clf.lin2.bias"), ws["logits"], C, N, C, 100)
         return ws
 
     def forward(self, input_tensor, speaker_tensor, text_length, label=None, **kwargs):
@@ -226,15 +227,21 @@ class DGCNModule(nn.Module):
         x, spk, lens, ys = batch["input_tensor"], batch["speaker_tensor"], batch["text_length"], batch["label"]
         B, T, N = self._shape(x, lens, ys)
         training = self.training
-        ws = self._forward_impl(x, spk, lens, B, T, N, training)
+        fused_tail = self.n_classes <= 8
+        ws = self._forward_impl(x, spk, lens, B, T, N, training, with_logits=not fused_tail)
         fp, g, pl, off = self.flat, ws["g"], ws["planner"], self.flat.offsets
         C, BT, XW = self.n_classes, B * T, G_DIM + H1
         Xc, dXc = ws["Xc"], ws["dXc"]
-        capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
         p = self.drop_p if training else 0.0
         # classifier
-        capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("clf.lin2.weight"), 100, 1, None, ws["dZc"], 100, N, 100, C,
-                      act=2, aux=ws["Zc"], ldaux=100, act_scale=1.0 / (1.0 - p))
+        if fused_tail:
+            # lin2 + cross entropy + their backward through the ReLU / dropout mask in one launch (dgcn_models.py:163-170)
+            capi.head_ce(ws["Zc"], 100, 100, C, N, fp.w("clf.lin2.weight"), fp.w("clf.lin2.bias"), ys, class_weight,
+                         1.0 / (1.0 - p), ws["logits"], C, ws["dlogits"], C, ws["dZc"], 100, ws["stats"])
+        else:
+            capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
+            capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("clf.lin2.weight"), 100, 1, None, ws["dZc"], 100, N, 100, C,
+                          act=2, aux=ws["Zc"], ldaux=100, act_scale=1.0 / (1.0 - p))
         linear_wgrad(pl, ws["dlogits"], C, ws["Zc"], 100, None, C, 100, N, off["clf.lin2.weight"], off["clf.lin2.bias"], defer=True)
         capi.gemm_f32(ws["dZc"], 100, 0, None, fp.w("clf.lin1.weight"), XW, 1, None, dXc, XW, N, XW, 100)
         linear_wgrad(pl, ws["dZc"], 100, Xc, XW, None, 100, XW, N, off["clf.lin1.weight"], off["clf.lin1.bias"], defer=True)
