@@ -425,6 +425,36 @@ def test_fused_adam_matches_torch(capi, decoupled, wd, clip):
     assert st[:4] == [4, 4, 1, 0] and st[4:4 + n_wg] == [4] * n_wg and not any(st[4 + n_wg:])
 
 
+@pytest.mark.parametrize("C,weighted,p", [(6, True, 0.5), (7, False, 0.0), (4, True, 0.0)])
+def test_head_ce_matches_torch(capi, C, weighted, p):
+    """erc_head_ce: last Linear + F.cross_entropy + their backward through the ReLU / inverted-dropout mask in one launch
+    (dgcn_models.py:163-170) against torch autograd."""
+    torch.manual_seed(C)
+    N, Fh = 531, 100
+    pre = torch.randn(N, Fh)
+    keep = (torch.rand(N, Fh) >= p).float() / (1.0 - p) if p > 0 else torch.ones(N, Fh)
+    W, b = torch.randn(C, Fh) * 0.2, torch.randn(C) * 0.1
+    y = torch.randint(0, C, (N,))
+    w = torch.rand(C) + 0.5 if weighted else None
+    pre_t = pre.clone().requires_grad_(True)
+    Z = torch.relu(pre_t) * keep
+    logits = Z @ W.t() + b
+    logits.retain_grad()
+    loss = torch.nn.functional.cross_entropy(logits, y, weight=w)
+    loss.backward()
+    Zd = Z.detach().to(DEV)
+    out_l, out_dl, out_dz = torch.zeros(N, C, device=DEV), torch.zeros(N, C, device=DEV), torch.zeros(N, Fh, device=DEV)
+    stats = torch.zeros(capi.head_ce_stats_floats(N), device=DEV)
+    for _ in range(2):      # twice: the arrival counter in stats must be back at zero
+        capi.head_ce(Zd, Fh, Fh, C, N, W.to(DEV), b.to(DEV), y.to(DEV), w.to(DEV) if weighted else None, 1.0 / (1.0 - p),
+                     out_l, C, out_dl, C, out_dz, Fh, stats)
+    _close(out_l, logits.detach(), 2e-5, 1e-5)
+    _close(out_dl, logits.grad, 1e-6, 1e-4)
+    _close(out_dz, pre_t.grad, 2e-6, 1e-4)       # = dZ through relu and the dropout mask
+    st = stats.cpu()
+    assert abs(float(st[0]) - float(loss.detach())) < 2e-5 and int(st[1]) == int((logits.argmax(-1) == y).sum())
+
+
 def test_wgrad_table(capi):
     """erc_wgrad_table: several dW = A^T B[gather] products in one launch (fp32 / bf16 B, bias strips, vector and
     scalar access paths, split and unsplit K), launched twice to check that the arrival counters are left zero."""
