@@ -88,6 +88,8 @@ _SIGS = {
                                     _vp]),
     "erc_gather_rows": (C.c_int, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp]),
     "erc_edge_att_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "erc_edge_att_bwd_parts": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_int64, _vp, _i, _i,
+                                         _vp, _i, _vp, _vp]),
     "erc_edge_att_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i,
                                    _vp, _vp]),
     "erc_brgcn_agg_fwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -544,11 +546,12 @@ def edge_att_fwd(x, ldx, att, lda, F, N, g, norm):
                                   ptr(g["out_eid"]), ptr(norm), stream()), "erc_edge_att_fwd")
 
 
-def edge_att_bwd(x, ldx, att, lda, F, N, g, norm, dnorm, dx, lddx, accumulate_dx, datt, ldda, dscore):
-    _check(lib().erc_edge_att_bwd(ptr(x), ldx, ptr(att), lda, F, N, ptr(g["in_ptr"]), ptr(g["in_src"]),
-                                  ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_eid"]), ptr(norm), ptr(dnorm),
-                                  ptr(dx), lddx, accumulate_dx, ptr(datt), ldda, ptr(dscore), stream()),
-           "erc_edge_att_bwd")
+def edge_att_bwd(x, ldx, att, lda, F, N, g, norm, dnorm, dx, lddx, accumulate_dx, datt, ldda, dscore, dn_parts=1, dn_stride=0):
+    """dn_parts > 1: dnorm holds that many partial vectors, dn_stride floats apart (erc_brgcn_bwd_edges_tile's slabs)"""
+    _check(lib().erc_edge_att_bwd_parts(ptr(x), ldx, ptr(att), lda, F, N, ptr(g["in_ptr"]), ptr(g["in_src"]),
+                                        ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_eid"]), ptr(norm), ptr(dnorm),
+                                        dn_parts, dn_stride, ptr(dx), lddx, accumulate_dx, ptr(datt), ldda, ptr(dscore),
+                                        stream()), "erc_edge_att_bwd_parts")
 
 
 def brgcn_agg_fwd(x, ldx, F, N, g, norm, att, nb, Z):

@@ -82,19 +82,26 @@ __global__ __launch_bounds__(256) void edge_att_bwd_source_kernel(const float* _
                                                                   const int32_t* __restrict__ out_eid,
                                                                   const float* __restrict__ norm,
                                                                   const float* __restrict__ dnorm, float* __restrict__ dx,
-                                                                  int lddx, float* __restrict__ dscore, int accumulate) {
+                                                                  int lddx, float* __restrict__ dscore, int accumulate,
+                                                                  int dn_parts, int64_t dn_stride) {
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= N) return;
     const int e0 = out_ptr[j], e1 = out_ptr[j + 1];
+    // d norm may arrive as dn_parts partial vectors (the basis groups of erc_brgcn_bwd_edges_tile), summed here in order
+    auto dn = [&](int id) {
+        float v = dnorm[id];
+        for (int s = 1; s < dn_parts; ++s) v += dnorm[(int64_t)s * dn_stride + id];
+        return v;
+    };
     float t = 0.f;
-    for (int e = e0 + lane; e < e1; e += 64) t += norm[out_eid[e]] * dnorm[out_eid[e]];
+    for (int e = e0 + lane; e < e1; e += 64) t += norm[out_eid[e]] * dn(out_eid[e]);
     t = wave_sum(t);
     Lane4 acc = {{0.f, 0.f, 0.f, 0.f}};
     for (int w0 = e0; w0 < e1; w0 += 64) {      // lane-parallel edge metadata, then 8 attention rows per batch
         const int nwin = min(64, e1 - w0);
         const int el = w0 + min(lane, nwin - 1);
         const int id = out_eid[el], my_dst = out_dst[el];
-        const float my_ds = lane < nwin ? norm[id] * (dnorm[id] - t) : 0.f;
+        const float my_ds = lane < nwin ? norm[id] * (dn(id) - t) : 0.f;
         if (lane < nwin) dscore[id] = my_ds;
         for (int base = 0; base < nwin; base += EB) {
             Lane4 a[EB];
@@ -1087,15 +1094,31 @@ extern "C" int erc_edge_att_fwd(const float* x, int ldx, const float* att, int l
     return ERC_OK;
 }
 
+extern "C" int erc_edge_att_bwd_parts(const float* x, int ldx, const float* att, int lda, int F, int N, const int32_t* in_ptr,
+                                      const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                      const int32_t* out_eid, const float* norm, const float* dnorm, int dn_parts,
+                                      int64_t dn_stride, float* dx, int lddx, int accumulate_dx, float* datt, int ldda,
+                                      float* dscore, void* stream);
+
 extern "C" int erc_edge_att_bwd(const float* x, int ldx, const float* att, int lda, int F, int N, const int32_t* in_ptr,
                                 const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                 const int32_t* out_eid, const float* norm, const float* dnorm, float* dx, int lddx,
                                 int accumulate_dx, float* datt, int ldda, float* dscore, void* stream) {
+    return erc_edge_att_bwd_parts(x, ldx, att, lda, F, N, in_ptr, in_src, out_ptr, out_dst, out_eid, norm, dnorm, 1, 0, dx, lddx,
+                                  accumulate_dx, datt, ldda, dscore, stream);
+}
+
+extern "C" int erc_edge_att_bwd_parts(const float* x, int ldx, const float* att, int lda, int F, int N, const int32_t* in_ptr,
+                                      const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                      const int32_t* out_eid, const float* norm, const float* dnorm, int dn_parts,
+                                      int64_t dn_stride, float* dx, int lddx, int accumulate_dx, float* datt, int ldda,
+                                      float* dscore, void* stream) {
+    ERC_REQUIRE(dn_parts >= 1 && (dn_parts == 1 || dn_stride > 0), "edge_att_bwd: dn_parts=%d", dn_parts);
     ERC_REQUIRE(x && att && in_ptr && in_src && out_ptr && out_dst && out_eid && norm && dnorm && dx && datt && dscore,
                 "edge_att_bwd: null pointer");
     ERC_REQUIRE(N > 0 && F > 0 && F <= 256, "edge_att_bwd: N=%d F=%d", N, F);
     hipLaunchKernelGGL(edge_att_bwd_source_kernel, NODE_GRID(N), att, lda, F, N, out_ptr, out_dst, out_eid, norm, dnorm,
-                       dx, lddx, dscore, accumulate_dx);
+                       dx, lddx, dscore, accumulate_dx, dn_parts, dn_stride);
     ERC_LAUNCH_CHECK("edge_att_bwd_source");
     hipLaunchKernelGGL(edge_att_bwd_target_kernel, NODE_GRID(N), x, ldx, F, N, in_ptr, in_src, dscore, datt, ldda);
     ERC_LAUNCH_CHECK("edge_att_bwd_target");

@@ -256,6 +256,7 @@ class DGCNModule(nn.Module):
         # RGCNConv(basis)
         KB = self._kb
         K1 = KB * G_DIM
+        dn_src, dn_parts, dn_stride = ws["dnorm"], 1, 0
         if self.relation_space:
             capi.gemm_f32(ws["dHc"], H1, 0, None, ws["Wr"], H1, 0, None, ws["dZ"], K1, N, K1, H1)
             capi.rrgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["dZ"], ws["dnorm"])
@@ -269,7 +270,7 @@ class DGCNModule(nn.Module):
                 capi.brgcn_bwd_edges_tile(Xc, XW, G_DIM, H1, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB,
                                           fp.w("gcn.conv1.basis"), ws["dHc"], H1, ws["TT"], ws["dn_slabs"], E_cap,
                                           fp.g("gcn.conv1.att"))
-                capi.slab_reduce(ws["dn_slabs"], capi.brgcn_fwd_tile_slabs(), E_cap, None, 0, 0, ws["dnorm"], E_cap)
+                dn_src, dn_parts, dn_stride = ws["dn_slabs"], capi.brgcn_fwd_tile_slabs(), E_cap      # summed by edge_att_bwd
             else:
                 capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.basis"), H1, 0, None, ws["dZ"], K1, N, K1, H1)
                 capi.brgcn_bwd_edges(Xc, XW, G_DIM, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB, ws["dZ"], ws["dnorm"],
@@ -288,8 +289,8 @@ class DGCNModule(nn.Module):
             capi.gemm_f32(ws["U"], KB * H1, 0, None, ws["basisT"], G_DIM, 1, None, dXc, XW, N, G_DIM, KB * H1, accumulate=1)
             capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.root"), H1, 0, None, dXc, XW, N, G_DIM, H1, accumulate=1)
         # EdgeAtt
-        capi.edge_att_bwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"], ws["dnorm"], dXc, XW, 1, ws["DATT"], G_DIM,
-                          ws["dscore"])
+        capi.edge_att_bwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"], dn_src, dXc, XW, 1, ws["DATT"], G_DIM,
+                          ws["dscore"], dn_parts=dn_parts, dn_stride=dn_stride)
         linear_wgrad(pl, ws["DATT"], G_DIM, Xc, XW, None, G_DIM, G_DIM, N, off["edge_att.weight"], None, defer=True)
         capi.gemm_f32(ws["DATT"], G_DIM, 0, None, fp.w("edge_att.weight"), G_DIM, 1, None, dXc, XW, N, G_DIM, G_DIM,
                       accumulate=1)

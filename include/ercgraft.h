@@ -609,6 +609,13 @@ int erc_edge_att_bwd(const float* x, int ldx, const float* att, int lda, int F, 
                      const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
                      const float* norm, const float* dnorm, float* dx, int lddx, int accumulate_dx,
                      float* datt, int ldda, float* dscore, void* stream);
+/* the same with d norm given as dn_parts partial vectors dnorm[s * dn_stride + e] (the basis groups of
+ * erc_brgcn_bwd_edges_tile), summed in order while they are read */
+int erc_edge_att_bwd_parts(const float* x, int ldx, const float* att, int lda, int F, int N,
+                           const int32_t* in_ptr, const int32_t* in_src,
+                           const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                           const float* norm, const float* dnorm, int dn_parts, int64_t dn_stride, float* dx, int lddx,
+                           int accumulate_dx, float* datt, int ldda, float* dscore, void* stream);
 /* basis-decomposed RGCNConv with edge_norm, add aggregation (models/rgcn.py:329-355), num_bases = 30:
  *   Z[i, b*F + c] = sum_{e into i} norm_e att[type_e, b] x[src_e, c]      so that
  *   conv(x) = Z @ basis.view(30F, out) + x @ root + bias                  (two GEMMs by the caller). */
