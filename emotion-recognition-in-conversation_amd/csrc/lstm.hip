@@ -142,24 +142,28 @@ __global__ __launch_bounds__(NTH) void lstm_fwd_kernel(LstmP p) {
     // packed multiply-add whose unused operand half happens to be the register next to it waits for the request.)
     __shared__ float s_gx[2][SC][NTH];
     float gx_cur[SC], o_gate[SC], o_unit[SC];
+    // per-lane pointers advanced by uniform steps: a store or request is then ~6 instructions, not 30 - 50 of 64-bit row
+    // arithmetic (steps past the end of the dialogue are skipped by a uniform branch; requests are clamped to the last row)
+    const int64_t gx_step = dstep * p.ldgx, gate_step = dstep * (2 * G4);
     auto request_chunk = [&](int c0, int buf) {
         float* dst = &s_gx[buf][0][tid & ~63];
+        const float* src = p.GX + (row_first + (int64_t)c0 * dstep) * p.ldgx + gcol;
+        const float* last = p.GX + (row_first + (int64_t)(L - 1) * dstep) * p.ldgx + gcol;
 #pragma unroll
         for (int r = 0; r < SC; ++r) {
-            const float* grow_p = p.GX + (row_first + (int64_t)min(c0 + r, L - 1) * dstep) * p.ldgx;      // uniform
-            __builtin_amdgcn_global_load_lds(grow_p + gcol, (lds_void*)(dst + r * NTH), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds(c0 + r < L ? src : last, (lds_void*)(dst + r * NTH), 4, 0, 0);
+            src += gx_step;
         }
     };
     if (L > 0) request_chunk(0, 0);
     auto store_chunk = [&](int c0) {
         float* up = uptr0 + c0 * ustep;
+        float* gp = p.gates + (row_first + (int64_t)c0 * dstep) * (2 * G4) + gcol;
+        int64_t row = row_first + (int64_t)c0 * dstep;
 #pragma unroll
         for (int r = 0; r < SC; ++r) {
-            const int s = c0 + r;
-            if (s < L) {       // uniform
-                const int64_t row = row_first + (int64_t)s * dstep;
-                float* grow_p = p.gates + row * 2 * G4;      // uniform
-                if (live) grow_p[gcol] = o_gate[r];
+            if (c0 + r < L) {       // uniform
+                if (live) *gp = o_gate[r];
                 float val = o_unit[r];
                 if (dropping) {    // uniform
                     const float uu = erc_uniform(rseed, roff, (uint64_t)row * 2 * H + d * H + uc);
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(NTH) void lstm_fwd_kernel(LstmP p) {
                 }
                 if (ostore) *up = val;
             }
-            up += ustep;
+            up += ustep, gp += gate_step, row += dstep;
         }
     };
     unsigned long long t_c0 = 0, t_r0 = 0;
