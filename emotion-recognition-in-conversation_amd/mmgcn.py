@@ -197,6 +197,12 @@ class MMGCNModule(nn.Module):
         X = ws["X"]
         for mi, m in enumerate(self.order):
             x = feats[m].reshape(TB, self.dims[m])
+            if m != "t":
+                # audio / visual: Linear only -- computed for the N valid utterances straight into node order (the padded rows
+                # and the gather behind them are not needed; the text branch keeps them for its unpacked LSTM)
+                linear_fwd(pl, x, self.dims[m], ws["node_row"], fp.w(_LIN[m] + ".weight"), fp.w(_LIN[m] + ".bias"),
+                           X[mi * N:], FD, N, FD, self.dims[m])
+                continue
             linear_fwd(pl, x, self.dims[m], None, fp.w(_LIN[m] + ".weight"), fp.w(_LIN[m] + ".bias"), ws["LIN"][m], FD, TB,
                        FD, self.dims[m])
             src = ws["LIN"][m]
@@ -360,6 +366,11 @@ class MMGCNModule(nn.Module):
         # per modality: back to the padded [T,B] rows, (speaker embedding, BiLSTM,) Linear
         for mi, m in enumerate(self.order):
             dm = dX[mi * N:]
+            x = feats[m].reshape(TB, self.dims[m])
+            if m != "t":
+                linear_wgrad(pl, dm, FD, x, self.dims[m], ws["node_row"], FD, self.dims[m], N, off[_LIN[m] + ".weight"],
+                             off[_LIN[m] + ".bias"])
+                continue
             dpad = ws["dLIN"][m]
             dpad.zero_()
             capi.gather_rows(dm, FD, ws["node_row"], N, FD, dpad, FD, scatter=1)
