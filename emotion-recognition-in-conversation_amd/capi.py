@@ -70,8 +70,8 @@ _SIGS = {
     "erc_head_ce": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _i64, _i64,
                                 _vp, _vp]),
-    "erc_adam_step_tab": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "erc_shadow_refresh": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "erc_adam_step_tab": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "erc_shadow_refresh": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "erc_cogmen_fwd_tile_ws_doubles": (C.c_int64, [_i]),
     "erc_cogmen_set_stamps": (C.c_int, [_vp]),
     "erc_head_set_stamps": (C.c_int, [_vp]),
@@ -136,16 +136,18 @@ _SIGS = {
     "erc_gcnii_chain_prep": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
     "erc_gcnii_chain_config": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "erc_gcnii_chain_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i, _vp, _vp,
-                                      _f, _vp, C.c_uint64, _vp]),
+                                      _vp, _f, _vp, C.c_uint64, _vp]),
     "erc_gcnii_chain_bwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _vp,
-                                      _vp, _f, _vp]),
+                                      _vp, _vp, _f, _vp]),
     "erc_dag_meta": (C.c_int, [_vp, _vp, _i64, _i64, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_dag_rec_config": (C.c_int, [_i, _i, _i, _i, _i, _i, _i, _vp]),
     "erc_dag_rec_scratch_bytes": (C.c_int64, [_i, _i, _i, _vp]),
     "erc_dag_rec_set_stamps": (C.c_int, [_vp]),
-    "erc_dag_rec_fwd": (C.c_int, [_vp, _i, _i] + [_vp] * 8 + [_vp, _vp, _i, _i, _vp, _i, _vp, _i] + [_vp] * 5 + [_vp, _vp, _vp, _vp]),
+    "erc_dag_rec_fwd": (C.c_int, [_vp, _i, _i] + [_vp] * 8 + [_vp, _vp, _i, _i, _vp, _i, _vp, _i] + [_vp] * 5 + [_vp, _vp, _vp, _vp, _vp]),
     "erc_dag_rec_bwd": (C.c_int, [_i, _vp, _i, _vp, _i] + [_vp] * 9 + [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp,
-                                  _vp, _vp, _vp, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp]),
+    "erc_health_roll": (C.c_int, [_vp, _vp, _vp]),
+    "erc_gcnii_chain_set_spin_limit": (C.c_int, [_i]),
     "erc_dag_attn_sums": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
 }
 
@@ -211,7 +213,7 @@ def lib():
                     _record.append((_name, a))
                 return _fn(*a)
             setattr(rec, name, call)
-        if handle.erc_abi_version() != 1:
+        if handle.erc_abi_version() != 2:
             raise ErcGraftError("libercgraft ABI version mismatch")
         _raw, _lib = handle, rec
     return _lib
@@ -397,12 +399,24 @@ def mfma_b_fragment_order(W, n_kblocks):
 
 def adam_step_tab(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, clip_norm, gnorm, state, table, skip_flag=None):
     _check(lib().erc_adam_step_tab(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale,
-                                   clip_norm, ptr(gnorm), ptr(state), ptr(table.buf), table.tab_ptr, ptr(skip_flag),
+                                   clip_norm, ptr(gnorm), ptr(state), ptr(table.buf), table.buf.numel(), table.tab_ptr, ptr(skip_flag),
                                    stream()), "erc_adam_step_tab")
 
 
+def health_roll(health, events):
+    """start of a step: a health word still raised becomes one event, the word is cleared (ercgraft.h)"""
+    _check(lib().erc_health_roll(ptr(health), ptr(events), stream()), "erc_health_roll")
+
+
+HEALTH_RAISED = 0x3f800000
+
+
+def gcnii_chain_set_spin_limit(limit):
+    _check(lib().erc_gcnii_chain_set_spin_limit(int(limit)), "erc_gcnii_chain_set_spin_limit")
+
+
 def shadow_refresh(p, n, table):
-    _check(lib().erc_shadow_refresh(ptr(p), n, ptr(table.buf), table.tab_ptr, stream()), "erc_shadow_refresh")
+    _check(lib().erc_shadow_refresh(ptr(p), n, ptr(table.buf), table.buf.numel(), table.tab_ptr, stream()), "erc_shadow_refresh")
 
 
 def cogmen_set_stamps(t):
@@ -458,15 +472,16 @@ def gcnii_chain_config(B, T, Mo, P):
 
 
 def gcnii_chain_fwd(ADJ, P, CR, node_off, N, Mo, B, T, cfg, VT, Call, ldc, HD, hd_plane, ZS, lds, ZX, state, drop_p, rng,
-                    rng_stream0):
+                    rng_stream0, health=None):
     _check(lib().erc_gcnii_chain_fwd(ptr(ADJ), P, ptr(CR), ptr(node_off), N, Mo, B, T, cfg[0], cfg[1], cfg[2], ptr(VT), ptr(Call),
-                                     ldc, ptr(HD), hd_plane, ptr(ZS), lds, ptr(ZX), ptr(state), drop_p, ptr(rng), rng_stream0,
+                                     ldc, ptr(HD), hd_plane, ptr(ZS), lds, ptr(ZX), ptr(state), ptr(health), drop_p, ptr(rng), rng_stream0,
                                      stream()), "erc_gcnii_chain_fwd")
 
 
-def gcnii_chain_bwd(ADJ, P, CR, node_off, N, Mo, B, T, cfg, V, HD, hd_plane, dHin, dHout, DG, DZ, lds, ZX, state, drop_p):
+def gcnii_chain_bwd(ADJ, P, CR, node_off, N, Mo, B, T, cfg, V, HD, hd_plane, dHin, dHout, DG, DZ, lds, ZX, state, drop_p,
+                    health=None):
     _check(lib().erc_gcnii_chain_bwd(ptr(ADJ), P, ptr(CR), ptr(node_off), N, Mo, B, T, cfg[0], cfg[1], cfg[2], ptr(V), ptr(HD),
-                                     hd_plane, ptr(dHin), ptr(dHout), ptr(DG), ptr(DZ), lds, ptr(ZX), ptr(state), drop_p,
+                                     hd_plane, ptr(dHin), ptr(dHout), ptr(DG), ptr(DZ), lds, ptr(ZX), ptr(state), ptr(health), drop_p,
                                      stream()), "erc_gcnii_chain_bwd")
 
 
@@ -491,7 +506,7 @@ def ptr_table(tensors):
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-def dag_rec_fwd(H0, ldh0, n_layers, tables, pred, spk, B, T, ldo, ldgi, cfg, state, scratch):
+def dag_rec_fwd(H0, ldh0, n_layers, tables, pred, spk, B, T, ldo, ldgi, cfg, state, scratch, health=None):
     """tables: dict of ptr_table()s -- Wh bh W_hh_c b_hh_c W_ih_p b_ih_p Wr w_k | H1 GI Mseq GH R ks alpha"""
     _dev(H0)
     t = tables
@@ -500,10 +515,10 @@ def dag_rec_fwd(H0, ldh0, n_layers, tables, pred, spk, B, T, ldo, ldgi, cfg, sta
                                  C.addressof(t["Wr"]), C.addressof(t["w_k"]), ptr(pred), ptr(spk), B, T,
                                  C.addressof(t["H1"]), ldo, C.addressof(t["GI"]), ldgi, C.addressof(t["Mseq"]),
                                  C.addressof(t["GH"]), C.addressof(t["R"]), C.addressof(t["ks"]), C.addressof(t["alpha"]),
-                                 C.addressof(cfg), ptr(state), ptr(scratch), stream()), "erc_dag_rec_fwd")
+                                 C.addressof(cfg), ptr(state), ptr(health), ptr(scratch), stream()), "erc_dag_rec_fwd")
 
 
-def dag_rec_bwd(n_layers, tables, ldh, ldgi, pred, spk, B, T, dHall, ldd, lddgi, cfg, state, scratch):
+def dag_rec_bwd(n_layers, tables, ldh, ldgi, pred, spk, B, T, dHall, ldd, lddgi, cfg, state, scratch, health=None):
     """tables: ptr_table()s -- Hl GI GH Mseq R alpha Wh W_hh_c W_ih_p Wr w_k | DGI DGH dM dks"""
     _dev(dHall)
     t = tables
@@ -512,7 +527,7 @@ def dag_rec_bwd(n_layers, tables, ldh, ldgi, pred, spk, B, T, dHall, ldd, lddgi,
                                  C.addressof(t["W_hh_c"]), C.addressof(t["W_ih_p"]), C.addressof(t["Wr"]),
                                  C.addressof(t["w_k"]), ptr(pred), ptr(spk), B, T, ptr(dHall), ldd, C.addressof(t["DGI"]),
                                  lddgi, C.addressof(t["DGH"]), C.addressof(t["dM"]), C.addressof(t["dks"]),
-                                 C.addressof(cfg), ptr(state), ptr(scratch), stream()), "erc_dag_rec_bwd")
+                                 C.addressof(cfg), ptr(state), ptr(health), ptr(scratch), stream()), "erc_dag_rec_bwd")
 
 
 def dag_attn_sums(alpha, H1, ldo, pred, spk, B, T, A):

@@ -65,7 +65,7 @@ __device__ __forceinline__ void st_tag(u64* p, float v, unsigned tag) {
     __hip_atomic_store(p, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ int ld_err(const int* e) { return __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void set_err(int* e) { __hip_atomic_store(e, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void set_err(int* e) { __hip_atomic_store(e, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // re-poll one record until it carries `tag` (bounded; once any member has given up, everybody drains quickly)
 __device__ __forceinline__ float settle(const u64* p, u64 v, unsigned tag, int& spins, int* err) {
@@ -1032,8 +1032,8 @@ extern "C" int erc_dag_rec_fwd(const float* H0, int ldh0, int n_layers, const fl
                                const float* const* b_ih_p, const float* const* Wr, const float* const* w_k,
                                const int32_t* pred, const int32_t* spk, int B, int T, float* const* H1, int ldo,
                                float* const* GI, int ldgi, float* const* Mseq, float* const* GH, float* const* R,
-                               float* const* ks, float* const* alpha, const int* cfg, int32_t* state, void* scratch,
-                               void* stream) {
+                               float* const* ks, float* const* alpha, const int* cfg, int32_t* state, int32_t* health,
+                               void* scratch, void* stream) {
     ERC_REQUIRE(H0 && Wh && bh && W_hh_c && b_hh_c && W_ih_p && b_ih_p && Wr && w_k && pred && spk && H1 && GI && Mseq && GH &&
                     R && ks && alpha && state && scratch,
                 "dag_rec_fwd: null pointer");
@@ -1065,7 +1065,7 @@ extern "C" int erc_dag_rec_fwd(const float* H0, int ldh0, int n_layers, const fl
             for (int l = nl; l < ML; ++l) p.ly[l] = p.ly[0];
             p.ldo = ldo, p.ldgi = ldgi, p.pred = pred, p.spk = spk;
             p.B = B, p.T = T, p.DG = dg, p.g0 = g0, p.nl = nl;
-            p.xm = xm, p.xh = xh, p.epoch = state + 1, p.err = state, p.stamps = g_stamps;
+            p.xm = xm, p.xh = xh, p.epoch = state + 1, p.err = health ? health : state, p.stamps = g_stamps;
             REC_DISPATCH(dag_rec_fwd_kernel, p, lds, ng * nl)
             ERC_LAUNCH_CHECK("dag_rec_fwd");
         }
@@ -1079,7 +1079,7 @@ extern "C" int erc_dag_rec_bwd(int n_layers, const float* const* Hl, int ldh, co
                                const float* const* W_ih_p, const float* const* Wr, const float* const* w_k,
                                const int32_t* pred, const int32_t* spk, int B, int T, float* dHall, int ldd,
                                float* const* DGI, int lddgi, float* const* DGH, float* const* dM, float* const* dks,
-                               const int* cfg, int32_t* state, void* scratch, void* stream) {
+                               const int* cfg, int32_t* state, int32_t* health, void* scratch, void* stream) {
     ERC_REQUIRE(Hl && GI && GH && Mseq && R && alpha && Wh && W_hh_c && W_ih_p && Wr && w_k && pred && spk && dHall && DGI && DGH &&
                     dM && dks && state && scratch,
                 "dag_rec_bwd: null pointer");
@@ -1113,7 +1113,7 @@ extern "C" int erc_dag_rec_bwd(int n_layers, const float* const* Hl, int ldh, co
             p.ldh = ldh, p.ldgi = ldgi, p.ldd = ldd, p.lddgi = lddgi;
             p.dLow = dHall + (int64_t)HID * l0, p.relu_low = l0 == 0;
             p.pred = pred, p.spk = spk, p.B = B, p.T = T, p.DG = dg, p.g0 = g0, p.nl = nl;
-            p.xd = xd, p.xm = xm, p.xu = xu, p.epoch = state + 1, p.err = state, p.stamps = g_stamps;
+            p.xd = xd, p.xm = xm, p.xu = xu, p.epoch = state + 1, p.err = health ? health : state, p.stamps = g_stamps;
             REC_DISPATCH(dag_rec_bwd_kernel, p, lds, ng * nl)
             ERC_LAUNCH_CHECK("dag_rec_bwd");
         }

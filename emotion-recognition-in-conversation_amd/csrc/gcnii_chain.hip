@@ -61,6 +61,7 @@ struct Chain {
     int* err;
     float drop_p, ks; const uint64_t* rng; uint64_t rng_stream0;     // dropout of layer l: stream rng_stream0 + l (as gcnii_layer_fwd)
     uint64_t* stamps;                     // diagnostic phase stamps of workgroup 0 (or nullptr)
+    int spin_limit;                       // bound of a poll (SPIN_LIMIT; lowered by the timeout test)
 };
 
 #define CHAIN_STAMP(layer, slot)                                                                               \
@@ -254,8 +255,8 @@ __device__ __forceinline__ void chain_body(const Chain& p, float* smem, int b, i
                                              : p.flags + fbase + ((lane - nparts) + ((lane - nparts) >= m ? 1 : 0)) * p.pmax + part;
                 int spins = 0;
                 while (ld_i32(f) - want < 0) {             // monotonic: a fast member may already show a later layer
-                    if (++spins > SPIN_LIMIT) {
-                        st_i32(p.err, 1);
+                    if (++spins > p.spin_limit) {
+                        st_i32(p.err, ERC_HEALTH_RAISED);
                         break;
                     }
                     if ((spins & 255) == 0 && ld_i32(p.err)) break;
@@ -590,10 +591,17 @@ extern "C" int erc_gcnii_chain_set_stamps(uint64_t* stamps) {
     g_chain_stamps = stamps;
     return ERC_OK;
 }
+static int g_chain_spin_limit = SPIN_LIMIT;
+// test hook: bound of the per-layer exchange polls (<= 0 restores the default).  With a bound of 1 the first wait that is
+// not satisfied at once raises the health word: the timeout path end to end (tests/test_gpu_mmgcn.py).
+extern "C" int erc_gcnii_chain_set_spin_limit(int limit) {
+    g_chain_spin_limit = limit > 0 ? limit : SPIN_LIMIT;
+    return ERC_OK;
+}
 static int chain_launch(bool bwd, const float* ADJ, int P, const float* CR, const int32_t* node_off, int N, int Mo, int B, int T,
                         int parts, int grid_cap, int dpl, const float* W, const float* Call, int ldc, float* HD, int64_t hd_plane,
                         float* ZS, float* DG, float* DZ, int lds_, const float* dHin, float* dHout, float* ZX, int32_t* state,
-                        float drop_p, const uint64_t* rng, uint64_t rng_stream0, void* stream) {
+                        int32_t* health, float drop_p, const uint64_t* rng, uint64_t rng_stream0, void* stream) {
     const int lds = chain_lds(T);
     hipStream_t st = (hipStream_t)stream;
     for (int b0 = 0; b0 < B; b0 += dpl) {
@@ -601,8 +609,9 @@ static int chain_launch(bool bwd, const float* ADJ, int P, const float* CR, cons
         int grid = Mo * nb * ((T + 15) / 16);              // 16-row parts if the lengths allow (the device decides), never more
         if (grid > grid_cap) grid = grid_cap;
         Chain p{ADJ, P, CR, node_off, N, Mo, B, b0, nb, parts, chain_ap(T), W, Call, ldc, HD, hd_plane, ZS, DG, DZ, lds_, dHin, dHout,
-                ZX, state + 1 + B, state + 1, state, drop_p, drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, rng, rng_stream0, nullptr};
+                ZX, state + 1 + B, state + 1, health ? health : state, drop_p, drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f, rng, rng_stream0, nullptr};
         p.stamps = b0 == 0 ? g_chain_stamps : nullptr;
+        p.spin_limit = g_chain_spin_limit;
         if (bwd) {
             if (!chain_ensure_lds(gcnii_chain_kernel<true>, lds)) return ERC_E_LAUNCH;
             hipLaunchKernelGGL(gcnii_chain_kernel<true>, dim3(grid), dim3(CNT), lds, st, p);
@@ -617,8 +626,8 @@ static int chain_launch(bool bwd, const float* ADJ, int P, const float* CR, cons
 
 extern "C" int erc_gcnii_chain_fwd(const float* ADJ, int P, const float* CR, const int32_t* node_off, int N, int Mo, int B, int T,
                                    int parts, int grid_cap, int dialogues_per_launch, const float* VT, const float* Call, int ldc,
-                                   float* HD, int64_t hd_plane, float* ZS, int lds, float* ZX, int32_t* state, float drop_p,
-                                   const uint64_t* rng_state, uint64_t rng_stream0, void* stream) {
+                                   float* HD, int64_t hd_plane, float* ZS, int lds, float* ZX, int32_t* state, int32_t* health,
+                                   float drop_p, const uint64_t* rng_state, uint64_t rng_stream0, void* stream) {
     ERC_REQUIRE(ADJ && CR && node_off && VT && Call && HD && ZS && ZX && state, "gcnii_chain_fwd: null pointer");
     ERC_REQUIRE(N > 0 && Mo >= 2 && Mo <= 3 && B > 0 && T > 0 && T <= MAXT && P >= T && parts >= (T + 15) / 16 &&
                     dialogues_per_launch >= 1 && grid_cap >= dialogues_per_launch * Mo * ((T + MAXRW - 1) / MAXRW) &&
@@ -626,17 +635,17 @@ extern "C" int erc_gcnii_chain_fwd(const float* ADJ, int P, const float* CR, con
                 "gcnii_chain_fwd: bad sizes (T=%d parts=%d grid cap=%d)", T, parts, grid_cap);
     ERC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state), "gcnii_chain_fwd: drop_p=%f", (double)drop_p);
     return chain_launch(false, ADJ, P, CR, node_off, N, Mo, B, T, parts, grid_cap, dialogues_per_launch, VT, Call, ldc, HD, hd_plane, ZS,
-                        nullptr, nullptr, lds, nullptr, nullptr, ZX, state, drop_p, rng_state, rng_stream0, stream);
+                        nullptr, nullptr, lds, nullptr, nullptr, ZX, state, health, drop_p, rng_state, rng_stream0, stream);
 }
 
 extern "C" int erc_gcnii_chain_bwd(const float* ADJ, int P, const float* CR, const int32_t* node_off, int N, int Mo, int B, int T,
                                    int parts, int grid_cap, int dialogues_per_launch, const float* V, const float* HD,
                                    int64_t hd_plane, const float* dHin, float* dHout, float* DG, float* DZ, int lds, float* ZX,
-                                   int32_t* state, float drop_p, void* stream) {
+                                   int32_t* state, int32_t* health, float drop_p, void* stream) {
     ERC_REQUIRE(ADJ && CR && node_off && V && HD && dHin && dHout && DG && DZ && ZX && state, "gcnii_chain_bwd: null pointer");
     ERC_REQUIRE(N > 0 && Mo >= 2 && Mo <= 3 && B > 0 && T > 0 && T <= MAXT && P >= T && parts >= (T + 15) / 16 &&
                     dialogues_per_launch >= 1 && grid_cap >= dialogues_per_launch * Mo * ((T + MAXRW - 1) / MAXRW) && lds >= NL * FD,
                 "gcnii_chain_bwd: bad sizes (T=%d parts=%d grid cap=%d)", T, parts, grid_cap);
     return chain_launch(true, ADJ, P, CR, node_off, N, Mo, B, T, parts, grid_cap, dialogues_per_launch, V, nullptr, 0,
-                        const_cast<float*>(HD), hd_plane, nullptr, DG, DZ, lds, dHin, dHout, ZX, state, drop_p, nullptr, 0, stream);
+                        const_cast<float*>(HD), hd_plane, nullptr, DG, DZ, lds, dHin, dHout, ZX, state, health, drop_p, nullptr, 0, stream);
 }

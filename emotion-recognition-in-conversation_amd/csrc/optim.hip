@@ -179,6 +179,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Start of a training step: a health word still raised from the previous step (its update was skipped) is counted as an
+// event and cleared, so that ONE timeout costs one step, not the rest of the epoch.  Stream order puts this behind the
+// previous step's optimizer launch (the only reader of the word) and in front of every kernel that may raise it again.
+__global__ void health_roll_kernel(int32_t* live, int32_t* events) {
+    if (*live != 0) {
+        events[0] += 1;
+        *live = 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float scale,
                                                     double* __restrict__ partial) {
     __shared__ double sh[4];
@@ -229,20 +239,31 @@ extern "C" int erc_clock_probe(uint64_t* out, int iters, void* stream) {
     return ERC_OK;
 }
 
-static int check_shadow_tab(const ShadowTab& tab, int64_t n, const char* who) {
+// shadow_numel: bf16 elements behind shadow_base.  Strides are non-negative, so the largest (n, k) a range reaches is at
+// the largest digits; its destination must lie inside the buffer (a bad table would otherwise write out of bounds).
+static int check_shadow_tab(const ShadowTab& tab, int64_t n, int64_t shadow_numel, const char* who) {
     ERC_REQUIRE(tab.n >= 0 && tab.n <= SHADOW_MAX, "%s: %d shadow descriptors (max %d)", who, tab.n, SHADOW_MAX);
     for (int t = 0; t < tab.n; ++t) {
         const ShadowDesc& d = tab.d[t];
         ERC_REQUIRE(d.src_off >= 0 && d.n_el > 0 && d.src_off + d.n_el <= n && d.n_el < (1ll << 31) && d.n0 > 0 && d.n1 > 0 &&
                         d.dst_off >= 0 && d.ld > 0 && (d.mode == 0 || d.mode == 1) && d.sn0 >= 0 && d.sn1 >= 0 && d.sn2 >= 0 &&
                         d.sk0 >= 0 && d.sk1 >= 0 && d.sk2 >= 0, "%s: shadow descriptor %d out of range", who, t);
+        const int64_t m0 = (d.n0 < d.n_el ? d.n0 : d.n_el) - 1, q1 = (d.n_el - 1) / d.n0, m1 = q1 < d.n1 ? q1 : d.n1 - 1,
+                      m2 = q1 / d.n1;
+        const int64_t nmax = m0 * d.sn0 + m1 * d.sn1 + m2 * d.sn2, kmax = m0 * d.sk0 + m1 * d.sk1 + m2 * d.sk2;
+        const int64_t last = d.mode == 0 ? d.dst_off + nmax * d.ld + kmax
+                                         : d.dst_off + (((nmax >> 4) * d.ld + (kmax >> 5)) << 9) + 511;
+        ERC_REQUIRE((d.mode == 0 || (kmax >> 5) < d.ld) && last < shadow_numel,
+                    "%s: shadow descriptor %d reaches element %lld of a %lld-element shadow buffer", who, t, (long long)last,
+                    (long long)shadow_numel);
     }
     return ERC_OK;
 }
 
 static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int decoupled, float grad_scale, float clip_norm, const float* gnorm,
-                       int64_t* state, void* shadow_base, const ShadowTab& tab_in, const int32_t* skip_flag, void* stream) {
+                       int64_t* state, void* shadow_base, int64_t shadow_numel, const ShadowTab& tab_in,
+                       const int32_t* skip_flag, void* stream) {
     ShadowTab tab = tab_in;
     // quad fast path (flags bit 0): every range starts on a quad of the flat buffer and has rows of a multiple of 4
     // elements; bit 1 + t: range t runs along k with k % 4 == 0 for every quad and 8-byte aligned destinations
@@ -257,7 +278,7 @@ static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, 
     ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
     ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
     ERC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: 16-byte alignment");
-    if (int rc = check_shadow_tab(tab, n, "adam_step")) return rc;
+    if (int rc = check_shadow_tab(tab, n, shadow_numel, "adam_step")) return rc;
     int grid = (int)((n / 4 + 255) / 256);   // one float4 per thread
     if (grid < 1) grid = 1;
     if (grid > 512) grid = 512;  // one arrival atomic per block on a single word: keep the count low
@@ -279,32 +300,40 @@ extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64
         tab.d[0] = ShadowDesc{shadow_off, shadow_n, 0, (int32_t)shadow_n, 1, 0, 0, 0, 1, 0, 0, (int32_t)shadow_n, 0};   // identity: k = idx
     }
     return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, clip_norm, gnorm, state,
-                       bf16_shadow, tab, skip_flag, stream);
+                       bf16_shadow, shadow_n, tab, skip_flag, stream);
 }
 
 // Same step with a table of bf16 shadow ranges (ErcShadowTab in ercgraft.h, a HOST struct passed by value to the kernel).
 extern "C" int erc_adam_step_tab(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                                  float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
                                  float clip_norm, const float* gnorm, int64_t* state, void* shadow_base,
-                                 const ErcShadowTab* tab_host, const int32_t* skip_flag, void* stream) {
+                                 int64_t shadow_numel, const ErcShadowTab* tab_host, const int32_t* skip_flag, void* stream) {
     static_assert(sizeof(ShadowTab) == sizeof(ErcShadowTab), "shadow table layout");
     ShadowTab tab{};
     if (tab_host) memcpy(&tab, tab_host, sizeof(tab));
     ERC_REQUIRE(tab.n == 0 || shadow_base, "adam_step_tab: shadow table without a shadow buffer");
     return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, clip_norm, gnorm, state,
-                       shadow_base, tab, skip_flag, stream);
+                       shadow_base, shadow_numel, tab, skip_flag, stream);
 }
 
 // (Re)build every shadow range of the table from the fp32 parameters (after loading a state dict, or when no optimizer
 // maintains them).
-extern "C" int erc_shadow_refresh(const float* p, int64_t n, void* shadow_base, const ErcShadowTab* tab_host, void* stream) {
+extern "C" int erc_shadow_refresh(const float* p, int64_t n, void* shadow_base, int64_t shadow_numel,
+                                  const ErcShadowTab* tab_host, void* stream) {
     ERC_REQUIRE(p && shadow_base && tab_host, "shadow_refresh: null pointer");
     ShadowTab tab{};
     memcpy(&tab, tab_host, sizeof(tab));
     ERC_REQUIRE(tab.n > 0, "shadow_refresh: empty table");
-    if (int rc = check_shadow_tab(tab, n, "shadow_refresh")) return rc;
+    if (int rc = check_shadow_tab(tab, n, shadow_numel, "shadow_refresh")) return rc;
     hipLaunchKernelGGL(shadow_refresh_kernel, dim3(64, tab.n), dim3(256), 0, (hipStream_t)stream, p, (unsigned short*)shadow_base, tab);
     ERC_LAUNCH_CHECK("shadow_refresh");
+    return ERC_OK;
+}
+
+extern "C" int erc_health_roll(int32_t* health, int32_t* events, void* stream) {
+    ERC_REQUIRE(health && events, "health_roll: null pointer");
+    hipLaunchKernelGGL(health_roll_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, health, events);
+    ERC_LAUNCH_CHECK("health_roll");
     return ERC_OK;
 }
 

@@ -144,12 +144,10 @@ class DAGERCModule(nn.Module):
     def check_cluster(self):
         """Raise if a recurrence kernel flagged an exchange wait that ran into its bound (its workgroups were not all
         resident at once, e.g. another process holds CUs).  The affected optimizer steps were already skipped ON THE
-        DEVICE (FusedAdam.skip_flag = this flag); this host-side check (one device->host copy) reports it -- the trainer
-        calls it after the training loop and after the evaluation loop of every epoch."""
-        if int(self.rec_state[0].item()) != 0:
-            self.rec_state[0] = 0
-            raise capi.ErcGraftError("DAG-ERC recurrence: an exchange between the workgroups of a dialogue group timed out; "
-                                     "the optimizer steps of the affected batches were skipped")
+        DEVICE, on every rank (FusedAdam.skip_flag = the health word in the tail of the flat gradient buffer, which the
+        gradient all-reduce sums over the ranks); this host-side check (one device->host copy) reports how many -- the
+        trainer calls it after the training loop and after the evaluation loop of every epoch."""
+        self.flat.check_health("DAG-ERC recurrence")
 
     def _shape(self, input_tensor, text_length, label, n_nodes=None):
         B, T = input_tensor.shape[0], input_tensor.shape[1]
@@ -186,7 +184,7 @@ class DAGERCModule(nn.Module):
         # all layers in one pipelined launch (csrc/dag_rec.hip): the hoisted products (gates of both cells' hoisted sides,
         # query score) are computed -- and saved to GI -- by the recurrence's own workgroups
         capi.dag_rec_fwd(Hall, W5, L, ws["tables"], ws["pred"], ws["spk"], B, T, W5, LDG, ws["cfg_f"], self.rec_state,
-                         ws["scratch_f"])
+                         ws["scratch_f"], health=fp.health)
         # head: Y1 = relu([Hall | x] W0^T + b0) as two GEMMs into one slab set
         W0 = fp.w("out_mlp.0.weight")
         Sa = pl.split_for(BT, HID, W5)
@@ -221,6 +219,7 @@ class DAGERCModule(nn.Module):
         x, spk, lens, ys = batch["input_tensor"], batch["speaker_tensor"], batch["text_length"], batch["label"]
         B, T, N = self._shape(x, lens, ys)
         training = self.training
+        self.flat.roll_health()      # a timeout of the previous step: counted, cleared -- this step runs normally
         ws = self._forward_impl(x, spk, lens, B, T, N, training)
         fp, pl = self.flat, ws["planner"]
         BT, L, C, D, W5 = B * T, self.gnn_layers, self.n_classes, self.emb_dim, HID * (self.gnn_layers + 1)
@@ -248,7 +247,7 @@ class DAGERCModule(nn.Module):
         # all layers in one pipelined launch, top layer first (csrc/dag_rec.hip): leaves the gate gradients, dM and dks of
         # every layer and the complete gradient wrt H_0 (through fc1's relu mask) in block 0 of dHall
         capi.dag_rec_bwd(L, ws["tables"], W5, LDG, ws["pred"], ws["spk"], B, T, ws["dHall"], W5, LDG, ws["cfg_b"],
-                         self.rec_state, ws["scratch_b"])
+                         self.rec_state, ws["scratch_b"], health=fp.health)
         for l in range(L):
             Hl, H1 = ws["Hall"][:, HID * l:], ws["Hall"][:, HID * (l + 1):]
             # d[W_ih_c ; W_hh_p] and their biases (1800 rows: 16-byte operand loads); the two halves of gather.linear:
@@ -285,7 +284,7 @@ class DAGERCTrainer:
         self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.get("weight_decay", 1e-2),
                                decoupled=(o.name == "AdamW"), clip_norm=5.0, seed=params.seed)
         self.model.rng_state = self.optim.rng_state
-        self.optim.skip_flag = self.model.rec_state      # [0]: a recurrence exchange timed out -> the update is skipped
+        self.optim.skip_flag = self.model.flat.health    # a recurrence exchange timed out (on any rank) -> the update is skipped
 
     def to_logits(self, batch):
         return self.model(**batch)[0]

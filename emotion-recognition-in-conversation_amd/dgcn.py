@@ -171,9 +171,10 @@ class DGCNModule(nn.Module):
         if self.compact_lstm:
             # the BiLSTM on the N valid positions in node order (row = node_off[b] + t), written next to the graph output
             self.lstm.forward(pl, x, D, N, B, T, T, 1, lens, training, self.rng_state, Xc, XW, x_bf16=x_bf16,
-                              node_off=g["node_off"], node_row=g["node_row"])
+                              node_off=g["node_off"], node_row=g["node_row"], store=ws)
         else:
-            self.lstm.forward(pl, x, D, BT, B, T, T, 1, lens, training, self.rng_state, ws["rnn_out"], G_DIM, x_bf16=x_bf16)
+            self.lstm.forward(pl, x, D, BT, B, T, T, 1, lens, training, self.rng_state, ws["rnn_out"], G_DIM, x_bf16=x_bf16,
+                              store=ws)
             capi.gather_rows(ws["rnn_out"], G_DIM, g["node_row"], N, G_DIM, Xc, XW)
         # EdgeAtt: att = x W^T, softmax over each source's window
         capi.gemm_f32(Xc, XW, 0, None, fp.w("edge_att.weight"), G_DIM, 0, None, ws["ATT"], G_DIM, N, G_DIM, G_DIM)

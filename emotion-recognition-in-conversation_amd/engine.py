@@ -26,13 +26,13 @@ class WorkspaceCache:
     """Per-module workspace sets keyed by batch shape, least-recently-used eviction.  In the real training loop
     (shuffled batches, smaller last batch: mmbase.py:468) the number of valid utterances N changes almost every step;
     an unbounded ``dict`` of (B, T, N) -> workspace would grow by hundreds of MB per new shape (DAG-ERC: ~350 MB).
-    ``maxsize`` shapes stay resident (env ERC_WS_CACHE); a HIP graph captured over a workspace pins it (``pin``)."""
+    ``maxsize`` shapes stay resident (env ERC_WS_CACHE).  A HIP graph captured over a workspace keeps the workspace OBJECT
+    alive itself (trainer.StepGraphs stores it next to the graph), so eviction here never frees memory a graph points to."""
 
     def __init__(self, maxsize=None):
         import collections
         self.maxsize = int(os.environ.get("ERC_WS_CACHE", 4)) if maxsize is None else maxsize
         self._d = collections.OrderedDict()
-        self._pinned = set()
         self.last = None
 
     def get(self, key, make):
@@ -40,8 +40,8 @@ class WorkspaceCache:
         if ws is None:
             ws = make()
             self._d[key] = ws
-            while len(self._d) - len(self._pinned) > self.maxsize:
-                victim = next((k for k in self._d if k not in self._pinned and k != key), None)
+            while len(self._d) > self.maxsize:
+                victim = next((k for k in self._d if k != key), None)
                 if victim is None:
                     break
                 del self._d[victim]
@@ -49,9 +49,6 @@ class WorkspaceCache:
             self._d.move_to_end(key)
         self.last = ws
         return ws
-
-    def pin(self, key):
-        self._pinned.add(key)
 
     def values(self):
         return list(self._d.values())
@@ -78,7 +75,13 @@ class FlatParams:
                 off += p.numel()
         self.numel = (off + ALIGN - 1) // ALIGN * ALIGN
         self.data = torch.zeros(self.numel, dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros_like(self.data)
+        # the gradient buffer carries one extra group: its first word is the step's HEALTH WORD (ercgraft.h, erc_health_roll),
+        # raised by a persistent kernel whose bounded poll timed out.  Living behind the gradients, it travels in the step's
+        # one all-reduce, so under data parallelism every rank skips the update when any rank raised it.
+        self.grad_full = torch.zeros(self.numel + ALIGN, dtype=torch.float32, device=self.device)
+        self.grad = self.grad_full[:self.numel]
+        self.health = self.grad_full[self.numel:self.numel + 1].view(torch.int32)
+        self.events = torch.zeros(2, dtype=torch.int32, device=self.device)   # [0]: steps skipped since the last check_health
         self.exp_avg = torch.zeros_like(self.data)
         self.exp_avg_sq = torch.zeros_like(self.data)
         self.params = {}
@@ -102,8 +105,30 @@ class FlatParams:
     def w(self, name):
         return self.view(self.data, name)
 
+    def roll_health(self):
+        """Start of a training step: a health word the previous step left raised becomes one counted event and is
+        cleared (one launch, no host synchronisation)."""
+        capi.health_roll(self.health, self.events)
+
+    def check_health(self, what):
+        """Host-side report (one device->host copy; the trainer calls it once per epoch): raises if any step since the
+        last call was skipped on the device, or if the word is raised right now (evaluation pass)."""
+        ev, live = int(self.events[0].item()), int(self.health[0].item())
+        if ev or live:
+            self.events.zero_()
+            self.health.zero_()
+            raise capi.ErcGraftError("%s: a bounded wait between cooperating workgroups timed out (not all of them were "
+                                     "resident at once, e.g. another process holds CUs); %d optimizer step(s) were skipped "
+                                     "on the device%s" % (what, ev + (1 if live else 0),
+                                                          " on every rank" if _world_size() > 1 else ""))
+
     def g(self, name):
         return self.view(self.grad, name)
+
+
+def _world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 class GemmPlanner:
@@ -361,7 +386,7 @@ def all_reduce_grads(flat, always=False):
     one-rank group too (bench.py --rehearse_dp)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or always):
-        dist.all_reduce(flat.grad)
+        dist.all_reduce(flat.grad_full)     # gradients + the health word behind them
         return 1.0 / dist.get_world_size()
     return 1.0
 

@@ -170,6 +170,13 @@ class MMGCNModule(nn.Module):
         ws["jobs"] = None
         return ws
 
+    def check_cluster(self):
+        """Raise if a GCNII chain kernel (csrc/gcnii_chain.hip) flagged a per-layer exchange wait that ran into its bound.
+        The affected optimizer steps were skipped ON THE DEVICE, on every rank (FusedAdam.skip_flag = the health word the
+        chain kernels raise, summed over the ranks by the gradient all-reduce); the trainer calls this once per epoch
+        after the training loop and after the evaluation loop, as for DAG-ERC."""
+        self.flat.check_health("MMGCN GCNII chain")
+
     def _shape(self, batch_feat, lens, label, n_nodes=None):
         T, B = batch_feat.shape[0], batch_feat.shape[1]
         N = int(label.shape[0]) if label is not None else (int(n_nodes) if n_nodes is not None else int(lens.sum().item()))
@@ -209,7 +216,7 @@ class MMGCNModule(nn.Module):
             emb = spk = None
             if m == "t":
                 # unpacked BiLSTM over the padded [T,B,200] block (row(b,t) = t*B + b): mmgcn.py:113-114
-                self.lstm.forward(pl, ws["LIN"][m], FD, TB, B, T, 1, B, None, training, rng, ws["LO"], FD)
+                self.lstm.forward(pl, ws["LIN"][m], FD, TB, B, T, 1, B, None, training, rng, ws["LO"], FD, store=ws)
                 src, emb, spk = ws["LO"], fp.w("graph_model.speaker_embeddings.weight"), ws["node_spk"]
             capi.mm_flatten(src, FD, ws["node_row"], emb, spk, N, X[mi * N:], FD)
         # adjacency (mmgcn_models.py:582-646)
@@ -238,7 +245,7 @@ class MMGCNModule(nn.Module):
             capi.gcnii_chain_prep(fp.w(Wn0), w_stride, LAMDA, ALPHA, ws["VT"], ws["V"], ws["U"])
             capi.gemm_f32(H0, FD, 0, None, ws["U"], LDS, 1, None, ws["Call"], LDS, R3, LDS, FD)
             capi.gcnii_chain_fwd(ws["ADJ"], P, ws["CR"], ws["node_off"], N, Mo, B, T, ws["chain_cfg"], ws["VT"], ws["Call"], LDS,
-                                 HD, R3 * FD, ws["ZS"], LDS, ws["ZX"], ws["chain_state"], p, rng, 2000)
+                                 HD, R3 * FD, ws["ZS"], LDS, ws["ZX"], ws["chain_state"], p, rng, 2000, health=fp.health)
         else:
             # every layer's input rows are [hi_l | h0] (pitch 2 FD): h0 is copied next to the 64 hi slots once per step, so that
             # [hi | h0] W is ONE product per layer, with the GCNII tail (residual mix, relu, dropout) in its epilogue
@@ -307,6 +314,7 @@ class MMGCNModule(nn.Module):
         feats = self._feats(batch)
         qmask, lens, ys = batch["speaker_tensor"], batch["text_length"], batch["label"]
         B, T, N = self._shape(feats[self.order[0]], lens, ys)
+        self.flat.roll_health()      # a timeout of the previous step: counted, cleared -- this step runs normally
         ws = self._forward_impl(feats, qmask, lens, B, T, N, self.training)
         fp, pl, off = self.flat, ws["planner"], self.flat.offsets
         Mo, C, TB, P = len(self.order), self.n_classes, T * B, ws["P"]
@@ -330,7 +338,7 @@ class MMGCNModule(nn.Module):
             dH0 = ws["dH0"]
             ws["dCR"].zero_()
             capi.gcnii_chain_bwd(ws["ADJ"], P, ws["CR"], ws["node_off"], N, Mo, B, T, ws["chain_cfg"], ws["V"], HD, plane, DH,
-                                 ws["DH1"], ws["DGl"], ws["DZl"], LDS, ws["ZX"], ws["chain_state"], p)
+                                 ws["DH1"], ws["DGl"], ws["DZl"], LDS, ws["ZX"], ws["chain_state"], p, health=fp.health)
             for l in range(1, NLAYERS + 1):
                 Wn = gn + "convs.%d.weight" % (l - 1)
                 th = self.theta(l)
@@ -400,6 +408,7 @@ class MMGCNTrainer:
         self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.get("weight_decay", 0.0),
                                decoupled=(o.name == "AdamW"), seed=params.seed)
         self.model.rng_state = self.optim.rng_state
+        self.optim.skip_flag = self.model.flat.health    # a chain exchange timed out (on any rank) -> the update is skipped
 
     def to_logits(self, batch):
         return self.model(**batch)[0]

@@ -25,7 +25,7 @@ def lstm_groups(prefix, m):
 class BiLSTM2:
     def __init__(self, flat, prefix, d_in, drop_p=0.4):
         self.flat, self.prefix, self.d_in, self.drop_p = flat, prefix, d_in, drop_p
-        self._ws = {}
+        self._own = {}     # buffers of callers that pass no store (tests): one set, replaced when the row count changes
 
     def _w(self, name):
         return self.flat.w(self.prefix + name)
@@ -33,26 +33,35 @@ class BiLSTM2:
     def _off(self, name):
         return self.flat.offsets[self.prefix + name]
 
-    def _buf(self, rows, device):
-        ws = self._ws.get(rows)
-        if ws is None:
+    def _buf(self, rows, device, store=None):
+        """The recurrence's saved state for ``rows`` positions.  ``store`` is the calling module's per-shape workspace
+        dict: the buffers live (and are evicted, and are kept alive by a captured HIP graph) with it -- with compact rows
+        the row count changes almost every step of a shuffled epoch, and a cache of its own here would grow by ~25 KB per
+        row and distinct count."""
+        if store is None:
+            store = self._own
+            if store.get("lstm_rows") != rows:
+                store.clear()
+        key = "lstm:" + self.prefix
+        ws = store.get(key)
+        if ws is None or store.get("lstm_rows", rows) != rows:
             # zeros, not empty: rows of padded positions are never written but ARE read by the weight-gradient
             # GEMMs (times a zero gate gradient), so they must stay finite
             f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
             ws = dict(GX=[f32(rows, 8 * H), f32(rows, 8 * H)], gates=[f32(rows, 8 * H), f32(rows, 8 * H)],
                       Cst=[f32(rows, 2 * H), f32(rows, 2 * H)], Hprev=[f32(rows, 2 * H), f32(rows, 2 * H)],
                       H0=f32(rows, 2 * H), H0d=f32(rows, 2 * H), dGX=[f32(rows, 8 * H), f32(rows, 8 * H)], dH0d=f32(rows, 2 * H))
-            self._ws[rows] = ws
+            store[key], store["lstm_rows"] = ws, rows
         return ws
 
     def forward(self, pl, x, ldx, rows, B, T, sb, st, lengths, training, rng, out, ldo, x_bf16=False, node_off=None,
-                node_row=None):
+                node_row=None, store=None):
         """x [*, d_in] -> out [rows, 200] (row pitch ldo).  Padded rows: row(b,t) = b*sb + t*st of x and of every buffer.
         Compact rows (``node_off`` [B+1] and ``node_row`` [rows] given, packed sequences only): every buffer holds the
         ``rows`` = sum(lengths) valid positions in dialogue order (row = node_off[b] + t), x is read through node_row --
         the input projections, the saved state and the weight gradients shrink from B*T to sum(lengths) rows and the
         caller needs no gather / scatter between the padded and the node layout (DialogueGCN)."""
-        ws = self._buf(rows, out.device)
+        ws = self._buf(rows, out.device, store)
         p = self.drop_p if training else 0.0
         linear_fwd(pl, x, ldx, node_row, self._w("weight_ih_l0"), self._w("bias_ih_l0"), ws["GX"][0], 8 * H, rows, 8 * H,
                    self.d_in, x_bf16=x_bf16)
@@ -63,13 +72,13 @@ class BiLSTM2:
                    8 * H, 2 * H)
         capi.lstm_scan_fwd(ws["GX"][1], 8 * H, self._w("weight_hh_l1"), self._w("bias_hh_l1"), lengths, node_off, sb, st,
                            B, T, out, ldo, None, 0, 0.0, None, 0, ws["gates"][1], ws["Cst"][1], ws["Hprev"][1])
-        self._last = (x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16, node_off, node_row)
+        self._last = (x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16, node_off, node_row, store)
 
     def backward(self, pl, dout, lddo, dx=None, lddx=0):
         """dout = gradient wrt the layer-1 output.  Registers all weight-gradient jobs; optionally writes
         dx [rows, d_in] (needed when the LSTM input is itself trainable, MMGCN)."""
-        x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16, node_off, node_row = self._last
-        ws = self._buf(rows, dout.device)
+        x, ldx, rows, B, T, sb, st, lengths, p, rng, x_bf16, node_off, node_row, store = self._last
+        ws = self._buf(rows, dout.device, store)
         # one gate-gradient buffer per layer: every weight gradient of the LSTM then joins the step's ONE batched
         # weight-gradient launch (erc_wgrad_table) instead of 6 split-K GEMMs + a slab reduce per layer pair
         for k in (1, 0):

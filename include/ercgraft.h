@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ERC_ABI_VERSION 1
+#define ERC_ABI_VERSION 2
 
 #define ERC_OK 0
 #define ERC_E_ARG (-1)     /* bad shape / null pointer / unsupported size */
@@ -453,10 +453,24 @@ typedef struct ErcShadowTab {
 int erc_adam_step_tab(float* p, const float* g, float* m, float* v, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, int decoupled,
                       float grad_scale, float clip_norm, const float* gnorm, int64_t* state,
-                      void* shadow_base, const ErcShadowTab* tab_host, const int32_t* skip_flag, void* stream);
+                      void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host, const int32_t* skip_flag,
+                      void* stream);
 /* Rebuild every shadow range from the fp32 parameters p[0, n) (after loading a state dict; or per forward when no
- * optimizer maintains the shadows). */
-int erc_shadow_refresh(const float* p, int64_t n, void* shadow_base, const ErcShadowTab* tab_host, void* stream);
+ * optimizer maintains the shadows).  shadow_numel (here and above): bf16 elements behind shadow_base; a descriptor
+ * whose largest destination index lies outside is rejected (ERC_E_ARG). */
+int erc_shadow_refresh(const float* p, int64_t n, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
+                       void* stream);
+
+/* Health word: one device int32 that the persistent kernels with bounded polls (erc_dag_rec_*, erc_gcnii_chain_*: their
+ * `health` argument; NULL = use state[0] as before) raise to ERC_HEALTH_RAISED when a poll ran into its bound, i.e. when
+ * this step's results are invalid.  The value is the bit pattern of 1.0f: the host side keeps the word in the tail of the
+ * flat fp32 gradient buffer, so that under data parallelism it travels in the step's ONE gradient all-reduce and every
+ * rank sees a non-zero word if any rank raised it.  erc_adam_step{,_tab}(skip_flag = the word) then skips the update on
+ * every rank alike.  erc_health_roll, launched at the start of the next step, adds 1 to events[0] and clears the word if
+ * it is still raised: a timeout costs that one step, the following steps run normally, and the host reads the event
+ * count once per epoch. */
+#define ERC_HEALTH_RAISED 0x3f800000
+int erc_health_roll(int32_t* health, int32_t* events, void* stream);
 /* diagnostic: out[0] = shader cycles, out[1] = 10-ns ticks of a fixed dependent-MFMA loop (bench.py --clock_probe) */
 int erc_clock_probe(uint64_t* out, int iters, void* stream);
 /* gnorm[0] = ||g * grad_scale||_2 ; ws >= 1024 floats */
@@ -478,19 +492,22 @@ int erc_grad_norm(const float* g, int64_t n, float grad_scale, float* gnorm, flo
  *   erc_gcnii_chain_bwd: dHin = gradient wrt plane 65, dHout = gradient wrt plane 1; saves dg_l = d out_l -> DG and
  *     dz_l = A dg_l -> DZ (same layout as ZS).  Left to the caller (they only meet in sums over the layers):
  *     dW_l[:200] = theta_l HD_l^T dz_l, dW_l[200:] = theta_l H0^T dg_l, dH0 = DG U^T, dADJ = sum_l dg_l z_l^T (blocks, cross).
- *   ZX: exchange buffer [2][Mo*N][200]; state: int32 [1 + B + B*Mo*parts], zero-filled once ([0] error flag, epochs, flags). */
+ *   ZX: exchange buffer [2][Mo*N][200]; state: int32 [1 + B + B*Mo*parts], zero-filled once ([0] error flag when health is
+ *   NULL, epochs, flags); health: the health word (see erc_health_roll) a poll timeout raises. */
 int erc_gcnii_chain_prep(const float* W, int64_t w_stride, float lamda, float alpha, float* VT, float* V, float* U, void* stream);
 int erc_gcnii_chain_config(int B, int T, int Mo, int P, int* parts, int* rows, int* dialogues_per_launch);
 int erc_gcnii_chain_fwd(const float* ADJ, int P, const float* CR, const int32_t* node_off, int N, int Mo, int B, int T,
                         int parts, int rows, int dialogues_per_launch, const float* VT, const float* Call, int ldc,
-                        float* HD, int64_t hd_plane, float* ZS, int lds, float* ZX, int32_t* state, float drop_p,
-                        const uint64_t* rng_state, uint64_t rng_stream0, void* stream);
+                        float* HD, int64_t hd_plane, float* ZS, int lds, float* ZX, int32_t* state, int32_t* health,
+                        float drop_p, const uint64_t* rng_state, uint64_t rng_stream0, void* stream);
 int erc_gcnii_chain_bwd(const float* ADJ, int P, const float* CR, const int32_t* node_off, int N, int Mo, int B, int T,
                         int parts, int rows, int dialogues_per_launch, const float* V, const float* HD, int64_t hd_plane,
                         const float* dHin, float* dHout, float* DG, float* DZ, int lds, float* ZX, int32_t* state,
-                        float drop_p, void* stream);
+                        int32_t* health, float drop_p, void* stream);
 /* diagnostic: phase stamps (s_memtime) of workgroup 0 of the following launches, [64][16] uint64; NULL switches them off */
 int erc_gcnii_chain_set_stamps(uint64_t* stamps);
+/* test hook: bound of the chain kernels' exchange polls for the following launches (<= 0: the default, 4 000 000) */
+int erc_gcnii_chain_set_spin_limit(int limit);
 
 /* ------------------------------------------------------------------------
  * K6  DAG-ERC (track_mm/dagerc.py:109-189, track_mm/dagerc_models.py:312-365).
@@ -538,7 +555,8 @@ int erc_dag_meta(const float* speaker_onehot, const int64_t* speaker_ids, int64_
  *     score): d[W_ih_c ; W_hh_p ; w_q] = DGI^T H_l), DGH [B*T,1800] (d[W_hh_c ; W_ih_p] = DGH^T Mseq), dM [B*T,300]
  *     (d[Wr0 ; Wr1] = dM^T A with A from erc_dag_attn_sums), dks [B*T] (dw_k = dks^T H1).  Hl[l] = the input of layer l.
  *   state: int32 [1 + ceil(B / dg)], zero-filled ONCE by the caller: [0] is raised when a poll ran into its bound (results
- *     invalid; pass it to erc_adam_step as skip_flag), then one launch epoch per group (shared by both directions).
+ *     invalid; pass it to erc_adam_step as skip_flag) unless `health` names another word (erc_health_roll), then one
+ *     launch epoch per group (shared by both directions).
  *   scratch: erc_dag_rec_scratch_bytes(dir, B, T, cfg) bytes per direction, 8-byte aligned, zero-filled ONCE.
  * T <= 1022 and the per-workgroup LDS (histories of the slice: grows with dg * T) <= 160 KB. */
 int erc_dag_rec_config(int dir, int B, int T, int n_layers, int epc_hint, int dg_hint, int lpl_hint, int* cfg);
@@ -551,13 +569,14 @@ int erc_dag_rec_fwd(const float* H0, int ldh0, int n_layers, const float* const*
                     const float* const* b_ih_p, const float* const* Wr, const float* const* w_k,
                     const int32_t* pred, const int32_t* spk, int B, int T, float* const* H1, int ldo,
                     float* const* GI, int ldgi, float* const* Mseq, float* const* GH, float* const* R,
-                    float* const* ks, float* const* alpha, const int* cfg, int32_t* state, void* scratch, void* stream);
+                    float* const* ks, float* const* alpha, const int* cfg, int32_t* state, int32_t* health, void* scratch,
+                    void* stream);
 int erc_dag_rec_bwd(int n_layers, const float* const* Hl, int ldh, const float* const* GI, int ldgi,
                     const float* const* GH, const float* const* Mseq, const float* const* R, const float* const* alpha,
                     const float* const* Wh, const float* const* W_hh_c, const float* const* W_ih_p,
                     const float* const* Wr, const float* const* w_k, const int32_t* pred, const int32_t* spk, int B, int T,
                     float* dHall, int ldd, float* const* DGI, int lddgi, float* const* DGH, float* const* dM,
-                    float* const* dks, const int* cfg, int32_t* state, void* scratch, void* stream);
+                    float* const* dks, const int* cfg, int32_t* state, int32_t* health, void* scratch, void* stream);
 /* A[i, sel*300 + k] = sum_{j in window(i), relation sel} alpha[i,j] H1[j,k]  (sel 0: same speaker): the attention-weighted
  * sums of the hidden states, [B*T, 600].  d[Wr0 ; Wr1] = dM^T A (dagerc_models.py:356-358 under autograd). */
 int erc_dag_attn_sums(const float* alpha, const float* H1, int ldo, const int32_t* pred, const int32_t* spk, int B, int T,

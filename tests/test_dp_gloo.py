@@ -51,6 +51,15 @@ def _worker(rank, world, port, q):
     all_reduce_grads(flat)
     r0 = others[0]
     ok = ok and torch.allclose(torch.cat([flat.g(n).flatten() for n in flat.params]), r0, atol=1e-6)
+    # the health word rides behind the gradients: raised on ONE rank (a poll timeout there), non-zero on EVERY rank after
+    # the exchange, so all ranks skip the same update (FusedAdam.skip_flag) and all of them report it
+    ok = ok and int(flat.health[0]) == 0
+    if rank == 1:
+        flat.health.fill_(0x3f800000)        # ERC_HEALTH_RAISED
+    all_reduce_grads(flat)
+    ok = ok and int(flat.health[0]) != 0
+    all_reduce_grads(flat)                   # stays non-zero however often it is summed before the next roll
+    ok = ok and int(flat.health[0]) != 0 and flat.grad.data_ptr() == flat.grad_full.data_ptr()
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -66,6 +66,42 @@ def test_cogmen_bf16_feature_mode_full_config2():
     assert res["grad_norm_err"] < 1.5e-2, res["grad_norm_err"]
 
 
+# The bf16 compute mode against the UNROUNDED fp32 oracle at the benched shape: the mode's tolerance against the reference
+# as a pinned figure (BASELINE.md quotes these bounds next to the bf16 throughput; the 1e-4 path is --compute=f32).
+BF16_MODE_LOGIT_MAX, BF16_MODE_LOGIT_MEAN, BF16_MODE_GRAD_NORM = 5e-2, 6e-3, 5e-2
+
+
+def test_cogmen_bf16_mode_vs_unrounded_fp32_reference_config2():
+    """BASELINE.json configs[1] (B=32, T=110, D=1380) in the benched bf16 compute mode versus the oracle WITHOUT any
+    rounding (fp32 features, weights and products = the reference's PyTorch-CPU path).  What is bounded here is the
+    mode's quantisation (bf16 feature block, bf16 operands of the projection / RGCN / QKVS / weight-gradient products,
+    fp32 accumulation): logits of O(1) magnitude deviate by at most BF16_MODE_LOGIT_MAX (max) / BF16_MODE_LOGIT_MEAN
+    (mean), every live gradient by at most BF16_MODE_GRAD_NORM norm-wise.  north_star's 1e-4 is met by --compute=f32
+    (test_cogmen_config2_shape_parity), whose throughput bench.py reports next to this mode's."""
+    res = run_cogmen_parity(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=16),
+                            compute="bf16", ref_rounding=False)
+    print("bf16 mode vs fp32 reference: max|dlogit| %.3e mean %.3e (logit scale %.2f), grad norm-wise %.3e entry-wise %.3e"
+          % (res["logit_err"], res["logit_err_mean"], res["logit_scale"], res["grad_norm_err"], res["grad_err"]))
+    assert res["logit_err"] < BF16_MODE_LOGIT_MAX, res
+    assert res["logit_err_mean"] < BF16_MODE_LOGIT_MEAN, res
+    assert res["grad_norm_err"] < BF16_MODE_GRAD_NORM, res["grad_errs"]
+
+
+def test_cogmen_bf16_many_nodes_path():
+    """N > BN_FUSED_MAX_N (8 192): the path the B=512 figure of BASELINE.md runs on -- BatchNorm batch statistics in their
+    own launch (erc_bn_batch_stats), the head kernel reducing its own records, several rounds of weight-gradient work
+    items -- against the oracle with the mode's operand rounding.  Small D keeps the oracle's CPU time in seconds."""
+    from erc_amd.cogmen import COGMENModule
+    case = cogmen_case(B=160, min_len=40, max_len=70, dims=dict(a=12, t=20, v=16), seed=21)
+    assert int(case["batch"]["label"].shape[0]) > COGMENModule.BN_FUSED_MAX_N
+    res = run_cogmen_parity(case, compute="bf16")
+    assert res["logit_err"] < 1e-3, res
+    assert res["loss_err"] < 1e-4, res
+    assert res["grad_err"] < 5e-2, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:8]
+    assert res["grad_norm_err"] < 2e-2, res["grad_norm_err"]
+    assert res["bn_mean_err"] < 1e-4 and res["bn_var_err"] < 1e-4, res
+
+
 @pytest.mark.parametrize("case", [
     dict(B=4, min_len=3, max_len=14, dims=dict(a=12, t=20, v=16), seed=3),
     dict(B=3, min_len=1, max_len=1, dims=dict(a=4, t=4, v=4), seed=4),          # one-utterance dialogues: self loops only

@@ -123,27 +123,39 @@ def test_recurrence_configurations_agree(monkeypatch):
         assert float((res[key][2] - base[2]).abs().max()) <= 2e-6 * max(1.0, float(base[2].abs().max())), key
 
 
-def test_recurrence_timeout_fails_the_step_on_the_device():
-    """A raised error flag (what a recurrence kernel sets when an exchange wait runs into its bound) makes the optimizer
-    kernel skip the update -- parameters, moments and the step counter untouched, no host synchronisation involved -- and
-    check_cluster() reports it."""
+def _timeout_protocol(tr, batch):
+    """What the trainer sees when a persistent kernel's bounded poll times out in the middle of a step (the kernels store
+    ERC_HEALTH_RAISED into the health word, which lives behind the flat gradient): that step's update is skipped on the
+    device -- parameters, moments and the step counter untouched, no host synchronisation involved --, the NEXT step
+    counts the event, clears the word and trains normally, and check_cluster() reports the count once."""
     from erc_amd import capi
+    tr.train_step(batch)
+    before, step = tr.model.flat.data.clone(), int(tr.optim.state[0])
+    assert step == 1
+    tr.model.train()
+    tr.model.loss_and_grads(batch)
+    tr.model.flat.health.fill_(capi.HEALTH_RAISED)         # raised between the step's first launch and its optimizer launch
+    tr.optim.step()
+    assert torch.equal(tr.model.flat.data, before) and int(tr.optim.state[0]) == step
+    tr.train_step(batch)                                   # event counted and word cleared on the device: training continues
+    assert not torch.equal(tr.model.flat.data, before) and int(tr.optim.state[0]) == step + 1
+    assert int(tr.model.flat.health[0]) == 0 and int(tr.model.flat.events[0]) == 1
+    with pytest.raises(capi.ErcGraftError, match="1 optimizer step"):
+        tr.model.check_cluster()
+    tr.model.check_cluster()                               # reported once
+    tr.model.flat.health.fill_(capi.HEALTH_RAISED)         # raised by an evaluation pass: reported without a roll
+    with pytest.raises(capi.ErcGraftError):
+        tr.model.check_cluster()
+
+
+def test_recurrence_timeout_fails_the_step_on_the_device():
     from erc_amd.dagerc import DAGERCTrainer
     from erc_amd.params import ERCParams
     p = ERCParams().from_args(["--dataset=iemocap-cogmen-6", "--modality=a"])
     p.speaker_onehot, p.dropout = True, 0.0
     tr = DAGERCTrainer(p, DEV)
     batch = tr.prepare_batch(make_batch(3, p.dims(), n_classes=6, min_len=2, max_len=9, seed=3, modality="a", speaker_onehot=True))
-    tr.train_step(batch)
-    before, step = tr.model.flat.data.clone(), int(tr.optim.state[0])
-    assert step == 1
-    tr.model.rec_state[0] = 1
-    tr.train_step(batch)
-    assert torch.equal(tr.model.flat.data, before) and int(tr.optim.state[0]) == step
-    with pytest.raises(capi.ErcGraftError):
-        tr.model.check_cluster()
-    tr.train_step(batch)                                   # flag cleared by check_cluster: training continues
-    assert not torch.equal(tr.model.flat.data, before) and int(tr.optim.state[0]) == step + 1
+    _timeout_protocol(tr, batch)
 
 
 def test_dagerc_train_step_clip_adamw():

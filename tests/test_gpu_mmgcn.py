@@ -98,3 +98,47 @@ def test_mmgcn_train_steps_with_dropout_run():
     batch = make_batch(4, p.dims(), n_classes=6, min_len=5, max_len=20, seed=6, batch_first=False, speaker_onehot=True)
     losses = [float(tr.train_step(tr.prepare_batch(batch)).cpu()[0]) for _ in range(3)]
     assert all(math.isfinite(l) for l in losses)
+
+
+def _mmgcn_trainer():
+    from erc_amd.mmgcn import MMGCNTrainer
+    from erc_amd.params import ERCParams, Group
+    p = ERCParams().from_args(["--dataset=iemocap-cogmen-6", "--modality=atv"])
+    p.optim = Group(name="Adam", lr=3e-4, weight_decay=3e-5)
+    p.batch_first, p.speaker_onehot = False, True
+    tr = MMGCNTrainer(p, DEV)
+    batch = tr.prepare_batch(make_batch(4, p.dims(), n_classes=6, min_len=17, max_len=40, seed=6, batch_first=False,
+                                        speaker_onehot=True))
+    return tr, batch
+
+
+def test_chain_timeout_protocol():
+    """health word raised in the middle of a step -> update skipped on the device, next step counts + clears, reported once"""
+    from tests.test_gpu_dagerc import _timeout_protocol
+    _timeout_protocol(*_mmgcn_trainer())
+
+
+def test_chain_poll_timeout_fails_the_step_on_the_device():
+    """The real thing: with the poll bound at 1 the GCNII chain kernels (several workgroups per dialogue and modality that
+    exchange rows every layer) run into it, raise the health word themselves and drain; the optimizer launch of that step
+    leaves parameters, moments and the step count alone; check_cluster() reports it; the next step, with the default
+    bound, trains."""
+    from erc_amd import capi
+    tr, batch = _mmgcn_trainer()
+    tr.train_step(batch)
+    before, m_before, step = tr.model.flat.data.clone(), tr.model.flat.exp_avg.clone(), int(tr.optim.state[0])
+    assert tr.model._last_ws["chain"] and step == 1
+    capi.gcnii_chain_set_spin_limit(1)
+    try:
+        tr.train_step(batch)
+        torch.cuda.synchronize()
+    finally:
+        capi.gcnii_chain_set_spin_limit(0)
+    assert int(tr.model.flat.health[0]) == capi.HEALTH_RAISED
+    assert torch.equal(tr.model.flat.data, before) and torch.equal(tr.model.flat.exp_avg, m_before)
+    assert int(tr.optim.state[0]) == step
+    with pytest.raises(capi.ErcGraftError, match="GCNII chain"):
+        tr.model.check_cluster()
+    tr.train_step(batch)
+    assert int(tr.optim.state[0]) == step + 1 and int(tr.model.flat.health[0]) == 0
+    tr.model.check_cluster()

@@ -40,14 +40,17 @@ def rel_err(a, b, floor=1e-5):
     return float((a - b).abs().max() / (b.abs().max() + floor))
 
 
-def run_cogmen_parity(case, device="cuda:0", compute="f32", zero_grad=(), zero_tol=1e-5):
-    """eval-mode logits and train-mode (dropout p=0) loss/gradients: HIP path vs oracle."""
+def run_cogmen_parity(case, device="cuda:0", compute="f32", zero_grad=(), zero_tol=1e-5, ref_rounding=True):
+    """eval-mode logits and train-mode (dropout p=0) loss/gradients: HIP path vs oracle.
+    ``ref_rounding=False`` with compute="bf16": the oracle stays the UNROUNDED fp32 restatement of the reference (fp32
+    features, fp32 weights, fp32 products) -- what is measured is the bf16 compute mode's deviation from the reference,
+    quantisation included."""
     from oracle.cogmen import COGMENOracle
     from erc_amd.cogmen import COGMENModule
     torch.manual_seed(case["seed"])
     D, C, S = case["D"], case["n_classes"], case["n_speakers"]
     # bf16 mode runs the graph part's dense products on bf16 matrix cores: the oracle rounds the same operands
-    ref = COGMENOracle(D, 100, 17, S, C, dead_encoder=False, bf16_products=(compute == "bf16"))
+    ref = COGMENOracle(D, 100, 17, S, C, dead_encoder=False, bf16_products=(compute == "bf16" and ref_rounding))
     with torch.no_grad():  # make BN affine / running stats non-trivial
         ref.gcn.bn.weight.uniform_(0.5, 1.5)
         ref.gcn.bn.bias.uniform_(-0.3, 0.3)
@@ -64,10 +67,11 @@ def run_cogmen_parity(case, device="cuda:0", compute="f32", zero_grad=(), zero_t
         # give the oracle the SAME rounded operands so that the test isolates implementation error
         # (fp32 accumulate) from the quantisation error of the mode itself.
         dbatch["input_tensor"] = dbatch["input_tensor"].to(torch.bfloat16)
-        batch = dict(batch, input_tensor=batch["input_tensor"].to(torch.bfloat16).float())
-        with torch.no_grad():
-            ref.rnn[1].weight.copy_(ref.rnn[1].weight.to(torch.bfloat16).float())
-            mine.rnn[1].weight.copy_(ref.rnn[1].weight.to(device))
+        if ref_rounding:
+            batch = dict(batch, input_tensor=batch["input_tensor"].to(torch.bfloat16).float())
+            with torch.no_grad():
+                ref.rnn[1].weight.copy_(ref.rnn[1].weight.to(torch.bfloat16).float())
+                mine.rnn[1].weight.copy_(ref.rnn[1].weight.to(device))
     out = {}
     # --- eval logits
     ref.eval(), mine.eval()
@@ -75,6 +79,8 @@ def run_cogmen_parity(case, device="cuda:0", compute="f32", zero_grad=(), zero_t
         want, want_feat = ref(**batch)
     got, got_feat = mine(**dbatch)
     out["logit_err"] = float((got.cpu() - want).abs().max())
+    out["logit_err_mean"] = float((got.cpu() - want).abs().mean())
+    out["logit_scale"] = float(want.abs().max())
     out["feat_err"] = float((got_feat.cpu() - want_feat).abs().max())
     # --- train mode, dropout off: loss + every live gradient + BN running stats
     ref.train(), mine.train()

@@ -3,7 +3,8 @@
 # tracked summaries under profiles/ from the newest run of every directory.
 set -e
 cd "$(dirname "$0")/.."
-T=r02_cogmen_b32_bf16
+R=${ROUND:-r03}
+T=${R}_cogmen_b32_bf16
 python tools/pmc_summary.py --trace gpurun_out/prof_r2 --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --tag $T --kernel wgrad_table > /dev/null
 cp profiles/${T}_pmc.json profiles/${T}_wgrad_table_pmc.json
 for k in gemm_bf16a_persist:projection cogmen_fwd_tile:cogmen_fwd_tile cogmen_bwd_tile:cogmen_bwd_tile adam_kernel:adam_kernel head_fused:head_fused; do
@@ -12,8 +13,8 @@ for k in gemm_bf16a_persist:projection cogmen_fwd_tile:cogmen_fwd_tile cogmen_bw
   cp /tmp/pmcs/${T}_${tg}_pmc.json profiles/
 done
 for m in dagerc dgcn mmgcn; do
-  python tools/pmc_summary.py --trace gpurun_out/prof_$m --tag r02_$m --kernel zzz --out /tmp/pmcs > /dev/null
-  cp /tmp/pmcs/r02_${m}_kernel_stats.csv profiles/
+  python tools/pmc_summary.py --trace gpurun_out/prof_$m --tag ${R}_$m --kernel zzz --out /tmp/pmcs > /dev/null
+  cp /tmp/pmcs/${R}_${m}_kernel_stats.csv profiles/
 done
 python - <<'PY'
 import csv, glob, os, json
@@ -28,9 +29,10 @@ for k, d in acc.items():
         cu = sum(d["SQ_BUSY_CU_CYCLES"]) / len(d["SQ_BUSY_CU_CYCLES"])
         if cu > 0 and busy > 0:
             out[k.replace("(anonymous namespace)::", "").split("(")[0]] = round(busy / (4 * cu), 4)
-p = "profiles/r02_cogmen_b32_bf16_mfma_pmc.json"
-old = json.load(open(p))
-key = [k for k in old if k.startswith("mfma_busy")][0]
+p = "profiles/%s_cogmen_b32_bf16_mfma_pmc.json" % os.environ.get("ROUND", "r03")
+key = "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), own --pmc pass (tools/pmc_mfma.sh)"
+old = json.load(open(p)) if os.path.exists(p) else {}
+key = next((k for k in old if k.startswith("mfma_busy")), key)
 old[key] = dict(sorted(out.items(), key=lambda kv: -kv[1]))
 json.dump(old, open(p, "w"), indent=1)
 PY
