@@ -93,6 +93,7 @@ class COGMENModule(nn.Module):
         self.use_fused_graph = False   # set by finalize() in bf16 mode
         self.wgrad_bf16 = True         # bf16 mode: the graph part's and the projection's weight gradients on bf16 matrix cores
         self.fuse_head = True   # training path: csrc/head.hip instead of separate BN / Linear / CE launches
+        self.fuse_project_graph = True   # bf16 mode: graph build inside the projection launch (csrc/cogmen_project.hip)
         self.flat = None
         self._ws = WorkspaceCache()
         self._seed = seed
@@ -244,16 +245,26 @@ class COGMENModule(nn.Module):
         pl.reset()
         F, C, D = F_HID, self.n_classes, self.input_size
         x_bf16 = x.dtype == torch.bfloat16
-        capi.window_graph_build(text_length, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
-                                B, T, WP, WF, self.n_speakers, N, ws["E"], g)
+        if self.shadows is not None and self._shadow_auto:
+            self.refresh_shadows()
+        # bf16 mode: the projection's workgroups build the window graph themselves (csrc/cogmen_project.hip): one launch
+        # and one launch gap less than graph build + projection
+        project_graph = (self.fuse_project_graph and x_bf16 and self.w1_shadow is not None and self.enc_train is None
+                         and speaker_tensor.dim() == 2 and x.is_contiguous()
+                         and capi.cogmen_project_graph_ok(D, F, B, D, D))
+        if project_graph:
+            capi.cogmen_project_graph(x, D, self.w1_shadow, D, fp.w("rnn.1.bias"), ws["H0"], F, F, D, text_length,
+                                      speaker_tensor, B, T, WP, WF, self.n_speakers, N, ws["E"], g)
+        else:
+            capi.window_graph_build(text_length, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
+                                    B, T, WP, WF, self.n_speakers, N, ws["E"], g)
         if self.enc_train is not None:      # chained mode: the projection reads the encoder's bf16 output
             x = self.enc_train.forward(x, text_length, training, self.rng_state)
             x_bf16 = True
             ws["x_enc"] = x
-        if self.shadows is not None and self._shadow_auto:
-            self.refresh_shadows()
         W1 = self.w1_shadow if (x_bf16 and self.w1_shadow is not None) else fp.w("rnn.1.weight")
-        linear_fwd(pl, x, D, g["node_row"], W1, fp.w("rnn.1.bias"), ws["H0"], F, N, F, D, x_bf16=x_bf16)
+        if not project_graph:
+            linear_fwd(pl, x, D, g["node_row"], W1, fp.w("rnn.1.bias"), ws["H0"], F, N, F, D, x_bf16=x_bf16)
         if ws.get("fused"):
             bn = self.gcn.bn
             # training with the fused head: BatchNorm's batch statistics come out of the same launch

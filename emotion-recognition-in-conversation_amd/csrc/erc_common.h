@@ -47,6 +47,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Window graph (track_mm/cogmen_utils.py:109-172): sum_{q<p} deg(q) with deg(q) = min(L-1, q+fwd) - max(0, q-back) + 1 --
+// the closed form behind every CSR offset of a dialogue of L utterances.
+__device__ __forceinline__ int erc_window_prefix(int p, int L, int back, int fwd) {
+    const int a = min(p, max(0, L - fwd));  // #q<p whose upper end is not clipped
+    const int c = max(0, p - back);         // #q<p whose lower end is not clipped
+    return a * (a - 1) / 2 + a * fwd + (p - a) * (L - 1) - c * (c - 1) / 2 + p;
+}
+
 // Counter-based RNG (splitmix64 finaliser over (seed, offset, index)): one
 // uniform in [0,1) per element, reproducible between forward and backward.
 __device__ __forceinline__ float erc_uniform(uint64_t seed, uint64_t offset, uint64_t idx) {

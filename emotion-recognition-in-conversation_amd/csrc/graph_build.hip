@@ -10,12 +10,7 @@
 
 namespace {
 
-// sum_{q<p} deg(q) with deg(q) = min(L-1, q+fwd) - max(0, q-back) + 1
-__device__ __forceinline__ int window_prefix(int p, int L, int back, int fwd) {
-    int a = min(p, max(0, L - fwd));  // #q<p whose upper end is not clipped
-    int c = max(0, p - back);         // #q<p whose lower end is not clipped
-    return a * (a - 1) / 2 + a * fwd + (p - a) * (L - 1) - c * (c - 1) / 2 + p;
-}
+__device__ __forceinline__ int window_prefix(int p, int L, int back, int fwd) { return erc_window_prefix(p, L, back, fwd); }
 
 __global__ __launch_bounds__(256) void window_graph_kernel(
     const int64_t* __restrict__ lengths, const int64_t* __restrict__ speakers, int64_t spk_sb, int64_t spk_st,

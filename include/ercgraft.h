@@ -425,6 +425,22 @@ int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes,
                         const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
                         int head_part_floats, float* dgamma, float* dbeta, float* stats, void* stream);
 
+/* COGMEN bf16 mode, first launch of the step (csrc/cogmen_project.hip): the input projection
+ *   H0[n, :n_out] = X[row(n), :K] W^T + bias   (track_mm/cogmen.py:103-105,147: rnn.1 on the valid utterances; X bf16
+ *   [B*T, ldx] = the padded feature block of ERCCollate, W bf16 [n_out, ldw] = the optimizer-maintained shadow)
+ * AND every output of erc_window_graph_build (same arrays, same values: track_mm/cogmen_utils.py:109-172) computed from
+ * lengths [B] / speakers [B, T] by the projection's own workgroups -- no separate graph-build launch, no node -> row map
+ * read in front of the feature rows.  counts[0] / counts[1] = number of nodes / edges; nothing else is written when they
+ * exceed n_cap / e_cap.  Lengths are clamped to [0, T].  Supported sizes: erc_cogmen_project_graph_ok() != 0
+ * (n_out <= 112, 32 <= K <= 1536, K, ldx, ldw multiples of 4, B <= 2048); X, W 8-byte aligned. */
+int erc_cogmen_project_graph_ok(int K, int n_out, int B, int ldx, int ldw);
+int erc_cogmen_project_graph(const void* X, int ldx, const void* W, int ldw, const float* bias, float* H0, int ldh0,
+                             int n_out, int K, const int64_t* lengths, const int64_t* speakers, int64_t spk_sb,
+                             int64_t spk_st, int B, int T, int wp, int wf, int n_speakers, int n_cap, int e_cap,
+                             int32_t* node_off, int32_t* node_row, int32_t* node_spk, int32_t* in_ptr, int32_t* in_src,
+                             int32_t* in_typ, int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ, int32_t* out_eid,
+                             int32_t* counts, void* stream);
+
 /* diagnostic: phase stamps (10 ns ticks) of the middle workgroup of the following erc_cogmen_{fwd,bwd}_tile launches,
  * 8 x uint64 device memory; NULL switches them off (tools/cogmen_stamps.py) */
 int erc_cogmen_set_stamps(uint64_t* stamps);
