@@ -70,8 +70,11 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- exclusive scan of (nodes, edges) per dialogue over the batch, 512 dialogues per pass
+    // ---- exclusive scan of (nodes, edges) per dialogue over the batch, 512 dialogues per pass.  The thread of dialogue t
+    //      knows its node range without reading LDS, so it marks the rows of this workgroup's FIRST row group right away:
+    //      two barriers between the lengths and the feature-row addresses
     int carry_n = 0, carry_e = 0;
+    const int n0_first = pair * 16;
     for (int c0 = 0; c0 < p.B; c0 += 512) {
         const int t = c0 + tid;
         int L = c0 == 0 ? L0 : (int)p.lengths[min(t, p.B - 1)];
@@ -83,6 +86,7 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
             const int vn = __shfl_up(sn, o, 64), ve = __shfl_up(se, o, 64);
             if (lane >= o) sn += vn, se += ve;
         }
+        if (c0 > 0) __syncthreads();    // the previous pass has read s_wn / s_we
         if (lane == 63) s_wn[w] = sn, s_we[w] = se;
         __syncthreads();
         int bn = carry_n, be = carry_e, tn = 0, te = 0;
@@ -92,9 +96,12 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
             tn += a, te += b;
             if (ww < w) bn += a, be += b;
         }
-        if (t < p.B) s_noff[t] = bn + sn - L, s_eoff[t] = be + se - E;
+        if (t < p.B) {
+            const int off = bn + sn - L;
+            s_noff[t] = off, s_eoff[t] = be + se - E;
+            for (int n = max(off, n0_first); n < min(off + L, n0_first + 16); ++n) s_dlg[n - n0_first] = t;
+        }
         carry_n += tn, carry_e += te;
-        __syncthreads();
     }
     if (tid == 0) s_noff[p.B] = carry_n, s_eoff[p.B] = carry_e;
     const int N = carry_n, Etot = carry_e;
@@ -131,13 +138,15 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
     const int n_rg = (N + 15) / 16;
     for (int rg = pair; rg < n_rg; rg += n_pairs) {
         const int n0 = rg * 16;
-        // ---- node -> dialogue of the 16 rows: dialogue t marks the rows of [n0, n0 + 16) it owns
-        __syncthreads();
-        for (int t = tid; t < p.B; t += 512) {
-            const int lo = max(s_noff[t], n0), hi = min(s_noff[t + 1], n0 + 16);
-            for (int n = lo; n < hi; ++n) s_dlg[n - n0] = t;
+        // ---- node -> dialogue of the 16 rows: dialogue t marks the rows of [n0, n0 + 16) it owns (first group: done above)
+        if (rg != pair) {
+            __syncthreads();
+            for (int t = tid; t < p.B; t += 512) {
+                const int lo = max(s_noff[t], n0), hi = min(s_noff[t + 1], n0 + 16);
+                for (int n = lo; n < hi; ++n) s_dlg[n - n0] = t;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // ---- A fragments: feature row of node n0 + r is row b * T + position of the padded block
         bf16x8 af[PG_NB];
         {

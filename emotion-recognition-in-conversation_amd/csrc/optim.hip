@@ -50,11 +50,10 @@ __device__ __forceinline__ unsigned short f2bf_u16(float f) {
 // Four consecutive elements (i0 % 4 == 0) at once: with src_off, n0 multiples of 4 (checked by the host; the flat buffer
 // aligns every group to 64 floats) they share d1 and d2, so one index decomposition serves the quad, and when they run
 // along k (sn0 = 0, sk0 = 1, k % 4 == 0) the four bf16 are one 8-byte store in either layout.
-__device__ __forceinline__ void shadow_store4(unsigned short* __restrict__ shadow, const ShadowTab& tab, int64_t i0, float4 pn,
-                                              int skip = -1) {
+__device__ __forceinline__ void shadow_store4(unsigned short* __restrict__ shadow, const ShadowTab& tab, int64_t i0, float4 pn) {
 #pragma unroll
     for (int t = 0; t < SHADOW_MAX; ++t) {
-        if (t < tab.n && t != skip) {
+        if (t < tab.n) {
             const ShadowDesc& d = tab.d[t];
             const int64_t idx = i0 - d.src_off;
             if (idx >= 0 && idx < d.n_el) {
@@ -101,22 +100,6 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __rest
     }
 }
 
-// Work decomposition of the optimizer launch when the shadow table holds ROW-TRANSPOSED ranges (source [k][n] row-major with
-// n0 = row length, destination fragment order [n][k]: consecutive source elements land 2 bytes each in different cache
-// lines -- 130 k scattered 2-byte stores for the two transposed copies of the fused COGMEN kernels, +2.4 us).  The flat
-// buffer is cut into regions: plain ones in 1024-element chunks, a transposed range in chunks of 8 source rows (8 n0 <=
-// 1024 elements, aligned to multiples of 8 rows), one workgroup per chunk.  A chunk of a transposed range stages its new
-// values in LDS and writes, per destination column n, the 8 consecutive k as ONE 16-byte store.  Passed by value: a
-// workgroup finds its chunk with scalar compares, no table read in front of its loads.
-constexpr int SEG_MAX = 2 * SHADOW_MAX + 1;
-struct AdamSegs {
-    int n;                       // regions in use (0: uniform 1024-element chunks with a grid stride, no staging)
-    int blk0[SEG_MAX + 1];       // first workgroup of the region; blk0[n] = number of workgroups
-    int chunk[SEG_MAX];          // elements per workgroup
-    int tdesc[SEG_MAX];          // shadow descriptor transposed through LDS, or -1
-    int64_t start[SEG_MAX], end[SEG_MAX];
-};
-
 // torch.optim.Adam / AdamW update (torch/optim/adam.py single-tensor path):
 //   g += wd*p (Adam)  |  p *= 1 - lr*wd (AdamW)
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
@@ -127,27 +110,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float grad_scale, float clip_norm,
                                                    const float* __restrict__ gnorm, int64_t* state,
                                                    unsigned short* __restrict__ shadow, const ShadowTab tab,
-                                                   const int32_t* __restrict__ skip_flag, const AdamSegs segs) {
-    __shared__ __attribute__((aligned(16))) unsigned short s_t[1024];
+                                                   const int32_t* __restrict__ skip_flag) {
     // a producer of this step's gradients (the DAG-ERC recurrence kernels) flagged an exchange timeout: the
     // gradients are invalid -- leave parameters, moments and the step counter untouched (checked on the device, no sync)
     if (skip_flag && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     // first quad of this thread: requested before the (dependent, transcendental) bias-correction math
-    int64_t nq = n >> 2;
-    int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x, q_stride = (int64_t)gridDim.x * 256;
-    int td = -1;
-    int64_t e0 = 0, e1 = 0;
-    if (segs.n > 0) {   // (uniform) this workgroup's chunk
-        const int b = blockIdx.x;
-        int ri = 0;
-#pragma unroll
-        for (int t = 1; t < SEG_MAX; ++t)
-            if (t < segs.n && b >= segs.blk0[t]) ri = t;
-        e0 = segs.start[ri] + (int64_t)(b - segs.blk0[ri]) * segs.chunk[ri];
-        e1 = min(e0 + segs.chunk[ri], segs.end[ri]);
-        td = segs.tdesc[ri];
-        q0 = (e0 >> 2) + threadIdx.x, nq = e1 >> 2, q_stride = (int64_t)1 << 40;
-    }
+    const int64_t nq = n >> 2;
+    const int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t q0c = q0 < nq ? q0 : 0;
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), mv = pv, vv = pv, gv = pv;
     if (nq > 0) {  // uniform
@@ -181,7 +150,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         if (shadow) shadow_store(shadow, tab, i, pn);
     };
     // 16-byte accesses: one quad per thread and grid stride (the launch sizes the grid for a single pass)
-    for (int64_t q = q0; q < nq; q += q_stride) {
+    for (int64_t q = q0; q < nq; q += (int64_t)gridDim.x * 256) {
         if (q != q0) {
             pv = reinterpret_cast<float4*>(p)[q], mv = reinterpret_cast<float4*>(m)[q], vv = reinterpret_cast<float4*>(v)[q];
             gv = reinterpret_cast<const float4*>(g)[q];
@@ -190,35 +159,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         update(pv.z, gv.z, mv.z, vv.z), update(pv.w, gv.w, mv.w, vv.w);
         reinterpret_cast<float4*>(m)[q] = mv, reinterpret_cast<float4*>(v)[q] = vv, reinterpret_cast<float4*>(p)[q] = pv;
         if (shadow) {
-            if (quad_ok) shadow_store4(shadow, tab, 4 * q, pv, td);
+            if (quad_ok) shadow_store4(shadow, tab, 4 * q, pv);
             else to_shadow(4 * q, pv.x), to_shadow(4 * q + 1, pv.y), to_shadow(4 * q + 2, pv.z), to_shadow(4 * q + 3, pv.w);
-            if (td >= 0) {   // stage the chunk for the transposed copy (one quad per thread in this mode)
-                const int li = (int)(4 * q - e0);
-                *reinterpret_cast<uint2*>(s_t + li) = make_uint2((uint32_t)f2bf_u16(pv.x) | ((uint32_t)f2bf_u16(pv.y) << 16),
-                                                                 (uint32_t)f2bf_u16(pv.z) | ((uint32_t)f2bf_u16(pv.w) << 16));
-            }
-        }
-    }
-    if (td >= 0) {   // (uniform) rows [k0, k0 + rows) of the source, n0 columns: column c -> 8 consecutive k of destination row c
-        __syncthreads();
-        const ShadowDesc& d = tab.d[td];
-        const int n0 = d.n0, k0 = (int)((e0 - d.src_off) / n0), rows = (int)((e1 - e0) / n0);
-        const int c = threadIdx.x;
-        if (c < n0) {
-            if (rows == 8) {
-                unsigned short h[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] = s_t[j * n0 + c];
-                *reinterpret_cast<uint4*>(shadow + shadow_dst(d, c, k0)) =
-                    make_uint4((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16),
-                               (uint32_t)h[4] | ((uint32_t)h[5] << 16), (uint32_t)h[6] | ((uint32_t)h[7] << 16));
-            } else {
-                for (int j = 0; j < rows; ++j) shadow[shadow_dst(d, c, k0 + j)] = s_t[j * n0 + c];
-            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const int64_t i = ((n >> 2) << 2) + threadIdx.x;
+        const int64_t i = (nq << 2) + threadIdx.x;
         float pi = p[i], mi = m[i], vi = v[i];
         update(pi, g[i], mi, vi);
         m[i] = mi, v[i] = vi, p[i] = pi;
@@ -329,53 +275,17 @@ static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, 
                         (d.mode == 1 || d.ld % 4 == 0) && ((uintptr_t)shadow_base & 7) == 0;
         if (kq) tab.flags |= 2 << t;
     }
-    // regions for the LDS-transposed copies: descriptors with n = d0 (sn = 1,0,0), k = d1 (sk = 0,1,0), fragment order,
-    // rows of n0 <= 128 elements (n0 % 4 == 0), on the quad fast path, ranges disjoint
-    AdamSegs segs{};
-    if ((tab.flags & 1) && tab.n > 0) {
-        int order[SHADOW_MAX], nt = 0;
-        for (int t = 0; t < tab.n; ++t) {
-            const ShadowDesc& d = tab.d[t];
-            if (d.mode == 1 && d.sn0 == 1 && d.sn1 == 0 && d.sn2 == 0 && d.sk0 == 0 && d.sk1 == 1 && d.sk2 == 0 && d.n0 % 4 == 0 &&
-                d.n0 <= 128 && d.n_el % d.n0 == 0 && (int64_t)d.n0 * d.n1 >= d.n_el && d.dst_off % 8 == 0 &&
-                ((uintptr_t)shadow_base & 15) == 0)
-                order[nt++] = t;
-        }
-        for (int a = 1; a < nt; ++a)   // by source offset
-            for (int b = a; b > 0 && tab.d[order[b]].src_off < tab.d[order[b - 1]].src_off; --b) {
-                const int x = order[b]; order[b] = order[b - 1]; order[b - 1] = x;
-            }
-        bool ok = nt > 0 && (n & 3) == 0;
-        int64_t pos = 0;
-        int blk = 0, nr = 0;
-        auto add = [&](int64_t a, int64_t b, int chunk, int td) {
-            if (b <= a) return;
-            segs.blk0[nr] = blk, segs.chunk[nr] = chunk, segs.tdesc[nr] = td, segs.start[nr] = a, segs.end[nr] = b;
-            blk += (int)((b - a + chunk - 1) / chunk);
-            ++nr;
-        };
-        for (int a = 0; a < nt && ok; ++a) {
-            const ShadowDesc& d = tab.d[order[a]];
-            if (d.src_off < pos) { ok = false; break; }
-            add(pos, d.src_off, 1024, -1);
-            add(d.src_off, d.src_off + d.n_el, 8 * d.n0, order[a]);
-            pos = d.src_off + d.n_el;
-        }
-        if (ok) add(pos, n, 1024, -1);
-        if (ok && blk <= 512) segs.n = nr, segs.blk0[nr] = blk;   // blk0[n] = number of workgroups
-    }
     ERC_REQUIRE(p && g && m && v && state && n > 0, "adam_step: bad arguments");
     ERC_REQUIRE(clip_norm <= 0.f || gnorm, "adam_step: clip_norm needs gnorm");
     ERC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: 16-byte alignment");
     if (int rc = check_shadow_tab(tab, n, shadow_numel, "adam_step")) return rc;
     int grid = (int)((n / 4 + 255) / 256);   // one float4 per thread
     if (grid < 1) grid = 1;
-    if (grid > 512) grid = 512;  // one private step count per workgroup in state[4 ..)
-    if (segs.n > 0) grid = segs.blk0[segs.n];
+    if (grid > 512) grid = 512;  // one arrival atomic per block on a single word: keep the count low
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                        decoupled, grad_scale, clip_norm, gnorm, state, tab.n > 0 ? (unsigned short*)shadow_base : nullptr, tab,
-                       skip_flag, segs);
+                       skip_flag);
     ERC_LAUNCH_CHECK("adam_step");
     return ERC_OK;
 }

@@ -173,6 +173,7 @@ class GemmPlanner:
             cap = capi.wgrad_max_k_per_split()
             raw, items, tiles, bases = [], 0, 0, []
             steps = int(os.environ.get("ERC_WG_STEPS", 0))
+            max_split = int(os.environ.get("ERC_WG_MAXSPLIT", 32))
             if steps <= 0:
                 # 64 k-steps per item (16 per wavefront) while all items of the launch fit the chip at once (768 workgroup
                 # slots: COGMEN, DialogueGCN); with several rounds of items the per-item overhead (LDS reduce, slab, arrival)
@@ -187,12 +188,12 @@ class GemmPlanner:
                         (not bf16 and b.dtype != torch.float32) or (a_bf16 and bf16):
                     raise capi.ErcGraftError("wgrad table: operand dtypes %s %s %s" % (a.dtype, b.dtype, c.dtype))
                 nks = -(-K // 4)
-                splits = max(1, min(32, (nks + steps // 2) // steps))
+                splits = max(1, min(max_split, (nks + steps // 2) // steps))
                 splits = max(splits, -(-K // cap))
                 per = -(-nks // splits)
                 splits = -(-nks // per)                       # no empty split
                 if per * 4 > cap:
-                    raise capi.ErcGraftError("wgrad table: K=%d needs more than 32 splits" % K)
+                    raise capi.ErcGraftError("wgrad table: K=%d needs more than %d splits" % (K, max_split))
                 tm, tn = -(-M // 64), -(-N // 64)
                 vec = (1 if (M % 4 == 0 and lda % 4 == 0 and a.data_ptr() % (8 if a_bf16 else 16) == 0) else 0) \
                     | (2 if (N % 4 == 0 and ldb % 4 == 0 and b.data_ptr() % (8 if bf16 else 16) == 0) else 0) \
