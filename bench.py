@@ -67,10 +67,11 @@ def _probe_candidates(module, params, host_batch, trainer):
     N = sum(lens)
     if module == "cogmen":
         pl = trainer.model._last_ws["planner"]
-        fl = sum(2.0 * d[6] * d[7] * d[8] for d in pl.deferred)
+        recs = pl.deferred + pl.deferred16
+        fl = sum(2.0 * d[6] * d[7] * d[8] for d in recs)
         # operands of every dW = A^T B record read once + the gradient written once: K*M*sizeof(A) + K*N*sizeof(B) + M*N*4
         wg_bytes = sum(d[8] * d[6] * d[0].element_size() + d[8] * d[7] * d[2].element_size() + d[6] * d[7] * 4.0
-                       for d in pl.deferred)
+                       for d in recs)
         C = params.n_classes
         E = 11 * N
         fused = bool(trainer.model._last_ws.get("fused"))
@@ -83,6 +84,8 @@ def _probe_candidates(module, params, host_batch, trainer):
         bwd_b = N * (400 + 400 + 1600 + 1600 + 400 + 400) + E * (17 + 4.0) + 0.26e6   # dY, H2, QKVS in; dQKVS, dH1, dH0 out
         cands = {"erc_wgrad_table": ("wgrad_table_kernel (every weight gradient of the step, one launch)", fl, wg_bytes) +
                  (bf if fused and trainer.model.wgrad_bf16 else f32p),
+                 "erc_wgrad_bf16": ("wgrad_bf16_kernel (every weight gradient of the step from bf16 operands, one launch)", fl,
+                                    wg_bytes) + bf,
                  # BatchNorm apply, two 100 x 100 products forward + one backward, the C-wide products on the VALU
                  "erc_head_fused": ("head_fused_kernel (BatchNorm apply .. cross entropy .. dY, one launch)",
                                     N * (3 * 2.0 * 100 * 100 + 4.0 * 100 * C), head_b) + f32p,

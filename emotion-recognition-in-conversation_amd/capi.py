@@ -47,9 +47,14 @@ _SIGS = {
     "erc_bn_batch_stats": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "erc_head_fused_ws_floats": (C.c_int64, [_i]),
     "erc_head_fused": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "erc_head_fused_bn": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
-                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _i, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _i,
+                                    _vp, _vp, _vp, _vp, _i, _vp]),
+    "erc_wgrad_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "erc_wgrad_bf16_slab_floats": (C.c_int64, []),
+    "erc_wgrad_bf16_set_stamps": (C.c_int, [_vp, _i]),
+    "erc_wgrad_bf16_max_k_per_split": (C.c_int, []),
     "erc_bn_bwd_apply": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_wgrad_max_k_per_split": (C.c_int, []),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
@@ -81,7 +86,7 @@ _SIGS = {
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
                                       _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp]),
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "erc_head_fused_part_floats": (C.c_int, []),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
@@ -465,13 +470,14 @@ def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, 
 
 
 def cogmen_bwd_tile(dY, H2, ldh2, N, wp, wf, gamma, saved, bn_bwd, QKVS, alpha, g, inv_cnt, WqT, Wb, scale, dQKVS, dH1,
-                    dH0, lddh0, n_speakers=2, head_part=None, head_parts=0, dgamma=None, dbeta=None, stats=None):
+                    dH0, lddh0, n_speakers=2, head_part=None, head_parts=0, dgamma=None, dbeta=None, stats=None, grads_bf16=False,
+                    lddh1=100):
     _check(lib().erc_cogmen_bwd_tile(ptr(dY), ptr(H2), ldh2, N, wp, wf, ptr(gamma), ptr(saved), ptr(bn_bwd), ptr(QKVS),
                                      ptr(alpha), ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["out_ptr"]), ptr(g["out_dst"]),
                                      ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(inv_cnt), ptr(WqT), ptr(Wb), scale,
                                      ptr(dQKVS), ptr(dH1), ptr(dH0), lddh0, ptr(g["node_spk"]), n_speakers, ptr(head_part),
                                      head_parts, head_fused_part_floats() if head_part is not None else 0, ptr(dgamma),
-                                     ptr(dbeta), ptr(stats), stream()), "erc_cogmen_bwd_tile")
+                                     ptr(dbeta), ptr(stats), int(grads_bf16), lddh1, stream()), "erc_cogmen_bwd_tile")
 
 
 def grad_norm(g, n, grad_scale, gnorm, ws):
@@ -786,17 +792,20 @@ def head_fused_ws_floats(n_rows):
 
 
 def head_fused(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
-               H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws):
+               H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bf16_out=None):
+    """bf16_out: (H3b, Zb, dZb, dlb, pitch) -- bf16 copies of the classifier's weight-gradient operands, or None"""
+    b = bf16_out if bf16_out is not None else (None, None, None, None, 0)
     _call("erc_head_fused", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
-          float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws)
+          float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, b[0], b[1], b[2], b[3], b[4])
 
 
 def head_fused_bn(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                   H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, running_mean,
-                  running_var, momentum, eps, defer_reduce=False):
+                  running_var, momentum, eps, defer_reduce=False, bf16_out=None):
+    b = bf16_out if bf16_out is not None else (None, None, None, None, 0)
     _call("erc_head_fused_bn", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
           float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles,
-          running_mean, running_var, float(momentum), float(eps), int(defer_reduce))
+          running_mean, running_var, float(momentum), float(eps), int(defer_reduce), b[0], b[1], b[2], b[3], b[4])
 
 
 def head_fused_part_floats():
@@ -867,6 +876,23 @@ def enc_colsum(X, ldx, R, Cn, out, ws):
 
 def enc_inverse_rows(node_row, N, inv, n_rows):
     _call("erc_enc_inverse_rows", node_row, N, inv, n_rows)
+
+
+def wgrad_bf16(table, n_desc, item_base, n_items, slabs, counters):
+    """item_base: ctypes int32 array (host) of the descriptors' first work items (csrc/wgrad_bf16.hip)"""
+    _check(lib().erc_wgrad_bf16(ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), stream()), "erc_wgrad_bf16")
+
+
+def wgrad_bf16_set_stamps(t, item=0):
+    _check(lib().erc_wgrad_bf16_set_stamps(ptr(t), int(item)), "erc_wgrad_bf16_set_stamps")
+
+
+def wgrad_bf16_slab_floats():
+    return int(lib().erc_wgrad_bf16_slab_floats())
+
+
+def wgrad_bf16_max_k_per_split():
+    return int(lib().erc_wgrad_bf16_max_k_per_split())
 
 
 def wgrad_slab_floats():

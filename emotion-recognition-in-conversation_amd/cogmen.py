@@ -219,6 +219,9 @@ class COGMENModule(nn.Module):
             bn_tile_ws=torch.zeros(capi.cogmen_fwd_tile_ws_doubles(N), dtype=torch.float64, device=device),
             head_ws=torch.zeros(capi.head_fused_ws_floats(N), dtype=torch.float32, device=device), bn_bwd=f32(2 * F),
             dlogits=f32(N, C), dZ=f32(N, F), dH3=f32(N, F), dQKVS=f32(N, 4 * F), dH1=f32(N, F), dH0=f32(N, F),
+            # bf16 operands of the weight-gradient launch (csrc/wgrad_bf16.hip), written by the head / backward tile kernels;
+            # zero-filled once: the pad columns are read (into output rows nobody stores) and must stay finite
+            H3b=bf(N, 104), Zb=bf(N, 104), dZb=bf(N, 104), dlb=bf(N, 8), dQKVSb=bf(N, 4 * F), dH1b=bf(N, 104), dH0b=bf(N, 104),
         )
         slab = 16 * N * F + 8 * (F * D + 9 * F * F + 4 * F * F + 2 * F * F) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
@@ -334,6 +337,10 @@ class COGMENModule(nn.Module):
         fused = bool(ws.get("fused"))
         if fused and not fused_head:
             raise capi.ErcGraftError("COGMEN bf16 mode trains through the fused head (C <= 8)")
+        # bf16 mode: every weight gradient of the step on the bf16 matrix cores from bf16 operands (csrc/wgrad_bf16.hip)
+        w16 = bool(fused and self.wgrad_bf16 and x_bf16 and C <= 8 and D % 4 == 0 and x.is_contiguous() and x.data_ptr() % 8 == 0)
+        ws["w16"] = w16
+        b16 = (ws["H3b"], ws["Zb"], ws["dZb"], ws["dlb"], 104) if w16 else None
         if fused_head:
             head_args = (ws["H2"], F, N, F, C, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
                          fp.w("cls.0.weight"), fp.w("cls.0.bias"), fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys,
@@ -344,23 +351,27 @@ class COGMENModule(nn.Module):
                 # BatchNorm's batch statistics: per-tile sums from the forward tile kernel, added up by every head workgroup
                 # ... and the head's own cross-workgroup sums (BatchNorm backward means, loss) are left to the backward tile kernel
                 capi.head_fused_bn(*head_args, ws["bn_tile_ws"][2:].view(torch.float32), -(-N // 16), bn.running_mean,
-                                   bn.running_var, bn.momentum, bn.eps, defer_reduce=True)
+                                   bn.running_var, bn.momentum, bn.eps, defer_reduce=True, bf16_out=b16)
                 ws["head_deferred"] = True
             else:
                 capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
                                     ws["bn_stats_ws"])
-                capi.head_fused(*head_args)
+                capi.head_fused(*head_args, bf16_out=b16)
                 ws["head_deferred"] = False
         else:
             capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
             capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
                           act=2, aux=ws["Z"], ldaux=F, act_scale=1.0 / (1.0 - p))
-        with self.side.fork():
-            linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
-                         fp.offsets["cls.3.bias"], defer=True)
-        with self.side.fork():
-            linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
-                         fp.offsets["cls.0.bias"], defer=True)
+        if w16:
+            pl.defer16(ws["Zb"], 104, ws["dlb"], 8, fp.g("cls.3.weight"), F, F, C, N, ct=True, bias_b=fp.g("cls.3.bias"))
+            pl.defer16(ws["dZb"], 104, ws["H3b"], 104, fp.g("cls.0.weight"), F, F, F, N, bias_a=fp.g("cls.0.bias"))
+        else:
+            with self.side.fork():
+                linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
+                             fp.offsets["cls.3.bias"], defer=True)
+            with self.side.fork():
+                linear_wgrad(pl, ws["dZ"], F, ws["H3"], F, None, F, F, N, fp.offsets["cls.0.weight"],
+                             fp.offsets["cls.0.bias"], defer=True)
         if fused:
             self._backward_fused(ws, x, x_bf16, N)
             return ws["stats"]
@@ -408,11 +419,23 @@ class COGMENModule(nn.Module):
         """bf16 mode: BatchNorm backward .. dH0 in one launch (csrc/cogmen_fused.hip), then the batched weight gradients."""
         fp, g, pl = self.flat, ws["g"], ws["planner"]
         F, D = F_HID, self.input_size
-        capi.cogmen_bwd_tile(ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"],
-                             ws["QKVS"], ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F),
-                             ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers,
-                             **(dict(head_part=ws["head_ws"], head_parts=-(-N // 32), dgamma=fp.g("gcn.bn.weight"),
-                                     dbeta=fp.g("gcn.bn.bias"), stats=ws["stats"]) if ws.get("head_deferred") else {}))
+        w16 = ws["w16"]
+        head_kw = dict(head_part=ws["head_ws"], head_parts=-(-N // 32), dgamma=fp.g("gcn.bn.weight"), dbeta=fp.g("gcn.bn.bias"),
+                       stats=ws["stats"]) if ws.get("head_deferred") else {}
+        bwd_args = (ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["QKVS"],
+                    ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F))
+        if w16:
+            # the three gradients the backward hands to the weight-gradient launch are written as bf16 (nothing else reads them)
+            capi.cogmen_bwd_tile(*bwd_args, ws["dQKVSb"], ws["dH1b"], ws["dH0b"], 104, n_speakers=self.n_speakers,
+                                 grads_bf16=True, lddh1=104, **head_kw)
+            pl.defer16(ws["H1b"], 104, ws["dQKVSb"], 4 * F, fp.g("gcn.conv2.lin_query.weight"), F, F, 4 * F, N, ct=True,
+                       bias_b=fp.g("gcn.conv2.lin_query.bias"))
+            pl.defer16(ws["dH1b"], 104, ws["Mb"], 904, fp.g("gcn.conv1.weight"), F, F, 9 * F, N, ct=True,
+                       bias_a=fp.g("gcn.conv1.bias"))
+            pl.defer16(ws["dH0b"], 104, x, D, fp.g("rnn.1.weight"), D, F, D, N, bias_a=fp.g("rnn.1.bias"), gather=g["node_row"])
+            pl.reduce_into(ws, fp.grad)
+            return
+        capi.cogmen_bwd_tile(*bwd_args, ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers, **head_kw)
         pl.mma_bf16 = self.wgrad_bf16     # these three products on bf16 matrix cores (the head's stay fp32)
         linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1b"], 104, None, 4 * F, F, N,
                      fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"], defer=True)

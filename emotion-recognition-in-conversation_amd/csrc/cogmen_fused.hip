@@ -653,11 +653,11 @@ struct CgBwdP {
     int head_parts, hp_floats;
     const unsigned short* WqT;     // bf16, fragment order (7 x 13 x 512)
     const unsigned short* Wb;      // bf16, fragment order (7 x 30 x 512)
-    float* dQKVS;                  // out [N, 400]
-    float* dH1;                    // out [N, F]
-    float* dH0;                    // out [N, lddh0]
+    float* dQKVS;                  // out [N, 400]      (grads_bf16: the three are bf16 buffers, pitches 400 / lddh1 / lddh0
+    float* dH1;                    // out [N, lddh1]     elements -- they are only ever operands of the bf16 weight-gradient
+    float* dH0;                    // out [N, lddh0]     products, csrc/wgrad_bf16.hip; pad columns are left untouched)
     float scale;
-    int N, ldh2, lddh0, two_spk;
+    int N, ldh2, lddh0, lddh1, grads_bf16, two_spk;
     uint64_t* stamps;
     int stamp_block;
 };
@@ -894,7 +894,10 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                 const float2 gv = *reinterpret_cast<const float2*>(sG + (em + CG_HL) * CG_F + 2 * cp);
                 sDQw[em * (CG_SDQ / 2) + 150 + cp] = (uint32_t)f2bf(gv.x) | ((uint32_t)f2bf(gv.y) << 16);
                 const int node = mb + em;
-                if (em >= CG_HL && em < CG_HL + CG_TR && node < N) *reinterpret_cast<float2*>(p.dQKVS + (int64_t)node * 400 + 3 * CG_F + 2 * cp) = gv;
+                if (em >= CG_HL && em < CG_HL + CG_TR && node < N) {
+                    if (p.grads_bf16) *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned short*>(p.dQKVS) + (int64_t)node * 400 + 3 * CG_F + 2 * cp) = (uint32_t)f2bf(gv.x) | ((uint32_t)f2bf(gv.y) << 16);
+                    else *reinterpret_cast<float2*>(p.dQKVS + (int64_t)node * 400 + 3 * CG_F + 2 * cp) = gv;
+                }
             }
         }
         // (the B fragments of the dH0 product, K = 960: blocks [15 kh, 15 kh + 15), are requested five at a time between the
@@ -933,7 +936,10 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                 if (rowv && 16 * cti + r < CG_F) {
                     const bool nv = node >= 0 && node < N;
                     sDQ[em * CG_SDQ + coff + 16 * cti + r] = f2bf(nv ? acc[q] : 0.f);
-                    if (nv && em >= CG_HL && em < CG_HL + CG_TR) p.dQKVS[(int64_t)node * 400 + coff + 16 * cti + r] = acc[q];
+                    if (nv && em >= CG_HL && em < CG_HL + CG_TR) {
+                        if (p.grads_bf16) reinterpret_cast<unsigned short*>(p.dQKVS)[(int64_t)node * 400 + coff + 16 * cti + r] = f2bf(acc[q]);
+                        else p.dQKVS[(int64_t)node * 400 + coff + 16 * cti + r] = acc[q];
+                    }
                 }
             }
         }
@@ -974,7 +980,10 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                         const float v = h ? acc1[i] + p1[i] : acc0[i] + p0[i];
                         sDH1[e * CG_F + col] = v;
                         const int node = mb + e;
-                        if (e >= CG_HL && e < CG_HL + CG_TR && node < N) p.dH1[(int64_t)node * CG_F + col] = v;
+                        if (e >= CG_HL && e < CG_HL + CG_TR && node < N) {
+                            if (p.grads_bf16) reinterpret_cast<unsigned short*>(p.dH1)[(int64_t)node * p.lddh1 + col] = f2bf(v);
+                            else p.dH1[(int64_t)node * p.lddh1 + col] = v;
+                        }
                     }
             }
         }
@@ -1084,7 +1093,10 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int node = r0 + 4 * g + i;
-                if (col < CG_F && node < N) p.dH0[(int64_t)node * p.lddh0 + col] = acc[i] + p0[i];
+                if (col < CG_F && node < N) {
+                    if (p.grads_bf16) reinterpret_cast<unsigned short*>(p.dH0)[(int64_t)node * p.lddh0 + col] = f2bf(acc[i] + p0[i]);
+                    else p.dH0[(int64_t)node * p.lddh0 + col] = acc[i] + p0[i];
+                }
             }
         }
     }
@@ -1152,15 +1164,18 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
                                    const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
                                    const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                    const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
-                                   const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0,
+                                   const void* Wb, float scale, void* dQKVS, void* dH1, void* dH0, int lddh0,
                                    const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
-                                   int head_part_floats, float* dgamma, float* dbeta, float* stats, void* stream) {
+                                   int head_part_floats, float* dgamma, float* dbeta, float* stats, int grads_bf16, int lddh1,
+                                   void* stream) {
     ERC_REQUIRE(!head_part || (head_parts > 0 && head_part_floats >= 227 && head_part_floats <= 256 && dgamma && dbeta && stats),
                 "cogmen_bwd_tile: head record operands");
     ERC_REQUIRE(dY && H2 && gamma && saved && bn_bwd && QKVS && alpha && in_ptr && in_src && out_ptr && out_dst && out_typ &&
                     out_eid && inv_cnt && WqT && Wb && dQKVS && dH1 && dH0 && node_spk, "cogmen_bwd_tile: null pointer");
     ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_bwd_tile: window (%d, %d) exceeds the halo %d",
                 wp, wf, CG_HL);
+    ERC_REQUIRE(lddh1 >= CG_F && (!grads_bf16 || (lddh0 % 2 == 0 && lddh1 % 2 == 0 && ((uintptr_t)dQKVS & 3) == 0)),
+                "cogmen_bwd_tile: gradient pitches");
     ERC_REQUIRE(ldh2 >= CG_F && ldh2 % 4 == 0 && lddh0 >= CG_F &&
                     (((uintptr_t)dY | (uintptr_t)H2 | (uintptr_t)QKVS | (uintptr_t)gamma | (uintptr_t)saved | (uintptr_t)bn_bwd |
                       (uintptr_t)WqT | (uintptr_t)Wb) & 15) == 0, "cogmen_bwd_tile: pitch / alignment");
@@ -1169,7 +1184,8 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
     p.dY = dY; p.H2 = H2; p.gamma = gamma; p.saved = saved; p.bn_bwd = bn_bwd; p.QKVS = QKVS; p.alpha = alpha;
     p.in_ptr = in_ptr; p.in_src = in_src; p.out_ptr = out_ptr; p.out_dst = out_dst; p.out_typ = out_typ; p.out_eid = out_eid;
     p.inv_cnt = inv_cnt; p.WqT = (const unsigned short*)WqT; p.Wb = (const unsigned short*)Wb;
-    p.dQKVS = dQKVS; p.dH1 = dH1; p.dH0 = dH0; p.scale = scale; p.N = n_nodes; p.ldh2 = ldh2; p.lddh0 = lddh0;
+    p.dQKVS = (float*)dQKVS; p.dH1 = (float*)dH1; p.dH0 = (float*)dH0; p.scale = scale; p.N = n_nodes; p.ldh2 = ldh2; p.lddh0 = lddh0;
+    p.lddh1 = lddh1; p.grads_bf16 = grads_bf16;
     p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0;
     p.head_part = head_part; p.head_parts = head_parts; p.hp_floats = head_part_floats; p.bn_bwd_out = const_cast<float*>(bn_bwd);
     p.dgamma = dgamma; p.dbeta = dbeta; p.stats = stats;

@@ -146,12 +146,21 @@ struct HeadP {
     int bn_tiles;
     int defer;               // 1: leave the workgroup records for the consumer to add up (erc_cogmen_bwd_tile), no last arriver
     uint64_t* stamps;        // diagnostic phase stamps of the middle workgroup (tools/cogmen_stamps.py) or null
+    // bf16 copies of the weight-gradient operands (COGMEN bf16 compute mode, csrc/wgrad_bf16.hip), or null: H3, Z, dZ
+    // [N, ldb16 >= F] and dlogits [N, 8]; pad columns are left untouched
+    unsigned short *H3b, *Zb, *dZb, *dlb;
+    int ldb16;
 };
 
 #define HF_STAMP(slot)                                                                                              \
     do {                                                                                                            \
         if (p.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
+
+__device__ __forceinline__ unsigned short hf_bf(float f) {
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, h);
+}
 
 // DPP lane exchanges inside a row of 16 lanes (VALU, no LDS traffic)
 template <int CTRL>
@@ -308,7 +317,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
             h[t] = (z > 0.f ? z : z * p.slope);
             a1[kb][t] = h[t] * km;
         }
-        if ((kb & 3) == cq && mrow < N && kv) *reinterpret_cast<f32x4*>(p.H3 + (int64_t)mrow * F + k0) = h;
+        if ((kb & 3) == cq && mrow < N && kv) {
+            *reinterpret_cast<f32x4*>(p.H3 + (int64_t)mrow * F + k0) = h;
+            if (p.H3b) *reinterpret_cast<uint2*>(p.H3b + (int64_t)mrow * p.ldb16 + k0) =
+                make_uint2((uint32_t)hf_bf(h[0]) | ((uint32_t)hf_bf(h[1]) << 16), (uint32_t)hf_bf(h[2]) | ((uint32_t)hf_bf(h[3]) << 16));
+        }
     }
     // operands of the later phases, requested now so that their latency hides behind the first MFMA product
     int ylab[4];
@@ -372,7 +385,10 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
                 }
                 z *= cm[jn];
                 zreg[jn][q] = z;
-                if (row < N && 16 * nt + r < F) p.Z[(int64_t)row * F + 16 * nt + r] = z;
+                if (row < N && 16 * nt + r < F) {
+                    p.Z[(int64_t)row * F + 16 * nt + r] = z;
+                    if (p.Zb) p.Zb[(int64_t)row * p.ldb16 + 16 * nt + r] = hf_bf(z);
+                }
             }
         }
     }
@@ -413,6 +429,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
             if (rv && r < C) {
                 p.logits[(int64_t)row * C + r] = v;
                 p.dlogits[(int64_t)row * C + r] = dq;
+                if (p.dlb) p.dlb[(int64_t)row * 8 + r] = hf_bf(dq);
             }
             if (rv && r == 0) lsum += wyq[q] * (lse - ly), hsum += ((int)am == y) ? 1.f : 0.f;
         }
@@ -441,7 +458,10 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) s += dhi[c] * w3[4 + c][jn];
                 const float dz = zreg[jn][q] > 0.f ? s * scale : 0.f;
-                if (row < N && 16 * nt + r < F) p.dZ[(int64_t)row * F + 16 * nt + r] = dz;
+                if (row < N && 16 * nt + r < F) {
+                    p.dZ[(int64_t)row * F + 16 * nt + r] = dz;
+                    if (p.dZb) p.dZb[(int64_t)row * p.ldb16 + 16 * nt + r] = hf_bf(dz);
+                }
                 tile[(4 * g + q) * HF_ST + 16 * nt + r] = dz;
             }
         }
@@ -602,7 +622,10 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
                              const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                              const float* bn_part, int bn_tiles, float* saved_out, float* running_mean, float* running_var,
-                             float momentum, float eps, int defer, void* stream) {
+                             float momentum, float eps, int defer, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16,
+                             void* stream) {
+    ERC_REQUIRE((!H3b && !Zb && !dZb && !dlb) || (H3b && Zb && dZb && dlb && ldb16 >= F && ldb16 % 4 == 0 && (((uintptr_t)H3b) & 7) == 0),
+                "head_fused: bf16 operand copies (all four or none, pitch %% 4 == 0)");
     ERC_REQUIRE(H2 && gamma && beta && (saved || bn_part) && W0 && b0 && W3 && b3 && labels && H3 && Z && logits && dlogits && dZ && dY &&
                     bn_bwd && dgamma && dbeta && stats && ws,
                 "head_fused: null pointer");
@@ -620,6 +643,7 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     p.bn_part = bn_part, p.bn_tiles = bn_tiles, p.saved_out = saved_out, p.running_mean = running_mean, p.running_var = running_var;
     p.momentum = momentum, p.eps = eps;
     p.defer = defer ? 1 : 0;
+    p.H3b = (unsigned short*)H3b, p.Zb = (unsigned short*)Zb, p.dZb = (unsigned short*)dZb, p.dlb = (unsigned short*)dlb, p.ldb16 = ldb16;
     p.stamps = g_head_stamps;
     const int grid = erc_cdiv(n_rows, 32);
     p.part = ws;
@@ -634,11 +658,12 @@ extern "C" int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C
                               const float* saved, float slope, const float* W0, const float* b0, const float* W3,
                               const float* b3, const int64_t* labels, const float* weight, float drop_p,
                               const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
-                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* stream) {
+                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* H3b, void* Zb,
+                              void* dZb, void* dlb, int ldb16, void* stream) {
     ERC_REQUIRE(saved, "head_fused: null pointer");
     return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                              H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, nullptr, 0, nullptr, nullptr,
-                             nullptr, 0.f, 0.f, 0, stream);
+                             nullptr, 0.f, 0.f, 0, H3b, Zb, dZb, dlb, ldb16, stream);
 }
 
 extern "C" int erc_head_fused_part_floats(void) { return HF_PART; }
@@ -652,11 +677,11 @@ extern "C" int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, in
                                  const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                                  float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                                  const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
-                                 float eps, int defer_reduce, void* stream) {
+                                 float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, void* stream) {
     ERC_REQUIRE(bn_part && saved, "head_fused_bn: null pointer");
     return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, nullptr, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                              H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, saved,
-                             running_mean, running_var, momentum, eps, defer_reduce, stream);
+                             running_mean, running_var, momentum, eps, defer_reduce, H3b, Zb, dZb, dlb, ldb16, stream);
 }
 
 extern "C" int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,

@@ -150,6 +150,7 @@ class GemmPlanner:
         self.jobs = []
         self.max_numel = 0
         self.deferred = []     # (A, lda, B, ldb, C, ldc, M, N, K, ones, bias_out): one batched launch at the end
+        self.deferred16 = []   # bf16 compute mode: records of the bf16 weight-gradient launch (defer16)
 
     mma_bf16 = False   # bf16 compute mode: deferred weight gradients on bf16 matrix cores (operands rounded, fp32 accumulate)
 
@@ -218,6 +219,64 @@ class GemmPlanner:
         capi.wgrad_table(cache["wgrad_table"], len(self.deferred), cache["wgrad_bases"], cache["wgrad_items"],
                          cache["wgrad_slabs"], cache["wgrad_counters"])
 
+    # ------------------------------------------------------------------ bf16 weight gradients (csrc/wgrad_bf16.hip)
+    def defer16(self, A, lda, B, ldb, Cm, ldc, M, N, K, ct=False, bias_a=None, bias_b=None, gather=None):
+        """C[M,N] = A[K,M]^T B[gather(K),N] with both operands bf16 in memory (COGMEN bf16 mode); ``ct`` stores C
+        transposed (C[n * ldc + m]); bias_a / bias_b receive the fp32 column sums of A / B."""
+        if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or Cm.dtype != torch.float32:
+            raise capi.ErcGraftError("bf16 wgrad: operand dtypes %s %s %s" % (A.dtype, B.dtype, Cm.dtype))
+        if M > 128 or lda % 8 or lda < -(-M // 8) * 8 or ldb % 4 or ldb < -(-N // 4) * 4 or A.data_ptr() % 16 or B.data_ptr() % 8:
+            raise capi.ErcGraftError("bf16 wgrad: M=%d lda=%d N=%d ldb=%d unsupported" % (M, lda, N, ldb))
+        self.deferred16.append((A, lda, B, ldb, Cm, ldc, M, N, K, bool(ct), bias_a, bias_b, gather))
+
+    def flush_wgrads_bf16(self, cache):
+        """Every record of defer16 as ONE launch (erc_wgrad_bf16); table, slabs and counters are built once per shape."""
+        if not self.deferred16:
+            return
+        import ctypes
+        import struct
+        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, ct, g.data_ptr() if g is not None else 0)
+                    for a, _, b, _, c, _, M, N, K, ct, _, _, g in self.deferred16)
+        if cache.get("w16_key") != key:
+            cap = capi.wgrad_bf16_max_k_per_split()
+            tiles = sum(-(-N // 64) for _, _, _, _, _, _, _, N, _, _, _, _, _ in self.deferred16)
+            K = max(d[8] for d in self.deferred16)
+            # one 4-wavefront workgroup per CU (428 registers per lane): while every item of the launch is resident at once
+            # (<= 256), as many splits as that allows; beyond, ~ERC_W2_ROWS k per item
+            rows = int(os.environ.get("ERC_W2_ROWS", 1024))
+            s_max = max(1, min(32, 256 // tiles, -(-K // 64)))
+            # a wavefront works in groups of 8 k-steps (32 k): among the split counts that fit, the smallest one with the
+            # fewest groups per wavefront (K = 1982: 4 splits of 31 steps per wavefront, not 5 of 25 -- both are 4 groups)
+            groups = lambda sp: -(-(-(-(-(-K // 4) // sp) // 4)) // 8)
+            splits = min(range(1, s_max + 1), key=lambda sp: (groups(sp), sp))
+            splits = max(splits, min(32, -(-K // rows)), -(-K // cap))
+            raw, items, n_tiles, bases = [], 0, 0, []
+            for a, lda, b, ldb, c, ldc, M, N, Kr, ct, ba, bb, g in self.deferred16:
+                nks = -(-Kr // 4)
+                per = -(-nks // splits)
+                sp = -(-nks // per)                       # no empty split
+                if per * 4 > cap:
+                    raise capi.ErcGraftError("bf16 wgrad: K=%d needs more than %d splits" % (Kr, splits))
+                tn = -(-N // 64)
+                cvec = int(c.data_ptr() % 16 == 0 and ldc % 4 == 0)
+                raw.append(struct.pack("<QQQQQQ16i", a.data_ptr(), b.data_ptr(), c.data_ptr(),
+                                       ba.data_ptr() if ba is not None else 0, bb.data_ptr() if bb is not None else 0,
+                                       g.data_ptr() if g is not None else 0, lda, ldb, ldc, M, N, Kr, int(ct), cvec, sp, tn,
+                                       items, tn * sp, n_tiles, 0, 0, 0))
+                bases.append(items)
+                items += tn * sp
+                n_tiles += tn
+            # (the table is a small host -> device copy made OUTSIDE any stream capture: trainer.StepGraphs runs the first
+            #  step of a shape on the graph's own static buffers before it captures)
+            cache["w16_table"] = torch.frombuffer(bytearray(b"".join(raw)), dtype=torch.uint8).to(self.device)
+            cache["w16_slabs"] = torch.empty(items * capi.wgrad_bf16_slab_floats(), dtype=torch.float32, device=self.device)
+            cache["w16_counters"] = torch.zeros(n_tiles, dtype=torch.int32, device=self.device)
+            cache["w16_items"] = items
+            cache["w16_bases"] = (ctypes.c_int32 * len(bases))(*bases)
+            cache["w16_key"] = key
+        capi.wgrad_bf16(cache["w16_table"], len(self.deferred16), cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
+                        cache["w16_counters"])
+
     def split_for(self, M, N, K, bk=None, min_chunks=None):
         if N <= 1025 and bk is None:
             return 1   # skinny output: the register-streaming kernel splits K inside the workgroup, no slabs
@@ -246,6 +305,7 @@ class GemmPlanner:
         """Flush the deferred weight gradients, then run the batched slab reduce for the registered jobs (no-op
         when every gradient was written directly)."""
         self.flush_wgrads(cache)
+        self.flush_wgrads_bf16(cache)
         if not self.jobs:
             return
         if cache.get("jobs") is None or cache["jobs"].shape[0] != len(self.jobs):

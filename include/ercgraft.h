@@ -132,6 +132,21 @@ int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_
 int erc_wgrad_table(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
                     int32_t* counters, void* stream);
 int64_t erc_wgrad_slab_floats(void);
+/* The same for the COGMEN bf16 compute mode (csrc/wgrad_bf16.hip): every record is C = A^T B with A [K, M <= 128] and
+ * B [K, N] both K-major and BF16 in memory (B optionally through a row gather), on v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation; wave tile 128 x 64, so the wide operand is read once.  Record layout (112 bytes, little endian):
+ *   u64 A, B, C, bias_a, bias_b, b_gather; i32 lda, ldb, ldc, M, N, K, ct, cvec, splits, tiles_n, item_base, n_items,
+ *   tile_base, 0, 0, 0
+ * ct != 0 stores C transposed (C[n * ldc + m]); bias_a [M] / bias_b [N] = fp32 column sums of the operand values over k (or
+ * NULL); lda % 8 == 0 and ldb % 4 == 0 with finite pad columns up to 8 ceil(M / 8) resp. 4 ceil(N / 4); tiles_n =
+ * ceil(N / 64); n_items = tiles_n * splits; K / splits <= erc_wgrad_bf16_max_k_per_split(); at most 16 records. */
+int erc_wgrad_bf16(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs, int32_t* counters,
+                   void* stream);
+int64_t erc_wgrad_bf16_slab_floats(void);
+/* diagnostic: phase stamps (10 ns ticks) of work item `item` (of record 0) of the following erc_wgrad_bf16 launches,
+ * 16 x uint64 device memory; NULL switches them off (tools/wgrad_stamps.py) */
+int erc_wgrad_bf16_set_stamps(uint64_t* stamps, int item);
+int erc_wgrad_bf16_max_k_per_split(void);
 int erc_wgrad_max_k_per_split(void);
 
 /* Forward input projection on a bf16 feature block: C[M,N] = act(X[gather(m), :K] W[N,K]^T + bias), X bf16,
@@ -327,7 +342,10 @@ int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const flo
                    const float* saved, float slope, const float* W0, const float* b0, const float* W3,
                    const float* b3, const int64_t* labels, const float* weight, float drop_p,
                    const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
-                   float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* stream);
+                   float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* H3b, void* Zb,
+                   void* dZb, void* dlb, int ldb16, void* stream);
+/* H3b / Zb / dZb [n_rows, ldb16 >= F] and dlb [n_rows, 8]: optional bf16 copies (all four or none) of H3, Z, dZ and dlogits,
+ * the operands of the classifier's weight gradients in the bf16 compute mode (erc_wgrad_bf16); pad columns untouched. */
 
 /* erc_head_fused with BatchNorm's batch statistics finalised inside (training mode of nn.BatchNorm1d, cogmen.py:67):
  * bn_part [bn_tiles][2F] floats = per-tile column sums (sum x | sum x^2) from erc_cogmen_fwd_tile (bn_fused = 2);
@@ -340,7 +358,7 @@ int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const 
                       const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                       float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                       const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
-                      float eps, int defer_reduce, void* stream);
+                      float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, void* stream);
 /* floats per workgroup record of erc_head_fused's workspace: [0,112) column sums of dY, [112,224) of dY * xhat, [224] loss
  * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / 32) records */
 int erc_head_fused_part_floats(void);
@@ -421,9 +439,13 @@ int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes,
                         const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
                         const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                         const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
-                        const void* Wb, float scale, float* dQKVS, float* dH1, float* dH0, int lddh0,
+                        const void* Wb, float scale, void* dQKVS, void* dH1, void* dH0, int lddh0,
                         const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
-                        int head_part_floats, float* dgamma, float* dbeta, float* stats, void* stream);
+                        int head_part_floats, float* dgamma, float* dbeta, float* stats, int grads_bf16, int lddh1,
+                        void* stream);
+/* grads_bf16 != 0: dQKVS [N, 400], dH1 [N, lddh1], dH0 [N, lddh0] are written as bf16 (pitches in elements, pad columns
+ * untouched): they are only ever operands of the bf16 weight-gradient products (erc_wgrad_bf16), so the rounding moves from
+ * that kernel's loads to these stores.  Otherwise fp32 (lddh1 >= 100). */
 
 /* COGMEN bf16 mode, first launch of the step (csrc/cogmen_project.hip): the input projection
  *   H0[n, :n_out] = X[row(n), :K] W^T + bias   (track_mm/cogmen.py:103-105,147: rnn.1 on the valid utterances; X bf16

@@ -58,6 +58,19 @@ class COGMENOracle(nn.Module):
         # bf16_products: the graph part's dense products with the operand rounding of the bf16 compute mode
         # (oracle/pyg.py RoundedLinear / RGCNMeanRounded) -- the same algorithm, rounded where that mode rounds
         self.gcn.conv1.rounded = self.gcn.conv2.rounded = bool(bf16_products)
+        self.bf16_products = bool(bf16_products)
+
+    def _linear(self, mod, t):
+        """rnn.1 / cls.0 / cls.3: in the bf16 mode only their WEIGHT gradient is a bf16 product (pyg.RoundedWgradLinear)"""
+        if self.bf16_products:
+            from .pyg import RoundedWgradLinear
+            return RoundedWgradLinear.apply(t, mod.weight, mod.bias)
+        return mod(t)
+
+    def _cls(self, t):
+        if not self.bf16_products:
+            return self.cls(t)
+        return self._linear(self.cls[3], self.cls[2](self.cls[1](self._linear(self.cls[0], t))))
 
     def forward(self, input_tensor, speaker_tensor, text_length, *args, **kwargs):
         if self.chained:
@@ -76,12 +89,12 @@ class COGMENOracle(nn.Module):
         for mod in self.rnn:  # each module sees the raw input (cogmen.py:146-147)
             if mod is self.rnn[0] and not self.dead_encoder:
                 continue
-            node_features = mod(input_tensor)
+            node_features = self._linear(mod, input_tensor) if mod is self.rnn[1] else mod(input_tensor)
         x, edge_index, edge_type, _ = window_graph_loop(
             node_features, text_length, speaker_tensor, 5, 5, self.n_speakers)
         self.last_graph = (edge_index, edge_type)
         out = self.gcn(x, edge_index, edge_type)
-        return self.cls(out), x
+        return self._cls(out), x
 
 
 def cogmen_train_step(model, optim, batch):

@@ -26,7 +26,8 @@ def rb(t):
 class RoundedLinear(torch.autograd.Function):
     """nn.Linear as the bf16 compute mode evaluates it (csrc/cogmen_fused.hip): y = rb(x) rb(W)^T + b with fp32
     accumulation; backward dx = rb(dy) rb(W) (bf16 product), dW = rb(dy)^T rb(x) (the batched weight-gradient launch
-    runs on bf16 matrix cores in this mode: both operands rounded, fp32 accumulate), db = colsum(dy) in fp32.  Not part of the reference: it restates the SAME algorithm
+    runs on bf16 matrix cores in this mode from operands the backward kernels STORE as bf16), db = colsum(rb(dy)) in fp32
+    (the bias strip of that launch sums the stored values).  Not part of the reference: it restates the SAME algorithm
     with the operand rounding of the mode, so that a parity test isolates implementation error from quantisation."""
 
     @staticmethod
@@ -39,7 +40,24 @@ class RoundedLinear(torch.autograd.Function):
     def backward(ctx, dy):
         xr, Wr = ctx.saved_tensors
         dyr = rb(dy)
-        return dyr @ Wr, dyr.t() @ xr, dy.sum(0)
+        return dyr @ Wr, dyr.t() @ xr, dyr.sum(0)
+
+
+class RoundedWgradLinear(torch.autograd.Function):
+    """nn.Linear whose forward and input gradient stay fp32 (the input projection's product is exact on its already
+    rounded operands; the classifier head runs on the fp32 matrix cores) but whose WEIGHT gradient is the bf16 product of
+    the mode's batched weight-gradient launch (csrc/wgrad_bf16.hip): dW = rb(dy)^T rb(x), db = colsum(rb(dy))."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        return x @ W.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dyr = rb(dy).reshape(-1, dy.shape[-1])          # [B, T, .] inputs (the padded block in front of rnn.1): rows flattened
+        return dy @ W, dyr.t() @ rb(x).reshape(-1, x.shape[-1]), dyr.sum(0)
 
 
 class RGCNMeanRounded(torch.autograd.Function):
@@ -81,7 +99,7 @@ class RGCNMeanRounded(torch.autograd.Function):
             dx = dx + rb(dP) @ Wr[r * F:(r + 1) * F].t()
         dx = dx + rb(dH1) @ Wr[R * F:].t()
         dW = Mr.t() @ rb(dH1)
-        return dx, dW[:R * F].reshape(R, F, -1), dW[R * F:], dH1.sum(0), None, None, None
+        return dx, dW[:R * F].reshape(R, F, -1), dW[R * F:], rb(dH1).sum(0), None, None, None
 
 
 def scatter_sum(src, index, n):

@@ -123,7 +123,7 @@ def test_interlayer_dropout_is_consistent_between_forward_and_backward():
     rng = torch.tensor([3, 99], dtype=torch.int64, device=DEV)
     out = torch.zeros(B * T, 200, device=DEV)
     run.forward(pl, x.to(DEV).view(B * T, D), D, B * T, B, T, T, 1, lens.to(DEV), True, rng, out, 200)
-    ws = run._ws[B * T]
+    ws = run._own["lstm:" + run.prefix]
     h0, h0d = ws["H0"].cpu(), ws["H0d"].cpu()
     kept = h0d != 0
     assert 0.4 < float(kept.float().sum() / (h0 != 0).float().sum()) < 0.8

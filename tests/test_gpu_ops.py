@@ -512,3 +512,57 @@ def test_gemm_bf16a_projection(capi, M, K, N, w_bf16):
     capi.gemm_bf16a_stream(X.to(DEV), K, idx.to(DEV), W.to(DEV), K, out, N, M, N, K, bias=b.to(DEV), act=1)
     ref = torch.relu(X[idx.long()].double() @ W.bfloat16().double().t() + b.double()).float()
     _close(out, ref, 2e-3)
+
+
+@pytest.mark.parametrize("K", [1, 7, 130, 1982, 9001])
+def test_wgrad_bf16_batched_launch(K):
+    """csrc/wgrad_bf16.hip (every weight gradient of the COGMEN bf16 step as one launch, both operands bf16 in memory)
+    against float64 products of the same bf16 values: the five record shapes of the step -- gathered wide B, transposed
+    stores, N not a multiple of 4, padded pitches whose pad columns hold (finite) garbage -- and bit-reproducibility."""
+    import torch
+    from erc_amd.engine import GemmPlanner
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(K)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    R = K + 5                                                     # rows of the gathered operand's source block
+    recs = []   # (A [K, lda] bf16, M, B, N, gather, ct, bias_a?, bias_b?)
+    def pad(t, ld, fill):
+        out = torch.full((t.shape[0], ld), fill, dtype=torch.float32)
+        out[:, :t.shape[1]] = t
+        return out.to(torch.bfloat16).to(dev)
+    gather = torch.randint(0, R, (K,), generator=g).to(torch.int32)
+    shapes = [(100, 104, 1380, 1380, True, False, True, False),   # dW1 = dH0^T X[gather]
+              (100, 104, 900, 904, False, True, True, False),     # d[W_r; root]^T
+              (100, 104, 400, 400, False, True, False, True),     # d[q;k;v;s]
+              (100, 104, 100, 104, False, False, True, False),    # cls.0
+              (100, 104, 6, 8, False, True, False, True),         # cls.3 (N = 6: no vector stores along n)
+              (36, 40, 52, 52, False, False, True, True)]         # small odd sizes
+    pl = GemmPlanner(dev, 64)
+    cache, want = {}, []
+    for M, lda, N, ldb, gath, ct, ba, bb in shapes:
+        A = pad(rnd(K, M), lda, 3.0)                              # pad columns: finite garbage, must not leak into the result
+        Bsrc = pad(rnd(R if gath else K, N), ldb, -2.0)
+        C = torch.full((N, M) if ct else (M, N), float("nan"), device=dev)
+        bias_a = torch.full((M,), float("nan"), device=dev) if ba else None
+        bias_b = torch.full((N,), float("nan"), device=dev) if bb else None
+        gi = gather.to(dev) if gath else None
+        pl.defer16(A, lda, Bsrc, ldb, C, M if ct else N, M, N, K, ct=ct, bias_a=bias_a, bias_b=bias_b, gather=gi)
+        Ad = A[:, :M].double().cpu()
+        Bd = (Bsrc[gather.long().to(dev)] if gath else Bsrc)[:, :N].double().cpu()
+        ref = Ad.t() @ Bd
+        want.append((C, ref.t() if ct else ref, bias_a, Ad.sum(0), bias_b, Bd.sum(0)))
+    pl.flush_wgrads_bf16(cache)
+    torch.cuda.synchronize()
+    first = [c.clone() for c, *_ in want]
+    for C, ref, bias_a, ra, bias_b, rb_ in want:
+        scale = float(ref.abs().max()) + 1e-6
+        assert float((C.double().cpu() - ref).abs().max()) < 2e-5 * scale + 1e-5 * (K ** 0.5), (tuple(C.shape), K)
+        if bias_a is not None:
+            assert float((bias_a.double().cpu() - ra).abs().max()) < 1e-5 * (float(ra.abs().max()) + K ** 0.5)
+        if bias_b is not None:
+            assert float((bias_b.double().cpu() - rb_).abs().max()) < 1e-5 * (float(rb_.abs().max()) + K ** 0.5)
+    for C, *_ in want:
+        C.fill_(float("nan"))
+    pl.flush_wgrads_bf16(cache)                                   # same table, slabs and counters: a second launch
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, c) for a, (c, *_) in zip(first, want))
