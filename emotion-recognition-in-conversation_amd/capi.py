@@ -88,6 +88,7 @@ _SIGS = {
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "erc_head_fused_part_floats": (C.c_int, []),
+    "erc_head_fused_rows_per_workgroup": (C.c_int, []),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
     "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
@@ -806,6 +807,10 @@ def head_fused_bn(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, 
     _call("erc_head_fused_bn", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
           float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles,
           running_mean, running_var, float(momentum), float(eps), int(defer_reduce), b[0], b[1], b[2], b[3], b[4])
+
+
+def head_fused_rows_per_workgroup():
+    return int(lib().erc_head_fused_rows_per_workgroup())
 
 
 def head_fused_part_floats():

@@ -420,7 +420,7 @@ class COGMENModule(nn.Module):
         fp, g, pl = self.flat, ws["g"], ws["planner"]
         F, D = F_HID, self.input_size
         w16 = ws["w16"]
-        head_kw = dict(head_part=ws["head_ws"], head_parts=-(-N // 32), dgamma=fp.g("gcn.bn.weight"), dbeta=fp.g("gcn.bn.bias"),
+        head_kw = dict(head_part=ws["head_ws"], head_parts=-(-N // capi.head_fused_rows_per_workgroup()), dgamma=fp.g("gcn.bn.weight"), dbeta=fp.g("gcn.bn.bias"),
                        stats=ws["stats"]) if ws.get("head_deferred") else {}
         bwd_args = (ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["QKVS"],
                     ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F))

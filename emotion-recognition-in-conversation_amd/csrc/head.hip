@@ -17,6 +17,9 @@
 // Cross-workgroup sums (BatchNorm backward, loss, accuracy): per-workgroup partials written with write-through (sc1)
 // stores, an arrival counter, and the last workgroup adds them in workgroup order in fp64 -- deterministic, no fences.
 #include "erc_common.h"
+#include <stdlib.h>
+
+extern "C" int erc_head_fused_rows_per_workgroup(void);
 
 namespace {
 
@@ -187,16 +190,17 @@ __device__ __forceinline__ float row8_min(float v) {
 
 // Workgroup = 8 wavefronts = 32 rows: wavefront w works on row tile rt = w >> 2 (16 rows) and column tiles
 // nt = 2 (w & 3), 2 (w & 3) + 1 of the 7; the class-space quantities (8 wide) are exchanged through LDS.
-template <bool BNP>
+template <bool BNP, int RPW>
 __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
+    constexpr int NCW = 8 / RPW;   // wavefronts per row tile; each takes RPW of the 7 column tiles
     __shared__ __attribute__((aligned(16))) float sW[HF_MAXF * HF_S];  // W0, row pitch HF_S
-    __shared__ __attribute__((aligned(16))) float sT[2][16 * HF_ST];    // dZ row tiles (transposition between the MFMA products); sT[0] first holds sLg
-    __shared__ __attribute__((aligned(16))) float sD[2][16][8];  // dlogits of the two row tiles
-    __shared__ float sCol[2][2][112];
-    __shared__ float sLoss[2][2];
+    __shared__ __attribute__((aligned(16))) float sT[RPW][16 * HF_ST > 2048 ? 16 * HF_ST : 2048];   // (>= 8 KB: the BatchNorm sums stage uses it first)    // dZ row tiles (transposition between the MFMA products); sT[0] first holds sLg
+    __shared__ __attribute__((aligned(16))) float sD[RPW][16][8];  // dlogits of the two row tiles
+    __shared__ float sCol[RPW][2][112];
+    __shared__ float sLoss[RPW][2];
     __shared__ double sRed[8];
     __shared__ int s_last;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rt = w >> 2, cq = w & 3;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rt = RPW == 2 ? w >> 2 : 0, cq = RPW == 2 ? w & 3 : w;
     const int r = lane & 15, g = lane >> 4;
     const int F = p.F, C = p.C, N = p.N;
     float* const sLg = &sT[0][0];  // [rt][cq][16 rows][8 classes] partial logits, dead before sT is written
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     __shared__ __attribute__((aligned(16))) float sGB[2 * HF_MAXF];      // BNP: gamma | beta, staged with the first loads
 
     // the H2 rows of the A fragments are requested first: they do not depend on the BatchNorm statistics computed below
-    const int m0 = ((int)blockIdx.x * 2 + rt) * 16;
+    const int m0 = ((int)blockIdx.x * RPW + rt) * 16;
     const int mrow = m0 + r, mrc = min(mrow, N - 1);
     f32x4 xh[HF_NT];
 #pragma unroll
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
             h[t] = (z > 0.f ? z : z * p.slope);
             a1[kb][t] = h[t] * km;
         }
-        if ((kb & 3) == cq && mrow < N && kv) {
+        if ((RPW == 2 ? (kb & 3) : kb) == cq && mrow < N && kv) {
             *reinterpret_cast<f32x4*>(p.H3 + (int64_t)mrow * F + k0) = h;
             if (p.H3b) *reinterpret_cast<uint2*>(p.H3b + (int64_t)mrow * p.ldb16 + k0) =
                 make_uint2((uint32_t)hf_bf(h[0]) | ((uint32_t)hf_bf(h[1]) << 16), (uint32_t)hf_bf(h[2]) | ((uint32_t)hf_bf(h[3]) << 16));
@@ -330,11 +334,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     for (int q = 0; q < 4; ++q) ylab[q] = (int)p.labels[min(m0 + 4 * g + q, N - 1)];
 #pragma unroll
     for (int q = 0; q < 4; ++q) wyq[q] = p.weight ? p.weight[ylab[q]] : 1.f;
-    int colc[2];
-    float cm[2], x6[2][4], mu6[2], rs6[2], ga6[2], be6[2], b0c[2], w3[HF_MAXC][2];
+    int colc[RPW];
+    float cm[RPW], x6[RPW][4], mu6[RPW], rs6[RPW], ga6[RPW], be6[RPW], b0c[RPW], w3[HF_MAXC][RPW];
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-        const int col = 16 * (2 * cq + jn) + r;
+    for (int jn = 0; jn < RPW; ++jn) {
+        const int col = 16 * (RPW * cq + jn) + r;
         colc[jn] = min(col, F - 1);
         cm[jn] = col < F ? 1.f : 0.f;
         mu6[jn] = BNP ? sSaved[colc[jn]] : p.saved[colc[jn]], rs6[jn] = BNP ? sSaved[F + colc[jn]] : p.saved[F + colc[jn]];
@@ -358,13 +362,17 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     const float inv_w = (float)(1.0 / wsum);
 
     // ---- P2: Z = dropout(relu(H3 W0^T + b0)) for this wavefront's column tiles; rows m0 + 4g + q, columns 16 nt + r
-    float zreg[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float zreg[RPW][4];
+#pragma unroll
+    for (int jn = 0; jn < RPW; ++jn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zreg[jn][q] = 0.f;
     const float scale = 1.f / (1.f - p.drop_p);
     uint64_t rng_off = 0, rng_seed = 0;
     if (p.drop_p > 0.f) rng_off = p.rng[0], rng_seed = p.rng[1];
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-        const int nt = 2 * cq + jn;
+    for (int jn = 0; jn < RPW; ++jn) {
+        const int nt = RPW * cq + jn;
         if (nt < HF_NT) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -399,10 +407,12 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         float mine = 0.f;
 #pragma unroll
         for (int c = 0; c < HF_MAXC; ++c) {
-            const float s = row16_sum(zreg[0][q] * w3[c][0] + zreg[1][q] * w3[c][1]);
+            float zw = zreg[0][q] * w3[c][0];
+            if (RPW == 2) zw += zreg[RPW - 1][q] * w3[c][RPW - 1];
+            const float s = row16_sum(zw);
             if (c == cr) mine = s;
         }
-        if (r < 8) sLg[((rt * 4 + cq) * 16 + 4 * g + q) * 8 + cr] = mine;
+        if (r < 8) sLg[((rt * NCW + cq) * 16 + 4 * g + q) * 8 + cr] = mine;
     }
     __syncthreads();
     HF_STAMP(2);
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         const bool rv = row < N;
         float v = b3c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v += sLg[((rt * 4 + j) * 16 + 4 * g + q) * 8 + cr];
+        for (int j = 0; j < NCW; ++j) v += sLg[((rt * NCW + j) * 16 + 4 * g + q) * 8 + cr];
         const float mx = row8_max(cv ? v : -3.0e38f);
         const float se = row8_sum(cv ? expf(v - mx) : 0.f);
         const float lse = mx + logf(se);
@@ -449,8 +459,8 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         const f32x4 dhi = *reinterpret_cast<const f32x4*>(&sD[rt][4 * g + q][4]);
         const int row = m0 + 4 * g + q;
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const int nt = 2 * cq + jn;
+        for (int jn = 0; jn < RPW; ++jn) {
+            const int nt = RPW * cq + jn;
             if (nt < HF_NT) {
                 float s = 0.f;
 #pragma unroll
@@ -478,8 +488,8 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
         for (int t = 0; t < 4; ++t) a2[kb][t] = v[t];
     }
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-        const int nt = 2 * cq + jn;
+    for (int jn = 0; jn < RPW; ++jn) {
+        const int nt = RPW * cq + jn;
         if (nt < HF_NT) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -510,10 +520,10 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     HF_STAMP(5);
     float* const rec = p.part + (int64_t)blockIdx.x * HF_PART;
     if (tid < 112) {
-        st_sc1(rec + tid, sCol[0][0][tid] + sCol[1][0][tid]);
-        st_sc1(rec + 112 + tid, sCol[0][1][tid] + sCol[1][1][tid]);
+        st_sc1(rec + tid, sCol[0][0][tid] + (RPW == 2 ? sCol[RPW - 1][0][tid] : 0.f));
+        st_sc1(rec + 112 + tid, sCol[0][1][tid] + (RPW == 2 ? sCol[RPW - 1][1][tid] : 0.f));
     } else if (tid < 114) {
-        st_sc1(rec + 224 + (tid - 112), sLoss[0][tid - 112] + sLoss[1][tid - 112]);
+        st_sc1(rec + 224 + (tid - 112), sLoss[0][tid - 112] + (RPW == 2 ? sLoss[RPW - 1][tid - 112] : 0.f));
     } else if (tid == 114) {
         st_sc1(rec + 226, (float)wsum);
     }
@@ -607,7 +617,17 @@ extern "C" int erc_bn_batch_stats(const float* x, int ldx, int N, int F, float* 
     return ERC_OK;
 }
 
-extern "C" int64_t erc_head_fused_ws_floats(int n_rows) { return (int64_t)erc_cdiv(n_rows, 32) * HF_PART + 16; }
+// Rows per workgroup of the fused head: 16 (the default: every one of the 7 column tiles of a row tile has its own wavefront;
+// ceil(n_rows / 16) workgroups and partial records) or 32 (ERC_HEAD_ROWS=32: two row tiles, two column tiles per wavefront).
+extern "C" int erc_head_fused_rows_per_workgroup(void) {
+    static int rows = 0;
+    if (!rows) {
+        const char* e = getenv("ERC_HEAD_ROWS");
+        rows = (e && atoi(e) == 32) ? 32 : 16;
+    }
+    return rows;
+}
+extern "C" int64_t erc_head_fused_ws_floats(int n_rows) { return (int64_t)erc_cdiv(n_rows, 16) * HF_PART + 16; }
 
 static uint64_t* g_head_stamps = nullptr;
 // diagnostic: 8 x uint64 phase stamps (10 ns ticks) of the following erc_head_fused launches; NULL switches them off
@@ -645,11 +665,17 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     p.defer = defer ? 1 : 0;
     p.H3b = (unsigned short*)H3b, p.Zb = (unsigned short*)Zb, p.dZb = (unsigned short*)dZb, p.dlb = (unsigned short*)dlb, p.ldb16 = ldb16;
     p.stamps = g_head_stamps;
-    const int grid = erc_cdiv(n_rows, 32);
+    const int rpw = erc_head_fused_rows_per_workgroup() / 16;
+    const int grid = erc_cdiv(n_rows, 16 * rpw);
     p.part = ws;
     p.counter = reinterpret_cast<int*>(ws + (int64_t)grid * HF_PART);
-    if (bn_part) hipLaunchKernelGGL(head_fused_kernel<true>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(head_fused_kernel<false>, dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    if (rpw == 2) {
+        if (bn_part) hipLaunchKernelGGL((head_fused_kernel<true, 2>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((head_fused_kernel<false, 2>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    } else {
+        if (bn_part) hipLaunchKernelGGL((head_fused_kernel<true, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((head_fused_kernel<false, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+    }
     ERC_LAUNCH_CHECK("head_fused");
     return ERC_OK;
 }

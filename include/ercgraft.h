@@ -360,8 +360,11 @@ int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const 
                       const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
                       float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, void* stream);
 /* floats per workgroup record of erc_head_fused's workspace: [0,112) column sums of dY, [112,224) of dY * xhat, [224] loss
- * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / 32) records */
+ * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / erc_head_fused_rows_per_workgroup()) records */
 int erc_head_fused_part_floats(void);
+/* rows per workgroup (= per partial record) of erc_head_fused{,_bn}: 16, or 32 with ERC_HEAD_ROWS=32; the consumer of the
+ * deferred records (erc_cogmen_bwd_tile) is told ceil(n_rows / this) records */
+int erc_head_fused_rows_per_workgroup(void);
 
 /* diagnostic: 8 x uint64 phase stamps (10 ns ticks) of the middle workgroup of the following erc_head_fused[_bn] launches;
  * NULL switches them off (tools/cogmen_stamps.py) */
