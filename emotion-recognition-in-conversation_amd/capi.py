@@ -47,10 +47,10 @@ _SIGS = {
     "erc_bn_batch_stats": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "erc_head_fused_ws_floats": (C.c_int64, [_i]),
     "erc_head_fused": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "erc_head_fused_bn": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _i,
-                                    _vp, _vp, _vp, _vp, _i, _vp]),
+                                    _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16_slab_floats": (C.c_int64, []),
     "erc_wgrad_bf16_set_stamps": (C.c_int, [_vp, _i]),
@@ -84,9 +84,9 @@ _SIGS = {
                                  + [_vp] * 11 + [_vp]),
     "erc_head_set_stamps": (C.c_int, [_vp]),
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
-                                      _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp]),
+                                      _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+                                      _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "erc_head_fused_part_floats": (C.c_int, []),
     "erc_head_fused_rows_per_workgroup": (C.c_int, []),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
@@ -461,24 +461,24 @@ def cogmen_fwd_tile_ws_doubles(n):
 
 def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, inv_cnt, H1b, ldh1b, QKVS, H2, ldh2, alpha,
                     bn_fused=False, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, saved=None, bn_ws=None,
-                    n_speakers=2):
+                    n_speakers=2, n_dev=None):
     _check(lib().erc_cogmen_fwd_tile(ptr(H0), ldh0, N, wp, wf, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
                                      ptr(WcatT), ptr(b1), ptr(Wq), ptr(bq), scale, ptr(Mb), ldmb, ptr(inv_cnt), ptr(H1b),
                                      ldh1b, ptr(QKVS), ptr(H2), ldh2, ptr(alpha), int(bn_fused), ptr(running_mean),
                                      ptr(running_var), momentum, eps, ptr(saved), ptr(bn_ws), ptr(g["node_spk"]), n_speakers,
-                                     stream()),
+                                     ptr(n_dev), stream()),
            "erc_cogmen_fwd_tile")
 
 
 def cogmen_bwd_tile(dY, H2, ldh2, N, wp, wf, gamma, saved, bn_bwd, QKVS, alpha, g, inv_cnt, WqT, Wb, scale, dQKVS, dH1,
                     dH0, lddh0, n_speakers=2, head_part=None, head_parts=0, dgamma=None, dbeta=None, stats=None, grads_bf16=False,
-                    lddh1=100):
+                    lddh1=100, n_dev=None):
     _check(lib().erc_cogmen_bwd_tile(ptr(dY), ptr(H2), ldh2, N, wp, wf, ptr(gamma), ptr(saved), ptr(bn_bwd), ptr(QKVS),
                                      ptr(alpha), ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["out_ptr"]), ptr(g["out_dst"]),
                                      ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(inv_cnt), ptr(WqT), ptr(Wb), scale,
                                      ptr(dQKVS), ptr(dH1), ptr(dH0), lddh0, ptr(g["node_spk"]), n_speakers, ptr(head_part),
                                      head_parts, head_fused_part_floats() if head_part is not None else 0, ptr(dgamma),
-                                     ptr(dbeta), ptr(stats), int(grads_bf16), lddh1, stream()), "erc_cogmen_bwd_tile")
+                                     ptr(dbeta), ptr(stats), int(grads_bf16), lddh1, ptr(n_dev), stream()), "erc_cogmen_bwd_tile")
 
 
 def grad_norm(g, n, grad_scale, gnorm, ws):
@@ -793,20 +793,22 @@ def head_fused_ws_floats(n_rows):
 
 
 def head_fused(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
-               H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bf16_out=None):
+               H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bf16_out=None, n_dev=None, label_rows=None):
     """bf16_out: (H3b, Zb, dZb, dlb, pitch) -- bf16 copies of the classifier's weight-gradient operands, or None"""
     b = bf16_out if bf16_out is not None else (None, None, None, None, 0)
     _call("erc_head_fused", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
-          float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, b[0], b[1], b[2], b[3], b[4])
+          float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, b[0], b[1], b[2], b[3], b[4],
+          n_dev, label_rows)
 
 
 def head_fused_bn(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                   H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, running_mean,
-                  running_var, momentum, eps, defer_reduce=False, bf16_out=None):
+                  running_var, momentum, eps, defer_reduce=False, bf16_out=None, n_dev=None, label_rows=None):
     b = bf16_out if bf16_out is not None else (None, None, None, None, 0)
     _call("erc_head_fused_bn", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
           float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles,
-          running_mean, running_var, float(momentum), float(eps), int(defer_reduce), b[0], b[1], b[2], b[3], b[4])
+          running_mean, running_var, float(momentum), float(eps), int(defer_reduce), b[0], b[1], b[2], b[3], b[4], n_dev,
+          label_rows)
 
 
 def head_fused_rows_per_workgroup():

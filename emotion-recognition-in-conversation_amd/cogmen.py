@@ -94,6 +94,11 @@ class COGMENModule(nn.Module):
         self.wgrad_bf16 = True         # bf16 mode: the graph part's and the projection's weight gradients on bf16 matrix cores
         self.fuse_head = True   # training path: csrc/head.hip instead of separate BN / Linear / CE launches
         self.fuse_project_graph = True   # bf16 mode: graph build inside the projection launch (csrc/cogmen_project.hip)
+        # CAPACITY MODE (trainer.StepGraphs buckets): the batch tensors are capacity-sized static buffers -- B dialogues of
+        # which some may have length 0, label [N_cap] -- and the true node count is whatever the lengths add up to: the
+        # projection launch writes it to g["counts"][0] and every later kernel of the step reads it there (n_dev / k_dev),
+        # so ONE captured HIP graph serves every batch that fits the bucket.  bf16 fused path only (supports_capacity).
+        self.dynamic_n = False
         self.flat = None
         self._ws = WorkspaceCache()
         self._seed = seed
@@ -157,6 +162,15 @@ class COGMENModule(nn.Module):
         self.shadows = t
         self._sh = dict(w1=t.view(i_w1).view(F, D), catT=t.view(i_catT), wb=t.view(i_wb), q=t.view(i_q), qT=t.view(i_qT))
         self.use_fused_graph = True
+
+    def supports_capacity(self, batch):
+        """Can a training step on ``batch`` run in capacity mode (every launch of the step takes the node count from the
+        device)?  Needs the fused bf16 path end to end."""
+        x, C, D = batch["input_tensor"], self.n_classes, self.input_size
+        return bool(self.fused_graph and self.enc_train is None and self.w1_shadow is not None and self.fuse_head and
+                    self.fuse_project_graph and self.wgrad_bf16 and x.dtype == torch.bfloat16 and x.dim() == 3 and C <= 8 and
+                    D % 4 == 0 and batch["speaker_tensor"].dim() == 2 and
+                    capi.cogmen_project_graph_ok(D, F_HID, x.shape[0], D, D))
 
     def refresh_shadows(self):
         if self.shadows is not None:
@@ -255,6 +269,9 @@ class COGMENModule(nn.Module):
         project_graph = (self.fuse_project_graph and x_bf16 and self.w1_shadow is not None and self.enc_train is None
                          and speaker_tensor.dim() == 2 and x.is_contiguous()
                          and capi.cogmen_project_graph_ok(D, F, B, D, D))
+        if self.dynamic_n and not (project_graph and ws.get("fused") and upto_h2 and N <= self.BN_FUSED_MAX_N):
+            raise capi.ErcGraftError("COGMEN capacity mode needs the fused bf16 training path (supports_capacity)")
+        nd = g["counts"] if self.dynamic_n else None
         if project_graph:
             capi.cogmen_project_graph(x, D, self.w1_shadow, D, fp.w("rnn.1.bias"), ws["H0"], F, F, D, text_length,
                                       speaker_tensor, B, T, WP, WF, self.n_speakers, N, ws["E"], g)
@@ -276,7 +293,7 @@ class COGMENModule(nn.Module):
                                  fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], 904, ws["inv_cnt"],
                                  ws["H1b"], 104, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=2 if ws["bn_in_tile"] else 0,
                                  running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum,
-                                 eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=self.n_speakers)
+                                 eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=self.n_speakers, n_dev=nd)
             if upto_h2:
                 return ws
             return self._forward_tail(ws, N, training)
@@ -341,6 +358,9 @@ class COGMENModule(nn.Module):
         w16 = bool(fused and self.wgrad_bf16 and x_bf16 and C <= 8 and D % 4 == 0 and x.is_contiguous() and x.data_ptr() % 8 == 0)
         ws["w16"] = w16
         b16 = (ws["H3b"], ws["Zb"], ws["dZb"], ws["dlb"], 104) if w16 else None
+        nd = g["counts"] if self.dynamic_n else None
+        if self.dynamic_n and not (w16 and fused_head):
+            raise capi.ErcGraftError("COGMEN capacity mode needs the fused bf16 training path (supports_capacity)")
         if fused_head:
             head_args = (ws["H2"], F, N, F, C, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
                          fp.w("cls.0.weight"), fp.w("cls.0.bias"), fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys,
@@ -351,7 +371,8 @@ class COGMENModule(nn.Module):
                 # BatchNorm's batch statistics: per-tile sums from the forward tile kernel, added up by every head workgroup
                 # ... and the head's own cross-workgroup sums (BatchNorm backward means, loss) are left to the backward tile kernel
                 capi.head_fused_bn(*head_args, ws["bn_tile_ws"][2:].view(torch.float32), -(-N // 16), bn.running_mean,
-                                   bn.running_var, bn.momentum, bn.eps, defer_reduce=True, bf16_out=b16)
+                                   bn.running_var, bn.momentum, bn.eps, defer_reduce=True, bf16_out=b16, n_dev=nd,
+                                   label_rows=batch.get("label_rows"))
                 ws["head_deferred"] = True
             else:
                 capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
@@ -363,8 +384,8 @@ class COGMENModule(nn.Module):
             capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
                           act=2, aux=ws["Z"], ldaux=F, act_scale=1.0 / (1.0 - p))
         if w16:
-            pl.defer16(ws["Zb"], 104, ws["dlb"], 8, fp.g("cls.3.weight"), F, F, C, N, ct=True, bias_b=fp.g("cls.3.bias"))
-            pl.defer16(ws["dZb"], 104, ws["H3b"], 104, fp.g("cls.0.weight"), F, F, F, N, bias_a=fp.g("cls.0.bias"))
+            pl.defer16(ws["Zb"], 104, ws["dlb"], 8, fp.g("cls.3.weight"), F, F, C, N, ct=True, bias_b=fp.g("cls.3.bias"), k_dev=nd)
+            pl.defer16(ws["dZb"], 104, ws["H3b"], 104, fp.g("cls.0.weight"), F, F, F, N, bias_a=fp.g("cls.0.bias"), k_dev=nd)
         else:
             with self.side.fork():
                 linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
@@ -420,6 +441,7 @@ class COGMENModule(nn.Module):
         fp, g, pl = self.flat, ws["g"], ws["planner"]
         F, D = F_HID, self.input_size
         w16 = ws["w16"]
+        nd = g["counts"] if self.dynamic_n else None
         head_kw = dict(head_part=ws["head_ws"], head_parts=-(-N // capi.head_fused_rows_per_workgroup()), dgamma=fp.g("gcn.bn.weight"), dbeta=fp.g("gcn.bn.bias"),
                        stats=ws["stats"]) if ws.get("head_deferred") else {}
         bwd_args = (ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["QKVS"],
@@ -427,12 +449,13 @@ class COGMENModule(nn.Module):
         if w16:
             # the three gradients the backward hands to the weight-gradient launch are written as bf16 (nothing else reads them)
             capi.cogmen_bwd_tile(*bwd_args, ws["dQKVSb"], ws["dH1b"], ws["dH0b"], 104, n_speakers=self.n_speakers,
-                                 grads_bf16=True, lddh1=104, **head_kw)
+                                 grads_bf16=True, lddh1=104, n_dev=nd, **head_kw)
             pl.defer16(ws["H1b"], 104, ws["dQKVSb"], 4 * F, fp.g("gcn.conv2.lin_query.weight"), F, F, 4 * F, N, ct=True,
-                       bias_b=fp.g("gcn.conv2.lin_query.bias"))
+                       bias_b=fp.g("gcn.conv2.lin_query.bias"), k_dev=nd)
             pl.defer16(ws["dH1b"], 104, ws["Mb"], 904, fp.g("gcn.conv1.weight"), F, F, 9 * F, N, ct=True,
-                       bias_a=fp.g("gcn.conv1.bias"))
-            pl.defer16(ws["dH0b"], 104, x, D, fp.g("rnn.1.weight"), D, F, D, N, bias_a=fp.g("rnn.1.bias"), gather=g["node_row"])
+                       bias_a=fp.g("gcn.conv1.bias"), k_dev=nd)
+            pl.defer16(ws["dH0b"], 104, x, D, fp.g("rnn.1.weight"), D, F, D, N, bias_a=fp.g("rnn.1.bias"), gather=g["node_row"],
+                       k_dev=nd)
             pl.reduce_into(ws, fp.grad)
             return
         capi.cogmen_bwd_tile(*bwd_args, ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers, **head_kw)
@@ -539,6 +562,7 @@ class COGMENTrainer:
         self.optim = FusedAdam(self.model.flat, lr=o.lr, weight_decay=o.weight_decay,
                                decoupled=(o.name == "AdamW"), seed=params.seed)
         self.model.rng_state = self.optim.rng_state   # dropout offset advances with the optimizer step
+        self.optim.skip_flag = self.model.flat.health  # (nothing in this step raises it; StepGraphs.precapture's warm-ups do)
         if self.model.compute == "bf16" and self.model.enc_train is None:
             self.model.attach_bf16_shadow(self.optim)
         self.class_weight = None
@@ -561,6 +585,62 @@ class COGMENTrainer:
             out["n_nodes"] = int(tl.sum())      # host tensor: no device sync when a batch carries no labels
         if self.model.compute == "bf16":
             out["input_tensor"] = out["input_tensor"].to(torch.bfloat16)
+        return out
+
+    N_BUCKET = 256     # capacity buckets: node counts rounded up to a multiple of this
+
+    def _bucket(self, like, B_cap, T_cap, N_cap):
+        x, dev, D = like["input_tensor"], self.device, like["input_tensor"].shape[2]
+
+        def make():
+            return dict(input_tensor=torch.zeros(B_cap, T_cap, D, dtype=x.dtype, device=dev),
+                        speaker_tensor=torch.zeros(B_cap, T_cap, dtype=like["speaker_tensor"].dtype, device=dev),
+                        text_length=torch.zeros(B_cap, dtype=like["text_length"].dtype, device=dev),
+                        label=torch.zeros(N_cap, dtype=like["label"].dtype, device=dev))
+
+        def fill(static, b):
+            Bb, Tb = b["input_tensor"].shape[:2]
+            static["input_tensor"][:Bb, :Tb].copy_(b["input_tensor"], non_blocking=True)
+            static["speaker_tensor"][:Bb, :Tb].copy_(b["speaker_tensor"], non_blocking=True)
+            static["text_length"].zero_()                     # dialogues the batch does not have: length 0
+            static["text_length"][:Bb].copy_(b["text_length"], non_blocking=True)
+            static["label"][:b["label"].shape[0]].copy_(b["label"], non_blocking=True)
+
+        return ("capacity", B_cap, T_cap, N_cap), make, fill
+
+    def _caps(self, batch):
+        B, T, D = batch["input_tensor"].shape
+        B_cap = max(B, int(self.params.train.batch_size))
+        return B_cap, max(T, int(getattr(self, "t_cap", 0))), D
+
+    def capacity_bucket(self, batch):
+        """trainer.StepGraphs: (key, make_static, fill) of the capacity bucket that holds ``batch`` (a prepared device batch),
+        or None when the step cannot run in capacity mode (fp32 parity path, chained / faithful-cost encoder modes)."""
+        if self.encoder is not None or not self.model.supports_capacity(batch):
+            return None
+        B_cap, T_cap, D = self._caps(batch)
+        N = int(batch["label"].shape[0])
+        N_cap = min(-(-N // self.N_BUCKET) * self.N_BUCKET, B_cap * T_cap)
+        if N_cap > self.model.BN_FUSED_MAX_N or not capi.cogmen_project_graph_ok(D, F_HID, B_cap, D, D):
+            return None
+        return self._bucket(batch, B_cap, T_cap, N_cap)
+
+    def all_capacity_buckets(self, batch):
+        """Every bucket a batch of this loader can fall into, smallest first, each with a synthetic filler (all B_cap
+        dialogues present, lengths adding up to the capacity): data parallel runs capture all of them up front, in the
+        same order on every rank (a captured step holds a collective: ranks must not capture at different times)."""
+        if self.capacity_bucket(batch) is None:
+            return []
+        B_cap, T_cap, D = self._caps(batch)
+        out = []
+        for N_cap in range(self.N_BUCKET, min(B_cap * T_cap, self.model.BN_FUSED_MAX_N) + 1, self.N_BUCKET):
+            key, make, fill = self._bucket(batch, B_cap, T_cap, N_cap)
+
+            def synth(static, n=N_cap):
+                lens = torch.full((B_cap, ), n // B_cap, dtype=torch.int64)
+                lens[:n - int(lens.sum())] += 1                        # lengths add up to n, each <= T_cap
+                static["text_length"].copy_(lens.clamp_(max=T_cap))
+            out.append((key, make, fill, synth))
         return out
 
     def train_step(self, batch):

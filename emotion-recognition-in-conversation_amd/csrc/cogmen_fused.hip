@@ -140,6 +140,7 @@ struct CgFwdP {
     float* saved;                  // out [0,F) mean, [F,2F) rstd
     float momentum, eps, scale;
     int N, ldh0, ldmb, ldh1b, ldh2, bn_fused, two_spk;
+    const int32_t* n_dev;          // capacity mode: the true node count lives on the device (N is the capacity the grid is sized for)
     uint64_t* stamps;
     int stamp_block;
 };
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     int* const sSpk = reinterpret_cast<int*>(lds + FW_SPK_OFF);
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar branches below
-    const int N = p.N;
+    const int N = p.n_dev ? min(max(*p.n_dev, 1), p.N) : p.N;   // (uniform scalar load; rows >= N of a capacity-sized grid are masked)
     const int r0 = (int)blockIdx.x * CG_TR;
     const int mb = r0 - CG_HL, ob = r0 - 2 * CG_HL;   // first node of the mid / outer row ranges
     const int c1 = min(lane + 64, CG_F - 1);
@@ -658,6 +659,7 @@ struct CgBwdP {
     float* dH0;                    // out [N, lddh0]     products, csrc/wgrad_bf16.hip; pad columns are left untouched)
     float scale;
     int N, ldh2, lddh0, lddh1, grads_bf16, two_spk;
+    const int32_t* n_dev;          // capacity mode: true node count (see CgFwdP)
     uint64_t* stamps;
     int stamp_block;
 };
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     float* const sPart5 = sG;                                              // K-split partials of the dH0 product
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar branches below
-    const int N = p.N;
+    const int N = p.n_dev ? min(max(*p.n_dev, 1), p.N) : p.N;   // (uniform scalar load; rows >= N of a capacity-sized grid are masked)
     const int r0 = (int)blockIdx.x * CG_TR;
     const int mb = r0 - CG_HL, ob = r0 - 2 * CG_HL, fb = r0 - 3 * CG_HL;
     const int c1 = min(lane + 64, CG_F - 1);
@@ -1131,7 +1133,7 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
                                    const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
                                    int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
                                    float* running_mean, float* running_var, float momentum, float eps, float* saved,
-                                   double* bn_ws, const int32_t* node_spk, int n_speakers, void* stream) {
+                                   double* bn_ws, const int32_t* node_spk, int n_speakers, const int32_t* n_dev, void* stream) {
     ERC_REQUIRE(H0 && in_ptr && in_src && in_typ && WcatT && b1 && Wq && bq && Mb && inv_cnt && H1b && QKVS && H2 && alpha && node_spk,
                 "cogmen_fwd_tile: null pointer");
     ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_fwd_tile: window (%d, %d) exceeds the halo %d",
@@ -1153,7 +1155,7 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
     p.running_mean = running_mean; p.running_var = running_var; p.saved = saved;
     p.momentum = momentum; p.eps = eps; p.scale = scale;
     p.N = n_nodes; p.ldh0 = ldh0; p.ldmb = ldmb; p.ldh1b = ldh1b; p.ldh2 = ldh2; p.bn_fused = bn_fused;
-    p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0;
+    p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0; p.n_dev = n_dev;
     p.stamps = g_cg_stamps; p.stamp_block = tiles / 2;
     hipLaunchKernelGGL(cogmen_fwd_tile_kernel, dim3(tiles), dim3(CG_NTH), FW_LDS, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("cogmen_fwd_tile");
@@ -1167,7 +1169,7 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
                                    const void* Wb, float scale, void* dQKVS, void* dH1, void* dH0, int lddh0,
                                    const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
                                    int head_part_floats, float* dgamma, float* dbeta, float* stats, int grads_bf16, int lddh1,
-                                   void* stream) {
+                                   const int32_t* n_dev, void* stream) {
     ERC_REQUIRE(!head_part || (head_parts > 0 && head_part_floats >= 227 && head_part_floats <= 256 && dgamma && dbeta && stats),
                 "cogmen_bwd_tile: head record operands");
     ERC_REQUIRE(dY && H2 && gamma && saved && bn_bwd && QKVS && alpha && in_ptr && in_src && out_ptr && out_dst && out_typ &&
@@ -1186,7 +1188,7 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
     p.inv_cnt = inv_cnt; p.WqT = (const unsigned short*)WqT; p.Wb = (const unsigned short*)Wb;
     p.dQKVS = (float*)dQKVS; p.dH1 = (float*)dH1; p.dH0 = (float*)dH0; p.scale = scale; p.N = n_nodes; p.ldh2 = ldh2; p.lddh0 = lddh0;
     p.lddh1 = lddh1; p.grads_bf16 = grads_bf16;
-    p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0;
+    p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0; p.n_dev = n_dev;
     p.head_part = head_part; p.head_parts = head_parts; p.hp_floats = head_part_floats; p.bn_bwd_out = const_cast<float*>(bn_bwd);
     p.dgamma = dgamma; p.dbeta = dbeta; p.stats = stats;
     p.stamps = g_cg_stamps; p.stamp_block = erc_cdiv(n_nodes, CG_TR) / 2;

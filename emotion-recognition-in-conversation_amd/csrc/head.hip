@@ -153,6 +153,8 @@ struct HeadP {
     // [N, ldb16 >= F] and dlogits [N, 8]; pad columns are left untouched
     unsigned short *H3b, *Zb, *dZb, *dlb;
     int ldb16;
+    const int32_t* n_dev;        // capacity mode: the true row count lives on the device (N = the capacity the grid is sized for)
+    const int32_t* label_rows;   // labels[label_rows[row]] instead of labels[row] (labels kept in a resident store), or null
 };
 
 #define HF_STAMP(slot)                                                                                              \
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, rt = RPW == 2 ? w >> 2 : 0, cq = RPW == 2 ? w & 3 : w;
     const int r = lane & 15, g = lane >> 4;
-    const int F = p.F, C = p.C, N = p.N;
+    const int F = p.F, C = p.C, N = p.n_dev ? min(max(*p.n_dev, 1), p.N) : p.N;
     float* const sLg = &sT[0][0];  // [rt][cq][16 rows][8 classes] partial logits, dead before sT is written
     HF_STAMP(0);
     __shared__ __attribute__((aligned(16))) float sSaved[2 * HF_MAXF];
@@ -291,7 +293,10 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
             int y[4];
             float wv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = (int)p.labels[min(i0 + j * 512 + tid, N - 1)];
+            for (int j = 0; j < 4; ++j) {
+                const int rr = min(i0 + j * 512 + tid, N - 1);
+                y[j] = (int)p.labels[p.label_rows ? p.label_rows[rr] : rr];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) wv[j] = p.weight[y[j]];
 #pragma unroll
@@ -331,7 +336,10 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     int ylab[4];
     float wyq[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ylab[q] = (int)p.labels[min(m0 + 4 * g + q, N - 1)];
+    for (int q = 0; q < 4; ++q) {
+        const int rr = min(m0 + 4 * g + q, N - 1);
+        ylab[q] = (int)p.labels[p.label_rows ? p.label_rows[rr] : rr];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) wyq[q] = p.weight ? p.weight[ylab[q]] : 1.f;
     int colc[RPW];
@@ -643,7 +651,7 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                              const float* bn_part, int bn_tiles, float* saved_out, float* running_mean, float* running_var,
                              float momentum, float eps, int defer, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16,
-                             void* stream) {
+                             const int32_t* n_dev, const int32_t* label_rows, void* stream) {
     ERC_REQUIRE((!H3b && !Zb && !dZb && !dlb) || (H3b && Zb && dZb && dlb && ldb16 >= F && ldb16 % 4 == 0 && (((uintptr_t)H3b) & 7) == 0),
                 "head_fused: bf16 operand copies (all four or none, pitch %% 4 == 0)");
     ERC_REQUIRE(H2 && gamma && beta && (saved || bn_part) && W0 && b0 && W3 && b3 && labels && H3 && Z && logits && dlogits && dZ && dY &&
@@ -664,6 +672,7 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     p.momentum = momentum, p.eps = eps;
     p.defer = defer ? 1 : 0;
     p.H3b = (unsigned short*)H3b, p.Zb = (unsigned short*)Zb, p.dZb = (unsigned short*)dZb, p.dlb = (unsigned short*)dlb, p.ldb16 = ldb16;
+    p.n_dev = n_dev, p.label_rows = label_rows;
     p.stamps = g_head_stamps;
     const int rpw = erc_head_fused_rows_per_workgroup() / 16;
     const int grid = erc_cdiv(n_rows, 16 * rpw);
@@ -685,11 +694,11 @@ extern "C" int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C
                               const float* b3, const int64_t* labels, const float* weight, float drop_p,
                               const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                               float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* H3b, void* Zb,
-                              void* dZb, void* dlb, int ldb16, void* stream) {
+                              void* dZb, void* dlb, int ldb16, const int32_t* n_dev, const int32_t* label_rows, void* stream) {
     ERC_REQUIRE(saved, "head_fused: null pointer");
     return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                              H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, nullptr, 0, nullptr, nullptr,
-                             nullptr, 0.f, 0.f, 0, H3b, Zb, dZb, dlb, ldb16, stream);
+                             nullptr, 0.f, 0.f, 0, H3b, Zb, dZb, dlb, ldb16, n_dev, label_rows, stream);
 }
 
 extern "C" int erc_head_fused_part_floats(void) { return HF_PART; }
@@ -703,11 +712,12 @@ extern "C" int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, in
                                  const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                                  float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                                  const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
-                                 float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, void* stream) {
+                                 float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, const int32_t* n_dev,
+                                 const int32_t* label_rows, void* stream) {
     ERC_REQUIRE(bn_part && saved, "head_fused_bn: null pointer");
     return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, nullptr, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                              H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, saved,
-                             running_mean, running_var, momentum, eps, defer_reduce, H3b, Zb, dZb, dlb, ldb16, stream);
+                             running_mean, running_var, momentum, eps, defer_reduce, H3b, Zb, dZb, dlb, ldb16, n_dev, label_rows, stream);
 }
 
 extern "C" int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,

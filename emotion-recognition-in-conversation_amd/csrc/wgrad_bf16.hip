@@ -39,16 +39,17 @@ constexpr int W2_IDX_CAP = 4096;            // k per work item (row-gather stage
 constexpr int W2_SLAB = 128 * 64 + 192;     // floats per partial tile: 128 x 64 + the two bias strips
 constexpr int W2_MAX_DESC = 16;
 
-struct W2Desc {  // 112 bytes; mirrored by engine.GemmPlanner.flush_wgrads_bf16 ("<QQQQQQ16i")
+struct W2Desc {  // 112 bytes; mirrored by engine.GemmPlanner.flush_wgrads_bf16 ("<QQQQQQQ14i")
     const unsigned short* A;  // bf16 [K, lda]: M <= 128 columns used; lda % 8 == 0, lda >= 8 ceil(M / 8), pad columns finite
     const unsigned short* B;  // bf16 [K or gathered rows, ldb]: ldb % 4 == 0, ldb >= 4 ceil(N / 4), pad columns finite
     float* C;                 // ct == 0: C[m * ldc + n]; ct == 1: C[n * ldc + m]
     float* bias_a;            // [M] column sums of A over k (or null)
     float* bias_b;            // [N] column sums of B over k (or null)
     const int32_t* b_gather;  // row of B for every k, or null
+    const int32_t* k_dev;     // capacity mode: the true K lives on the device (K below = the capacity the splits are cut for), or null
     int lda, ldb, ldc, M, N, K;
     int ct, cvec, splits, tiles_n, item_base, n_items, tile_base;   // cvec: 16-byte stores of C are legal
-    int pad0, pad1, pad2;
+    int pad0;
 };
 static_assert(sizeof(W2Desc) == 112, "W2Desc layout");
 
@@ -89,6 +90,8 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     const int ks_begin = split * per, ks_end = min(nks, ks_begin + per);
     const int k_begin = ks_begin * 4;
     const int nk = max(1, min(d.K, ks_end * 4) - k_begin);
+    // capacity mode: rows [K_true, K) hold stale values of earlier steps -- they are read (in bounds) and masked
+    const int K_true = d.k_dev ? min(*(const ERC_GLOBAL int32_t*)d.k_dev, d.K) : d.K;
     const ERC_GLOBAL int32_t* const gather = (const ERC_GLOBAL int32_t*)d.b_gather;
     const bool gath = gather != nullptr;   // uniform
     const ERC_GLOBAL unsigned short* const Ag = (const ERC_GLOBAL unsigned short*)d.A;
@@ -152,12 +155,12 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
 
     auto mma_group = [&](const int s0, u32x4 (&a)[8], u32x2 (&b)[8]) {
         // k mask of every step, applied to the raw words -- only a group that reaches past the item's k range needs it (uniform)
-        const bool ragged = 4 * (ks_begin + 4 * (s0 + 7) + 3) + 3 >= min(d.K, 4 * ks_end);
+        const bool ragged = 4 * (ks_begin + 4 * (s0 + 7) + 3) + 3 >= min(K_true, 4 * ks_end);
         if (ragged) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int ks = ks_begin + w + 4 * (s0 + u);
-                const unsigned km = (ks < ks_end && 4 * ks + g < d.K) ? 0xffffffffu : 0u;
+                const unsigned km = (ks < ks_end && 4 * ks + g < K_true) ? 0xffffffffu : 0u;
                 a[u] = (u32x4){a[u].x & km, a[u].y & km, a[u].z & km, a[u].w & km};
                 b[u] = (u32x2){b[u].x & km, b[u].y & km};
             }

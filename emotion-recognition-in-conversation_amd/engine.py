@@ -220,14 +220,15 @@ class GemmPlanner:
                          cache["wgrad_slabs"], cache["wgrad_counters"])
 
     # ------------------------------------------------------------------ bf16 weight gradients (csrc/wgrad_bf16.hip)
-    def defer16(self, A, lda, B, ldb, Cm, ldc, M, N, K, ct=False, bias_a=None, bias_b=None, gather=None):
+    def defer16(self, A, lda, B, ldb, Cm, ldc, M, N, K, ct=False, bias_a=None, bias_b=None, gather=None, k_dev=None):
         """C[M,N] = A[K,M]^T B[gather(K),N] with both operands bf16 in memory (COGMEN bf16 mode); ``ct`` stores C
-        transposed (C[n * ldc + m]); bias_a / bias_b receive the fp32 column sums of A / B."""
+        transposed (C[n * ldc + m]); bias_a / bias_b receive the fp32 column sums of A / B; ``k_dev`` (device int32): K is a
+        capacity, the true row count is read on the device."""
         if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or Cm.dtype != torch.float32:
             raise capi.ErcGraftError("bf16 wgrad: operand dtypes %s %s %s" % (A.dtype, B.dtype, Cm.dtype))
         if M > 128 or lda % 8 or lda < -(-M // 8) * 8 or ldb % 4 or ldb < -(-N // 4) * 4 or A.data_ptr() % 16 or B.data_ptr() % 8:
             raise capi.ErcGraftError("bf16 wgrad: M=%d lda=%d N=%d ldb=%d unsupported" % (M, lda, N, ldb))
-        self.deferred16.append((A, lda, B, ldb, Cm, ldc, M, N, K, bool(ct), bias_a, bias_b, gather))
+        self.deferred16.append((A, lda, B, ldb, Cm, ldc, M, N, K, bool(ct), bias_a, bias_b, gather, k_dev))
 
     def flush_wgrads_bf16(self, cache):
         """Every record of defer16 as ONE launch (erc_wgrad_bf16); table, slabs and counters are built once per shape."""
@@ -235,11 +236,11 @@ class GemmPlanner:
             return
         import ctypes
         import struct
-        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, ct, g.data_ptr() if g is not None else 0)
-                    for a, _, b, _, c, _, M, N, K, ct, _, _, g in self.deferred16)
+        key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, ct, g.data_ptr() if g is not None else 0,
+                     kd.data_ptr() if kd is not None else 0) for a, _, b, _, c, _, M, N, K, ct, _, _, g, kd in self.deferred16)
         if cache.get("w16_key") != key:
             cap = capi.wgrad_bf16_max_k_per_split()
-            tiles = sum(-(-N // 64) for _, _, _, _, _, _, _, N, _, _, _, _, _ in self.deferred16)
+            tiles = sum(-(-d[7] // 64) for d in self.deferred16)
             K = max(d[8] for d in self.deferred16)
             # one 4-wavefront workgroup per CU (428 registers per lane): while every item of the launch is resident at once
             # (<= 256), as many splits as that allows; beyond, ~ERC_W2_ROWS k per item
@@ -251,7 +252,7 @@ class GemmPlanner:
             splits = min(range(1, s_max + 1), key=lambda sp: (groups(sp), sp))
             splits = max(splits, min(32, -(-K // rows)), -(-K // cap))
             raw, items, n_tiles, bases = [], 0, 0, []
-            for a, lda, b, ldb, c, ldc, M, N, Kr, ct, ba, bb, g in self.deferred16:
+            for a, lda, b, ldb, c, ldc, M, N, Kr, ct, ba, bb, g, kd in self.deferred16:
                 nks = -(-Kr // 4)
                 per = -(-nks // splits)
                 sp = -(-nks // per)                       # no empty split
@@ -259,10 +260,10 @@ class GemmPlanner:
                     raise capi.ErcGraftError("bf16 wgrad: K=%d needs more than %d splits" % (Kr, splits))
                 tn = -(-N // 64)
                 cvec = int(c.data_ptr() % 16 == 0 and ldc % 4 == 0)
-                raw.append(struct.pack("<QQQQQQ16i", a.data_ptr(), b.data_ptr(), c.data_ptr(),
+                raw.append(struct.pack("<QQQQQQQ14i", a.data_ptr(), b.data_ptr(), c.data_ptr(),
                                        ba.data_ptr() if ba is not None else 0, bb.data_ptr() if bb is not None else 0,
-                                       g.data_ptr() if g is not None else 0, lda, ldb, ldc, M, N, Kr, int(ct), cvec, sp, tn,
-                                       items, tn * sp, n_tiles, 0, 0, 0))
+                                       g.data_ptr() if g is not None else 0, kd.data_ptr() if kd is not None else 0,
+                                       lda, ldb, ldc, M, N, Kr, int(ct), cvec, sp, tn, items, tn * sp, n_tiles, 0))
                 bases.append(items)
                 items += tn * sp
                 n_tiles += tn

@@ -23,6 +23,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
+from . import capi
 from .collate import ERCCollate
 from .synthetic import make_dialogues
 
@@ -92,6 +93,7 @@ def load_dialogues(params, rank=0, world=1):
         return shard_dialogues(train, rank, world), read_dialogues(params.dataset, "test", roots)
     meld = "meld" in params.dataset
     lo, hi = (1, 33) if meld else (20, 110)
+    lo, hi = int(params.get("syn_min_len", lo)), int(params.get("syn_max_len", hi))     # (tests: equal lengths -> repeating shapes)
     mk = lambda n, seed: make_dialogues(n, params.dims(), n_speakers=params.n_speakers, n_classes=params.n_classes,
                                         min_len=lo, max_len=hi, seed=seed)
     return mk(params.n_train, params.seed + 1000 * rank), mk(params.n_test, params.seed + 7)   # every rank draws its own
@@ -113,6 +115,22 @@ def make_loaders(params, rank=0, world=1, device=None):
     return tl, el
 
 
+def longest_dialogue(loader):
+    """longest training dialogue of this rank's split (the T capacity of the buckets)"""
+    if isinstance(loader, StoreLoader):
+        return int(loader.store.lengths.max())
+    return max(len(d["label"]) for d in loader.dataset.dialogs)
+
+
+def first_batch(loader):
+    """a batch of the loader's shape WITHOUT advancing its shuffling generator (the epochs must see the same permutations
+    whether or not a probe was drawn)"""
+    if isinstance(loader, StoreLoader):
+        return loader.store.batch(torch.arange(min(loader.batch_size, len(loader.store))))
+    n = min(loader.batch_size, len(loader.dataset))
+    return loader.collate_fn([loader.dataset[i] for i in range(n)])
+
+
 class FixedBatches:
     """``--fixed_batches``: the training batches are collated once and kept on the device; an epoch visits them in a
     freshly shuffled ORDER.  Batch shapes then repeat every epoch, so every step after the first epoch is one HIP-graph
@@ -132,53 +150,142 @@ class FixedBatches:
 
 
 class StepGraphs:
-    """One captured HIP graph of the whole training step per batch shape (B, T, N), least-recently-used eviction.  The
-    FIRST step of a shape runs eagerly -- it is a real training step and allocates that shape's workspace -- and is then
-    captured (capture records, it does not execute); later steps of the shape copy the batch into the graph's static
-    input buffers and replay.  Losses are therefore identical to the eager loop."""
+    """Captured HIP graphs of the whole training step, least-recently-used eviction.
 
-    def __init__(self, trainer, maxsize=16):
+    * CAPACITY BUCKETS (trainers that offer ``capacity_bucket``: COGMEN in the bf16 compute mode).  The reference reshuffles
+      the dialogues every epoch and its last batch is smaller (lumo/trainer/trainer.py:429-442, mmbase.py:468), so (B, T, N)
+      almost never repeats.  A bucket is a set of static capacity-sized input buffers -- ``batch_size`` dialogues (missing
+      ones get length 0), the longest dialogue of the split, N rounded up to a multiple of 256 -- plus one graph captured
+      over them; the step's kernels read the true node count from the device (COGMENModule.dynamic_n), so every batch
+      that fits replays that graph: a reshuffled epoch hits a handful of graphs.
+    * otherwise one graph per exact batch shape, captured when the shape shows up the SECOND time (under shuffling most
+      shapes never repeat: capturing each one would cost a synchronisation + instantiation per step and pin a workspace).
+
+    Whatever the key, the first step of a key is a real training step run EAGERLY ON THE GRAPH'S OWN STATIC BUFFERS (the
+    batch is copied in first): every pointer the later capture sees -- inputs, workspace, weight-gradient table -- already
+    exists, so nothing is allocated or uploaded while capturing.  Losses are those of the eager loop."""
+
+    def __init__(self, trainer, maxsize=16, capture=True):
         import collections
         self.trainer, self.maxsize = trainer, maxsize
-        self.cache = collections.OrderedDict()
-        self.replays = self.eager = 0
+        self.capture = capture     # False (--graph_capture=False): same buckets and static buffers, every step eager
+        self.cache = collections.OrderedDict()     # key -> [static, graph or None, out, workspace, fill, dynamic]
+        self.replays = self.eager = self.captures = 0
+        self.capture_failed = False
+        self.lazy = True           # False (data parallel): only precaptured graphs, everything else eager
 
     @staticmethod
     def shape_key(batch):
         return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v)) + \
             tuple((k, v) for k, v in sorted(batch.items()) if isinstance(v, int))
 
+    @staticmethod
+    def _copy_in(static, batch):
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                static[k].copy_(v, non_blocking=True)
+
+    def _run(self, ent, eager):
+        static, graph, out, dynamic = ent[0], ent[1], ent[2], ent[5]
+        model = self.trainer.model
+        if dynamic:
+            model.dynamic_n = True
+        try:
+            if eager:
+                return self.trainer.train_step(static)
+            graph.replay()
+            return out
+        finally:
+            if dynamic:
+                model.dynamic_n = False
+
+    def precapture(self, probe):
+        """Data parallel: capture every capacity bucket NOW, in the same order on every rank.  A captured step contains the
+        gradient all-reduce; a rank that captured lazily (whenever ITS batch first hit a bucket) would record a collective its
+        peers execute.  Each bucket runs one warm-up step on synthetic lengths with the health word raised -- every kernel
+        runs (workspaces, weight-gradient tables, the collective), the optimizer skips: parameters, moments, step count and
+        dropout offset stay as they are; BatchNorm's running statistics are put back -- and is then captured."""
+        tr = self.trainer
+        flat, model = tr.model.flat, tr.model
+        saved = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+        for key, make, fill, synth in tr.all_capacity_buckets(probe):
+            static = make()
+            synth(static)
+            ent = self.cache[key] = [static, None, None, None, fill, True, 1]
+            flat.health.fill_(capi.HEALTH_RAISED)
+            self._run(ent, eager=True)
+            flat.health.fill_(capi.HEALTH_RAISED)      # (the step's own roll cleared it and counted an event)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            model.dynamic_n = True
+            try:
+                with torch.cuda.graph(g):
+                    out = tr.train_step(static)
+            finally:
+                model.dynamic_n = False
+            ent[1], ent[2], ent[3] = g, out, getattr(model, "_last_ws", None)
+            self.captures += 1
+        flat.health.zero_()
+        flat.events.zero_()
+        with torch.no_grad():
+            sd = model.state_dict()
+            for k, v in saved.items():
+                sd[k].copy_(v)
+        self.maxsize = max(self.maxsize, len(self.cache) + 2)
+
     def step(self, batch, key=None, resident=False):
         """``resident``: ``batch`` lives in fixed device buffers of its own (FixedBatches) -- the graph binds to them."""
-        key = (key, ) if key is not None else self.shape_key(batch)
+        bucket = None
+        if key is not None:
+            key = (key, )
+        else:
+            bucket = self.trainer.capacity_bucket(batch) if hasattr(self.trainer, "capacity_bucket") else None
+            key = bucket[0] if bucket is not None else self.shape_key(batch)
         ent = self.cache.get(key)
-        if ent is not None:
-            static, graph, out = ent[:3]
+        if ent is None and not self.lazy:
+            self.eager += 1
+            return self.trainer.train_step(batch)
+        if ent is None:
+            if bucket is not None:
+                static, fill = bucket[1](), bucket[2]
+            else:
+                static = batch if resident else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+                fill = None if resident else self._copy_in
+            ent = self.cache[key] = [static, None, None, None, fill, bucket is not None]
+            ent.append(0)            # occurrences
+            while len(self.cache) > self.maxsize:
+                self.cache.popitem(last=False)
+        else:
             self.cache.move_to_end(key)
-            if not resident:
-                for k, v in batch.items():
-                    if torch.is_tensor(v):
-                        static[k].copy_(v, non_blocking=True)
-            graph.replay()
+        static, graph, fill = ent[0], ent[1], ent[4]
+        ent[6] += 1
+        if fill is not None and (graph is not None or ent[6] > 1 or ent[5]):
+            fill(static, batch)          # (a plain first occurrence was cloned above: already in place)
+        if graph is not None:
             self.replays += 1
-            return out
-        stats = self.trainer.train_step(batch)                # the real step of this shape's first occurrence
+            return self._run(ent, eager=False)
+        stats = self._run(ent, eager=True)                  # a real step, on the static buffers
         self.eager += 1
-        static = batch if resident else {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        if self.capture_failed or not self.capture or not (ent[5] or ent[6] >= 2 or resident):
+            return stats                                    # plain shapes are captured on their second occurrence
         try:
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            g = torch.cuda.CUDAGraph()
+            if ent[5]:
+                self.trainer.model.dynamic_n = True
+            with torch.cuda.graph(g):
                 out = self.trainer.train_step(static)
         except Exception as exc:                               # a step that cannot be captured stays eager
             print(json.dumps({"graph_replay": "capture failed, staying eager", "error": str(exc)[:200]}), file=sys.stderr)
-            self.step = lambda b, key=None, resident=False: self.trainer.train_step(b)
+            self.capture_failed = True
             return stats
-        # the graph holds raw pointers into this shape's workspace: keep the workspace object alive with the graph, whatever
+        finally:
+            if ent[5]:
+                self.trainer.model.dynamic_n = False
+        # the graph holds raw pointers into this key's workspace: keep the workspace object alive with the graph, whatever
         # the module's own LRU cache does with it (evaluation batches of other shapes come in between)
-        self.cache[key] = (static, graph, out, getattr(self.trainer.model, "_last_ws", None))
-        while len(self.cache) > self.maxsize:
-            self.cache.popitem(last=False)
+        ent[1], ent[2], ent[3] = g, out, getattr(self.trainer.model, "_last_ws", None)
+        self.captures += 1
         return stats
 
 
@@ -219,10 +326,21 @@ def run(trainer_cls, params_cls, argv=None):
         checkpoint.load(trainer, params.load)
     train_loader, test_loader = make_loaders(params, rank, world, device)
     best = {}
-    # one captured graph per batch shape; with gradient exchange (world > 1) the step stays eager: the all-reduce is
-    # issued from the host between backward and optimizer
-    graphs = StepGraphs(trainer) if (params.get("graph_replay", True) and world == 1) else None
+    # captured whole-step graphs (StepGraphs): capacity buckets where the trainer offers them, exact shapes otherwise.  Under
+    # data parallelism the captured step is the same one -- forward, backward, the RCCL all-reduce, the optimizer -- but
+    # every capture must happen at the same point on every rank: buckets are captured up front, in one order
+    # (StepGraphs.precapture); a trainer without buckets keeps the eager step there.
+    if hasattr(trainer, "capacity_bucket"):
+        trainer.t_cap = longest_dialogue(train_loader)
+    graphs = StepGraphs(trainer, capture=params.get("graph_capture", True)) if params.get("graph_replay", True) else None
     fixed = FixedBatches(train_loader, trainer, params.seed + rank) if params.get("fixed_batches", False) else None
+    if graphs is not None and world > 1 and fixed is None:
+        probe = trainer.prepare_batch(first_batch(train_loader))
+        if hasattr(trainer, "all_capacity_buckets") and trainer.all_capacity_buckets(probe):
+            graphs.precapture(probe)
+            graphs.lazy = False         # a batch outside every bucket runs eagerly (same collectives, no capture)
+        else:
+            graphs = None
     n_steps = len(fixed) if fixed is not None else len(train_loader)
     ring = torch.zeros(max(1, n_steps), 4, dtype=torch.float32, device=device)    # per-step {loss, #correct, ...}: read once per epoch
     for epoch in range(params.epoch):
@@ -263,7 +381,8 @@ def run(trainer_cls, params_cls, argv=None):
                 best[k] = max(best.get(k, 0.0), rep[k])
             print(json.dumps({"epoch": epoch, "train_utt_per_s": n_utt / dt, "test": {k: rep[k] for k in rep if k != "cm"},
                               "best": best, "graph_replays": graphs.replays if graphs else 0,
-                              "eager_steps": graphs.eager if graphs else len(counts)}), flush=True)
+                              "eager_steps": graphs.eager if graphs else len(counts),
+                              "graphs_captured": graphs.captures if graphs else 0}), flush=True)
     if params.get("save") and rank == 0:
         from . import checkpoint
         checkpoint.save(trainer, params.save)

@@ -135,8 +135,9 @@ int64_t erc_wgrad_slab_floats(void);
 /* The same for the COGMEN bf16 compute mode (csrc/wgrad_bf16.hip): every record is C = A^T B with A [K, M <= 128] and
  * B [K, N] both K-major and BF16 in memory (B optionally through a row gather), on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation; wave tile 128 x 64, so the wide operand is read once.  Record layout (112 bytes, little endian):
- *   u64 A, B, C, bias_a, bias_b, b_gather; i32 lda, ldb, ldc, M, N, K, ct, cvec, splits, tiles_n, item_base, n_items,
- *   tile_base, 0, 0, 0
+ *   u64 A, B, C, bias_a, bias_b, b_gather, k_dev; i32 lda, ldb, ldc, M, N, K, ct, cvec, splits, tiles_n, item_base, n_items,
+ *   tile_base, 0
+ * k_dev (or 0): device int32 holding the true K <= K (capacity mode, see erc_cogmen_bwd_tile): rows beyond it are masked;
  * ct != 0 stores C transposed (C[n * ldc + m]); bias_a [M] / bias_b [N] = fp32 column sums of the operand values over k (or
  * NULL); lda % 8 == 0 and ldb % 4 == 0 with finite pad columns up to 8 ceil(M / 8) resp. 4 ceil(N / 4); tiles_n =
  * ceil(N / 64); n_items = tiles_n * splits; K / splits <= erc_wgrad_bf16_max_k_per_split(); at most 16 records. */
@@ -343,8 +344,10 @@ int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const flo
                    const float* b3, const int64_t* labels, const float* weight, float drop_p,
                    const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                    float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* H3b, void* Zb,
-                   void* dZb, void* dlb, int ldb16, void* stream);
-/* H3b / Zb / dZb [n_rows, ldb16 >= F] and dlb [n_rows, 8]: optional bf16 copies (all four or none) of H3, Z, dZ and dlogits,
+                   void* dZb, void* dlb, int ldb16, const int32_t* n_dev, const int32_t* label_rows, void* stream);
+/* label_rows (or NULL): the label of row i is labels[label_rows[i]] -- labels kept in a resident store (or a padded [B, T]
+ * block) are read through the node -> row map instead of being compacted per batch.
+ * H3b / Zb / dZb [n_rows, ldb16 >= F] and dlb [n_rows, 8]: optional bf16 copies (all four or none) of H3, Z, dZ and dlogits,
  * the operands of the classifier's weight gradients in the bf16 compute mode (erc_wgrad_bf16); pad columns untouched. */
 
 /* erc_head_fused with BatchNorm's batch statistics finalised inside (training mode of nn.BatchNorm1d, cogmen.py:67):
@@ -358,7 +361,8 @@ int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const 
                       const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                       float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                       const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
-                      float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, void* stream);
+                      float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, const int32_t* n_dev,
+                      const int32_t* label_rows, void* stream);
 /* floats per workgroup record of erc_head_fused's workspace: [0,112) column sums of dY, [112,224) of dY * xhat, [224] loss
  * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / erc_head_fused_rows_per_workgroup()) records */
 int erc_head_fused_part_floats(void);
@@ -430,7 +434,8 @@ int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int wp, int wf, 
                         const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
                         int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
                         float* running_mean, float* running_var, float momentum, float eps, float* saved,
-                        double* bn_ws, const int32_t* node_spk, int n_speakers, void* stream);
+                        double* bn_ws, const int32_t* node_spk, int n_speakers, const int32_t* n_dev,
+                        void* stream);
 /* Backward of the same: dY [N,100] = dL/d(BatchNorm output) (erc_head_fused), BatchNorm's elementwise backward
  * (gamma, saved, bn_bwd as erc_bn_bwd_apply), TransformerConv backward (target and source side), dH1 = dQKVS Wq,
  * the transposed relation means and dH0 = dP [W_r^T].  Outputs fp32: dQKVS [N,400], dH1 [N,100], dH0 [N, lddh0] --
@@ -445,7 +450,11 @@ int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes,
                         const void* Wb, float scale, void* dQKVS, void* dH1, void* dH0, int lddh0,
                         const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
                         int head_part_floats, float* dgamma, float* dbeta, float* stats, int grads_bf16, int lddh1,
-                        void* stream);
+                        const int32_t* n_dev, void* stream);
+/* n_dev (here, in erc_cogmen_fwd_tile and in erc_head_fused{,_bn}; NULL = off): CAPACITY MODE.  n_nodes / n_rows is then the
+ * capacity the grid and the buffers are sized for and the true count (<= capacity) is read from device memory -- counts[0]
+ * of erc_cogmen_project_graph -- so that ONE captured HIP graph serves every batch whose node count fits the capacity
+ * (rows >= the true count are masked exactly like the partial last tile; erc_wgrad_bf16 takes the same word as k_dev). */
 /* grads_bf16 != 0: dQKVS [N, 400], dH1 [N, lddh1], dH0 [N, lddh0] are written as bf16 (pitches in elements, pad columns
  * untouched): they are only ever operands of the bf16 weight-gradient products (erc_wgrad_bf16), so the rounding moves from
  * that kernel's loads to these stores.  Otherwise fp32 (lddh1 >= 100). */

@@ -412,3 +412,76 @@ def test_training_loop_graph_replay_equals_eager():
     assert ep[0]["graph_replays"] == 0 and ep[0]["eager_steps"] == 3          # epoch 0: every shape is new
     assert ep[2]["graph_replays"] == 6 and ep[2]["eager_steps"] == 3          # epochs 1, 2: replays only
     assert runs["eager"][1][2]["graph_replays"] == 0
+
+
+def test_capacity_mode_step_equals_exact_step():
+    """COGMEN bf16, capacity mode (COGMENModule.dynamic_n): the batch sits in capacity-sized static buffers -- more dialogue
+    slots than dialogues (length 0), a longer T, a label buffer of N_cap > N entries -- and every kernel of the step reads
+    the true node count from the device.  Loss, statistics, every gradient and BatchNorm's running statistics equal the
+    exact-shape step (gradients up to the fp32 summation order of the weight-gradient splits, which are cut for the
+    capacity); the rows beyond N hold NaN-free garbage of an earlier, larger batch."""
+    from erc_amd.cogmen import COGMENTrainer
+    from erc_amd.params import ERCParams
+    outs = []
+    for cap in (False, True):
+        torch.manual_seed(0)
+        p = ERCParams().from_args(["--dataset=iemocap-cogmen-sbert-6", "--compute=bf16", "--train.batch_size=12"])
+        tr = COGMENTrainer(p, "cuda:0")
+        tr.model.drop_p = 0.0
+        big = tr.prepare_batch(cogmen_case(B=12, min_len=30, max_len=70, dims=dict(a=100, t=768, v=512), seed=3)["batch"])
+        small = tr.prepare_batch(cogmen_case(B=9, min_len=5, max_len=40, dims=dict(a=100, t=768, v=512), seed=4)["batch"])
+        lr, tr.optim.lr = tr.optim.lr, 0.0   # the first step only fills the buffers: the weights of the compared step are the same
+        if cap:
+            tr.t_cap = 80
+            key, make, fill = tr.capacity_bucket(big)
+            assert key == ("capacity", 12, 80, -(-int(big["label"].shape[0]) // 256) * 256)
+            static = make()
+            tr.model.dynamic_n = True
+            fill(static, big)
+            tr.train_step(static)                 # leaves rows of a LARGER batch behind in every buffer of the bucket
+            fill(static, small)
+            tr.optim.lr = lr
+            stats = tr.train_step(static).cpu()
+            tr.model.dynamic_n = False
+        else:
+            tr.train_step(big)
+            tr.optim.lr = lr
+            stats = tr.train_step(small).cpu()
+        n = int(small["label"].shape[0])
+        outs.append((stats, tr.model.flat.grad.clone(), tr.model._last_ws["logits"][:n].clone(), tr.model.gcn.bn.running_mean.clone(),
+                     tr.model.flat.data.clone()))
+    (s0, g0, l0, m0, w0), (s1, g1, l1, m1, w1) = outs
+    assert abs(float(s0[0]) - float(s1[0])) < 1e-6 and float(s0[1]) == float(s1[1])
+    assert float((l0 - l1).abs().max()) < 1e-5
+    assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
+    assert float((m0 - m1).abs().max()) < 1e-6
+    assert float((w0 - w1).abs().max()) < 2.5e-3    # one Adam step of lr 1e-3 (a near-zero gradient entry may change sign)
+
+
+def _run_cli(args, timeout=300):
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "train_mm.py"] + args, cwd=repo, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [json.loads(l) for l in res.stdout.splitlines() if l.startswith("{")]
+    return [l["Lall"] for l in lines if "Lall" in l], [l for l in lines if "test" in l]
+
+
+def test_training_loop_default_sampling_replays_capacity_buckets():
+    """trainer.run with the REFERENCE'S sampling (dialogues reshuffled every epoch, smaller last batch:
+    lumo/trainer/trainer.py:429-442, mmbase.py:468; no --fixed_batches): batch shapes never repeat, the capacity buckets
+    do -- after the first epoch almost every step is a replay of one of a handful of graphs, and the per-step losses are
+    IDENTICAL to the same loop with capture switched off (same buckets, every step eager on the static buffers)."""
+    args = ["--module=cogmen", "--dataset=iemocap-cogmen-6", "--epoch=3", "--n_train=44", "--n_test=6", "--train.batch_size=8",
+            "--test.batch_size=8", "--compute=bf16"]
+    g_loss, g_ep = _run_cli(args)
+    e_loss, e_ep = _run_cli(args + ["--graph_capture=False"])
+    assert len(g_loss) == 18 and g_loss == e_loss
+    assert e_ep[2]["graph_replays"] == 0 and e_ep[2]["graphs_captured"] == 0
+    assert g_ep[2]["graphs_captured"] <= 8
+    assert g_ep[2]["graph_replays"] + g_ep[2]["eager_steps"] == 18
+    assert g_ep[2]["eager_steps"] == g_ep[2]["graphs_captured"]            # one eager step per bucket, everything else replayed
+    assert g_ep[2]["graph_replays"] >= 10

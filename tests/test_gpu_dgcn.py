@@ -479,3 +479,18 @@ def test_classifier_ops_vs_reference_golden(golden, name):
     capi.gemm_f32(dl, C, 1, None, Z, 100, 1, None, dW2, 100, C, 100, N, ones_col=1, bias_out=db2)
     check_grad_digest(fx, [("clf.lin1.weight", dW1), ("clf.lin1.bias", db1), ("clf.lin2.weight", dW2),
                            ("clf.lin2.bias", db2)], tol=1e-4)
+
+
+def test_training_loop_exact_shape_graphs_capture_on_second_occurrence():
+    """trainer.run for a module without capacity buckets (DialogueGCN), default sampling: a shape is captured when it shows
+    up the second time -- its first step runs eagerly ON the static buffers the later graph binds to, so nothing (workspace,
+    weight-gradient table) is allocated or uploaded while capturing -- and replayed from then on; per-step losses are
+    identical to the eager loop.  Equal-length synthetic dialogues make the shapes repeat."""
+    from tests.test_gpu_cogmen import _run_cli
+    args = ["--module=dgcn", "--dataset=meld-mmgcn-7", "--loss_weights=False", "--epoch=2", "--n_train=20", "--n_test=4",
+            "--train.batch_size=4", "--test.batch_size=4", "--syn_min_len=12", "--syn_max_len=12"]
+    g_loss, g_ep = _run_cli(args)
+    e_loss, e_ep = _run_cli(args + ["--graph_replay=False"])
+    assert len(g_loss) == 10 and g_loss == e_loss
+    assert g_ep[1]["graphs_captured"] == 1 and g_ep[1]["eager_steps"] == 2 and g_ep[1]["graph_replays"] == 8
+    assert e_ep[1]["graph_replays"] == 0
