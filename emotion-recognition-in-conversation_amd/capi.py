@@ -81,7 +81,7 @@ _SIGS = {
     "erc_cogmen_set_stamps": (C.c_int, [_vp]),
     "erc_cogmen_project_graph_ok": (C.c_int, [_i, _i, _i, _i, _i]),
     "erc_cogmen_project_graph": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _i]
-                                 + [_vp] * 11 + [_vp]),
+                                 + [_vp] * 11 + [_vp, _vp]),
     "erc_head_set_stamps": (C.c_int, [_vp]),
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
                                       _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -432,14 +432,18 @@ def cogmen_project_graph_ok(K, n_out, B, ldx, ldw):
     return bool(lib().erc_cogmen_project_graph_ok(K, n_out, B, ldx, ldw))
 
 
-def cogmen_project_graph(x, ldx, W, ldw, bias, H0, ldh0, n_out, K, lengths, speakers, B, T, wp, wf, n_speakers, n_cap, e_cap, g):
-    """input projection + window graph in one launch (csrc/cogmen_project.hip); g: the graph dict of window_graph_build"""
+def cogmen_project_graph(x, ldx, W, ldw, bias, H0, ldh0, n_out, K, lengths, speakers, B, T, wp, wf, n_speakers, n_cap, e_cap, g,
+                         desc=None):
+    """input projection + window graph in one launch (csrc/cogmen_project.hip); g: the graph dict of window_graph_build.
+    desc (int32 [2 B]: lengths | first store rows): resident mode -- x / speakers are a store's [U, ldx] / [U] arrays"""
     _dev(x)
+    sb, st = (0, speakers.stride(0)) if desc is not None else (speakers.stride(0), speakers.stride(1))
     _check(lib().erc_cogmen_project_graph(ptr(x), ldx, ptr(W), ldw, ptr(bias), ptr(H0), ldh0, n_out, K, ptr(lengths),
-                                          ptr(speakers), speakers.stride(0), speakers.stride(1), B, T, wp, wf, n_speakers,
+                                          ptr(speakers), sb, st, B, T, wp, wf, n_speakers,
                                           n_cap, e_cap, ptr(g["node_off"]), ptr(g["node_row"]), ptr(g["node_spk"]),
                                           ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]), ptr(g["out_ptr"]),
-                                          ptr(g["out_dst"]), ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(g["counts"]), stream()),
+                                          ptr(g["out_dst"]), ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(g["counts"]), ptr(desc),
+                                          stream()),
            "erc_cogmen_project_graph")
 
 

@@ -255,7 +255,9 @@ class COGMENModule(nn.Module):
             N = int(text_length.sum().item())
         return B, T, N
 
-    def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training, upto_h2=False):
+    def _forward_impl(self, x, speaker_tensor, text_length, B, T, N, training, upto_h2=False, desc=None):
+        """``desc`` (int32 [2 B]: lengths | first store rows): RESIDENT batch -- x [U, D] / speaker_tensor [U] are a feature
+        store's arrays, B / T / N are capacities (capacity mode is implied), no padded block exists."""
         fp, dev = self.flat, x.device
         ws = self._workspace(B, T, N, dev)
         g, pl = ws["g"], ws["planner"]
@@ -267,14 +269,16 @@ class COGMENModule(nn.Module):
         # bf16 mode: the projection's workgroups build the window graph themselves (csrc/cogmen_project.hip): one launch
         # and one launch gap less than graph build + projection
         project_graph = (self.fuse_project_graph and x_bf16 and self.w1_shadow is not None and self.enc_train is None
-                         and speaker_tensor.dim() == 2 and x.is_contiguous()
+                         and speaker_tensor.dim() == (1 if desc is not None else 2) and x.is_contiguous()
                          and capi.cogmen_project_graph_ok(D, F, B, D, D))
+        if desc is not None and not (project_graph and self.dynamic_n):
+            raise capi.ErcGraftError("COGMEN resident batches need the fused bf16 training path in capacity mode")
         if self.dynamic_n and not (project_graph and ws.get("fused") and upto_h2 and N <= self.BN_FUSED_MAX_N):
             raise capi.ErcGraftError("COGMEN capacity mode needs the fused bf16 training path (supports_capacity)")
         nd = g["counts"] if self.dynamic_n else None
         if project_graph:
             capi.cogmen_project_graph(x, D, self.w1_shadow, D, fp.w("rnn.1.bias"), ws["H0"], F, F, D, text_length,
-                                      speaker_tensor, B, T, WP, WF, self.n_speakers, N, ws["E"], g)
+                                      speaker_tensor, B, T, WP, WF, self.n_speakers, N, ws["E"], g, desc=desc)
         else:
             capi.window_graph_build(text_length, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
                                     B, T, WP, WF, self.n_speakers, N, ws["E"], g)
@@ -341,12 +345,13 @@ class COGMENModule(nn.Module):
         """Forward in the module's current mode, cross entropy, full backward into ``flat.grad``.
         Returns the stats tensor {loss, #correct, weight sum} (device, no sync)."""
         x, spk, lens, ys = batch["input_tensor"], batch["speaker_tensor"], batch["text_length"], batch["label"]
-        B, T, N = self._shape(x, lens, ys)
+        desc = batch.get("desc")          # resident batch (trainer.ResidentEpochs): store arrays + 2 B int32 of batch description
+        B, T, N = batch["caps"] if desc is not None else self._shape(x, lens, ys)
         training = self.training
         F, C, D = F_HID, self.n_classes, self.input_size
         # fused head (csrc/head.hip): BatchNorm apply .. cross entropy .. BatchNorm-backward sums in one launch
         fused_head = self.fuse_head and training and C <= 8 and F % 4 == 0 and F <= 100
-        ws = self._forward_impl(x, spk, lens, B, T, N, training, upto_h2=fused_head)
+        ws = self._forward_impl(x, spk, lens, B, T, N, training, upto_h2=fused_head, desc=desc)
         fp, g, pl = self.flat, ws["g"], ws["planner"]
         x_bf16 = x.dtype == torch.bfloat16
         p = self.drop_p if training else 0.0
@@ -372,7 +377,7 @@ class COGMENModule(nn.Module):
                 # ... and the head's own cross-workgroup sums (BatchNorm backward means, loss) are left to the backward tile kernel
                 capi.head_fused_bn(*head_args, ws["bn_tile_ws"][2:].view(torch.float32), -(-N // 16), bn.running_mean,
                                    bn.running_var, bn.momentum, bn.eps, defer_reduce=True, bf16_out=b16, n_dev=nd,
-                                   label_rows=batch.get("label_rows"))
+                                   label_rows=g["node_row"] if desc is not None else None)
                 ws["head_deferred"] = True
             else:
                 capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
@@ -624,6 +629,19 @@ class COGMENTrainer:
         if N_cap > self.model.BN_FUSED_MAX_N or not capi.cogmen_project_graph_ok(D, F_HID, B_cap, D, D):
             return None
         return self._bucket(batch, B_cap, T_cap, N_cap)
+
+    def resident_batch(self, store, cur_desc, B_cap, T_cap, N_cap):
+        """trainer.ResidentEpochs: the "batch" of a step whose dialogues stay in the HBM-resident store -- the store's arrays,
+        the 2 B_cap int32 the host rewrites per step (lengths | first store rows of the batch's dialogue slots) and the
+        capacities the launches are sized for.  None when the step cannot run that way."""
+        probe = dict(input_tensor=store.fused[None, :1], speaker_tensor=store.speaker[None, :1])
+        D = int(store.fused.shape[1])
+        if self.encoder is not None or store.fused.dtype != torch.bfloat16 or not self.model.supports_capacity(
+                dict(probe, input_tensor=store.fused.view(1, -1, D))) or N_cap > self.model.BN_FUSED_MAX_N or \
+                not capi.cogmen_project_graph_ok(D, F_HID, B_cap, D, D):
+            return None
+        return dict(input_tensor=store.fused, speaker_tensor=store.speaker, text_length=None, label=store.label, desc=cur_desc,
+                    caps=(B_cap, T_cap, N_cap))
 
     def all_capacity_buckets(self, batch):
         """Every bucket a batch of this loader can fall into, smallest first, each with a synthetic filler (all B_cap

@@ -37,11 +37,15 @@ struct PgP {
     int64_t spk_sb, spk_st;
     int B, T, wp, wf, S, n_cap, e_cap;
     int32_t *node_off, *node_row, *node_spk, *in_ptr, *in_src, *in_typ, *out_ptr, *out_dst, *out_typ, *out_eid, *counts;
+    // RESIDENT mode (or null): the batch is a list of dialogues of a feature store that lives in HBM -- desc[b] = length of
+    // dialogue slot b (0: empty slot), desc[B + b] = its first row in the store.  X / speakers are then the store's [U, ldx]
+    // feature rows / [U] speaker ids, lengths is unused, and node_row holds store rows: no padded [B, T, D] block exists.
+    const int32_t* desc;
 };
 
 __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) {
     __shared__ float red[8 * PG_NT * 4 * 64];   // 32 KB: partial tiles of the 8 wavefronts
-    __shared__ int s_noff[PG_BMAX + 1], s_eoff[PG_BMAX + 1];
+    __shared__ int s_noff[PG_BMAX + 1], s_eoff[PG_BMAX + 1], s_base[PG_BMAX];   // node / edge offsets, first feature row of a dialogue
     __shared__ int s_wn[8], s_we[8];
     __shared__ int s_dlg[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
@@ -50,7 +54,8 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
     const int nkb = (p.K + 31) / 32;
 
     // ---- the lengths first: everything but the weight fragments waits for them
-    int L0 = (int)p.lengths[min(tid, p.B - 1)];
+    int L0 = p.desc ? p.desc[min(tid, p.B - 1)] : (int)p.lengths[min(tid, p.B - 1)];
+    int base0 = p.desc ? p.desc[p.B + min(tid, p.B - 1)] : min(tid, p.B - 1) * p.T;
     __builtin_amdgcn_sched_barrier(0);
     // ---- this wavefront's K blocks of W (as gemm_bf16a_persist_kernel): a block that would run past K is shifted back to
     //      end at K; the k it then shares with the previous block are zeroed in the W fragment (K >= 32, K % 4 == 0)
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
     const int n0_first = pair * 16;
     for (int c0 = 0; c0 < p.B; c0 += 512) {
         const int t = c0 + tid;
-        int L = c0 == 0 ? L0 : (int)p.lengths[min(t, p.B - 1)];
+        int L = c0 == 0 ? L0 : (p.desc ? p.desc[min(t, p.B - 1)] : (int)p.lengths[min(t, p.B - 1)]);
+        const int base = c0 == 0 ? base0 : (p.desc ? p.desc[p.B + min(t, p.B - 1)] : min(t, p.B - 1) * p.T);
         L = t < p.B ? min(max(L, 0), p.T) : 0;
         const int E = erc_window_prefix(L, L, p.wf, p.wp);
         int sn = L, se = E;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
         }
         if (t < p.B) {
             const int off = bn + sn - L;
-            s_noff[t] = off, s_eoff[t] = be + se - E;
+            s_noff[t] = off, s_eoff[t] = be + se - E, s_base[t] = base;
             for (int n = max(off, n0_first); n < min(off + L, n0_first + 16); ++n) s_dlg[n - n0_first] = t;
         }
         carry_n += tn, carry_e += te;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
         {
             const int nr = min(n0 + r, N - 1);
             const int b = s_dlg[nr - n0];
-            const int64_t arow = ((int64_t)b * p.T + (nr - s_noff[b])) * p.ldx;
+            const int64_t arow = ((int64_t)s_base[b] + (nr - s_noff[b])) * p.ldx;
 #pragma unroll
             for (int s = 0; s < PG_NB; ++s) {
                 const unsigned short* ar = p.X + arow + k0[s] + 8 * g;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
             const int i = tid >> 5, slot = tid & 31;
             const int nn = min(n0 + i, N - 1);
             const int b = s_dlg[nn - n0], noff = s_noff[b], Lb = s_noff[b + 1] - noff, pp = nn - noff;
-            const int64_t* const spk = p.speakers + (int64_t)b * p.spk_sb;
+            const int64_t* const spk = p.speakers + (p.desc ? (int64_t)s_base[b] * p.spk_st : (int64_t)b * p.spk_sb);
             const int back = slot < 16 ? p.wf : p.wp;
             const int first = min(max(0, pp - back) + (slot & 15), Lb - 1);
             sp = (int)spk[(int64_t)pp * p.spk_st];
@@ -204,12 +210,12 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
             const bool nv = n < N;
             const int nn = min(n, N - 1);
             const int b = s_dlg[nn - n0], noff = s_noff[b], Lb = s_noff[b + 1] - noff, pp = nn - noff, eoff = s_eoff[b];
-            const int64_t* const spk = p.speakers + (int64_t)b * p.spk_sb;
+            const int64_t* const spk = p.speakers + (p.desc ? (int64_t)s_base[b] * p.spk_st : (int64_t)b * p.spk_sb);
             if (slot < 16) {
                 // in-edges of target pp: sources j in [pp - wf, pp + wp]  (canonical order: target-major, then source)
                 const int lo = max(0, pp - p.wf), hi = min(Lb - 1, pp + p.wp);
                 const int base = eoff + erc_window_prefix(pp, Lb, p.wf, p.wp);
-                if (slot == 0 && nv) p.node_row[n] = b * p.T + pp, p.node_spk[n] = sp, p.in_ptr[n] = base;
+                if (slot == 0 && nv) p.node_row[n] = s_base[b] + pp, p.node_spk[n] = sp, p.in_ptr[n] = base;
                 for (int j = lo + slot; j <= hi; j += 16) {
                     const int sj = j == lo + slot ? s_nb : (int)spk[(int64_t)j * p.spk_st];
                     if (nv) {
@@ -249,8 +255,8 @@ extern "C" int erc_cogmen_project_graph(const void* X, int ldx, const void* W, i
                                         int64_t spk_st, int B, int T, int wp, int wf, int n_speakers, int n_cap, int e_cap,
                                         int32_t* node_off, int32_t* node_row, int32_t* node_spk, int32_t* in_ptr,
                                         int32_t* in_src, int32_t* in_typ, int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ,
-                                        int32_t* out_eid, int32_t* counts, void* stream) {
-    ERC_REQUIRE(X && W && bias && H0 && lengths && speakers && node_off && node_row && node_spk && in_ptr && in_src && in_typ &&
+                                        int32_t* out_eid, int32_t* counts, const int32_t* desc, void* stream) {
+    ERC_REQUIRE(X && W && bias && H0 && (lengths || desc) && speakers && node_off && node_row && node_spk && in_ptr && in_src && in_typ &&
                     out_ptr && out_dst && out_typ && out_eid && counts,
                 "cogmen_project_graph: null pointer");
     ERC_REQUIRE(erc_cogmen_project_graph_ok(K, n_out, B, ldx, ldw) && ((uintptr_t)X & 7) == 0 && ((uintptr_t)W & 7) == 0 &&
@@ -259,7 +265,7 @@ extern "C" int erc_cogmen_project_graph(const void* X, int ldx, const void* W, i
     ERC_REQUIRE(wp >= -1 && wf >= -1, "cogmen_project_graph: window must be >= -1");
     PgP p{(const unsigned short*)X, (const unsigned short*)W, bias, H0, ldx, ldw, ldh0, K, n_out, lengths, speakers, spk_sb, spk_st,
           B, T, wp < 0 ? T : wp, wf < 0 ? T : wf, n_speakers, n_cap, e_cap, node_off, node_row, node_spk, in_ptr, in_src, in_typ,
-          out_ptr, out_dst, out_typ, out_eid, counts};
+          out_ptr, out_dst, out_typ, out_eid, counts, desc};
     hipLaunchKernelGGL(cogmen_project_graph_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, p);   // 128 pairs of workgroups
     ERC_LAUNCH_CHECK("cogmen_project_graph");
     return ERC_OK;

@@ -289,6 +289,90 @@ class StepGraphs:
         return stats
 
 
+class ResidentEpochs:
+    """``--resident``: the training dialogues live in HBM (datasets.DeviceDialogueStore, 288 GB per GPU: IEMOCAP's features are
+    16 MB) and a step's batch is never materialised.  Per epoch the host draws the permutation (DataLoader(shuffle=True)
+    semantics: every dialogue once, a smaller last batch) and uploads ONE int32 table [steps, 2 B] (lengths | first store
+    rows of every batch's dialogues); per step it copies that step's 2 B int32 into the fixed descriptor buffer and replays
+    the bucket's captured graph -- the projection launch reads feature rows, speakers and labels straight from the store
+    (csrc/cogmen_project.hip, resident mode).  Host work per step: one 256-byte device copy + one graph launch."""
+
+    N_BUCKET = 128
+
+    def __init__(self, trainer, store, batch_size, seed, capture=True):
+        self.trainer, self.store, self.B = trainer, store, int(batch_size)
+        self.gen = torch.Generator().manual_seed(seed)
+        self.T = int(store.lengths.max())
+        dev = store.device
+        self.cur_desc = torch.zeros(2 * self.B, dtype=torch.int32, device=dev)
+        self.acc = torch.zeros(4, dtype=torch.float64, device=dev)      # sums of the steps' {loss, #correct, weight, -}
+        self.graphs, self.capture = {}, capture
+        self.replays = self.eager = self.captures = 0
+        self._lens32, self._offs32 = store.lengths.to(torch.int32), store.offsets[:-1].to(torch.int32)
+        self._ahead = []           # (node counts per step, device table) of the epochs planned ahead
+
+    def plan(self, n_epochs):
+        """Draw the permutations of the next ``n_epochs`` epochs (sequential randperm draws: the same epochs as drawing them
+        one by one) and upload their batch tables -- int32 [steps, 2 B]: lengths | first store rows, 0 for the empty slots of
+        a smaller last batch -- in one copy: nothing but the step loop is left inside an epoch."""
+        import numpy as np
+        st, B = self.store, self.B
+        n = len(st)
+        steps = -(-n // B)
+        lens, offs = self._lens32.numpy(), self._offs32.numpy()
+        tabs = np.zeros((n_epochs, steps, 2 * B), dtype=np.int32)
+        for e in range(n_epochs):
+            order = torch.randperm(n, generator=self.gen).numpy()
+            flat_l, flat_o = np.zeros(steps * B, dtype=np.int32), np.zeros(steps * B, dtype=np.int32)
+            flat_l[:n], flat_o[:n] = lens[order], offs[order]
+            tabs[e, :, :B], tabs[e, :, B:] = flat_l.reshape(steps, B), flat_o.reshape(steps, B)
+        dev = torch.from_numpy(tabs).to(st.device)
+        for e in range(n_epochs):
+            self._ahead.append((tabs[e, :, :B].sum(1).tolist(), dev[e]))
+
+    def supported(self):
+        return self.trainer.resident_batch(self.store, self.cur_desc, self.B, self.T, self.N_BUCKET) is not None
+
+    def _step_fn(self, batch):
+        stats = self.trainer.train_step(batch)
+        self.acc.add_(stats[:4])
+        return stats
+
+    def epoch(self):
+        """one pass over the store; returns (#utterances, #steps)"""
+        st, B = self.store, self.B
+        n = len(st)
+        steps = -(-n // B)
+        if not self._ahead:
+            self.plan(1)
+        counts, table_dev = self._ahead.pop(0)
+        model = self.trainer.model
+        model.dynamic_n = True
+        try:
+            for s in range(steps):
+                self.cur_desc.copy_(table_dev[s], non_blocking=True)
+                n_cap = min(-(-counts[s] // self.N_BUCKET) * self.N_BUCKET, B * self.T)
+                ent = self.graphs.get(n_cap)
+                if ent is not None and ent[0] is not None:
+                    ent[0].replay()
+                    self.replays += 1
+                    continue
+                batch = self.trainer.resident_batch(st, self.cur_desc, B, self.T, n_cap)
+                self._step_fn(batch)                    # a real step; allocates the bucket's workspace
+                self.eager += 1
+                if not self.capture:
+                    continue
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_fn(batch)
+                self.graphs[n_cap] = (g, batch, getattr(model, "_last_ws", None))
+                self.captures += 1
+        finally:
+            model.dynamic_n = False
+        return sum(counts), steps
+
+
 def classification_report(true, pred, n_classes):
     """The metric set of mmbase.py:259-275."""
     from sklearn import metrics
@@ -343,10 +427,27 @@ def run(trainer_cls, params_cls, argv=None):
             graphs = None
     n_steps = len(fixed) if fixed is not None else len(train_loader)
     ring = torch.zeros(max(1, n_steps), 4, dtype=torch.float32, device=device)    # per-step {loss, #correct, ...}: read once per epoch
+    resident, acc_prev = None, [0.0] * 4
+    if params.get("resident", False):
+        if world > 1 or not isinstance(train_loader, StoreLoader) or not hasattr(trainer, "resident_batch"):
+            raise SystemExit("--resident needs --device_collate, one rank and a trainer with resident batches (cogmen, --compute=bf16)")
+        resident = ResidentEpochs(trainer, train_loader.store, params.train.batch_size, params.seed + rank,
+                                  capture=params.get("graph_capture", True))
+        if not resident.supported():
+            raise SystemExit("--resident: this configuration cannot run the fused bf16 step in capacity mode")
+        resident.plan(params.epoch)
     for epoch in range(params.epoch):
         trainer.model.train()
         t0, n_utt, counts = time.perf_counter(), 0, []
-        for i, item in enumerate(fixed if fixed is not None else train_loader):
+        if resident is not None:
+            n_utt, n_st = resident.epoch()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tot = resident.acc.cpu().tolist()                           # running totals: this epoch = the difference
+            acc, acc_prev = [a - b for a, b in zip(tot, acc_prev)], tot
+            if rank == 0 and params.log_every:
+                print(json.dumps({"epoch": epoch, "steps": n_st, "Lall": acc[0] / n_st, "Acc": acc[1] / max(1, n_utt)}), flush=True)
+        for i, item in enumerate(() if resident is not None else (fixed if fixed is not None else train_loader)):
             if fixed is not None:
                 bid, (n_b, dev_batch) = item
             else:
@@ -358,7 +459,8 @@ def run(trainer_cls, params_cls, argv=None):
         torch.cuda.synchronize()
         if hasattr(trainer.model, "check_cluster"):
             trainer.model.check_cluster()
-        dt = time.perf_counter() - t0
+        if resident is None:
+            dt = time.perf_counter() - t0
         if rank == 0 and params.log_every:
             rows = ring[:len(counts)].cpu().tolist()
             for i, (row, n_b) in enumerate(zip(rows, counts)):
@@ -380,9 +482,9 @@ def run(trainer_cls, params_cls, argv=None):
             for k in ("acc", "wa", "f1", "mif1", "maf1", "pre", "rec"):
                 best[k] = max(best.get(k, 0.0), rep[k])
             print(json.dumps({"epoch": epoch, "train_utt_per_s": n_utt / dt, "test": {k: rep[k] for k in rep if k != "cm"},
-                              "best": best, "graph_replays": graphs.replays if graphs else 0,
-                              "eager_steps": graphs.eager if graphs else len(counts),
-                              "graphs_captured": graphs.captures if graphs else 0}), flush=True)
+                              "best": best, "graph_replays": (resident or graphs).replays if (resident or graphs) else 0,
+                              "eager_steps": (resident or graphs).eager if (resident or graphs) else len(counts),
+                              "graphs_captured": (resident or graphs).captures if (resident or graphs) else 0}), flush=True)
     if params.get("save") and rank == 0:
         from . import checkpoint
         checkpoint.save(trainer, params.save)

@@ -473,7 +473,12 @@ int erc_cogmen_project_graph(const void* X, int ldx, const void* W, int ldw, con
                              int64_t spk_st, int B, int T, int wp, int wf, int n_speakers, int n_cap, int e_cap,
                              int32_t* node_off, int32_t* node_row, int32_t* node_spk, int32_t* in_ptr, int32_t* in_src,
                              int32_t* in_typ, int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ, int32_t* out_eid,
-                             int32_t* counts, void* stream);
+                             int32_t* counts, const int32_t* desc, void* stream);
+/* desc (or NULL): RESIDENT mode.  The batch is a list of B dialogue slots of a feature store that lives in HBM: desc[b] =
+ * length of slot b (0 = empty), desc[B + b] = its first row in the store; X = the store's [U, ldx] bf16 feature rows,
+ * speakers = its [U] speaker ids (element stride spk_st), lengths is unused (may be NULL), node_row receives STORE rows (the
+ * weight-gradient gather and erc_head_fused's label_rows read the store through it).  No padded [B, T, D] block exists:
+ * a training step needs 2 B int32 of new input. */
 
 /* diagnostic: phase stamps (10 ns ticks) of the middle workgroup of the following erc_cogmen_{fwd,bwd}_tile launches,
  * 8 x uint64 device memory; NULL switches them off (tools/cogmen_stamps.py) */

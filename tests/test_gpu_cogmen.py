@@ -485,3 +485,22 @@ def test_training_loop_default_sampling_replays_capacity_buckets():
     assert g_ep[2]["graph_replays"] + g_ep[2]["eager_steps"] == 18
     assert g_ep[2]["eager_steps"] == g_ep[2]["graphs_captured"]            # one eager step per bucket, everything else replayed
     assert g_ep[2]["graph_replays"] >= 10
+
+
+def test_resident_epochs_equal_the_collated_loop():
+    """``--resident``: the dialogues stay in the HBM store and a step's input is 2 B int32 (lengths | first store rows of
+    the batch's dialogues) -- the projection launch reads features, speakers and labels straight from the store.  Same
+    seed, same permutations, same batches as the device-collated loop (which pads every batch into a [B, T, D] block and
+    copies it into the bucket's static buffers): the epoch mean losses are equal and every step after a bucket's first
+    is a graph replay."""
+    args = ["--module=cogmen", "--dataset=iemocap-cogmen-6", "--epoch=3", "--n_train=44", "--n_test=6", "--train.batch_size=8",
+            "--test.batch_size=8", "--compute=bf16", "--device_collate"]
+    c_loss, c_ep = _run_cli(args)
+    r_loss, r_ep = _run_cli(args + ["--resident"])
+    assert len(c_loss) == 18 and len(r_loss) == 3
+    for e in range(3):
+        want = sum(c_loss[6 * e:6 * e + 6]) / 6
+        assert abs(r_loss[e] - want) < 2e-6 * max(1.0, abs(want)), (e, r_loss[e], want)
+    assert r_ep[2]["graphs_captured"] <= 8 and r_ep[2]["graph_replays"] + r_ep[2]["eager_steps"] == 18
+    assert r_ep[2]["eager_steps"] == r_ep[2]["graphs_captured"]
+    assert [x["test"]["acc"] for x in r_ep] == [x["test"]["acc"] for x in c_ep]
