@@ -502,7 +502,9 @@ def main():
                                        params.hidden_visual, params.hidden_all, params.n_classes),
                        "utterances_per_step_per_gpu": n_utt, "global_batch_dialogues": args.batch * world,
                        "parallelism": "dp%d" % world, "hip_graph": use_graph,
-                       "dp_exchange": ("none" if not dp else ("eager after the graph" if os.environ.get("ERC_DP_EAGER", "0") == "1" or not use_graph else "captured in the step graph")),
+                       "dp_exchange": ("none" if not dp else (
+                           "fused into the optimizer launch (peer-mapped buffers, ERC_DP_P2P=1)" if getattr(trainer.model.flat, "p2p", None) is not None
+                           else ("eager after the graph" if os.environ.get("ERC_DP_EAGER", "0") == "1" or not use_graph else "captured in the step graph (RCCL all-reduce)"))),
                        "features_dtype": args.dtype, "loss": stats[0],
                        "faithful_dead_encoder": bool(args.faithful_dead_encoder and args.module == "cogmen"),
                        "chained_encoder": bool(args.chained_encoder and args.module == "cogmen")},

@@ -156,6 +156,11 @@ _SIGS = {
     "erc_dag_rec_bwd": (C.c_int, [_i, _vp, _i, _vp, _i] + [_vp] * 9 + [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp,
                                   _vp, _vp, _vp, _vp, _vp]),
     "erc_health_roll": (C.c_int, [_vp, _vp, _vp]),
+    "erc_p2p_alloc": (C.c_int, [_i64, _vp, _vp]),
+    "erc_p2p_open": (C.c_int, [_vp, _vp]),
+    "erc_p2p_close": (C.c_int, [_vp]),
+    "erc_p2p_free": (C.c_int, [_vp]),
+    "erc_adam_step_p2p": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp, _i64, _vp, _vp, _vp]),
     "erc_gcnii_chain_set_spin_limit": (C.c_int, [_i]),
     "erc_dag_attn_sums": (C.c_int, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
 }
@@ -410,6 +415,41 @@ def adam_step_tab(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, cli
     _check(lib().erc_adam_step_tab(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale,
                                    clip_norm, ptr(gnorm), ptr(state), ptr(table.buf), table.buf.numel(), table.tab_ptr, ptr(skip_flag),
                                    stream()), "erc_adam_step_tab")
+
+
+class ErcP2P(C.Structure):
+    """host mirror of ErcP2P (ercgraft.h)"""
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("spin_limit", C.c_int32), ("pad", C.c_int32),
+                ("pub", C.c_void_p * 8), ("flags", C.c_void_p * 8), ("epoch", C.c_void_p), ("health", C.c_void_p),
+                ("n_pad", C.c_int64)]
+
+
+def p2p_alloc(nbytes):
+    """(device pointer, 64-byte IPC handle) of a zero-filled buffer other processes can map"""
+    out, handle = C.c_void_p(), C.create_string_buffer(64)
+    _check(lib().erc_p2p_alloc(nbytes, C.addressof(out), C.addressof(handle)), "erc_p2p_alloc")
+    return out.value, handle.raw
+
+
+def p2p_open(handle):
+    out = C.c_void_p()
+    _check(lib().erc_p2p_open(C.c_char_p(handle), C.addressof(out)), "erc_p2p_open")
+    return out.value
+
+
+def p2p_close(ptr_):
+    _check(lib().erc_p2p_close(C.c_void_p(ptr_)), "erc_p2p_close")
+
+
+def p2p_free(ptr_):
+    _check(lib().erc_p2p_free(C.c_void_p(ptr_)), "erc_p2p_free")
+
+
+def adam_step_p2p(p, g, m, v, n, lr, b1, b2, eps, wd, decoupled, grad_scale, state, table, x):
+    """x: ErcP2P.  table: ShadowTable or None."""
+    _check(lib().erc_adam_step_p2p(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale, ptr(state),
+                                   ptr(table.buf) if table is not None else None, table.buf.numel() if table is not None else 0,
+                                   table.tab_ptr if table is not None else None, C.addressof(x), stream()), "erc_adam_step_p2p")
 
 
 def health_roll(health, events):

@@ -568,6 +568,7 @@ class COGMENTrainer:
                                decoupled=(o.name == "AdamW"), seed=params.seed)
         self.model.rng_state = self.optim.rng_state   # dropout offset advances with the optimizer step
         self.optim.skip_flag = self.model.flat.health  # (nothing in this step raises it; StepGraphs.precapture's warm-ups do)
+        self.optim.enable_p2p()                        # ERC_DP_P2P=1 under torch.distributed: exchange fused into the optimizer
         if self.model.compute == "bf16" and self.model.enc_train is None:
             self.model.attach_bf16_shadow(self.optim)
         self.class_weight = None

@@ -100,6 +100,38 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __rest
     }
 }
 
+// ---- one-shot gradient exchange fused into the optimizer launch (ERC_DP_P2P=1; SURVEY.md 8e: the latency-class
+//      all-reduce for COGMEN's 1.1 MB of gradients).  Every rank maps every peer's PUBLISH buffer and FLAG array (hipIpc);
+//      workgroup b of a rank owns quads [256 b, 256 b + 256) of the flat gradient:
+//        1. it copies its chunk of the local gradient into the publish buffer of this step's parity (write-through,
+//           system scope), drains, and stores (step << 1 | local health bit) into flags[rank][b] of EVERY rank (one 4-byte
+//           store per peer over xGMI);
+//        2. it polls its LOCAL flags[r][b], r = 0 .. world-1 (bounded; a timeout raises the health word), i.e. it waits for
+//           the same chunk of every peer -- no grid-wide barrier, chunks pipeline;
+//        3. it sums the chunk of all ranks IN RANK ORDER (its own included, read back from the publish buffer): the sum is
+//           bit-identical on every rank; the update follows with grad_scale = 1 / world.
+//      The parity double-buffers the publish area: a peer can only be one step ahead (it needs this rank's flags of step
+//      t + 1 to finish step t + 1), so buffer t & 1 is never rewritten while step t is still being read.  If ANY rank's
+//      health bit is set, every rank skips the update (the collective form of skip_flag).  No extra launch, no RCCL call.
+constexpr int P2P_MAXW = 8;
+struct P2PArgs {
+    int world, rank, spin_limit, pad;
+    float* pub[P2P_MAXW];          // [2][n_pad] floats per rank (this process's mappings; pub[rank] is local memory)
+    int32_t* flags[P2P_MAXW];      // [world][gridDim.x] per rank
+    int64_t* epoch;                // local: one private step counter per workgroup (as state[4 + b])
+    int32_t* health;               // local health word (raised on a poll timeout)
+    int64_t n_pad;
+};
+typedef float p2p_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_sys_x4(float* p, p2p_f4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ p2p_f4 ld_sys_x4(const float* p) {
+    p2p_f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // torch.optim.Adam / AdamW update (torch/optim/adam.py single-tensor path):
 //   g += wd*p (Adam)  |  p *= 1 - lr*wd (AdamW)
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
@@ -110,10 +142,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float grad_scale, float clip_norm,
                                                    const float* __restrict__ gnorm, int64_t* state,
                                                    unsigned short* __restrict__ shadow, const ShadowTab tab,
-                                                   const int32_t* __restrict__ skip_flag) {
+                                                   const int32_t* __restrict__ skip_flag, const P2PArgs p2p) {
+    __shared__ int s_p2p_skip;
     // a producer of this step's gradients (the DAG-ERC recurrence kernels) flagged an exchange timeout: the
     // gradients are invalid -- leave parameters, moments and the step counter untouched (checked on the device, no sync)
-    if (skip_flag && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const int local_skip = (skip_flag && __hip_atomic_load(skip_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1 : 0;
+    if (p2p.world <= 1 && local_skip) return;
     // first quad of this thread: requested before the (dependent, transcendental) bias-correction math
     const int64_t nq = n >> 2;
     const int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -122,6 +156,55 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     if (nq > 0) {  // uniform
         pv = reinterpret_cast<float4*>(p)[q0c], mv = reinterpret_cast<float4*>(m)[q0c], vv = reinterpret_cast<float4*>(v)[q0c];
         gv = reinterpret_cast<const float4*>(g)[q0c];
+    }
+    if (p2p.world > 1) {   // (uniform) the gradient exchange, see P2PArgs; single pass: gridDim.x * 256 >= nq (host contract)
+        const int b = blockIdx.x, nblk = gridDim.x;
+        int64_t* const my_ep = p2p.epoch + b;
+        const int ep = (int)(*my_ep + 1);
+        const int64_t poff = (int64_t)(ep & 1) * p2p.n_pad + 4 * q0c;
+        if (q0 < nq) st_sys_x4(p2p.pub[p2p.rank] + poff, (p2p_f4){gv.x, gv.y, gv.z, gv.w});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if ((int)threadIdx.x < p2p.world) {
+            int32_t* f = nullptr;      // flags array of rank threadIdx.x (selected without indexing the by-value struct dynamically)
+#pragma unroll
+            for (int r = 0; r < P2P_MAXW; ++r)
+                if (r == (int)threadIdx.x) f = p2p.flags[r];
+            __hip_atomic_store(f + p2p.rank * nblk + b, ep * 2 + local_skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // wait for the same chunk of rank threadIdx.x in the LOCAL flag array
+            int32_t* mine = nullptr;
+#pragma unroll
+            for (int r = 0; r < P2P_MAXW; ++r)
+                if (r == p2p.rank) mine = p2p.flags[r];
+            const int32_t* w = mine + (int)threadIdx.x * nblk + b;
+            int val = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), spins = 0;
+            while ((val >> 1) - ep < 0) {
+                if (++spins > p2p.spin_limit) {
+                    __hip_atomic_store(p2p.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    val = 2 * ep + 1;      // give up: this rank skips (its peers time out on their own or see the bit next step)
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                val = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const unsigned long long any = __ballot((val & 1) != 0);
+            if (threadIdx.x == 0) s_p2p_skip = any != 0ull;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) *my_ep = ep;
+        if (s_p2p_skip) return;        // some rank's gradients are invalid: every rank leaves this step out
+        p2p_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        p2p_f4 part[P2P_MAXW];
+#pragma unroll
+        for (int r = 0; r < P2P_MAXW; ++r) part[r] = r < p2p.world ? ld_sys_x4(p2p.pub[r] + poff) : (p2p_f4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int r = 0; r < P2P_MAXW; ++r)
+            if (r < p2p.world) acc += part[r];
+        gv = make_float4(acc.x, acc.y, acc.z, acc.w);
     }
     // Every workgroup keeps its OWN copy of the step count (state[4 + blockIdx.x], all equal between launches): nothing that
     // another workgroup writes is read here, so no arrival counter is needed.  ("The last arriver bumps state[0]" was 274
@@ -263,8 +346,10 @@ static int check_shadow_tab(const ShadowTab& tab, int64_t n, int64_t shadow_nume
 static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                        float weight_decay, int decoupled, float grad_scale, float clip_norm, const float* gnorm,
                        int64_t* state, void* shadow_base, int64_t shadow_numel, const ShadowTab& tab_in,
-                       const int32_t* skip_flag, void* stream) {
+                       const int32_t* skip_flag, void* stream, const P2PArgs* p2p_in = nullptr) {
     ShadowTab tab = tab_in;
+    P2PArgs p2p{};
+    if (p2p_in) p2p = *p2p_in;
     // quad fast path (flags bit 0): every range starts on a quad of the flat buffer and has rows of a multiple of 4
     // elements; bit 1 + t: range t runs along k with k % 4 == 0 for every quad and 8-byte aligned destinations
     tab.flags = tab.n > 0;
@@ -282,10 +367,12 @@ static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, 
     int grid = (int)((n / 4 + 255) / 256);   // one float4 per thread
     if (grid < 1) grid = 1;
     if (grid > 512) grid = 512;  // one arrival atomic per block on a single word: keep the count low
+    ERC_REQUIRE(p2p.world <= 1 || ((int64_t)grid * 256 >= n / 4 && (n & 3) == 0 && clip_norm <= 0.f),
+                "adam_step_p2p: the fused exchange takes n <= 524288 parameters, n %% 4 == 0, no clip-norm (use the RCCL all-reduce)");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                        decoupled, grad_scale, clip_norm, gnorm, state, tab.n > 0 ? (unsigned short*)shadow_base : nullptr, tab,
-                       skip_flag);
+                       skip_flag, p2p);
     ERC_LAUNCH_CHECK("adam_step");
     return ERC_OK;
 }
@@ -348,4 +435,62 @@ extern "C" int erc_grad_norm(const float* g, int64_t n, float grad_scale, float*
     hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(256), 0, st, (const double*)ws, grid, gnorm);
     ERC_LAUNCH_CHECK("grad_norm.final");
     return ERC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Peer-mapped buffers of the fused gradient exchange (P2PArgs above).  erc_p2p_alloc: device memory other processes can
+// map (uncached where the runtime offers it: the flag words and publish buffers are written and read with system-scope
+// accesses only) + its 64-byte IPC handle; erc_p2p_open maps a peer's handle into this process.
+extern "C" int erc_p2p_alloc(int64_t bytes, void** ptr, void* handle64) {
+    ERC_REQUIRE(bytes > 0 && ptr && handle64, "p2p_alloc: bad arguments");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    void* q = nullptr;
+    if (hipExtMallocWithFlags(&q, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        ERC_REQUIRE(hipMalloc(&q, (size_t)bytes) == hipSuccess, "p2p_alloc: %lld bytes refused", (long long)bytes);
+    }
+    ERC_REQUIRE(hipMemset(q, 0, (size_t)bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess, "p2p_alloc: memset failed");
+    hipIpcMemHandle_t h;
+    ERC_REQUIRE(hipIpcGetMemHandle(&h, q) == hipSuccess, "p2p_alloc: hipIpcGetMemHandle failed: %s", hipGetErrorString(hipGetLastError()));
+    memcpy(handle64, &h, 64);
+    *ptr = q;
+    return ERC_OK;
+}
+extern "C" int erc_p2p_open(const void* handle64, void** ptr) {
+    ERC_REQUIRE(handle64 && ptr, "p2p_open: bad arguments");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, 64);
+    ERC_REQUIRE(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess, "p2p_open: hipIpcOpenMemHandle failed: %s",
+                hipGetErrorString(hipGetLastError()));
+    return ERC_OK;
+}
+extern "C" int erc_p2p_close(void* ptr) {
+    ERC_REQUIRE(hipIpcCloseMemHandle(ptr) == hipSuccess, "p2p_close failed");
+    return ERC_OK;
+}
+extern "C" int erc_p2p_free(void* ptr) {
+    ERC_REQUIRE(hipFree(ptr) == hipSuccess, "p2p_free failed");
+    return ERC_OK;
+}
+
+// erc_adam_step_tab with the gradient exchange fused in (ErcP2P in ercgraft.h): g is this rank's LOCAL gradient, the update
+// uses the rank-ordered sum over all ranks times grad_scale; skip_flag must be p2p->health.
+extern "C" int erc_adam_step_p2p(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                 float eps, float weight_decay, int decoupled, float grad_scale, int64_t* state,
+                                 void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host, const ErcP2P* x,
+                                 void* stream) {
+    ERC_REQUIRE(x && x->world >= 2 && x->world <= P2P_MAXW && x->rank >= 0 && x->rank < x->world && x->epoch && x->health &&
+                    x->n_pad >= n && x->n_pad % 4 == 0, "adam_step_p2p: bad exchange descriptor (world <= %d)", P2P_MAXW);
+    ShadowTab tab{};
+    if (tab_host) memcpy(&tab, tab_host, sizeof(tab));
+    ERC_REQUIRE(tab.n == 0 || shadow_base, "adam_step_p2p: shadow table without a shadow buffer");
+    P2PArgs a{};
+    a.world = x->world, a.rank = x->rank, a.spin_limit = x->spin_limit > 0 ? x->spin_limit : 4000000;
+    for (int r = 0; r < x->world; ++r) {
+        ERC_REQUIRE(x->pub[r] && x->flags[r] && ((uintptr_t)x->pub[r] & 15) == 0, "adam_step_p2p: peer %d not mapped", r);
+        a.pub[r] = (float*)x->pub[r], a.flags[r] = (int32_t*)x->flags[r];
+    }
+    a.epoch = (int64_t*)x->epoch, a.health = (int32_t*)x->health, a.n_pad = x->n_pad;
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, 0.f, nullptr, state, shadow_base,
+                       shadow_numel, tab, (const int32_t*)x->health, stream, &a);
 }

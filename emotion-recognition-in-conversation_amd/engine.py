@@ -426,8 +426,24 @@ class FusedAdam:
     def rng_state(self):
         return self.state[1:3]
 
+    def enable_p2p(self, group=None):
+        """ERC_DP_P2P=1 and a process group of >= 2 ranks: fuse the gradient exchange into this optimizer's launch
+        (P2PExchange).  Collective call; returns whether it is on.  Modules with clip-norm or more than 524 288
+        parameters keep the RCCL all-reduce."""
+        import torch.distributed as dist
+        if os.environ.get("ERC_DP_P2P", "0") != "1" or not (dist.is_available() and dist.is_initialized()) or \
+                dist.get_world_size(group) < 2 or self.clip_norm > 0 or self.flat.numel > P2PExchange.MAX_PARAMS:
+            return False
+        self.flat.p2p = P2PExchange(self.flat, group)
+        self.skip_flag = self.flat.health
+        return True
+
     def step(self, grad_scale=1.0):
         f = self.flat
+        if getattr(f, "p2p", None) is not None:
+            capi.adam_step_p2p(f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                               self.weight_decay, self.decoupled, grad_scale, self.state, self.shadow_table, f.p2p.desc)
+            return
         if self.clip_norm > 0:
             capi.grad_norm(f.grad, f.numel, grad_scale, self.gnorm, self.norm_ws)
         if self.shadow_table is not None:
@@ -442,12 +458,57 @@ class FusedAdam:
                        *(self.shadow if self.shadow is not None else (None, 0, 0)), skip_flag=self.skip_flag)
 
 
+class P2PExchange:
+    """ERC_DP_P2P=1: the gradient exchange of a data-parallel step fused into the optimizer launch (csrc/optim.hip, P2PArgs;
+    SURVEY.md 8e).  Construction is collective: every rank allocates its publish buffer and flag array, the 64-byte IPC
+    handles travel through ``torch.distributed.all_gather_object`` (any backend), peers are mapped.  ``FusedAdam.step``
+    then calls erc_adam_step_p2p instead of all-reduce + erc_adam_step: no RCCL call, no extra launch."""
+
+    MAX_PARAMS = 512 * 1024
+
+    def __init__(self, flat, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if self.world > 8 or flat.numel > self.MAX_PARAMS or flat.numel % 4:
+            raise capi.ErcGraftError("P2P gradient exchange: world <= 8 and <= %d parameters (this module: %d)" % (
+                self.MAX_PARAMS, flat.numel))
+        self.n_pad = flat.numel
+        self._mine = [capi.p2p_alloc(2 * self.n_pad * 4), capi.p2p_alloc(self.world * 512 * 4)]
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (self._mine[0][1], self._mine[1][1]), group=group)
+        self._peers = []
+        x = capi.ErcP2P()
+        x.world, x.rank, x.spin_limit, x.n_pad = self.world, self.rank, int(os.environ.get("ERC_P2P_SPIN", 0)), self.n_pad
+        for r in range(self.world):
+            if r == self.rank:
+                x.pub[r], x.flags[r] = self._mine[0][0], self._mine[1][0]
+            else:
+                pp, pf = capi.p2p_open(handles[r][0]), capi.p2p_open(handles[r][1])
+                self._peers += [pp, pf]
+                x.pub[r], x.flags[r] = pp, pf
+        self.epoch = torch.zeros(512, dtype=torch.int64, device=flat.device)
+        x.epoch, x.health = self.epoch.data_ptr(), flat.health.data_ptr()
+        self.desc, self.flat = x, flat
+        dist.barrier(group=group)          # nobody launches before everybody has mapped everybody
+
+    def close(self):
+        for p in self._peers:
+            capi.p2p_close(p)
+        self._peers = []
+        for p, _ in self._mine:
+            capi.p2p_free(p)
+        self._mine = []
+
+
 def all_reduce_grads(flat, always=False):
     """DP exchange step (SURVEY.md 8e): one sum all-reduce of the flat live-gradient buffer;
     the 1/world scaling is folded into the optimizer's grad_scale.  `always` issues the collective on a
     one-rank group too (bench.py --rehearse_dp)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or always):
+        if getattr(flat, "p2p", None) is not None:
+            return 1.0 / dist.get_world_size()      # ERC_DP_P2P=1: the optimizer launch sums the ranks' gradients itself
         dist.all_reduce(flat.grad_full)     # gradients + the health word behind them
         return 1.0 / dist.get_world_size()
     return 1.0

@@ -174,6 +174,18 @@ class StepGraphs:
         self.capture_failed = False
         self.lazy = True           # False (data parallel): only precaptured graphs, everything else eager
 
+    # -- the two places that touch the HIP runtime (a test replaces them with a recorder that, like a real capture, does not
+    #    execute what it records)
+    def _capture(self, fn):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
+    def _sync(self):
+        torch.cuda.synchronize()
+
     @staticmethod
     def shape_key(batch):
         return tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(batch.items()) if torch.is_tensor(v)) + \
@@ -214,13 +226,9 @@ class StepGraphs:
             ent = self.cache[key] = [static, None, None, None, fill, True, 1]
             flat.health.fill_(capi.HEALTH_RAISED)
             self._run(ent, eager=True)
-            flat.health.fill_(capi.HEALTH_RAISED)      # (the step's own roll cleared it and counted an event)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
             model.dynamic_n = True
             try:
-                with torch.cuda.graph(g):
-                    out = tr.train_step(static)
+                g, out = self._capture(lambda: tr.train_step(static))
             finally:
                 model.dynamic_n = False
             ent[1], ent[2], ent[3] = g, out, getattr(model, "_last_ws", None)
@@ -269,12 +277,9 @@ class StepGraphs:
         if self.capture_failed or not self.capture or not (ent[5] or ent[6] >= 2 or resident):
             return stats                                    # plain shapes are captured on their second occurrence
         try:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
             if ent[5]:
                 self.trainer.model.dynamic_n = True
-            with torch.cuda.graph(g):
-                out = self.trainer.train_step(static)
+            g, out = self._capture(lambda: self.trainer.train_step(static))
         except Exception as exc:                               # a step that cannot be captured stays eager
             print(json.dumps({"graph_replay": "capture failed, staying eager", "error": str(exc)[:200]}), file=sys.stderr)
             self.capture_failed = True

@@ -516,6 +516,31 @@ int erc_adam_step_tab(float* p, const float* g, float* m, float* v, int64_t n,
 int erc_shadow_refresh(const float* p, int64_t n, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
                        void* stream);
 
+/* One-shot gradient exchange fused into the optimizer launch (data parallel, latency class: COGMEN's 1.1 MB of gradients;
+ * SURVEY.md 8e; opt-in, ERC_DP_P2P=1 -- the RCCL all-reduce stays the default and the only choice for > 524 288 parameters or
+ * clip-norm).  Every rank allocates a PUBLISH buffer (2 * n_pad floats: two parities) and a FLAG array (world * 512 int32)
+ * with erc_p2p_alloc, exchanges the 64-byte IPC handles out of band and maps its peers' with erc_p2p_open.
+ * erc_adam_step_p2p then replaces all-reduce + erc_adam_step_tab: per 1024-element chunk a workgroup publishes the local
+ * gradient (write-through), posts (step << 1 | health bit) into flags[rank][chunk] of every rank, waits for the same chunk
+ * of every rank in its local flag array (bounded polls; a timeout raises the health word) and applies the update with the
+ * RANK-ORDERED sum (bit-identical on all ranks) times grad_scale.  A set health bit on any rank makes every rank skip the
+ * step.  epoch: device int64 [512], zero-filled once; health: the local health word (also the step's skip flag). */
+typedef struct ErcP2P {
+    int32_t world, rank, spin_limit, pad;
+    void* pub[8];        /* publish buffers of ranks 0 .. world-1 as mapped in THIS process (pub[rank] = the local one) */
+    void* flags[8];      /* flag arrays likewise */
+    void* epoch;
+    void* health;
+    int64_t n_pad;       /* floats per parity of a publish buffer, >= n, multiple of 4 */
+} ErcP2P;
+int erc_p2p_alloc(int64_t bytes, void** ptr, void* handle64);
+int erc_p2p_open(const void* handle64, void** ptr);
+int erc_p2p_close(void* ptr);
+int erc_p2p_free(void* ptr);
+int erc_adam_step_p2p(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int decoupled, float grad_scale, int64_t* state, void* shadow_base,
+                      int64_t shadow_numel, const ErcShadowTab* tab_host, const ErcP2P* x, void* stream);
+
 /* Health word: one device int32 that the persistent kernels with bounded polls (erc_dag_rec_*, erc_gcnii_chain_*: their
  * `health` argument; NULL = use state[0] as before) raise to ERC_HEALTH_RAISED when a poll ran into its bound, i.e. when
  * this step's results are invalid.  The value is the bit pattern of 1.0f: the host side keeps the word in the tail of the

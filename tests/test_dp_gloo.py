@@ -135,3 +135,85 @@ def test_shard_dialogues_properties():
             if n:
                 assert set().union(*map(set, shards)) == set(range(n))
                 assert sum(map(len, shards)) - n < world
+
+
+class _FakeGraph:
+    """stands in for a captured HIP graph: ``capture`` records the step WITHOUT executing it, ``replay`` executes it"""
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def replay(self):
+        self.fn()
+
+
+def _graphs_worker(rank, world, port, q):
+    """Control flow of trainer.StepGraphs under data parallelism (the captured step contains the gradient all-reduce): every
+    rank precaptures all capacity buckets in one order -- each warm-up is a real collective on every rank -- and then walks
+    ITS OWN sequence of batches (different buckets per rank and step, some outside every bucket): the number of
+    collectives per step is 1 on every rank whatever mix of replay / eager the ranks run, and nothing is captured lazily."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from erc_amd.trainer import StepGraphs
+    calls = []
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.bn = torch.nn.BatchNorm1d(3)
+            self.dynamic_n = False
+            self.flat = types.SimpleNamespace(health=torch.zeros(1, dtype=torch.int32), events=torch.zeros(2, dtype=torch.int32))
+
+    class Trainer:
+        model = Model()
+
+        def train_step(self, batch):
+            t = torch.ones(2)
+            dist.all_reduce(t)                       # the step's one collective
+            assert float(t[0]) == world
+            calls.append(int(batch["cap"]))
+            return torch.zeros(4)
+
+        def _mk(self, cap):
+            return (("capacity", cap), (lambda: {"cap": cap, "n": torch.zeros(1)}), (lambda static, b: static["n"].copy_(b["n"])),
+                    (lambda static: None))
+
+        def capacity_bucket(self, batch):
+            cap = -(-int(batch["n"]) // 4) * 4
+            return self._mk(cap)[:3] if cap <= 12 else None
+
+        def all_capacity_buckets(self, probe):
+            return [self._mk(c) for c in (4, 8, 12)]
+
+    class Graphs(StepGraphs):
+        def _capture(self, fn):
+            return _FakeGraph(fn), torch.zeros(4)
+
+        def _sync(self):
+            pass
+
+    tr = Trainer()
+    g = Graphs(tr)
+    g.precapture({"n": torch.tensor([1.0])})
+    g.lazy = False
+    warm = len(calls)
+    sizes = [[3, 9, 30, 5, 12, 1], [11, 2, 7, 40, 4, 8]][rank]            # rank-specific bucket sequences; 30 / 40: no bucket
+    for n in sizes:
+        g.step({"n": torch.tensor([float(n)]), "cap": -1})
+    q.put((rank, warm, len(calls) - warm, g.captures, g.replays, g.eager))
+    dist.destroy_process_group()
+
+
+def test_stepgraphs_data_parallel_control_flow():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graphs_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    # 3 warm-up collectives during precapture, 6 step collectives, 3 graphs, 5 replays + 1 eager (the batch outside every bucket)
+    assert res == [(0, 3, 6, 3, 5, 1), (1, 3, 6, 3, 5, 1)]
