@@ -26,6 +26,7 @@ _SIGS = {
                                       _vp, _i, _vp, _i, _f, _f, _vp, _i, _vp]),
     "erc_gemm_bf16a_stream": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "erc_wgrad_table": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "erc_wgrad_table_x3": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_enc_to_bf16": (C.c_int, [_vp, _i64, _vp, _vp]),
     "erc_enc_gemm_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "erc_enc_attention": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp]),
@@ -816,6 +817,12 @@ def axpy_mask(x, mask, n, scale, accumulate, y):
 
 def clock_probe(out, iters):
     _call("erc_clock_probe", out, iters)
+
+
+def wgrad_table_x3(table, n_desc, item_base, n_items, slabs, counters):
+    """erc_wgrad_table with the three-term bf16 split for records of mode 2"""
+    _check(lib().erc_wgrad_table_x3(ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), stream()),
+           "erc_wgrad_table_x3")
 
 
 def wgrad_table(table, n_desc, item_base, n_items, slabs, counters):

@@ -72,7 +72,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 // consecutive k-steps of its wavefront -- slot j of lane (r, g) holds k-step j's k = 4 ks + g for both operands, which is
 // all the instruction needs (any assignment of k to slots works as long as A and B agree).  16 MFMAs of 16 cycles per 8
 // k-steps instead of 128 of 32 cycles; the accumulator layout, and with it the whole epilogue, is unchanged.
-template <bool ABF, bool BF16, bool VEC, bool MB>
+// MB == 2: fp32-class products on the bf16 matrix cores.  Every fp32 operand value x is split into three bf16 terms
+// x = h + m + l (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): 24 significant bits) and the six cross products of
+// weight >= 2^-16 -- l l', m l' and l m' are below fp32 resolution -- are accumulated in fp32: 6 x 16 cycles per 32 k
+// against 8 x 32 cycles of v_mfma_f32_16x16x4_f32, at fp32-class error (MMGCN's weight gradients ran at 76 % of the fp32
+// matrix peak: the fp32 instruction itself was the ceiling).  Same loads, same accumulator layout, same epilogue.
+template <bool ABF, bool BF16, bool VEC, int MB>
 __device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, float* red, float* bred, int* idx,
                                            int* s_flag, float* slabs, int* counters) {
     const gfloat_cp A = (gfloat_cp)d.A;
@@ -175,7 +180,52 @@ __device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, flo
     // wavefront w takes k-steps ks_begin + w + 4 s; batches of WG_U steps, the next batch's loads issued before
     // the current batch's MFMAs
     const int ns = (max(0, ks_end - ks_begin) + 3) >> 2;
-    if (MB) {
+    if (MB == 2) {
+        auto split3 = [](float x, float& h, float& m, float& l) {
+            h = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xffff0000u);      // truncation: the remainder is exact
+            const float r = x - h;
+            m = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r) & 0xffff0000u);
+            l = r - m;                                                                           // rounded to bf16 when packed
+        };
+        auto hi16 = [](float lo, float hi) -> unsigned {      // two values that already are bf16: take the high halves
+            return (__builtin_bit_cast(unsigned, lo) >> 16) | (__builtin_bit_cast(unsigned, hi) & 0xffff0000u);
+        };
+        for (int s0 = 0; s0 < ns; s0 += 8) {
+            float xa[8][4], xb[8][4], xk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load(ks_begin + w + 4 * (s0 + u), xa[u], xb[u], xk[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 ah[4], am[4], al[4], bh[4], bm[4], bl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    float h0, m0, l0, h1, m1, l1;
+                    const float x0 = xa[2 * dd][i] * xk[2 * dd], x1 = xa[2 * dd + 1][i] * xk[2 * dd + 1];
+                    bsa[i] += x0 + x1;
+                    split3(x0, h0, m0, l0), split3(x1, h1, m1, l1);
+                    ah[i][dd] = hi16(h0, h1), am[i][dd] = hi16(m0, m1), al[i][dd] = pack_bf16x2(l0, l1);
+                    const float y0 = xb[2 * dd][i] * xk[2 * dd], y1 = xb[2 * dd + 1][i] * xk[2 * dd + 1];
+                    bsb[i] += y0 + y1;
+                    split3(y0, h0, m0, l0), split3(y1, h1, m1, l1);
+                    bh[i][dd] = hi16(h0, h1), bm[i][dd] = hi16(m0, m1), bl[i][dd] = pack_bf16x2(l0, l1);
+                }
+            }
+#define ERC_MF(A_, B_) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A_[i]), __builtin_bit_cast(bf16x8, B_[j]), acc[i][j], 0, 0, 0)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {      // small terms first
+                    ERC_MF(al, bh);
+                    ERC_MF(ah, bl);
+                    ERC_MF(am, bm);
+                    ERC_MF(am, bh);
+                    ERC_MF(ah, bm);
+                    ERC_MF(ah, bh);
+                }
+#undef ERC_MF
+        }
+    } else if (MB) {
         // groups of 8 steps = one MFMA per (i, j); loaded four steps at a time (the second half's loads are in flight
         // while the first half is rounded and packed)
         for (int s0 = 0; s0 < ns; s0 += 8) {
@@ -363,13 +413,10 @@ struct WgBases {  // first work item of every descriptor, passed by value (no de
     int v[WG_MAX_DESC];
 };
 
-__global__ __launch_bounds__(256, 3) void wgrad_table_kernel(const WgDesc* __restrict__ table, const int n_desc,
-                                                          const WgBases bases, const int item_offset, float* slabs,
-                                                          int* counters) {
-    __shared__ float red[4 * 2048];
-    __shared__ float bred[4 * 64];
-    __shared__ int idx[WG_IDX_CAP];
-    __shared__ int s_flag;
+template <bool X3>
+__device__ __forceinline__ void wgrad_dispatch(const WgDesc* __restrict__ table, const int n_desc, const WgBases& bases,
+                                               const int item_offset, float* slabs, int* counters, float* red, float* bred, int* idx,
+                                               int* s_flag) {
     const int L = blockIdx.x + item_offset;
     int di = 0;
 #pragma unroll
@@ -379,20 +426,44 @@ __global__ __launch_bounds__(256, 3) void wgrad_table_kernel(const WgDesc* __res
     const int local = L - d.item_base;
     if (local >= d.n_items) return;
     const bool vec = (d.vec & 3) == 3;
-    if (d.mma_bf16) {   // bf16 matrix cores (COGMEN bf16 compute mode); vector access is a host contract there
-        if (d.a_bf16) wgrad_body<true, false, true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else if (d.b_bf16) wgrad_body<false, true, true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<false, false, true, true>(d, local, red, bred, idx, &s_flag, slabs, counters);
+    if (X3 && d.mma_bf16 == 2 && !d.a_bf16 && !d.b_bf16 && vec) {   // fp32 operands, three-term bf16 split
+        wgrad_body<false, false, true, 2>(d, local, red, bred, idx, s_flag, slabs, counters);
+    } else if (d.mma_bf16 == 1) {   // bf16 matrix cores (COGMEN bf16 compute mode); vector access is a host contract there
+        if (d.a_bf16) wgrad_body<true, false, true, 1>(d, local, red, bred, idx, s_flag, slabs, counters);
+        else if (d.b_bf16) wgrad_body<false, true, true, 1>(d, local, red, bred, idx, s_flag, slabs, counters);
+        else wgrad_body<false, false, true, 1>(d, local, red, bred, idx, s_flag, slabs, counters);
     } else if (d.a_bf16) {   // bf16 A with an fp32 B (COGMEN bf16 mode: d[W_r ; W_root] = M^T dH1)
-        if (vec) wgrad_body<true, false, true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<true, false, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        if (vec) wgrad_body<true, false, true, 0>(d, local, red, bred, idx, s_flag, slabs, counters);
+        else wgrad_body<true, false, false, 0>(d, local, red, bred, idx, s_flag, slabs, counters);
     } else if (d.b_bf16) {
-        if (vec) wgrad_body<false, true, true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<false, true, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        if (vec) wgrad_body<false, true, true, 0>(d, local, red, bred, idx, s_flag, slabs, counters);
+        else wgrad_body<false, true, false, 0>(d, local, red, bred, idx, s_flag, slabs, counters);
     } else {
-        if (vec) wgrad_body<false, false, true, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
-        else wgrad_body<false, false, false, false>(d, local, red, bred, idx, &s_flag, slabs, counters);
+        if (vec) wgrad_body<false, false, true, 0>(d, local, red, bred, idx, s_flag, slabs, counters);
+        else wgrad_body<false, false, false, 0>(d, local, red, bred, idx, s_flag, slabs, counters);
     }
+}
+
+__global__ __launch_bounds__(256, 3) void wgrad_table_kernel(const WgDesc* __restrict__ table, const int n_desc,
+                                                          const WgBases bases, const int item_offset, float* slabs,
+                                                          int* counters) {
+    __shared__ float red[4 * 2048];
+    __shared__ float bred[4 * 64];
+    __shared__ int idx[WG_IDX_CAP];
+    __shared__ int s_flag;
+    wgrad_dispatch<false>(table, n_desc, bases, item_offset, slabs, counters, red, bred, idx, &s_flag);
+}
+
+// The same launch with the three-term bf16 split available (records with mma_bf16 == 2): its operand fragments need ~220
+// registers, i.e. two workgroups per CU instead of three.
+__global__ __launch_bounds__(256, 2) void wgrad_table_x3_kernel(const WgDesc* __restrict__ table, const int n_desc,
+                                                             const WgBases bases, const int item_offset, float* slabs,
+                                                             int* counters) {
+    __shared__ float red[4 * 2048];
+    __shared__ float bred[4 * 64];
+    __shared__ int idx[WG_IDX_CAP];
+    __shared__ int s_flag;
+    wgrad_dispatch<true>(table, n_desc, bases, item_offset, slabs, counters, red, bred, idx, &s_flag);
 }
 
 }  // namespace
@@ -402,8 +473,8 @@ extern "C" int erc_wgrad_max_k_per_split(void) { return WG_IDX_CAP; }
 
 // table: n_desc WgDesc records (device memory); item_base: HOST array of the records' item_base fields; n_items = sum of tiles * splits; slabs: n_items * erc_wgrad_slab_floats()
 // floats; counters: one zero-initialised int32 per output tile (left zero by the launch).
-extern "C" int erc_wgrad_table(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
-                               int32_t* counters, void* stream) {
+static int wgrad_table_launch(bool x3, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                              int32_t* counters, void* stream) {
     ERC_REQUIRE(table && item_base && n_desc > 0 && n_items > 0 && slabs && counters, "wgrad_table: bad arguments");
     for (int t = 0; t < n_desc; ++t)
         ERC_REQUIRE(item_base[t] >= 0 && item_base[t] < n_items && (t == 0 ? item_base[0] == 0 : item_base[t] > item_base[t - 1]),
@@ -414,9 +485,24 @@ extern "C" int erc_wgrad_table(const void* table, int n_desc, const int32_t* ite
         WgBases bases{};
         for (int t = 0; t < nd; ++t) bases.v[t] = item_base[t0 + t];
         const int end = t0 + nd < n_desc ? item_base[t0 + nd] : n_items;
-        hipLaunchKernelGGL(wgrad_table_kernel, dim3(end - item_base[t0]), dim3(256), 0, (hipStream_t)stream,
-                           (const WgDesc*)table + t0, nd, bases, item_base[t0], slabs, counters);
+        if (x3)
+            hipLaunchKernelGGL(wgrad_table_x3_kernel, dim3(end - item_base[t0]), dim3(256), 0, (hipStream_t)stream,
+                               (const WgDesc*)table + t0, nd, bases, item_base[t0], slabs, counters);
+        else
+            hipLaunchKernelGGL(wgrad_table_kernel, dim3(end - item_base[t0]), dim3(256), 0, (hipStream_t)stream,
+                               (const WgDesc*)table + t0, nd, bases, item_base[t0], slabs, counters);
         ERC_LAUNCH_CHECK("wgrad_table");
     }
     return ERC_OK;
+}
+
+extern "C" int erc_wgrad_table(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                               int32_t* counters, void* stream) {
+    return wgrad_table_launch(false, table, n_desc, item_base, n_items, slabs, counters, stream);
+}
+// records with mma_bf16 == 2 (fp32 operands, both 16-byte accessible) run as three-term bf16 splits: fp32-class products at
+// ~2x the rate of the fp32 matrix-core instruction; every other record as in erc_wgrad_table
+extern "C" int erc_wgrad_table_x3(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                                  int32_t* counters, void* stream) {
+    return wgrad_table_launch(true, table, n_desc, item_base, n_items, slabs, counters, stream);
 }

@@ -152,12 +152,14 @@ class GemmPlanner:
         self.deferred = []     # (A, lda, B, ldb, C, ldc, M, N, K, ones, bias_out): one batched launch at the end
         self.deferred16 = []   # bf16 compute mode: records of the bf16 weight-gradient launch (defer16)
 
-    mma_bf16 = False   # bf16 compute mode: deferred weight gradients on bf16 matrix cores (operands rounded, fp32 accumulate)
+    # deferred weight gradients: 0 / False = exact fp32 matrix cores; 1 / True = bf16 matrix cores, operands rounded (COGMEN
+    # bf16 compute mode); 2 = three-term bf16 split of fp32 operands (fp32-class results, ~2x the fp32 instruction's rate)
+    mma_bf16 = 0
 
     def defer(self, A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather=None, scale=1.0, mma_bf16=None):
         """C[M,N] = scale * A[K,M]^T B[gather(K),N] (+ bias strip); B may be the bf16 feature block."""
         mb = self.mma_bf16 if mma_bf16 is None else mma_bf16
-        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather, float(scale), bool(mb)))
+        self.deferred.append((A, lda, B, ldb, Cm, ldc, M, N, K, ones, bias_out, gather, float(scale), int(mb)))
 
     WG_STEPS = 64   # k-steps (4 k each) per work item: 16 per wavefront (measured best of 48..128 on COGMEN B=32)
 
@@ -201,7 +203,9 @@ class GemmPlanner:
                     | (4 if (N % 4 == 0 and ldc % 4 == 0 and c.data_ptr() % 16 == 0) else 0)
                 n_it = tm * tn * splits
                 if mb and (vec & 3) != 3:
-                    mb = False      # the bf16 matrix-core path needs vector access to both operands
+                    mb = 0          # the bf16 matrix-core paths need vector access to both operands
+                if mb == 2 and (bf16 or a_bf16):
+                    mb = 0          # the three-term split is for fp32 operands
                 raw.append(struct.pack("<QQQQQ14ifii4x", a.data_ptr(), b.data_ptr(), c.data_ptr(),
                                        bo.data_ptr() if bo is not None else 0, g.data_ptr() if g is not None else 0,
                                        lda, ldb, ldc, M, N, K, ones if bo is not None else 0, int(bf16), splits, tn,
@@ -216,8 +220,10 @@ class GemmPlanner:
             import ctypes
             cache["wgrad_bases"] = (ctypes.c_int32 * len(bases))(*bases)
             cache["wgrad_key"] = key
-        capi.wgrad_table(cache["wgrad_table"], len(self.deferred), cache["wgrad_bases"], cache["wgrad_items"],
-                         cache["wgrad_slabs"], cache["wgrad_counters"])
+            cache["wgrad_x3"] = any(d[13] == 2 for d in self.deferred)
+        (capi.wgrad_table_x3 if cache["wgrad_x3"] else capi.wgrad_table)(
+            cache["wgrad_table"], len(self.deferred), cache["wgrad_bases"], cache["wgrad_items"], cache["wgrad_slabs"],
+            cache["wgrad_counters"])
 
     # ------------------------------------------------------------------ bf16 weight gradients (csrc/wgrad_bf16.hip)
     def defer16(self, A, lda, B, ldb, Cm, ldc, M, N, K, ct=False, bias_a=None, bias_b=None, gather=None, k_dev=None):

@@ -132,6 +132,13 @@ int erc_gemm_f32_stream(const float* A, int lda, int a_kmajor, const int32_t* a_
 int erc_wgrad_table(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
                     int32_t* counters, void* stream);
 int64_t erc_wgrad_slab_floats(void);
+/* erc_wgrad_table with the THREE-TERM BF16 SPLIT available: a record whose mma_bf16 field is 2 (fp32 operands, 16-byte
+ * accessible) multiplies x = h + m + l (three bf16 terms = 24 significant bits per operand value) on
+ * v_mfma_f32_16x16x32_bf16, six cross products accumulated in fp32 -- fp32-class results at ~2x the rate of the exact fp32
+ * matrix-core instruction, which is the ceiling of MMGCN's weight gradients (track_mm/mmgcn_models.py:373-394 under
+ * autograd).  Other records behave as in erc_wgrad_table. */
+int erc_wgrad_table_x3(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                       int32_t* counters, void* stream);
 /* The same for the COGMEN bf16 compute mode (csrc/wgrad_bf16.hip): every record is C = A^T B with A [K, M <= 128] and
  * B [K, N] both K-major and BF16 in memory (B optionally through a row gather), on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation; wave tile 128 x 64, so the wide operand is read once.  Record layout (112 bytes, little endian):

@@ -566,3 +566,32 @@ def test_wgrad_bf16_batched_launch(K):
     pl.flush_wgrads_bf16(cache)                                   # same table, slabs and counters: a second launch
     torch.cuda.synchronize()
     assert all(torch.equal(a, c) for a, (c, *_) in zip(first, want))
+
+
+def test_wgrad_three_term_bf16_split_is_fp32_class():
+    """csrc/wgrad.hip MB == 2 (erc_wgrad_table_x3): fp32 operands split into three bf16 terms each, six cross products on the
+    bf16 matrix cores, fp32 accumulation.  Against float64 the error must be that of an fp32 product (the exact-fp32 path of
+    the same launch is the yardstick), three orders of magnitude below a single bf16 rounding -- on operands whose entries
+    span six decades."""
+    import torch
+    from erc_amd.engine import GemmPlanner
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    K, M, N = 3001, 200, 400
+    A = (torch.randn(K, M, generator=g) * torch.logspace(-3, 3, M)).to(dev)       # column scales 1e-3 .. 1e3
+    B = (torch.randn(K, N, generator=g) * torch.logspace(2, -2, N)).to(dev)
+    ref = A.double().t() @ B.double()
+    errs = {}
+    for mode in (0, 2, 1):
+        pl = GemmPlanner(dev, 64)
+        C = torch.full((M, N), float("nan"), device=dev)
+        bias = torch.full((M,), float("nan"), device=dev)
+        pl.defer(A, M, B, N, C, N, M, N, K, 1, bias, mma_bf16=mode)
+        pl.flush_wgrads({})
+        torch.cuda.synchronize()
+        # error relative to the size of the terms that enter each entry (|A|^T |B|): cancellation does not count against a path
+        scale = A.double().abs().t() @ B.double().abs()
+        errs[mode] = float(((C.double() - ref).abs() / scale).max())
+        assert float((bias.double() - A.double().sum(0)).abs().max()) <= 1e-5 * float(A.double().abs().sum(0).max())
+    assert errs[2] < 4 * max(errs[0], 1e-7), errs          # fp32 class ...
+    assert errs[2] < 1e-6 and errs[1] > 1e-4, errs        # ... not bf16 class
