@@ -390,13 +390,15 @@ def main():
         dom = dominant_kernel(args.module, params, host_batch, batch, trainer, args.kernel_reps) if world == 1 else None
         tag = "%s_%s_b%d_%s" % (PROFILE_ROUND, args.module, args.batch, args.dtype)
         traffic, tsrc = None, None
-        pmc = os.path.join(REPO, "profiles", tag + "_pmc.json")
-        if os.path.exists(pmc):
-            # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-            # this same command (tools/pmc_summary.py; gfx950 correction: read bytes = 2 x FETCH_SIZE)
+        # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+        # command (tools/collect_profiles.sh -> tools/pmc_summary.py; gfx950 correction: read bytes = 2 x FETCH_SIZE): one
+        # summary per kernel of the step, picked by the dominant kernel's name
+        import glob
+        for pmc in sorted(glob.glob(os.path.join(REPO, "profiles", tag + "_*_pmc.json"))):
             with open(pmc) as fh:
                 prec = json.load(fh)
-            if dom is not None and prec.get("kernel_substring", "") in dom["kernel"]:
+            sub = prec.get("kernel_substring", "")
+            if dom is not None and sub and sub in dom["kernel"] and prec.get("hbm_bytes_per_launch"):
                 traffic, tsrc = prec.get("hbm_bytes_per_launch"), os.path.relpath(pmc, REPO)
         roof = {"bound": None, "kernel": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": traffic,
                 "traffic_source": tsrc}
@@ -428,7 +430,7 @@ def main():
         if args.module == "cogmen":
             pr = trainer.model.dominant_kernel_probe(batch, reps=args.kernel_reps)
             ptraffic = None
-            ppmc = os.path.join(REPO, "profiles", tag + "_projection_pmc.json")
+            ppmc = os.path.join(REPO, "profiles", tag + "_project_graph_pmc.json")
             if os.path.exists(ppmc):
                 with open(ppmc) as fh:
                     ptraffic = json.load(fh).get("hbm_bytes_per_launch")

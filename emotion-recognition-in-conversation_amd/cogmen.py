@@ -494,10 +494,18 @@ class COGMENModule(nn.Module):
         pl, g, fp = ws["planner"], ws["g"], self.flat
         F, D = F_HID, self.input_size
         x_bf16 = x.dtype == torch.bfloat16
-        if x_bf16:
+        spk = batch["speaker_tensor"]
+        fusedpg = (self.fuse_project_graph and x_bf16 and self.w1_shadow is not None and self.enc_train is None and spk.dim() == 2
+                   and capi.cogmen_project_graph_ok(D, F, B, D, D))
+        extra = 0
+        if fusedpg:     # what the bf16 step launches: projection + window graph in one kernel (csrc/cogmen_project.hip)
+            launch = lambda: capi.cogmen_project_graph(x, D, self.w1_shadow, D, fp.w("rnn.1.bias"), ws["H0"], F, F, D, lens, spk, B, T,
+                                                       WP, WF, self.n_speakers, N, ws["E"], g)
+            name = "cogmen_project_graph_kernel (input projection, bf16 features, weights resident in registers, + the window graph)"
+            extra = int(g["counts"][1]) * 17 + N * 12 + B * 16      # CSR arrays written, lengths / speakers read
+        elif x_bf16:
             W1 = self.w1_shadow if self.w1_shadow is not None else fp.w("rnn.1.weight")
-            launch = lambda: capi.gemm_bf16a_stream(x, D, g["node_row"], W1, D, ws["H0"], F, N, F, D,
-                                                    bias=fp.w("rnn.1.bias"))
+            launch = lambda: capi.gemm_bf16a_stream(x, D, g["node_row"], W1, D, ws["H0"], F, N, F, D, bias=fp.w("rnn.1.bias"))
             name = ("gemm_bf16a_persist_kernel (input projection, bf16 features, weights resident in registers)"
                     if (self.w1_shadow is not None and N >= 1024) else
                     "gemm_bf16a_stream_kernel<8,%s,6> (input projection, bf16 features)" % (
@@ -508,7 +516,7 @@ class COGMENModule(nn.Module):
             name = "gemm_f32_stream_kernel<0,0,8> (input projection, fp32 features)"
         S = 1
         wbytes = 2 if (x_bf16 and self.w1_shadow is not None) else 4
-        nbytes = N * D * x.element_size() + F * D * wbytes + N * F * 4 + N * 4
+        nbytes = N * D * x.element_size() + F * D * wbytes + N * F * 4 + N * 4 + extra
         for _ in range(10):
             launch()
         torch.cuda.synchronize()

@@ -4,7 +4,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r2 -- python3 $R/bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_fp32_path > $R/gpurun_out/prof_r2.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r3 -- python3 $R/bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_fp32_path > $R/gpurun_out/prof_r3.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- python3 $R/bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_fp32_path --no_graph > $R/gpurun_out/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- python3 $R/bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_fp32_path --no_graph > $R/gpurun_out/pmc_write.log 2>&1 || exit 1
 for m in dagerc dgcn mmgcn; do

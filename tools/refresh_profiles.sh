@@ -5,11 +5,12 @@ set -e
 cd "$(dirname "$0")/.."
 R=${ROUND:-r03}
 T=${R}_cogmen_b32_bf16
-python tools/pmc_summary.py --trace gpurun_out/prof_r2 --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --tag $T --kernel wgrad_table > /dev/null
-cp profiles/${T}_pmc.json profiles/${T}_wgrad_table_pmc.json
-for k in gemm_bf16a_persist:projection cogmen_fwd_tile:cogmen_fwd_tile cogmen_bwd_tile:cogmen_bwd_tile adam_kernel:adam_kernel head_fused:head_fused; do
+python tools/pmc_summary.py --trace gpurun_out/prof_r3 --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --tag $T --kernel wgrad_bf16 > /dev/null
+cp profiles/${T}_pmc.json profiles/${T}_wgrad_bf16_pmc.json
+rm profiles/${T}_pmc.json
+for k in cogmen_project_graph:project_graph cogmen_fwd_tile:cogmen_fwd_tile cogmen_bwd_tile:cogmen_bwd_tile adam_kernel:adam_kernel head_fused:head_fused; do
   kn=${k%%:*}; tg=${k##*:}
-  python tools/pmc_summary.py --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --trace gpurun_out/prof_r2 --tag ${T}_$tg --kernel $kn --out /tmp/pmcs > /dev/null
+  python tools/pmc_summary.py --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --trace gpurun_out/prof_r3 --tag ${T}_$tg --kernel $kn --out /tmp/pmcs > /dev/null
   cp /tmp/pmcs/${T}_${tg}_pmc.json profiles/
 done
 for m in dagerc dgcn mmgcn; do
@@ -36,4 +37,4 @@ key = next((k for k in old if k.startswith("mfma_busy")), key)
 old[key] = dict(sorted(out.items(), key=lambda kv: -kv[1]))
 json.dump(old, open(p, "w"), indent=1)
 PY
-python tools/top_kernels.py gpurun_out/prof_r2 8
+python tools/top_kernels.py gpurun_out/prof_r3 8
