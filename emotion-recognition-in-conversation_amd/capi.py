@@ -89,7 +89,7 @@ _SIGS = {
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "erc_head_fused_part_floats": (C.c_int, []),
-    "erc_head_fused_rows_per_workgroup": (C.c_int, []),
+    "erc_head_fused_rows_per_workgroup": (C.c_int, [_i]),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),
     "erc_lstm_scan_fwd": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _i64, _i64, _i, _i, _vp, _i, _vp, _i, _f, _vp,
@@ -862,8 +862,8 @@ def head_fused_bn(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, 
           label_rows)
 
 
-def head_fused_rows_per_workgroup():
-    return int(lib().erc_head_fused_rows_per_workgroup())
+def head_fused_rows_per_workgroup(n_rows):
+    return int(lib().erc_head_fused_rows_per_workgroup(int(n_rows)))
 
 
 def head_fused_part_floats():

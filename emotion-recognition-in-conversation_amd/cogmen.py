@@ -29,6 +29,8 @@ from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, SideStre
     matmul_wgrad_io
 
 F_HID = 100
+PA = 128              # row pitch (bf16 elements) of the 100-wide weight-gradient operands: 256-byte rows = two full cache lines
+PM = 960              # row pitch of the relation-mean operand M [N, 900]: 1920 bytes = 15 cache lines
 WP = WF = 5           # cogmen.py:153-154
 N_REL = 8             # GNN(n_speakers=2) always: cogmen.py:62-64,114
 
@@ -226,7 +228,7 @@ class COGMENModule(nn.Module):
                  in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
         ws = dict(
             g=g, E=E, fused=True,
-            H0=f32(N, F), Mb=bf(N, 904), inv_cnt=f32(N, N_REL), H1b=bf(N, 104), QKVS=f32(N, 4 * F),
+            H0=f32(N, F), Mb=bf(N, PM), inv_cnt=f32(N, N_REL), H1b=bf(N, PA), QKVS=f32(N, 4 * F),
             alpha=f32(E), H2=f32(N, F), H3=f32(N, F), Z=f32(N, F), logits=f32(N, C),
             bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=torch.zeros(1024, dtype=torch.float32, device=device),
             bn_stats_ws=torch.zeros(capi.bn_batch_stats_ws_floats(F), dtype=torch.float32, device=device),
@@ -235,7 +237,7 @@ class COGMENModule(nn.Module):
             dlogits=f32(N, C), dZ=f32(N, F), dH3=f32(N, F), dQKVS=f32(N, 4 * F), dH1=f32(N, F), dH0=f32(N, F),
             # bf16 operands of the weight-gradient launch (csrc/wgrad_bf16.hip), written by the head / backward tile kernels;
             # zero-filled once: the pad columns are read (into output rows nobody stores) and must stay finite
-            H3b=bf(N, 104), Zb=bf(N, 104), dZb=bf(N, 104), dlb=bf(N, 8), dQKVSb=bf(N, 4 * F), dH1b=bf(N, 104), dH0b=bf(N, 104),
+            H3b=bf(N, PA), Zb=bf(N, PA), dZb=bf(N, PA), dlb=bf(N, 8), dQKVSb=bf(N, 4 * F), dH1b=bf(N, PA), dH0b=bf(N, PA),
         )
         slab = 16 * N * F + 8 * (F * D + 9 * F * F + 4 * F * F + 2 * F * F) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
@@ -270,6 +272,7 @@ class COGMENModule(nn.Module):
         # and one launch gap less than graph build + projection
         project_graph = (self.fuse_project_graph and x_bf16 and self.w1_shadow is not None and self.enc_train is None
                          and speaker_tensor.dim() == (1 if desc is not None else 2) and x.is_contiguous()
+                         and N <= self.BN_FUSED_MAX_N      # beyond: many row groups per workgroup, the separate launches win (B = 512: 45 vs 54 us)
                          and capi.cogmen_project_graph_ok(D, F, B, D, D))
         if desc is not None and not (project_graph and self.dynamic_n):
             raise capi.ErcGraftError("COGMEN resident batches need the fused bf16 training path in capacity mode")
@@ -294,8 +297,8 @@ class COGMENModule(nn.Module):
             # training with the fused head: BatchNorm's batch statistics come out of the same launch
             ws["bn_in_tile"] = bool(upto_h2 and N <= self.BN_FUSED_MAX_N)   # tile sums here, finalised by the head kernel
             capi.cogmen_fwd_tile(ws["H0"], F, N, WP, WF, g, self._sh["catT"], fp.w("gcn.conv1.bias"), self._sh["q"],
-                                 fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], 904, ws["inv_cnt"],
-                                 ws["H1b"], 104, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=2 if ws["bn_in_tile"] else 0,
+                                 fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], PM, ws["inv_cnt"],
+                                 ws["H1b"], PA, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=2 if ws["bn_in_tile"] else 0,
                                  running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum,
                                  eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=self.n_speakers, n_dev=nd)
             if upto_h2:
@@ -360,9 +363,12 @@ class COGMENModule(nn.Module):
         if fused and not fused_head:
             raise capi.ErcGraftError("COGMEN bf16 mode trains through the fused head (C <= 8)")
         # bf16 mode: every weight gradient of the step on the bf16 matrix cores from bf16 operands (csrc/wgrad_bf16.hip)
-        w16 = bool(fused and self.wgrad_bf16 and x_bf16 and C <= 8 and D % 4 == 0 and x.is_contiguous() and x.data_ptr() % 8 == 0)
+        # (N <= 8 192: with several rounds of work items per CU the 64 x 64-tile kernel at three workgroups per CU wins,
+        #  167 vs 181 us at N = 33 k -- wgrad_bf16's 428-register wavefronts leave one workgroup per CU)
+        w16 = bool(fused and self.wgrad_bf16 and x_bf16 and C <= 8 and D % 4 == 0 and x.is_contiguous() and x.data_ptr() % 8 == 0
+                   and N <= self.BN_FUSED_MAX_N)
         ws["w16"] = w16
-        b16 = (ws["H3b"], ws["Zb"], ws["dZb"], ws["dlb"], 104) if w16 else None
+        b16 = (ws["H3b"], ws["Zb"], ws["dZb"], ws["dlb"], PA) if w16 else None
         nd = g["counts"] if self.dynamic_n else None
         if self.dynamic_n and not (w16 and fused_head):
             raise capi.ErcGraftError("COGMEN capacity mode needs the fused bf16 training path (supports_capacity)")
@@ -389,8 +395,8 @@ class COGMENModule(nn.Module):
             capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("cls.3.weight"), F, 1, None, ws["dZ"], F, N, F, C,
                           act=2, aux=ws["Z"], ldaux=F, act_scale=1.0 / (1.0 - p))
         if w16:
-            pl.defer16(ws["Zb"], 104, ws["dlb"], 8, fp.g("cls.3.weight"), F, F, C, N, ct=True, bias_b=fp.g("cls.3.bias"), k_dev=nd)
-            pl.defer16(ws["dZb"], 104, ws["H3b"], 104, fp.g("cls.0.weight"), F, F, F, N, bias_a=fp.g("cls.0.bias"), k_dev=nd)
+            pl.defer16(ws["Zb"], PA, ws["dlb"], 8, fp.g("cls.3.weight"), F, F, C, N, ct=True, bias_b=fp.g("cls.3.bias"), k_dev=nd)
+            pl.defer16(ws["dZb"], PA, ws["H3b"], PA, fp.g("cls.0.weight"), F, F, F, N, bias_a=fp.g("cls.0.bias"), k_dev=nd)
         else:
             with self.side.fork():
                 linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
@@ -447,27 +453,27 @@ class COGMENModule(nn.Module):
         F, D = F_HID, self.input_size
         w16 = ws["w16"]
         nd = g["counts"] if self.dynamic_n else None
-        head_kw = dict(head_part=ws["head_ws"], head_parts=-(-N // capi.head_fused_rows_per_workgroup()), dgamma=fp.g("gcn.bn.weight"), dbeta=fp.g("gcn.bn.bias"),
+        head_kw = dict(head_part=ws["head_ws"], head_parts=-(-N // capi.head_fused_rows_per_workgroup(N)), dgamma=fp.g("gcn.bn.weight"), dbeta=fp.g("gcn.bn.bias"),
                        stats=ws["stats"]) if ws.get("head_deferred") else {}
         bwd_args = (ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["QKVS"],
                     ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F))
         if w16:
             # the three gradients the backward hands to the weight-gradient launch are written as bf16 (nothing else reads them)
-            capi.cogmen_bwd_tile(*bwd_args, ws["dQKVSb"], ws["dH1b"], ws["dH0b"], 104, n_speakers=self.n_speakers,
-                                 grads_bf16=True, lddh1=104, n_dev=nd, **head_kw)
-            pl.defer16(ws["H1b"], 104, ws["dQKVSb"], 4 * F, fp.g("gcn.conv2.lin_query.weight"), F, F, 4 * F, N, ct=True,
+            capi.cogmen_bwd_tile(*bwd_args, ws["dQKVSb"], ws["dH1b"], ws["dH0b"], PA, n_speakers=self.n_speakers,
+                                 grads_bf16=True, lddh1=PA, n_dev=nd, **head_kw)
+            pl.defer16(ws["H1b"], PA, ws["dQKVSb"], 4 * F, fp.g("gcn.conv2.lin_query.weight"), F, F, 4 * F, N, ct=True,
                        bias_b=fp.g("gcn.conv2.lin_query.bias"), k_dev=nd)
-            pl.defer16(ws["dH1b"], 104, ws["Mb"], 904, fp.g("gcn.conv1.weight"), F, F, 9 * F, N, ct=True,
+            pl.defer16(ws["dH1b"], PA, ws["Mb"], PM, fp.g("gcn.conv1.weight"), F, F, 9 * F, N, ct=True,
                        bias_a=fp.g("gcn.conv1.bias"), k_dev=nd)
-            pl.defer16(ws["dH0b"], 104, x, D, fp.g("rnn.1.weight"), D, F, D, N, bias_a=fp.g("rnn.1.bias"), gather=g["node_row"],
+            pl.defer16(ws["dH0b"], PA, x, D, fp.g("rnn.1.weight"), D, F, D, N, bias_a=fp.g("rnn.1.bias"), gather=g["node_row"],
                        k_dev=nd)
             pl.reduce_into(ws, fp.grad)
             return
         capi.cogmen_bwd_tile(*bwd_args, ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers, **head_kw)
         pl.mma_bf16 = self.wgrad_bf16     # these three products on bf16 matrix cores (the head's stay fp32)
-        linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1b"], 104, None, 4 * F, F, N,
+        linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1b"], PA, None, 4 * F, F, N,
                      fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"], defer=True)
-        matmul_wgrad_io(pl, ws["Mb"], 904, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
+        matmul_wgrad_io(pl, ws["Mb"], PM, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
                         fp.offsets["gcn.conv1.bias"], defer=True)
         linear_wgrad(pl, ws["dH0"], F, x, D, g["node_row"], F, D, N, fp.offsets["rnn.1.weight"],
                      fp.offsets["rnn.1.bias"], x_bf16=x_bf16, defer=True)

@@ -19,7 +19,7 @@
 #include "erc_common.h"
 #include <stdlib.h>
 
-extern "C" int erc_head_fused_rows_per_workgroup(void);
+extern "C" int erc_head_fused_rows_per_workgroup(int n_rows);
 
 namespace {
 
@@ -625,15 +625,18 @@ extern "C" int erc_bn_batch_stats(const float* x, int ldx, int N, int F, float* 
     return ERC_OK;
 }
 
-// Rows per workgroup of the fused head: 16 (the default: every one of the 7 column tiles of a row tile has its own wavefront;
-// ceil(n_rows / 16) workgroups and partial records) or 32 (ERC_HEAD_ROWS=32: two row tiles, two column tiles per wavefront).
-extern "C" int erc_head_fused_rows_per_workgroup(void) {
-    static int rows = 0;
-    if (!rows) {
+// Rows per workgroup of the fused head.  16 while the launch is latency-bound (n_rows <= 8192: every one of the 7 column
+// tiles of a row tile has its own wavefront -- the per-wavefront chain is what sets the time there, 16.5 -> 13.1 us of work
+// at 2 000 rows); 32 beyond (two row tiles, two column tiles per wavefront: half the workgroups, W0 staged half as often --
+// 186 -> ~130 us at 33 000 rows).  ERC_HEAD_ROWS=16 / 32 forces one.
+extern "C" int erc_head_fused_rows_per_workgroup(int n_rows) {
+    static int forced = -1;
+    if (forced < 0) {
         const char* e = getenv("ERC_HEAD_ROWS");
-        rows = (e && atoi(e) == 32) ? 32 : 16;
+        forced = e ? atoi(e) : 0;
     }
-    return rows;
+    if (forced == 16 || forced == 32) return forced;
+    return n_rows <= 8192 ? 16 : 32;
 }
 extern "C" int64_t erc_head_fused_ws_floats(int n_rows) { return (int64_t)erc_cdiv(n_rows, 16) * HF_PART + 16; }
 
@@ -674,7 +677,7 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     p.H3b = (unsigned short*)H3b, p.Zb = (unsigned short*)Zb, p.dZb = (unsigned short*)dZb, p.dlb = (unsigned short*)dlb, p.ldb16 = ldb16;
     p.n_dev = n_dev, p.label_rows = label_rows;
     p.stamps = g_head_stamps;
-    const int rpw = erc_head_fused_rows_per_workgroup() / 16;
+    const int rpw = erc_head_fused_rows_per_workgroup(n_rows) / 16;
     const int grid = erc_cdiv(n_rows, 16 * rpw);
     p.part = ws;
     p.counter = reinterpret_cast<int*>(ws + (int64_t)grid * HF_PART);

@@ -371,11 +371,12 @@ int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const 
                       float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, const int32_t* n_dev,
                       const int32_t* label_rows, void* stream);
 /* floats per workgroup record of erc_head_fused's workspace: [0,112) column sums of dY, [112,224) of dY * xhat, [224] loss
- * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / erc_head_fused_rows_per_workgroup()) records */
+ * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / erc_head_fused_rows_per_workgroup(n_rows)) records */
 int erc_head_fused_part_floats(void);
-/* rows per workgroup (= per partial record) of erc_head_fused{,_bn}: 16, or 32 with ERC_HEAD_ROWS=32; the consumer of the
- * deferred records (erc_cogmen_bwd_tile) is told ceil(n_rows / this) records */
-int erc_head_fused_rows_per_workgroup(void);
+/* rows per workgroup (= per partial record) of erc_head_fused{,_bn} at n_rows rows: 16 up to 8 192 rows, 32 beyond
+ * (ERC_HEAD_ROWS=16 / 32 forces one); the consumer of the deferred records (erc_cogmen_bwd_tile) is told
+ * ceil(n_rows / this) records */
+int erc_head_fused_rows_per_workgroup(int n_rows);
 
 /* diagnostic: 8 x uint64 phase stamps (10 ns ticks) of the middle workgroup of the following erc_head_fused[_bn] launches;
  * NULL switches them off (tools/cogmen_stamps.py) */

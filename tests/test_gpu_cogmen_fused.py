@@ -53,7 +53,7 @@ def test_fused_kernels_stagewise(case, n_spk):
     rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
     capi.poison_lds()
     capi.cogmen_fwd_tile(H0, F, N, WP, WF, g, m._sh["catT"], fp.w("gcn.conv1.bias"), m._sh["q"],
-                         fp.w("gcn.conv2.lin_query.bias"), scale, ws["Mb"], 904, ws["inv_cnt"], ws["H1b"], 104, ws["QKVS"],
+                         fp.w("gcn.conv2.lin_query.bias"), scale, ws["Mb"], ws["Mb"].shape[1], ws["inv_cnt"], ws["H1b"], ws["H1b"].shape[1], ws["QKVS"],
                          ws["H2"], F, ws["alpha"], bn_fused=True, running_mean=bn.running_mean, running_var=bn.running_var,
                          momentum=bn.momentum, eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=n_spk)
     # ---- relation means: the fp32 kernel's result rounded to bf16.  The fused kernel divides by rcp + one Newton step and,
