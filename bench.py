@@ -326,6 +326,8 @@ def main():
         # behind the last weight-gradient kernel); ERC_DP_EAGER=1 keeps the exchange and the optimizer outside the graph
         # (the round-1 structure) for comparison
         trainer.model.train()
+        if hasattr(trainer.model, "fused_optim"):
+            trainer.model.fused_optim = None      # N > 1 structure: the optimizer is its own launch behind the exchange
         cw = getattr(trainer, "class_weight", None)
         dead_encoder = getattr(trainer, "encoder", None)            # --faithful_dead_encoder
         trained_encoder = getattr(trainer.model, "enc_train", None)  # --chained_encoder

@@ -53,6 +53,8 @@ _SIGS = {
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _i,
                                     _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "erc_wgrad_bf16_adam": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp,
+                                      _i64, _vp, _vp, _vp]),
     "erc_wgrad_bf16_slab_floats": (C.c_int64, []),
     "erc_wgrad_bf16_set_stamps": (C.c_int, [_vp, _i]),
     "erc_wgrad_bf16_max_k_per_split": (C.c_int, []),
@@ -939,6 +941,16 @@ def enc_inverse_rows(node_row, N, inv, n_rows):
 def wgrad_bf16(table, n_desc, item_base, n_items, slabs, counters):
     """item_base: ctypes int32 array (host) of the descriptors' first work items (csrc/wgrad_bf16.hip)"""
     _check(lib().erc_wgrad_bf16(ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), stream()), "erc_wgrad_bf16")
+
+
+def wgrad_bf16_adam(table, n_desc, item_base, n_items, slabs, counters, n_tiles, p, g, m, v, n, lr, b1, b2, eps, wd, decoupled,
+                    grad_scale, state, shadow_table, health):
+    """erc_wgrad_bf16 with the optimizer fused in (ercgraft.h)"""
+    st = shadow_table
+    _check(lib().erc_wgrad_bf16_adam(ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), int(n_tiles), ptr(p), ptr(g),
+                                     ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale, ptr(state),
+                                     ptr(st.buf) if st is not None else None, st.buf.numel() if st is not None else 0,
+                                     st.tab_ptr if st is not None else None, ptr(health), stream()), "erc_wgrad_bf16_adam")
 
 
 def wgrad_bf16_set_stamps(t, item=0):

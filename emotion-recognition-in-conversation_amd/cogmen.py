@@ -101,6 +101,8 @@ class COGMENModule(nn.Module):
         # projection launch writes it to g["counts"][0] and every later kernel of the step reads it there (n_dev / k_dev),
         # so ONE captured HIP graph serves every batch that fits the bucket.  bf16 fused path only (supports_capacity).
         self.dynamic_n = False
+        # set by the trainer: a FusedAdam whose step the bf16 weight-gradient launch applies itself (single-rank steps)
+        self.fused_optim = None
         self.flat = None
         self._ws = WorkspaceCache()
         self._seed = seed
@@ -467,6 +469,12 @@ class COGMENModule(nn.Module):
                        bias_a=fp.g("gcn.conv1.bias"), k_dev=nd)
             pl.defer16(ws["dH0b"], PA, x, D, fp.g("rnn.1.weight"), D, F, D, N, bias_a=fp.g("rnn.1.bias"), gather=g["node_row"],
                        k_dev=nd)
+            # BatchNorm's scale / shift gradients were completed by the backward tile launch: with the optimizer fused into
+            # the weight-gradient launch, one of its work items updates them
+            o_g, o_b = fp.offsets["gcn.bn.weight"], fp.offsets["gcn.bn.bias"]
+            pl.defer16_range(fp.grad[o_g:o_g + F])
+            pl.defer16_range(fp.grad[o_b:o_b + F])
+            pl.fused_adam = self.fused_optim
             pl.reduce_into(ws, fp.grad)
             return
         capi.cogmen_bwd_tile(*bwd_args, ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers, **head_kw)
@@ -583,6 +591,9 @@ class COGMENTrainer:
         self.model.rng_state = self.optim.rng_state   # dropout offset advances with the optimizer step
         self.optim.skip_flag = self.model.flat.health  # (nothing in this step raises it; StepGraphs.precapture's warm-ups do)
         self.optim.enable_p2p()                        # ERC_DP_P2P=1 under torch.distributed: exchange fused into the optimizer
+        import os
+        if os.environ.get("ERC_FUSE_ADAM", "1") != "0" and self.model.enc_train is None:
+            self.model.fused_optim = self.optim        # single rank, bf16 mode: the optimizer rides in the weight-gradient launch
         if self.model.compute == "bf16" and self.model.enc_train is None:
             self.model.attach_bf16_shadow(self.optim)
         self.class_weight = None
@@ -682,6 +693,8 @@ class COGMENTrainer:
         if self.encoder is not None:
             self.encoder.forward(batch["input_tensor"])      # dead work, result discarded (cogmen.py:146-147)
         stats = self.model.loss_and_grads(batch, self.class_weight)
+        if self.model._last_ws["planner"].adam_fused:      # the weight-gradient launch applied the update (no optimizer launch)
+            return stats
         scale = all_reduce_grads(self.model.flat)
         self.optim.step(grad_scale=scale)
         if self.model.enc_train is not None:

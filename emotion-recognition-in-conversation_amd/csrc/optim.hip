@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "erc_common.h"
+#include "optim_dev.h"
 
 static thread_local char g_err[512] = "";
 
@@ -17,78 +18,6 @@ extern "C" const char* erc_last_error(void) { return g_err; }
 extern "C" int erc_abi_version(void) { return ERC_ABI_VERSION; }
 
 namespace {
-
-// bf16 shadow copies of parameter ranges (operands of the bf16 matrix-core products), written by the optimizer
-// kernel itself so that no extra launch keeps them in sync.  Element i of [src_off, src_off + n_el) of the flat
-// buffer, idx = i - src_off, is split into digits d0 = idx % n0, d1 = (idx / n0) % n1, d2 = idx / (n0 n1); the digits
-// give the element's coordinates in the LOGICAL B operand of its product, n = sum d_i sn_i (output column) and
-// k = sum d_i sk_i (reduction index), and the layout places it:
-//   mode 0: shadow[dst_off + n * ld + k]                                   (row-major [n][k]: identity copies)
-//   mode 1: the fragment order of v_mfma_f32_16x16x32_bf16's B operand, ld = number of 32-deep K blocks: the 512
-//           elements of (column tile n / 16, K block k / 32) are contiguous, lane (r = n % 16, g = (k % 32) / 8) at
-//           [(g * 16 + r) * 8, +8) -- a wavefront's fragment load is ONE contiguous 1 KB run (8 full cache lines;
-//           the row-major layout cost 16 half-used lines per load and the L1 miss path, not bytes, set the time).
-struct ShadowDesc {
-    int64_t src_off, n_el, dst_off;
-    int32_t n0, n1, sn0, sn1, sn2, sk0, sk1, sk2, ld, mode;
-};
-constexpr int SHADOW_MAX = 8;
-struct ShadowTab {
-    int32_t n, flags;
-    ShadowDesc d[SHADOW_MAX];
-};
-
-__device__ __forceinline__ int64_t shadow_dst(const ShadowDesc& d, int32_t n, int32_t k) {
-    if (d.mode == 0) return d.dst_off + (int64_t)n * d.ld + k;
-    return d.dst_off + ((((int64_t)(n >> 4) * d.ld + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) << 3) + (k & 7);
-}
-__device__ __forceinline__ unsigned short f2bf_u16(float f) {
-    const __bf16 h = (__bf16)f;
-    return __builtin_bit_cast(unsigned short, h);
-}
-
-// Four consecutive elements (i0 % 4 == 0) at once: with src_off, n0 multiples of 4 (checked by the host; the flat buffer
-// aligns every group to 64 floats) they share d1 and d2, so one index decomposition serves the quad, and when they run
-// along k (sn0 = 0, sk0 = 1, k % 4 == 0) the four bf16 are one 8-byte store in either layout.
-__device__ __forceinline__ void shadow_store4(unsigned short* __restrict__ shadow, const ShadowTab& tab, int64_t i0, float4 pn) {
-#pragma unroll
-    for (int t = 0; t < SHADOW_MAX; ++t) {
-        if (t < tab.n) {
-            const ShadowDesc& d = tab.d[t];
-            const int64_t idx = i0 - d.src_off;
-            if (idx >= 0 && idx < d.n_el) {
-                const int32_t x = (int32_t)idx;
-                const int32_t q = x / d.n0, d0 = x - q * d.n0, d2 = q / d.n1, d1 = q - d2 * d.n1;
-                const int32_t n = d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, k = d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2;
-                const unsigned short h0 = f2bf_u16(pn.x), h1 = f2bf_u16(pn.y), h2 = f2bf_u16(pn.z), h3 = f2bf_u16(pn.w);
-                if (d.sn0 == 0 && d.sk0 == 1 && (tab.flags & (2 << t))) {   // flag: k % 4 == 0 and 8-byte aligned destinations
-                    *reinterpret_cast<uint2*>(shadow + shadow_dst(d, n, k)) =
-                        make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
-                } else {
-                    shadow[shadow_dst(d, n, k)] = h0;
-                    shadow[shadow_dst(d, n + d.sn0, k + d.sk0)] = h1;
-                    shadow[shadow_dst(d, n + 2 * d.sn0, k + 2 * d.sk0)] = h2;
-                    shadow[shadow_dst(d, n + 3 * d.sn0, k + 3 * d.sk0)] = h3;
-                }
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void shadow_store(unsigned short* __restrict__ shadow, const ShadowTab& tab, int64_t i, float pn) {
-#pragma unroll
-    for (int t = 0; t < SHADOW_MAX; ++t) {
-        if (t < tab.n) {
-            const ShadowDesc& d = tab.d[t];
-            const int64_t idx = i - d.src_off;
-            if (idx >= 0 && idx < d.n_el) {
-                const int32_t x = (int32_t)idx;
-                const int32_t q = x / d.n0, d0 = x - q * d.n0, d2 = q / d.n1, d1 = q - d2 * d.n1;
-                shadow[shadow_dst(d, d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2)] = f2bf_u16(pn);
-            }
-        }
-    }
-}
 
 __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __restrict__ p, unsigned short* __restrict__ shadow,
                                                              const ShadowTab tab) {
@@ -124,7 +53,10 @@ struct P2PArgs {
 };
 typedef float p2p_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_sys_x4(float* p, p2p_f4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    // (s_nop: a store of more than 64 bits needs wait states before its data registers may be overwritten, and the compiler's
+    //  hazard recognizer does not look inside an asm statement -- without them a v_cndmask scheduled right behind the store
+    //  replaced the last dword of lanes 12-15 of every 16: finding 44)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ p2p_f4 ld_sys_x4(const float* p) {
     p2p_f4 v;
@@ -211,23 +143,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     // atomics on one word at the tail of the launch: 2.3 us of 10.)
     int64_t* my_step = state + 4 + blockIdx.x;
     const int64_t step = *my_step + 1;
-    const float bc1 = 1.0f - powf(b1, (float)step);
-    const float bc2 = 1.0f - powf(b2, (float)step);
-    const float step_size = lr / bc1;
-    const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
     float gs = grad_scale;
     if (clip_norm > 0.f) {
         const float coef = clip_norm / (gnorm[0] + 1e-6f);
         if (coef < 1.f) gs *= coef;
     }
-    const float decay = decoupled ? 1.0f - lr * wd : 1.0f, l2 = decoupled ? 0.f : wd;
-    auto update = [&](float& pi, float gi, float& mi, float& vi) {
-        pi *= decay;
-        gi = gi * gs + l2 * pi;
-        mi = b1 * mi + (1.f - b1) * gi;
-        vi = b2 * vi + (1.f - b2) * gi * gi;
-        pi = pi - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
-    };
+    AdamCoef ac;
+    ac.init(lr, b1, b2, eps, wd, decoupled, gs, step);
+    auto update = [&](float& pi, float gi, float& mi, float& vi) { ac.upd(pi, gi, mi, vi); };
     const bool quad_ok = tab.flags & 1;          // host: every range starts on a quad, n0 % 4 == 0, n_el % 4 == 0
     auto to_shadow = [&](int64_t i, float pn) {  // bf16 copies for the bf16 matrix-core products
         if (shadow) shadow_store(shadow, tab, i, pn);
@@ -260,6 +183,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             state[1] += 1;    // RNG offset: a fresh dropout mask next step
         }
     }
+    // the private copies no workgroup of THIS launch owns (a launch with another grid -- the weight-gradient launch with the
+    // optimizer fused in, csrc/wgrad_bf16.hip -- may own them next time)
+    if (blockIdx.x == 0)
+        for (int t = gridDim.x + threadIdx.x; t < 512; t += 256) state[4 + t] = step;
 }
 
 // Start of a training step: a health word still raised from the previous step (its update was skipped) is counted as an

@@ -26,6 +26,8 @@
 // tiles through a slab with write-through stores + an arrival counter; the last arriver adds them in split order): no
 // float atomics, bit-reproducible.
 #include "erc_common.h"
+#include "optim_dev.h"
+#include <string.h>
 
 namespace {
 
@@ -49,7 +51,30 @@ struct W2Desc {  // 112 bytes; mirrored by engine.GemmPlanner.flush_wgrads_bf16 
     const int32_t* k_dev;     // capacity mode: the true K lives on the device (K below = the capacity the splits are cut for), or null
     int lda, ldb, ldc, M, N, K;
     int ct, cvec, splits, tiles_n, item_base, n_items, tile_base;   // cvec: 16-byte stores of C are legal
-    int pad0;
+    int kind;                 // 0: product record; 1 (fused optimizer only): plain range -- C[0, M) are finished gradients written
+                              // by an earlier launch (BatchNorm's scale / shift): one work item applies the update to them
+};
+
+// THE OPTIMIZER INSIDE THIS LAUNCH (wgrad_bf16_kernel<true>; single-rank steps).  A first version let the LAST ARRIVER of a
+// tile apply Adam to the whole 128 x 64 tile it had just summed: 48 us -- the update of 280 k parameters (index decomposition
+// for five bf16 shadow layouts per quad) ran on the 47 CUs that happened to arrive last instead of on 274 workgroups.  Here
+// the final reduction is a REDUCE-SCATTER: every split of a tile publishes its partial tile, waits until all S splits of
+// the tile have (monotonic per-tile counter against S x the launch sequence number; bounded; every item of the launch is
+// resident: the host admits <= 256), and then finishes the quads x with x % S == its split index -- sums them over the S
+// slabs in split order, writes the gradient and applies torch.optim.Adam / AdamW to the same elements of the flat
+// parameter / moment buffers (same layout as the gradient), bf16 shadows included.  The update is spread over all work items,
+// the slab sums over S times as many threads, and the optimizer launch (9.8 us + a launch gap of a 96 us step) is gone.
+// Every workgroup keeps private copies of the step count (state[4 + b], as adam_kernel) and of the launch sequence number.
+struct W2Adam {
+    int decoupled, pad;
+    float lr, b1, b2, eps, wd, grad_scale;
+    float *data, *grad, *m, *v;
+    int64_t* state;
+    unsigned short* shadow;
+    const int32_t* skip;
+    int32_t* seq;          // [512] private launch sequence numbers
+    int32_t* health;       // raised when the wait for a tile's splits times out
+    ShadowTab tab;
 };
 static_assert(sizeof(W2Desc) == 112, "W2Desc layout");
 
@@ -58,7 +83,10 @@ __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p
 // 16-byte write-through store / cache-bypassing load of a slab quad (sc0 sc1 = system scope: the partial tiles cross XCDs,
 // whose L2s are not coherent with each other).  The compiler does not count inline-asm loads: the caller waits (vmcnt).
 __device__ __forceinline__ void st_sc1_x4(float* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+    // (s_nop: a store of more than 64 bits needs wait states before its data registers may be overwritten, and the compiler's
+    //  hazard recognizer does not look inside an asm statement -- without them a v_cndmask scheduled right behind the store
+    //  replaced the last dword of lanes 12-15 of every 16: finding 44)
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ f32x4 ld_sc1_x4(const float* p) {
     f32x4 v;
@@ -78,10 +106,107 @@ __device__ __forceinline__ unsigned perm_hi(unsigned x, unsigned y) { return __b
         if (stamps && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memrealtime();        \
     } while (0)
 
+template <bool ADAM>
 __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float* red, float* bred, int* idx, int* s_flag,
-                                        float* slabs, int* counters, uint64_t* stamps_item, uint64_t* stamps_tile) {
+                                        float* slabs, int* counters, uint64_t* stamps_item, uint64_t* stamps_tile, const W2Adam& ad) {
     uint64_t* stamps = stamps_item;
     W2_STAMP(0);
+    // fused optimizer: the step's skip decision and this workgroup's private step count, requested before the K loop
+    bool adam_on = false;
+    int64_t adam_step = 0;
+    AdamCoef ac;
+    if (ADAM && d.kind == 1) {
+        const bool skip = ad.skip && __hip_atomic_load(ad.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        adam_step = ad.state[4 + blockIdx.x] + 1;
+        adam_on = !skip;
+        ac.init(ad.lr, ad.b1, ad.b2, ad.eps, ad.wd, ad.decoupled, ad.grad_scale, adam_step);
+    }
+    // (the counts are WRITTEN behind a workgroup barrier: a wavefront that starts late must not read a bumped value)
+    auto bump_step = [&]() __attribute__((always_inline)) {
+        if (!ADAM || !adam_on) return;
+        if (threadIdx.x == 0) {
+            ad.state[4 + blockIdx.x] = adam_step;
+            if (blockIdx.x == 0) ad.state[0] = adam_step, ad.state[1] += 1;     // nobody reads them during this launch
+        }
+        if (blockIdx.x == 0)                                                    // the copies no workgroup of this launch owns
+            for (int t = gridDim.x + threadIdx.x; t < 512; t += 256) ad.state[4 + t] = adam_step;
+    };
+    // one finished gradient quad at flat offset `off`: the update of the same four elements of data / m / v + their shadows
+    // the shadow table is read from an LDS copy (the reduction buffer is free by then): as a kernel argument its 130 words
+    // were held in SGPRs across the whole kernel (~700 spilled)
+    const ShadowTab& stab = *reinterpret_cast<const ShadowTab*>(red);
+    auto copy_tab = [&]() __attribute__((always_inline)) {
+        ShadowTab* const wt = reinterpret_cast<ShadowTab*>(red);
+        wt->n = ad.tab.n, wt->flags = ad.tab.flags;
+#pragma unroll
+        for (int t = 0; t < SHADOW_MAX; ++t) {      // (field by field: a struct assignment goes through a private copy)
+            const ShadowDesc& a = ad.tab.d[t];
+            ShadowDesc& b = wt->d[t];
+            b.src_off = a.src_off, b.n_el = a.n_el, b.dst_off = a.dst_off, b.n0 = a.n0, b.n1 = a.n1, b.sn0 = a.sn0, b.sn1 = a.sn1;
+            b.sn2 = a.sn2, b.sk0 = a.sk0, b.sk1 = a.sk1, b.sk2 = a.sk2, b.ld = a.ld, b.mode = a.mode;
+        }
+    };
+    auto adam_quad = [&](const int64_t off, const f32x4 gq, const f32x4 pq, const f32x4 mq, const f32x4 vq) __attribute__((always_inline)) -> float4 {
+        float4 pv = make_float4(pq.x, pq.y, pq.z, pq.w), mv = make_float4(mq.x, mq.y, mq.z, mq.w), vv = make_float4(vq.x, vq.y, vq.z, vq.w);
+        ac.upd(pv.x, gq.x, mv.x, vv.x), ac.upd(pv.y, gq.y, mv.y, vv.y), ac.upd(pv.z, gq.z, mv.z, vv.z), ac.upd(pv.w, gq.w, mv.w, vv.w);
+        *(ERC_GLOBAL f32x4*)(ad.data + off) = (f32x4){pv.x, pv.y, pv.z, pv.w};
+        *(ERC_GLOBAL f32x4*)(ad.m + off) = (f32x4){mv.x, mv.y, mv.z, mv.w}, *(ERC_GLOBAL f32x4*)(ad.v + off) = (f32x4){vv.x, vv.y, vv.z, vv.w};
+        return pv;
+    };
+    // the bf16 shadows of up to 8 updated quads: ONE pass over the table's descriptors (read from the LDS copy, not unrolled)
+    auto shadow_quads = [&](const int64_t (&offs)[8], const float4 (&pn)[8], const int count, const bool (&isq)[8], const unsigned tmask) __attribute__((always_inline)) {
+        if (!ad.shadow) return;
+        const bool quads = (stab.flags & 1) != 0;
+        const int nt = stab.n;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            if (o >= count || !isq[o]) continue;
+            const int64_t i0 = offs[o];
+            const float4 pv = pn[o];
+#pragma unroll 1
+            for (int t = 0; t < nt; ++t) {
+                if (!((tmask >> t) & 1)) continue;      // (uniform) ranges that do not meet this record's gradient
+                const ShadowDesc& sd = stab.d[t];
+                if (quads) {
+                    shadow_store4_desc(ad.shadow, sd, (stab.flags & (2 << t)) != 0, i0, pv);
+                } else {
+                    shadow_store_desc(ad.shadow, sd, i0, pv.x), shadow_store_desc(ad.shadow, sd, i0 + 1, pv.y);
+                    shadow_store_desc(ad.shadow, sd, i0 + 2, pv.z), shadow_store_desc(ad.shadow, sd, i0 + 3, pv.w);
+                }
+            }
+        }
+    };
+    auto adam_one = [&](const int64_t off, const float gval) __attribute__((always_inline)) {
+        float pv = ad.data[off], mv = ad.m[off], vv = ad.v[off];
+        ac.upd(pv, gval, mv, vv);
+        ad.data[off] = pv, ad.m[off] = mv, ad.v[off] = vv;
+        if (ad.shadow) {
+            const int nt = stab.n;
+#pragma unroll 1
+            for (int t = 0; t < nt; ++t) shadow_store_desc(ad.shadow, stab.d[t], off, pv);
+        }
+    };
+    if (ADAM && d.kind == 1) {   // plain range of finished gradients: d.C[0, M)
+        if (threadIdx.x == 64) copy_tab();
+        __syncthreads();
+        bump_step();
+        if (adam_on) {
+            const int64_t base = d.C - ad.grad;
+            for (int e = 4 * (int)threadIdx.x; e < d.M; e += 1024) {
+                if (e + 3 < d.M && ((base + e) & 3) == 0) {
+                    int64_t offs[8] = {base + e};
+                    float4 pn[8];
+                    const bool isq[8] = {true};
+                    pn[0] = adam_quad(base + e, *(const ERC_GLOBAL f32x4*)(d.C + e), *(const ERC_GLOBAL f32x4*)(ad.data + base + e),
+                                      *(const ERC_GLOBAL f32x4*)(ad.m + base + e), *(const ERC_GLOBAL f32x4*)(ad.v + base + e));
+                    shadow_quads(offs, pn, 1, isq, ~0u);
+                } else {
+                    for (int t = e; t < min(e + 4, d.M); ++t) adam_one(base + t, d.C[t]);
+                }
+            }
+        }
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
     const int split = local % d.splits, tn = local / d.splits;
     const int n0 = tn * 64;
@@ -238,8 +363,22 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     //        ct == 0: pass h = rows i in {2 h, 2 h + 1}, float4 over j       -> 16 bytes along n of C[m][n]
     //        ct == 1: pass h = column j = h, float4 over i in {4 a .. 4 a + 3} -> 16 bytes along m of C[n][m]
     float* const slab = slabs + (int64_t)(d.item_base + local) * W2_SLAB;
-    const bool direct = d.splits == 1;
+    const bool direct = !ADAM && d.splits == 1;      // (the fused-optimizer kernel always goes through the slab)
     const bool ct = d.ct != 0;
+    // where quad (f4, h) of the tile goes: offset into C of its first element, and how many of its four elements
+    // (consecutive in memory) exist
+    auto quad_addr = [&](const int f4, const int h, int& valid) __attribute__((always_inline)) -> int64_t {
+        const int il = f4 >> 8, q = (f4 >> 6) & 3, ln = f4 & 63;
+        const int rp = 4 * (ln >> 4) + q;
+        if (!ct) {
+            const int m = 8 * rp + 2 * h + il, n = n0 + 4 * (ln & 15);
+            valid = (m < d.M && n < d.N) ? min(4, d.N - n) : 0;
+            return (int64_t)m * d.ldc + n;
+        }
+        const int m = 8 * rp + 4 * il, n = n0 + 4 * (ln & 15) + h;
+        valid = (m < d.M && n < d.N) ? min(4, d.M - m) : 0;
+        return (int64_t)n * d.ldc + m;
+    };
     auto store_c = [&](const int f4, const int h, const f32x4 v) {
         const int il = f4 >> 8, q = (f4 >> 6) & 3, ln = f4 & 63;
         const int rp = 4 * (ln >> 4) + q;
@@ -314,6 +453,159 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     }
     W2_STAMP(3);
     if (direct) return;
+    if (ADAM) {
+        // ---- reduce-scatter among the S splits of the tile (see W2Adam).  S is a power of two <= 8 (host): this split owns
+        // the 8 / S quads x = split + S o of every thread, i.e. exactly 8 slab quads to fetch per thread.
+        const int S = d.splits, lgS = 31 - __builtin_clz(S), owned = 8 >> lgS;
+        const int64_t cbase = d.C - ad.grad;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this split's partial tile is in memory
+        __syncthreads();
+        W2_STAMP(4);
+        int* const counter = counters + d.tile_base + tn;
+        int seq = 0;
+        if (tid == 0) {
+            seq = ad.seq[blockIdx.x] + 1;
+            ad.seq[blockIdx.x] = seq;
+            __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 64) copy_tab();
+        // while the other splits finish: this split's parameter / moment quads (they do not depend on anybody)
+        int64_t off[8];
+        int valid[8];
+        f32x4 pq[8], mq[8], vq[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int x = split + (o << lgS);
+            valid[o] = 0;
+            off[o] = cbase;
+            if (o < owned) {
+                int vl;
+                const int64_t a = cbase + quad_addr(tid + 256 * (x & 1), x >> 1, vl);
+                valid[o] = (vl == 4 && d.cvec) ? 4 : -vl;       // > 0: one aligned quad; < 0: that many single elements
+                if (vl) off[o] = a;
+                const int64_t oc = valid[o] == 4 ? a : cbase;   // (unconditional loads)
+                pq[o] = *(const ERC_GLOBAL f32x4*)(ad.data + oc), mq[o] = *(const ERC_GLOBAL f32x4*)(ad.m + oc), vq[o] = *(const ERC_GLOBAL f32x4*)(ad.v + oc);
+            }
+        }
+        // (split 0: the bias strip element of this thread, its parameter and moments)
+        float* bdst = nullptr;
+        if (split == 0 && tid < 192) {
+            if (tid < 128) {
+                if (want_a && tid < d.M) bdst = d.bias_a + tid;
+            } else if (want_b && n0 + tid - 128 < d.N) {
+                bdst = d.bias_b + (n0 + tid - 128);
+            }
+        }
+        const int64_t boff = bdst ? bdst - ad.grad : cbase;
+        float bp = ad.data[boff], bm = ad.m[boff], bv = ad.v[boff];
+        const bool skip = ad.skip && __hip_atomic_load(ad.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        adam_step = ad.state[4 + blockIdx.x] + 1;
+        adam_on = !skip;
+        ac.init(ad.lr, ad.b1, ad.b2, ad.eps, ad.wd, ad.decoupled, ad.grad_scale, adam_step);
+        if (tid == 0) {
+            int ok = 1, spins = 0;
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - S * seq < 0) {
+                if (++spins > 2000000) {      // a split of this tile never arrived: this step's gradients are invalid
+                    __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            *s_flag = ok;
+        }
+        __syncthreads();
+        W2_STAMP(5);
+        bump_step();                    // (every thread read the step count in front of the barriers)
+        if (!*s_flag) return;
+        stamps = stamps_tile ? stamps_tile : stamps;
+        W2_STAMP(8);
+        const float* const tile_slabs = slabs + (int64_t)(d.item_base + tn * S) * W2_SLAB;
+        f32x4 part[8];      // load L: owned quad o = L / S, slab j = L % S
+#pragma unroll
+        for (int L = 0; L < 8; ++L) {
+            const int x = split + ((L >> lgS) << lgS), jx = L & (S - 1);
+            part[L] = ld_sc1_x4(tile_slabs + (int64_t)jx * W2_SLAB + (x * 256 + tid) * 4);
+        }
+        float bt[8];      // the bias strip's S partial sums (slots >= S re-read the last slab and are masked)
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) bt[jj] = split == 0 ? ld_sc1(tile_slabs + (int64_t)min(jj, S - 1) * W2_SLAB + 8192 + (tid < 192 ? tid : 0)) : 0.f;
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7])
+                     :
+                     : "memory");
+        // the sums in split order (the left fold of the last arriver above: bit-identical gradients)
+        const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 res[8];
+        if (S == 1) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) res[o] = z + part[o];
+        } else if (S == 2) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) res[o] = o < 4 ? (z + part[2 * (o & 3)]) + part[2 * (o & 3) + 1] : z;
+        } else if (S == 4) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) res[o] = o < 2 ? (((z + part[4 * (o & 1)]) + part[4 * (o & 1) + 1]) + part[4 * (o & 1) + 2]) + part[4 * (o & 1) + 3] : z;
+        } else {
+            res[0] = (((((((z + part[0]) + part[1]) + part[2]) + part[3]) + part[4]) + part[5]) + part[6]) + part[7];
+#pragma unroll
+            for (int o = 1; o < 8; ++o) res[o] = z;
+        }
+        W2_STAMP(9);
+        const bool upd = adam_on;
+        unsigned tmask = 0;      // shadow ranges that meet this record's gradient [cbase, cbase + rows * ldc)
+        {
+            const int64_t lo = cbase, hi = cbase + (int64_t)(ct ? d.N : d.M) * d.ldc;
+            const int nt = stab.n;
+            for (int t = 0; t < nt; ++t)
+                if (stab.d[t].src_off < hi && stab.d[t].src_off + stab.d[t].n_el > lo) tmask |= 1u << t;
+        }
+        // One copy of the update code, executed `owned` times on element 0 of the register arrays, which are shifted down
+        // after every pass (8 unrolled copies with scalar fallbacks were 24 000 instructions of cold code: the instruction
+        // fetch, not the arithmetic, set the 4.3 us this phase took).  Quads are all-or-nothing here: the host only fuses
+        // records whose rows are multiples of 4 elements and 16-byte aligned.
+#pragma unroll 1
+        for (int it = 0; it < owned; ++it) {
+            if (valid[0] == 4) {
+                *(ERC_GLOBAL f32x4*)(ad.grad + off[0]) = res[0];
+                if (upd) {
+                    const float4 pv = adam_quad(off[0], res[0], pq[0], mq[0], vq[0]);
+                    if (it == 0) W2_STAMP(13);
+                    if (ad.shadow) {
+                        const int nt = stab.n;
+#pragma unroll 1
+                        for (int t = 0; t < nt; ++t) {
+                            if (!((tmask >> t) & 1)) continue;
+                            shadow_store4_desc(ad.shadow, stab.d[t], (stab.flags & (2 << t)) != 0, off[0], pv);
+                        }
+                    }
+                }
+            } else if (valid[0] != 0) {      // (a record the host should not have fused)
+                __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (it < 2) W2_STAMP(11 + it);
+#pragma unroll
+            for (int o = 0; o < 7; ++o)
+                res[o] = res[o + 1], pq[o] = pq[o + 1], mq[o] = mq[o + 1], vq[o] = vq[o + 1], off[o] = off[o + 1], valid[o] = valid[o + 1];
+        }
+        if (bdst) {      // bias strips: split 0 of the tile
+            float v = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) v += bt[jj] * (jj < S ? 1.f : 0.f);
+            *(ERC_GLOBAL float*)bdst = v;
+            if (upd) {
+                ac.upd(bp, v, bm, bv);
+                ad.data[boff] = bp, ad.m[boff] = bm, ad.v[boff] = bv;
+                if (ad.shadow) {
+                    const int nt = stab.n;
+#pragma unroll 1
+                    for (int t = 0; t < nt; ++t) shadow_store_desc(ad.shadow, stab.d[t], boff, bp);
+                }
+            }
+        }
+        W2_STAMP(10);
+        return;
+    }
 
     // ---- publish the partial tile; the workgroup that arrives last adds the slabs in split order
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -386,8 +678,9 @@ struct W2Bases {  // first work item of every descriptor, passed by value (no de
     int v[W2_MAX_DESC];
 };
 
+template <bool ADAM>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const W2Desc* __restrict__ table, const int n_desc, const W2Bases bases,
-                                                         float* slabs, int* counters, uint64_t* stamps, int stamp_item) {
+                                                         float* slabs, int* counters, uint64_t* stamps, int stamp_item, const W2Adam ad) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4096];   // 64 KB: two reduction passes
     __shared__ float bred[4 * 192];
     __shared__ int idx[W2_IDX_CAP];
@@ -402,7 +695,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const W2Desc* __restric
     if (local >= d.n_items) return;
     // (stamp_item is a work item of record 0)
     const bool st_item = stamps && L == stamp_item, st_tile = stamps && di == 0 && local / d.splits == stamp_item / d.splits;
-    w2_body(d, local, red, bred, idx, &s_flag, slabs, counters, st_item ? stamps : nullptr, st_tile ? stamps : nullptr);
+    w2_body<ADAM>(d, local, red, bred, idx, &s_flag, slabs, counters, st_item ? stamps : nullptr, st_tile ? stamps : nullptr, ad);
 }
 
 }  // namespace
@@ -420,8 +713,8 @@ extern "C" int erc_wgrad_bf16_max_k_per_split(void) { return W2_IDX_CAP; }
 // table: n_desc W2Desc records (device memory, <= 16); item_base: HOST array of the records' item_base fields; n_items = sum
 // of tiles * splits; slabs: n_items * erc_wgrad_bf16_slab_floats() floats; counters: one zero-initialised int32 per output
 // tile (left zero by the launch).
-extern "C" int erc_wgrad_bf16(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
-                              int32_t* counters, void* stream) {
+static int w2_launch(bool adam, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs, int32_t* counters,
+                     const W2Adam& ad, void* stream) {
     ERC_REQUIRE(table && item_base && n_desc > 0 && n_desc <= W2_MAX_DESC && n_items > 0 && slabs && counters,
                 "wgrad_bf16: bad arguments (at most %d records per launch)", W2_MAX_DESC);
     W2Bases bases{};
@@ -430,8 +723,55 @@ extern "C" int erc_wgrad_bf16(const void* table, int n_desc, const int32_t* item
                     "wgrad_bf16: item_base[%d] = %d", t, item_base[t]);
         bases.v[t] = item_base[t];
     }
-    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc, bases,
-                       slabs, counters, g_w2_stamps, g_w2_stamp_item);
+    if (adam)
+        hipLaunchKernelGGL(wgrad_bf16_kernel<true>, dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc, bases,
+                           slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
+    else
+        hipLaunchKernelGGL(wgrad_bf16_kernel<false>, dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc, bases,
+                           slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
     ERC_LAUNCH_CHECK("wgrad_bf16");
     return ERC_OK;
+}
+
+extern "C" int erc_wgrad_bf16(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                              int32_t* counters, void* stream) {
+    W2Adam ad{};
+    return w2_launch(false, table, n_desc, item_base, n_items, slabs, counters, ad, stream);
+}
+
+// erc_wgrad_bf16 with the optimizer fused in (W2Adam above): every record's C / bias_a / bias_b must point into g[0, n);
+// the same offsets of p / m / v receive torch.optim.Adam's (decoupled != 0: AdamW's) update with the finished gradient
+// times grad_scale, the bf16 shadows of the table follow.  Records of kind 1 name ranges of g that an earlier launch
+// completed.  counters: one int32 per output tile + 512 (the private launch sequence numbers), zero-filled ONCE and owned
+// by this entry point (the per-tile counters count up monotonically here).  n_items <= 256: every work item resident.
+extern "C" int erc_wgrad_bf16_adam(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                                   int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                                   int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
+                                   int32_t* health, void* stream) {
+    static_assert(sizeof(ShadowTab) == sizeof(ErcShadowTab), "shadow table layout");
+    ERC_REQUIRE(p && g && m && v && state && health && n > 0 && n_tiles >= 0 && n_items <= 256,
+                "wgrad_bf16_adam: bad arguments (at most 256 work items: all of them must be resident)");
+    ERC_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "wgrad_bf16_adam: 16-byte alignment");
+    W2Adam ad{};
+    ad.decoupled = decoupled, ad.lr = lr, ad.b1 = beta1, ad.b2 = beta2, ad.eps = eps, ad.wd = weight_decay;
+    ad.grad_scale = grad_scale, ad.data = p, ad.grad = g, ad.m = m, ad.v = v, ad.state = state, ad.skip = health, ad.health = health;
+    ad.seq = counters + n_tiles;
+    if (tab_host) memcpy(&ad.tab, tab_host, sizeof(ad.tab));
+    ERC_REQUIRE(ad.tab.n == 0 || shadow_base, "wgrad_bf16_adam: shadow table without a shadow buffer");
+    ERC_REQUIRE(ad.tab.n >= 0 && ad.tab.n <= SHADOW_MAX, "wgrad_bf16_adam: %d shadow descriptors", ad.tab.n);
+    // the quad fast path flags of erc_adam_step_tab (bit 0: every range on quads; bit 1 + t: range t runs along k)
+    ad.tab.flags = ad.tab.n > 0;
+    for (int t = 0; t < ad.tab.n; ++t) {
+        const ShadowDesc& d = ad.tab.d[t];
+        ERC_REQUIRE(d.src_off >= 0 && d.n_el > 0 && d.src_off + d.n_el <= n && d.n0 > 0 && d.n1 > 0 && d.ld > 0,
+                    "wgrad_bf16_adam: shadow descriptor %d out of range", t);
+        if (d.src_off % 4 || d.n0 % 4 || d.n_el % 4) ad.tab.flags &= ~1;
+        const bool kq = d.sn0 == 0 && d.sk0 == 1 && d.sk1 % 4 == 0 && d.sk2 % 4 == 0 && d.dst_off % 4 == 0 &&
+                        (d.mode == 1 || d.ld % 4 == 0) && ((uintptr_t)shadow_base & 7) == 0;
+        if (kq) ad.tab.flags |= 2 << t;
+    }
+    (void)shadow_numel;     // (bounds-checked against the buffer by erc_shadow_refresh / erc_adam_step_tab when the table was built)
+    ad.shadow = ad.tab.n > 0 ? (unsigned short*)shadow_base : nullptr;
+    return w2_launch(true, table, n_desc, item_base, n_items, slabs, counters, ad, stream);
 }

@@ -151,6 +151,8 @@ class GemmPlanner:
         self.max_numel = 0
         self.deferred = []     # (A, lda, B, ldb, C, ldc, M, N, K, ones, bias_out): one batched launch at the end
         self.deferred16 = []   # bf16 compute mode: records of the bf16 weight-gradient launch (defer16)
+        self.ranges16 = []     # ... and finished gradient ranges its fused optimizer has to cover (defer16_range)
+        self.adam_fused = False
 
     # deferred weight gradients: 0 / False = exact fp32 matrix cores; 1 / True = bf16 matrix cores, operands rounded (COGMEN
     # bf16 compute mode); 2 = three-term bf16 split of fp32 operands (fp32-class results, ~2x the fp32 instruction's rate)
@@ -236,14 +238,27 @@ class GemmPlanner:
             raise capi.ErcGraftError("bf16 wgrad: M=%d lda=%d N=%d ldb=%d unsupported" % (M, lda, N, ldb))
         self.deferred16.append((A, lda, B, ldb, Cm, ldc, M, N, K, bool(ct), bias_a, bias_b, gather, k_dev))
 
+    def defer16_range(self, g_range):
+        """fused optimizer only: ``g_range`` (a slice of the flat gradient) was completed by an earlier launch of the step;
+        one work item of the weight-gradient launch applies the update to it"""
+        self.ranges16.append(g_range)
+
+    fused_adam = None     # a FusedAdam: its update is applied by the bf16 weight-gradient launch itself (single-rank steps)
+
     def flush_wgrads_bf16(self, cache):
-        """Every record of defer16 as ONE launch (erc_wgrad_bf16); table, slabs and counters are built once per shape."""
+        """Every record of defer16 as ONE launch (erc_wgrad_bf16); table, slabs and counters are built once per shape.
+        With ``fused_adam`` set (and nothing it cannot do: clip-norm, a single identity shadow, a gradient exchange) the
+        launch also applies the optimizer step -- ``adam_fused`` tells the trainer to skip ``optim.step()``."""
         if not self.deferred16:
             return
+        opt = self.fused_adam
+        fuse = opt is not None and opt.clip_norm <= 0 and opt.shadow is None and getattr(opt.flat, "p2p", None) is None and \
+            _world_size() == 1 and opt.flat.grad is self.grad
         import ctypes
         import struct
         key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, ct, g.data_ptr() if g is not None else 0,
-                     kd.data_ptr() if kd is not None else 0) for a, _, b, _, c, _, M, N, K, ct, _, _, g, kd in self.deferred16)
+                     kd.data_ptr() if kd is not None else 0) for a, _, b, _, c, _, M, N, K, ct, _, _, g, kd in self.deferred16) + \
+            ((tuple((r.data_ptr(), r.numel()) for r in self.ranges16), ) if fuse else ())
         if cache.get("w16_key") != key:
             cap = capi.wgrad_bf16_max_k_per_split()
             tiles = sum(-(-d[7] // 64) for d in self.deferred16)
@@ -257,7 +272,7 @@ class GemmPlanner:
             groups = lambda sp: -(-(-(-(-(-K // 4) // sp) // 4)) // 8)
             splits = min(range(1, s_max + 1), key=lambda sp: (groups(sp), sp))
             splits = max(splits, min(32, -(-K // rows)), -(-K // cap))
-            raw, items, n_tiles, bases = [], 0, 0, []
+            raw, items, n_tiles, bases, sps, whole_quads = [], 0, 0, [], set(), True
             for a, lda, b, ldb, c, ldc, M, N, Kr, ct, ba, bb, g, kd in self.deferred16:
                 nks = -(-Kr // 4)
                 per = -(-nks // splits)
@@ -271,17 +286,39 @@ class GemmPlanner:
                                        g.data_ptr() if g is not None else 0, kd.data_ptr() if kd is not None else 0,
                                        lda, ldb, ldc, M, N, Kr, int(ct), cvec, sp, tn, items, tn * sp, n_tiles, 0))
                 bases.append(items)
+                sps.add(sp)
+                whole_quads = whole_quads and bool(cvec) and (M if ct else N) % 4 == 0
                 items += tn * sp
                 n_tiles += tn
+            # the fused optimizer needs every work item resident at once (its splits wait for each other), split counts
+            # that divide a thread's 8 quads, and gradients made of whole aligned quads
+            fused = fuse and items + len(self.ranges16) <= 256 and sps <= {1, 2, 4, 8} and whole_quads
+            if fused:     # finished gradient ranges (kind 1): one work item each
+                for r in self.ranges16:
+                    raw.append(struct.pack("<QQQQQQQ14i", 0, 0, r.data_ptr(), 0, 0, 0, 0, 0, 0, 0, r.numel(), 0, 0, 0, 0, 1, 1,
+                                           items, 1, n_tiles, 1))
+                    bases.append(items)
+                    items += 1
+            cache["w16_fused"] = fused
+            cache["w16_tiles"] = n_tiles
+            cache["w16_records"] = len(raw)
             # (the table is a small host -> device copy made OUTSIDE any stream capture: trainer.StepGraphs runs the first
             #  step of a shape on the graph's own static buffers before it captures)
             cache["w16_table"] = torch.frombuffer(bytearray(b"".join(raw)), dtype=torch.uint8).to(self.device)
             cache["w16_slabs"] = torch.empty(items * capi.wgrad_bf16_slab_floats(), dtype=torch.float32, device=self.device)
-            cache["w16_counters"] = torch.zeros(n_tiles, dtype=torch.int32, device=self.device)
+            cache["w16_counters"] = torch.zeros(n_tiles + 512, dtype=torch.int32, device=self.device)
             cache["w16_items"] = items
             cache["w16_bases"] = (ctypes.c_int32 * len(bases))(*bases)
             cache["w16_key"] = key
-        capi.wgrad_bf16(cache["w16_table"], len(self.deferred16), cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
+        if fuse and cache["w16_fused"]:
+            f = opt.flat
+            capi.wgrad_bf16_adam(cache["w16_table"], cache["w16_records"], cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
+                                 cache["w16_counters"], cache["w16_tiles"], f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, opt.lr, opt.betas[0],
+                                 opt.betas[1], opt.eps, opt.weight_decay, opt.decoupled, 1.0, opt.state, opt.shadow_table,
+                                 opt.skip_flag)
+            self.adam_fused = True
+            return
+        capi.wgrad_bf16(cache["w16_table"], cache["w16_records"], cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
                         cache["w16_counters"])
 
     def split_for(self, M, N, K, bk=None, min_chunks=None):

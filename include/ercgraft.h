@@ -143,7 +143,7 @@ int erc_wgrad_table_x3(const void* table, int n_desc, const int32_t* item_base, 
  * B [K, N] both K-major and BF16 in memory (B optionally through a row gather), on v_mfma_f32_16x16x32_bf16 with fp32
  * accumulation; wave tile 128 x 64, so the wide operand is read once.  Record layout (112 bytes, little endian):
  *   u64 A, B, C, bias_a, bias_b, b_gather, k_dev; i32 lda, ldb, ldc, M, N, K, ct, cvec, splits, tiles_n, item_base, n_items,
- *   tile_base, 0
+ *   tile_base, kind
  * k_dev (or 0): device int32 holding the true K <= K (capacity mode, see erc_cogmen_bwd_tile): rows beyond it are masked;
  * ct != 0 stores C transposed (C[n * ldc + m]); bias_a [M] / bias_b [N] = fp32 column sums of the operand values over k (or
  * NULL); lda % 8 == 0 and ldb % 4 == 0 with finite pad columns up to 8 ceil(M / 8) resp. 4 ceil(N / 4); tiles_n =
@@ -548,6 +548,23 @@ int erc_p2p_free(void* ptr);
 int erc_adam_step_p2p(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                       float weight_decay, int decoupled, float grad_scale, int64_t* state, void* shadow_base,
                       int64_t shadow_numel, const ErcShadowTab* tab_host, const ErcP2P* x, void* stream);
+
+/* The same launch WITH THE OPTIMIZER INSIDE (single-rank steps; `optim.step()` of track_mm/cogmen.py:189 disappears as a
+ * launch).  The last reduction of a tile becomes a reduce-scatter among its S splits: every split publishes its partial
+ * tile, waits (bounded; `health` is raised on a timeout) until all S have, and finishes the quads x with x % S == its index:
+ * sums them in split order, writes the gradient and applies torch.optim.Adam / AdamW to the same elements of p / m / v
+ * (flat buffers with the layout of g; every record's C / bias_a / bias_b must point into g[0, n)), bf16 shadows of the table
+ * included.  A record of kind 1 (splits = tiles_n = n_items = 1) names a range C[0, M) of g that an EARLIER launch completed
+ * (BatchNorm's scale / shift).  counters: n_tiles + 512 int32, zero-filled once and then owned by this entry point (tile
+ * counters count up monotonically; the tail holds per-workgroup launch sequence numbers: always launch the SAME table
+ * with it).  `health` doubles as erc_adam_step_tab's skip_flag.  state / grad_scale / the shadow table as
+ * erc_adam_step_tab; at most 256 work items (all of them resident); every record's split count a power of two <= 8, its C
+ * 16-byte aligned with ldc % 4 == 0 and rows of whole quads (N % 4 == 0; M % 4 == 0 for ct records) -- a record that breaks
+ * this raises `health`; no clip-norm. */
+int erc_wgrad_bf16_adam(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs, int32_t* counters,
+                        int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int decoupled, float grad_scale, int64_t* state, void* shadow_base,
+                        int64_t shadow_numel, const ErcShadowTab* tab_host, int32_t* health, void* stream);
 
 /* Health word: one device int32 that the persistent kernels with bounded polls (erc_dag_rec_*, erc_gcnii_chain_*: their
  * `health` argument; NULL = use state[0] as before) raise to ERC_HEALTH_RAISED when a poll ran into its bound, i.e. when

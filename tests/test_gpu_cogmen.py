@@ -504,3 +504,37 @@ def test_resident_epochs_equal_the_collated_loop():
     assert r_ep[2]["graphs_captured"] <= 8 and r_ep[2]["graph_replays"] + r_ep[2]["eager_steps"] == 18
     assert r_ep[2]["eager_steps"] == r_ep[2]["graphs_captured"]
     assert [x["test"]["acc"] for x in r_ep] == [x["test"]["acc"] for x in c_ep]
+
+
+def test_optimizer_fused_into_the_weight_gradient_launch_equals_the_separate_launch():
+    """COGMEN bf16, one rank: the weight-gradient launch's last arrivers apply Adam themselves (csrc/wgrad_bf16.hip W2Adam; no
+    optimizer launch).  Same gradients, same element-wise update: parameters, both moments, the bf16 shadows, the step count
+    and the dropout offset are BIT-IDENTICAL to the step with the separate optimizer launch, over several steps with
+    dropout on; a raised health word skips the fused update as it skips the separate one."""
+    from erc_amd import capi
+    from erc_amd.cogmen import COGMENTrainer
+    from erc_amd.params import ERCParams
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        p = ERCParams().from_args(["--dataset=iemocap-cogmen-sbert-6", "--compute=bf16", "--optim.lr=0.003", "--optim.weight_decay=1e-4"])
+        tr = COGMENTrainer(p, "cuda:0")
+        assert tr.model.fused_optim is tr.optim
+        if not fused:
+            tr.model.fused_optim = None
+        losses = []
+        for step in range(4):
+            b = tr.prepare_batch(cogmen_case(B=7, min_len=4, max_len=33, dims=dict(a=100, t=768, v=512), seed=30 + step)["batch"])
+            if step == 2:
+                tr.model.flat.health.fill_(capi.HEALTH_RAISED)     # this step's update must be skipped either way
+            losses.append(float(tr.train_step(b).cpu()[0]))
+            assert tr.model._last_ws["planner"].adam_fused == fused
+            tr.model.flat.health.zero_()
+        f = tr.model.flat
+        outs.append((losses, f.data.clone(), f.exp_avg.clone(), f.exp_avg_sq.clone(), tr.model.shadows.buf.clone(),
+                     tr.optim.state[:2].clone(), tr.optim.state[4:].clone()))
+    a, b = outs
+    assert a[0] == b[0]
+    for x, y in zip(a[1:], b[1:]):
+        assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)
+    assert int(a[5][0]) == 3 and bool((a[6] == 3).all())          # 4 steps, one skipped; every private step copy agrees

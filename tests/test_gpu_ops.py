@@ -422,7 +422,8 @@ def test_fused_adam_matches_torch(capi, decoupled, wd, clip):
         _close(p, ref.detach(), 2e-6, 1e-5)
     st = state.cpu().tolist()
     n_wg = (n // 4 + 255) // 256
-    assert st[:4] == [4, 4, 1, 0] and st[4:4 + n_wg] == [4] * n_wg and not any(st[4 + n_wg:])
+    # state[4 ..): the workgroups' private copies of the step count, ALL kept current (a launch with another grid owns others)
+    assert st[:4] == [4, 4, 1, 0] and st[4:] == [4] * 512 and n_wg < 512
 
 
 @pytest.mark.parametrize("C,weighted,p", [(6, True, 0.5), (7, False, 0.0), (4, True, 0.0)])

@@ -29,10 +29,11 @@ def main():
     tr.train_step(batch)
     rec = capi.stop_recording()
     torch.cuda.synchronize()
-    call = [e for e in rec if e[0] == "erc_wgrad_bf16"][0]
+    call = [e for e in rec if e[0] in ("erc_wgrad_bf16", "erc_wgrad_bf16_adam")][0]
+    print(call[0])
     n_items = call[1][3]
     labels = ["first loads issued (A, gather stage, B)", "K loop", "LDS reduce + slab stores issued", "slab drained", "arrival ticket"]
-    for item in (0, 2, n_items // 2):
+    for item in (0, 1, 2, 3, n_items // 2):
         st = torch.zeros(16, dtype=torch.int64, device="cuda:0")
         capi.wgrad_bf16_set_stamps(st, item)
         acc = torch.zeros(16, dtype=torch.float64)
@@ -50,7 +51,10 @@ def main():
             v = float(acc[k + 1])
             print("   %-42s %6.2f us   (at %6.2f)" % (lab, (v - prev) * 0.01, v * 0.01))
             prev = v
-        if item < call[1][1] * 0 + 64:
+        if call[0].endswith("adam"):
+            print("   fused optimizer: all splits arrived %6.2f, slabs summed %6.2f, quad 0 updated %6.2f, + shadows %6.2f, quad 1 %6.2f, bias strip %6.2f" % tuple(
+                float(acc[k]) * 0.01 for k in (8, 9, 13, 11, 12, 10)))
+        elif item < call[1][1] * 0 + 64:
             print("   last arriver of the tile: starts at %6.2f, slabs summed at %6.2f, stored at %6.2f" % (
                 float(acc[8]) * 0.01, float(acc[9]) * 0.01, float(acc[10]) * 0.01))
 
