@@ -86,6 +86,12 @@ def _probe_candidates(module, params, host_batch, trainer):
                  (bf if fused and trainer.model.wgrad_bf16 else f32p),
                  "erc_wgrad_bf16": ("wgrad_bf16_kernel (every weight gradient of the step from bf16 operands, one launch)", fl,
                                     wg_bytes) + bf,
+                 # the same launch with the optimizer fused in: + parameters and both moments read and written once, the bf16
+                 # shadows written once
+                 "erc_wgrad_bf16_adam": ("wgrad_bf16_kernel<adam> (every weight gradient of the step from bf16 operands + the "
+                                         "Adam update of every parameter, one launch)", fl,
+                                         wg_bytes + trainer.model.flat.numel * 24.0 +
+                                         (trainer.model.shadows.buf.numel() * 2.0 if trainer.model.shadows is not None else 0.0)) + bf,
                  # BatchNorm apply, two 100 x 100 products forward + one backward, the C-wide products on the VALU
                  "erc_head_fused": ("head_fused_kernel (BatchNorm apply .. cross entropy .. dY, one launch)",
                                     N * (3 * 2.0 * 100 * 100 + 4.0 * 100 * C), head_b) + f32p,

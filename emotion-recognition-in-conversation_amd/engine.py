@@ -270,7 +270,10 @@ class GemmPlanner:
             # a wavefront works in groups of 8 k-steps (32 k): among the split counts that fit, the smallest one with the
             # fewest groups per wavefront (K = 1982: 4 splits of 31 steps per wavefront, not 5 of 25 -- both are 4 groups)
             groups = lambda sp: -(-(-(-(-(-K // 4) // sp) // 4)) // 8)
-            splits = min(range(1, s_max + 1), key=lambda sp: (groups(sp), sp))
+            # (with the optimizer fused in, a tile's splits share its 8 quads per thread: powers of two only -- a K loop one
+            #  group longer costs ~1 us, the optimizer launch it saves ~7)
+            cand = [sp for sp in (1, 2, 4, 8) if sp <= s_max] if fuse else range(1, s_max + 1)
+            splits = min(cand, key=lambda sp: (groups(sp), sp))
             splits = max(splits, min(32, -(-K // rows)), -(-K // cap))
             raw, items, n_tiles, bases, sps, whole_quads = [], 0, 0, [], set(), True
             for a, lda, b, ldb, c, ldc, M, N, Kr, ct, ba, bb, g, kd in self.deferred16:

@@ -500,7 +500,9 @@ def test_resident_epochs_equal_the_collated_loop():
     assert len(c_loss) == 18 and len(r_loss) == 3
     for e in range(3):
         want = sum(c_loss[6 * e:6 * e + 6]) / 6
-        assert abs(r_loss[e] - want) < 2e-6 * max(1.0, abs(want)), (e, r_loss[e], want)
+        # (the two loops round their node counts up to different capacity edges, so the weight-gradient launch may cut K
+        #  into different split counts: fp32 sums in another order, a few 1e-6 of the loss after an epoch)
+        assert abs(r_loss[e] - want) < 1e-5 * max(1.0, abs(want)), (e, r_loss[e], want)
     assert r_ep[2]["graphs_captured"] <= 8 and r_ep[2]["graph_replays"] + r_ep[2]["eager_steps"] == 18
     assert r_ep[2]["eager_steps"] == r_ep[2]["graphs_captured"]
     assert [x["test"]["acc"] for x in r_ep] == [x["test"]["acc"] for x in c_ep]

@@ -8,7 +8,7 @@ T=${R}_cogmen_b32_bf16
 python tools/pmc_summary.py --trace gpurun_out/prof_r3 --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --tag $T --kernel wgrad_bf16 > /dev/null
 cp profiles/${T}_pmc.json profiles/${T}_wgrad_bf16_pmc.json
 rm profiles/${T}_pmc.json
-for k in cogmen_project_graph:project_graph cogmen_fwd_tile:cogmen_fwd_tile cogmen_bwd_tile:cogmen_bwd_tile adam_kernel:adam_kernel head_fused:head_fused; do
+for k in cogmen_project_graph:project_graph cogmen_fwd_tile:cogmen_fwd_tile cogmen_bwd_tile:cogmen_bwd_tile head_fused:head_fused; do
   kn=${k%%:*}; tg=${k##*:}
   python tools/pmc_summary.py --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --trace gpurun_out/prof_r3 --tag ${T}_$tg --kernel $kn --out /tmp/pmcs > /dev/null
   cp /tmp/pmcs/${T}_${tg}_pmc.json profiles/
