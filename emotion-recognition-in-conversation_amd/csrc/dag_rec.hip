@@ -742,6 +742,55 @@ __global__ __launch_bounds__(NTH) void dag_rec_bwd_kernel(RecBwd p) {
         gather_partials(do_a, do_b, tag, i & 1);
         REC_STAMP(3);
         __syncthreads();
+        // ---- the window's (dialogue, j) pairs, COMPACTED: lane m < 16 of every wavefront holds the window size of dialogue m, a
+        //      wavefront scan gives the pair offsets and a ballot maps pair d back to its dialogue -- sum_m n_m pairs instead of
+        //      ndlg * max_m n_m (a third of them at two speakers: one dependent batch of row loads instead of three).
+        const int nm = lane < ndlg ? i - max(s_pred[min(lane, ndlg - 1) * T + i], 0) : 0;
+        int incl = nm;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        const int excl = incl - nm;
+        const int npair = __shfl(incl, 15, 64);
+        // pair d -> (dialogue, offset in its window); recomputed where needed instead of carried across the all-gather
+        auto pair_of = [&](int d0, int u, int& mm, int& jj) {
+            const int d = max(min(d0 + u, npair - 1), 0);
+            const unsigned long long hit = __ballot(lane < 16 && excl <= d && d < incl);
+            mm = min(__builtin_amdgcn_readfirstlane(__builtin_ctzll(hit | (1ull << 63))), ndlg - 1);
+            jj = max(d - __shfl(excl, mm, 64), 0);
+        };
+        auto load_batch = [&](int ii, int d0, float (&vv)[4][5]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int mm, jj;
+                pair_of(d0, u, mm, jj);
+                const int pr = s_pred[mm * T + ii], lo = pr > 0 ? pr : 0;
+                const int j = min(lo + jj, T - 1);
+                const float* v = L.R + ((int64_t)(b0 + mm) * T + j) * 2 * HID + (s_spk[mm * T + j] == s_spk[mm * T + ii] ? 0 : HID);
+#pragma unroll
+                for (int r = 0; r < 5; ++r) vv[u][r] = v[min(lane + 64 * r, HID - 1)];
+            }
+        };
+        auto dot_batch = [&](int d0, float (&vv)[4][5]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int mm, jj;
+                pair_of(d0, u, mm, jj);
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const int k = lane + 64 * r;
+                    s += vv[u][r] * dmfull[mm * DMP + min(k, HID - 1)] * (k < HID ? 1.f : 0.f);
+                }
+                s = wave_sum(s);
+                if (lane == 0 && d0 + u < npair) dal[mm * T + jj] = s;
+            }
+        };
+        // (Requesting the first batch of rows HERE, in front of the all-gather they do not depend on, was measured and lost:
+        //  the 20 registers they occupy across the poll spill, and a spilled load result is a wait -- 39.9 k cycles per step
+        //  against 38.3 k.)
         // ---- E2 / M2: dM_i of this slice -> all-gather; the input gradient of step i + 1 goes out; Y_i = Wr[:, E_c]^T dM_i
         if (wave >= FMW) {
             if (iv) {
@@ -772,42 +821,12 @@ __global__ __launch_bounds__(NTH) void dag_rec_bwd_kernel(RecBwd p) {
         if (i == 0) break;
         __syncthreads();
         REC_STAMP(5);
-        // ---- dalpha_ij = dM_i . V_j over the window (V_j = the relation row of j that step i read): all 8 wavefronts,
-        //      four (dialogue, j) pairs per batch so that their 20 row loads are in flight together
-        {
-            int nmax = 0;
-            for (int mm = 0; mm < ndlg; ++mm) {
-                const int pr = s_pred[mm * T + i];
-                nmax = max(nmax, i - (pr > 0 ? pr : 0));
-            }
-            const int npair = ndlg * nmax;
-            for (int d0 = 4 * wave; d0 < npair; d0 += 32) {
-                float vv[4][5];
-                int pm[4], pj[4];
-                bool ok[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int d = min(d0 + u, npair - 1), mm = d % ndlg, jj = d / ndlg;
-                    const int pr = s_pred[mm * T + i], lo = pr > 0 ? pr : 0;
-                    ok[u] = d0 + u < npair && jj < i - lo;
-                    const int j = ok[u] ? lo + jj : lo;
-                    pm[u] = mm, pj[u] = jj;
-                    const float* v = L.R + ((int64_t)(b0 + mm) * T + j) * 2 * HID + (s_spk[mm * T + j] == s_spk[mm * T + i] ? 0 : HID);
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) vv[u][r] = v[min(lane + 64 * r, HID - 1)];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float s = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) {
-                        const int k = lane + 64 * r;
-                        s += vv[u][r] * dmfull[pm[u] * DMP + min(k, HID - 1)] * (k < HID ? 1.f : 0.f);
-                    }
-                    s = wave_sum(s);
-                    if (lane == 0 && ok[u]) dal[pm[u] * T + pj[u]] = s;
-                }
-            }
+        // ---- dalpha_ij = dM_i . V_j over the window (V_j = the relation row of j that step i read): all 8 wavefronts, four
+        //      compacted (dialogue, j) pairs per wavefront and batch
+        for (int d0 = 4 * wave; d0 < npair; d0 += 32) {
+            float vv[4][5];
+            load_batch(i, d0, vv);
+            dot_batch(d0, vv);
         }
         REC_STAMP(6);
         __syncthreads();
