@@ -60,6 +60,7 @@ _SIGS = {
     "erc_wgrad_bf16_max_k_per_split": (C.c_int, []),
     "erc_bn_bwd_apply": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_wgrad_max_k_per_split": (C.c_int, []),
+    "erc_gemm_x3": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _vp]),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
                                  _i64, _vp]),
     "erc_slab_reduce": (C.c_int, [_vp, _i, _i64, _vp, _i, _i, _vp, _i, _i64, _vp]),
@@ -145,7 +146,7 @@ _SIGS = {
     "erc_axpy_mask": (C.c_int, [_vp, _vp, _i64, _f, _i, _vp, _vp]),
     "erc_test_poison_lds": (C.c_int, [_vp, _vp]),
     "erc_gcnii_chain_set_stamps": (C.c_int, [_vp]),
-    "erc_gcnii_chain_prep": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp, _vp, _vp]),
+    "erc_gcnii_chain_prep": (C.c_int, [_vp, _i64, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "erc_gcnii_chain_config": (C.c_int, [_i, _i, _i, _i, _vp, _vp, _vp]),
     "erc_gcnii_chain_fwd": (C.c_int, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i64, _vp, _i, _vp, _vp,
                                       _vp, _f, _vp, C.c_uint64, _vp]),
@@ -284,6 +285,12 @@ def gemm_bf16x(A, lda, a_kmajor, a_gather, B, ldb, b_kmajor, b_gather, x_is_a, C
     _check(lib().erc_gemm_bf16x(ptr(A), lda, a_kmajor, ptr(a_gather), ptr(B), ldb, b_kmajor, ptr(b_gather), x_is_a,
                                 ptr(Cmat), ldc, M, N, K, split_k, c_slab, ones_col, ptr(bias_out), bias_slab,
                                 stream()), "erc_gemm_bf16x")
+
+
+def gemm_x3(A, lda, B, ldb, Cmat, ldc, M, N, K, split_k=1, c_slab=0):
+    """C = A B^T (both K-contiguous fp32) on the bf16 matrix cores through a three-term split: fp32-class (ercgraft.h)"""
+    _dev(A, B, Cmat)
+    _check(lib().erc_gemm_x3(ptr(A), lda, ptr(B), ldb, ptr(Cmat), ldc, M, N, K, split_k, c_slab, stream()), "erc_gemm_x3")
 
 
 def gemm_bf16a_stream(X, ldx, gather, W, ldw, Cm, ldc, M, N, K, bias=None, act=0):
@@ -532,8 +539,8 @@ def grad_norm(g, n, grad_scale, gnorm, ws):
     _check(lib().erc_grad_norm(ptr(g), n, grad_scale, ptr(gnorm), ptr(ws), stream()), "erc_grad_norm")
 
 
-def gcnii_chain_prep(W, w_stride, lamda, alpha, VT, V, U):
-    _check(lib().erc_gcnii_chain_prep(ptr(W), w_stride, lamda, alpha, ptr(VT), ptr(V), ptr(U), stream()), "erc_gcnii_chain_prep")
+def gcnii_chain_prep(W, w_stride, lamda, alpha, VT, V, U, UT=None):
+    _check(lib().erc_gcnii_chain_prep(ptr(W), w_stride, lamda, alpha, ptr(VT), ptr(V), ptr(U), ptr(UT), stream()), "erc_gcnii_chain_prep")
 
 
 def gcnii_chain_config(B, T, Mo, P):

@@ -513,7 +513,8 @@ __global__ __launch_bounds__(CNT) void gcnii_chain_kernel(Chain p) {
 
 // V_l = theta W_l[:200] + (1 - theta)(1 - alpha) I in both orientations, U_l = theta W_l[200:] + (1 - theta) alpha I
 __global__ __launch_bounds__(256) void gcnii_prep_kernel(const float* __restrict__ W, int64_t w_stride, float lamda, float alpha,
-                                                         float* __restrict__ VT, float* __restrict__ V, float* __restrict__ U) {
+                                                         float* __restrict__ VT, float* __restrict__ V, float* __restrict__ U,
+                                                         float* __restrict__ UT) {
     const int l = blockIdx.y;                 // 0-based layer
     const float theta = logf(lamda / (float)(l + 1) + 1.f);
     const float* Wl = W + l * w_stride;
@@ -523,7 +524,9 @@ __global__ __launch_bounds__(256) void gcnii_prep_kernel(const float* __restrict
         const float v = theta * Wl[k * FD + n] + (1.f - theta) * (1.f - alpha) * d;
         V[((int64_t)l * FD + k) * KP + n] = v;
         VT[((int64_t)l * FD + n) * KP + k] = v;
-        U[(int64_t)k * NL * FD + l * FD + n] = theta * Wl[(FD + k) * FD + n] + (1.f - theta) * alpha * d;
+        const float u = theta * Wl[(FD + k) * FD + n] + (1.f - theta) * alpha * d;
+        U[(int64_t)k * NL * FD + l * FD + n] = u;
+        if (UT) UT[((int64_t)l * FD + n) * FD + k] = u;      // row (l, n), contiguous k: the B operand of Call = h0 UT^T (erc_gemm_x3)
     }
     // the pad columns 200..207 of V / VT stay zero (zero-filled by the caller once)
 }
@@ -554,9 +557,9 @@ bool chain_ensure_lds(K kernel, int lds) {
 }  // namespace
 
 extern "C" int erc_gcnii_chain_prep(const float* W, int64_t w_stride, float lamda, float alpha, float* VT, float* V, float* U,
-                                    void* stream) {
+                                    float* UT, void* stream) {
     ERC_REQUIRE(W && VT && V && U && w_stride >= 2 * FD * FD, "gcnii_chain_prep: bad arguments");
-    hipLaunchKernelGGL(gcnii_prep_kernel, dim3(8, NL), dim3(256), 0, (hipStream_t)stream, W, w_stride, lamda, alpha, VT, V, U);
+    hipLaunchKernelGGL(gcnii_prep_kernel, dim3(8, NL), dim3(256), 0, (hipStream_t)stream, W, w_stride, lamda, alpha, VT, V, U, UT);
     ERC_LAUNCH_CHECK("gcnii_chain_prep");
     return ERC_OK;
 }

@@ -84,6 +84,8 @@ def _unused_tables():
 
 
 class MMGCNModule(nn.Module):
+    X3_SPLIT = 10      # K splits of dh0 = DG U^T on erc_gemm_x3 (K = 12 800: 50 output tiles x 10 = 500 workgroups)
+
     def __init__(self, hidden_text=100, D_e=100, graph_hidden_size=200, n_speakers=2, max_seq_len=200, window_past=10,
                  window_future=10, n_classes=7, nodal_attention=True, hidden_visual=512, hidden_audio=100, modals="atv",
                  seed=1):
@@ -159,6 +161,11 @@ class MMGCNModule(nn.Module):
             ws["chain_cfg"] = capi.gcnii_chain_config(B, T, Mo, P)
             ws["VT"], ws["V"] = f32(NLAYERS + 1, FD, 208), f32(NLAYERS + 1, FD, 208)
             ws["U"], ws["Call"] = f32(FD, LDS), f32(R3, LDS)
+            # the two 16 GFLOP products around the chain (Call = h0 U, dh0 = DG U^T) as three-term bf16 splits on the bf16 matrix
+            # cores (csrc/gemm_x3.hip: fp32-class, 2.4 x the exact-fp32 tiles); ERC_MM_GEMM_X3=0 keeps erc_gemm_f32
+            ws["gemm_x3"] = os.environ.get("ERC_MM_GEMM_X3", "1") != "0"
+            if ws["gemm_x3"]:
+                ws["UT"], ws["dH0s3"] = f32(LDS, FD), f32(self.X3_SPLIT * R3 * FD)
             ws["ZS"], ws["DGl"], ws["DZl"] = f32(R3, LDS), f32(R3, LDS), f32(R3, LDS)
             ws["ZX"], ws["DH1"] = f32(2, R3, FD), f32(R3, FD)
             ws["chain_state"] = i32(1 + B + B * Mo * ws["chain_cfg"][0])
@@ -246,8 +253,11 @@ class MMGCNModule(nn.Module):
             Wn0 = gn + "convs.0.weight"
             w_stride = fp.offsets[gn + "convs.1.weight"] - fp.offsets[Wn0]
             LDS = NLAYERS * FD
-            capi.gcnii_chain_prep(fp.w(Wn0), w_stride, LAMDA, ALPHA, ws["VT"], ws["V"], ws["U"])
-            capi.gemm_f32(H0, FD, 0, None, ws["U"], LDS, 1, None, ws["Call"], LDS, R3, LDS, FD)
+            capi.gcnii_chain_prep(fp.w(Wn0), w_stride, LAMDA, ALPHA, ws["VT"], ws["V"], ws["U"], ws.get("UT"))
+            if ws["gemm_x3"]:
+                capi.gemm_x3(H0, FD, ws["UT"], FD, ws["Call"], LDS, R3, LDS, FD)
+            else:
+                capi.gemm_f32(H0, FD, 0, None, ws["U"], LDS, 1, None, ws["Call"], LDS, R3, LDS, FD)
             capi.gcnii_chain_fwd(ws["ADJ"], P, ws["CR"], ws["node_off"], N, Mo, B, T, ws["chain_cfg"], ws["VT"], ws["Call"], LDS,
                                  HD, R3 * FD, ws["ZS"], LDS, ws["ZX"], ws["chain_state"], p, rng, 2000, health=fp.health)
         else:
@@ -357,7 +367,11 @@ class MMGCNModule(nn.Module):
             capi.mm_cross_grad(ws["DGl"], LDS, ws["ZS"], LDS, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"], planes=NLAYERS,
                                d_plane=FD, h_plane=FD)
             # dh0 = sum_l dg_l U_l^T = DG U^T: one product with K = 64 * 200
-            linear_fwd(pl, ws["DGl"], LDS, None, ws["U"], None, dH0, FD, R3, FD, LDS)
+            if ws["gemm_x3"]:
+                capi.gemm_x3(ws["DGl"], LDS, ws["U"], LDS, ws["dH0s3"], FD, R3, FD, LDS, split_k=self.X3_SPLIT, c_slab=R3 * FD)
+                capi.slab_reduce(ws["dH0s3"], self.X3_SPLIT, R3 * FD, None, FD, 0, dH0, R3 * FD)
+            else:
+                linear_fwd(pl, ws["DGl"], LDS, None, ws["U"], None, dH0, FD, R3, FD, LDS)
             DH = ws["DH1"]
         else:
             DH, dH0 = self._legacy_chain_backward(ws, pl, DH, B, T, N, p, ks)

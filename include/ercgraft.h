@@ -177,6 +177,14 @@ int erc_gemm_bf16x(const void* A, int lda, int a_kmajor, const int32_t* a_gather
                    int split_k, int64_t c_slab, int ones_col, float* bias_out, int64_t bias_slab,
                    void* stream);
 
+/* C[M, N] = A[M, K] B[N, K]^T, fp32 operands and result, computed on the bf16 matrix cores from a three-term split of every
+ * operand value (x = h + m + l, six cross products, fp32 accumulate: fp32-class, ~2^-23 relative per product); 128 x 128
+ * tiles.  Replaces the exact-fp32 erc_gemm_f32 for the two 16 GFLOP products of MMGCN's GCNII chain
+ * (track_mm/mmgcn_models.py:373-394).  split_k > 1: split s writes its partial product to C + s * c_slab (erc_slab_reduce
+ * adds them).  K, lda, ldb multiples of 4; A, B 16-byte aligned. */
+int erc_gemm_x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int split_k,
+                int64_t c_slab, void* stream);
+
 /* out[(i / n_cols)*ld_out + i % n_cols] = act( sum_{s<S} slabs[s*slab_stride + i] + (bias ? bias[i % n_cols] : 0) ),
  * i < numel; ld_out = 0 means contiguous (ld_out = n_cols).  act: 0 none, 1 relu, 4 = add the sum to out instead of
  * overwriting it. */
@@ -588,7 +596,8 @@ int erc_grad_norm(const float* g, int64_t n, float grad_scale, float* gnorm, flo
  *   V_l = theta_l W_l[:200] + (1 - theta_l)(1 - alpha) I, U_l = theta_l W_l[200:] + (1 - theta_l) alpha I, theta_l = ln(lamda / l + 1).
  *   erc_gcnii_chain_prep: W = convs.0.weight, layer l at W + l * w_stride ([400,200] each) -> VT [65][200][208] (row n,
  *     contiguous k; zero-filled once by the caller, the last plane is padding), V [65][200][208] (row k, contiguous n),
- *     U [200][64*200] (layer l at column l * 200).  The caller computes Call = H0 U ([Mo*N][64*200]) with one GEMM.
+ *     U [200][64*200] (layer l at column l * 200), UT (or NULL) [64*200][200] = U transposed.  The caller computes
+ *     Call = H0 U ([Mo*N][64*200]) with one GEMM (erc_gemm_x3 on UT, or erc_gemm_f32 on U).
  *   erc_gcnii_chain_config: parts per (dialogue, modality) block, rows per workgroup (<= 32) and dialogues per launch so that
  *     every workgroup of a dialogue is resident (occupancy query); T <= 128.
  *   erc_gcnii_chain_fwd: HD planes [66][Mo*N][200] (plane stride hd_plane): plane 1 = dropout(relu(fc0 x)) on entry, planes
@@ -599,7 +608,8 @@ int erc_grad_norm(const float* g, int64_t n, float grad_scale, float* gnorm, flo
  *     dW_l[:200] = theta_l HD_l^T dz_l, dW_l[200:] = theta_l H0^T dg_l, dH0 = DG U^T, dADJ = sum_l dg_l z_l^T (blocks, cross).
  *   ZX: exchange buffer [2][Mo*N][200]; state: int32 [1 + B + B*Mo*parts], zero-filled once ([0] error flag when health is
  *   NULL, epochs, flags); health: the health word (see erc_health_roll) a poll timeout raises. */
-int erc_gcnii_chain_prep(const float* W, int64_t w_stride, float lamda, float alpha, float* VT, float* V, float* U, void* stream);
+int erc_gcnii_chain_prep(const float* W, int64_t w_stride, float lamda, float alpha, float* VT, float* V, float* U, float* UT,
+                         void* stream);
 int erc_gcnii_chain_config(int B, int T, int Mo, int P, int* parts, int* rows, int* dialogues_per_launch);
 int erc_gcnii_chain_fwd(const float* ADJ, int P, const float* CR, const int32_t* node_off, int N, int Mo, int B, int T,
                         int parts, int rows, int dialogues_per_launch, const float* VT, const float* Call, int ldc,

@@ -596,3 +596,27 @@ def test_wgrad_three_term_bf16_split_is_fp32_class():
         assert float((bias.double() - A.double().sum(0)).abs().max()) <= 1e-5 * float(A.double().abs().sum(0).max())
     assert errs[2] < 4 * max(errs[0], 1e-7), errs          # fp32 class ...
     assert errs[2] < 1e-6 and errs[1] > 1e-4, errs        # ... not bf16 class
+
+
+@pytest.mark.parametrize("M,N,K,split", [(300, 260, 200, 1), (131, 200, 1280, 4), (64, 128, 36, 1)])
+def test_gemm_x3_is_fp32_class(capi, M, N, K, split):
+    """erc_gemm_x3: C = A B^T on the bf16 matrix cores from a three-term split of both fp32 operands.  Against the float64
+    product its error is of the size of the exact-fp32 kernel's (erc_gemm_f32: an fp32 fma chain), orders below one bf16
+    rounding; ragged tiles, K not a multiple of the 32-chunk, split-K slabs."""
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K) * torch.logspace(-3, 2, K)       # wide dynamic range along K
+    Bm = torch.randn(N, K)
+    ref = A.double() @ Bm.double().t()
+    Ad, Bd = A.to(DEV), Bm.to(DEV)
+    slab = M * N
+    out = torch.full((split * slab,), float("nan"), device=DEV)
+    capi.gemm_x3(Ad, K, Bd, K, out, N, M, N, K, split_k=split, c_slab=slab)
+    C3 = out.view(split, M, N).sum(0).cpu().double()
+    C32 = torch.zeros(M, N, device=DEV)
+    capi.gemm_f32(Ad, K, 0, None, Bd, K, 0, None, C32, N, M, N, K)
+    scale = (A.double().abs() @ Bm.double().abs().t())       # sum |a||b|: the natural error scale of a dot product
+    e3 = float(((C3 - ref).abs() / scale).max())
+    e32 = float(((C32.cpu().double() - ref).abs() / scale).max())
+    ebf = float((((A.bfloat16().double() @ Bm.bfloat16().double().t()) - ref).abs() / scale).max())
+    assert e3 <= max(4 * e32, 3e-7), (e3, e32)
+    assert e3 < 1e-3 * ebf, (e3, ebf)
