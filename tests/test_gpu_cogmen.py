@@ -505,7 +505,8 @@ def test_resident_epochs_equal_the_collated_loop():
         assert abs(r_loss[e] - want) < 1e-5 * max(1.0, abs(want)), (e, r_loss[e], want)
     assert r_ep[2]["graphs_captured"] <= 8 and r_ep[2]["graph_replays"] + r_ep[2]["eager_steps"] == 18
     assert r_ep[2]["eager_steps"] == r_ep[2]["graphs_captured"]
-    assert [x["test"]["acc"] for x in r_ep] == [x["test"]["acc"] for x in c_ep]
+    # (same reason: a logit pair closer than that rounding may flip its argmax -- a few utterances of the ~400 at most)
+    assert all(abs(a["test"]["acc"] - b["test"]["acc"]) <= 0.01 for a, b in zip(r_ep, c_ep))
 
 
 def test_optimizer_fused_into_the_weight_gradient_launch_equals_the_separate_launch():
