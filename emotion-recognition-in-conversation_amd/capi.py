@@ -61,6 +61,7 @@ _SIGS = {
     "erc_bn_bwd_apply": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "erc_wgrad_max_k_per_split": (C.c_int, []),
     "erc_gemm_x3": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _vp]),
+    "erc_gemm_x3_grouped": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i64, _vp]),
     "erc_gemm_bf16x": (C.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i64, _i, _vp,
                                  _i64, _vp]),
     "erc_slab_reduce": (C.c_int, [_vp, _i, _i64, _vp, _i, _i, _vp, _i, _i64, _vp]),
@@ -291,6 +292,13 @@ def gemm_x3(A, lda, B, ldb, Cmat, ldc, M, N, K, split_k=1, c_slab=0):
     """C = A B^T (both K-contiguous fp32) on the bf16 matrix cores through a three-term split: fp32-class (ercgraft.h)"""
     _dev(A, B, Cmat)
     _check(lib().erc_gemm_x3(ptr(A), lda, ptr(B), ldb, ptr(Cmat), ldc, M, N, K, split_k, c_slab, stream()), "erc_gemm_x3")
+
+
+def gemm_x3_grouped(A, lda, B, ldb, Cmat, pitch, node_off, n_dlg, n_mod, n_nodes, max_rows, K, split_k=1, c_slab=0):
+    """per-(dialogue, modality) blocks A_rows B_rows^T with the three-term split (erc_gemm_f32_grouped form 1; ercgraft.h)"""
+    _dev(A, B, Cmat)
+    _check(lib().erc_gemm_x3_grouped(ptr(A), lda, ptr(B), ldb, ptr(Cmat), pitch, ptr(node_off), n_dlg, n_mod, n_nodes, max_rows, K,
+                                     split_k, c_slab, stream()), "erc_gemm_x3_grouped")
 
 
 def gemm_bf16a_stream(X, ldx, gather, W, ldw, Cm, ldc, M, N, K, bias=None, act=0):

@@ -61,13 +61,11 @@ __device__ __forceinline__ void split_store(unsigned short* dst, const f32x4 x) 
     *reinterpret_cast<u32x2*>(dst + 2 * XPLANE) = (u32x2){l[0], l[1]};
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3P p) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[6 * XPLANE];   // A: planes 0..2, B: planes 3..5
+__device__ __forceinline__ void gemm_x3_body(const X3P& p, const int n0, const int m0, const int z, unsigned short* lds) {
     unsigned short* const As = lds;
     unsigned short* const Bs = lds + 3 * XPLANE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
-    const int n0 = blockIdx.x * XT, m0 = blockIdx.y * XT, z = blockIdx.z;
     const int nchunk = (p.K + XK - 1) / XK;
     const int c_begin = z * p.chunks_per_split, c_end = min(nchunk, c_begin + p.chunks_per_split);
 
@@ -146,6 +144,29 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3P p) {
         }
 }
 
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3P p) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[6 * XPLANE];   // A: planes 0..2, B: planes 3..5
+    gemm_x3_body(p, blockIdx.x * XT, blockIdx.y * XT, blockIdx.z, lds);
+}
+
+// Grouped form (erc_gemm_f32_grouped form 1): block (dialogue b, modality m) of a block-diagonal result,
+// Blk[L, L] = A_rows[L, K] B_rows[L, K]^T over the node rows m * n_nodes + [node_off[b], node_off[b + 1]) -- one 128 x 128 tile
+// per block (L <= 128), split-K slabs.
+struct X3Group {
+    const int32_t* node_off;
+    int n_mod, n_nodes, pitch, split;
+};
+__global__ __launch_bounds__(256, 2) void gemm_x3_grouped_kernel(X3P p, const X3Group g) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[6 * XPLANE];
+    const int item = (int)blockIdx.x / g.split, sp = (int)blockIdx.x % g.split, b = item / g.n_mod, m = item % g.n_mod;
+    const int off = g.node_off[b], L = g.node_off[b + 1] - off;
+    if (L <= 0) return;
+    const int64_t row0 = (int64_t)m * g.n_nodes + off;
+    p.A += row0 * p.lda, p.B += row0 * p.ldb, p.C += (int64_t)item * g.pitch * g.pitch;
+    p.M = p.N = min(L, XT);
+    gemm_x3_body(p, 0, 0, sp, lds);
+}
+
 }  // namespace
 
 // C[M, N] = A[M, K] B[N, K]^T, fp32 in and out, three-term bf16 split inside (fp32-class: ~2^-23 relative per product).
@@ -163,5 +184,24 @@ extern "C" int erc_gemm_x3(const float* A, int lda, const float* B, int ldb, flo
     X3P p{A, B, C, c_slab, lda, ldb, ldc, M, N, K, cps};
     hipLaunchKernelGGL(gemm_x3_kernel, dim3(erc_cdiv(N, XT), erc_cdiv(M, XT), splits), dim3(256), 0, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("gemm_x3");
+    return ERC_OK;
+}
+
+// erc_gemm_f32_grouped(form 1) with the three-term split: dialogue blocks of at most 128 rows, C = [n_dlg * n_mod] blocks of
+// pitch x pitch floats (+ split-K slabs of c_slab floats), rows of block (b, m) = m * n_nodes + [node_off[b], node_off[b + 1]).
+extern "C" int erc_gemm_x3_grouped(const float* A, int lda, const float* B, int ldb, float* C, int pitch, const int32_t* node_off,
+                                   int n_dlg, int n_mod, int n_nodes, int max_rows, int K, int split_k, int64_t c_slab, void* stream) {
+    ERC_REQUIRE(A && B && C && node_off && n_dlg > 0 && n_mod > 0 && K > 0 && split_k >= 1, "gemm_x3_grouped: bad arguments");
+    ERC_REQUIRE(max_rows <= XT && pitch >= max_rows, "gemm_x3_grouped: blocks of at most %d rows (got %d, pitch %d)", XT, max_rows, pitch);
+    ERC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && (((uintptr_t)A | (uintptr_t)B) & 15) == 0,
+                "gemm_x3_grouped: K, lda, ldb must be multiples of 4 and the operands 16-byte aligned");
+    const int nchunk = erc_cdiv(K, XK);
+    const int cps = erc_cdiv(nchunk, split_k), splits = erc_cdiv(nchunk, cps);
+    ERC_REQUIRE(splits == split_k, "gemm_x3_grouped: split_k = %d leaves an empty split (K = %d: use %d)", split_k, K, splits);
+    ERC_REQUIRE(split_k == 1 || c_slab >= (int64_t)n_dlg * n_mod * pitch * pitch, "gemm_x3_grouped: c_slab too small");
+    X3P p{A, B, C, c_slab, lda, ldb, pitch, 0, 0, K, cps};
+    X3Group g{node_off, n_mod, n_nodes, pitch, splits};
+    hipLaunchKernelGGL(gemm_x3_grouped_kernel, dim3(n_dlg * n_mod * splits), dim3(256), 0, (hipStream_t)stream, p, g);
+    ERC_LAUNCH_CHECK("gemm_x3_grouped");
     return ERC_OK;
 }

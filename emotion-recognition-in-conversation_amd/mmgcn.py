@@ -361,8 +361,12 @@ class MMGCNModule(nn.Module):
                 matmul_wgrad_io(pl, ws["_H0"], FD, ws["DGl"][:, (l - 1) * FD:], LDS, FD, FD, R3, off[Wn] + FD * FD, None,
                                 defer=True, scale=th)
             # dA = sum_l dg_l z_l^T on the block structure (and its cross-modal entries)
-            capi.gemm_grouped(1, ws["DGl"], LDS, ws["ZS"], LDS, ws["dADJs"], P, FD, ws["node_off"], B, Mo, N, T, P, planes=NLAYERS,
-                              a_plane=FD, b_plane=FD, split=KSPLIT, c_slab=n_adj)
+            if ws["gemm_x3"]:     # the planes of a row are contiguous: one K = 64 * 200 contraction per block
+                capi.gemm_x3_grouped(ws["DGl"], LDS, ws["ZS"], LDS, ws["dADJs"], P, ws["node_off"], B, Mo, N, T, LDS,
+                                     split_k=KSPLIT, c_slab=n_adj)
+            else:
+                capi.gemm_grouped(1, ws["DGl"], LDS, ws["ZS"], LDS, ws["dADJs"], P, FD, ws["node_off"], B, Mo, N, T, P, planes=NLAYERS,
+                                  a_plane=FD, b_plane=FD, split=KSPLIT, c_slab=n_adj)
             capi.slab_reduce(ws["dADJs"], KSPLIT, n_adj, None, P, 0, ws["dADJ"], n_adj)
             capi.mm_cross_grad(ws["DGl"], LDS, ws["ZS"], LDS, ws["node_dlg"], ws["node_off"], Mo, N, P, ws["dCR"], planes=NLAYERS,
                                d_plane=FD, h_plane=FD)

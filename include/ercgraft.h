@@ -185,6 +185,12 @@ int erc_gemm_bf16x(const void* A, int lda, int a_kmajor, const int32_t* a_gather
 int erc_gemm_x3(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, int split_k,
                 int64_t c_slab, void* stream);
 
+/* erc_gemm_f32_grouped(form 1) on the same three-term split: block (b, m) of [n_dlg * n_mod] blocks of pitch x pitch floats,
+ * Blk[L, L] = A_rows[L, K] B_rows[L, K]^T over the node rows m * n_nodes + [node_off[b], node_off[b + 1]); L <= max_rows <= 128
+ * (one tile per block); split_k slabs of c_slab floats.  MMGCN: dAdj = sum_l dg_l z_l^T with K = 64 * 200. */
+int erc_gemm_x3_grouped(const float* A, int lda, const float* B, int ldb, float* C, int pitch, const int32_t* node_off,
+                        int n_dlg, int n_mod, int n_nodes, int max_rows, int K, int split_k, int64_t c_slab, void* stream);
+
 /* out[(i / n_cols)*ld_out + i % n_cols] = act( sum_{s<S} slabs[s*slab_stride + i] + (bias ? bias[i % n_cols] : 0) ),
  * i < numel; ld_out = 0 means contiguous (ld_out = n_cols).  act: 0 none, 1 relu, 4 = add the sum to out instead of
  * overwriting it. */

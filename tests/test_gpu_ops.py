@@ -620,3 +620,28 @@ def test_gemm_x3_is_fp32_class(capi, M, N, K, split):
     ebf = float((((A.bfloat16().double() @ Bm.bfloat16().double().t()) - ref).abs() / scale).max())
     assert e3 <= max(4 * e32, 3e-7), (e3, e32)
     assert e3 < 1e-3 * ebf, (e3, ebf)
+
+
+def test_gemm_x3_grouped_equals_the_exact_fp32_grouped_product(capi):
+    """erc_gemm_x3_grouped: the per-(dialogue, modality) blocks dg z^T of MMGCN's adjacency gradient (K = planes * 200 contiguous
+    per row) against erc_gemm_f32_grouped form 1 with planes, both through split-K slabs: fp32-class agreement, rows / columns
+    beyond a dialogue's length untouched."""
+    torch.manual_seed(5)
+    lens, Mo, FD, NP = [7, 33, 1, 128, 50], 3, 200, 4
+    B, N, P = len(lens), sum(lens), 128
+    off = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    A, Z = torch.randn(Mo * N, NP * FD, device=DEV), torch.randn(Mo * N, NP * FD, device=DEV)
+    n_adj, S = B * Mo * P * P, 5
+    ref_s, got_s = torch.zeros(S * n_adj, device=DEV), torch.full((S * n_adj,), 7.0, device=DEV)
+    capi.gemm_grouped(1, A, NP * FD, Z, NP * FD, ref_s, P, FD, off, B, Mo, N, max(lens), P, planes=NP, a_plane=FD, b_plane=FD,
+                      split=S, c_slab=n_adj)
+    capi.gemm_x3_grouped(A, NP * FD, Z, NP * FD, got_s, P, off, B, Mo, N, max(lens), NP * FD, split_k=S, c_slab=n_adj)
+    ref, got = ref_s.view(S, B * Mo, P, P).sum(0), got_s.view(S, B * Mo, P, P)
+    for b, L in enumerate(lens):
+        for m in range(Mo):
+            blk = got[:, b * Mo + m]
+            assert bool((blk[:, L:, :] == 7.0).all()) and bool((blk[:, :, L:] == 7.0).all())
+            want = (A[m * N + int(off[b]):m * N + int(off[b]) + L].double() @ Z[m * N + int(off[b]):m * N + int(off[b]) + L].double().t())
+            e3 = float((blk[:, :L, :L].sum(0).double() - want).abs().max())
+            e32 = float((ref[b * Mo + m, :L, :L].double() - want).abs().max())
+            assert e3 <= max(4 * e32, 1e-4), (b, m, e3, e32)
