@@ -175,9 +175,10 @@ class MMGCNModule(nn.Module):
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
         ws["planner"].MAX_SPLIT = 8      # 128 weight-gradient GEMMs per step: keep their slab sets small
         # ERC_MM_X3=1: weight gradients as three-term bf16 splits (csrc/wgrad.hip MB == 2: fp32-class products on the bf16
-        # matrix cores).  Measured: 3.961 -> 3.906 ms per step -- the operand split on the VALU (two truncations, two
-        # subtractions, three packs per value) eats most of what the matrix cores give back; off by default (exact fp32).
-        ws["planner"].mma_bf16 = 2 if os.environ.get("ERC_MM_X3", "0") == "1" else 0
+        # matrix cores).  Measured: 3.456 -> 3.421 ms per step -- the operand split on the VALU (two truncations, two
+        # subtractions, three packs per value) eats most of what the matrix cores give back.  On by default with the other
+        # fp32-class products (erc_gemm_x3); ERC_MM_X3=0 ERC_MM_GEMM_X3=0 is the exact-fp32 step.
+        ws["planner"].mma_bf16 = 2 if os.environ.get("ERC_MM_X3", "1") == "1" else 0
         ws["jobs"] = None
         return ws
 
