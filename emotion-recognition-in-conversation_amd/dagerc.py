@@ -16,6 +16,8 @@ H0..H4 are written straight into one [B*T, 1500] buffer, so the
 ``torch.cat`` of dagerc.py:190-192 never happens: the head's first Linear is
 two GEMMs (hidden block, raw-feature block) summed by the slab reducer.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -138,6 +140,9 @@ class DAGERCModule(nn.Module):
                             **{k: capi.ptr_table(ws[k]) for k in ("GI", "Mseq", "GH", "R", "ks", "alpha", "DGI", "DGH", "dM", "dks")})
         slab = 8 * BT * HID + 10 * (HID * self.in_dim) + 6 * L * (6 * HID * HID + 2 * HID * HID) + (1 << 20)
         ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
+        # the fp32 weight gradients as three-term bf16 splits (csrc/wgrad.hip MB == 2, fp32-class: 3.54 -> 3.50 ms per step);
+        # ERC_DAG_X3=0: exact fp32 products
+        ws["planner"].mma_bf16 = 2 if os.environ.get("ERC_DAG_X3", "1") == "1" else 0
         ws["jobs"] = None
         return ws
 
