@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""How much of a COGMEN step is the bubble BETWEEN two graph launches?  Times K steps replayed as K one-step graphs against
+K / S replays of an S-step graph, and the host cost of a replay call."""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import torch
+from bench import synthetic_batch
+import track_mm.cogmen as plugin
+
+params = plugin.ParamsType().from_args(["--dataset=iemocap-cogmen-sbert-6", "--modality=atv", "--compute=bf16"])
+tr = plugin.COGMENTrainer(params, "cuda:0")
+batch = tr.prepare_batch(synthetic_batch(params, 32, 110, seed=1))
+for _ in range(3):
+    tr.train_step(batch)
+torch.cuda.synchronize()
+K = 2400
+for S in (1, 2, 4, 8):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(S):
+            tr.train_step(batch)
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K // S):
+        g.replay()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    print("steps per graph %d: %.2f us per step (host enqueue %.2f us per replay)" % (S, t / K * 1e6, t_host / (K // S) * 1e6))
