@@ -55,6 +55,7 @@ _SIGS = {
     "erc_wgrad_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16_adam": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp,
                                       _i64, _vp, _vp, _vp]),
+    "erc_wgrad_bf16_wide": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16_slab_floats": (C.c_int64, []),
     "erc_wgrad_bf16_set_stamps": (C.c_int, [_vp, _i]),
     "erc_wgrad_bf16_max_k_per_split": (C.c_int, []),
@@ -966,6 +967,11 @@ def wgrad_bf16_adam(table, n_desc, item_base, n_items, slabs, counters, n_tiles,
                                      ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale, ptr(state),
                                      ptr(st.buf) if st is not None else None, st.buf.numel() if st is not None else 0,
                                      st.tab_ptr if st is not None else None, ptr(health), stream()), "erc_wgrad_bf16_adam")
+
+
+def wgrad_bf16_wide(table, n_desc, wg_base, n_wgs, slabs, counters):
+    """erc_wgrad_bf16 for large K: four neighbouring column tiles per workgroup (ercgraft.h)"""
+    _check(lib().erc_wgrad_bf16_wide(ptr(table), n_desc, wg_base, n_wgs, ptr(slabs), ptr(counters), stream()), "erc_wgrad_bf16_wide")
 
 
 def wgrad_bf16_set_stamps(t, item=0):

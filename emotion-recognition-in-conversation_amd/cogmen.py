@@ -20,6 +20,7 @@ accumulated as split-K slabs that one batched kernel reduces into the flat
 gradient buffer (deterministic; no float atomics).
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -365,10 +366,10 @@ class COGMENModule(nn.Module):
         if fused and not fused_head:
             raise capi.ErcGraftError("COGMEN bf16 mode trains through the fused head (C <= 8)")
         # bf16 mode: every weight gradient of the step on the bf16 matrix cores from bf16 operands (csrc/wgrad_bf16.hip)
-        # (N <= 8 192: with several rounds of work items per CU the 64 x 64-tile kernel at three workgroups per CU wins,
-        #  167 vs 181 us at N = 33 k -- wgrad_bf16's 428-register wavefronts leave one workgroup per CU)
+        # (N > 8 192: the planner takes the WIDE form of that kernel -- four column tiles per workgroup; the K-split form lost
+        #  there against the 64 x 64-tile kernel, 181 vs 167 us at N = 33 k, because it streams the A operand once per tile)
         w16 = bool(fused and self.wgrad_bf16 and x_bf16 and C <= 8 and D % 4 == 0 and x.is_contiguous() and x.data_ptr() % 8 == 0
-                   and N <= self.BN_FUSED_MAX_N)
+                   and (N <= self.BN_FUSED_MAX_N or os.environ.get("ERC_W2_WIDE", "1") != "0"))
         ws["w16"] = w16
         b16 = (ws["H3b"], ws["Zb"], ws["dZb"], ws["dlb"], PA) if w16 else None
         nd = g["counts"] if self.dynamic_n else None

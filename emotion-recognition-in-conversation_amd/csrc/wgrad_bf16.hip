@@ -106,7 +106,11 @@ __device__ __forceinline__ unsigned perm_hi(unsigned x, unsigned y) { return __b
         if (stamps && threadIdx.x == 0) stamps[slot] = __builtin_amdgcn_s_memrealtime();        \
     } while (0)
 
-template <bool ADAM>
+// WIDE (large K: B = 512 batches): the four wavefronts of a workgroup do not split K but take four NEIGHBOURING column tiles
+// of the record over the same k-steps -- they request the same A rows at about the same time, so the 256 B of an A row per
+// k reach the CU once instead of once per column tile (at N = 33 k the A operand, 6.6 MB per record, does not fit a 4 MB L2 and
+// was streamed through the fabric 22 times for the 22 column tiles of the projection gradient: 397 of the launch's 595 MB).
+template <bool ADAM, bool WIDE>
 __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float* red, float* bred, int* idx, int* s_flag,
                                         float* slabs, int* counters, uint64_t* stamps_item, uint64_t* stamps_tile, const W2Adam& ad) {
     uint64_t* stamps = stamps_item;
@@ -208,7 +212,8 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int split = local % d.splits, tn = local / d.splits;
+    const int split = local % d.splits;
+    const int tn = WIDE ? 4 * (local / d.splits) + w : local / d.splits;     // WIDE: the column tile of THIS wavefront (may be >= tiles_n)
     const int n0 = tn * 64;
     const int nks = (d.K + 3) >> 2;
     const int per = (nks + d.splits - 1) / d.splits;
@@ -226,7 +231,9 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     const int ma = 8 * r, nb = n0 + 4 * r;
     const int a_c = ma < d.M ? ma : 0;
     const int b_c = nb < d.N ? nb : 0;
-    const int ns = (max(0, ks_end - ks_begin) + 3) >> 2;      // k-steps of this wavefront: ks_begin + w + 4 s, s < ns
+    // k-steps of this wavefront: ks_begin + w + 4 s (WIDE: ks_begin + s), s < ns
+    const int ns = WIDE ? max(0, ks_end - ks_begin) : (max(0, ks_end - ks_begin) + 3) >> 2;
+    auto kstep = [&](const int sidx) __attribute__((always_inline)) { return WIDE ? ks_begin + sidx : ks_begin + w + 4 * sidx; };
 
     // Every global load is unconditional (a guarded load is a branch + a full wait, finding 1): an out-of-range k reads a
     // clamped row and its words are ANDed with 0.  A does not depend on the row gather: its first group is requested in
@@ -234,7 +241,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     auto load_a = [&](const int s0, u32x4 (&a)[8]) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int k = 4 * (ks_begin + w + 4 * (s0 + u)) + g;
+            const int k = 4 * kstep(s0 + u) + g;
             const int kl = max(0, min(k - k_begin, nk - 1));
             a[u] = *(const ERC_GLOBAL u32x4*)(Ag + (int64_t)(k_begin + kl) * d.lda + a_c);
         }
@@ -242,7 +249,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     auto load_b = [&](const int s0, u32x2 (&b)[8]) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int k = 4 * (ks_begin + w + 4 * (s0 + u)) + g;
+            const int k = 4 * kstep(s0 + u) + g;
             const int kl = max(0, min(k - k_begin, nk - 1));
             const int64_t brow = (int64_t)(gath ? idx[kl] : k_begin + kl) * d.ldb;
             b[u] = *(const ERC_GLOBAL u32x2*)(Bg + brow + b_c);
@@ -280,11 +287,11 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
 
     auto mma_group = [&](const int s0, u32x4 (&a)[8], u32x2 (&b)[8]) {
         // k mask of every step, applied to the raw words -- only a group that reaches past the item's k range needs it (uniform)
-        const bool ragged = 4 * (ks_begin + 4 * (s0 + 7) + 3) + 3 >= min(K_true, 4 * ks_end);
+        const bool ragged = 4 * (WIDE ? ks_begin + s0 + 7 : ks_begin + 4 * (s0 + 7) + 3) + 3 >= min(K_true, 4 * ks_end);
         if (ragged) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int ks = ks_begin + w + 4 * (s0 + u);
+                const int ks = kstep(s0 + u);
                 const unsigned km = (ks < ks_end && 4 * ks + g < K_true) ? 0xffffffffu : 0u;
                 a[u] = (u32x4){a[u].x & km, a[u].y & km, a[u].z & km, a[u].w & km};
                 b[u] = (u32x2){b[u].x & km, b[u].y & km};
@@ -344,341 +351,358 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
         load_a(s0 + 56, ga3), load_b(s0 + 56, gb3);
     }
     W2_STAMP(2);
-    // ---- bias strips of this wavefront -> LDS (summed over the wavefronts below).  bacc_a[i][q] of lane ln = sum_k A[k][m = 8 (4 (ln >> 4)
-    //      + q) + i], the same in all 16 columns: lanes with (ln & 15) == 0 write; bacc_b[j][q] = sum_k B[k][n0 + 4 (ln & 15) + j],
-    //      the same in all rows: lanes < 16 write row q = 0
-    if ((lane & 15) == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bred[w * 192 + 8 * (4 * g + q) + i] = bacc_a[i][q];
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bred[w * 192 + 128 + 4 * lane + j] = bacc_b[j][0];
-    }
+    // ---- everything behind the K loop, for ONE column tile: `tn_e` = the tile, `wsel` = 1 for the wavefronts whose accumulators
+    //      belong to it (all four when they split K; WIDE: the one wavefront that owns the tile, the others contribute zeros)
+    auto finish = [&](const int tn_e, const float wsel) __attribute__((always_inline)) {
+        const int tn = tn_e, n0 = 64 * tn_e;
+        const bool want_a = d.bias_a != nullptr && tn == 0, want_b = d.bias_b != nullptr;   // uniform
+        // ---- bias strips of this wavefront -> LDS (summed over the wavefronts below).  bacc_a[i][q] of lane ln = sum_k A[k][m = 8 (4 (ln >> 4)
+        //      + q) + i], the same in all 16 columns: lanes with (ln & 15) == 0 write; bacc_b[j][q] = sum_k B[k][n0 + 4 (ln & 15) + j],
+        //      the same in all rows: lanes < 16 write row q = 0
+        if ((lane & 15) == 0) {
+    #pragma unroll
+            for (int i = 0; i < 8; ++i)
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) bred[w * 192 + 8 * (4 * g + q) + i] = bacc_a[i][q] * wsel;
+        }
+        if (lane < 16) {
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) bred[w * 192 + 128 + 4 * lane + j] = bacc_b[j][0] * wsel;
+        }
 
-    // ---- epilogue.  acc[i][j][q] of lane ln is output (m = 8 (4 (ln >> 4) + q) + i, n = n0 + 4 (ln & 15) + j).  Four
-    //      quarters h (two per pass through LDS, 16 KB per wavefront and pass), a float4 per (lane, register quad):
-    //        ct == 0: pass h = rows i in {2 h, 2 h + 1}, float4 over j       -> 16 bytes along n of C[m][n]
-    //        ct == 1: pass h = column j = h, float4 over i in {4 a .. 4 a + 3} -> 16 bytes along m of C[n][m]
-    float* const slab = slabs + (int64_t)(d.item_base + local) * W2_SLAB;
-    const bool direct = !ADAM && d.splits == 1;      // (the fused-optimizer kernel always goes through the slab)
-    const bool ct = d.ct != 0;
-    // where quad (f4, h) of the tile goes: offset into C of its first element, and how many of its four elements
-    // (consecutive in memory) exist
-    auto quad_addr = [&](const int f4, const int h, int& valid) __attribute__((always_inline)) -> int64_t {
-        const int il = f4 >> 8, q = (f4 >> 6) & 3, ln = f4 & 63;
-        const int rp = 4 * (ln >> 4) + q;
-        if (!ct) {
-            const int m = 8 * rp + 2 * h + il, n = n0 + 4 * (ln & 15);
-            valid = (m < d.M && n < d.N) ? min(4, d.N - n) : 0;
-            return (int64_t)m * d.ldc + n;
-        }
-        const int m = 8 * rp + 4 * il, n = n0 + 4 * (ln & 15) + h;
-        valid = (m < d.M && n < d.N) ? min(4, d.M - m) : 0;
-        return (int64_t)n * d.ldc + m;
-    };
-    auto store_c = [&](const int f4, const int h, const f32x4 v) {
-        const int il = f4 >> 8, q = (f4 >> 6) & 3, ln = f4 & 63;
-        const int rp = 4 * (ln >> 4) + q;
-        ERC_GLOBAL float* const Cg = (ERC_GLOBAL float*)d.C;
-        if (!ct) {
-            const int m = 8 * rp + 2 * h + il, n = n0 + 4 * (ln & 15);
-            if (m >= d.M || n >= d.N) return;
-            ERC_GLOBAL float* dst = Cg + (int64_t)m * d.ldc + n;
-            if (d.cvec && n + 3 < d.N) {
-                *(ERC_GLOBAL f32x4*)dst = v;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n + j < d.N) dst[j] = v[j];
+        // ---- epilogue.  acc[i][j][q] of lane ln is output (m = 8 (4 (ln >> 4) + q) + i, n = n0 + 4 (ln & 15) + j).  Four
+        //      quarters h (two per pass through LDS, 16 KB per wavefront and pass), a float4 per (lane, register quad):
+        //        ct == 0: pass h = rows i in {2 h, 2 h + 1}, float4 over j       -> 16 bytes along n of C[m][n]
+        //        ct == 1: pass h = column j = h, float4 over i in {4 a .. 4 a + 3} -> 16 bytes along m of C[n][m]
+        float* const slab = slabs + (int64_t)(d.item_base + tn * d.splits + split) * W2_SLAB;
+        const bool direct = !ADAM && d.splits == 1;      // (the fused-optimizer kernel always goes through the slab)
+        const bool ct = d.ct != 0;
+        // where quad (f4, h) of the tile goes: offset into C of its first element, and how many of its four elements
+        // (consecutive in memory) exist
+        auto quad_addr = [&](const int f4, const int h, int& valid) __attribute__((always_inline)) -> int64_t {
+            const int il = f4 >> 8, q = (f4 >> 6) & 3, ln = f4 & 63;
+            const int rp = 4 * (ln >> 4) + q;
+            if (!ct) {
+                const int m = 8 * rp + 2 * h + il, n = n0 + 4 * (ln & 15);
+                valid = (m < d.M && n < d.N) ? min(4, d.N - n) : 0;
+                return (int64_t)m * d.ldc + n;
             }
-        } else {
             const int m = 8 * rp + 4 * il, n = n0 + 4 * (ln & 15) + h;
-            if (m >= d.M || n >= d.N) return;
-            ERC_GLOBAL float* dst = Cg + (int64_t)n * d.ldc + m;
-            if (d.cvec && m + 3 < d.M) {
-                *(ERC_GLOBAL f32x4*)dst = v;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (m + i < d.M) dst[i] = v[i];
-            }
-        }
-    };
-#pragma unroll
-    for (int P = 0; P < 2; ++P) {      // two passes of 16 KB per wavefront: h = 2 P, 2 P + 1
-        __syncthreads();   // pass 0: idx[] / bred complete; pass 1: red reuse
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int il = 0; il < 2; ++il)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int h = 2 * P + hh;
-                    f32x4 v;
-                    if (!ct) v = (f32x4){acc[2 * h + il][0][q], acc[2 * h + il][1][q], acc[2 * h + il][2][q], acc[2 * h + il][3][q]};
-                    else v = (f32x4){acc[4 * il][h][q], acc[4 * il + 1][h][q], acc[4 * il + 2][h][q], acc[4 * il + 3][h][q]};
-                    *reinterpret_cast<f32x4*>(red + w * 4096 + (((hh * 2 + il) * 4 + q) * 64 + lane) * 4) = v;
+            valid = (m < d.M && n < d.N) ? min(4, d.M - m) : 0;
+            return (int64_t)n * d.ldc + m;
+        };
+        auto store_c = [&](const int f4, const int h, const f32x4 v) {
+            const int il = f4 >> 8, q = (f4 >> 6) & 3, ln = f4 & 63;
+            const int rp = 4 * (ln >> 4) + q;
+            ERC_GLOBAL float* const Cg = (ERC_GLOBAL float*)d.C;
+            if (!ct) {
+                const int m = 8 * rp + 2 * h + il, n = n0 + 4 * (ln & 15);
+                if (m >= d.M || n >= d.N) return;
+                ERC_GLOBAL float* dst = Cg + (int64_t)m * d.ldc + n;
+                if (d.cvec && n + 3 < d.N) {
+                    *(ERC_GLOBAL f32x4*)dst = v;
+                } else {
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < d.N) dst[j] = v[j];
                 }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int f4 = tid + 256 * u;      // quad (hh = u >> 1, il, q, lane) of this pass
-            f32x4 s = *reinterpret_cast<const f32x4*>(red + f4 * 4);
-#pragma unroll
-            for (int ww = 1; ww < 4; ++ww) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(red + ww * 4096 + f4 * 4);
-                s += t;
+            } else {
+                const int m = 8 * rp + 4 * il, n = n0 + 4 * (ln & 15) + h;
+                if (m >= d.M || n >= d.N) return;
+                ERC_GLOBAL float* dst = Cg + (int64_t)n * d.ldc + m;
+                if (d.cvec && m + 3 < d.M) {
+                    *(ERC_GLOBAL f32x4*)dst = v;
+                } else {
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (m + i < d.M) dst[i] = v[i];
+                }
             }
-            if (direct) {
-                store_c(tid + 256 * (u & 1), 2 * P + (u >> 1), s);
-            } else {  // slab layout [h][u & 1][thread] quads: one 16-byte write-through store per thread, 1 KB runs per wave instruction
-                st_sc1_x4(slab + ((4 * P + u) * 256 + tid) * 4, s);
+        };
+    #pragma unroll
+        for (int P = 0; P < 2; ++P) {      // two passes of 16 KB per wavefront: h = 2 P, 2 P + 1
+            __syncthreads();   // pass 0: idx[] / bred complete; pass 1: red reuse
+    #pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+    #pragma unroll
+                for (int il = 0; il < 2; ++il)
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int h = 2 * P + hh;
+                        // (both layouts as VALUES and a select: a branch made the compiler choose between pointers to accumulators,
+                        //  which parked six of them in scratch once this code sat inside a lambda)
+                        const f32x4 v_n = (f32x4){acc[2 * h + il][0][q], acc[2 * h + il][1][q], acc[2 * h + il][2][q], acc[2 * h + il][3][q]};
+                        const f32x4 v_t = (f32x4){acc[4 * il][h][q], acc[4 * il + 1][h][q], acc[4 * il + 2][h][q], acc[4 * il + 3][h][q]};
+                        const f32x4 v = ct ? v_t : v_n;
+                        *reinterpret_cast<f32x4*>(red + w * 4096 + (((hh * 2 + il) * 4 + q) * 64 + lane) * 4) = v * wsel;
+                    }
+            __syncthreads();
+    #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f4 = tid + 256 * u;      // quad (hh = u >> 1, il, q, lane) of this pass
+                f32x4 s = *reinterpret_cast<const f32x4*>(red + f4 * 4);
+    #pragma unroll
+                for (int ww = 1; ww < 4; ++ww) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(red + ww * 4096 + f4 * 4);
+                    s += t;
+                }
+                if (direct) {
+                    store_c(tid + 256 * (u & 1), 2 * P + (u >> 1), s);
+                } else {  // slab layout [h][u & 1][thread] quads: one 16-byte write-through store per thread, 1 KB runs per wave instruction
+                    st_sc1_x4(slab + ((4 * P + u) * 256 + tid) * 4, s);
+                }
             }
         }
-    }
-    if (tid < 192) {
-        const float v = ((bred[tid] + bred[192 + tid]) + bred[384 + tid]) + bred[576 + tid];
-        if (direct) {
+        if (tid < 192) {
+            const float v = ((bred[tid] + bred[192 + tid]) + bred[384 + tid]) + bred[576 + tid];
+            if (direct) {
+                if (tid < 128) {
+                    if (want_a && tid < d.M) ((ERC_GLOBAL float*)d.bias_a)[tid] = v;
+                } else if (want_b && n0 + tid - 128 < d.N) {
+                    ((ERC_GLOBAL float*)d.bias_b)[n0 + tid - 128] = v;
+                }
+            } else {
+                st_sc1(slab + 8192 + tid, v);
+            }
+        }
+        W2_STAMP(3);
+        if (direct) return;
+        if (ADAM) {
+            // ---- reduce-scatter among the S splits of the tile (see W2Adam).  S is a power of two <= 8 (host): this split owns
+            // the 8 / S quads x = split + S o of every thread, i.e. exactly 8 slab quads to fetch per thread.
+            const int S = d.splits, lgS = 31 - __builtin_clz(S), owned = 8 >> lgS;
+            const int64_t cbase = d.C - ad.grad;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this split's partial tile is in memory
+            __syncthreads();
+            W2_STAMP(4);
+            int* const counter = counters + d.tile_base + tn;
+            int seq = 0;
+            if (tid == 0) {
+                seq = ad.seq[blockIdx.x] + 1;
+                ad.seq[blockIdx.x] = seq;
+                __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tid == 64) copy_tab();
+            // while the other splits finish: this split's parameter / moment quads (they do not depend on anybody)
+            int64_t off[8];
+            int valid[8];
+            f32x4 pq[8], mq[8], vq[8];
+    #pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const int x = split + (o << lgS);
+                valid[o] = 0;
+                off[o] = cbase;
+                if (o < owned) {
+                    int vl;
+                    const int64_t a = cbase + quad_addr(tid + 256 * (x & 1), x >> 1, vl);
+                    valid[o] = (vl == 4 && d.cvec) ? 4 : -vl;       // > 0: one aligned quad; < 0: that many single elements
+                    if (vl) off[o] = a;
+                    const int64_t oc = valid[o] == 4 ? a : cbase;   // (unconditional loads)
+                    pq[o] = *(const ERC_GLOBAL f32x4*)(ad.data + oc), mq[o] = *(const ERC_GLOBAL f32x4*)(ad.m + oc), vq[o] = *(const ERC_GLOBAL f32x4*)(ad.v + oc);
+                }
+            }
+            // (split 0: the bias strip element of this thread, its parameter and moments)
+            float* bdst = nullptr;
+            if (split == 0 && tid < 192) {
+                if (tid < 128) {
+                    if (want_a && tid < d.M) bdst = d.bias_a + tid;
+                } else if (want_b && n0 + tid - 128 < d.N) {
+                    bdst = d.bias_b + (n0 + tid - 128);
+                }
+            }
+            const int64_t boff = bdst ? bdst - ad.grad : cbase;
+            float bp = ad.data[boff], bm = ad.m[boff], bv = ad.v[boff];
+            const bool skip = ad.skip && __hip_atomic_load(ad.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            adam_step = ad.state[4 + blockIdx.x] + 1;
+            adam_on = !skip;
+            ac.init(ad.lr, ad.b1, ad.b2, ad.eps, ad.wd, ad.decoupled, ad.grad_scale, adam_step);
+            if (tid == 0) {
+                int ok = 1, spins = 0;
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - S * seq < 0) {
+                    if (++spins > 2000000) {      // a split of this tile never arrived: this step's gradients are invalid
+                        __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                *s_flag = ok;
+            }
+            __syncthreads();
+            W2_STAMP(5);
+            bump_step();                    // (every thread read the step count in front of the barriers)
+            if (!*s_flag) return;
+            stamps = stamps_tile ? stamps_tile : stamps;
+            W2_STAMP(8);
+            const float* const tile_slabs = slabs + (int64_t)(d.item_base + tn * S) * W2_SLAB;
+            f32x4 part[8];      // load L: owned quad o = L / S, slab j = L % S
+    #pragma unroll
+            for (int L = 0; L < 8; ++L) {
+                const int x = split + ((L >> lgS) << lgS), jx = L & (S - 1);
+                part[L] = ld_sc1_x4(tile_slabs + (int64_t)jx * W2_SLAB + (x * 256 + tid) * 4);
+            }
+            float bt[8];      // the bias strip's S partial sums (slots >= S re-read the last slab and are masked)
+    #pragma unroll
+            for (int jj = 0; jj < 8; ++jj) bt[jj] = split == 0 ? ld_sc1(tile_slabs + (int64_t)min(jj, S - 1) * W2_SLAB + 8192 + (tid < 192 ? tid : 0)) : 0.f;
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7])
+                         :
+                         : "memory");
+            // the sums in split order (the left fold of the last arriver above: bit-identical gradients)
+            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+            f32x4 res[8];
+            if (S == 1) {
+    #pragma unroll
+                for (int o = 0; o < 8; ++o) res[o] = z + part[o];
+            } else if (S == 2) {
+    #pragma unroll
+                for (int o = 0; o < 8; ++o) res[o] = o < 4 ? (z + part[2 * (o & 3)]) + part[2 * (o & 3) + 1] : z;
+            } else if (S == 4) {
+    #pragma unroll
+                for (int o = 0; o < 8; ++o) res[o] = o < 2 ? (((z + part[4 * (o & 1)]) + part[4 * (o & 1) + 1]) + part[4 * (o & 1) + 2]) + part[4 * (o & 1) + 3] : z;
+            } else {
+                res[0] = (((((((z + part[0]) + part[1]) + part[2]) + part[3]) + part[4]) + part[5]) + part[6]) + part[7];
+    #pragma unroll
+                for (int o = 1; o < 8; ++o) res[o] = z;
+            }
+            W2_STAMP(9);
+            const bool upd = adam_on;
+            unsigned tmask = 0;      // shadow ranges that meet this record's gradient [cbase, cbase + rows * ldc)
+            {
+                const int64_t lo = cbase, hi = cbase + (int64_t)(ct ? d.N : d.M) * d.ldc;
+                const int nt = stab.n;
+                for (int t = 0; t < nt; ++t)
+                    if (stab.d[t].src_off < hi && stab.d[t].src_off + stab.d[t].n_el > lo) tmask |= 1u << t;
+            }
+            // One copy of the update code, executed `owned` times on element 0 of the register arrays, which are shifted down
+            // after every pass (8 unrolled copies with scalar fallbacks were 24 000 instructions of cold code: the instruction
+            // fetch, not the arithmetic, set the 4.3 us this phase took).  Quads are all-or-nothing here: the host only fuses
+            // records whose rows are multiples of 4 elements and 16-byte aligned.
+    #pragma unroll 1
+            for (int it = 0; it < owned; ++it) {
+                if (valid[0] == 4) {
+                    *(ERC_GLOBAL f32x4*)(ad.grad + off[0]) = res[0];
+                    if (upd) {
+                        const float4 pv = adam_quad(off[0], res[0], pq[0], mq[0], vq[0]);
+                        if (it == 0) W2_STAMP(13);
+                        if (ad.shadow) {
+                            const int nt = stab.n;
+    #pragma unroll 1
+                            for (int t = 0; t < nt; ++t) {
+                                if (!((tmask >> t) & 1)) continue;
+                                shadow_store4_desc(ad.shadow, stab.d[t], (stab.flags & (2 << t)) != 0, off[0], pv);
+                            }
+                        }
+                    }
+                } else if (valid[0] != 0) {      // (a record the host should not have fused)
+                    __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (it < 2) W2_STAMP(11 + it);
+    #pragma unroll
+                for (int o = 0; o < 7; ++o)
+                    res[o] = res[o + 1], pq[o] = pq[o + 1], mq[o] = mq[o + 1], vq[o] = vq[o + 1], off[o] = off[o + 1], valid[o] = valid[o + 1];
+            }
+            if (bdst) {      // bias strips: split 0 of the tile
+                float v = 0.f;
+    #pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v += bt[jj] * (jj < S ? 1.f : 0.f);
+                *(ERC_GLOBAL float*)bdst = v;
+                if (upd) {
+                    ac.upd(bp, v, bm, bv);
+                    ad.data[boff] = bp, ad.m[boff] = bm, ad.v[boff] = bv;
+                    if (ad.shadow) {
+                        const int nt = stab.n;
+    #pragma unroll 1
+                        for (int t = 0; t < nt; ++t) shadow_store_desc(ad.shadow, stab.d[t], boff, bp);
+                    }
+                }
+            }
+            W2_STAMP(10);
+            return;
+        }
+
+        // ---- publish the partial tile; the workgroup that arrives last adds the slabs in split order
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        W2_STAMP(4);
+        int* const counter = counters + d.tile_base + tn;
+        if (tid == 0) {
+            const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = prev == d.splits - 1;
+            if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+            *s_flag = last;
+        }
+        __syncthreads();
+        W2_STAMP(5);
+        if (!*s_flag) return;
+        stamps = stamps_tile;
+        W2_STAMP(8);
+        const float* const tile_slabs = slabs + (int64_t)(d.item_base + tn * d.splits) * W2_SLAB;
+        // the 8 quads of a thread, 4 splits per batch: 32 independent 16-byte loads in flight (the accumulators are dead by now).
+        // The wait is an asm statement that takes the results as in/out operands, so nothing that uses them can be scheduled in
+        // front of it (an asm statement takes at most 30 operands: two statements of 16).
+        f32x4 sum[8];
+    #pragma unroll
+        for (int x = 0; x < 8; ++x) sum[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int sp0 = 0; sp0 < d.splits; sp0 += 4) {
+            f32x4 v[4][8];
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* p = tile_slabs + (int64_t)min(sp0 + j, d.splits - 1) * W2_SLAB + tid * 4;
+    #pragma unroll
+                for (int x = 0; x < 8; ++x) v[j][x] = ld_sc1_x4(p + x * 1024);
+            }
+    #pragma unroll
+            for (int jj = 0; jj < 4; jj += 2)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(v[jj][0]), "+v"(v[jj][1]), "+v"(v[jj][2]), "+v"(v[jj][3]), "+v"(v[jj][4]), "+v"(v[jj][5]), "+v"(v[jj][6]),
+                               "+v"(v[jj][7]), "+v"(v[jj + 1][0]), "+v"(v[jj + 1][1]), "+v"(v[jj + 1][2]), "+v"(v[jj + 1][3]),
+                               "+v"(v[jj + 1][4]), "+v"(v[jj + 1][5]), "+v"(v[jj + 1][6]), "+v"(v[jj + 1][7])
+                             :
+                             : "memory");
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float mk = sp0 + j < d.splits ? 1.f : 0.f;
+    #pragma unroll
+                for (int x = 0; x < 8; ++x) sum[x] += v[j][x] * mk;
+            }
+        }
+        W2_STAMP(9);
+    #pragma unroll
+        for (int x = 0; x < 8; ++x) store_c(tid + 256 * (x & 1), x >> 1, sum[x]);
+        if (tid < 192) {
+            float v = 0.f;
+            for (int sp0 = 0; sp0 < d.splits; sp0 += 8) {
+                float t[8];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = ld_sc1(tile_slabs + (int64_t)min(sp0 + j, d.splits - 1) * W2_SLAB + 8192 + tid);
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) v += t[j] * (sp0 + j < d.splits ? 1.f : 0.f);
+            }
             if (tid < 128) {
                 if (want_a && tid < d.M) ((ERC_GLOBAL float*)d.bias_a)[tid] = v;
             } else if (want_b && n0 + tid - 128 < d.N) {
                 ((ERC_GLOBAL float*)d.bias_b)[n0 + tid - 128] = v;
             }
-        } else {
-            st_sc1(slab + 8192 + tid, v);
-        }
-    }
-    W2_STAMP(3);
-    if (direct) return;
-    if (ADAM) {
-        // ---- reduce-scatter among the S splits of the tile (see W2Adam).  S is a power of two <= 8 (host): this split owns
-        // the 8 / S quads x = split + S o of every thread, i.e. exactly 8 slab quads to fetch per thread.
-        const int S = d.splits, lgS = 31 - __builtin_clz(S), owned = 8 >> lgS;
-        const int64_t cbase = d.C - ad.grad;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this split's partial tile is in memory
-        __syncthreads();
-        W2_STAMP(4);
-        int* const counter = counters + d.tile_base + tn;
-        int seq = 0;
-        if (tid == 0) {
-            seq = ad.seq[blockIdx.x] + 1;
-            ad.seq[blockIdx.x] = seq;
-            __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (tid == 64) copy_tab();
-        // while the other splits finish: this split's parameter / moment quads (they do not depend on anybody)
-        int64_t off[8];
-        int valid[8];
-        f32x4 pq[8], mq[8], vq[8];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const int x = split + (o << lgS);
-            valid[o] = 0;
-            off[o] = cbase;
-            if (o < owned) {
-                int vl;
-                const int64_t a = cbase + quad_addr(tid + 256 * (x & 1), x >> 1, vl);
-                valid[o] = (vl == 4 && d.cvec) ? 4 : -vl;       // > 0: one aligned quad; < 0: that many single elements
-                if (vl) off[o] = a;
-                const int64_t oc = valid[o] == 4 ? a : cbase;   // (unconditional loads)
-                pq[o] = *(const ERC_GLOBAL f32x4*)(ad.data + oc), mq[o] = *(const ERC_GLOBAL f32x4*)(ad.m + oc), vq[o] = *(const ERC_GLOBAL f32x4*)(ad.v + oc);
-            }
-        }
-        // (split 0: the bias strip element of this thread, its parameter and moments)
-        float* bdst = nullptr;
-        if (split == 0 && tid < 192) {
-            if (tid < 128) {
-                if (want_a && tid < d.M) bdst = d.bias_a + tid;
-            } else if (want_b && n0 + tid - 128 < d.N) {
-                bdst = d.bias_b + (n0 + tid - 128);
-            }
-        }
-        const int64_t boff = bdst ? bdst - ad.grad : cbase;
-        float bp = ad.data[boff], bm = ad.m[boff], bv = ad.v[boff];
-        const bool skip = ad.skip && __hip_atomic_load(ad.skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        adam_step = ad.state[4 + blockIdx.x] + 1;
-        adam_on = !skip;
-        ac.init(ad.lr, ad.b1, ad.b2, ad.eps, ad.wd, ad.decoupled, ad.grad_scale, adam_step);
-        if (tid == 0) {
-            int ok = 1, spins = 0;
-            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - S * seq < 0) {
-                if (++spins > 2000000) {      // a split of this tile never arrived: this step's gradients are invalid
-                    __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            *s_flag = ok;
-        }
-        __syncthreads();
-        W2_STAMP(5);
-        bump_step();                    // (every thread read the step count in front of the barriers)
-        if (!*s_flag) return;
-        stamps = stamps_tile ? stamps_tile : stamps;
-        W2_STAMP(8);
-        const float* const tile_slabs = slabs + (int64_t)(d.item_base + tn * S) * W2_SLAB;
-        f32x4 part[8];      // load L: owned quad o = L / S, slab j = L % S
-#pragma unroll
-        for (int L = 0; L < 8; ++L) {
-            const int x = split + ((L >> lgS) << lgS), jx = L & (S - 1);
-            part[L] = ld_sc1_x4(tile_slabs + (int64_t)jx * W2_SLAB + (x * 256 + tid) * 4);
-        }
-        float bt[8];      // the bias strip's S partial sums (slots >= S re-read the last slab and are masked)
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) bt[jj] = split == 0 ? ld_sc1(tile_slabs + (int64_t)min(jj, S - 1) * W2_SLAB + 8192 + (tid < 192 ? tid : 0)) : 0.f;
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7])
-                     :
-                     : "memory");
-        // the sums in split order (the left fold of the last arriver above: bit-identical gradients)
-        const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 res[8];
-        if (S == 1) {
-#pragma unroll
-            for (int o = 0; o < 8; ++o) res[o] = z + part[o];
-        } else if (S == 2) {
-#pragma unroll
-            for (int o = 0; o < 8; ++o) res[o] = o < 4 ? (z + part[2 * (o & 3)]) + part[2 * (o & 3) + 1] : z;
-        } else if (S == 4) {
-#pragma unroll
-            for (int o = 0; o < 8; ++o) res[o] = o < 2 ? (((z + part[4 * (o & 1)]) + part[4 * (o & 1) + 1]) + part[4 * (o & 1) + 2]) + part[4 * (o & 1) + 3] : z;
-        } else {
-            res[0] = (((((((z + part[0]) + part[1]) + part[2]) + part[3]) + part[4]) + part[5]) + part[6]) + part[7];
-#pragma unroll
-            for (int o = 1; o < 8; ++o) res[o] = z;
-        }
-        W2_STAMP(9);
-        const bool upd = adam_on;
-        unsigned tmask = 0;      // shadow ranges that meet this record's gradient [cbase, cbase + rows * ldc)
-        {
-            const int64_t lo = cbase, hi = cbase + (int64_t)(ct ? d.N : d.M) * d.ldc;
-            const int nt = stab.n;
-            for (int t = 0; t < nt; ++t)
-                if (stab.d[t].src_off < hi && stab.d[t].src_off + stab.d[t].n_el > lo) tmask |= 1u << t;
-        }
-        // One copy of the update code, executed `owned` times on element 0 of the register arrays, which are shifted down
-        // after every pass (8 unrolled copies with scalar fallbacks were 24 000 instructions of cold code: the instruction
-        // fetch, not the arithmetic, set the 4.3 us this phase took).  Quads are all-or-nothing here: the host only fuses
-        // records whose rows are multiples of 4 elements and 16-byte aligned.
-#pragma unroll 1
-        for (int it = 0; it < owned; ++it) {
-            if (valid[0] == 4) {
-                *(ERC_GLOBAL f32x4*)(ad.grad + off[0]) = res[0];
-                if (upd) {
-                    const float4 pv = adam_quad(off[0], res[0], pq[0], mq[0], vq[0]);
-                    if (it == 0) W2_STAMP(13);
-                    if (ad.shadow) {
-                        const int nt = stab.n;
-#pragma unroll 1
-                        for (int t = 0; t < nt; ++t) {
-                            if (!((tmask >> t) & 1)) continue;
-                            shadow_store4_desc(ad.shadow, stab.d[t], (stab.flags & (2 << t)) != 0, off[0], pv);
-                        }
-                    }
-                }
-            } else if (valid[0] != 0) {      // (a record the host should not have fused)
-                __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (it < 2) W2_STAMP(11 + it);
-#pragma unroll
-            for (int o = 0; o < 7; ++o)
-                res[o] = res[o + 1], pq[o] = pq[o + 1], mq[o] = mq[o + 1], vq[o] = vq[o + 1], off[o] = off[o + 1], valid[o] = valid[o + 1];
-        }
-        if (bdst) {      // bias strips: split 0 of the tile
-            float v = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) v += bt[jj] * (jj < S ? 1.f : 0.f);
-            *(ERC_GLOBAL float*)bdst = v;
-            if (upd) {
-                ac.upd(bp, v, bm, bv);
-                ad.data[boff] = bp, ad.m[boff] = bm, ad.v[boff] = bv;
-                if (ad.shadow) {
-                    const int nt = stab.n;
-#pragma unroll 1
-                    for (int t = 0; t < nt; ++t) shadow_store_desc(ad.shadow, stab.d[t], boff, bp);
-                }
-            }
         }
         W2_STAMP(10);
-        return;
-    }
-
-    // ---- publish the partial tile; the workgroup that arrives last adds the slabs in split order
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    W2_STAMP(4);
-    int* const counter = counters + d.tile_base + tn;
-    if (tid == 0) {
-        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = prev == d.splits - 1;
-        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        *s_flag = last;
-    }
-    __syncthreads();
-    W2_STAMP(5);
-    if (!*s_flag) return;
-    stamps = stamps_tile;
-    W2_STAMP(8);
-    const float* const tile_slabs = slabs + (int64_t)(d.item_base + tn * d.splits) * W2_SLAB;
-    // the 8 quads of a thread, 4 splits per batch: 32 independent 16-byte loads in flight (the accumulators are dead by now).
-    // The wait is an asm statement that takes the results as in/out operands, so nothing that uses them can be scheduled in
-    // front of it (an asm statement takes at most 30 operands: two statements of 16).
-    f32x4 sum[8];
-#pragma unroll
-    for (int x = 0; x < 8; ++x) sum[x] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int sp0 = 0; sp0 < d.splits; sp0 += 4) {
-        f32x4 v[4][8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float* p = tile_slabs + (int64_t)min(sp0 + j, d.splits - 1) * W2_SLAB + tid * 4;
-#pragma unroll
-            for (int x = 0; x < 8; ++x) v[j][x] = ld_sc1_x4(p + x * 1024);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; jj += 2)
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(v[jj][0]), "+v"(v[jj][1]), "+v"(v[jj][2]), "+v"(v[jj][3]), "+v"(v[jj][4]), "+v"(v[jj][5]), "+v"(v[jj][6]),
-                           "+v"(v[jj][7]), "+v"(v[jj + 1][0]), "+v"(v[jj + 1][1]), "+v"(v[jj + 1][2]), "+v"(v[jj + 1][3]),
-                           "+v"(v[jj + 1][4]), "+v"(v[jj + 1][5]), "+v"(v[jj + 1][6]), "+v"(v[jj + 1][7])
-                         :
-                         : "memory");
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float mk = sp0 + j < d.splits ? 1.f : 0.f;
-#pragma unroll
-            for (int x = 0; x < 8; ++x) sum[x] += v[j][x] * mk;
+    };
+    if (!WIDE) {
+        finish(tn, 1.f);
+    } else {
+        const int tg = 4 * (local / d.splits);
+        for (int t = 0; t < 4 && tg + t < d.tiles_n; ++t) {
+            if (t) __syncthreads();        // the previous tile's readers of red / bred / s_flag are done
+            finish(tg + t, w == t ? 1.f : 0.f);
         }
     }
-    W2_STAMP(9);
-#pragma unroll
-    for (int x = 0; x < 8; ++x) store_c(tid + 256 * (x & 1), x >> 1, sum[x]);
-    if (tid < 192) {
-        float v = 0.f;
-        for (int sp0 = 0; sp0 < d.splits; sp0 += 8) {
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = ld_sc1(tile_slabs + (int64_t)min(sp0 + j, d.splits - 1) * W2_SLAB + 8192 + tid);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v += t[j] * (sp0 + j < d.splits ? 1.f : 0.f);
-        }
-        if (tid < 128) {
-            if (want_a && tid < d.M) ((ERC_GLOBAL float*)d.bias_a)[tid] = v;
-        } else if (want_b && n0 + tid - 128 < d.N) {
-            ((ERC_GLOBAL float*)d.bias_b)[n0 + tid - 128] = v;
-        }
-    }
-    W2_STAMP(10);
 }
 
 struct W2Bases {  // first work item of every descriptor, passed by value (no dependent table reads to find one's descriptor)
     int v[W2_MAX_DESC];
 };
 
-template <bool ADAM>
+template <bool ADAM, bool WIDE>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const W2Desc* __restrict__ table, const int n_desc, const W2Bases bases,
                                                          float* slabs, int* counters, uint64_t* stamps, int stamp_item, const W2Adam ad) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4096];   // 64 KB: two reduction passes
@@ -691,11 +715,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const W2Desc* __restric
     for (int t = 1; t < W2_MAX_DESC; ++t)
         if (t < n_desc && L >= bases.v[t]) di = t;
     const W2Desc d = table[di];
-    const int local = L - d.item_base;
+    const int local = L - bases.v[di];      // (WIDE: a workgroup covers four column tiles -- item_base counts slabs, bases workgroups)
     if (local >= d.n_items) return;
     // (stamp_item is a work item of record 0)
     const bool st_item = stamps && L == stamp_item, st_tile = stamps && di == 0 && local / d.splits == stamp_item / d.splits;
-    w2_body<ADAM>(d, local, red, bred, idx, &s_flag, slabs, counters, st_item ? stamps : nullptr, st_tile ? stamps : nullptr, ad);
+    w2_body<ADAM, WIDE>(d, local, red, bred, idx, &s_flag, slabs, counters, st_item ? stamps : nullptr, st_tile ? stamps : nullptr, ad);
 }
 
 }  // namespace
@@ -713,7 +737,7 @@ extern "C" int erc_wgrad_bf16_max_k_per_split(void) { return W2_IDX_CAP; }
 // table: n_desc W2Desc records (device memory, <= 16); item_base: HOST array of the records' item_base fields; n_items = sum
 // of tiles * splits; slabs: n_items * erc_wgrad_bf16_slab_floats() floats; counters: one zero-initialised int32 per output
 // tile (left zero by the launch).
-static int w2_launch(bool adam, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs, int32_t* counters,
+static int w2_launch(int mode, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs, int32_t* counters,
                      const W2Adam& ad, void* stream) {
     ERC_REQUIRE(table && item_base && n_desc > 0 && n_desc <= W2_MAX_DESC && n_items > 0 && slabs && counters,
                 "wgrad_bf16: bad arguments (at most %d records per launch)", W2_MAX_DESC);
@@ -723,12 +747,15 @@ static int w2_launch(bool adam, const void* table, int n_desc, const int32_t* it
                     "wgrad_bf16: item_base[%d] = %d", t, item_base[t]);
         bases.v[t] = item_base[t];
     }
-    if (adam)
-        hipLaunchKernelGGL(wgrad_bf16_kernel<true>, dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc, bases,
-                           slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
+    if (mode == 1)
+        hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
+                           bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
+    else if (mode == 2)
+        hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
+                           bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
     else
-        hipLaunchKernelGGL(wgrad_bf16_kernel<false>, dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc, bases,
-                           slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
+        hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
+                           bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
     ERC_LAUNCH_CHECK("wgrad_bf16");
     return ERC_OK;
 }
@@ -736,7 +763,17 @@ static int w2_launch(bool adam, const void* table, int n_desc, const int32_t* it
 extern "C" int erc_wgrad_bf16(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
                               int32_t* counters, void* stream) {
     W2Adam ad{};
-    return w2_launch(false, table, n_desc, item_base, n_items, slabs, counters, ad, stream);
+    return w2_launch(0, table, n_desc, item_base, n_items, slabs, counters, ad, stream);
+}
+
+// The same products for LARGE K (N = 33 k nodes at B = 512): a workgroup's four wavefronts take four neighbouring column tiles
+// over the same k-steps instead of splitting K (see w2_body).  wg_base: HOST array, first workgroup of every record
+// (ceil(tiles_n / 4) * splits workgroups per record); the records' item_base / n_items fields = first slab (tiles_n * splits
+// slabs per record) / number of workgroups; n_wgs = total workgroups; slabs and counters as erc_wgrad_bf16.
+extern "C" int erc_wgrad_bf16_wide(const void* table, int n_desc, const int32_t* wg_base, int n_wgs, float* slabs, int32_t* counters,
+                                   void* stream) {
+    W2Adam ad{};
+    return w2_launch(2, table, n_desc, wg_base, n_wgs, slabs, counters, ad, stream);
 }
 
 // erc_wgrad_bf16 with the optimizer fused in (W2Adam above): every record's C / bias_a / bias_b must point into g[0, n);
@@ -773,5 +810,5 @@ extern "C" int erc_wgrad_bf16_adam(const void* table, int n_desc, const int32_t*
     }
     (void)shadow_numel;     // (bounds-checked against the buffer by erc_shadow_refresh / erc_adam_step_tab when the table was built)
     ad.shadow = ad.tab.n > 0 ? (unsigned short*)shadow_base : nullptr;
-    return w2_launch(true, table, n_desc, item_base, n_items, slabs, counters, ad, stream);
+    return w2_launch(1, table, n_desc, item_base, n_items, slabs, counters, ad, stream);
 }

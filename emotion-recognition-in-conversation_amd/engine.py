@@ -259,9 +259,15 @@ class GemmPlanner:
         key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, ct, g.data_ptr() if g is not None else 0,
                      kd.data_ptr() if kd is not None else 0) for a, _, b, _, c, _, M, N, K, ct, _, _, g, kd in self.deferred16) + \
             ((tuple((r.data_ptr(), r.numel()) for r in self.ranges16), ) if fuse else ())
+        # large K (B = 512: N = 33 k): the wide form -- a workgroup's four wavefronts take four neighbouring column tiles over the
+        # same k-steps, the A operand reaches a CU once per four tiles (csrc/wgrad_bf16.hip WIDE)
+        wide = max(d[8] for d in self.deferred16) > int(os.environ.get("ERC_W2_WIDE_K", 8192))
+        fuse = fuse and not wide
         if cache.get("w16_key") != key:
             cap = capi.wgrad_bf16_max_k_per_split()
             tiles = sum(-(-d[7] // 64) for d in self.deferred16)
+            if wide:
+                tiles = sum(-(-(-(-d[7] // 64)) // 4) for d in self.deferred16)      # workgroups per split
             K = max(d[8] for d in self.deferred16)
             # one 4-wavefront workgroup per CU (428 registers per lane): while every item of the launch is resident at once
             # (<= 256), as many splits as that allows; beyond, ~ERC_W2_ROWS k per item
@@ -275,7 +281,9 @@ class GemmPlanner:
             cand = [sp for sp in (1, 2, 4, 8) if sp <= s_max] if fuse else range(1, s_max + 1)
             splits = min(cand, key=lambda sp: (groups(sp), sp))
             splits = max(splits, min(32, -(-K // rows)), -(-K // cap))
-            raw, items, n_tiles, bases, sps, whole_quads = [], 0, 0, [], set(), True
+            if wide:
+                splits = max(-(-K // cap), max(1, min(32, 256 // tiles)))
+            raw, items, n_tiles, bases, sps, whole_quads, wgs = [], 0, 0, [], set(), True, 0
             for a, lda, b, ldb, c, ldc, M, N, Kr, ct, ba, bb, g, kd in self.deferred16:
                 nks = -(-Kr // 4)
                 per = -(-nks // splits)
@@ -284,11 +292,13 @@ class GemmPlanner:
                     raise capi.ErcGraftError("bf16 wgrad: K=%d needs more than %d splits" % (Kr, splits))
                 tn = -(-N // 64)
                 cvec = int(c.data_ptr() % 16 == 0 and ldc % 4 == 0)
+                n_wg = -(-tn // 4) * sp if wide else tn * sp      # workgroups of the record (its slabs: tn * sp either way)
                 raw.append(struct.pack("<QQQQQQQ14i", a.data_ptr(), b.data_ptr(), c.data_ptr(),
                                        ba.data_ptr() if ba is not None else 0, bb.data_ptr() if bb is not None else 0,
                                        g.data_ptr() if g is not None else 0, kd.data_ptr() if kd is not None else 0,
-                                       lda, ldb, ldc, M, N, Kr, int(ct), cvec, sp, tn, items, tn * sp, n_tiles, 0))
-                bases.append(items)
+                                       lda, ldb, ldc, M, N, Kr, int(ct), cvec, sp, tn, items, n_wg, n_tiles, 0))
+                bases.append(wgs if wide else items)
+                wgs += n_wg
                 sps.add(sp)
                 whole_quads = whole_quads and bool(cvec) and (M if ct else N) % 4 == 0
                 items += tn * sp
@@ -310,7 +320,7 @@ class GemmPlanner:
             cache["w16_table"] = torch.frombuffer(bytearray(b"".join(raw)), dtype=torch.uint8).to(self.device)
             cache["w16_slabs"] = torch.empty(items * capi.wgrad_bf16_slab_floats(), dtype=torch.float32, device=self.device)
             cache["w16_counters"] = torch.zeros(n_tiles + 512, dtype=torch.int32, device=self.device)
-            cache["w16_items"] = items
+            cache["w16_items"] = wgs if wide else items
             cache["w16_bases"] = (ctypes.c_int32 * len(bases))(*bases)
             cache["w16_key"] = key
         if fuse and cache["w16_fused"]:
@@ -321,8 +331,8 @@ class GemmPlanner:
                                  opt.skip_flag)
             self.adam_fused = True
             return
-        capi.wgrad_bf16(cache["w16_table"], cache["w16_records"], cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
-                        cache["w16_counters"])
+        (capi.wgrad_bf16_wide if wide else capi.wgrad_bf16)(cache["w16_table"], cache["w16_records"], cache["w16_bases"],
+                                                            cache["w16_items"], cache["w16_slabs"], cache["w16_counters"])
 
     def split_for(self, M, N, K, bk=None, min_chunks=None):
         if N <= 1025 and bk is None:

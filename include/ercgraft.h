@@ -150,6 +150,12 @@ int erc_wgrad_table_x3(const void* table, int n_desc, const int32_t* item_base, 
  * ceil(N / 64); n_items = tiles_n * splits; K / splits <= erc_wgrad_bf16_max_k_per_split(); at most 16 records. */
 int erc_wgrad_bf16(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs, int32_t* counters,
                    void* stream);
+/* The same for LARGE K (N = 33 k nodes at B = 512): a workgroup's four wavefronts take four neighbouring column tiles over the
+ * same k-steps instead of splitting K, so an A row reaches the CU once per four tiles.  wg_base: HOST array, first workgroup
+ * of every record (ceil(tiles_n / 4) * splits each); in the records item_base = first SLAB (tiles_n * splits slabs per record)
+ * and n_items = the record's number of workgroups; n_wgs = total workgroups. */
+int erc_wgrad_bf16_wide(const void* table, int n_desc, const int32_t* wg_base, int n_wgs, float* slabs, int32_t* counters,
+                        void* stream);
 int64_t erc_wgrad_bf16_slab_floats(void);
 /* diagnostic: phase stamps (10 ns ticks) of work item `item` (of record 0) of the following erc_wgrad_bf16 launches,
  * 16 x uint64 device memory; NULL switches them off (tools/wgrad_stamps.py) */
