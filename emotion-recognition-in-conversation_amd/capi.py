@@ -55,6 +55,7 @@ _SIGS = {
     "erc_wgrad_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16_adam": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp,
                                       _i64, _vp, _vp, _vp]),
+    "erc_wgrad_bf16_set_spin_limit": (C.c_int, [_i]),
     "erc_wgrad_bf16_wide": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16_slab_floats": (C.c_int64, []),
     "erc_wgrad_bf16_set_stamps": (C.c_int, [_vp, _i]),
@@ -90,7 +91,7 @@ _SIGS = {
                                  + [_vp] * 11 + [_vp, _vp]),
     "erc_head_set_stamps": (C.c_int, [_vp]),
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
-                                      _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp]),
+                                      _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "erc_head_fused_part_floats": (C.c_int, []),
@@ -524,12 +525,12 @@ def cogmen_fwd_tile_ws_doubles(n):
 
 def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, inv_cnt, H1b, ldh1b, QKVS, H2, ldh2, alpha,
                     bn_fused=False, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, saved=None, bn_ws=None,
-                    n_speakers=2, n_dev=None):
+                    n_speakers=2, n_dev=None, health=None, events=None):
     _check(lib().erc_cogmen_fwd_tile(ptr(H0), ldh0, N, wp, wf, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
                                      ptr(WcatT), ptr(b1), ptr(Wq), ptr(bq), scale, ptr(Mb), ldmb, ptr(inv_cnt), ptr(H1b),
                                      ldh1b, ptr(QKVS), ptr(H2), ldh2, ptr(alpha), int(bn_fused), ptr(running_mean),
                                      ptr(running_var), momentum, eps, ptr(saved), ptr(bn_ws), ptr(g["node_spk"]), n_speakers,
-                                     ptr(n_dev), stream()),
+                                     ptr(n_dev), ptr(health), ptr(events), stream()),
            "erc_cogmen_fwd_tile")
 
 
@@ -972,6 +973,10 @@ def wgrad_bf16_adam(table, n_desc, item_base, n_items, slabs, counters, n_tiles,
 def wgrad_bf16_wide(table, n_desc, wg_base, n_wgs, slabs, counters):
     """erc_wgrad_bf16 for large K: four neighbouring column tiles per workgroup (ercgraft.h)"""
     _check(lib().erc_wgrad_bf16_wide(ptr(table), n_desc, wg_base, n_wgs, ptr(slabs), ptr(counters), stream()), "erc_wgrad_bf16_wide")
+
+
+def wgrad_bf16_set_spin_limit(limit):
+    _check(lib().erc_wgrad_bf16_set_spin_limit(int(limit)), "erc_wgrad_bf16_set_spin_limit")
 
 
 def wgrad_bf16_set_stamps(t, item=0):

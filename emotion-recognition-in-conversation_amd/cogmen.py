@@ -303,7 +303,8 @@ class COGMENModule(nn.Module):
                                  fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], PM, ws["inv_cnt"],
                                  ws["H1b"], PA, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=2 if ws["bn_in_tile"] else 0,
                                  running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum,
-                                 eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=self.n_speakers, n_dev=nd)
+                                 eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=self.n_speakers, n_dev=nd,
+                                 health=fp.health if training else None, events=fp.events if training else None)
             if upto_h2:
                 return ws
             return self._forward_tail(ws, N, training)
@@ -338,6 +339,12 @@ class COGMENModule(nn.Module):
                    act=3 if p > 0 else 1, drop_p=p, rng=self.rng_state)
         linear_fwd(pl, ws["Z"], F, None, fp.w("cls.3.weight"), fp.w("cls.3.bias"), ws["logits"], C, N, C, F)
         return ws
+
+    def check_cluster(self):
+        """Raise if a bounded wait between cooperating workgroups timed out since the last call: the splits of a gradient tile
+        in the weight-gradient launch with the optimizer inside (csrc/wgrad_bf16.hip), or the peer-to-peer gradient exchange
+        (csrc/optim.hip).  The affected steps' updates were skipped on the device; trainer.run calls this once per epoch."""
+        self.flat.check_health("COGMEN weight-gradient / optimizer launch")
 
     def forward(self, input_tensor, speaker_tensor, text_length, *args, label=None, **kwargs):
         if self.flat is None:

@@ -141,11 +141,19 @@ struct CgFwdP {
     float momentum, eps, scale;
     int N, ldh0, ldmb, ldh1b, ldh2, bn_fused, two_spk;
     const int32_t* n_dev;          // capacity mode: the true node count lives on the device (N is the capacity the grid is sized for)
+    int32_t* health;               // training step: the health word (erc_health_roll's contract) and its event counter, or null --
+    int32_t* events;               //   this launch is the first of the step that may precede a reader of the word
     uint64_t* stamps;
     int stamp_block;
 };
 
 __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p) {
+    // erc_health_roll folded into this launch: a word the PREVIOUS step left raised (its update was skipped) becomes one counted
+    // event and is cleared, before any launch of this step reads it (the weight-gradient / optimizer launches further down)
+    if (p.health && blockIdx.x == 0 && threadIdx.x == 0 && *p.health != 0) {
+        p.events[0] += 1;
+        *p.health = 0;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned short* const sM = reinterpret_cast<unsigned short*>(lds + FW_SM_OFF);
     float* const sQ = reinterpret_cast<float*>(lds + FW_SM_OFF);       // aliases sM (after the H1 product)
@@ -1133,9 +1141,11 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
                                    const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
                                    int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
                                    float* running_mean, float* running_var, float momentum, float eps, float* saved,
-                                   double* bn_ws, const int32_t* node_spk, int n_speakers, const int32_t* n_dev, void* stream) {
+                                   double* bn_ws, const int32_t* node_spk, int n_speakers, const int32_t* n_dev, int32_t* health,
+                                   int32_t* events, void* stream) {
     ERC_REQUIRE(H0 && in_ptr && in_src && in_typ && WcatT && b1 && Wq && bq && Mb && inv_cnt && H1b && QKVS && H2 && alpha && node_spk,
                 "cogmen_fwd_tile: null pointer");
+    ERC_REQUIRE(!health == !events, "cogmen_fwd_tile: health and events come together");
     ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_fwd_tile: window (%d, %d) exceeds the halo %d",
                 wp, wf, CG_HL);
     ERC_REQUIRE(ldh0 >= CG_F && ldh0 % 4 == 0 && ((uintptr_t)H0 & 15) == 0 && ldmb >= CG_KM && ldmb % 2 == 0 && ((uintptr_t)Mb & 3) == 0 && ldh1b >= CG_F &&
@@ -1156,6 +1166,7 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
     p.momentum = momentum; p.eps = eps; p.scale = scale;
     p.N = n_nodes; p.ldh0 = ldh0; p.ldmb = ldmb; p.ldh1b = ldh1b; p.ldh2 = ldh2; p.bn_fused = bn_fused;
     p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0; p.n_dev = n_dev;
+    p.health = health, p.events = events;
     p.stamps = g_cg_stamps; p.stamp_block = tiles / 2;
     hipLaunchKernelGGL(cogmen_fwd_tile_kernel, dim3(tiles), dim3(CG_NTH), FW_LDS, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("cogmen_fwd_tile");

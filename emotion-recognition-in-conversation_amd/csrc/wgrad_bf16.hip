@@ -66,7 +66,7 @@ struct W2Desc {  // 112 bytes; mirrored by engine.GemmPlanner.flush_wgrads_bf16 
 // the slab sums over S times as many threads, and the optimizer launch (9.8 us + a launch gap of a 96 us step) is gone.
 // Every workgroup keeps private copies of the step count (state[4 + b], as adam_kernel) and of the launch sequence number.
 struct W2Adam {
-    int decoupled, pad;
+    int decoupled, spin_limit;     // spin_limit: bound of the wait for a tile's splits (test hook: erc_wgrad_bf16_set_spin_limit)
     float lr, b1, b2, eps, wd, grad_scale;
     float *data, *grad, *m, *v;
     int64_t* state;
@@ -519,7 +519,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
             if (tid == 0) {
                 int ok = 1, spins = 0;
                 while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - S * seq < 0) {
-                    if (++spins > 2000000) {      // a split of this tile never arrived: this step's gradients are invalid
+                    if (++spins >= ad.spin_limit) {      // a split of this tile never arrived: this step's gradients are invalid
                         __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok = 0;
                         break;
@@ -734,6 +734,14 @@ extern "C" int erc_wgrad_bf16_set_stamps(uint64_t* stamps, int item) {
 extern "C" int64_t erc_wgrad_bf16_slab_floats(void) { return W2_SLAB; }
 extern "C" int erc_wgrad_bf16_max_k_per_split(void) { return W2_IDX_CAP; }
 
+static int g_w2_spin_limit = 2000000;
+// test hook: bound of the fused-optimizer launch's wait for a tile's splits (<= 0 restores the default).  With a bound of 1
+// the first wait that is not satisfied at once raises the health word: the timeout path end to end (tests/test_gpu_cogmen.py).
+extern "C" int erc_wgrad_bf16_set_spin_limit(int limit) {
+    g_w2_spin_limit = limit > 0 ? limit : 2000000;
+    return ERC_OK;
+}
+
 // table: n_desc W2Desc records (device memory, <= 16); item_base: HOST array of the records' item_base fields; n_items = sum
 // of tiles * splits; slabs: n_items * erc_wgrad_bf16_slab_floats() floats; counters: one zero-initialised int32 per output
 // tile (left zero by the launch).
@@ -794,6 +802,7 @@ extern "C" int erc_wgrad_bf16_adam(const void* table, int n_desc, const int32_t*
     ad.decoupled = decoupled, ad.lr = lr, ad.b1 = beta1, ad.b2 = beta2, ad.eps = eps, ad.wd = weight_decay;
     ad.grad_scale = grad_scale, ad.data = p, ad.grad = g, ad.m = m, ad.v = v, ad.state = state, ad.skip = health, ad.health = health;
     ad.seq = counters + n_tiles;
+    ad.spin_limit = g_w2_spin_limit;
     if (tab_host) memcpy(&ad.tab, tab_host, sizeof(ad.tab));
     ERC_REQUIRE(ad.tab.n == 0 || shadow_base, "wgrad_bf16_adam: shadow table without a shadow buffer");
     ERC_REQUIRE(ad.tab.n >= 0 && ad.tab.n <= SHADOW_MAX, "wgrad_bf16_adam: %d shadow descriptors", ad.tab.n);

@@ -150,6 +150,8 @@ int erc_wgrad_table_x3(const void* table, int n_desc, const int32_t* item_base, 
  * ceil(N / 64); n_items = tiles_n * splits; K / splits <= erc_wgrad_bf16_max_k_per_split(); at most 16 records. */
 int erc_wgrad_bf16(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs, int32_t* counters,
                    void* stream);
+/* test hook: bound of erc_wgrad_bf16_adam's wait for a tile's splits (<= 0: default); 1 = the first unsatisfied wait times out */
+int erc_wgrad_bf16_set_spin_limit(int limit);
 /* The same for LARGE K (N = 33 k nodes at B = 512): a workgroup's four wavefronts take four neighbouring column tiles over the
  * same k-steps instead of splitting K, so an A row reaches the CU once per four tiles.  wg_base: HOST array, first workgroup
  * of every record (ceil(tiles_n / 4) * splits each); in the records item_base = first SLAB (tiles_n * splits slabs per record)
@@ -455,15 +457,17 @@ int erc_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
  * bn_fused = 1: also the training-mode BatchNorm statistics of H2 (saved = mean | rstd, running statistics updated)
  * by the last workgroup to arrive; bn_fused = 2: only the per-tile column sums, as floats [tiles][200] from bn_ws + 2
  * doubles on (= the bn_part operand of erc_head_fused_bn, which finalises them without a last arriver);
- * bn_ws = erc_cogmen_fwd_tile_ws_doubles(N) doubles, zero before the first call. */
+ * bn_ws = erc_cogmen_fwd_tile_ws_doubles(N) doubles, zero before the first call.
+ * health / events (both or neither): erc_health_roll folded into this launch -- the first of a training step that precedes
+ * a reader of the health word (erc_wgrad_bf16_adam, erc_adam_step*). */
 int64_t erc_cogmen_fwd_tile_ws_doubles(int n_nodes);
 int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int wp, int wf, const int32_t* in_ptr,
                         const int32_t* in_src, const int32_t* in_typ, const void* WcatT, const float* b1,
                         const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
                         int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
                         float* running_mean, float* running_var, float momentum, float eps, float* saved,
-                        double* bn_ws, const int32_t* node_spk, int n_speakers, const int32_t* n_dev,
-                        void* stream);
+                        double* bn_ws, const int32_t* node_spk, int n_speakers, const int32_t* n_dev, int32_t* health,
+                        int32_t* events, void* stream);
 /* Backward of the same: dY [N,100] = dL/d(BatchNorm output) (erc_head_fused), BatchNorm's elementwise backward
  * (gamma, saved, bn_bwd as erc_bn_bwd_apply), TransformerConv backward (target and source side), dH1 = dQKVS Wq,
  * the transposed relation means and dH0 = dP [W_r^T].  Outputs fp32: dQKVS [N,400], dH1 [N,100], dH0 [N, lddh0] --

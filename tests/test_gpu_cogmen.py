@@ -513,7 +513,7 @@ def test_optimizer_fused_into_the_weight_gradient_launch_equals_the_separate_lau
     """COGMEN bf16, one rank: the weight-gradient launch's last arrivers apply Adam themselves (csrc/wgrad_bf16.hip W2Adam; no
     optimizer launch).  Same gradients, same element-wise update: parameters, both moments, the bf16 shadows, the step count
     and the dropout offset are BIT-IDENTICAL to the step with the separate optimizer launch, over several steps with
-    dropout on; a raised health word skips the fused update as it skips the separate one."""
+    dropout on; a health word left raised by the previous step is rolled into the event count by the step's first launch."""
     from erc_amd import capi
     from erc_amd.cogmen import COGMENTrainer
     from erc_amd.params import ERCParams
@@ -529,10 +529,10 @@ def test_optimizer_fused_into_the_weight_gradient_launch_equals_the_separate_lau
         for step in range(4):
             b = tr.prepare_batch(cogmen_case(B=7, min_len=4, max_len=33, dims=dict(a=100, t=768, v=512), seed=30 + step)["batch"])
             if step == 2:
-                tr.model.flat.health.fill_(capi.HEALTH_RAISED)     # this step's update must be skipped either way
+                tr.model.flat.health.fill_(capi.HEALTH_RAISED)     # as a timed-out step 1 would have left it: rolled by step 2's first launch
             losses.append(float(tr.train_step(b).cpu()[0]))
             assert tr.model._last_ws["planner"].adam_fused == fused
-            tr.model.flat.health.zero_()
+            assert int(tr.model.flat.health[0].item()) == 0 and int(tr.model.flat.events[0].item()) == (1 if step >= 2 else 0)
         f = tr.model.flat
         outs.append((losses, f.data.clone(), f.exp_avg.clone(), f.exp_avg_sq.clone(), tr.model.shadows.buf.clone(),
                      tr.optim.state[:2].clone(), tr.optim.state[4:].clone()))
@@ -540,4 +540,48 @@ def test_optimizer_fused_into_the_weight_gradient_launch_equals_the_separate_lau
     assert a[0] == b[0]
     for x, y in zip(a[1:], b[1:]):
         assert torch.equal(x.view(torch.int16) if x.dtype == torch.bfloat16 else x, y.view(torch.int16) if y.dtype == torch.bfloat16 else y)
-    assert int(a[5][0]) == 3 and bool((a[6] == 3).all())          # 4 steps, one skipped; every private step copy agrees
+    assert int(a[5][0]) == 4 and bool((a[6] == 4).all())          # 4 steps; every private step copy agrees
+
+
+def test_fused_optimizer_timeout_fails_the_step_and_the_next_step_recovers():
+    """The weight-gradient launch with the optimizer inside waits (bounded) for the splits of a tile.  With the bound forced to 1
+    (erc_wgrad_bf16_set_spin_limit) some waits time out: the health word is raised, `check_cluster` reports the skipped step;
+    the NEXT step's first launch (erc_cogmen_fwd_tile: the health roll folded in) counts the event and clears the word, and a
+    step with the default bound then equals the same step of a trainer that never saw the timeout."""
+    from erc_amd import capi
+    from erc_amd.cogmen import COGMENTrainer
+    from erc_amd.params import ERCParams
+
+    def fresh():
+        torch.manual_seed(0)
+        p = ERCParams().from_args(["--dataset=iemocap-cogmen-sbert-6", "--compute=bf16"])
+        tr = COGMENTrainer(p, "cuda:0")
+        tr.model.drop_p = 0.0
+        return tr, tr.prepare_batch(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=41)["batch"])
+
+    tr, b = fresh()
+    before = tr.model.flat.data.clone()
+    capi.wgrad_bf16_set_spin_limit(1)
+    try:
+        tr.train_step(b)
+        torch.cuda.synchronize()
+    finally:
+        capi.wgrad_bf16_set_spin_limit(0)
+    assert tr.model._last_ws["planner"].adam_fused
+    assert int(tr.model.flat.health[0].item()) == capi.HEALTH_RAISED          # (a wait that finds its tile complete at once is rare)
+    with pytest.raises(capi.ErcGraftError, match="skipped"):
+        tr.model.check_cluster()                                              # reports and clears
+    # restore the weights, moments and step counts of a trainer that never stepped, then compare one clean step
+    ref, rb = fresh()
+    tr.model.flat.data.copy_(before), tr.model.flat.exp_avg.zero_(), tr.model.flat.exp_avg_sq.zero_()
+    tr.optim.state.copy_(ref.optim.state)
+    tr.model.refresh_shadows()
+    tr.model.flat.health.fill_(capi.HEALTH_RAISED)       # as a timed-out step leaves it
+    tr.model.gcn.bn.running_mean.copy_(ref.model.gcn.bn.running_mean), tr.model.gcn.bn.running_var.copy_(ref.model.gcn.bn.running_var)
+    s1, s0 = tr.train_step(b).cpu(), ref.train_step(rb).cpu()
+    torch.cuda.synchronize()
+    assert int(tr.model.flat.events[0].item()) == 1 and int(tr.model.flat.health[0].item()) == 0
+    assert torch.equal(s1[:3], s0[:3]) and torch.equal(tr.model.flat.data, ref.model.flat.data)
+    with pytest.raises(capi.ErcGraftError, match="skipped"):
+        tr.model.check_cluster()
+    ref.model.check_cluster()                            # nothing to report
