@@ -30,3 +30,20 @@ for S in (1, 2, 4, 8):
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
     print("steps per graph %d: %.2f us per step (host enqueue %.2f us per replay)" % (S, t / K * 1e6, t_host / (K // S) * 1e6))
+
+# two graph execs of the same step, replayed alternately (does the runtime serialize launches of ONE exec harder?)
+gs = []
+for _ in range(2):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        tr.train_step(batch)
+    gs.append(g)
+for _ in range(20):
+    gs[0].replay(), gs[1].replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K // 2):
+    gs[0].replay()
+    gs[1].replay()
+torch.cuda.synchronize()
+print("two execs alternating: %.2f us per step" % ((time.perf_counter() - t0) / K * 1e6))
