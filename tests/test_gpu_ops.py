@@ -598,7 +598,7 @@ def test_wgrad_three_term_bf16_split_is_fp32_class():
     assert errs[2] < 1e-6 and errs[1] > 1e-4, errs        # ... not bf16 class
 
 
-@pytest.mark.parametrize("M,N,K,split", [(300, 260, 200, 1), (131, 200, 1280, 4), (64, 128, 36, 1)])
+@pytest.mark.parametrize("M,N,K,split", [(300, 260, 200, 1), (131, 200, 1280, 4), (64, 128, 36, 1), (1, 1, 4, 1), (129, 1, 68, 1)])
 def test_gemm_x3_is_fp32_class(capi, M, N, K, split):
     """erc_gemm_x3: C = A B^T on the bf16 matrix cores from a three-term split of both fp32 operands.  Against the float64
     product its error is of the size of the exact-fp32 kernel's (erc_gemm_f32: an fp32 fma chain), orders below one bf16
