@@ -544,10 +544,11 @@ def test_optimizer_fused_into_the_weight_gradient_launch_equals_the_separate_lau
 
 
 def test_fused_optimizer_timeout_fails_the_step_and_the_next_step_recovers():
-    """The weight-gradient launch with the optimizer inside waits (bounded) for the splits of a tile.  With the bound forced to 1
-    (erc_wgrad_bf16_set_spin_limit) some waits time out: the health word is raised, `check_cluster` reports the skipped step;
-    the NEXT step's first launch (erc_cogmen_fwd_tile: the health roll folded in) counts the event and clears the word, and a
-    step with the default bound then equals the same step of a trainer that never saw the timeout."""
+    """The weight-gradient launch with the optimizer inside waits (bounded) for the splits of a tile.  With every tile's arrival
+    counter set back by one (no tile can ever complete) and a small bound (erc_wgrad_bf16_set_spin_limit) every wait times out:
+    the health word is raised, `check_cluster` reports the skipped step; the NEXT step's first launch (erc_cogmen_fwd_tile: the
+    health roll folded in) counts the event and clears the word, and a step with the counters and the bound restored equals the
+    same step of a trainer that never saw the timeout."""
     from erc_amd import capi
     from erc_amd.cogmen import COGMENTrainer
     from erc_amd.params import ERCParams
@@ -557,32 +558,38 @@ def test_fused_optimizer_timeout_fails_the_step_and_the_next_step_recovers():
         p = ERCParams().from_args(["--dataset=iemocap-cogmen-sbert-6", "--compute=bf16"])
         tr = COGMENTrainer(p, "cuda:0")
         tr.model.drop_p = 0.0
-        return tr, tr.prepare_batch(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=41)["batch"])
+        b = tr.prepare_batch(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=41)["batch"])
+        tr.train_step(b)                                     # step 0: builds the launch's table, slabs and counters
+        torch.cuda.synchronize()
+        return tr, b
 
     tr, b = fresh()
-    before = tr.model.flat.data.clone()
-    capi.wgrad_bf16_set_spin_limit(1)
+    ref, rb = fresh()
+    ws = tr.model._last_ws
+    assert ws["planner"].adam_fused and ws["w16_fused"]
+    tiles = ws["w16_tiles"]
+    ws["w16_counters"][:tiles] -= 1                          # a split short on every tile
+    capi.wgrad_bf16_set_spin_limit(64)
     try:
         tr.train_step(b)
         torch.cuda.synchronize()
     finally:
         capi.wgrad_bf16_set_spin_limit(0)
-    assert tr.model._last_ws["planner"].adam_fused
-    if int(tr.model.flat.health[0].item()) != capi.HEALTH_RAISED:
-        pytest.skip("every split found its tile complete at its first poll: no wait to time out in this run")
+        ws["w16_counters"][:tiles] += 1
+    assert int(tr.model.flat.health[0].item()) == capi.HEALTH_RAISED
     with pytest.raises(capi.ErcGraftError, match="skipped"):
         tr.model.check_cluster()                                              # reports and clears
-    # restore the weights, moments and step counts of a trainer that never stepped, then compare one clean step
-    ref, rb = fresh()
-    tr.model.flat.data.copy_(before), tr.model.flat.exp_avg.zero_(), tr.model.flat.exp_avg_sq.zero_()
+    # back to the state after step 0 (the timed-out launch updated what does not wait: BatchNorm's scale / shift records)
+    f, g = tr.model.flat, ref.model.flat
+    f.data.copy_(g.data), f.exp_avg.copy_(g.exp_avg), f.exp_avg_sq.copy_(g.exp_avg_sq)
     tr.optim.state.copy_(ref.optim.state)
     tr.model.refresh_shadows()
-    tr.model.flat.health.fill_(capi.HEALTH_RAISED)       # as a timed-out step leaves it
     tr.model.gcn.bn.running_mean.copy_(ref.model.gcn.bn.running_mean), tr.model.gcn.bn.running_var.copy_(ref.model.gcn.bn.running_var)
+    f.health.fill_(capi.HEALTH_RAISED)                   # as the timed-out step left it
     s1, s0 = tr.train_step(b).cpu(), ref.train_step(rb).cpu()
     torch.cuda.synchronize()
-    assert int(tr.model.flat.events[0].item()) == 1 and int(tr.model.flat.health[0].item()) == 0
-    assert torch.equal(s1[:3], s0[:3]) and torch.equal(tr.model.flat.data, ref.model.flat.data)
+    assert int(f.events[0].item()) == 1 and int(f.health[0].item()) == 0
+    assert torch.equal(s1[:3], s0[:3]) and torch.equal(f.data, g.data)
     with pytest.raises(capi.ErcGraftError, match="skipped"):
         tr.model.check_cluster()
     ref.model.check_cluster()                            # nothing to report
