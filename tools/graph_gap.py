@@ -47,3 +47,26 @@ for _ in range(K // 2):
     gs[1].replay()
 torch.cuda.synchronize()
 print("two execs alternating: %.2f us per step" % ((time.perf_counter() - t0) / K * 1e6))
+
+# the same one-step graph launched alternately on two streams, ordered by events (is the bubble a property of one queue?)
+s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+g1 = gs[0]
+evs = [torch.cuda.Event(), torch.cuda.Event()]
+torch.cuda.synchronize()
+def run_alt(n):
+    prev = None
+    for i in range(n):
+        st = s0 if i % 2 == 0 else s1
+        with torch.cuda.stream(st):
+            if prev is not None:
+                st.wait_event(prev)
+            g1.replay()
+            ev = evs[i % 2]
+            ev.record(st)
+            prev = ev
+run_alt(40)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+run_alt(K)
+torch.cuda.synchronize()
+print("one exec, two streams alternating with events: %.2f us per step" % ((time.perf_counter() - t0) / K * 1e6))
