@@ -48,13 +48,16 @@ _SIGS = {
     "erc_bn_batch_stats": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "erc_head_fused_ws_floats": (C.c_int64, [_i]),
     "erc_head_fused": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
-                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "erc_head_fused_bn": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _f, _i,
-                                    _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+                                    _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "erc_wgrad_bf16": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16_adam": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp, _vp,
                                       _i64, _vp, _vp, _vp]),
+    "erc_wgrad_split": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "erc_wgrad_split_adam": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp,
+                                       _vp, _i64, _vp, _vp, _vp]),
     "erc_wgrad_bf16_set_spin_limit": (C.c_int, [_i]),
     "erc_wgrad_bf16_wide": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16_slab_floats": (C.c_int64, []),
@@ -89,6 +92,8 @@ _SIGS = {
     "erc_cogmen_project_graph_ok": (C.c_int, [_i, _i, _i, _i, _i]),
     "erc_cogmen_project_graph": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _i]
                                  + [_vp] * 11 + [_vp, _vp]),
+    "erc_cogmen_project_graph_x": (C.c_int, [_i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i,
+                                             _i, _i] + [_vp] * 11 + [_vp, _vp]),
     "erc_head_set_stamps": (C.c_int, [_vp]),
     "erc_cogmen_fwd_tile": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
                                       _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
@@ -234,7 +239,7 @@ def lib():
                     _record.append((_name, a))
                 return _fn(*a)
             setattr(rec, name, call)
-        if handle.erc_abi_version() != 2:
+        if handle.erc_abi_version() != 3:
             raise ErcGraftError("libercgraft ABI version mismatch")
         _raw, _lib = handle, rec
     return _lib
@@ -391,15 +396,17 @@ class ShadowTable:
         self.buf = None
         self._packed = None
 
-    def add(self, src_off, n_el, dst_numel, n0, n1, sn, sk, ld, mode):
+    def add(self, src_off, n_el, dst_numel, n0, n1, sn, sk, ld, mode, terms=1):
         """digits (idx % n0, (idx / n0) % n1, idx / (n0 n1)) -> n = digits . sn, k = digits . sk; mode 0 row-major [n][ld],
-        mode 1 MFMA B-fragment order with ld K blocks."""
+        mode 1 MFMA B-fragment order with ld K blocks.  ``terms`` > 1: that many bf16 planes of ``dst_numel`` elements each
+        (rounded up to 64), plane t = term t of the parameter's bf16 expansion (split compute modes)."""
         if self.buf is not None or len(self.descs) == self.MAX:
             raise ErcGraftError("shadow table is sealed or full")
         dst_off = (self.numel + 63) // 64 * 64       # 128-byte aligned blocks
-        self.descs.append((src_off, n_el, dst_off, n0, n1) + tuple(sn) + tuple(sk) + (ld, mode))
-        self.sizes.append(dst_numel)
-        self.numel = dst_off + dst_numel
+        plane = (dst_numel + 63) // 64 * 64
+        self.descs.append((src_off, n_el, dst_off, n0, n1) + tuple(sn) + tuple(sk) + (ld, mode, plane if terms > 1 else 0, terms, 0))
+        self.sizes.append(plane * terms if terms > 1 else dst_numel)
+        self.numel = dst_off + self.sizes[-1]
         return len(self.descs) - 1
 
     def seal(self):
@@ -407,14 +414,18 @@ class ShadowTable:
         self.buf = torch.zeros(self.numel + 64, dtype=torch.bfloat16, device=self.device)
         raw = struct.pack("<ii", len(self.descs), 0)
         for d in self.descs:
-            raw += struct.pack("<qqq10i", *d)
-        raw += b"\0" * (8 + 64 * self.MAX - len(raw))
+            raw += struct.pack("<qqq10iq2i", *d)
+        raw += b"\0" * (8 + 80 * self.MAX - len(raw))
         self._packed = C.create_string_buffer(raw, len(raw))
         return self
 
     def view(self, i):
         off = self.descs[i][2]
         return self.buf[off:off + self.sizes[i]]
+
+    def plane(self, i):
+        """elements between the term planes of range i (0: a single plane)"""
+        return self.descs[i][13]
 
     @property
     def tab_ptr(self):
@@ -493,11 +504,22 @@ def cogmen_project_graph_ok(K, n_out, B, ldx, ldw):
 
 
 def cogmen_project_graph(x, ldx, W, ldw, bias, H0, ldh0, n_out, K, lengths, speakers, B, T, wp, wf, n_speakers, n_cap, e_cap, g,
-                         desc=None):
+                         desc=None, terms=1, w_plane=0):
     """input projection + window graph in one launch (csrc/cogmen_project.hip); g: the graph dict of window_graph_build.
-    desc (int32 [2 B]: lengths | first store rows): resident mode -- x / speakers are a store's [U, ldx] / [U] arrays"""
+    desc (int32 [2 B]: lengths | first store rows): resident mode -- x / speakers are a store's [U, ldx] / [U] arrays.
+    terms = 2 | 3: split compute mode -- x fp32, W = that many bf16 term planes ``w_plane`` elements apart"""
     _dev(x)
     sb, st = (0, speakers.stride(0)) if desc is not None else (speakers.stride(0), speakers.stride(1))
+    if terms > 1:
+        if x.dtype != torch.float32:
+            raise ErcGraftError("cogmen_project_graph: split modes take the fp32 feature block")
+        _check(lib().erc_cogmen_project_graph_x(terms, ptr(x), ldx, ptr(W), w_plane, ldw, ptr(bias), ptr(H0), ldh0, n_out, K,
+                                                ptr(lengths), ptr(speakers), sb, st, B, T, wp, wf, n_speakers, n_cap, e_cap,
+                                                ptr(g["node_off"]), ptr(g["node_row"]), ptr(g["node_spk"]), ptr(g["in_ptr"]),
+                                                ptr(g["in_src"]), ptr(g["in_typ"]), ptr(g["out_ptr"]), ptr(g["out_dst"]),
+                                                ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(g["counts"]), ptr(desc), stream()),
+               "erc_cogmen_project_graph_x")
+        return
     _check(lib().erc_cogmen_project_graph(ptr(x), ldx, ptr(W), ldw, ptr(bias), ptr(H0), ldh0, n_out, K, ptr(lengths),
                                           ptr(speakers), sb, st, B, T, wp, wf, n_speakers,
                                           n_cap, e_cap, ptr(g["node_off"]), ptr(g["node_row"]), ptr(g["node_spk"]),
@@ -863,22 +885,23 @@ def head_fused_ws_floats(n_rows):
 
 
 def head_fused(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
-               H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bf16_out=None, n_dev=None, label_rows=None):
-    """bf16_out: (H3b, Zb, dZb, dlb, pitch) -- bf16 copies of the classifier's weight-gradient operands, or None"""
+               H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bf16_out=None, n_dev=None, label_rows=None, lddl=0):
+    """bf16_out: (H3b, Zb, dZb, dlb, pitch) -- bf16 copies of the classifier's weight-gradient operands, or None; lddl: row pitch
+    of dlogits (0 = C)"""
     b = bf16_out if bf16_out is not None else (None, None, None, None, 0)
     _call("erc_head_fused", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
           float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, b[0], b[1], b[2], b[3], b[4],
-          n_dev, label_rows)
+          n_dev, label_rows, int(lddl))
 
 
 def head_fused_bn(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                   H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, running_mean,
-                  running_var, momentum, eps, defer_reduce=False, bf16_out=None, n_dev=None, label_rows=None):
+                  running_var, momentum, eps, defer_reduce=False, bf16_out=None, n_dev=None, label_rows=None, lddl=0):
     b = bf16_out if bf16_out is not None else (None, None, None, None, 0)
     _call("erc_head_fused_bn", H2, ldh, n_rows, F, C, gamma, beta, saved, float(slope), W0, b0, W3, b3, labels, weight,
           float(drop_p), rng_state, H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles,
           running_mean, running_var, float(momentum), float(eps), int(defer_reduce), b[0], b[1], b[2], b[3], b[4], n_dev,
-          label_rows)
+          label_rows, int(lddl))
 
 
 def head_fused_rows_per_workgroup(n_rows):
@@ -955,19 +978,27 @@ def enc_inverse_rows(node_row, N, inv, n_rows):
     _call("erc_enc_inverse_rows", node_row, N, inv, n_rows)
 
 
-def wgrad_bf16(table, n_desc, item_base, n_items, slabs, counters):
-    """item_base: ctypes int32 array (host) of the descriptors' first work items (csrc/wgrad_bf16.hip)"""
+def wgrad_bf16(table, n_desc, item_base, n_items, slabs, counters, terms=1):
+    """item_base: ctypes int32 array (host) of the descriptors' first work items (csrc/wgrad_bf16.hip); terms = 2 | 3: the
+    records' operands are fp32, expanded into that many bf16 terms in registers (erc_wgrad_split)"""
+    if terms > 1:
+        _check(lib().erc_wgrad_split(terms, ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), stream()), "erc_wgrad_split")
+        return
     _check(lib().erc_wgrad_bf16(ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), stream()), "erc_wgrad_bf16")
 
 
 def wgrad_bf16_adam(table, n_desc, item_base, n_items, slabs, counters, n_tiles, p, g, m, v, n, lr, b1, b2, eps, wd, decoupled,
-                    grad_scale, state, shadow_table, health):
-    """erc_wgrad_bf16 with the optimizer fused in (ercgraft.h)"""
+                    grad_scale, state, shadow_table, health, terms=1):
+    """erc_wgrad_bf16 (terms > 1: erc_wgrad_split) with the optimizer fused in (ercgraft.h)"""
     st = shadow_table
-    _check(lib().erc_wgrad_bf16_adam(ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), int(n_tiles), ptr(p), ptr(g),
-                                     ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale, ptr(state),
-                                     ptr(st.buf) if st is not None else None, st.buf.numel() if st is not None else 0,
-                                     st.tab_ptr if st is not None else None, ptr(health), stream()), "erc_wgrad_bf16_adam")
+    args = (ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), int(n_tiles), ptr(p), ptr(g),
+            ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale, ptr(state),
+            ptr(st.buf) if st is not None else None, st.buf.numel() if st is not None else 0,
+            st.tab_ptr if st is not None else None, ptr(health), stream())
+    if terms > 1:
+        _check(lib().erc_wgrad_split_adam(terms, *args), "erc_wgrad_split_adam")
+    else:
+        _check(lib().erc_wgrad_bf16_adam(*args), "erc_wgrad_bf16_adam")
 
 
 def wgrad_bf16_wide(table, n_desc, wg_base, n_wgs, slabs, counters):

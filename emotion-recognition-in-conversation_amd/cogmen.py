@@ -85,7 +85,13 @@ class COGMENModule(nn.Module):
         self.enc_train = None
         assert hidden_size == F_HID, "the reference hard-codes 100 (cogmen.py:116-122)"
         self.input_size, self.n_speakers, self.n_classes = input_size, n_speakers, n_classes
+        if compute not in ("f32", "bf16", "f32x2", "f32x3"):
+            raise capi.ErcGraftError("COGMEN compute mode %r (f32 | bf16 | f32x2 | f32x3)" % (compute, ))
         self.compute = compute
+        # SPLIT COMPUTE MODES (csrc/split_dev.h): fp32 data everywhere, every dense product on the bf16 matrix cores from operands
+        # expanded into `terms` bf16 terms -- the fused 5-launch step structure of the bf16 mode at fp32-class accuracy
+        # (north_star's 1e-4: two terms give 8e-6 on the logits of config 2, three are indistinguishable from fp32 arithmetic)
+        self.terms = {"f32x2": 2, "f32x3": 3}.get(compute, 1)
         layer = nn.TransformerEncoderLayer(d_model=input_size, nhead=pick_heads(input_size, num_head),
                                            dropout=0.5, batch_first=True)
         encoder = nn.TransformerEncoder(layer, num_layers=2, enable_nested_tensor=False)  # dead (see module doc)
@@ -140,7 +146,7 @@ class COGMENModule(nn.Module):
         if self.chained_encoder:
             from .encoder import EncoderTrain
             self.enc_train = EncoderTrain(self.rnn[0], self.flat, device, drop_p=0.5)
-        elif self.compute == "bf16":
+        elif self.compute == "bf16" or self.terms > 1:
             self._build_shadows()
         return self
 
@@ -154,19 +160,23 @@ class COGMENModule(nn.Module):
         projection's W1 as is, and the four packed / transposed copies of the fused graph kernels."""
         fp, D, F = self.flat, self.input_size, F_HID
         t = capi.ShadowTable(fp.device)
+        nt = self.terms          # split modes: every range as `terms` planes (the bf16 expansion of the weights)
         off_cat, off_q = fp.offsets["gcn.conv1.weight"], fp.offsets["gcn.conv2.lin_query.weight"]
         assert fp.offsets["gcn.conv1.root"] == off_cat + N_REL * F * F
         assert fp.offsets["gcn.conv2.lin_skip.weight"] == off_q + 3 * F * F
-        i_w1 = t.add(fp.offsets["rnn.1.weight"], F * D, F * D, D, F, (0, 1, 0), (1, 0, 0), D, 0)            # row-major copy
+        i_w1 = t.add(fp.offsets["rnn.1.weight"], F * D, F * D, D, F, (0, 1, 0), (1, 0, 0), D, 0, terms=nt)            # row-major copy
         # logical [n][k] operands in MFMA B-fragment order (ercgraft.h, mode 1)
-        i_catT = t.add(off_cat, 9 * F * F, 7 * 29 * 512, F, 9 * F, (1, 0, 0), (0, 1, 0), 29, 1)           # WcatT[o][r*100+c]
-        i_wb = t.add(off_cat, 9 * F * F, 7 * 30 * 512, F, F, (0, 1, 0), (1, 0, 104), 30, 1)               # Wb[c][r*104+o]
-        i_q = t.add(off_q, 4 * F * F, 25 * 4 * 512, F, 4 * F, (0, 1, 0), (1, 0, 0), 4, 1)                 # Wq[n][k]
-        i_qT = t.add(off_q, 4 * F * F, 7 * 13 * 512, F, 4 * F, (1, 0, 0), (0, 1, 0), 13, 1)               # WqT[k][n]
+        i_catT = t.add(off_cat, 9 * F * F, 7 * 29 * 512, F, 9 * F, (1, 0, 0), (0, 1, 0), 29, 1, terms=nt)           # WcatT[o][r*100+c]
+        i_wb = t.add(off_cat, 9 * F * F, 7 * 30 * 512, F, F, (0, 1, 0), (1, 0, 104), 30, 1, terms=nt)               # Wb[c][r*104+o]
+        i_q = t.add(off_q, 4 * F * F, 25 * 4 * 512, F, 4 * F, (0, 1, 0), (1, 0, 0), 4, 1, terms=nt)                 # Wq[n][k]
+        i_qT = t.add(off_q, 4 * F * F, 7 * 13 * 512, F, 4 * F, (1, 0, 0), (0, 1, 0), 13, 1, terms=nt)               # WqT[k][n]
         t.seal()
         self.shadows = t
-        self._sh = dict(w1=t.view(i_w1).view(F, D), catT=t.view(i_catT), wb=t.view(i_wb), q=t.view(i_q), qT=t.view(i_qT))
-        self.use_fused_graph = True
+        self._sh = dict(w1=t.view(i_w1)[:F * D].view(F, D), catT=t.view(i_catT), wb=t.view(i_wb), q=t.view(i_q), qT=t.view(i_qT))
+        self._sh_plane = dict(w1=t.plane(i_w1), catT=t.plane(i_catT), wb=t.plane(i_wb), q=t.plane(i_q), qT=t.plane(i_qT))
+        self.use_fused_graph = nt == 1 or os.environ.get("ERC_SPLIT_TILES", "0") != "0"
+        if nt > 1:     # (the planes are exact expansions of the weights: valid whoever keeps them in sync -- refreshed per forward
+            self.w1_shadow = self._sh["w1"]      #  until an optimizer takes over, attach_bf16_shadow)
 
     def supports_capacity(self, batch):
         """Can a training step on ``batch`` run in capacity mode (every launch of the step takes the node count from the
@@ -212,7 +222,9 @@ class COGMENModule(nn.Module):
             bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=torch.zeros(1024, dtype=torch.float32, device=device),
             bn_stats_ws=torch.zeros(capi.bn_batch_stats_ws_floats(F), dtype=torch.float32, device=device),
             head_ws=torch.zeros(capi.head_fused_ws_floats(N), dtype=torch.float32, device=device), bn_bwd=f32(2 * F),
-            dlogits=f32(N, C), dZ=f32(N, F), dH3=f32(N, F), dH2=f32(N, F), dQKVS=f32(N, 4 * F), dscore=f32(E),
+            # (split modes: dlogits with a pitch of 8 floats -- 16-byte rows for the weight-gradient launch; pad columns stay zero)
+            dlogits=torch.zeros(N, self.LDDL, dtype=torch.float32, device=device) if self.terms > 1 else f32(N, C),
+            dZ=f32(N, F), dH3=f32(N, F), dH2=f32(N, F), dQKVS=f32(N, 4 * F), dscore=f32(E),
             dH1=f32(N, F), dM=f32(N, 9 * F), dH0=f32(N, F),
         )
         # slab space: forward split-K of the input projection + every weight gradient, sized generously
@@ -247,6 +259,7 @@ class COGMENModule(nn.Module):
         ws["jobs"] = None
         return ws
 
+    LDDL = 8                # split modes: row pitch of dlogits
     BN_FUSED_MAX_N = 8192   # above: the tile partials are too many for one last arriver, BatchNorm statistics get their own launch
 
     # ---------------------------------------------------------------- forward
@@ -273,7 +286,9 @@ class COGMENModule(nn.Module):
             self.refresh_shadows()
         # bf16 mode: the projection's workgroups build the window graph themselves (csrc/cogmen_project.hip): one launch
         # and one launch gap less than graph build + projection
-        project_graph = (self.fuse_project_graph and x_bf16 and self.w1_shadow is not None and self.enc_train is None
+        split = self.terms > 1
+        project_graph = (self.fuse_project_graph and (x.dtype == torch.float32 if split else x_bf16) and self.w1_shadow is not None
+                         and self.enc_train is None
                          and speaker_tensor.dim() == (1 if desc is not None else 2) and x.is_contiguous()
                          and N <= self.BN_FUSED_MAX_N      # beyond: many row groups per workgroup, the separate launches win (B = 512: 45 vs 54 us)
                          and capi.cogmen_project_graph_ok(D, F, B, D, D))
@@ -284,7 +299,8 @@ class COGMENModule(nn.Module):
         nd = g["counts"] if self.dynamic_n else None
         if project_graph:
             capi.cogmen_project_graph(x, D, self.w1_shadow, D, fp.w("rnn.1.bias"), ws["H0"], F, F, D, text_length,
-                                      speaker_tensor, B, T, WP, WF, self.n_speakers, N, ws["E"], g, desc=desc)
+                                      speaker_tensor, B, T, WP, WF, self.n_speakers, N, ws["E"], g, desc=desc,
+                                      terms=self.terms, w_plane=self._sh_plane["w1"])
         else:
             capi.window_graph_build(text_length, speaker_tensor, speaker_tensor.stride(0), speaker_tensor.stride(1),
                                     B, T, WP, WF, self.n_speakers, N, ws["E"], g)
@@ -292,7 +308,7 @@ class COGMENModule(nn.Module):
             x = self.enc_train.forward(x, text_length, training, self.rng_state)
             x_bf16 = True
             ws["x_enc"] = x
-        W1 = self.w1_shadow if (x_bf16 and self.w1_shadow is not None) else fp.w("rnn.1.weight")
+        W1 = self.w1_shadow if (x_bf16 and self.w1_shadow is not None and not split) else fp.w("rnn.1.weight")
         if not project_graph:
             linear_fwd(pl, x, D, g["node_row"], W1, fp.w("rnn.1.bias"), ws["H0"], F, N, F, D, x_bf16=x_bf16)
         if ws.get("fused"):
@@ -375,13 +391,22 @@ class COGMENModule(nn.Module):
         # bf16 mode: every weight gradient of the step on the bf16 matrix cores from bf16 operands (csrc/wgrad_bf16.hip)
         # (N > 8 192: the planner takes the WIDE form of that kernel -- four column tiles per workgroup; the K-split form lost
         #  there against the 64 x 64-tile kernel, 181 vs 167 us at N = 33 k, because it streams the A operand once per tile)
-        w16 = bool(fused and self.wgrad_bf16 and x_bf16 and C <= 8 and D % 4 == 0 and x.is_contiguous() and x.data_ptr() % 8 == 0
+        split = self.terms > 1
+        w16 = bool(fused and not split and self.wgrad_bf16 and x_bf16 and C <= 8 and D % 4 == 0 and x.is_contiguous() and x.data_ptr() % 8 == 0
                    and (N <= self.BN_FUSED_MAX_N or os.environ.get("ERC_W2_WIDE", "1") != "0"))
-        ws["w16"] = w16
+        # split modes: the same launch from the fp32 operands, expanded into bf16 terms in registers (erc_wgrad_split)
+        wsp = bool(split and fused_head and x.dtype == torch.float32 and D % 4 == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0
+                   and self.enc_train is None)
+        if split and not wsp:
+            raise capi.ErcGraftError("COGMEN %s mode: fp32 contiguous features, D %% 4 == 0, C <= 8, training through the fused head"
+                                     % self.compute)
+        ws["w16"], ws["wsp"] = w16, wsp
+        pl.split_terms = self.terms if wsp else 1
         b16 = (ws["H3b"], ws["Zb"], ws["dZb"], ws["dlb"], PA) if w16 else None
+        lddl = self.LDDL if split else 0
         nd = g["counts"] if self.dynamic_n else None
-        if self.dynamic_n and not (w16 and fused_head):
-            raise capi.ErcGraftError("COGMEN capacity mode needs the fused bf16 training path (supports_capacity)")
+        if self.dynamic_n and not ((w16 or wsp) and fused_head):
+            raise capi.ErcGraftError("COGMEN capacity mode needs the fused bf16 / split training path (supports_capacity)")
         if fused_head:
             head_args = (ws["H2"], F, N, F, C, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
                          fp.w("cls.0.weight"), fp.w("cls.0.bias"), fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys,
@@ -393,12 +418,12 @@ class COGMENModule(nn.Module):
                 # ... and the head's own cross-workgroup sums (BatchNorm backward means, loss) are left to the backward tile kernel
                 capi.head_fused_bn(*head_args, ws["bn_tile_ws"][2:].view(torch.float32), -(-N // 16), bn.running_mean,
                                    bn.running_var, bn.momentum, bn.eps, defer_reduce=True, bf16_out=b16, n_dev=nd,
-                                   label_rows=g["node_row"] if desc is not None else None)
+                                   label_rows=g["node_row"] if desc is not None else None, lddl=lddl)
                 ws["head_deferred"] = True
             else:
                 capi.bn_batch_stats(ws["H2"], F, N, F, bn.running_mean, bn.running_var, bn.momentum, bn.eps, ws["bn_saved"],
                                     ws["bn_stats_ws"])
-                capi.head_fused(*head_args, bf16_out=b16)
+                capi.head_fused(*head_args, bf16_out=b16, lddl=lddl)
                 ws["head_deferred"] = False
         else:
             capi.cross_entropy(ws["logits"], C, C, N, None, ys, class_weight, 1.0, ws["dlogits"], C, ws["stats"])
@@ -407,6 +432,9 @@ class COGMENModule(nn.Module):
         if w16:
             pl.defer16(ws["Zb"], PA, ws["dlb"], 8, fp.g("cls.3.weight"), F, F, C, N, ct=True, bias_b=fp.g("cls.3.bias"), k_dev=nd)
             pl.defer16(ws["dZb"], PA, ws["H3b"], PA, fp.g("cls.0.weight"), F, F, F, N, bias_a=fp.g("cls.0.bias"), k_dev=nd)
+        elif wsp:
+            pl.defer16(ws["Z"], F, ws["dlogits"], self.LDDL, fp.g("cls.3.weight"), F, F, C, N, ct=True, bias_b=fp.g("cls.3.bias"), k_dev=nd)
+            pl.defer16(ws["dZ"], F, ws["H3"], F, fp.g("cls.0.weight"), F, F, F, N, bias_a=fp.g("cls.0.bias"), k_dev=nd)
         else:
             with self.side.fork():
                 linear_wgrad(pl, ws["dlogits"], C, ws["Z"], F, None, C, F, N, fp.offsets["cls.3.weight"],
@@ -430,15 +458,18 @@ class COGMENModule(nn.Module):
                             ws["dH3"] if fused_head else ws["dH2"], F, ws["dQKVS"], ws["dscore"], bn=bn_prologue)
         capi.gemm_f32(ws["dQKVS"], 4 * F, 0, None, fp.w("gcn.conv2.lin_query.weight"), F, 1, None, ws["dH1"], F,
                       N, F, 4 * F)
+        # RGCN: dM = dH1 @ Wcat^T ; dWcat = M^T dH1 ; dbias = colsum(dH1)
+        capi.gemm_f32(ws["dH1"], F, 0, None, fp.w("gcn.conv1.weight"), F, 0, None, ws["dM"], 9 * F, N, 9 * F, F)
+        capi.rgcn_mean_bwd(ws["dM"], 9 * F, F, N_REL, N, g, ws["inv_cnt"], ws["dH0"], F)
+        if wsp:      # split modes with the graph part on the unfused fp32 kernels: weight gradients + optimizer as in the fused path
+            self._split_wgrads(ws, x, N)
+            return ws["stats"]
         with self.side.fork():
             linear_wgrad(pl, ws["dQKVS"], 4 * F, ws["H1"], F, None, 4 * F, F, N,
                          fp.offsets["gcn.conv2.lin_query.weight"], fp.offsets["gcn.conv2.lin_query.bias"], defer=True)
-        # RGCN: dM = dH1 @ Wcat^T ; dWcat = M^T dH1 ; dbias = colsum(dH1)
-        capi.gemm_f32(ws["dH1"], F, 0, None, fp.w("gcn.conv1.weight"), F, 0, None, ws["dM"], 9 * F, N, 9 * F, F)
         with self.side.fork():
             matmul_wgrad_io(pl, ws["M"], 9 * F, ws["dH1"], F, 9 * F, F, N, fp.offsets["gcn.conv1.weight"],
                             fp.offsets["gcn.conv1.bias"], defer=True)
-        capi.rgcn_mean_bwd(ws["dM"], 9 * F, F, N_REL, N, g, ws["inv_cnt"], ws["dH0"], F)
         # input projection (no gradient into the features)
         if self.enc_train is not None:
             x, x_bf16 = ws["x_enc"], True
@@ -456,6 +487,23 @@ class COGMENModule(nn.Module):
             capi.enc_inverse_rows(g["node_row"], N, ews["inv"], B * T)
             self.enc_train.backward(ews["dXn"], ews["inv"])
         return ws["stats"]
+
+    def _split_wgrads(self, ws, x, N):
+        """split modes: the graph part's and the projection's weight gradients from fp32 operands (erc_wgrad_split), BatchNorm's
+        scale / shift as finished ranges, the optimizer inside the launch when the trainer attached one"""
+        fp, g, pl = self.flat, ws["g"], ws["planner"]
+        F, D = F_HID, self.input_size
+        nd = g["counts"] if self.dynamic_n else None
+        pl.defer16(ws["H1"], F, ws["dQKVS"], 4 * F, fp.g("gcn.conv2.lin_query.weight"), F, F, 4 * F, N, ct=True,
+                   bias_b=fp.g("gcn.conv2.lin_query.bias"), k_dev=nd)
+        pl.defer16(ws["dH1"], F, ws["M"], 9 * F, fp.g("gcn.conv1.weight"), F, F, 9 * F, N, ct=True,
+                   bias_a=fp.g("gcn.conv1.bias"), k_dev=nd)
+        pl.defer16(ws["dH0"], F, x, D, fp.g("rnn.1.weight"), D, F, D, N, bias_a=fp.g("rnn.1.bias"), gather=g["node_row"], k_dev=nd)
+        o_g, o_b = fp.offsets["gcn.bn.weight"], fp.offsets["gcn.bn.bias"]
+        pl.defer16_range(fp.grad[o_g:o_g + F])
+        pl.defer16_range(fp.grad[o_b:o_b + F])
+        pl.fused_adam = self.fused_optim
+        pl.reduce_into(ws, fp.grad)
 
     def _backward_fused(self, ws, x, x_bf16, N):
         """bf16 mode: BatchNorm backward .. dH0 in one launch (csrc/cogmen_fused.hip), then the batched weight gradients."""
@@ -602,7 +650,7 @@ class COGMENTrainer:
         import os
         if os.environ.get("ERC_FUSE_ADAM", "1") != "0" and self.model.enc_train is None:
             self.model.fused_optim = self.optim        # single rank, bf16 mode: the optimizer rides in the weight-gradient launch
-        if self.model.compute == "bf16" and self.model.enc_train is None:
+        if (self.model.compute == "bf16" or self.model.terms > 1) and self.model.enc_train is None:
             self.model.attach_bf16_shadow(self.optim)
         self.class_weight = None
         # faithful-cost mode: also run the reference's dead Transformer encoder on the padded

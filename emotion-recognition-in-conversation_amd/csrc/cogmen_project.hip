@@ -12,7 +12,13 @@
 //    in-edge slot | out-edge slot), all offsets from closed forms (erc_window_prefix), the neighbours' speakers requested
 //    together with the feature rows.
 // Bit-identical to erc_window_graph_build + erc_gemm_bf16a_stream with the gather (tests/test_gpu_cogmen_fused.py).
+//
+// SPLIT COMPUTE MODES (NT = 2, 3; csrc/split_dev.h): the feature block stays fp32 in memory (what the reference feeds
+// rnn.1), every A fragment is expanded into NT bf16 terms in registers and multiplied with the NT term planes of the weight
+// shadow -- fp32-class H0 on the bf16 matrix cores.  The resident weight fragments are NT times as many registers, so a row
+// group is shared by 4 (NT = 2: two column tiles each) or 8 (NT = 3: one each) workgroups of one XCD instead of 2.
 #include "erc_common.h"
+#include "split_dev.h"
 
 namespace {
 
@@ -23,12 +29,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PG_NB = 6;       // K blocks of 32 per wavefront (8 wavefronts: K <= 1536)
-constexpr int PG_NT = 4;       // column tiles of 16 per workgroup
 constexpr int PG_BMAX = 2048;  // dialogues per batch (offsets in LDS)
 
 struct PgP {
-    const unsigned short* X;       // bf16 [B*T, ldx]: the padded feature block
-    const unsigned short* W;       // bf16 [NO, ldw]: shadow of rnn.1.weight
+    const void* X;                 // bf16 (NT = 1) / fp32 (split modes) [B*T, ldx]: the padded feature block
+    const unsigned short* W;       // bf16 [NO, ldw]: shadow of rnn.1.weight; split modes: NT term planes, w_plane elements apart
+    int64_t w_plane;
     const float* bias;             // [NO]
     float* H0;                     // out [N, ldh0]
     int ldx, ldw, ldh0, K, NO;
@@ -43,13 +49,16 @@ struct PgP {
     const int32_t* desc;
 };
 
+// NT: bf16 terms per operand value (1: the bf16 compute mode); PG_NT: column tiles of 16 per workgroup; NWG: workgroups that
+// share a row group (ids id, id + 8, ..: one XCD), NWG * PG_NT >= 7
+template <int NT, int PG_NT, int NWG>
 __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) {
-    __shared__ float red[8 * PG_NT * 4 * 64];   // 32 KB: partial tiles of the 8 wavefronts
+    __shared__ float red[8 * PG_NT * 4 * 64];   // partial tiles of the 8 wavefronts (32 KB at 4 column tiles)
     __shared__ int s_noff[PG_BMAX + 1], s_eoff[PG_BMAX + 1], s_base[PG_BMAX];   // node / edge offsets, first feature row of a dialogue
     __shared__ int s_wn[8], s_we[8];
     __shared__ int s_dlg[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
-    const int id = blockIdx.x, half = (id >> 3) & 1, pair = (id & 7) + 8 * (id >> 4), n_pairs = (int)gridDim.x >> 1;
+    const int id = blockIdx.x, half = (id >> 3) % NWG, pair = (id & 7) + 8 * (id / (8 * NWG)), n_pairs = (int)gridDim.x / NWG;
     const int n_base = half * 16 * PG_NT;            // first column of this workgroup
     const int nkb = (p.K + 31) / 32;
 
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
     // ---- this wavefront's K blocks of W (as gemm_bf16a_persist_kernel): a block that would run past K is shifted back to
     //      end at K; the k it then shares with the previous block are zeroed in the W fragment (K >= 32, K % 4 == 0)
     int k0[PG_NB];
-    u32x4 wraw[PG_NB][PG_NT];
+    u32x4 wraw[PG_NB][PG_NT][NT];
 #pragma unroll
     for (int s = 0; s < PG_NB; ++s) {
         const int kb = w + 8 * s;
@@ -68,9 +77,12 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
 #pragma unroll
         for (int nt = 0; nt < PG_NT; ++nt) {
             const int n = n_base + 16 * nt + r;
-            const unsigned short* wr = p.W + (int64_t)min(n, p.NO - 1) * p.ldw + k0[s] + 8 * g;
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(wr), hi = *reinterpret_cast<const u32x2*>(wr + 4);
-            wraw[s][nt] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const unsigned short* wr = p.W + t * p.w_plane + (int64_t)min(n, p.NO - 1) * p.ldw + k0[s] + 8 * g;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(wr), hi = *reinterpret_cast<const u32x2*>(wr + 4);
+                wraw[s][nt][t] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
 
     // ---- the weight fragments have arrived long ago: zero what lies outside W (dead K blocks, the k a shifted last block
     //      shares with its predecessor, columns >= NO) with dword masks -- pairs of k never straddle kstart (K % 4 == 0)
-    bf16x8 wf[PG_NB][PG_NT];
+    u32x4 wf[PG_NB][PG_NT][NT];
 #pragma unroll
     for (int s = 0; s < PG_NB; ++s) {
         const int kb = w + 8 * s;
@@ -135,8 +147,11 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
 #pragma unroll
         for (int nt = 0; nt < PG_NT; ++nt) {
             const unsigned cm = n_base + 16 * nt + r < p.NO ? 0xffffffffu : 0u;
-            const u32x4 v = wraw[s][nt];
-            wf[s][nt] = __builtin_bit_cast(bf16x8, (u32x4){v.x & km[0] & cm, v.y & km[1] & cm, v.z & km[2] & cm, v.w & km[3] & cm});
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const u32x4 v = wraw[s][nt][t];
+                wf[s][nt][t] = (u32x4){v.x & km[0] & cm, v.y & km[1] & cm, v.z & km[2] & cm, v.w & km[3] & cm};
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -155,15 +170,21 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
         }
         // ---- A fragments: feature row of node n0 + r is row b * T + position of the padded block
         bf16x8 af[PG_NB];
+        f32x4 ax[NT > 1 ? PG_NB : 1][2];      // split modes: the raw fp32 values, expanded block by block in front of their products
         {
             const int nr = min(n0 + r, N - 1);
             const int b = s_dlg[nr - n0];
             const int64_t arow = ((int64_t)s_base[b] + (nr - s_noff[b])) * p.ldx;
 #pragma unroll
             for (int s = 0; s < PG_NB; ++s) {
-                const unsigned short* ar = p.X + arow + k0[s] + 8 * g;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(ar), hi = *reinterpret_cast<const bf16x4*>(ar + 4);
-                af[s] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if constexpr (NT == 1) {
+                    const unsigned short* ar = reinterpret_cast<const unsigned short*>(p.X) + arow + k0[s] + 8 * g;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(ar), hi = *reinterpret_cast<const bf16x4*>(ar + 4);
+                    af[s] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                } else {
+                    const float* ar = reinterpret_cast<const float*>(p.X) + arow + k0[s] + 8 * g;
+                    ax[s][0] = *reinterpret_cast<const f32x4*>(ar), ax[s][1] = *reinterpret_cast<const f32x4*>(ar + 4);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -186,23 +207,38 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
 #pragma unroll
         for (int nt = 0; nt < PG_NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < PG_NB; ++s)
+        for (int s = 0; s < PG_NB; ++s) {
+            if constexpr (NT == 1) {
 #pragma unroll
-            for (int nt = 0; nt < PG_NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], wf[s][nt], acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < PG_NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], __builtin_bit_cast(bf16x8, wf[s][nt][0]), acc[nt], 0, 0, 0);
+            } else {
+                u32x4 at[NT];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    unsigned tt[NT];
+                    sp_split2<NT>(ax[s][d >> 1][2 * (d & 1)], ax[s][d >> 1][2 * (d & 1) + 1], tt);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) at[t][d] = tt[t];
+                }
+#pragma unroll
+                for (int nt = 0; nt < PG_NT; ++nt) acc[nt] = sp_mfma<NT>(at, wf[s][nt], acc[nt]);
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < PG_NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[((w * PG_NT + nt) * 4 + i) * 64 + lane] = acc[nt][i];
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = tid + 512 * u, row = e >> 6, col = e & 63;
+        for (int u = 0; u < (PG_NT + 1) / 2; ++u) {
+            const int e = tid + 512 * u, row = e / (16 * PG_NT), col = e % (16 * PG_NT);
             const int idx = (((col >> 4) * 4) + (row & 3)) * 64 + 16 * (row >> 2) + (col & 15);
             float sum = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) sum += red[ww * PG_NT * 4 * 64 + idx];
+            for (int ww = 0; ww < 8; ++ww) sum += red[ww * PG_NT * 4 * 64 + min(idx, PG_NT * 4 * 64 - 1)];
             const int mrow = n0 + row, ncol = n_base + col;
-            if (mrow < N && ncol < p.NO) p.H0[(int64_t)mrow * p.ldh0 + ncol] = sum + p.bias[ncol];
+            if (e < 256 * PG_NT && mrow < N && ncol < p.NO) p.H0[(int64_t)mrow * p.ldh0 + ncol] = sum + p.bias[ncol];
         }
         if (half == 0) {
             const int i = tid >> 5, slot = tid & 31;
@@ -246,8 +282,34 @@ __global__ __launch_bounds__(512) void cogmen_project_graph_kernel(const PgP p) 
 }  // namespace
 
 extern "C" int erc_cogmen_project_graph_ok(int K, int n_out, int B, int ldx, int ldw) {
-    return n_out > 0 && n_out <= 16 * 2 * PG_NT - 16 && K >= 32 && K <= 32 * 8 * PG_NB && K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&
+    return n_out > 0 && n_out <= 112 && K >= 32 && K <= 32 * 8 * PG_NB && K % 4 == 0 && ldx % 4 == 0 && ldw % 4 == 0 &&
            B > 0 && B <= PG_BMAX;
+}
+
+static int project_graph_launch(int terms, const void* X, int ldx, const void* W, int64_t w_plane, int ldw, const float* bias, float* H0,
+                                int ldh0, int n_out, int K, const int64_t* lengths, const int64_t* speakers, int64_t spk_sb,
+                                int64_t spk_st, int B, int T, int wp, int wf, int n_speakers, int n_cap, int e_cap,
+                                int32_t* node_off, int32_t* node_row, int32_t* node_spk, int32_t* in_ptr, int32_t* in_src,
+                                int32_t* in_typ, int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ, int32_t* out_eid,
+                                int32_t* counts, const int32_t* desc, void* stream) {
+    ERC_REQUIRE(X && W && bias && H0 && (lengths || desc) && speakers && node_off && node_row && node_spk && in_ptr && in_src && in_typ &&
+                    out_ptr && out_dst && out_typ && out_eid && counts,
+                "cogmen_project_graph: null pointer");
+    ERC_REQUIRE(erc_cogmen_project_graph_ok(K, n_out, B, ldx, ldw) && ((uintptr_t)X & (terms > 1 ? 15 : 7)) == 0 && ((uintptr_t)W & 7) == 0 &&
+                    ldh0 >= n_out && T > 0 && n_speakers > 0 && n_cap > 0 && e_cap > 0,
+                "cogmen_project_graph: unsupported sizes K=%d n_out=%d B=%d T=%d (erc_cogmen_project_graph_ok)", K, n_out, B, T);
+    ERC_REQUIRE(wp >= -1 && wf >= -1, "cogmen_project_graph: window must be >= -1");
+    ERC_REQUIRE(terms >= 1 && terms <= 3 && (terms == 1 || (w_plane > 0 && w_plane % 4 == 0)), "cogmen_project_graph: terms=%d w_plane=%lld",
+                terms, (long long)w_plane);
+    PgP p{X, (const unsigned short*)W, w_plane, bias, H0, ldx, ldw, ldh0, K, n_out, lengths, speakers, spk_sb, spk_st,
+          B, T, wp < 0 ? T : wp, wf < 0 ? T : wf, n_speakers, n_cap, e_cap, node_off, node_row, node_spk, in_ptr, in_src, in_typ,
+          out_ptr, out_dst, out_typ, out_eid, counts, desc};
+    // 256 workgroups: 128 pairs (bf16 mode: column tiles 0-3 | 4-6), 64 quads (two terms: two tiles each), 32 octets (three: one each)
+    if (terms == 1) hipLaunchKernelGGL((cogmen_project_graph_kernel<1, 4, 2>), dim3(256), dim3(512), 0, (hipStream_t)stream, p);
+    else if (terms == 2) hipLaunchKernelGGL((cogmen_project_graph_kernel<2, 2, 4>), dim3(256), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((cogmen_project_graph_kernel<3, 1, 8>), dim3(256), dim3(512), 0, (hipStream_t)stream, p);
+    ERC_LAUNCH_CHECK("cogmen_project_graph");
+    return ERC_OK;
 }
 
 extern "C" int erc_cogmen_project_graph(const void* X, int ldx, const void* W, int ldw, const float* bias, float* H0, int ldh0,
@@ -256,17 +318,21 @@ extern "C" int erc_cogmen_project_graph(const void* X, int ldx, const void* W, i
                                         int32_t* node_off, int32_t* node_row, int32_t* node_spk, int32_t* in_ptr,
                                         int32_t* in_src, int32_t* in_typ, int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ,
                                         int32_t* out_eid, int32_t* counts, const int32_t* desc, void* stream) {
-    ERC_REQUIRE(X && W && bias && H0 && (lengths || desc) && speakers && node_off && node_row && node_spk && in_ptr && in_src && in_typ &&
-                    out_ptr && out_dst && out_typ && out_eid && counts,
-                "cogmen_project_graph: null pointer");
-    ERC_REQUIRE(erc_cogmen_project_graph_ok(K, n_out, B, ldx, ldw) && ((uintptr_t)X & 7) == 0 && ((uintptr_t)W & 7) == 0 &&
-                    ldh0 >= n_out && T > 0 && n_speakers > 0 && n_cap > 0 && e_cap > 0,
-                "cogmen_project_graph: unsupported sizes K=%d n_out=%d B=%d T=%d (erc_cogmen_project_graph_ok)", K, n_out, B, T);
-    ERC_REQUIRE(wp >= -1 && wf >= -1, "cogmen_project_graph: window must be >= -1");
-    PgP p{(const unsigned short*)X, (const unsigned short*)W, bias, H0, ldx, ldw, ldh0, K, n_out, lengths, speakers, spk_sb, spk_st,
-          B, T, wp < 0 ? T : wp, wf < 0 ? T : wf, n_speakers, n_cap, e_cap, node_off, node_row, node_spk, in_ptr, in_src, in_typ,
-          out_ptr, out_dst, out_typ, out_eid, counts, desc};
-    hipLaunchKernelGGL(cogmen_project_graph_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, p);   // 128 pairs of workgroups
-    ERC_LAUNCH_CHECK("cogmen_project_graph");
-    return ERC_OK;
+    return project_graph_launch(1, X, ldx, W, 0, ldw, bias, H0, ldh0, n_out, K, lengths, speakers, spk_sb, spk_st, B, T, wp, wf,
+                                n_speakers, n_cap, e_cap, node_off, node_row, node_spk, in_ptr, in_src, in_typ, out_ptr, out_dst,
+                                out_typ, out_eid, counts, desc, stream);
+}
+
+// Split compute modes: X fp32 [rows, ldx] (16-byte aligned rows), W = `terms` (2 | 3) bf16 planes [n_out, ldw], w_plane elements apart
+// (ErcShadowTab mode 0 with terms planes).  Everything else as erc_cogmen_project_graph.
+extern "C" int erc_cogmen_project_graph_x(int terms, const float* X, int ldx, const void* W, int64_t w_plane, int ldw, const float* bias,
+                                          float* H0, int ldh0, int n_out, int K, const int64_t* lengths, const int64_t* speakers,
+                                          int64_t spk_sb, int64_t spk_st, int B, int T, int wp, int wf, int n_speakers, int n_cap,
+                                          int e_cap, int32_t* node_off, int32_t* node_row, int32_t* node_spk, int32_t* in_ptr,
+                                          int32_t* in_src, int32_t* in_typ, int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ,
+                                          int32_t* out_eid, int32_t* counts, const int32_t* desc, void* stream) {
+    ERC_REQUIRE(terms == 2 || terms == 3, "cogmen_project_graph_x: terms = %d (2 or 3)", terms);
+    return project_graph_launch(terms, X, ldx, W, w_plane, ldw, bias, H0, ldh0, n_out, K, lengths, speakers, spk_sb, spk_st, B, T, wp,
+                                wf, n_speakers, n_cap, e_cap, node_off, node_row, node_spk, in_ptr, in_src, in_typ, out_ptr, out_dst,
+                                out_typ, out_eid, counts, desc, stream);
 }

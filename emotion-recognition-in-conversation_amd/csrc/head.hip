@@ -155,6 +155,7 @@ struct HeadP {
     int ldb16;
     const int32_t* n_dev;        // capacity mode: the true row count lives on the device (N = the capacity the grid is sized for)
     const int32_t* label_rows;   // labels[label_rows[row]] instead of labels[row] (labels kept in a resident store), or null
+    int lddl;                    // row pitch of dlogits (>= C; 8 in the split compute modes: 16-byte rows for the weight-gradient launch)
 };
 
 #define HF_STAMP(slot)                                                                                              \
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
             if (r < 8) sD[rt][4 * g + q][cr] = dq;
             if (rv && r < C) {
                 p.logits[(int64_t)row * C + r] = v;
-                p.dlogits[(int64_t)row * C + r] = dq;
+                p.dlogits[(int64_t)row * p.lddl + r] = dq;
                 if (p.dlb) p.dlb[(int64_t)row * 8 + r] = hf_bf(dq);
             }
             if (rv && r == 0) lsum += wyq[q] * (lse - ly), hsum += ((int)am == y) ? 1.f : 0.f;
@@ -654,7 +655,8 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
                              float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                              const float* bn_part, int bn_tiles, float* saved_out, float* running_mean, float* running_var,
                              float momentum, float eps, int defer, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16,
-                             const int32_t* n_dev, const int32_t* label_rows, void* stream) {
+                             const int32_t* n_dev, const int32_t* label_rows, int lddl, void* stream) {
+    ERC_REQUIRE(lddl == 0 || lddl >= C, "head_fused: lddl = %d < C = %d", lddl, C);
     ERC_REQUIRE((!H3b && !Zb && !dZb && !dlb) || (H3b && Zb && dZb && dlb && ldb16 >= F && ldb16 % 4 == 0 && (((uintptr_t)H3b) & 7) == 0),
                 "head_fused: bf16 operand copies (all four or none, pitch %% 4 == 0)");
     ERC_REQUIRE(H2 && gamma && beta && (saved || bn_part) && W0 && b0 && W3 && b3 && labels && H3 && Z && logits && dlogits && dZ && dY &&
@@ -675,7 +677,7 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     p.momentum = momentum, p.eps = eps;
     p.defer = defer ? 1 : 0;
     p.H3b = (unsigned short*)H3b, p.Zb = (unsigned short*)Zb, p.dZb = (unsigned short*)dZb, p.dlb = (unsigned short*)dlb, p.ldb16 = ldb16;
-    p.n_dev = n_dev, p.label_rows = label_rows;
+    p.n_dev = n_dev, p.label_rows = label_rows, p.lddl = lddl ? lddl : C;
     p.stamps = g_head_stamps;
     const int rpw = erc_head_fused_rows_per_workgroup(n_rows) / 16;
     const int grid = erc_cdiv(n_rows, 16 * rpw);
@@ -697,11 +699,11 @@ extern "C" int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C
                               const float* b3, const int64_t* labels, const float* weight, float drop_p,
                               const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                               float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* H3b, void* Zb,
-                              void* dZb, void* dlb, int ldb16, const int32_t* n_dev, const int32_t* label_rows, void* stream) {
+                              void* dZb, void* dlb, int ldb16, const int32_t* n_dev, const int32_t* label_rows, int lddl, void* stream) {
     ERC_REQUIRE(saved, "head_fused: null pointer");
     return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, saved, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                              H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, nullptr, 0, nullptr, nullptr,
-                             nullptr, 0.f, 0.f, 0, H3b, Zb, dZb, dlb, ldb16, n_dev, label_rows, stream);
+                             nullptr, 0.f, 0.f, 0, H3b, Zb, dZb, dlb, ldb16, n_dev, label_rows, lddl, stream);
 }
 
 extern "C" int erc_head_fused_part_floats(void) { return HF_PART; }
@@ -716,11 +718,11 @@ extern "C" int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, in
                                  float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                                  const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
                                  float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, const int32_t* n_dev,
-                                 const int32_t* label_rows, void* stream) {
+                                 const int32_t* label_rows, int lddl, void* stream) {
     ERC_REQUIRE(bn_part && saved, "head_fused_bn: null pointer");
     return head_fused_launch(H2, ldh, n_rows, F, C, gamma, beta, nullptr, slope, W0, b0, W3, b3, labels, weight, drop_p, rng_state,
                              H3, Z, logits, dlogits, dZ, dY, bn_bwd, dgamma, dbeta, stats, ws, bn_part, bn_tiles, saved,
-                             running_mean, running_var, momentum, eps, defer_reduce, H3b, Zb, dZb, dlb, ldb16, n_dev, label_rows, stream);
+                             running_mean, running_var, momentum, eps, defer_reduce, H3b, Zb, dZb, dlb, ldb16, n_dev, label_rows, lddl, stream);
 }
 
 extern "C" int erc_bn_bwd_apply(const float* x, int ldx, int N, int F, const float* gamma, const float* saved,

@@ -25,7 +25,9 @@ __global__ __launch_bounds__(256) void shadow_refresh_kernel(const float* __rest
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < d.n_el; idx += (int64_t)gridDim.x * 256) {
         const int32_t x = (int32_t)idx;
         const int32_t q = x / d.n0, d0 = x - q * d.n0, d2 = q / d.n1, d1 = q - d2 * d.n1;
-        shadow[shadow_dst(d, d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2)] = f2bf_u16(p[d.src_off + idx]);
+        const int64_t dst = shadow_dst(d, d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2);
+        float r = p[d.src_off + idx];
+        for (int t = 0; t < d.terms; ++t) shadow[dst + t * d.plane_stride] = bf_term_next(r);
     }
 }
 
@@ -257,12 +259,13 @@ static int check_shadow_tab(const ShadowTab& tab, int64_t n, int64_t shadow_nume
         const ShadowDesc& d = tab.d[t];
         ERC_REQUIRE(d.src_off >= 0 && d.n_el > 0 && d.src_off + d.n_el <= n && d.n_el < (1ll << 31) && d.n0 > 0 && d.n1 > 0 &&
                         d.dst_off >= 0 && d.ld > 0 && (d.mode == 0 || d.mode == 1) && d.sn0 >= 0 && d.sn1 >= 0 && d.sn2 >= 0 &&
-                        d.sk0 >= 0 && d.sk1 >= 0 && d.sk2 >= 0, "%s: shadow descriptor %d out of range", who, t);
+                        d.sk0 >= 0 && d.sk1 >= 0 && d.sk2 >= 0 && d.terms >= 1 && d.terms <= 3 && (d.terms == 1 || d.plane_stride > 0),
+                    "%s: shadow descriptor %d out of range", who, t);
         const int64_t m0 = (d.n0 < d.n_el ? d.n0 : d.n_el) - 1, q1 = (d.n_el - 1) / d.n0, m1 = q1 < d.n1 ? q1 : d.n1 - 1,
                       m2 = q1 / d.n1;
         const int64_t nmax = m0 * d.sn0 + m1 * d.sn1 + m2 * d.sn2, kmax = m0 * d.sk0 + m1 * d.sk1 + m2 * d.sk2;
-        const int64_t last = d.mode == 0 ? d.dst_off + nmax * d.ld + kmax
-                                         : d.dst_off + (((nmax >> 4) * d.ld + (kmax >> 5)) << 9) + 511;
+        const int64_t last = (d.mode == 0 ? d.dst_off + nmax * d.ld + kmax
+                                          : d.dst_off + (((nmax >> 4) * d.ld + (kmax >> 5)) << 9) + 511) + (d.terms - 1) * d.plane_stride;
         ERC_REQUIRE((d.mode == 0 || (kmax >> 5) < d.ld) && last < shadow_numel,
                     "%s: shadow descriptor %d reaches element %lld of a %lld-element shadow buffer", who, t, (long long)last,
                     (long long)shadow_numel);
@@ -283,7 +286,7 @@ static int adam_launch(float* p, const float* g, float* m, float* v, int64_t n, 
     for (int t = 0; t < tab.n; ++t) {
         const ShadowDesc& d = tab.d[t];
         if (d.src_off % 4 || d.n0 % 4 || d.n_el % 4) tab.flags &= ~1;
-        const bool kq = d.sn0 == 0 && d.sk0 == 1 && d.sk1 % 4 == 0 && d.sk2 % 4 == 0 && d.dst_off % 4 == 0 &&
+        const bool kq = d.sn0 == 0 && d.sk0 == 1 && d.sk1 % 4 == 0 && d.sk2 % 4 == 0 && d.dst_off % 4 == 0 && d.plane_stride % 4 == 0 &&
                         (d.mode == 1 || d.ld % 4 == 0) && ((uintptr_t)shadow_base & 7) == 0;
         if (kq) tab.flags |= 2 << t;
     }
@@ -311,7 +314,7 @@ extern "C" int erc_adam_step(float* p, const float* g, float* m, float* v, int64
     ShadowTab tab{};
     if (bf16_shadow && shadow_n > 0) {
         tab.n = 1;
-        tab.d[0] = ShadowDesc{shadow_off, shadow_n, 0, (int32_t)shadow_n, 1, 0, 0, 0, 1, 0, 0, (int32_t)shadow_n, 0};   // identity: k = idx
+        tab.d[0] = ShadowDesc{shadow_off, shadow_n, 0, (int32_t)shadow_n, 1, 0, 0, 0, 1, 0, 0, (int32_t)shadow_n, 0, 0, 1, 0};   // identity: k = idx
     }
     return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, clip_norm, gnorm, state,
                        bf16_shadow, shadow_n, tab, skip_flag, stream);

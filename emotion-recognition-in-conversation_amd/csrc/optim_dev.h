@@ -15,9 +15,15 @@ namespace {
 //           elements of (column tile n / 16, K block k / 32) are contiguous, lane (r = n % 16, g = (k % 32) / 8) at
 //           [(g * 16 + r) * 8, +8) -- a wavefront's fragment load is ONE contiguous 1 KB run (8 full cache lines;
 //           the row-major layout cost 16 half-used lines per load and the L1 miss path, not bytes, set the time).
+//   terms > 1 (the split compute modes f32x2 / f32x3, csrc/split_dev.h): the range is stored as `terms` bf16 PLANES of the same
+//   layout, plane t at + t * plane_stride elements, holding term t of the parameter's bf16 expansion
+//   p = t0 + t1 (+ t2),  t0 = bf16(p), t1 = bf16(p - t0), t2 = bf16(p - t0 - t1)   (round to nearest even; the remainders
+//   are exact in fp32), so that products against all planes are fp32-class on the bf16 matrix cores.
 struct ShadowDesc {
     int64_t src_off, n_el, dst_off;
     int32_t n0, n1, sn0, sn1, sn2, sk0, sk1, sk2, ld, mode;
+    int64_t plane_stride;
+    int32_t terms, pad_;
 };
 constexpr int SHADOW_MAX = 8;
 struct ShadowTab {
@@ -33,6 +39,12 @@ __device__ __forceinline__ unsigned short f2bf_u16(float f) {
     const __bf16 h = (__bf16)f;
     return __builtin_bit_cast(unsigned short, h);
 }
+// term t of the bf16 expansion of x (see ShadowDesc.terms); `r` carries the remainder from term to term
+__device__ __forceinline__ unsigned short bf_term_next(float& r) {
+    const __bf16 h = (__bf16)r;
+    r -= (float)h;
+    return __builtin_bit_cast(unsigned short, h);
+}
 
 // Four consecutive elements (i0 % 4 == 0) at once: with src_off, n0 multiples of 4 (checked by the host; the flat buffer
 // aligns every group to 64 floats) they share d1 and d2, so one index decomposition serves the quad, and when they run
@@ -44,15 +56,20 @@ __device__ __forceinline__ void shadow_store4_desc(unsigned short* __restrict__ 
         const int32_t x = (int32_t)idx;
         const int32_t q = x / d.n0, d0 = x - q * d.n0, d2 = q / d.n1, d1 = q - d2 * d.n1;
         const int32_t n = d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, k = d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2;
-        const unsigned short h0 = f2bf_u16(pn.x), h1 = f2bf_u16(pn.y), h2 = f2bf_u16(pn.z), h3 = f2bf_u16(pn.w);
-        if (d.sn0 == 0 && d.sk0 == 1 && k_quads) {   // k_quads (host flag): k % 4 == 0 and 8-byte aligned destinations
-            *reinterpret_cast<uint2*>(shadow + shadow_dst(d, n, k)) =
-                make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
-        } else {
-            shadow[shadow_dst(d, n, k)] = h0;
-            shadow[shadow_dst(d, n + d.sn0, k + d.sk0)] = h1;
-            shadow[shadow_dst(d, n + 2 * d.sn0, k + 2 * d.sk0)] = h2;
-            shadow[shadow_dst(d, n + 3 * d.sn0, k + 3 * d.sk0)] = h3;
+        float r0 = pn.x, r1 = pn.y, r2 = pn.z, r3 = pn.w;
+        unsigned short* sp = shadow;
+#pragma unroll 1
+        for (int t = 0; t < d.terms; ++t, sp += d.plane_stride) {
+            const unsigned short h0 = bf_term_next(r0), h1 = bf_term_next(r1), h2 = bf_term_next(r2), h3 = bf_term_next(r3);
+            if (d.sn0 == 0 && d.sk0 == 1 && k_quads) {   // k_quads (host flag): k % 4 == 0 and 8-byte aligned destinations
+                *reinterpret_cast<uint2*>(sp + shadow_dst(d, n, k)) =
+                    make_uint2((uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16));
+            } else {
+                sp[shadow_dst(d, n, k)] = h0;
+                sp[shadow_dst(d, n + d.sn0, k + d.sk0)] = h1;
+                sp[shadow_dst(d, n + 2 * d.sn0, k + 2 * d.sk0)] = h2;
+                sp[shadow_dst(d, n + 3 * d.sn0, k + 3 * d.sk0)] = h3;
+            }
         }
     }
 }
@@ -67,7 +84,10 @@ __device__ __forceinline__ void shadow_store_desc(unsigned short* __restrict__ s
     if (idx >= 0 && idx < d.n_el) {
         const int32_t x = (int32_t)idx;
         const int32_t q = x / d.n0, d0 = x - q * d.n0, d2 = q / d.n1, d1 = q - d2 * d.n1;
-        shadow[shadow_dst(d, d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2)] = f2bf_u16(pn);
+        const int64_t dst = shadow_dst(d, d0 * d.sn0 + d1 * d.sn1 + d2 * d.sn2, d0 * d.sk0 + d1 * d.sk1 + d2 * d.sk2);
+        float r = pn;
+#pragma unroll 1
+        for (int t = 0; t < d.terms; ++t) shadow[dst + t * d.plane_stride] = bf_term_next(r);
     }
 }
 __device__ __forceinline__ void shadow_store(unsigned short* __restrict__ shadow, const ShadowTab& tab, int64_t i, float pn) {

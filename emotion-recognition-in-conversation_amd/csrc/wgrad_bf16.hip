@@ -27,6 +27,7 @@
 // float atomics, bit-reproducible.
 #include "erc_common.h"
 #include "optim_dev.h"
+#include "split_dev.h"
 #include <string.h>
 
 namespace {
@@ -110,7 +111,7 @@ __device__ __forceinline__ unsigned perm_hi(unsigned x, unsigned y) { return __b
 // of the record over the same k-steps -- they request the same A rows at about the same time, so the 256 B of an A row per
 // k reach the CU once instead of once per column tile (at N = 33 k the A operand, 6.6 MB per record, does not fit a 4 MB L2 and
 // was streamed through the fabric 22 times for the 22 column tiles of the projection gradient: 397 of the launch's 595 MB).
-template <bool ADAM, bool WIDE>
+template <bool ADAM, bool WIDE, int NT>
 __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float* red, float* bred, int* idx, int* s_flag,
                                         float* slabs, int* counters, uint64_t* stamps_item, uint64_t* stamps_tile, const W2Adam& ad) {
     uint64_t* stamps = stamps_item;
@@ -148,6 +149,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
             ShadowDesc& b = wt->d[t];
             b.src_off = a.src_off, b.n_el = a.n_el, b.dst_off = a.dst_off, b.n0 = a.n0, b.n1 = a.n1, b.sn0 = a.sn0, b.sn1 = a.sn1;
             b.sn2 = a.sn2, b.sk0 = a.sk0, b.sk1 = a.sk1, b.sk2 = a.sk2, b.ld = a.ld, b.mode = a.mode;
+            b.plane_stride = a.plane_stride, b.terms = a.terms;
         }
     };
     auto adam_quad = [&](const int64_t off, const f32x4 gq, const f32x4 pq, const f32x4 mq, const f32x4 vq) __attribute__((always_inline)) -> float4 {
@@ -235,41 +237,6 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     const int ns = WIDE ? max(0, ks_end - ks_begin) : (max(0, ks_end - ks_begin) + 3) >> 2;
     auto kstep = [&](const int sidx) __attribute__((always_inline)) { return WIDE ? ks_begin + sidx : ks_begin + w + 4 * sidx; };
 
-    // Every global load is unconditional (a guarded load is a branch + a full wait, finding 1): an out-of-range k reads a
-    // clamped row and its words are ANDed with 0.  A does not depend on the row gather: its first group is requested in
-    // front of the gather stage.
-    auto load_a = [&](const int s0, u32x4 (&a)[8]) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = 4 * kstep(s0 + u) + g;
-            const int kl = max(0, min(k - k_begin, nk - 1));
-            a[u] = *(const ERC_GLOBAL u32x4*)(Ag + (int64_t)(k_begin + kl) * d.lda + a_c);
-        }
-    };
-    auto load_b = [&](const int s0, u32x2 (&b)[8]) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = 4 * kstep(s0 + u) + g;
-            const int kl = max(0, min(k - k_begin, nk - 1));
-            const int64_t brow = (int64_t)(gath ? idx[kl] : k_begin + kl) * d.ldb;
-            b[u] = *(const ERC_GLOBAL u32x2*)(Bg + brow + b_c);
-        }
-    };
-    // FOUR 8-step groups in flight per wavefront (192 VGPRs of operand words; the accumulators live in AGPRs): at N = 1982 a
-    // wavefront's whole K range (31 steps) is requested before the first product -- one memory latency instead of two
-    u32x4 ga0[8], ga1[8], ga2[8], ga3[8];
-    u32x2 gb0[8], gb1[8], gb2[8], gb3[8];
-    load_a(0, ga0);
-    if (gath) {
-        for (int t = tid; t < nk; t += 256) idx[t] = gather[k_begin + t];
-        __syncthreads();
-    }
-    load_b(0, gb0);
-    load_a(8, ga1), load_b(8, gb1);
-    load_a(16, ga2), load_b(16, gb2);
-    load_a(24, ga3), load_b(24, gb3);
-    W2_STAMP(1);
-
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -285,70 +252,207 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
     const bool want_a = d.bias_a != nullptr && tn == 0, want_b = d.bias_b != nullptr;   // uniform
 
-    auto mma_group = [&](const int s0, u32x4 (&a)[8], u32x2 (&b)[8]) {
-        // k mask of every step, applied to the raw words -- only a group that reaches past the item's k range needs it (uniform)
-        const bool ragged = 4 * (WIDE ? ks_begin + s0 + 7 : ks_begin + 4 * (s0 + 7) + 3) + 3 >= min(K_true, 4 * ks_end);
-        if (ragged) {
-#pragma unroll
+    if constexpr (NT == 1) {
+        // Every global load is unconditional (a guarded load is a branch + a full wait, finding 1): an out-of-range k reads a
+        // clamped row and its words are ANDed with 0.  A does not depend on the row gather: its first group is requested in
+        // front of the gather stage.
+        auto load_a = [&](const int s0, u32x4 (&a)[8]) {
+    #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int ks = kstep(s0 + u);
-                const unsigned km = (ks < ks_end && 4 * ks + g < K_true) ? 0xffffffffu : 0u;
-                a[u] = (u32x4){a[u].x & km, a[u].y & km, a[u].z & km, a[u].w & km};
-                b[u] = (u32x2){b[u].x & km, b[u].y & km};
+                const int k = 4 * kstep(s0 + u) + g;
+                const int kl = max(0, min(k - k_begin, nk - 1));
+                a[u] = *(const ERC_GLOBAL u32x4*)(Ag + (int64_t)(k_begin + kl) * d.lda + a_c);
             }
+        };
+        auto load_b = [&](const int s0, u32x2 (&b)[8]) {
+    #pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = 4 * kstep(s0 + u) + g;
+                const int kl = max(0, min(k - k_begin, nk - 1));
+                const int64_t brow = (int64_t)(gath ? idx[kl] : k_begin + kl) * d.ldb;
+                b[u] = *(const ERC_GLOBAL u32x2*)(Bg + brow + b_c);
+            }
+        };
+        // FOUR 8-step groups in flight per wavefront (192 VGPRs of operand words; the accumulators live in AGPRs): at N = 1982 a
+        // wavefront's whole K range (31 steps) is requested before the first product -- one memory latency instead of two
+        u32x4 ga0[8], ga1[8], ga2[8], ga3[8];
+        u32x2 gb0[8], gb1[8], gb2[8], gb3[8];
+        load_a(0, ga0);
+        if (gath) {
+            for (int t = tid; t < nk; t += 256) idx[t] = gather[k_begin + t];
+            __syncthreads();
         }
-        // fragment j of B: slot pair (2 dd, 2 dd + 1) = element j of loads 2 dd, 2 dd + 1
-        u32x4 fb[4];
+        load_b(0, gb0);
+        load_a(8, ga1), load_b(8, gb1);
+        load_a(16, ga2), load_b(16, gb2);
+        load_a(24, ga3), load_b(24, gb3);
+        W2_STAMP(1);
+
+        auto mma_group = [&](const int s0, u32x4 (&a)[8], u32x2 (&b)[8]) {
+            // k mask of every step, applied to the raw words -- only a group that reaches past the item's k range needs it (uniform)
+            const bool ragged = 4 * (WIDE ? ks_begin + s0 + 7 : ks_begin + 4 * (s0 + 7) + 3) + 3 >= min(K_true, 4 * ks_end);
+            if (ragged) {
+    #pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ks = kstep(s0 + u);
+                    const unsigned km = (ks < ks_end && 4 * ks + g < K_true) ? 0xffffffffu : 0u;
+                    a[u] = (u32x4){a[u].x & km, a[u].y & km, a[u].z & km, a[u].w & km};
+                    b[u] = (u32x2){b[u].x & km, b[u].y & km};
+                }
+            }
+            // fragment j of B: slot pair (2 dd, 2 dd + 1) = element j of loads 2 dd, 2 dd + 1
+            u32x4 fb[4];
+    #pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                fb[0][dd] = perm_lo(b[2 * dd].x, b[2 * dd + 1].x), fb[1][dd] = perm_hi(b[2 * dd].x, b[2 * dd + 1].x);
+                fb[2][dd] = perm_lo(b[2 * dd].y, b[2 * dd + 1].y), fb[3][dd] = perm_hi(b[2 * dd].y, b[2 * dd + 1].y);
+            }
+            if (want_b) {
+    #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    bacc_b[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, fb[j]), bacc_b[j], 0, 0, 0);
+            }
+    #pragma unroll
+            for (int ip = 0; ip < 4; ++ip) {   // fragments 2 ip, 2 ip + 1 of A come from dword ip of the loads
+                u32x4 fa0, fa1;
+    #pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    fa0[dd] = perm_lo(a[2 * dd][ip], a[2 * dd + 1][ip]);
+                    fa1[dd] = perm_hi(a[2 * dd][ip], a[2 * dd + 1][ip]);
+                }
+                if (want_a) {
+                    bacc_a[2 * ip] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa0), ones, bacc_a[2 * ip], 0, 0, 0);
+                    bacc_a[2 * ip + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa1), ones, bacc_a[2 * ip + 1], 0, 0, 0);
+                }
+    #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * ip][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa0), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                             acc[2 * ip][j], 0, 0, 0);
+                    acc[2 * ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa1), __builtin_bit_cast(bf16x8, fb[j]),
+                                                                                 acc[2 * ip + 1][j], 0, 0, 0);
+                }
+            }
+        };
+        // ring of four groups: a group's buffers are refilled (unconditionally: past the end the clamped rows are re-read and
+        // never multiplied) as soon as its products are issued
+        for (int s0 = 0; s0 < ns; s0 += 32) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(s0, ga0, gb0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(s0 + 32, ga0), load_b(s0 + 32, gb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 8 < ns) mma_group(s0 + 8, ga1, gb1);     // (uniform)
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(s0 + 40, ga1), load_b(s0 + 40, gb1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 16 < ns) mma_group(s0 + 16, ga2, gb2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(s0 + 48, ga2), load_b(s0 + 48, gb2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 24 < ns) mma_group(s0 + 24, ga3, gb3);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(s0 + 56, ga3), load_b(s0 + 56, gb3);
+        }
+    } else {
+        // ---- split compute modes: A [K, lda] and B [K or gathered rows, ldb] are FP32 in memory (lda, ldb multiples of 4, 16-byte
+        //      aligned rows); a k-step is two 16-byte loads of A (output rows m = 8 r .. 8 r + 7) and one of B (columns 4 r ..), every
+        //      value is expanded into NT bf16 terms in registers (csrc/split_dev.h) -- slot pair (2 dd, 2 dd + 1) of fragment i is ONE
+        //      v_cvt_pk_bf16_f32 of element i of k-steps 2 dd, 2 dd + 1 -- and the NT (NT + 1) / 2 term products run on the bf16 matrix
+        //      cores.  
+        const ERC_GLOBAL float* const Af = (const ERC_GLOBAL float*)d.A;
+        const ERC_GLOBAL float* const Bf = (const ERC_GLOBAL float*)d.B;
+        const int a_c1 = ma + 4 < d.M ? ma + 4 : 0;
+        // the ring unit is a HALF group (4 k-steps: 48 operand registers); three of them -- two full 8-step groups in flight spill
+        // (the expansion needs ~50 registers of its own), one leaves a single memory latency uncovered per group
+        struct Half {
+            u32x4 a[8], b[4];
+        };
+        auto load_half = [&](const int s0, Half& h) {
 #pragma unroll
-        for (int dd = 0; dd < 4; ++dd) {
-            fb[0][dd] = perm_lo(b[2 * dd].x, b[2 * dd + 1].x), fb[1][dd] = perm_hi(b[2 * dd].x, b[2 * dd + 1].x);
-            fb[2][dd] = perm_lo(b[2 * dd].y, b[2 * dd + 1].y), fb[3][dd] = perm_hi(b[2 * dd].y, b[2 * dd + 1].y);
+            for (int u = 0; u < 4; ++u) {
+                const int k = 4 * kstep(s0 + u) + g;
+                const int kl = max(0, min(k - k_begin, nk - 1));
+                const ERC_GLOBAL float* row = Af + (int64_t)(k_begin + kl) * d.lda;
+                h.a[2 * u] = *(const ERC_GLOBAL u32x4*)(row + a_c), h.a[2 * u + 1] = *(const ERC_GLOBAL u32x4*)(row + a_c1);
+                const int64_t brow = (int64_t)(gath ? idx[kl] : k_begin + kl) * d.ldb;
+                h.b[u] = *(const ERC_GLOBAL u32x4*)(Bf + brow + b_c);
+            }
+        };
+        Half h0, h1, h2;
+        if (gath) {
+            for (int t = tid; t < nk; t += 256) idx[t] = gather[k_begin + t];
+            __syncthreads();
         }
-        if (want_b) {
+        load_half(0, h0), load_half(4, h1), load_half(8, h2);
+        W2_STAMP(1);
+        auto f32 = [](unsigned w_) __attribute__((always_inline)) { return __builtin_bit_cast(float, w_); };
+        // one 8-step group = halves x (k-steps s0 .. s0 + 3: slot pairs 0, 1) and y (s0 + 4 .. s0 + 7: slot pairs 2, 3)
+        auto mma_group = [&](const int s0, Half& x, Half& y) {
+            const bool ragged = 4 * (ks_begin + 4 * (s0 + 7) + 3) + 3 >= min(K_true, 4 * ks_end);
+            if (ragged) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ks = kstep(s0 + u);
+                    const unsigned km = (ks < ks_end && 4 * ks + g < K_true) ? 0xffffffffu : 0u;
+                    Half& h = u < 4 ? x : y;
+                    const int v = u & 3;
+                    h.a[2 * v] = (u32x4){h.a[2 * v].x & km, h.a[2 * v].y & km, h.a[2 * v].z & km, h.a[2 * v].w & km};
+                    h.a[2 * v + 1] = (u32x4){h.a[2 * v + 1].x & km, h.a[2 * v + 1].y & km, h.a[2 * v + 1].z & km, h.a[2 * v + 1].w & km};
+                    h.b[v] = (u32x4){h.b[v].x & km, h.b[v].y & km, h.b[v].z & km, h.b[v].w & km};
+                }
+            }
+            u32x4 fb[4][NT];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                bacc_b[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, fb[j]), bacc_b[j], 0, 0, 0);
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    const Half& h = dd < 2 ? x : y;
+                    unsigned tt[NT];
+                    sp_split2<NT>(f32(h.b[2 * (dd & 1)][j]), f32(h.b[2 * (dd & 1) + 1][j]), tt);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) fb[j][t][dd] = tt[t];
+                }
+            if (want_b) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = NT - 1; t >= 0; --t)
+                        bacc_b[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8, fb[j][t]), bacc_b[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {      // fragment i of A: element i & 3 of the load half i >> 2
+                u32x4 fa[NT];
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    const Half& h = dd < 2 ? x : y;
+                    unsigned tt[NT];
+                    sp_split2<NT>(f32(h.a[2 * (2 * (dd & 1)) + (i >> 2)][i & 3]), f32(h.a[2 * (2 * (dd & 1) + 1) + (i >> 2)][i & 3]), tt);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) fa[t][dd] = tt[t];
+                }
+                if (want_a) {
+#pragma unroll
+                    for (int t = NT - 1; t >= 0; --t)
+                        bacc_a[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[t]), ones, bacc_a[i], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = sp_mfma<NT>(fa, fb[j], acc[i][j]);
+            }
+        };
+        for (int s0 = 0; s0 < ns; s0 += 24) {
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(s0, h0, h1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(s0 + 12, h0), load_half(s0 + 16, h1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 8 < ns) mma_group(s0 + 8, h2, h0);     // (uniform)
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(s0 + 20, h2), load_half(s0 + 24, h0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s0 + 16 < ns) mma_group(s0 + 16, h1, h2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_half(s0 + 28, h1), load_half(s0 + 32, h2);
         }
-#pragma unroll
-        for (int ip = 0; ip < 4; ++ip) {   // fragments 2 ip, 2 ip + 1 of A come from dword ip of the loads
-            u32x4 fa0, fa1;
-#pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                fa0[dd] = perm_lo(a[2 * dd][ip], a[2 * dd + 1][ip]);
-                fa1[dd] = perm_hi(a[2 * dd][ip], a[2 * dd + 1][ip]);
-            }
-            if (want_a) {
-                bacc_a[2 * ip] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa0), ones, bacc_a[2 * ip], 0, 0, 0);
-                bacc_a[2 * ip + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa1), ones, bacc_a[2 * ip + 1], 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[2 * ip][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa0), __builtin_bit_cast(bf16x8, fb[j]),
-                                                                         acc[2 * ip][j], 0, 0, 0);
-                acc[2 * ip + 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa1), __builtin_bit_cast(bf16x8, fb[j]),
-                                                                             acc[2 * ip + 1][j], 0, 0, 0);
-            }
-        }
-    };
-    // ring of four groups: a group's buffers are refilled (unconditionally: past the end the clamped rows are re-read and
-    // never multiplied) as soon as its products are issued
-    for (int s0 = 0; s0 < ns; s0 += 32) {
-        __builtin_amdgcn_sched_barrier(0);
-        mma_group(s0, ga0, gb0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(s0 + 32, ga0), load_b(s0 + 32, gb0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s0 + 8 < ns) mma_group(s0 + 8, ga1, gb1);     // (uniform)
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(s0 + 40, ga1), load_b(s0 + 40, gb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s0 + 16 < ns) mma_group(s0 + 16, ga2, gb2);
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(s0 + 48, ga2), load_b(s0 + 48, gb2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s0 + 24 < ns) mma_group(s0 + 24, ga3, gb3);
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(s0 + 56, ga3), load_b(s0 + 56, gb3);
     }
     W2_STAMP(2);
     // ---- everything behind the K loop, for ONE column tile: `tn_e` = the tile, `wsel` = 1 for the wavefronts whose accumulators
@@ -702,7 +806,7 @@ struct W2Bases {  // first work item of every descriptor, passed by value (no de
     int v[W2_MAX_DESC];
 };
 
-template <bool ADAM, bool WIDE>
+template <bool ADAM, bool WIDE, int NT>
 __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const W2Desc* __restrict__ table, const int n_desc, const W2Bases bases,
                                                          float* slabs, int* counters, uint64_t* stamps, int stamp_item, const W2Adam ad) {
     __shared__ __attribute__((aligned(16))) float red[4 * 4096];   // 64 KB: two reduction passes
@@ -719,7 +823,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const W2Desc* __restric
     if (local >= d.n_items) return;
     // (stamp_item is a work item of record 0)
     const bool st_item = stamps && L == stamp_item, st_tile = stamps && di == 0 && local / d.splits == stamp_item / d.splits;
-    w2_body<ADAM, WIDE>(d, local, red, bred, idx, &s_flag, slabs, counters, st_item ? stamps : nullptr, st_tile ? stamps : nullptr, ad);
+    w2_body<ADAM, WIDE, NT>(d, local, red, bred, idx, &s_flag, slabs, counters, st_item ? stamps : nullptr, st_tile ? stamps : nullptr, ad);
 }
 
 }  // namespace
@@ -746,7 +850,7 @@ extern "C" int erc_wgrad_bf16_set_spin_limit(int limit) {
 // of tiles * splits; slabs: n_items * erc_wgrad_bf16_slab_floats() floats; counters: one zero-initialised int32 per output
 // tile (left zero by the launch).
 static int w2_launch(int mode, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs, int32_t* counters,
-                     const W2Adam& ad, void* stream) {
+                     const W2Adam& ad, void* stream, int terms = 1) {
     ERC_REQUIRE(table && item_base && n_desc > 0 && n_desc <= W2_MAX_DESC && n_items > 0 && slabs && counters,
                 "wgrad_bf16: bad arguments (at most %d records per launch)", W2_MAX_DESC);
     W2Bases bases{};
@@ -755,15 +859,26 @@ static int w2_launch(int mode, const void* table, int n_desc, const int32_t* ite
                     "wgrad_bf16: item_base[%d] = %d", t, item_base[t]);
         bases.v[t] = item_base[t];
     }
-    if (mode == 1)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
+    ERC_REQUIRE(terms >= 1 && terms <= 3 && (terms == 1 || mode != 2), "wgrad_split: terms = %d (1 .. 3; the wide form is bf16 only)", terms);
+#define W2_GO(ADAM_, NT_)                                                                                                              \
+    hipLaunchKernelGGL((wgrad_bf16_kernel<ADAM_, false, NT_>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, \
+                       n_desc, bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad)
+    if (terms == 2) {
+        if (mode == 1) W2_GO(true, 2);
+        else W2_GO(false, 2);
+    } else if (terms == 3) {
+        if (mode == 1) W2_GO(true, 3);
+        else W2_GO(false, 3);
+    } else if (mode == 1)
+        hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, 1>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
                            bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
     else if (mode == 2)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
+        hipLaunchKernelGGL((wgrad_bf16_kernel<false, true, 1>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
                            bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
     else
-        hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
+        hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, 1>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
                            bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
+#undef W2_GO
     ERC_LAUNCH_CHECK("wgrad_bf16");
     return ERC_OK;
 }
@@ -789,11 +904,11 @@ extern "C" int erc_wgrad_bf16_wide(const void* table, int n_desc, const int32_t*
 // times grad_scale, the bf16 shadows of the table follow.  Records of kind 1 name ranges of g that an earlier launch
 // completed.  counters: one int32 per output tile + 512 (the private launch sequence numbers), zero-filled ONCE and owned
 // by this entry point (the per-tile counters count up monotonically here).  n_items <= 256: every work item resident.
-extern "C" int erc_wgrad_bf16_adam(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
-                                   int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
-                                   float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
-                                   int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
-                                   int32_t* health, void* stream) {
+static int w2_adam_entry(int terms, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                         int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                         int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
+                         int32_t* health, void* stream) {
     static_assert(sizeof(ShadowTab) == sizeof(ErcShadowTab), "shadow table layout");
     ERC_REQUIRE(p && g && m && v && state && health && n > 0 && n_tiles >= 0 && n_items <= 256,
                 "wgrad_bf16_adam: bad arguments (at most 256 work items: all of them must be resident)");
@@ -813,11 +928,40 @@ extern "C" int erc_wgrad_bf16_adam(const void* table, int n_desc, const int32_t*
         ERC_REQUIRE(d.src_off >= 0 && d.n_el > 0 && d.src_off + d.n_el <= n && d.n0 > 0 && d.n1 > 0 && d.ld > 0,
                     "wgrad_bf16_adam: shadow descriptor %d out of range", t);
         if (d.src_off % 4 || d.n0 % 4 || d.n_el % 4) ad.tab.flags &= ~1;
-        const bool kq = d.sn0 == 0 && d.sk0 == 1 && d.sk1 % 4 == 0 && d.sk2 % 4 == 0 && d.dst_off % 4 == 0 &&
+        const bool kq = d.sn0 == 0 && d.sk0 == 1 && d.sk1 % 4 == 0 && d.sk2 % 4 == 0 && d.dst_off % 4 == 0 && d.plane_stride % 4 == 0 &&
                         (d.mode == 1 || d.ld % 4 == 0) && ((uintptr_t)shadow_base & 7) == 0;
         if (kq) ad.tab.flags |= 2 << t;
     }
     (void)shadow_numel;     // (bounds-checked against the buffer by erc_shadow_refresh / erc_adam_step_tab when the table was built)
     ad.shadow = ad.tab.n > 0 ? (unsigned short*)shadow_base : nullptr;
-    return w2_launch(1, table, n_desc, item_base, n_items, slabs, counters, ad, stream);
+    return w2_launch(1, table, n_desc, item_base, n_items, slabs, counters, ad, stream, terms);
+}
+
+extern "C" int erc_wgrad_bf16_adam(const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                                   int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
+                                   float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                                   int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
+                                   int32_t* health, void* stream) {
+    return w2_adam_entry(1, table, n_desc, item_base, n_items, slabs, counters, n_tiles, p, g, m, v, n, lr, beta1, beta2, eps,
+                         weight_decay, decoupled, grad_scale, state, shadow_base, shadow_numel, tab_host, health, stream);
+}
+
+// SPLIT COMPUTE MODES (terms = 2 | 3; csrc/split_dev.h): the same launches for FP32 operands -- the records' A [K, lda] and
+// B [K or gathered rows, ldb] are fp32 (lda, ldb multiples of 4, rows 16-byte aligned, M and N multiples of 4; columns
+// [M, 8 ceil(M / 8)) of A are never read) -- expanded into `terms` bf16 terms in registers: fp32-class weight gradients at the
+// bf16 matrix cores' rate.  Tables, slabs, counters and the fused optimizer exactly as erc_wgrad_bf16 / erc_wgrad_bf16_adam.
+extern "C" int erc_wgrad_split(int terms, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                               int32_t* counters, void* stream) {
+    ERC_REQUIRE(terms == 2 || terms == 3, "wgrad_split: terms = %d (2 or 3)", terms);
+    W2Adam ad{};
+    return w2_launch(0, table, n_desc, item_base, n_items, slabs, counters, ad, stream, terms);
+}
+extern "C" int erc_wgrad_split_adam(int terms, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                                    int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                                    int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
+                                    int32_t* health, void* stream) {
+    ERC_REQUIRE(terms == 2 || terms == 3, "wgrad_split_adam: terms = %d (2 or 3)", terms);
+    return w2_adam_entry(terms, table, n_desc, item_base, n_items, slabs, counters, n_tiles, p, g, m, v, n, lr, beta1, beta2, eps,
+                         weight_decay, decoupled, grad_scale, state, shadow_base, shadow_numel, tab_host, health, stream);
 }

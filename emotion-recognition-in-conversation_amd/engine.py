@@ -232,6 +232,13 @@ class GemmPlanner:
         """C[M,N] = A[K,M]^T B[gather(K),N] with both operands bf16 in memory (COGMEN bf16 mode); ``ct`` stores C
         transposed (C[n * ldc + m]); bias_a / bias_b receive the fp32 column sums of A / B; ``k_dev`` (device int32): K is a
         capacity, the true row count is read on the device."""
+        if self.split_terms > 1:     # split compute modes: fp32 operands, expanded into bf16 terms in registers (erc_wgrad_split)
+            if A.dtype != torch.float32 or B.dtype != torch.float32 or Cm.dtype != torch.float32:
+                raise capi.ErcGraftError("split wgrad: operand dtypes %s %s %s" % (A.dtype, B.dtype, Cm.dtype))
+            if M > 128 or M % 4 or lda % 4 or lda < M or ldb % 4 or ldb < -(-N // 4) * 4 or A.data_ptr() % 16 or B.data_ptr() % 16:
+                raise capi.ErcGraftError("split wgrad: M=%d lda=%d N=%d ldb=%d unsupported" % (M, lda, N, ldb))
+            self.deferred16.append((A, lda, B, ldb, Cm, ldc, M, N, K, bool(ct), bias_a, bias_b, gather, k_dev))
+            return
         if A.dtype != torch.bfloat16 or B.dtype != torch.bfloat16 or Cm.dtype != torch.float32:
             raise capi.ErcGraftError("bf16 wgrad: operand dtypes %s %s %s" % (A.dtype, B.dtype, Cm.dtype))
         if M > 128 or lda % 8 or lda < -(-M // 8) * 8 or ldb % 4 or ldb < -(-N // 4) * 4 or A.data_ptr() % 16 or B.data_ptr() % 8:
@@ -244,6 +251,7 @@ class GemmPlanner:
         self.ranges16.append(g_range)
 
     fused_adam = None     # a FusedAdam: its update is applied by the bf16 weight-gradient launch itself (single-rank steps)
+    split_terms = 1       # 2 | 3: the records of defer16 hold fp32 operands (split compute modes f32x2 / f32x3)
 
     def flush_wgrads_bf16(self, cache):
         """Every record of defer16 as ONE launch (erc_wgrad_bf16); table, slabs and counters are built once per shape.
@@ -261,7 +269,8 @@ class GemmPlanner:
             ((tuple((r.data_ptr(), r.numel()) for r in self.ranges16), ) if fuse else ())
         # large K (B = 512: N = 33 k): the wide form -- a workgroup's four wavefronts take four neighbouring column tiles over the
         # same k-steps, the A operand reaches a CU once per four tiles (csrc/wgrad_bf16.hip WIDE)
-        wide = max(d[8] for d in self.deferred16) > int(os.environ.get("ERC_W2_WIDE_K", 8192))
+        terms = self.split_terms
+        wide = terms == 1 and max(d[8] for d in self.deferred16) > int(os.environ.get("ERC_W2_WIDE_K", 8192))
         fuse = fuse and not wide
         if cache.get("w16_key") != key:
             cap = capi.wgrad_bf16_max_k_per_split()
@@ -328,11 +337,15 @@ class GemmPlanner:
             capi.wgrad_bf16_adam(cache["w16_table"], cache["w16_records"], cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
                                  cache["w16_counters"], cache["w16_tiles"], f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, opt.lr, opt.betas[0],
                                  opt.betas[1], opt.eps, opt.weight_decay, opt.decoupled, 1.0, opt.state, opt.shadow_table,
-                                 opt.skip_flag)
+                                 opt.skip_flag, terms=terms)
             self.adam_fused = True
             return
-        (capi.wgrad_bf16_wide if wide else capi.wgrad_bf16)(cache["w16_table"], cache["w16_records"], cache["w16_bases"],
-                                                            cache["w16_items"], cache["w16_slabs"], cache["w16_counters"])
+        if wide:
+            capi.wgrad_bf16_wide(cache["w16_table"], cache["w16_records"], cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
+                                 cache["w16_counters"])
+        else:
+            capi.wgrad_bf16(cache["w16_table"], cache["w16_records"], cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
+                            cache["w16_counters"], terms=terms)
 
     def split_for(self, M, N, K, bk=None, min_chunks=None):
         if N <= 1025 and bk is None:

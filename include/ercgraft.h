@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define ERC_ABI_VERSION 2
+#define ERC_ABI_VERSION 3
 
 #define ERC_OK 0
 #define ERC_E_ARG (-1)     /* bad shape / null pointer / unsupported size */
@@ -373,8 +373,10 @@ int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const flo
                    const float* b3, const int64_t* labels, const float* weight, float drop_p,
                    const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                    float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* H3b, void* Zb,
-                   void* dZb, void* dlb, int ldb16, const int32_t* n_dev, const int32_t* label_rows, void* stream);
-/* label_rows (or NULL): the label of row i is labels[label_rows[i]] -- labels kept in a resident store (or a padded [B, T]
+                   void* dZb, void* dlb, int ldb16, const int32_t* n_dev, const int32_t* label_rows, int lddl, void* stream);
+/* lddl: row pitch of dlogits in floats (0 = C; the split compute modes pass 8: 16-byte rows for erc_wgrad_split, pad columns
+ * are left untouched and must be finite).
+ * label_rows (or NULL): the label of row i is labels[label_rows[i]] -- labels kept in a resident store (or a padded [B, T]
  * block) are read through the node -> row map instead of being compacted per batch.
  * H3b / Zb / dZb [n_rows, ldb16 >= F] and dlb [n_rows, 8]: optional bf16 copies (all four or none) of H3, Z, dZ and dlogits,
  * the operands of the classifier's weight gradients in the bf16 compute mode (erc_wgrad_bf16); pad columns untouched. */
@@ -391,7 +393,7 @@ int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const 
                       float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws,
                       const float* bn_part, int bn_tiles, float* running_mean, float* running_var, float momentum,
                       float eps, int defer_reduce, void* H3b, void* Zb, void* dZb, void* dlb, int ldb16, const int32_t* n_dev,
-                      const int32_t* label_rows, void* stream);
+                      const int32_t* label_rows, int lddl, void* stream);
 /* floats per workgroup record of erc_head_fused's workspace: [0,112) column sums of dY, [112,224) of dY * xhat, [224] loss
  * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / erc_head_fused_rows_per_workgroup(n_rows)) records */
 int erc_head_fused_part_floats(void);
@@ -506,6 +508,17 @@ int erc_cogmen_project_graph(const void* X, int ldx, const void* W, int ldw, con
                              int32_t* node_off, int32_t* node_row, int32_t* node_spk, int32_t* in_ptr, int32_t* in_src,
                              int32_t* in_typ, int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ, int32_t* out_eid,
                              int32_t* counts, const int32_t* desc, void* stream);
+/* SPLIT COMPUTE MODES (terms = 2 | 3; "f32x2" / "f32x3"): the same launch with the fp32 feature block the reference feeds
+ * rnn.1 (track_mm/cogmen.py:103-105,147) -- X fp32 [rows, ldx], 16-byte aligned rows -- and W = `terms` bf16 planes [n_out, ldw],
+ * w_plane elements apart (ErcShadowTab mode 0, terms planes: the bf16 expansion of rnn.1.weight).  Every A fragment is
+ * expanded into `terms` bf16 terms in registers; the term products of weight >= 2^(-8 (terms - 1)) are accumulated in fp32 on
+ * v_mfma_f32_16x16x32_bf16: H0 to 2^-17 (two terms) / 2^-25 (three) of the exact product's operands (csrc/split_dev.h). */
+int erc_cogmen_project_graph_x(int terms, const float* X, int ldx, const void* W, int64_t w_plane, int ldw, const float* bias,
+                               float* H0, int ldh0, int n_out, int K, const int64_t* lengths, const int64_t* speakers,
+                               int64_t spk_sb, int64_t spk_st, int B, int T, int wp, int wf, int n_speakers, int n_cap,
+                               int e_cap, int32_t* node_off, int32_t* node_row, int32_t* node_spk, int32_t* in_ptr,
+                               int32_t* in_src, int32_t* in_typ, int32_t* out_ptr, int32_t* out_dst, int32_t* out_typ,
+                               int32_t* out_eid, int32_t* counts, const int32_t* desc, void* stream);
 /* desc (or NULL): RESIDENT mode.  The batch is a list of B dialogue slots of a feature store that lives in HBM: desc[b] =
  * length of slot b (0 = empty), desc[B + b] = its first row in the store; X = the store's [U, ldx] bf16 feature rows,
  * speakers = its [U] speaker ids (element stride spk_st), lengths is unused (may be NULL), node_row receives STORE rows (the
@@ -531,6 +544,11 @@ int erc_cogmen_set_stamps(uint64_t* stamps);
 typedef struct ErcShadowDesc {
     int64_t src_off, n_el, dst_off;
     int32_t n0, n1, sn0, sn1, sn2, sk0, sk1, sk2, ld, mode;
+    /* ABI 3: terms = 1 .. 3 bf16 PLANES of the same layout, plane t at + t * plane_stride elements, holding term t of the
+     * parameter's bf16 expansion p = t0 + t1 (+ t2), t0 = bf16(p), t1 = bf16(p - t0), t2 = bf16(p - t0 - t1) -- the weight
+     * operands of the split compute modes (f32x2 / f32x3: fp32-class products on the bf16 matrix cores). */
+    int64_t plane_stride;
+    int32_t terms, pad_;
 } ErcShadowDesc;
 typedef struct ErcShadowTab {
     int32_t n, flags;          /* descriptors in use, <= 8; flags: set by the library */
@@ -589,6 +607,20 @@ int erc_wgrad_bf16_adam(const void* table, int n_desc, const int32_t* item_base,
                         int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, int decoupled, float grad_scale, int64_t* state, void* shadow_base,
                         int64_t shadow_numel, const ErcShadowTab* tab_host, int32_t* health, void* stream);
+
+/* SPLIT COMPUTE MODES (terms = 2 | 3; "f32x2" / "f32x3"): erc_wgrad_bf16 / erc_wgrad_bf16_adam for FP32 operands -- the
+ * autograd weight gradients of loss.backward() (track_mm/cogmen.py:187-188) at fp32-class accuracy on the bf16 matrix cores.
+ * Same table records, but A [K, lda] and B [K or gathered rows, ldb] are fp32 in memory (lda, ldb multiples of 4, rows 16-byte
+ * aligned, M and N multiples of 4); every value is expanded into `terms` bf16 terms in registers and the term products of
+ * weight >= 2^(-8 (terms - 1)) are accumulated in fp32 (csrc/split_dev.h).  Slabs, counters, bias strips, capacity mode (k_dev)
+ * and the fused optimizer exactly as the bf16 entry points (the wide form does not exist here). */
+int erc_wgrad_split(int terms, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                    int32_t* counters, void* stream);
+int erc_wgrad_split_adam(int terms, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                         int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                         int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
+                         int32_t* health, void* stream);
 
 /* Health word: one device int32 that the persistent kernels with bounded polls (erc_dag_rec_*, erc_gcnii_chain_*: their
  * `health` argument; NULL = use state[0] as before) raise to ERC_HEALTH_RAISED when a poll ran into its bound, i.e. when

@@ -18,7 +18,7 @@ def test_library_builds_and_exports_header_symbols():
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.erc_abi_version() == 2
+    assert lib.erc_abi_version() == 3
 
 
 def test_argument_errors_are_reported_not_thrown():

@@ -1,0 +1,210 @@
+"""Split compute modes (f32x2 / f32x3, csrc/split_dev.h): fp32-class products on the bf16 matrix cores.
+
+The reference computes in fp32 (track_mm/cogmen.py:61-74,116-122,179-195) and north_star asks for logits within 1e-4 of
+it.  These tests pin (a) every new building block against float64 products of the SAME fp32 operands, (b) the whole step
+against the UNROUNDED oracle at the tolerances of the fp32 parity path (tests/test_gpu_cogmen.py: 1e-4 / 2e-3), with
+the measured figures printed."""
+import math
+
+import pytest
+import torch
+
+from erc_amd import capi
+from tests.util_cases import cogmen_case, run_cogmen_parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOGIT_TOL, GRAD_TOL = 1e-4, 2e-3
+# what a product may deviate from the float64 product of its fp32 operands, relative to |A| |B| summed over k:
+# two terms keep 2^-17 of every operand, three 2^-25 (fp32 accumulation adds its own ~1e-7 per partial sum)
+PROD_TOL = {2: 3e-5, 3: 3e-7}
+
+
+def _terms_of(w, terms):
+    out, r = [], w.clone()
+    for _ in range(terms):
+        t = r.to(torch.bfloat16).float()
+        out.append(t)
+        r = r - t
+    return out
+
+
+@pytest.mark.parametrize("terms", [1, 2, 3])
+def test_shadow_term_planes(terms):
+    """ErcShadowTab with `terms` planes: plane t holds term t of the bf16 expansion, in both layouts; the planes add up to the
+    parameter to 2^(-8 terms - 1), and an optimizer step keeps them in sync (erc_adam_step_tab)."""
+    torch.manual_seed(0)
+    n_out, K = 100, 232
+    flat = torch.randn(n_out * K + 64, device=DEV) * 0.3
+    t = capi.ShadowTable(DEV)
+    i0 = t.add(64, n_out * K, n_out * K, K, n_out, (0, 1, 0), (1, 0, 0), K, 0, terms=terms)                     # row-major [n][k]
+    i1 = t.add(64, n_out * K, 7 * 8 * 512, K, n_out, (0, 1, 0), (1, 0, 0), 8, 1, terms=terms)                  # fragment order
+    t.seal()
+    capi.shadow_refresh(flat, flat.numel(), t)
+    W = flat[64:64 + n_out * K].view(n_out, K)
+    want = _terms_of(W, terms)
+    for ti in range(terms):
+        p0 = t.view(i0)[ti * t.plane(i0):ti * t.plane(i0) + n_out * K] if terms > 1 else t.view(i0)
+        assert torch.equal(p0.float().view(n_out, K), want[ti]), ti
+        p1 = t.view(i1)[ti * t.plane(i1):ti * t.plane(i1) + 7 * 8 * 512] if terms > 1 else t.view(i1)
+        assert torch.equal(p1, capi.mfma_b_fragment_order(want[ti].to(torch.bfloat16), 8)), ti
+    resid = (W - sum(want)).abs().max() / W.abs().max()
+    assert resid < 2.0 ** (-8 * terms), resid
+    # one Adam step with the table attached: planes follow the updated parameters
+    g = torch.randn_like(flat) * 0.01
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    state = torch.zeros(4 + 512, dtype=torch.int64, device=DEV)
+    capi.adam_step_tab(flat, g, m, v, flat.numel(), 1e-2, 0.9, 0.999, 1e-8, 0.0, False, 1.0, 0.0, None, state, t)
+    want = _terms_of(flat[64:64 + n_out * K].view(n_out, K), terms)
+    for ti in range(terms):
+        p0 = t.view(i0)[ti * t.plane(i0):ti * t.plane(i0) + n_out * K] if terms > 1 else t.view(i0)
+        assert torch.equal(p0.float().view(n_out, K), want[ti]), ti
+
+
+def _project_case(B, T, D, seed, lens=None):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, T + 1, (B, ), generator=g) if lens is None else torch.tensor(lens)
+    x = torch.randn(B, T, D, generator=g)
+    spk = torch.randint(0, 2, (B, T), generator=g)
+    W = (torch.rand(100, D, generator=g) * 2 - 1) / math.sqrt(D)
+    b = torch.randn(100, generator=g) * 0.1
+    return x, lens, spk, W, b
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("shape", [(4, 14, 48, None), (9, 30, 712, None), (32, 110, 1380, None), (3, 5, 32, [5, 1, 3])],
+                         ids=["tiny", "d712", "config2", "k32"])
+def test_project_graph_split(terms, shape):
+    """erc_cogmen_project_graph_x: H0 against the float64 product of the fp32 operands; the graph bit-equal to erc_window_graph_build."""
+    from erc_amd.cogmen import build_graph_tensors
+    B, T, D, lens = shape
+    x, lens, spk, W, b = _project_case(B, T, D, 7, lens)
+    N = int(lens.sum())
+    xd, ld, sd, bd = x.to(DEV), lens.to(DEV), spk.to(DEV), b.to(DEV)
+    flat = torch.zeros(64 + 100 * D, device=DEV)
+    flat[64:] = W.flatten().to(DEV)
+    t = capi.ShadowTable(DEV)
+    i0 = t.add(64, 100 * D, 100 * D, D, 100, (0, 1, 0), (1, 0, 0), D, 0, terms=terms)
+    t.seal()
+    capi.shadow_refresh(flat, flat.numel(), t)
+    g_ref, _, _ = build_graph_tensors(ld, sd, 5, 5, 2, n_nodes=N, explicit=False)
+    E = g_ref["e_cap"]
+    i32 = lambda *s: torch.full(s, -7, dtype=torch.int32, device=DEV)
+    g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E), in_typ=i32(E),
+             out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
+    H0 = torch.full((N, 100), float("nan"), device=DEV)
+    capi.cogmen_project_graph(xd, D, t.view(i0), D, bd, H0, 100, 100, D, ld, sd, B, T, 5, 5, 2, N, E, g, terms=terms, w_plane=t.plane(i0))
+    torch.cuda.synchronize()
+    n_e = int(g["counts"][1])
+    assert int(g["counts"][0]) == N and n_e == int(g_ref["counts"][1])
+    for k in ("node_off", "node_row", "node_spk", "in_ptr", "out_ptr"):
+        assert torch.equal(g[k].cpu(), g_ref[k].cpu()[:g[k].numel()]), k
+    for k in ("in_src", "in_typ", "out_dst", "out_typ", "out_eid"):
+        assert torch.equal(g[k][:n_e].cpu(), g_ref[k][:n_e].cpu()), k
+    rows = torch.cat([x[bi, :int(lens[bi])] for bi in range(B)]).double()
+    want = rows @ W.double().t() + b.double()
+    scale = (rows.abs() @ W.double().abs().t()).max()
+    err = float((H0.cpu().double() - want).abs().max() / scale)
+    print("project_graph_x terms=%d D=%d: max err / sum|a||w| = %.2e" % (terms, D, err))
+    assert err < PROD_TOL[terms], err
+
+
+@pytest.mark.parametrize("terms", [2, 3])
+@pytest.mark.parametrize("fuse_adam", [False, True], ids=["plain", "adam"])
+def test_wgrad_split_products(terms, fuse_adam):
+    """erc_wgrad_split{,_adam}: three records of the shapes the COGMEN step has (ct / non-ct, bias strips on either side, a
+    gathered B operand, N not a multiple of 64, a 6-wide B with a pitch of 8) against float64 products of the same fp32
+    operands; with the optimizer inside, parameters / moments against torch.optim.Adam on those gradients."""
+    from erc_amd.engine import GemmPlanner, FusedAdam
+    torch.manual_seed(3)
+    K, D = 1982, 232
+
+    class Flat:
+        pass
+    sizes = dict(w3=(6, 100), b3=(6, ), w0=(100, 100), b0=(100, ), w1=(100, D), b1=(100, ))
+    offs, off = {}, 0
+    for k, shp in sizes.items():
+        offs[k] = off
+        off += -(-math.prod(shp) // 64) * 64
+    fl = Flat()
+    fl.numel, fl.device = off, torch.device(DEV)
+    fl.data = torch.randn(off, device=DEV) * 0.1
+    fl.grad_full = torch.zeros(off + 64, device=DEV)
+    fl.grad = fl.grad_full[:off]
+    fl.health = fl.grad_full[off:off + 1].view(torch.int32)
+    fl.exp_avg, fl.exp_avg_sq = torch.zeros(off, device=DEV), torch.zeros(off, device=DEV)
+    gv = lambda k: fl.grad[offs[k]:offs[k] + math.prod(sizes[k])].view(sizes[k])
+    Z, dl = torch.randn(K, 100, device=DEV), torch.zeros(K, 8, device=DEV)
+    dl[:, :6] = torch.randn(K, 6, device=DEV) * 1e-3
+    dZ, H3 = torch.randn(K, 100, device=DEV) * 1e-3, torch.randn(K, 100, device=DEV)
+    dH0 = torch.randn(K, 100, device=DEV) * 1e-4
+    X = torch.randn(3000, D, device=DEV)
+    rows = torch.randperm(3000, device=DEV)[:K].to(torch.int32)
+    pl = GemmPlanner(DEV, 1 << 20, grad=fl.grad)
+    pl.split_terms = terms
+    pl.defer16(Z, 100, dl, 8, gv("w3"), 100, 100, 6, K, ct=True, bias_b=gv("b3"))
+    pl.defer16(dZ, 100, H3, 100, gv("w0"), 100, 100, 100, K, bias_a=gv("b0"))
+    pl.defer16(dH0, 100, X, D, gv("w1"), D, 100, D, K, bias_a=gv("b1"), gather=rows)
+    p0 = fl.data.clone()
+    if fuse_adam:
+        opt = FusedAdam(fl, lr=1e-3)
+        opt.skip_flag = fl.health
+        pl.fused_adam = opt
+    cache = {}
+    pl.flush_wgrads_bf16(cache)
+    torch.cuda.synchronize()
+    assert pl.adam_fused == fuse_adam
+    Xg = X[rows.long()].double()
+    want = dict(w3=dl[:, :6].double().t() @ Z.double(), b3=dl[:, :6].double().sum(0), w0=dZ.double().t() @ H3.double(),
+                b0=dZ.double().sum(0), w1=dH0.double().t() @ Xg, b1=dH0.double().sum(0))
+    scale = dict(w3=dl[:, :6].double().abs().t() @ Z.double().abs(), b3=dl[:, :6].double().abs().sum(0),
+                 w0=dZ.double().abs().t() @ H3.double().abs(), b0=dZ.double().abs().sum(0),
+                 w1=dH0.double().abs().t() @ Xg.abs(), b1=dH0.double().abs().sum(0))
+    for k in sizes:
+        err = float(((gv(k).double() - want[k]).abs() / scale[k].max()).max())
+        print("wgrad_split terms=%d %s: %.2e" % (terms, k, err))
+        assert err < PROD_TOL[terms], (k, err)
+    if fuse_adam:
+        ref = p0.clone().requires_grad_(True)
+        ref.grad = fl.grad.clone()
+        torch.optim.Adam([ref], lr=1e-3).step()
+        assert float((ref.detach() - fl.data).abs().max()) < 1e-6
+        assert int(opt.state[0]) == 1
+
+
+CASES = [
+    dict(B=4, min_len=3, max_len=14, dims=dict(a=12, t=20, v=16), seed=3),
+    dict(B=3, min_len=1, max_len=1, dims=dict(a=4, t=4, v=4), seed=4),
+    dict(B=9, min_len=1, max_len=30, dims=dict(a=100, t=100, v=512), seed=5),
+    dict(B=2, min_len=16, max_len=16, dims=dict(a=12, t=20, v=16), seed=8),
+    dict(B=5, min_len=33, max_len=47, dims=dict(a=12, t=20, v=16), seed=9),
+    dict(B=8, min_len=20, max_len=60, dims=dict(a=100, t=768, v=512), seed=6),
+]
+
+
+@pytest.mark.parametrize("compute", ["f32x2", "f32x3"])
+@pytest.mark.parametrize("case", CASES, ids=["tiny", "one-utt", "ragged", "len16", "mid", "d1380"])
+def test_cogmen_split_parity(case, compute, monkeypatch):
+    """The whole step in a split mode against the UNROUNDED oracle (= the reference's fp32 arithmetic) at the tolerances of the
+    fp32 parity path: logits 1e-4, every live gradient 2e-3 of its tensor's scale, BatchNorm running statistics 1e-5."""
+    from tests.util_cases import poison_lds_before
+    poison_lds_before(monkeypatch, "cogmen_fwd_tile", "cogmen_bwd_tile")
+    res = run_cogmen_parity(cogmen_case(**case), compute=compute, zero_grad=("gcn.conv1.bias",) if case["max_len"] == 1 else ())
+    print("%s: logits %.2e (mean %.2e, scale %.2f), gradients %.2e entry-wise / %.2e norm-wise"
+          % (compute, res["logit_err"], res["logit_err_mean"], res["logit_scale"], res["grad_err"], res["grad_norm_err"]))
+    assert res["logit_err"] < LOGIT_TOL, res
+    assert res["feat_err"] < LOGIT_TOL, res
+    assert res["loss_err"] < 1e-5, res
+    assert res["acc_match"], res
+    assert res["grad_err"] < GRAD_TOL, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:6]
+    assert res["bn_mean_err"] < 1e-5 and res["bn_var_err"] < 1e-5, res
+
+
+@pytest.mark.parametrize("compute", ["f32x2", "f32x3"])
+def test_cogmen_split_config2_shape_parity(compute):
+    """BASELINE.json configs[1] shape (B=32, T=110, D=1380, 6 classes) through the split mode's step: north_star's 1e-4."""
+    res = run_cogmen_parity(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=1), compute=compute)
+    print("%s config 2: logits %.2e (mean %.2e, scale %.2f), gradients %.2e entry-wise / %.2e norm-wise"
+          % (compute, res["logit_err"], res["logit_err_mean"], res["logit_scale"], res["grad_err"], res["grad_norm_err"]))
+    assert res["logit_err"] < LOGIT_TOL, res
+    assert res["grad_err"] < GRAD_TOL, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:6]
