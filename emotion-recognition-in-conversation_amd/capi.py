@@ -99,6 +99,10 @@ _SIGS = {
                                       _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "erc_cogmen_bwd_tile": (C.c_int, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "erc_cogmen_fwd_tile_x": (C.c_int, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _f, _vp, _i, _vp, _vp, _i, _vp,
+                                        _vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "erc_cogmen_bwd_tile_x": (C.c_int, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _i64, _vp, _i64, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_head_fused_part_floats": (C.c_int, []),
     "erc_head_fused_rows_per_workgroup": (C.c_int, [_i]),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
@@ -547,7 +551,16 @@ def cogmen_fwd_tile_ws_doubles(n):
 
 def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, inv_cnt, H1b, ldh1b, QKVS, H2, ldh2, alpha,
                     bn_fused=False, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, saved=None, bn_ws=None,
-                    n_speakers=2, n_dev=None, health=None, events=None):
+                    n_speakers=2, n_dev=None, health=None, events=None, terms=1, catT_plane=0, q_plane=0):
+    """terms = 2 | 3: split compute mode -- WcatT / Wq are term planes, Mb / H1b the FP32 operand buffers (erc_cogmen_fwd_tile_x)"""
+    if terms > 1:
+        _check(lib().erc_cogmen_fwd_tile_x(terms, ptr(H0), ldh0, N, wp, wf, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
+                                           ptr(WcatT), catT_plane, ptr(b1), ptr(Wq), q_plane, ptr(bq), scale, ptr(Mb), ldmb,
+                                           ptr(inv_cnt), ptr(H1b), ldh1b, ptr(QKVS), ptr(H2), ldh2, ptr(alpha), int(bn_fused),
+                                           ptr(running_mean), ptr(running_var), momentum, eps, ptr(saved), ptr(bn_ws),
+                                           ptr(g["node_spk"]), n_speakers, ptr(n_dev), ptr(health), ptr(events), stream()),
+               "erc_cogmen_fwd_tile_x")
+        return
     _check(lib().erc_cogmen_fwd_tile(ptr(H0), ldh0, N, wp, wf, ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["in_typ"]),
                                      ptr(WcatT), ptr(b1), ptr(Wq), ptr(bq), scale, ptr(Mb), ldmb, ptr(inv_cnt), ptr(H1b),
                                      ldh1b, ptr(QKVS), ptr(H2), ldh2, ptr(alpha), int(bn_fused), ptr(running_mean),
@@ -558,7 +571,16 @@ def cogmen_fwd_tile(H0, ldh0, N, wp, wf, g, WcatT, b1, Wq, bq, scale, Mb, ldmb, 
 
 def cogmen_bwd_tile(dY, H2, ldh2, N, wp, wf, gamma, saved, bn_bwd, QKVS, alpha, g, inv_cnt, WqT, Wb, scale, dQKVS, dH1,
                     dH0, lddh0, n_speakers=2, head_part=None, head_parts=0, dgamma=None, dbeta=None, stats=None, grads_bf16=False,
-                    lddh1=100, n_dev=None):
+                    lddh1=100, n_dev=None, terms=1, qT_plane=0, wb_plane=0):
+    """terms = 2 | 3: split compute mode -- WqT / Wb are term planes, the gradients fp32 (erc_cogmen_bwd_tile_x)"""
+    if terms > 1:
+        _check(lib().erc_cogmen_bwd_tile_x(terms, ptr(dY), ptr(H2), ldh2, N, wp, wf, ptr(gamma), ptr(saved), ptr(bn_bwd), ptr(QKVS),
+                                           ptr(alpha), ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["out_ptr"]), ptr(g["out_dst"]),
+                                           ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(inv_cnt), ptr(WqT), qT_plane, ptr(Wb), wb_plane,
+                                           scale, ptr(dQKVS), ptr(dH1), ptr(dH0), lddh0, ptr(g["node_spk"]), n_speakers,
+                                           ptr(head_part), head_parts, head_fused_part_floats() if head_part is not None else 0,
+                                           ptr(dgamma), ptr(dbeta), ptr(stats), lddh1, ptr(n_dev), stream()), "erc_cogmen_bwd_tile_x")
+        return
     _check(lib().erc_cogmen_bwd_tile(ptr(dY), ptr(H2), ldh2, N, wp, wf, ptr(gamma), ptr(saved), ptr(bn_bwd), ptr(QKVS),
                                      ptr(alpha), ptr(g["in_ptr"]), ptr(g["in_src"]), ptr(g["out_ptr"]), ptr(g["out_dst"]),
                                      ptr(g["out_typ"]), ptr(g["out_eid"]), ptr(inv_cnt), ptr(WqT), ptr(Wb), scale,

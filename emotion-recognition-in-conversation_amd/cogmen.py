@@ -152,8 +152,9 @@ class COGMENModule(nn.Module):
 
     @property
     def fused_graph(self):
-        """bf16 mode: the graph part runs as the two row-tile kernels of csrc/cogmen_fused.hip (bf16 matrix cores)."""
-        return self.shadows is not None and self.use_fused_graph
+        """bf16 mode: the graph part runs as the two row-tile kernels of csrc/cogmen_fused.hip (bf16 matrix cores); split modes:
+        the same kernels on term planes -- two-speaker graphs only (other speaker counts keep the unfused fp32 graph kernels)."""
+        return self.shadows is not None and self.use_fused_graph and (self.terms == 1 or self.n_speakers == 2)
 
     def _build_shadows(self):
         """bf16 copies of the weights in the layouts the bf16 products read them (ercgraft.h, ErcShadowTab): the input
@@ -174,7 +175,7 @@ class COGMENModule(nn.Module):
         self.shadows = t
         self._sh = dict(w1=t.view(i_w1)[:F * D].view(F, D), catT=t.view(i_catT), wb=t.view(i_wb), q=t.view(i_q), qT=t.view(i_qT))
         self._sh_plane = dict(w1=t.plane(i_w1), catT=t.plane(i_catT), wb=t.plane(i_wb), q=t.plane(i_q), qT=t.plane(i_qT))
-        self.use_fused_graph = nt == 1 or os.environ.get("ERC_SPLIT_TILES", "0") != "0"
+        self.use_fused_graph = nt == 1 or os.environ.get("ERC_SPLIT_TILES", "1") != "0"
         if nt > 1:     # (the planes are exact expansions of the weights: valid whoever keeps them in sync -- refreshed per forward
             self.w1_shadow = self._sh["w1"]      #  until an optimizer takes over, attach_bf16_shadow)
 
@@ -183,7 +184,8 @@ class COGMENModule(nn.Module):
         device)?  Needs the fused bf16 path end to end."""
         x, C, D = batch["input_tensor"], self.n_classes, self.input_size
         return bool(self.fused_graph and self.enc_train is None and self.w1_shadow is not None and self.fuse_head and
-                    self.fuse_project_graph and self.wgrad_bf16 and x.dtype == torch.bfloat16 and x.dim() == 3 and C <= 8 and
+                    self.fuse_project_graph and self.wgrad_bf16 and x.dtype == (torch.float32 if self.terms > 1 else torch.bfloat16) and
+                    x.dim() == 3 and C <= 8 and
                     D % 4 == 0 and batch["speaker_tensor"].dim() == 2 and
                     capi.cogmen_project_graph_ok(D, F_HID, x.shape[0], D, D))
 
@@ -241,6 +243,24 @@ class COGMENModule(nn.Module):
         C, F, D = self.n_classes, F_HID, self.input_size
         g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E),
                  in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
+        if self.terms > 1:
+            # split modes: every buffer between the launches is fp32 (the weight-gradient launch expands its operands itself);
+            # zero-filled once: capacity mode reads rows beyond the true count (masked) and dlogits' pad columns
+            z32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+            ws = dict(
+                g=g, E=E, fused=True,
+                H0=f32(N, F), M=z32(N, 9 * F), inv_cnt=f32(N, N_REL), H1=z32(N, F), QKVS=f32(N, 4 * F),
+                alpha=f32(E), H2=f32(N, F), H3=z32(N, F), Z=z32(N, F), logits=f32(N, C),
+                bn_saved=f32(2 * F), bn_ws=f32(capi.bn_ws_floats(F)), stats=torch.zeros(1024, dtype=torch.float32, device=device),
+                bn_stats_ws=torch.zeros(capi.bn_batch_stats_ws_floats(F), dtype=torch.float32, device=device),
+                bn_tile_ws=torch.zeros(capi.cogmen_fwd_tile_ws_doubles(N), dtype=torch.float64, device=device),
+                head_ws=torch.zeros(capi.head_fused_ws_floats(N), dtype=torch.float32, device=device), bn_bwd=f32(2 * F),
+                dlogits=z32(N, self.LDDL), dZ=z32(N, F), dH3=f32(N, F), dQKVS=z32(N, 4 * F), dH1=z32(N, F), dH0=z32(N, F),
+            )
+            slab = 16 * N * F + 8 * (F * D + 9 * F * F + 4 * F * F + 2 * F * F) + (1 << 20)
+            ws["planner"] = GemmPlanner(device, slab, grad=self.flat.grad)
+            ws["jobs"] = None
+            return ws
         ws = dict(
             g=g, E=E, fused=True,
             H0=f32(N, F), Mb=bf(N, PM), inv_cnt=f32(N, N_REL), H1b=bf(N, PA), QKVS=f32(N, 4 * F),
@@ -315,12 +335,18 @@ class COGMENModule(nn.Module):
             bn = self.gcn.bn
             # training with the fused head: BatchNorm's batch statistics come out of the same launch
             ws["bn_in_tile"] = bool(upto_h2 and N <= self.BN_FUSED_MAX_N)   # tile sums here, finalised by the head kernel
-            capi.cogmen_fwd_tile(ws["H0"], F, N, WP, WF, g, self._sh["catT"], fp.w("gcn.conv1.bias"), self._sh["q"],
-                                 fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], PM, ws["inv_cnt"],
-                                 ws["H1b"], PA, ws["QKVS"], ws["H2"], F, ws["alpha"], bn_fused=2 if ws["bn_in_tile"] else 0,
-                                 running_mean=bn.running_mean, running_var=bn.running_var, momentum=bn.momentum,
-                                 eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=self.n_speakers, n_dev=nd,
-                                 health=fp.health if training else None, events=fp.events if training else None)
+            tile_kw = dict(bn_fused=2 if ws["bn_in_tile"] else 0, running_mean=bn.running_mean, running_var=bn.running_var,
+                           momentum=bn.momentum, eps=bn.eps, saved=ws["bn_saved"], bn_ws=ws["bn_tile_ws"], n_speakers=self.n_speakers,
+                           n_dev=nd, health=fp.health if training else None, events=fp.events if training else None)
+            if split:      # fp32 operands out, weights as term planes (erc_cogmen_fwd_tile_x)
+                capi.cogmen_fwd_tile(ws["H0"], F, N, WP, WF, g, self._sh["catT"], fp.w("gcn.conv1.bias"), self._sh["q"],
+                                     fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["M"], 9 * F, ws["inv_cnt"],
+                                     ws["H1"], F, ws["QKVS"], ws["H2"], F, ws["alpha"], terms=self.terms,
+                                     catT_plane=self._sh_plane["catT"], q_plane=self._sh_plane["q"], **tile_kw)
+            else:
+                capi.cogmen_fwd_tile(ws["H0"], F, N, WP, WF, g, self._sh["catT"], fp.w("gcn.conv1.bias"), self._sh["q"],
+                                     fp.w("gcn.conv2.lin_query.bias"), 1.0 / math.sqrt(F), ws["Mb"], PM, ws["inv_cnt"],
+                                     ws["H1b"], PA, ws["QKVS"], ws["H2"], F, ws["alpha"], **tile_kw)
             if upto_h2:
                 return ws
             return self._forward_tail(ws, N, training)
@@ -515,6 +541,11 @@ class COGMENModule(nn.Module):
                        stats=ws["stats"]) if ws.get("head_deferred") else {}
         bwd_args = (ws["dH3"], ws["H2"], F, N, WP, WF, fp.w("gcn.bn.weight"), ws["bn_saved"], ws["bn_bwd"], ws["QKVS"],
                     ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F))
+        if ws.get("wsp"):      # split modes: fp32 gradient tiles, weights as term planes; then the weight gradients + optimizer
+            capi.cogmen_bwd_tile(*bwd_args, ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers, lddh1=F, n_dev=nd,
+                                 terms=self.terms, qT_plane=self._sh_plane["qT"], wb_plane=self._sh_plane["wb"], **head_kw)
+            self._split_wgrads(ws, x, N)
+            return
         if w16:
             # the three gradients the backward hands to the weight-gradient launch are written as bf16 (nothing else reads them)
             capi.cogmen_bwd_tile(*bwd_args, ws["dQKVSb"], ws["dH1b"], ws["dH0b"], PA, n_speakers=self.n_speakers,
@@ -718,7 +749,8 @@ class COGMENTrainer:
         capacities the launches are sized for.  None when the step cannot run that way."""
         probe = dict(input_tensor=store.fused[None, :1], speaker_tensor=store.speaker[None, :1])
         D = int(store.fused.shape[1])
-        if self.encoder is not None or store.fused.dtype != torch.bfloat16 or not self.model.supports_capacity(
+        if self.encoder is not None or store.fused.dtype != (torch.float32 if self.model.terms > 1 else torch.bfloat16) or \
+                not self.model.supports_capacity(
                 dict(probe, input_tensor=store.fused.view(1, -1, D))) or N_cap > self.model.BN_FUSED_MAX_N or \
                 not capi.cogmen_project_graph_ok(D, F_HID, B_cap, D, D):
             return None

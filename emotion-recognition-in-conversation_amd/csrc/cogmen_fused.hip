@@ -24,6 +24,7 @@
 // Everything else (means, softmax, BatchNorm) is fp32.  The graph is read through the CSR that erc_window_graph_build
 // wrote; the kernels only rely on |source - target| <= 5 (checked by the host wrapper through wp / wf).
 #include "erc_common.h"
+#include "split_dev.h"
 
 namespace {
 
@@ -66,6 +67,32 @@ constexpr int FW_SPK_OFF = FW_PFX_OFF + FW_PFX_BYTES;          // speakers of th
 constexpr int FW_LDS = FW_SPK_OFF + 64 * 4;
 static_assert(FW_PFX_OFF % 16 == 0 && FW_LDS <= 160 * 1024, "forward LDS map");
 static_assert(7 * 64 * 8 * 4 <= FW_SH0_BYTES, "K-split partials must fit the H0 area");
+
+// ---- SPLIT COMPUTE MODES (NT = 2, 3 bf16 terms per fp32 operand value; csrc/split_dev.h): LDS map of the forward kernel.
+// Two-speaker graphs only (the reference's GNN(n_speakers = 2), cogmen.py:62-64): a target with speaker a has in-edges of
+// relations 2 a + {0, 1, 4, 5} only, so its row of M holds FIVE non-empty blocks (four relation means + self).  The M tile is
+// stored COMPACT, [26 rows][5 x 100] per term plane, and the H1 product still runs over the K = 928 of the weight shadow: a
+// lookup table maps every 4-element group of K to its compact column and the speaker it belongs to, rows of the other
+// speaker (and the K padding) read a zero slot.  NT planes of the full [27][936] tile would not fit next to the fp64 prefix sums.
+constexpr int FX_CM = 520;                                     // pitch of the compact M tile (bf16 elements; 1040 B rows)
+constexpr int FX_MPLANE = CG_MID * FX_CM * 2;                  // 27040 bytes per term plane
+constexpr int FX_ZERO = 2 * 512;                               // plane-relative byte offset of 8 zero bytes (row 0, columns [512, 516): never written by the aggregation)
+constexpr int FX_PF = 2;                                       // weight fragments of the H1 product requested ahead (K blocks)
+template <int NT>
+struct FxMap {
+    static constexpr int SM_OFF = 0;                           // M planes; the fp64 segment totals of the prefix scan before them; later the QKVS tile
+    static constexpr int SM_BYTES = NT * FX_MPLANE > CG_MID * CG_SQ * 4 ? NT * FX_MPLANE : CG_MID * CG_SQ * 4;
+    static constexpr int SH0_OFF = SM_OFF + SM_BYTES;          // H0 rows, then the K-split partials, then the H2 tile (as FW_SH0)
+    static constexpr int SE_OFF = SH0_OFF + FW_SH0_BYTES;
+    static constexpr int PFX_OFF = ((SE_OFF + FW_SE_BYTES + 15) / 16) * 16;   // prefix sums; after the aggregation: H1 planes | BatchNorm scratch
+    static constexpr int SH1_OFF = PFX_OFF;
+    static constexpr int RED_OFF = PFX_OFF + 3 * FW_SH1_BYTES;
+    static constexpr int SPK_OFF = PFX_OFF + FW_PFX_BYTES;
+    static constexpr int LUT_OFF = SPK_OFF + 256;              // 256 x uint32: compact byte offset | needed speaker << 16
+    static constexpr int LDS = LUT_OFF + 1024;
+    static_assert(RED_OFF + FW_RED_BYTES + 16 <= PFX_OFF + FW_PFX_BYTES && PFX_OFF % 16 == 0 && LDS <= 160 * 1024, "split forward LDS map");
+    static_assert(2048 + 4 * 2 * CG_F * 8 <= FX_MPLANE && FX_ZERO + 8 <= 2048, "segment totals of the prefix scan live in the M area, clear of the zero slots");
+};
 
 __device__ __forceinline__ unsigned short f2bf(float f) {
     const __bf16 h = (__bf16)f;
@@ -145,9 +172,17 @@ struct CgFwdP {
     int32_t* events;               //   this launch is the first of the step that may precede a reader of the word
     uint64_t* stamps;
     int stamp_block;
+    // split compute modes: WcatT / Wq are NT term planes, *_plane elements apart; the weight-gradient operands are written as fp32
+    int64_t catT_plane, q_plane;
+    float* Mf;                     // out fp32 [N, ldmf >= 900]
+    float* H1f;                    // out fp32 [N, ldh1f >= 100]
+    int ldmf, ldh1f;
 };
 
+template <int NT>
 __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p) {
+    constexpr bool X = NT > 1;
+    using XM = FxMap<X ? NT : 2>;
     // erc_health_roll folded into this launch: a word the PREVIOUS step left raised (its update was skipped) becomes one counted
     // event and is cleared, before any launch of this step reads it (the weight-gradient / optimizer launches further down)
     if (p.health && blockIdx.x == 0 && threadIdx.x == 0 && *p.health != 0) {
@@ -155,19 +190,20 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
         *p.health = 0;
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned short* const sM = reinterpret_cast<unsigned short*>(lds + FW_SM_OFF);
-    float* const sQ = reinterpret_cast<float*>(lds + FW_SM_OFF);       // aliases sM (after the H1 product)
-    unsigned short* const sH1 = reinterpret_cast<unsigned short*>(lds + FW_SH1_OFF);
-    float* const sH0 = reinterpret_cast<float*>(lds + FW_SH0_OFF);
+    unsigned short* const sM = reinterpret_cast<unsigned short*>(lds + (X ? XM::SM_OFF : FW_SM_OFF));
+    float* const sQ = reinterpret_cast<float*>(lds + (X ? XM::SM_OFF : FW_SM_OFF));       // aliases sM (after the H1 product)
+    unsigned short* const sH1 = reinterpret_cast<unsigned short*>(lds + (X ? XM::SH1_OFF : FW_SH1_OFF));
+    float* const sH0 = reinterpret_cast<float*>(lds + (X ? XM::SH0_OFF : FW_SH0_OFF));
     float* const sPart = sH0;                                           // aliases sH0 (after the aggregation)
     float* const sH2 = sH0;                                             // aliases sH0 (after the H1 product)
-    int* const sSrc = reinterpret_cast<int*>(lds + FW_SE_OFF);
+    int* const sSrc = reinterpret_cast<int*>(lds + (X ? XM::SE_OFF : FW_SE_OFF));
     int* const sTyp = sSrc + FW_ECAP;
     int* const sIp = sTyp + FW_ECAP;
-    double* const sRed = reinterpret_cast<double*>(lds + FW_RED_OFF);
-    int* const s_last = reinterpret_cast<int*>(lds + FW_RED_OFF + FW_RED_BYTES);
-    double* const sPfx = reinterpret_cast<double*>(lds + FW_PFX_OFF);
-    int* const sSpk = reinterpret_cast<int*>(lds + FW_SPK_OFF);
+    double* const sRed = reinterpret_cast<double*>(lds + (X ? XM::RED_OFF : FW_RED_OFF));
+    int* const s_last = reinterpret_cast<int*>(lds + (X ? XM::RED_OFF : FW_RED_OFF) + FW_RED_BYTES);
+    double* const sPfx = reinterpret_cast<double*>(lds + (X ? XM::PFX_OFF : FW_PFX_OFF));
+    int* const sSpk = reinterpret_cast<int*>(lds + (X ? XM::SPK_OFF : FW_SPK_OFF));
+    uint32_t* const sLut = reinterpret_cast<uint32_t*>(lds + XM::LUT_OFF);               // (split modes)
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar branches below
     const int N = p.n_dev ? min(max(*p.n_dev, 1), p.N) : p.N;   // (uniform scalar load; rows >= N of a capacity-sized grid are masked)
@@ -207,15 +243,36 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
             const int sp = p.node_spk[min(max(node, 0), N - 1)];
             sSpk[tid - 960] = (node >= 0 && node < N) ? sp : -1;
         }
-        // columns [900, 936) of rows 0..25: 18 dwords each; row 26 entirely: 468 dwords
-        uint32_t* const sMw = reinterpret_cast<uint32_t*>(sM);
-        if (tid < 26 * 18) sMw[(tid / 18) * (CG_SM / 2) + CG_KM / 2 + (tid % 18)] = 0u;
-        if (tid >= 512 && tid < 512 + CG_SM / 2) sMw[26 * (CG_SM / 2) + tid - 512] = 0u;
+        if constexpr (!X) {
+            // columns [900, 936) of rows 0..25: 18 dwords each; row 26 entirely: 468 dwords
+            uint32_t* const sMw = reinterpret_cast<uint32_t*>(sM);
+            if (tid < 26 * 18) sMw[(tid / 18) * (CG_SM / 2) + CG_KM / 2 + (tid % 18)] = 0u;
+            if (tid >= 512 && tid < 512 + CG_SM / 2) sMw[26 * (CG_SM / 2) + tid - 512] = 0u;
+        } else {
+            // the K -> compact column table (one entry per 4 k: compact BYTE offset | needed target speaker + 1 << 16; 0: any
+            // speaker (self block), 3: none (K padding)) and the zero slot of every plane
+            if (tid >= 512 && tid < 768) {
+                const int k4 = 4 * (tid - 512), q = k4 / CG_F, within = k4 - q * CG_F;
+                uint32_t e = 3u << 16;
+                if (q < CG_R) e = (uint32_t)(2 * ((((q >> 2) << 1) | (q & 1)) * CG_F + within)) | ((1u + ((q >> 1) & 1)) << 16);
+                else if (q == CG_R) e = (uint32_t)(2 * (4 * CG_F + within));
+                sLut[tid - 512] = e;
+            }
+            if (tid >= 768 && tid < 768 + 2 * NT) reinterpret_cast<uint32_t*>(lds + XM::SM_OFF + ((tid - 768) >> 1) * FX_MPLANE + FX_ZERO)[tid & 1] = 0u;
+        }
     }
     __builtin_amdgcn_sched_barrier(0);   // the tile / graph loads above are queued first
-    bf16x8 bx[KH0];
+    bf16x8 bx[X ? 1 : KH0];
+    sp_u32x4 bxr[X ? FX_PF : 1][X ? NT : 1];      // split modes: a ring of FX_PF K blocks x NT term planes
+    if constexpr (!X) {
 #pragma unroll
-    for (int u = 0; u < KH0; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow + 512 * min(u, nkb - 1));
+        for (int u = 0; u < KH0; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow + 512 * min(u, nkb - 1));
+    } else {
+#pragma unroll
+        for (int u = 0; u < FX_PF; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bxr[u][t] = *reinterpret_cast<const sp_u32x4*>(brow + t * p.catT_plane + 512 * min(u, nkb - 1));
+    }
     __syncthreads();
     CG_STAMP(1);
 
@@ -225,7 +282,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     //      (two adds executed per edge instead of an 8-way select chain), the edge loop stays rolled (two edges per
     //      trip; the code of this kernel runs once per launch from a cold instruction cache), and the mean is
     //      sum * rcp(count) with one Newton step (3 instructions; IEEE division is ~25).
-    if (p.two_spk) {
+    if (X || p.two_spk) {     // (the split modes exist for two-speaker graphs only: the host checks)
         // Two speakers (the reference's GNN(n_speakers = 2), cogmen.py:62-64): the relation of an edge is
         // 4 spk(source) + 2 spk(target) + (source < target ? 0 : 1) and the sources of a target are a contiguous run of rows,
         // so the four non-empty relation sums of a target are DIFFERENCES of per-speaker prefix sums over the tile's rows: a
@@ -234,7 +291,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
         // is -- a halo row gets bit-identical means in every tile that recomputes it, which the backward relies on (it reads
         // the OWNER tile's QKVS).  Scan: 4 segments of 9 rows in parallel (800 threads), then the segment offsets.
         {
-            double* const sTot = sRed;                        // [4][200] segment totals (the BatchNorm scratch is free here)
+            double* const sTot = X ? reinterpret_cast<double*>(lds + XM::SM_OFF + 2048) : sRed;   // (behind plane 0's zero slot)   // [4][200] segment totals (the BatchNorm scratch / the M area is free here)
             const int sg = tid / (2 * CG_F), bc = tid % (2 * CG_F), b = bc / CG_F, c = bc % CG_F;
             double* const pf = sPfx + (b * (CG_OUT + 1) + 9 * sg) * CG_F + c;
             double acc = 0.0;
@@ -291,19 +348,44 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
             float2 self = *reinterpret_cast<const float2*>(sH0 + le * CG_F + c2);
             if (!valid) self = make_float2(0.f, 0.f);
             uint32_t pk4[4];
+            float2 mq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float fc = (float)max(cnt[q], 1), rc = __builtin_amdgcn_rcpf(fc);
                 float m0 = sum[q].x * rc, m1 = sum[q].y * rc;
                 m0 = fmaf(fmaf(-m0, fc, sum[q].x), rc, m0), m1 = fmaf(fmaf(-m1, fc, sum[q].y), rc, m1);
                 pk4[q] = cnt[q] > 0 ? ((uint32_t)f2bf(m0) | ((uint32_t)f2bf(m1) << 16)) : 0u;
+                mq[q] = cnt[q] > 0 ? make_float2(m0, m1) : make_float2(0.f, 0.f);
             }
             const uint32_t pks = (uint32_t)f2bf(self.x) | ((uint32_t)f2bf(self.y) << 16);
             const bool own = valid && e >= CG_HL && e < CG_HL + CG_TR;
+            if constexpr (X) {
+                // compact row [4 relation means | self] x 100 as NT term planes; the tile's own rows also as the fp32 [9 x 100] row
+                // of the weight-gradient operand (relation r = 4 b + 2 a + dir: group (b, dir) lands in block 2 a + {0, 1, 4, 5})
+                if (act) {
+                    uint32_t* const crow = reinterpret_cast<uint32_t*>(lds + XM::SM_OFF) + e * (FX_CM / 2) + lane;
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) {
+                        unsigned tt[NT];
+                        sp_split2<NT>(q < 4 ? mq[q & 3].x : self.x, q < 4 ? mq[q & 3].y : self.y, tt);
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) crow[t * (FX_MPLANE / 4) + q * (CG_F / 2)] = tt[t];
+                    }
+                    if (own) {
+                        float* const grow = p.Mf + (int64_t)node * p.ldmf + c2;
+#pragma unroll
+                        for (int q = 0; q < CG_R; ++q) {
+                            const int grp = (q >> 2) * 2 + (q & 1);
+                            *reinterpret_cast<float2*>(grow + q * CG_F) = ((q >> 1) & 1) == a ? mq[grp] : make_float2(0.f, 0.f);
+                        }
+                        *reinterpret_cast<float2*>(grow + CG_R * CG_F) = self;
+                    }
+                }
+            }
             uint32_t* const mrow = reinterpret_cast<uint32_t*>(sM + e * CG_SM);
             uint32_t* const grow = reinterpret_cast<uint32_t*>(p.Mb + (int64_t)(own ? node : 0) * p.ldmb);
             // relation r = 4 b + 2 a + dir: groups (b, dir) = 0..3 land in blocks 2 a + {0, 1, 4, 5}; the other four are empty
-            if (act) {
+            if (!X && act) {
 #pragma unroll
                 for (int q = 0; q < CG_R; ++q) {
                     const int grp = (q >> 2) * 2 + (q & 1);            // which group block q would hold
@@ -387,15 +469,50 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     //      wavefronts of a column tile, partial tiles of the second half summed through LDS
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (mma_wave) {
-        const unsigned short* const a0 = sM + r * CG_SM + 8 * g + 32 * KH0 * kh;
-        const unsigned short* const a1 = sM + min(16 + r, 26) * CG_SM + 8 * g + 32 * KH0 * kh;
+        if constexpr (!X) {
+            const unsigned short* const a0 = sM + r * CG_SM + 8 * g + 32 * KH0 * kh;
+            const unsigned short* const a1 = sM + min(16 + r, 26) * CG_SM + 8 * g + 32 * KH0 * kh;
 #pragma unroll
-        for (int u = 0; u < KH0; ++u) {
-            if (u < nkb) {    // wave-uniform
-                const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(a0 + 32 * u);
-                const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(a1 + 32 * u);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, bx[u], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, bx[u], acc1, 0, 0, 0);
+            for (int u = 0; u < KH0; ++u) {
+                if (u < nkb) {    // wave-uniform
+                    const bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(a0 + 32 * u);
+                    const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(a1 + 32 * u);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, bx[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, bx[u], acc1, 0, 0, 0);
+                }
+            }
+        } else {
+            // lane (r, g) feeds rows r and 16 + r of the tile: speaker of each (rows >= 26 do not exist: every group reads zero)
+            const int spk0 = max(sSpk[CG_HL + r], 0), spk1 = 16 + r < CG_MID ? max(sSpk[CG_HL + min(16 + r, CG_MID - 1)], 0) : 7;
+            const int rb0 = r * (FX_CM * 2), rb1 = min(16 + r, CG_MID - 1) * (FX_CM * 2);
+            const unsigned char* const mbase = lds + XM::SM_OFF;
+            const uint2* const lut = reinterpret_cast<const uint2*>(sLut) + 4 * KH0 * kh + g;    // entry pair of (K block u, lane group g)
+#pragma unroll
+            for (int u = 0; u < KH0; ++u) {
+                if (u < nkb) {    // wave-uniform
+                    const uint2 le = lut[4 * u];
+                    int ad0[2], ad1[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const uint32_t en = hh ? le.y : le.x;
+                        const int cc = (int)(en & 0xffffu), need = (int)(en >> 16);
+                        ad0[hh] = (need == 0 || need == 1 + spk0) ? rb0 + cc : FX_ZERO;
+                        ad1[hh] = (need == 0 || need == 1 + spk1) ? rb1 + cc : FX_ZERO;
+                    }
+                    sp_u32x4 fa0[NT], fa1[NT], fb[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const unsigned char* const pl = mbase + t * FX_MPLANE;
+                        const uint2 x0 = *reinterpret_cast<const uint2*>(pl + ad0[0]), x1 = *reinterpret_cast<const uint2*>(pl + ad0[1]);
+                        const uint2 y0 = *reinterpret_cast<const uint2*>(pl + ad1[0]), y1 = *reinterpret_cast<const uint2*>(pl + ad1[1]);
+                        fa0[t] = (sp_u32x4){x0.x, x0.y, x1.x, x1.y}, fa1[t] = (sp_u32x4){y0.x, y0.y, y1.x, y1.y};
+                        fb[t] = bxr[u % FX_PF][t];
+                        if (u + FX_PF < KH0)      // (compile time) refill the ring slot: K block u + FX_PF, clamped (a block past the end is never multiplied)
+                            bxr[u % FX_PF][t] = *reinterpret_cast<const sp_u32x4*>(brow + t * p.catT_plane + 512 * min(u + FX_PF, nkb - 1));
+                    }
+                    acc0 = sp_mfma<NT>(fa0, fb, acc0);
+                    acc1 = sp_mfma<NT>(fa1, fb, acc1);
+                }
             }
         }
         if (kh) {
@@ -404,14 +521,23 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
         }
     }
     // B fragments of the QKVS product (wavefront w: column tiles w and w + 16 of 25; K = 128): in flight across the barrier
-    bf16x8 fq[2][4];
+    // (split modes: the first column tile's NT planes; the second tile's are requested while the first is multiplied)
+    bf16x8 fq[X ? 1 : 2][4];
+    sp_u32x4 fqx[X ? 4 : 1][X ? NT : 1];
     float qbias[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int qt = min(w + 16 * j, 24);
         const unsigned short* const bq = p.Wq + ((int64_t)qt * 4 * 64 + lane) * 8;
+        if constexpr (!X) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) fq[j][kb] = *reinterpret_cast<const bf16x8*>(bq + 512 * kb);
+            for (int kb = 0; kb < 4; ++kb) fq[j][kb] = *reinterpret_cast<const bf16x8*>(bq + 512 * kb);
+        } else if (j == 0) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) fqx[kb][t] = *reinterpret_cast<const sp_u32x4*>(bq + t * p.q_plane + 512 * kb);
+        }
         qbias[j] = p.bq[16 * qt + r];
     }
     __syncthreads();
@@ -426,33 +552,73 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
             for (int i = 0; i < 4; ++i) {
                 const int e = 16 * h + 4 * g + i;
                 const float v = (h ? acc1[i] + p1[i] : acc0[i] + p0[i]) + bias;
-                const unsigned short hb = col < CG_F ? f2bf(v) : (unsigned short)0;
-                sH1[e * CG_SH1 + col] = hb;
                 const int node = mb + e;
-                if (col < CG_F && e >= CG_HL && e < CG_HL + CG_TR && node < N) p.H1b[(int64_t)node * p.ldh1b + col] = hb;
+                if constexpr (!X) {
+                    const unsigned short hb = col < CG_F ? f2bf(v) : (unsigned short)0;
+                    sH1[e * CG_SH1 + col] = hb;
+                    if (col < CG_F && e >= CG_HL && e < CG_HL + CG_TR && node < N) p.H1b[(int64_t)node * p.ldh1b + col] = hb;
+                } else {
+                    float rem = col < CG_F ? v : 0.f;      // the NT terms of the value, one per plane
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const __bf16 hb = (__bf16)rem;
+                        rem -= (float)hb;
+                        sH1[t * (FW_SH1_BYTES / 2) + e * CG_SH1 + col] = __builtin_bit_cast(unsigned short, hb);
+                    }
+                    if (col < CG_F && e >= CG_HL && e < CG_HL + CG_TR && node < N) p.H1f[(int64_t)node * p.ldh1f + col] = v;
+                }
             }
     } else if (w == 7) {
         // columns [112, 128) of the H1 tile are K padding of the next product
-        for (int i = lane; i < 32 * 16; i += 64) sH1[(i >> 4) * CG_SH1 + 112 + (i & 15)] = 0;
+        for (int i = lane; i < 32 * 16 * NT; i += 64) sH1[(i >> 9) * (FW_SH1_BYTES / 2) + ((i >> 4) & 31) * CG_SH1 + 112 + (i & 15)] = 0;
     }
     __syncthreads();
     CG_STAMP(3);
 
     // ---- stage C: QKVS = H1 Wq^T + bq, 25 column tiles over the 16 wavefronts, both row tiles; K = 128 (4 blocks)
     {
-        bf16x8 fa[2][4];
+        bf16x8 fa[X ? 1 : 2][4];
+        if constexpr (!X) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) fa[h][kb] = *reinterpret_cast<const bf16x8*>(sH1 + (16 * h + r) * CG_SH1 + 32 * kb + 8 * g);
+                for (int kb = 0; kb < 4; ++kb) fa[h][kb] = *reinterpret_cast<const bf16x8*>(sH1 + (16 * h + r) * CG_SH1 + 32 * kb + 8 * g);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int qt = w + 16 * j;
             f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            if constexpr (X) {
+                // K block by K block: the A fragments of both row tiles from the NT planes of the H1 tile, the weight fragments of
+                // this column tile from registers -- and, behind each block's products, the next column tile's fragments requested
+                // into the registers just freed
+                const unsigned short* const bq1 = p.Wq + ((int64_t)min(w + 16, 24) * 4 * 64 + lane) * 8;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    sp_u32x4 fa0[NT], fa1[NT], fb[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const unsigned short* const pl = sH1 + t * (FW_SH1_BYTES / 2) + 32 * kb + 8 * g;
+                        fa0[t] = *reinterpret_cast<const sp_u32x4*>(pl + r * CG_SH1), fa1[t] = *reinterpret_cast<const sp_u32x4*>(pl + (16 + r) * CG_SH1);
+                        fb[t] = fqx[kb][t];
+                        if (j == 0 && NT == 2) fqx[kb][t] = *reinterpret_cast<const sp_u32x4*>(bq1 + t * p.q_plane + 512 * kb);
+                    }
+                    acc[0] = sp_mfma<NT>(fa0, fb, acc[0]);
+                    acc[1] = sp_mfma<NT>(fa1, fb, acc[1]);
+                }
+                if (j == 0 && NT > 2) {      // (three planes: refilling block by block spills -- one exposed L2 latency instead)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) fqx[kb][t] = *reinterpret_cast<const sp_u32x4*>(bq1 + t * p.q_plane + 512 * kb);
+                }
+            } else {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[h][kb], fq[j][kb], acc[h], 0, 0, 0);
+            }
             if (qt < 25) {   // wave-uniform
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
@@ -636,6 +802,33 @@ static_assert(CG_TR * CG_SDP * 2 <= BW_SDP_BYTES && BW_SDP_OFF % 16 == 0 && BW_L
 static_assert(2 * BW_ROWS * BW_BAND * 4 <= BW_SDP_BYTES, "the two band matrices live in the dP tile's area until the dP stage");
 static_assert(3 * 4 * 2 * 64 * 4 * 4 <= BW_SDQ_BYTES, "K-split partials of the band product live in the dQKVS tile's area");
 
+// ---- split compute modes: LDS map of the backward kernel.  The dQKVS tile is NT planes of [27][424] (26 mid rows + one zero row),
+// the dP tile NT COMPACT planes [16][5 x 104]: a source with speaker b only has out-edges of relations 4 b .. 4 b + 3 (two-speaker
+// graphs), so its row of dP holds four relation blocks + self; the dH0 product runs over the K = 960 of the weight shadow through a
+// lookup table (as the forward's H1 product).  Regions are ordered so that the dQKVS planes grow from the V tile (dead after the
+// band product dA) into the area behind it.
+constexpr int BX_DQ_ROWS = CG_MID + 1;                           // 27
+constexpr int BX_DQPLANE = BX_DQ_ROWS * CG_SDQ * 2;              // 22896 bytes per term plane
+constexpr int BX_CP = 528;                                       // pitch of the compact dP tile (bf16 elements)
+constexpr int BX_DPPLANE = CG_TR * BX_CP * 2;                    // 16896
+constexpr int BX_ZERO = 2 * 520;                                 // plane-relative byte offset of 8 zero bytes in a dP plane (row 0, columns [520, 524))
+constexpr int BX_PF = 2;                                         // weight fragments requested ahead (K blocks)
+constexpr int BX_SE_BYTES16 = ((BW_SE_BYTES + 15) / 16) * 16;
+template <int NT>
+struct BxMap {
+    static constexpr int SK_OFF = 0, SQ_OFF = BW_SK_BYTES, SG_OFF = 2 * BW_SK_BYTES;      // K | Q | G row tiles; stage 3: K-split partials; stages 4, 5: dP planes
+    static constexpr int SE_OFF = 3 * BW_SK_BYTES;
+    static constexpr int BAND_OFF = SE_OFF + BX_SE_BYTES16;                                // band matrices; stage 3 on: the dH1 tile | K-split partials of stage 5
+    static constexpr int BAND_BYTES = 2 * BW_ROWS * BW_BAND * 4;
+    static constexpr int SV_OFF = BAND_OFF + BAND_BYTES;                                   // V row tile; from (c) on: the dQKVS planes
+    static constexpr int E_OFF = SV_OFF + BW_SK_BYTES;                                     // head records / K-split partials of the band product; dQKVS planes
+    static constexpr int E_BYTES = NT * BX_DQPLANE - BW_SK_BYTES > 24576 ? NT * BX_DQPLANE - BW_SK_BYTES : 24576;
+    static constexpr int LUT_OFF = E_OFF + E_BYTES;
+    static constexpr int LDS = LUT_OFF + 1024;
+    static_assert(NT * BX_DPPLANE <= 3 * BW_SK_BYTES && BW_SDH1_BYTES + 7 * 64 * 4 * 4 <= BAND_BYTES && LDS <= 160 * 1024 && SV_OFF % 16 == 0 &&
+                      E_OFF % 16 == 0, "split backward LDS map");
+};
+
 struct CgBwdP {
     const float* dY;               // [N, F]: dL/d(BatchNorm output) (through the LeakyReLU), from the head kernel
     const float* H2;               // [N, ldh2]: BatchNorm input
@@ -670,15 +863,19 @@ struct CgBwdP {
     const int32_t* n_dev;          // capacity mode: true node count (see CgFwdP)
     uint64_t* stamps;
     int stamp_block;
+    int64_t qT_plane, wb_plane;    // split compute modes: WqT / Wb are NT term planes, this many elements apart
 };
 
+template <int NT>
 __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p) {
+    constexpr bool X = NT > 1;
+    using XM = BxMap<X ? NT : 2>;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    float* const sK = reinterpret_cast<float*>(lds + BW_SK_OFF);
-    float* const sV = reinterpret_cast<float*>(lds + BW_SV_OFF);
-    float* const sQq = reinterpret_cast<float*>(lds + BW_SQ_OFF);
-    float* const sG = reinterpret_cast<float*>(lds + BW_SG_OFF);
-    float* const sAl = reinterpret_cast<float*>(lds + BW_SE_OFF);          // alpha of in-edge E_lo + i
+    float* const sK = reinterpret_cast<float*>(lds + (X ? XM::SK_OFF : BW_SK_OFF));
+    float* const sV = reinterpret_cast<float*>(lds + (X ? XM::SV_OFF : BW_SV_OFF));
+    float* const sQq = reinterpret_cast<float*>(lds + (X ? XM::SQ_OFF : BW_SQ_OFF));
+    float* const sG = reinterpret_cast<float*>(lds + (X ? XM::SG_OFF : BW_SG_OFF));
+    float* const sAl = reinterpret_cast<float*>(lds + (X ? XM::SE_OFF : BW_SE_OFF));          // alpha of in-edge E_lo + i
     int* const sSrc = reinterpret_cast<int*>(sAl + 2 * BW_ECAP);           // its source node
     int* const sOd = sSrc + BW_ECAP;                                       // out-edge O_lo + i: target node
     int* const sOt = sOd + 2 * BW_OCAP;                                    //   relation
@@ -686,11 +883,12 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     int* const sIp = reinterpret_cast<int*>(sOw + BW_OCAP);                // in_ptr of outer rows (37)
     int* const sOp = sIp + 40;                                             // out_ptr of mid rows (27)
     int* const sSpkOwn = reinterpret_cast<int*>(sAl + BW_ECAP);            // speakers of the 16 own rows (the unused d(score) slot)
-    unsigned short* const sDQ = reinterpret_cast<unsigned short*>(lds + BW_SDQ_OFF);
-    float* const sDH1 = reinterpret_cast<float*>(lds + BW_SDH1_OFF);
-    unsigned short* const sDP = reinterpret_cast<unsigned short*>(lds + BW_SDP_OFF);
+    unsigned short* const sDQ = reinterpret_cast<unsigned short*>(lds + (X ? XM::SV_OFF : BW_SDQ_OFF));
+    float* const sDH1 = reinterpret_cast<float*>(lds + (X ? XM::BAND_OFF : BW_SDH1_OFF));
+    unsigned short* const sDP = reinterpret_cast<unsigned short*>(lds + (X ? XM::SK_OFF : BW_SDP_OFF));
     float* const sPart3 = sK;                                              // K-split partials of the dH1 product
-    float* const sPart5 = sG;                                              // K-split partials of the dH0 product
+    float* const sPart5 = X ? reinterpret_cast<float*>(lds + XM::BAND_OFF + BW_SDH1_BYTES) : sG;   // K-split partials of the dH0 product
+    uint32_t* const sLut = reinterpret_cast<uint32_t*>(lds + XM::LUT_OFF);                     // (split modes)
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar branches below
     const int N = p.n_dev ? min(max(*p.n_dev, 1), p.N) : p.N;   // (uniform scalar load; rows >= N of a capacity-sized grid are masked)
@@ -710,8 +908,19 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     if (tid < CG_OUT + 1) sIp[tid] = p.in_ptr[min(max(ob + tid, 0), N)];
     if (tid >= 64 && tid < 64 + CG_MID + 1) sOp[tid - 64] = p.out_ptr[min(max(mb + tid - 64, 0), N)];
     if (tid >= 128 && tid < 128 + CG_TR) sSpkOwn[tid - 128] = p.node_spk[min(r0 + tid - 128, N - 1)];
-    double* const sHp = reinterpret_cast<double*>(lds + BW_SDQ_OFF);                  // [4][256] partial sums of the head records
-    float* const sBnB = reinterpret_cast<float*>(lds + BW_SDQ_OFF + 4 * 256 * 8);     // [224] mean dY | mean dY * xhat
+    double* const sHp = reinterpret_cast<double*>(lds + (X ? XM::E_OFF : BW_SDQ_OFF));                  // [4][256] partial sums of the head records
+    float* const sBnB = reinterpret_cast<float*>(lds + (X ? XM::E_OFF : BW_SDQ_OFF) + 4 * 256 * 8);     // [224] mean dY | mean dY * xhat
+    if constexpr (X) {
+        // the K -> compact column table of the dH0 product (one entry per 4 k of the K = 960 = 9 blocks of 104 + padding): compact
+        // BYTE offset | needed source speaker + 1 << 16 (0: any -- the self block; 3: none)
+        if (tid >= 768 && tid < 1024) {
+            const int k4 = 4 * (tid - 768), q = k4 / 104, within = k4 - q * 104;
+            uint32_t e = 3u << 16;
+            if (q < CG_R) e = (uint32_t)(2 * ((q & 3) * 104 + within)) | ((1u + (uint32_t)(q >> 2)) << 16);
+            else if (q == CG_R) e = (uint32_t)(2 * (4 * 104 + within));
+            sLut[tid - 768] = e;
+        }
+    }
     if (p.head_part) {   // (uniform) the head's workgroup records: slot = tid % 256, a quarter of the record list each
         const int slot = tid & 255, part = tid >> 8;
         const int G = p.head_parts, Gq = (G + 3) >> 2;
@@ -821,9 +1030,9 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     //        dA = G V^T (band)  ->  ds = alpha (dA - sum_s alpha dA) scale  (elementwise on the band, DPP row sums)
     //        dq = DS K,  dk = DS^T Q,  dv = AL^T G                          (band x row tiles, K = 32 sources / targets)
     //      One wavefront per graph row with 12-edge gathers cost 9.5 us for these two stages (wave-instruction bound).
-    float* const sDS = reinterpret_cast<float*>(lds + BW_SDP_OFF);            // [48][68] d(score), 0 outside the band
+    float* const sDS = reinterpret_cast<float*>(lds + (X ? XM::BAND_OFF : BW_SDP_OFF));            // [48][68] d(score), 0 outside the band
     float* const sAL = sDS + BW_ROWS * BW_BAND;                               // [48][68] alpha in the same layout
-    float* const sPartA = reinterpret_cast<float*>(lds + BW_SDQ_OFF);         // K-split partials (the dQKVS tile is written later)
+    float* const sPartA = reinterpret_cast<float*>(lds + (X ? XM::E_OFF : BW_SDQ_OFF));         // K-split partials (the dQKVS tile is written later)
     {
         // (a) dA: row tile i = w >> 2 (outer rows 16 i ..), K quarter j = w & 3 (25 k-steps as 7 + 7 + 7 + 4), both
         //     column tiles (far rows 16 i .. 16 i + 31); wavefronts 12..15 zero the band matrices meanwhile
@@ -883,26 +1092,51 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
 
     // B fragments of the dH1 product (K = 416: blocks [7 kh, 7 kh + 7), the second half has 6): requested now
     const unsigned short* const brow3 = p.WqT + ((int64_t)(min(ct, CG_NT - 1) * 13 + 7 * kh) * 64 + lane) * 8;
-    bf16x8 fb3[7];
+    bf16x8 fb3[X ? 1 : 7];
+    sp_u32x4 fb3r[X ? BX_PF : 1][X ? NT : 1], bxr[X ? BX_PF : 1][X ? NT : 1];      // split modes: rings of BX_PF K blocks x NT planes
+    if constexpr (!X) {
 #pragma unroll
-    for (int u = 0; u < 7; ++u) fb3[u] = *reinterpret_cast<const bf16x8*>(brow3 + 512 * min(u, kh ? 5 : 6));
+        for (int u = 0; u < 7; ++u) fb3[u] = *reinterpret_cast<const bf16x8*>(brow3 + 512 * min(u, kh ? 5 : 6));
+    } else {
+#pragma unroll
+        for (int u = 0; u < BX_PF; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) fb3r[u][t] = *reinterpret_cast<const sp_u32x4*>(brow3 + t * p.qT_plane + 512 * u);
+    }
 
     const unsigned short* const brow5 = p.Wb + ((int64_t)(min(ct, CG_NT - 1) * 30 + 15 * kh) * 64 + lane) * 8;
-    bf16x8 bx[15];
+    bf16x8 bx[X ? 1 : 15];
     {
         // (c) the dQKVS tile [26 mid rows][400] (bf16, the A operand of the dH1 product; own rows also to global memory):
         //     K padding / dead rows, the skip part (= dH2), then 42 units of 8 MFMAs: dq for outer row tiles 0, 1 (7 column
         //     tiles each), dk and dv for mid row tiles 0, 1
         uint32_t* const sDQw = reinterpret_cast<uint32_t*>(sDQ);
-        if (tid < CG_MID * 12) sDQw[(tid / 12) * (CG_SDQ / 2) + 200 + (tid % 12)] = 0u;
-        for (int i = tid; i < 6 * (CG_SDQ / 2); i += CG_NTH) sDQw[CG_MID * (CG_SDQ / 2) + i] = 0u;
+        constexpr int DQPW = BX_DQPLANE / 4;                  // dwords per plane (split modes)
+        if constexpr (!X) {
+            if (tid < CG_MID * 12) sDQw[(tid / 12) * (CG_SDQ / 2) + 200 + (tid % 12)] = 0u;
+            for (int i = tid; i < 6 * (CG_SDQ / 2); i += CG_NTH) sDQw[CG_MID * (CG_SDQ / 2) + i] = 0u;
+        } else {
+            // K padding [400, 424) of the 26 rows and the whole zero row 26, in every plane
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (tid < CG_MID * 12) sDQw[t * DQPW + (tid / 12) * (CG_SDQ / 2) + 200 + (tid % 12)] = 0u;
+                if (tid >= 512 && tid < 512 + CG_SDQ / 2) sDQw[t * DQPW + CG_MID * (CG_SDQ / 2) + tid - 512] = 0u;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int i = tid + CG_NTH * j;                 // 26 rows x 50 channel pairs
             const int em = i / 50, cp = i % 50;
             if (i < CG_MID * 50) {
                 const float2 gv = *reinterpret_cast<const float2*>(sG + (em + CG_HL) * CG_F + 2 * cp);
-                sDQw[em * (CG_SDQ / 2) + 150 + cp] = (uint32_t)f2bf(gv.x) | ((uint32_t)f2bf(gv.y) << 16);
+                if constexpr (!X) {
+                    sDQw[em * (CG_SDQ / 2) + 150 + cp] = (uint32_t)f2bf(gv.x) | ((uint32_t)f2bf(gv.y) << 16);
+                } else {
+                    unsigned tt[NT];
+                    sp_split2<NT>(gv.x, gv.y, tt);
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) sDQw[t * DQPW + em * (CG_SDQ / 2) + 150 + cp] = tt[t];
+                }
                 const int node = mb + em;
                 if (em >= CG_HL && em < CG_HL + CG_TR && node < N) {
                     if (p.grads_bf16) *reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned short*>(p.dQKVS) + (int64_t)node * 400 + 3 * CG_F + 2 * cp) = (uint32_t)f2bf(gv.x) | ((uint32_t)f2bf(gv.y) << 16);
@@ -914,8 +1148,10 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
         //  units: a burst of 15 loads in front of the transposed-means stage stalled it by ~3 us)
 #pragma unroll
         for (int ui = 0; ui < 3; ++ui) {
+            if constexpr (!X) {
 #pragma unroll
-            for (int t5 = 0; t5 < 5; ++t5) bx[5 * ui + t5] = *reinterpret_cast<const bf16x8*>(brow5 + 512 * (5 * ui + t5));
+                for (int t5 = 0; t5 < 5; ++t5) bx[5 * ui + t5] = *reinterpret_cast<const bf16x8*>(brow5 + 512 * (5 * ui + t5));
+            }
             const int u = w + CG_NW * ui;
             if (u >= 42) continue;      // wave-uniform
             // unit -> (kind: 0 dq | 1 dk | 2 dv, row tile, column tile)
@@ -945,7 +1181,17 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                 const bool rowv = em >= 0 && em < CG_MID;
                 if (rowv && 16 * cti + r < CG_F) {
                     const bool nv = node >= 0 && node < N;
-                    sDQ[em * CG_SDQ + coff + 16 * cti + r] = f2bf(nv ? acc[q] : 0.f);
+                    if constexpr (!X) {
+                        sDQ[em * CG_SDQ + coff + 16 * cti + r] = f2bf(nv ? acc[q] : 0.f);
+                    } else {
+                        float rem = nv ? acc[q] : 0.f;      // the NT terms of the value, one per plane
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const __bf16 hb = (__bf16)rem;
+                            rem -= (float)hb;
+                            sDQ[t * (BX_DQPLANE / 2) + em * CG_SDQ + coff + 16 * cti + r] = __builtin_bit_cast(unsigned short, hb);
+                        }
+                    }
                     if (nv && em >= CG_HL && em < CG_HL + CG_TR) {
                         if (p.grads_bf16) reinterpret_cast<unsigned short*>(p.dQKVS)[(int64_t)node * 400 + coff + 16 * cti + r] = f2bf(acc[q]);
                         else p.dQKVS[(int64_t)node * 400 + coff + 16 * cti + r] = acc[q];
@@ -962,6 +1208,7 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (mma_wave) {
             const unsigned short* const a0 = sDQ + r * CG_SDQ + 8 * g + 32 * 7 * kh;
+            if constexpr (!X) {
 #pragma unroll
             for (int u = 0; u < 7; ++u) {
                 if (u < (kh ? 6 : 7)) {   // wave-uniform
@@ -969,6 +1216,30 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                     const bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(a0 + 16 * CG_SDQ + 32 * u);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0, fb3[u], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1, fb3[u], acc1, 0, 0, 0);
+                }
+            }
+            } else {
+                const int nkb3 = kh ? 6 : 7;
+                const unsigned short* const a1 = sDQ + min(16 + r, CG_MID) * CG_SDQ + 8 * g + 32 * 7 * kh;      // rows >= 26: the zero row
+                // the first blocks of the dH0 product's weights: in flight across the transposed-means stage
+#pragma unroll
+                for (int u = 0; u < BX_PF; ++u)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bxr[u][t] = *reinterpret_cast<const sp_u32x4*>(brow5 + t * p.wb_plane + 512 * u);
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    if (u < nkb3) {   // wave-uniform
+                        sp_u32x4 fa0[NT], fa1[NT], fb[NT];
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            fa0[t] = *reinterpret_cast<const sp_u32x4*>(a0 + t * (BX_DQPLANE / 2) + 32 * u);
+                            fa1[t] = *reinterpret_cast<const sp_u32x4*>(a1 + t * (BX_DQPLANE / 2) + 32 * u);
+                            fb[t] = fb3r[u % BX_PF][t];
+                            if (u + BX_PF < 7) fb3r[u % BX_PF][t] = *reinterpret_cast<const sp_u32x4*>(brow3 + t * p.qT_plane + 512 * min(u + BX_PF, nkb3 - 1));
+                        }
+                        acc0 = sp_mfma<NT>(fa0, fb, acc0);
+                        acc1 = sp_mfma<NT>(fa1, fb, acc1);
+                    }
                 }
             }
             if (kh) {
@@ -1020,11 +1291,13 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
         float s0[CG_R], s1[CG_R];
 #pragma unroll
         for (int q = 0; q < CG_R; ++q) s0[q] = s1[q] = 0.f;
-        if (p.two_spk) {
+        float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};      // (two-speaker path) the four non-empty relation blocks
+        int b4 = 0;
+        if (X || p.two_spk) {
             // two speakers: an out-edge of a source with speaker b has relation 4 b + (2 spk(target) + dir), so only the
             // four blocks 4 b .. 4 b + 3 of the row are non-empty: all 12 target rows are requested at once and a 4-way
             // scalar branch picks the accumulator (the rolled two-edges-per-trip loop below pays an LDS round trip per trip)
-            const int b4 = 4 * __builtin_amdgcn_readfirstlane(min(max(sSpkOwn[li], 0), 1));
+            b4 = 4 * __builtin_amdgcn_readfirstlane(min(max(sSpkOwn[li], 0), 1));
             float2 v[CG_CH];
             float wv[CG_CH];
             int gid[CG_CH];
@@ -1036,7 +1309,6 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                 wv[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), uu));
                 v[u] = *reinterpret_cast<const float2*>(sDH1 + f + c2);
             }
-            float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < CG_CH; ++u) {
                 const float a0 = v[u].x * wv[u], a1 = v[u].y * wv[u];
@@ -1071,15 +1343,31 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
         }
         float2 self = *reinterpret_cast<const float2*>(sDH1 + em * CG_F + c2);
         if (!valid) self = make_float2(0.f, 0.f);
-        uint32_t* const row = sDPw + li * (CG_SDP / 2);
-        if (act) {
+        if constexpr (!X) {
+            uint32_t* const row = sDPw + li * (CG_SDP / 2);
+            if (act) {
 #pragma unroll
-            for (int q = 0; q < CG_R; ++q) row[q * 52 + lane] = (uint32_t)f2bf(s0[q]) | ((uint32_t)f2bf(s1[q]) << 16);
-            row[CG_R * 52 + lane] = (uint32_t)f2bf(self.x) | ((uint32_t)f2bf(self.y) << 16);
+                for (int q = 0; q < CG_R; ++q) row[q * 52 + lane] = (uint32_t)f2bf(s0[q]) | ((uint32_t)f2bf(s1[q]) << 16);
+                row[CG_R * 52 + lane] = (uint32_t)f2bf(self.x) | ((uint32_t)f2bf(self.y) << 16);
+            }
+            // padding: columns [100, 104) of every block and [936, 968)
+            if (lane < CG_R + 1) row[lane * 52 + 50] = 0u, row[lane * 52 + 51] = 0u;
+            if (lane >= 32 && lane < 48) row[CG_KB / 2 + (lane - 32)] = 0u;
+        } else {
+            // compact row [relation blocks 4 b .. 4 b + 3 | self] x 104 (columns [100, 104) zero) as NT term planes; the zero slot
+            uint32_t* const row = sDPw + li * (BX_CP / 2);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                unsigned tt[NT];
+                sp_split2<NT>(q < 4 ? t0[q & 3] : self.x, q < 4 ? t1[q & 3] : self.y, tt);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (act) row[t * (BX_DPPLANE / 4) + q * 52 + lane] = tt[t];
+                    else if (lane < 52) row[t * (BX_DPPLANE / 4) + q * 52 + lane] = 0u;
+                }
+            }
+            if (li == 0 && lane < 2 * NT) sDPw[(lane >> 1) * (BX_DPPLANE / 4) + BX_ZERO / 4 + (lane & 1)] = 0u;
         }
-        // padding: columns [100, 104) of every block and [936, 968)
-        if (lane < CG_R + 1) row[lane * 52 + 50] = 0u, row[lane * 52 + 51] = 0u;
-        if (lane >= 32 && lane < 48) row[CG_KB / 2 + (lane - 32)] = 0u;
     }
     __syncthreads();
     CG_STAMP(5);
@@ -1088,11 +1376,39 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (mma_wave) {
-            const unsigned short* const arow = sDP + r * CG_SDP + 8 * g + 32 * 15 * kh;
+            if constexpr (!X) {
+                const unsigned short* const arow = sDP + r * CG_SDP + 8 * g + 32 * 15 * kh;
 #pragma unroll
-            for (int u = 0; u < 15; ++u) {
-                const bf16x8 fa = *reinterpret_cast<const bf16x8*>(arow + 32 * u);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bx[u], acc, 0, 0, 0);
+                for (int u = 0; u < 15; ++u) {
+                    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(arow + 32 * u);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bx[u], acc, 0, 0, 0);
+                }
+            } else {
+                const int spk_r = min(max(sSpkOwn[r], 0), 1);
+                const int rb = r * (BX_CP * 2);
+                const unsigned char* const pbase = reinterpret_cast<const unsigned char*>(sDP);
+                const uint2* const lut = reinterpret_cast<const uint2*>(sLut) + 4 * 15 * kh + g;      // entry pair of (K block u, lane group g)
+#pragma unroll
+                for (int u = 0; u < 15; ++u) {
+                    const uint2 le = lut[4 * u];
+                    int ad[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const uint32_t en = hh ? le.y : le.x;
+                        const int cc = (int)(en & 0xffffu), need = (int)(en >> 16);
+                        ad[hh] = (need == 0 || need == 1 + spk_r) ? rb + cc : BX_ZERO;
+                    }
+                    sp_u32x4 fa[NT], fb[NT];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const unsigned char* const pl = pbase + t * BX_DPPLANE;
+                        const uint2 x0 = *reinterpret_cast<const uint2*>(pl + ad[0]), x1 = *reinterpret_cast<const uint2*>(pl + ad[1]);
+                        fa[t] = (sp_u32x4){x0.x, x0.y, x1.x, x1.y};
+                        fb[t] = bxr[u % BX_PF][t];
+                        if (u + BX_PF < 15) bxr[u % BX_PF][t] = *reinterpret_cast<const sp_u32x4*>(brow5 + t * p.wb_plane + 512 * (u + BX_PF));
+                    }
+                    acc = sp_mfma<NT>(fa, fb, acc);
+                }
             }
             if (kh) *reinterpret_cast<f32x4*>(sPart5 + (ct * 64 + lane) * 4) = acc;
         }
@@ -1136,6 +1452,58 @@ extern "C" int erc_cogmen_set_stamps(uint64_t* stamps) {
 
 extern "C" int64_t erc_cogmen_fwd_tile_ws_doubles(int n_nodes) { return (int64_t)erc_cdiv(n_nodes, CG_TR) * 2 * CG_F + 2; }
 
+static int fwd_tile_launch(int terms, const float* H0, int ldh0, int n_nodes, int wp, int wf, const int32_t* in_ptr,
+                           const int32_t* in_src, const int32_t* in_typ, const void* WcatT, int64_t catT_plane, const float* b1,
+                           const void* Wq, int64_t q_plane, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt,
+                           void* H1b, int ldh1b, float* QKVS, float* H2, int ldh2, float* alpha, int bn_fused,
+                           float* running_mean, float* running_var, float momentum, float eps, float* saved,
+                           double* bn_ws, const int32_t* node_spk, int n_speakers, const int32_t* n_dev, int32_t* health,
+                           int32_t* events, void* stream) {
+    ERC_REQUIRE(H0 && in_ptr && in_src && in_typ && WcatT && b1 && Wq && bq && Mb && inv_cnt && H1b && QKVS && H2 && alpha && node_spk,
+                "cogmen_fwd_tile: null pointer");
+    ERC_REQUIRE(!health == !events, "cogmen_fwd_tile: health and events come together");
+    ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_fwd_tile: window (%d, %d) exceeds the halo %d",
+                wp, wf, CG_HL);
+    ERC_REQUIRE(ldh0 >= CG_F && ldh0 % 4 == 0 && ((uintptr_t)H0 & 15) == 0 && ldmb >= CG_KM && ldmb % 2 == 0 &&
+                    ((uintptr_t)Mb & (terms > 1 ? 7 : 3)) == 0 && ldh1b >= CG_F &&
+                    ldh2 >= CG_F && ldh2 % 2 == 0 && ((uintptr_t)H2 & 7) == 0 &&
+                    ((uintptr_t)QKVS & 15) == 0 && ((uintptr_t)WcatT & 15) == 0 && ((uintptr_t)Wq & 15) == 0,
+                "cogmen_fwd_tile: pitch / alignment");
+    ERC_REQUIRE(terms == 1 || ((terms == 2 || terms == 3) && n_speakers == 2 && catT_plane > 0 && catT_plane % 8 == 0 && q_plane > 0 &&
+                               q_plane % 8 == 0),
+                "cogmen_fwd_tile_x: terms = %d (2 | 3), two-speaker graphs only (n_speakers = %d), plane strides multiples of 8", terms, n_speakers);
+    ERC_REQUIRE(bn_fused >= 0 && bn_fused <= 2 && (bn_fused != 1 || (running_mean && running_var && saved)) && (!bn_fused || bn_ws),
+                "cogmen_fwd_tile: BatchNorm operands");
+    const void* kern = terms == 1 ? reinterpret_cast<const void*>(cogmen_fwd_tile_kernel<1>)
+                     : terms == 2 ? reinterpret_cast<const void*>(cogmen_fwd_tile_kernel<2>)
+                                  : reinterpret_cast<const void*>(cogmen_fwd_tile_kernel<3>);
+    const int lds_bytes = terms == 1 ? FW_LDS : terms == 2 ? FxMap<2>::LDS : FxMap<3>::LDS;
+    ERC_REQUIRE(ensure_lds(kern, lds_bytes), "cogmen_fwd_tile: %d bytes of LDS refused", lds_bytes);
+    CgFwdP p{};
+    p.H0 = H0; p.in_ptr = in_ptr; p.in_src = in_src; p.in_typ = in_typ; p.WcatT = (const unsigned short*)WcatT; p.b1 = b1;
+    p.Wq = (const unsigned short*)Wq; p.bq = bq; p.inv_cnt = inv_cnt;
+    if (terms == 1) {
+        p.Mb = (unsigned short*)Mb; p.H1b = (unsigned short*)H1b; p.ldmb = ldmb; p.ldh1b = ldh1b;
+    } else {
+        p.Mf = (float*)Mb; p.H1f = (float*)H1b; p.ldmf = ldmb; p.ldh1f = ldh1b; p.catT_plane = catT_plane; p.q_plane = q_plane;
+    }
+    p.QKVS = QKVS; p.H2 = H2; p.alpha = alpha;
+    const int tiles = erc_cdiv(n_nodes, CG_TR);
+    p.bn_part = bn_ws ? bn_ws + 2 : nullptr;                     // [0] holds the arrival counter (8-byte slot)
+    p.bn_counter = reinterpret_cast<int*>(bn_ws);
+    p.running_mean = running_mean; p.running_var = running_var; p.saved = saved;
+    p.momentum = momentum; p.eps = eps; p.scale = scale;
+    p.N = n_nodes; p.ldh0 = ldh0; p.ldh2 = ldh2; p.bn_fused = bn_fused;
+    p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0; p.n_dev = n_dev;
+    p.health = health, p.events = events;
+    p.stamps = g_cg_stamps; p.stamp_block = tiles / 2;
+    if (terms == 1) hipLaunchKernelGGL(cogmen_fwd_tile_kernel<1>, dim3(tiles), dim3(CG_NTH), lds_bytes, (hipStream_t)stream, p);
+    else if (terms == 2) hipLaunchKernelGGL(cogmen_fwd_tile_kernel<2>, dim3(tiles), dim3(CG_NTH), lds_bytes, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(cogmen_fwd_tile_kernel<3>, dim3(tiles), dim3(CG_NTH), lds_bytes, (hipStream_t)stream, p);
+    ERC_LAUNCH_CHECK("cogmen_fwd_tile");
+    return ERC_OK;
+}
+
 extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int wp, int wf, const int32_t* in_ptr,
                                    const int32_t* in_src, const int32_t* in_typ, const void* WcatT, const float* b1,
                                    const void* Wq, const float* bq, float scale, void* Mb, int ldmb, float* inv_cnt, void* H1b,
@@ -1143,44 +1511,35 @@ extern "C" int erc_cogmen_fwd_tile(const float* H0, int ldh0, int n_nodes, int w
                                    float* running_mean, float* running_var, float momentum, float eps, float* saved,
                                    double* bn_ws, const int32_t* node_spk, int n_speakers, const int32_t* n_dev, int32_t* health,
                                    int32_t* events, void* stream) {
-    ERC_REQUIRE(H0 && in_ptr && in_src && in_typ && WcatT && b1 && Wq && bq && Mb && inv_cnt && H1b && QKVS && H2 && alpha && node_spk,
-                "cogmen_fwd_tile: null pointer");
-    ERC_REQUIRE(!health == !events, "cogmen_fwd_tile: health and events come together");
-    ERC_REQUIRE(n_nodes > 0 && wp >= 0 && wf >= 0 && wp <= CG_HL && wf <= CG_HL, "cogmen_fwd_tile: window (%d, %d) exceeds the halo %d",
-                wp, wf, CG_HL);
-    ERC_REQUIRE(ldh0 >= CG_F && ldh0 % 4 == 0 && ((uintptr_t)H0 & 15) == 0 && ldmb >= CG_KM && ldmb % 2 == 0 && ((uintptr_t)Mb & 3) == 0 && ldh1b >= CG_F &&
-                    ldh2 >= CG_F && ldh2 % 2 == 0 && ((uintptr_t)H2 & 7) == 0 &&
-                    ((uintptr_t)QKVS & 15) == 0 && ((uintptr_t)WcatT & 15) == 0 && ((uintptr_t)Wq & 15) == 0,
-                "cogmen_fwd_tile: pitch / alignment");
-    ERC_REQUIRE(bn_fused >= 0 && bn_fused <= 2 && (bn_fused != 1 || (running_mean && running_var && saved)) && (!bn_fused || bn_ws),
-                "cogmen_fwd_tile: BatchNorm operands");
-    ERC_REQUIRE(ensure_lds(reinterpret_cast<const void*>(cogmen_fwd_tile_kernel), FW_LDS), "cogmen_fwd_tile: %d bytes of LDS refused", FW_LDS);
-    CgFwdP p{};
-    p.H0 = H0; p.in_ptr = in_ptr; p.in_src = in_src; p.in_typ = in_typ; p.WcatT = (const unsigned short*)WcatT; p.b1 = b1;
-    p.Wq = (const unsigned short*)Wq; p.bq = bq; p.Mb = (unsigned short*)Mb; p.inv_cnt = inv_cnt; p.H1b = (unsigned short*)H1b;
-    p.QKVS = QKVS; p.H2 = H2; p.alpha = alpha;
-    const int tiles = erc_cdiv(n_nodes, CG_TR);
-    p.bn_part = bn_ws ? bn_ws + 2 : nullptr;                     // [0] holds the arrival counter (8-byte slot)
-    p.bn_counter = reinterpret_cast<int*>(bn_ws);
-    p.running_mean = running_mean; p.running_var = running_var; p.saved = saved;
-    p.momentum = momentum; p.eps = eps; p.scale = scale;
-    p.N = n_nodes; p.ldh0 = ldh0; p.ldmb = ldmb; p.ldh1b = ldh1b; p.ldh2 = ldh2; p.bn_fused = bn_fused;
-    p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0; p.n_dev = n_dev;
-    p.health = health, p.events = events;
-    p.stamps = g_cg_stamps; p.stamp_block = tiles / 2;
-    hipLaunchKernelGGL(cogmen_fwd_tile_kernel, dim3(tiles), dim3(CG_NTH), FW_LDS, (hipStream_t)stream, p);
-    ERC_LAUNCH_CHECK("cogmen_fwd_tile");
-    return ERC_OK;
+    return fwd_tile_launch(1, H0, ldh0, n_nodes, wp, wf, in_ptr, in_src, in_typ, WcatT, 0, b1, Wq, 0, bq, scale, Mb, ldmb, inv_cnt, H1b,
+                           ldh1b, QKVS, H2, ldh2, alpha, bn_fused, running_mean, running_var, momentum, eps, saved, bn_ws, node_spk,
+                           n_speakers, n_dev, health, events, stream);
 }
 
-extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes, int wp, int wf, const float* gamma,
-                                   const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
-                                   const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
-                                   const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
-                                   const void* Wb, float scale, void* dQKVS, void* dH1, void* dH0, int lddh0,
-                                   const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
-                                   int head_part_floats, float* dgamma, float* dbeta, float* stats, int grads_bf16, int lddh1,
-                                   const int32_t* n_dev, void* stream) {
+// Split compute modes (terms = 2 | 3): WcatT / Wq = that many bf16 term planes (ErcShadowTab mode 1, planes catT_plane / q_plane
+// elements apart); the weight-gradient operands are written as FP32: Mf [N, ldmf >= 900] = [mean_r H0 | H0], H1f [N, ldh1f >= 100].
+// Two-speaker graphs only (n_speakers == 2).  Everything else as erc_cogmen_fwd_tile.
+extern "C" int erc_cogmen_fwd_tile_x(int terms, const float* H0, int ldh0, int n_nodes, int wp, int wf, const int32_t* in_ptr,
+                                     const int32_t* in_src, const int32_t* in_typ, const void* WcatT, int64_t catT_plane,
+                                     const float* b1, const void* Wq, int64_t q_plane, const float* bq, float scale, float* Mf,
+                                     int ldmf, float* inv_cnt, float* H1f, int ldh1f, float* QKVS, float* H2, int ldh2,
+                                     float* alpha, int bn_fused, float* running_mean, float* running_var, float momentum,
+                                     float eps, float* saved, double* bn_ws, const int32_t* node_spk, int n_speakers,
+                                     const int32_t* n_dev, int32_t* health, int32_t* events, void* stream) {
+    ERC_REQUIRE(terms == 2 || terms == 3, "cogmen_fwd_tile_x: terms = %d (2 or 3)", terms);
+    return fwd_tile_launch(terms, H0, ldh0, n_nodes, wp, wf, in_ptr, in_src, in_typ, WcatT, catT_plane, b1, Wq, q_plane, bq, scale, Mf,
+                           ldmf, inv_cnt, H1f, ldh1f, QKVS, H2, ldh2, alpha, bn_fused, running_mean, running_var, momentum, eps, saved,
+                           bn_ws, node_spk, n_speakers, n_dev, health, events, stream);
+}
+
+static int bwd_tile_launch(int terms, const float* dY, const float* H2, int ldh2, int n_nodes, int wp, int wf, const float* gamma,
+                           const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
+                           const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                           const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT, int64_t qT_plane,
+                           const void* Wb, int64_t wb_plane, float scale, void* dQKVS, void* dH1, void* dH0, int lddh0,
+                           const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
+                           int head_part_floats, float* dgamma, float* dbeta, float* stats, int grads_bf16, int lddh1,
+                           const int32_t* n_dev, void* stream) {
     ERC_REQUIRE(!head_part || (head_parts > 0 && head_part_floats >= 227 && head_part_floats <= 256 && dgamma && dbeta && stats),
                 "cogmen_bwd_tile: head record operands");
     ERC_REQUIRE(dY && H2 && gamma && saved && bn_bwd && QKVS && alpha && in_ptr && in_src && out_ptr && out_dst && out_typ &&
@@ -1192,18 +1551,59 @@ extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, i
     ERC_REQUIRE(ldh2 >= CG_F && ldh2 % 4 == 0 && lddh0 >= CG_F &&
                     (((uintptr_t)dY | (uintptr_t)H2 | (uintptr_t)QKVS | (uintptr_t)gamma | (uintptr_t)saved | (uintptr_t)bn_bwd |
                       (uintptr_t)WqT | (uintptr_t)Wb) & 15) == 0, "cogmen_bwd_tile: pitch / alignment");
-    ERC_REQUIRE(ensure_lds(reinterpret_cast<const void*>(cogmen_bwd_tile_kernel), BW_LDS), "cogmen_bwd_tile: %d bytes of LDS refused", BW_LDS);
+    ERC_REQUIRE(terms == 1 || ((terms == 2 || terms == 3) && n_speakers == 2 && !grads_bf16 && qT_plane > 0 && qT_plane % 8 == 0 &&
+                               wb_plane > 0 && wb_plane % 8 == 0 && ((uintptr_t)dQKVS & 7) == 0),
+                "cogmen_bwd_tile_x: terms = %d (2 | 3), two-speaker graphs only (n_speakers = %d), fp32 gradients, plane strides multiples of 8",
+                terms, n_speakers);
+    const void* kern = terms == 1 ? reinterpret_cast<const void*>(cogmen_bwd_tile_kernel<1>)
+                     : terms == 2 ? reinterpret_cast<const void*>(cogmen_bwd_tile_kernel<2>)
+                                  : reinterpret_cast<const void*>(cogmen_bwd_tile_kernel<3>);
+    const int lds_bytes = terms == 1 ? BW_LDS : terms == 2 ? BxMap<2>::LDS : BxMap<3>::LDS;
+    ERC_REQUIRE(ensure_lds(kern, lds_bytes), "cogmen_bwd_tile: %d bytes of LDS refused", lds_bytes);
     CgBwdP p{};
     p.dY = dY; p.H2 = H2; p.gamma = gamma; p.saved = saved; p.bn_bwd = bn_bwd; p.QKVS = QKVS; p.alpha = alpha;
     p.in_ptr = in_ptr; p.in_src = in_src; p.out_ptr = out_ptr; p.out_dst = out_dst; p.out_typ = out_typ; p.out_eid = out_eid;
     p.inv_cnt = inv_cnt; p.WqT = (const unsigned short*)WqT; p.Wb = (const unsigned short*)Wb;
+    p.qT_plane = qT_plane; p.wb_plane = wb_plane;
     p.dQKVS = (float*)dQKVS; p.dH1 = (float*)dH1; p.dH0 = (float*)dH0; p.scale = scale; p.N = n_nodes; p.ldh2 = ldh2; p.lddh0 = lddh0;
     p.lddh1 = lddh1; p.grads_bf16 = grads_bf16;
     p.node_spk = node_spk; p.two_spk = n_speakers == 2 ? 1 : 0; p.n_dev = n_dev;
     p.head_part = head_part; p.head_parts = head_parts; p.hp_floats = head_part_floats; p.bn_bwd_out = const_cast<float*>(bn_bwd);
     p.dgamma = dgamma; p.dbeta = dbeta; p.stats = stats;
     p.stamps = g_cg_stamps; p.stamp_block = erc_cdiv(n_nodes, CG_TR) / 2;
-    hipLaunchKernelGGL(cogmen_bwd_tile_kernel, dim3(erc_cdiv(n_nodes, CG_TR)), dim3(CG_NTH), BW_LDS, (hipStream_t)stream, p);
+    const dim3 grid(erc_cdiv(n_nodes, CG_TR));
+    if (terms == 1) hipLaunchKernelGGL(cogmen_bwd_tile_kernel<1>, grid, dim3(CG_NTH), lds_bytes, (hipStream_t)stream, p);
+    else if (terms == 2) hipLaunchKernelGGL(cogmen_bwd_tile_kernel<2>, grid, dim3(CG_NTH), lds_bytes, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(cogmen_bwd_tile_kernel<3>, grid, dim3(CG_NTH), lds_bytes, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("cogmen_bwd_tile");
     return ERC_OK;
+}
+
+extern "C" int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes, int wp, int wf, const float* gamma,
+                                   const float* saved, const float* bn_bwd, const float* QKVS, const float* alpha,
+                                   const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                   const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt, const void* WqT,
+                                   const void* Wb, float scale, void* dQKVS, void* dH1, void* dH0, int lddh0,
+                                   const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
+                                   int head_part_floats, float* dgamma, float* dbeta, float* stats, int grads_bf16, int lddh1,
+                                   const int32_t* n_dev, void* stream) {
+    return bwd_tile_launch(1, dY, H2, ldh2, n_nodes, wp, wf, gamma, saved, bn_bwd, QKVS, alpha, in_ptr, in_src, out_ptr, out_dst, out_typ,
+                           out_eid, inv_cnt, WqT, 0, Wb, 0, scale, dQKVS, dH1, dH0, lddh0, node_spk, n_speakers, head_part, head_parts,
+                           head_part_floats, dgamma, dbeta, stats, grads_bf16, lddh1, n_dev, stream);
+}
+
+// Split compute modes (terms = 2 | 3): WqT / Wb = that many bf16 term planes, qT_plane / wb_plane elements apart; the three gradient
+// tiles are written as FP32 (dQKVS [N, 400], dH1 [N, lddh1], dH0 [N, lddh0]: operands of erc_wgrad_split).  Two-speaker graphs only.
+extern "C" int erc_cogmen_bwd_tile_x(int terms, const float* dY, const float* H2, int ldh2, int n_nodes, int wp, int wf,
+                                     const float* gamma, const float* saved, const float* bn_bwd, const float* QKVS,
+                                     const float* alpha, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                                     const int32_t* out_dst, const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt,
+                                     const void* WqT, int64_t qT_plane, const void* Wb, int64_t wb_plane, float scale, float* dQKVS,
+                                     float* dH1, float* dH0, int lddh0, const int32_t* node_spk, int n_speakers,
+                                     const float* head_part, int head_parts, int head_part_floats, float* dgamma, float* dbeta,
+                                     float* stats, int lddh1, const int32_t* n_dev, void* stream) {
+    ERC_REQUIRE(terms == 2 || terms == 3, "cogmen_bwd_tile_x: terms = %d (2 or 3)", terms);
+    return bwd_tile_launch(terms, dY, H2, ldh2, n_nodes, wp, wf, gamma, saved, bn_bwd, QKVS, alpha, in_ptr, in_src, out_ptr, out_dst,
+                           out_typ, out_eid, inv_cnt, WqT, qT_plane, Wb, wb_plane, scale, dQKVS, dH1, dH0, lddh0, node_spk, n_speakers,
+                           head_part, head_parts, head_part_floats, dgamma, dbeta, stats, 0, lddh1, n_dev, stream);
 }

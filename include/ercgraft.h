@@ -485,6 +485,29 @@ int erc_cogmen_bwd_tile(const float* dY, const float* H2, int ldh2, int n_nodes,
                         const int32_t* node_spk, int n_speakers, const float* head_part, int head_parts,
                         int head_part_floats, float* dgamma, float* dbeta, float* stats, int grads_bf16, int lddh1,
                         const int32_t* n_dev, void* stream);
+/* SPLIT COMPUTE MODES (terms = 2 | 3; "f32x2" / "f32x3"): the same two launches at fp32-class accuracy -- what the reference's
+ * fp32 GNN.forward / backward computes (track_mm/cogmen.py:61-74,187-188) -- on the bf16 matrix cores.  The weights are read
+ * from `terms` bf16 PLANES per operand (ErcShadowTab with terms planes, *_plane elements apart: the bf16 expansion w = t0 + t1
+ * (+ t2)), the activation tiles are expanded into term planes as they are staged in LDS, and every product accumulates the
+ * term products of weight >= 2^(-8 (terms - 1)) in fp32.  The operands handed to the weight-gradient launch
+ * (erc_wgrad_split) are FP32: Mf [N, ldmf >= 900], H1f [N, ldh1f >= 100]; dQKVS [N, 400], dH1 [N, lddh1], dH0 [N, lddh0].
+ * Two-speaker graphs only (n_speakers == 2, the reference's GNN(n_speakers = 2)): a node's row of M / dP then holds five
+ * non-empty blocks, which is what lets the term planes fit in LDS.  Everything else as erc_cogmen_fwd_tile / _bwd_tile. */
+int erc_cogmen_fwd_tile_x(int terms, const float* H0, int ldh0, int n_nodes, int wp, int wf, const int32_t* in_ptr,
+                          const int32_t* in_src, const int32_t* in_typ, const void* WcatT, int64_t catT_plane,
+                          const float* b1, const void* Wq, int64_t q_plane, const float* bq, float scale, float* Mf,
+                          int ldmf, float* inv_cnt, float* H1f, int ldh1f, float* QKVS, float* H2, int ldh2,
+                          float* alpha, int bn_fused, float* running_mean, float* running_var, float momentum,
+                          float eps, float* saved, double* bn_ws, const int32_t* node_spk, int n_speakers,
+                          const int32_t* n_dev, int32_t* health, int32_t* events, void* stream);
+int erc_cogmen_bwd_tile_x(int terms, const float* dY, const float* H2, int ldh2, int n_nodes, int wp, int wf,
+                          const float* gamma, const float* saved, const float* bn_bwd, const float* QKVS,
+                          const float* alpha, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                          const int32_t* out_dst, const int32_t* out_typ, const int32_t* out_eid, const float* inv_cnt,
+                          const void* WqT, int64_t qT_plane, const void* Wb, int64_t wb_plane, float scale, float* dQKVS,
+                          float* dH1, float* dH0, int lddh0, const int32_t* node_spk, int n_speakers,
+                          const float* head_part, int head_parts, int head_part_floats, float* dgamma, float* dbeta,
+                          float* stats, int lddh1, const int32_t* n_dev, void* stream);
 /* n_dev (here, in erc_cogmen_fwd_tile and in erc_head_fused{,_bn}; NULL = off): CAPACITY MODE.  n_nodes / n_rows is then the
  * capacity the grid and the buffers are sized for and the true count (<= capacity) is read from device memory -- counts[0]
  * of erc_cogmen_project_graph -- so that ONE captured HIP graph serves every batch whose node count fits the capacity

@@ -203,8 +203,14 @@ def test_cogmen_split_parity(case, compute, monkeypatch):
 @pytest.mark.parametrize("compute", ["f32x2", "f32x3"])
 def test_cogmen_split_config2_shape_parity(compute):
     """BASELINE.json configs[1] shape (B=32, T=110, D=1380, 6 classes) through the split mode's step: north_star's 1e-4."""
-    res = run_cogmen_parity(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=1), compute=compute)
-    print("%s config 2: logits %.2e (mean %.2e, scale %.2f), gradients %.2e entry-wise / %.2e norm-wise"
-          % (compute, res["logit_err"], res["logit_err_mean"], res["logit_scale"], res["grad_err"], res["grad_norm_err"]))
+    # two terms deviate by ~3e-6 on the logits: with 183 500 ReLU units at N = 1 835, one of them sits within that of its kink in
+    # about every other batch (seed 1 has one: 6.6e-3 of cls.0.weight's scale appears / vanishes with it) -- the oracle's backward
+    # runs with the compared path's activation pattern, units that differ must be within 2e-5 of the kink (util_cases).  Three
+    # terms (2e-7, as plain fp32 arithmetic) are compared as they are.
+    res = run_cogmen_parity(cogmen_case(B=32, min_len=20, max_len=110, dims=dict(a=100, t=768, v=512), seed=1), compute=compute,
+                            kink_aware=(compute == "f32x2"))
+    print("%s config 2: logits %.2e (mean %.2e, scale %.2f), gradients %.2e entry-wise / %.2e norm-wise%s"
+          % (compute, res["logit_err"], res["logit_err_mean"], res["logit_scale"], res["grad_err"], res["grad_norm_err"],
+             "  units on the other side of a kink: %s" % (res["kink_flips"], ) if "kink_flips" in res else ""))
     assert res["logit_err"] < LOGIT_TOL, res
     assert res["grad_err"] < GRAD_TOL, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:6]

@@ -40,7 +40,8 @@ def rel_err(a, b, floor=1e-5):
     return float((a - b).abs().max() / (b.abs().max() + floor))
 
 
-def run_cogmen_parity(case, device="cuda:0", compute="f32", zero_grad=(), zero_tol=1e-5, ref_rounding=True):
+def run_cogmen_parity(case, device="cuda:0", compute="f32", zero_grad=(), zero_tol=1e-5, ref_rounding=True, kink_aware=False,
+                      kink_tol=2e-5):
     """eval-mode logits and train-mode (dropout p=0) loss/gradients: HIP path vs oracle.
     ``ref_rounding=False`` with compute="bf16": the oracle stays the UNROUNDED fp32 restatement of the reference (fp32
     features, fp32 weights, fp32 products) -- what is measured is the bf16 compute mode's deviation from the reference,
@@ -88,11 +89,33 @@ def run_cogmen_parity(case, device="cuda:0", compute="f32", zero_grad=(), zero_t
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     mine.drop_p = 0.0
+    stats = mine.loss_and_grads(dbatch).cpu()
+    if kink_aware:
+        # ReLU / LeakyReLU have a derivative JUMP at 0: a unit whose pre-activation lies within the compared path's own
+        # forward deviation of 0 may sit on the other side there, and that one unit's whole gradient contribution appears or
+        # vanishes (measured at config 2: 3e-3 of cls.0.weight's scale per unit, whatever the size of the deviation).  The
+        # oracle's backward is therefore evaluated with the activation PATTERN of the compared path; every unit whose pattern
+        # differs must have an oracle pre-activation below ``kink_tol``.
+        ws = mine._last_ws
+        pat = {"cls": ws["Z"].cpu() > 0, "gcn": ws["H3"].cpu() > 0}
+        flips = []
+
+        def masked(slope, key):
+            def fwd(x):
+                m = pat[key]
+                diff = m != (x > 0)
+                flips.append((key, int(diff.sum()), float(x.detach()[diff].abs().max()) if bool(diff.any()) else 0.0))
+                return torch.where(m, x, x * slope)
+            return fwd
+        ref.cls[1].forward = masked(0.0, "cls")
+        ref.gcn.relu.forward = masked(0.01, "gcn")
     logits, _ = ref(**batch)
     loss = F.cross_entropy(logits, batch["label"])
     ref.zero_grad()
     loss.backward()
-    stats = mine.loss_and_grads(dbatch).cpu()
+    if kink_aware:
+        out["kink_flips"] = flips
+        assert all(mag < kink_tol for _, _, mag in flips), flips
     out["loss_err"] = abs(float(stats[0]) - float(loss))
     out["acc_match"] = int(stats[1]) == int((logits.argmax(-1) == batch["label"]).sum())
     worst, names, worst_norm = 0.0, {}, 0.0
