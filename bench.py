@@ -102,6 +102,28 @@ def _probe_candidates(module, params, host_batch, trainer):
                                          N * 2.0 * (900 * 100 + 100 * 400), fwd_b) + bf,
                  "erc_cogmen_bwd_tile": ("cogmen_bwd_tile_kernel (BatchNorm / attention backward, dH1 and dH0 products; halo tiles)",
                                          N * 2.0 * (400 * 100 + 900 * 100), bwd_b) + bf}
+        nt = getattr(trainer.model, "terms", 1)
+        if nt > 1:
+            ntb = trainer.model.terms_bwd
+            # split compute modes: the same launches on fp32 data; a product costs nt (nt + 1) / 2 term products on the bf16 matrix
+            # cores, counted here as ALGORITHMIC fp32 FLOPs against the rate those term products allow (bf16 peak / their number)
+            def sp_of(n_):
+                npr = n_ * (n_ + 1) // 2
+                return (MFMA_BF16_PEAK_TFS / npr, "bf16 matrix-core peak / %d: every fp32-class product is %d term products on "
+                                                   "v_mfma_f32_16x16x32_bf16 (%d bf16 terms per operand value)" % (npr, npr, n_))
+            sp, spb = sp_of(nt), sp_of(ntb)
+            fwd_x = N * (400 + 1600 + 3600 + 400 + 400) + E * (8 + 4.0) + 0.26e6 * nt      # H0 in; QKVS, fp32 M / H1, H2, alpha out
+            bwd_x = N * (400 + 400 + 1600 + 1600 + 400 + 400) + E * (17 + 4.0) + 0.26e6 * nt
+            adam_b = trainer.model.flat.numel * 24.0 + (trainer.model.shadows.buf.numel() * 2.0 if trainer.model.shadows is not None else 0.0)
+            cands.update({
+                "erc_wgrad_split": ("wgrad_bf16_kernel<terms=%d> (every weight gradient of the step from fp32 operands, one launch)" % ntb,
+                                    fl, wg_bytes) + spb,
+                "erc_wgrad_split_adam": ("wgrad_bf16_kernel<adam, terms=%d> (every weight gradient of the step from fp32 operands + the "
+                                         "Adam update of every parameter, one launch)" % ntb, fl, wg_bytes + adam_b) + spb,
+                "erc_cogmen_fwd_tile_x": ("cogmen_fwd_tile_kernel<terms=%d> (relation means, RGCN and QKVS products, attention; halo tiles)" % nt,
+                                          N * 2.0 * (900 * 100 + 100 * 400), fwd_x) + sp,
+                "erc_cogmen_bwd_tile_x": ("cogmen_bwd_tile_kernel<terms=%d> (BatchNorm / attention backward, dH1 and dH0 products; halo tiles)" % ntb,
+                                          N * 2.0 * (400 * 100 + 900 * 100), bwd_x) + spb})
         return cands
     if module == "dagerc":
         B, T = host_batch["input_tensor"].shape[:2]
@@ -255,7 +277,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x2", "f32x3", "f32x32"],
+                    help="compute mode: bf16 (BASELINE.json configs[1]); f32x3 / f32x2: fp32 data, products on the bf16 matrix cores from "
+                         "operands expanded into 3 / 2 bf16 terms (COGMEN: the 1e-4 parity path on the fused step); f32: exact-fp32 kernels")
     ap.add_argument("--module", default="cogmen", choices=sorted(WORKLOADS))  # headline = cogmen (configs[1])
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--max_len", type=int, default=None)
@@ -300,8 +324,8 @@ def main():
 
     ds, bsz, mlen, extra = WORKLOADS[args.module]
     args.dataset, args.batch, args.max_len = args.dataset or ds, args.batch or bsz, args.max_len or mlen
-    if args.module == "mmgcn":
-        args.dtype = "f32"  # three separate feature blocks; no bf16 feature mode for MMGCN
+    if args.module == "mmgcn" or (args.module != "cogmen" and args.dtype.startswith("f32x")):
+        args.dtype = "f32"  # three separate feature blocks; no bf16 feature mode for MMGCN; the split modes are COGMEN's
     plugin = importlib.import_module("track_mm." + args.module)
     if args.faithful_dead_encoder and args.module == "cogmen":
         extra = extra + ["--faithful_dead_encoder"]

@@ -85,13 +85,18 @@ class COGMENModule(nn.Module):
         self.enc_train = None
         assert hidden_size == F_HID, "the reference hard-codes 100 (cogmen.py:116-122)"
         self.input_size, self.n_speakers, self.n_classes = input_size, n_speakers, n_classes
-        if compute not in ("f32", "bf16", "f32x2", "f32x3"):
-            raise capi.ErcGraftError("COGMEN compute mode %r (f32 | bf16 | f32x2 | f32x3)" % (compute, ))
+        if compute not in ("f32", "bf16", "f32x2", "f32x3", "f32x32"):
+            raise capi.ErcGraftError("COGMEN compute mode %r (f32 | bf16 | f32x2 | f32x3 | f32x32)" % (compute, ))
         self.compute = compute
         # SPLIT COMPUTE MODES (csrc/split_dev.h): fp32 data everywhere, every dense product on the bf16 matrix cores from operands
         # expanded into `terms` bf16 terms -- the fused 5-launch step structure of the bf16 mode at fp32-class accuracy
         # (north_star's 1e-4: two terms give 8e-6 on the logits of config 2, three are indistinguishable from fp32 arithmetic)
-        self.terms = {"f32x2": 2, "f32x3": 3}.get(compute, 1)
+        # f32x32: three terms in the FORWARD products (projection, RGCN, QKVS), two in the backward ones (dH1, dH0, every weight
+        # gradient).  The forward feeds ReLU / LeakyReLU kinks and the argmax: a forward deviation of 3e-6 (two terms) puts a unit on
+        # the other side of its kink in about every other config-2 batch, which moves a gradient entry by 3e-3 of its tensor's scale;
+        # the backward is linear in its operands (1e-5 of a gradient's scale with two terms, against fp32's own 5e-6).
+        self.terms = {"f32x2": 2, "f32x3": 3, "f32x32": 3}.get(compute, 1)
+        self.terms_bwd = {"f32x32": 2}.get(compute, self.terms)
         layer = nn.TransformerEncoderLayer(d_model=input_size, nhead=pick_heads(input_size, num_head),
                                            dropout=0.5, batch_first=True)
         encoder = nn.TransformerEncoder(layer, num_layers=2, enable_nested_tensor=False)  # dead (see module doc)
@@ -168,9 +173,9 @@ class COGMENModule(nn.Module):
         i_w1 = t.add(fp.offsets["rnn.1.weight"], F * D, F * D, D, F, (0, 1, 0), (1, 0, 0), D, 0, terms=nt)            # row-major copy
         # logical [n][k] operands in MFMA B-fragment order (ercgraft.h, mode 1)
         i_catT = t.add(off_cat, 9 * F * F, 7 * 29 * 512, F, 9 * F, (1, 0, 0), (0, 1, 0), 29, 1, terms=nt)           # WcatT[o][r*100+c]
-        i_wb = t.add(off_cat, 9 * F * F, 7 * 30 * 512, F, F, (0, 1, 0), (1, 0, 104), 30, 1, terms=nt)               # Wb[c][r*104+o]
+        i_wb = t.add(off_cat, 9 * F * F, 7 * 30 * 512, F, F, (0, 1, 0), (1, 0, 104), 30, 1, terms=self.terms_bwd)   # Wb[c][r*104+o]
         i_q = t.add(off_q, 4 * F * F, 25 * 4 * 512, F, 4 * F, (0, 1, 0), (1, 0, 0), 4, 1, terms=nt)                 # Wq[n][k]
-        i_qT = t.add(off_q, 4 * F * F, 7 * 13 * 512, F, 4 * F, (1, 0, 0), (0, 1, 0), 13, 1, terms=nt)               # WqT[k][n]
+        i_qT = t.add(off_q, 4 * F * F, 7 * 13 * 512, F, 4 * F, (1, 0, 0), (0, 1, 0), 13, 1, terms=self.terms_bwd)   # WqT[k][n]
         t.seal()
         self.shadows = t
         self._sh = dict(w1=t.view(i_w1)[:F * D].view(F, D), catT=t.view(i_catT), wb=t.view(i_wb), q=t.view(i_q), qT=t.view(i_qT))
@@ -427,7 +432,7 @@ class COGMENModule(nn.Module):
             raise capi.ErcGraftError("COGMEN %s mode: fp32 contiguous features, D %% 4 == 0, C <= 8, training through the fused head"
                                      % self.compute)
         ws["w16"], ws["wsp"] = w16, wsp
-        pl.split_terms = self.terms if wsp else 1
+        pl.split_terms = self.terms_bwd if wsp else 1
         b16 = (ws["H3b"], ws["Zb"], ws["dZb"], ws["dlb"], PA) if w16 else None
         lddl = self.LDDL if split else 0
         nd = g["counts"] if self.dynamic_n else None
@@ -543,7 +548,7 @@ class COGMENModule(nn.Module):
                     ws["alpha"], g, ws["inv_cnt"], self._sh["qT"], self._sh["wb"], 1.0 / math.sqrt(F))
         if ws.get("wsp"):      # split modes: fp32 gradient tiles, weights as term planes; then the weight gradients + optimizer
             capi.cogmen_bwd_tile(*bwd_args, ws["dQKVS"], ws["dH1"], ws["dH0"], F, n_speakers=self.n_speakers, lddh1=F, n_dev=nd,
-                                 terms=self.terms, qT_plane=self._sh_plane["qT"], wb_plane=self._sh_plane["wb"], **head_kw)
+                                 terms=self.terms_bwd, qT_plane=self._sh_plane["qT"], wb_plane=self._sh_plane["wb"], **head_kw)
             self._split_wgrads(ws, x, N)
             return
         if w16:
@@ -596,13 +601,17 @@ class COGMENModule(nn.Module):
         F, D = F_HID, self.input_size
         x_bf16 = x.dtype == torch.bfloat16
         spk = batch["speaker_tensor"]
-        fusedpg = (self.fuse_project_graph and x_bf16 and self.w1_shadow is not None and self.enc_train is None and spk.dim() == 2
-                   and capi.cogmen_project_graph_ok(D, F, B, D, D))
+        split = self.terms > 1
+        fusedpg = (self.fuse_project_graph and (x.dtype == torch.float32 if split else x_bf16) and self.w1_shadow is not None
+                   and self.enc_train is None and spk.dim() == 2 and capi.cogmen_project_graph_ok(D, F, B, D, D))
         extra = 0
-        if fusedpg:     # what the bf16 step launches: projection + window graph in one kernel (csrc/cogmen_project.hip)
+        if fusedpg:     # what the bf16 / split step launches: projection + window graph in one kernel (csrc/cogmen_project.hip)
             launch = lambda: capi.cogmen_project_graph(x, D, self.w1_shadow, D, fp.w("rnn.1.bias"), ws["H0"], F, F, D, lens, spk, B, T,
-                                                       WP, WF, self.n_speakers, N, ws["E"], g)
-            name = "cogmen_project_graph_kernel (input projection, bf16 features, weights resident in registers, + the window graph)"
+                                                       WP, WF, self.n_speakers, N, ws["E"], g, terms=self.terms,
+                                                       w_plane=self._sh_plane["w1"])
+            name = ("cogmen_project_graph_kernel<terms=%d> (input projection, fp32 features expanded into bf16 terms, weight planes "
+                    "resident in registers, + the window graph)" % self.terms) if split else \
+                "cogmen_project_graph_kernel (input projection, bf16 features, weights resident in registers, + the window graph)"
             extra = int(g["counts"][1]) * 17 + N * 12 + B * 16      # CSR arrays written, lengths / speakers read
         elif x_bf16:
             W1 = self.w1_shadow if self.w1_shadow is not None else fp.w("rnn.1.weight")
@@ -616,7 +625,7 @@ class COGMENModule(nn.Module):
                                            bias=fp.w("rnn.1.bias"))
             name = "gemm_f32_stream_kernel<0,0,8> (input projection, fp32 features)"
         S = 1
-        wbytes = 2 if (x_bf16 and self.w1_shadow is not None) else 4
+        wbytes = 2 * self.terms if ((x_bf16 or split) and self.w1_shadow is not None) else 4
         nbytes = N * D * x.element_size() + F * D * wbytes + N * F * 4 + N * 4 + extra
         for _ in range(10):
             launch()

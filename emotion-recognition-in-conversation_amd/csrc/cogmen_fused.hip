@@ -77,7 +77,11 @@ static_assert(7 * 64 * 8 * 4 <= FW_SH0_BYTES, "K-split partials must fit the H0 
 constexpr int FX_CM = 520;                                     // pitch of the compact M tile (bf16 elements; 1040 B rows)
 constexpr int FX_MPLANE = CG_MID * FX_CM * 2;                  // 27040 bytes per term plane
 constexpr int FX_ZERO = 2 * 512;                               // plane-relative byte offset of 8 zero bytes (row 0, columns [512, 516): never written by the aggregation)
-constexpr int FX_PF = 2;                                       // weight fragments of the H1 product requested ahead (K blocks)
+// weight fragments of the H1 product requested ahead (K blocks per wavefront, of its 15).  Measured: 2 ahead 21.3 / 27.0 us per launch
+// (2 / 3 terms), 7 / 5 ahead -- everything the registers hold across the aggregation -- 22.3 / 27.5: a tile's NT x 0.3 MB of weight planes
+// come through the per-CU L2 path (~70 GB/s) whenever they are requested, and a burst in front of a stage delays that stage's own loads
+// (DESIGN.md finding 20)
+template <int NT> constexpr int FX_PF = 3;
 template <int NT>
 struct FxMap {
     static constexpr int SM_OFF = 0;                           // M planes; the fp64 segment totals of the prefix scan before them; later the QKVS tile
@@ -263,13 +267,13 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
     }
     __builtin_amdgcn_sched_barrier(0);   // the tile / graph loads above are queued first
     bf16x8 bx[X ? 1 : KH0];
-    sp_u32x4 bxr[X ? FX_PF : 1][X ? NT : 1];      // split modes: a ring of FX_PF K blocks x NT term planes
+    sp_u32x4 bxr[X ? FX_PF<NT> : 1][X ? NT : 1];      // split modes: a ring of FX_PF K blocks x NT term planes
     if constexpr (!X) {
 #pragma unroll
         for (int u = 0; u < KH0; ++u) bx[u] = *reinterpret_cast<const bf16x8*>(brow + 512 * min(u, nkb - 1));
     } else {
 #pragma unroll
-        for (int u = 0; u < FX_PF; ++u)
+        for (int u = 0; u < FX_PF<NT>; ++u)
 #pragma unroll
             for (int t = 0; t < NT; ++t) bxr[u][t] = *reinterpret_cast<const sp_u32x4*>(brow + t * p.catT_plane + 512 * min(u, nkb - 1));
     }
@@ -506,9 +510,9 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_fwd_tile_kernel(const CgFwdP p)
                         const uint2 x0 = *reinterpret_cast<const uint2*>(pl + ad0[0]), x1 = *reinterpret_cast<const uint2*>(pl + ad0[1]);
                         const uint2 y0 = *reinterpret_cast<const uint2*>(pl + ad1[0]), y1 = *reinterpret_cast<const uint2*>(pl + ad1[1]);
                         fa0[t] = (sp_u32x4){x0.x, x0.y, x1.x, x1.y}, fa1[t] = (sp_u32x4){y0.x, y0.y, y1.x, y1.y};
-                        fb[t] = bxr[u % FX_PF][t];
-                        if (u + FX_PF < KH0)      // (compile time) refill the ring slot: K block u + FX_PF, clamped (a block past the end is never multiplied)
-                            bxr[u % FX_PF][t] = *reinterpret_cast<const sp_u32x4*>(brow + t * p.catT_plane + 512 * min(u + FX_PF, nkb - 1));
+                        fb[t] = bxr[u % FX_PF<NT>][t];
+                        if (u + FX_PF<NT> < KH0)      // (compile time) refill the ring slot: K block u + FX_PF, clamped (a block past the end is never multiplied)
+                            bxr[u % FX_PF<NT>][t] = *reinterpret_cast<const sp_u32x4*>(brow + t * p.catT_plane + 512 * min(u + FX_PF<NT>, nkb - 1));
                     }
                     acc0 = sp_mfma<NT>(fa0, fb, acc0);
                     acc1 = sp_mfma<NT>(fa1, fb, acc1);
@@ -812,7 +816,7 @@ constexpr int BX_DQPLANE = BX_DQ_ROWS * CG_SDQ * 2;              // 22896 bytes 
 constexpr int BX_CP = 528;                                       // pitch of the compact dP tile (bf16 elements)
 constexpr int BX_DPPLANE = CG_TR * BX_CP * 2;                    // 16896
 constexpr int BX_ZERO = 2 * 520;                                 // plane-relative byte offset of 8 zero bytes in a dP plane (row 0, columns [520, 524))
-constexpr int BX_PF = 2;                                         // weight fragments requested ahead (K blocks)
+template <int NT> constexpr int BX_PF = 3;                       // weight fragments requested ahead (K blocks; see FX_PF)
 constexpr int BX_SE_BYTES16 = ((BW_SE_BYTES + 15) / 16) * 16;
 template <int NT>
 struct BxMap {
@@ -1093,15 +1097,15 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
     // B fragments of the dH1 product (K = 416: blocks [7 kh, 7 kh + 7), the second half has 6): requested now
     const unsigned short* const brow3 = p.WqT + ((int64_t)(min(ct, CG_NT - 1) * 13 + 7 * kh) * 64 + lane) * 8;
     bf16x8 fb3[X ? 1 : 7];
-    sp_u32x4 fb3r[X ? BX_PF : 1][X ? NT : 1], bxr[X ? BX_PF : 1][X ? NT : 1];      // split modes: rings of BX_PF K blocks x NT planes
+    sp_u32x4 fb3r[X ? BX_PF<NT> : 1][X ? NT : 1], bxr[X ? BX_PF<NT> : 1][X ? NT : 1];      // split modes: rings of BX_PF K blocks x NT planes
     if constexpr (!X) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) fb3[u] = *reinterpret_cast<const bf16x8*>(brow3 + 512 * min(u, kh ? 5 : 6));
     } else {
 #pragma unroll
-        for (int u = 0; u < BX_PF; ++u)
+        for (int u = 0; u < BX_PF<NT>; ++u)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) fb3r[u][t] = *reinterpret_cast<const sp_u32x4*>(brow3 + t * p.qT_plane + 512 * u);
+            for (int t = 0; t < NT; ++t) fb3r[u][t] = *reinterpret_cast<const sp_u32x4*>(brow3 + t * p.qT_plane + 512 * min(u, kh ? 5 : 6));
     }
 
     const unsigned short* const brow5 = p.Wb + ((int64_t)(min(ct, CG_NT - 1) * 30 + 15 * kh) * 64 + lane) * 8;
@@ -1221,11 +1225,6 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
             } else {
                 const int nkb3 = kh ? 6 : 7;
                 const unsigned short* const a1 = sDQ + min(16 + r, CG_MID) * CG_SDQ + 8 * g + 32 * 7 * kh;      // rows >= 26: the zero row
-                // the first blocks of the dH0 product's weights: in flight across the transposed-means stage
-#pragma unroll
-                for (int u = 0; u < BX_PF; ++u)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) bxr[u][t] = *reinterpret_cast<const sp_u32x4*>(brow5 + t * p.wb_plane + 512 * u);
 #pragma unroll
                 for (int u = 0; u < 7; ++u) {
                     if (u < nkb3) {   // wave-uniform
@@ -1234,13 +1233,20 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                         for (int t = 0; t < NT; ++t) {
                             fa0[t] = *reinterpret_cast<const sp_u32x4*>(a0 + t * (BX_DQPLANE / 2) + 32 * u);
                             fa1[t] = *reinterpret_cast<const sp_u32x4*>(a1 + t * (BX_DQPLANE / 2) + 32 * u);
-                            fb[t] = fb3r[u % BX_PF][t];
-                            if (u + BX_PF < 7) fb3r[u % BX_PF][t] = *reinterpret_cast<const sp_u32x4*>(brow3 + t * p.qT_plane + 512 * min(u + BX_PF, nkb3 - 1));
+                            fb[t] = fb3r[u % BX_PF<NT>][t];
+                            if (u + BX_PF<NT> < 7) fb3r[u % BX_PF<NT>][t] = *reinterpret_cast<const sp_u32x4*>(brow3 + t * p.qT_plane + 512 * min(u + BX_PF<NT>, nkb3 - 1));
                         }
                         acc0 = sp_mfma<NT>(fa0, fb, acc0);
                         acc1 = sp_mfma<NT>(fa1, fb, acc1);
                     }
                 }
+                // the first blocks of the dH0 product's weights, into the registers the ring above has just freed: in flight across
+                // the transposed-means stage
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < BX_PF<NT>; ++u)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) bxr[u][t] = *reinterpret_cast<const sp_u32x4*>(brow5 + t * p.wb_plane + 512 * u);
             }
             if (kh) {
                 float* dst = sPart3 + (ct * 64 + lane) * 8;
@@ -1404,8 +1410,8 @@ __global__ __launch_bounds__(CG_NTH) void cogmen_bwd_tile_kernel(const CgBwdP p)
                         const unsigned char* const pl = pbase + t * BX_DPPLANE;
                         const uint2 x0 = *reinterpret_cast<const uint2*>(pl + ad[0]), x1 = *reinterpret_cast<const uint2*>(pl + ad[1]);
                         fa[t] = (sp_u32x4){x0.x, x0.y, x1.x, x1.y};
-                        fb[t] = bxr[u % BX_PF][t];
-                        if (u + BX_PF < 15) bxr[u % BX_PF][t] = *reinterpret_cast<const sp_u32x4*>(brow5 + t * p.wb_plane + 512 * (u + BX_PF));
+                        fb[t] = bxr[u % BX_PF<NT>][t];
+                        if (u + BX_PF<NT> < 15) bxr[u % BX_PF<NT>][t] = *reinterpret_cast<const sp_u32x4*>(brow5 + t * p.wb_plane + 512 * (u + BX_PF<NT>));
                     }
                     acc = sp_mfma<NT>(fa, fb, acc);
                 }

@@ -304,10 +304,12 @@ static int project_graph_launch(int terms, const void* X, int ldx, const void* W
     PgP p{X, (const unsigned short*)W, w_plane, bias, H0, ldx, ldw, ldh0, K, n_out, lengths, speakers, spk_sb, spk_st,
           B, T, wp < 0 ? T : wp, wf < 0 ? T : wf, n_speakers, n_cap, e_cap, node_off, node_row, node_spk, in_ptr, in_src, in_typ,
           out_ptr, out_dst, out_typ, out_eid, counts, desc};
-    // 256 workgroups: 128 pairs (bf16 mode: column tiles 0-3 | 4-6), 64 quads (two terms: two tiles each), 32 octets (three: one each)
+    // 128 pairs of workgroups (bf16 mode: column tiles 0-3 | 4-6); 64 quads in the split modes (two tiles each: 96 / 144 registers of
+    // resident weight fragments per lane; measured at config 2: two terms 13.8 us as quads, 16.0 as 80 triples of three tiles; three terms
+    // 17.2 us as quads, 20.9 as 32 octets of one tile)
     if (terms == 1) hipLaunchKernelGGL((cogmen_project_graph_kernel<1, 4, 2>), dim3(256), dim3(512), 0, (hipStream_t)stream, p);
     else if (terms == 2) hipLaunchKernelGGL((cogmen_project_graph_kernel<2, 2, 4>), dim3(256), dim3(512), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((cogmen_project_graph_kernel<3, 1, 8>), dim3(256), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((cogmen_project_graph_kernel<3, 2, 4>), dim3(256), dim3(512), 0, (hipStream_t)stream, p);
     ERC_LAUNCH_CHECK("cogmen_project_graph");
     return ERC_OK;
 }

@@ -182,7 +182,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("compute", ["f32x2", "f32x3"])
+@pytest.mark.parametrize("compute", ["f32x2", "f32x3", "f32x32"])
 @pytest.mark.parametrize("case", CASES, ids=["tiny", "one-utt", "ragged", "len16", "mid", "d1380"])
 def test_cogmen_split_parity(case, compute, monkeypatch):
     """The whole step in a split mode against the UNROUNDED oracle (= the reference's fp32 arithmetic) at the tolerances of the
@@ -200,7 +200,7 @@ def test_cogmen_split_parity(case, compute, monkeypatch):
     assert res["bn_mean_err"] < 1e-5 and res["bn_var_err"] < 1e-5, res
 
 
-@pytest.mark.parametrize("compute", ["f32x2", "f32x3"])
+@pytest.mark.parametrize("compute", ["f32x2", "f32x3", "f32x32"])
 def test_cogmen_split_config2_shape_parity(compute):
     """BASELINE.json configs[1] shape (B=32, T=110, D=1380, 6 classes) through the split mode's step: north_star's 1e-4."""
     # two terms deviate by ~3e-6 on the logits: with 183 500 ReLU units at N = 1 835, one of them sits within that of its kink in

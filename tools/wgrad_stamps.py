@@ -16,11 +16,12 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--compute", default="bf16", help="bf16 | f32x2 | f32x3")
     a = ap.parse_args()
     from bench import synthetic_batch
     from erc_amd import capi
     import track_mm.cogmen as plugin
-    params = plugin.ParamsType().from_args(["--dataset=iemocap-cogmen-sbert-6", "--modality=atv", "--compute=bf16"])
+    params = plugin.ParamsType().from_args(["--dataset=iemocap-cogmen-sbert-6", "--modality=atv", "--compute=" + a.compute])
     tr = plugin.COGMENTrainer(params, "cuda:0")
     batch = tr.prepare_batch(synthetic_batch(params, a.batch, 110, seed=1))
     for _ in range(3):
@@ -29,9 +30,9 @@ def main():
     tr.train_step(batch)
     rec = capi.stop_recording()
     torch.cuda.synchronize()
-    call = [e for e in rec if e[0] in ("erc_wgrad_bf16", "erc_wgrad_bf16_adam")][0]
+    call = [e for e in rec if e[0] in ("erc_wgrad_bf16", "erc_wgrad_bf16_adam", "erc_wgrad_split", "erc_wgrad_split_adam")][0]
     print(call[0])
-    n_items = call[1][3]
+    n_items = call[1][4 if "split" in call[0] else 3]
     labels = ["first loads issued (A, gather stage, B)", "K loop", "LDS reduce + slab stores issued", "slab drained", "arrival ticket"]
     for item in (0, 1, 2, 3, n_items // 2):
         st = torch.zeros(16, dtype=torch.int64, device="cuda:0")
