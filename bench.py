@@ -15,6 +15,7 @@ One JSON line on rank 0; see DESIGN.md "Measurement" for the roofline and
 cpu_baseline definitions.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -28,7 +29,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFS = 157.3   # v_mfma_f32_16x16x4_f32 / 32x32x2_f32: exact fp32, = the fp32 vector rate (same guide)
 MFMA_BF16_PEAK_TFS = 2500.0  # dense bf16
-PROFILE_ROUND = "r03"        # profiles/<round>_<module>_b<B>_<dtype>_pmc.json: counter summaries of this same command
+PROFILE_ROUND = "r04"        # profiles/<round>_<module>_b<B>_<dtype>_pmc.json: counter summaries of this same command
 
 
 def step_work(module, params, host_batch, features_bf16):
@@ -297,7 +298,32 @@ def main():
                     help="COGMEN: opt-in variant rnn.1(rnn.0(x, padding mask)) -- the encoder is trained (SURVEY.md 8f-4)")
     ap.add_argument("--rehearse_dp", action="store_true",
                     help="diagnostic: run the N>1 step structure (RCCL group, eager exchange + optimizer) on one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL; gloo: --dry_run)")
+    ap.add_argument("--dry_run", action="store_true",
+                    help="launch the ranks, form the process group, count them with one all-reduce and print the line -- no GPU work "
+                         "(the launcher's CPU test: --gpus 2 --backend gloo --dry_run)")
     args = ap.parse_args()
+
+    # ---------------------------------------------------------------- N > 1 without a launcher: start the N ranks ourselves
+    # (the reference gets its ranks from `accelerate launch`, lumo/trainer/trainer.py:62-64,377-384).  The parent never touches
+    # the GPU (torch.cuda.device_count() does not initialise it): it re-runs this file under torch.distributed.run -- one fresh
+    # process per GPU -- forwards their output (rank 0 prints the JSON line) and exits with their return code.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        if not (args.dry_run and args.backend == "gloo"):
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                print("bench.py: --gpus %d but only %d device(s) visible: not running (a 1-rank line would not be the requested "
+                      "measurement)" % (args.gpus, have), file=sys.stderr)
+                sys.exit(2)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -310,10 +336,22 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29573")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        if args.dry_run:
+            dist.init_process_group(args.backend)
+            cnt = torch.ones(1, dtype=torch.float64, device="cuda:%d" % local_rank if args.backend == "nccl" else "cpu")
+            dist.all_reduce(cnt)
+            if rank == 0:
+                print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": int(cnt.item()), "backend": args.backend,
+                                  "requested_gpus": args.gpus}))
+            dist.destroy_process_group()
+            sys.exit(0 if int(cnt.item()) == args.gpus else 3)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world == 1 and args.gpus > 1:
-        print("bench.py: --gpus %d needs torch.distributed.run; running 1 rank" % args.gpus, file=sys.stderr)
+        dist.init_process_group(args.backend, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and not args.rehearse_dp:
+        # (a launcher that started a different number of ranks than --gpus asks for: refuse rather than mislabel the line)
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -406,11 +444,11 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([n_utt], dtype=torch.float64, device=device)
+        cnt = torch.tensor([n_utt, 1.0], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(cnt)
-        total_utt = float(cnt.item())
+        total_utt, rccl_ranks = float(cnt[0].item()), int(cnt[1].item())
     else:
-        total_utt = float(n_utt)
+        total_utt, rccl_ranks = float(n_utt), 1
     stats = trainer.model._last_ws["stats"].cpu().tolist()
 
     # ---------------------------------------------------------------- roofline: dominant kernel (HIP events) + whole step
@@ -425,7 +463,6 @@ def main():
         # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
         # command (tools/collect_profiles.sh -> tools/pmc_summary.py; gfx950 correction: read bytes = 2 x FETCH_SIZE): one
         # summary per kernel of the step, picked by the dominant kernel's name
-        import glob
         for pmc in sorted(glob.glob(os.path.join(REPO, "profiles", tag + "_*_pmc.json"))):
             with open(pmc) as fh:
                 prec = json.load(fh)
@@ -490,33 +527,71 @@ def main():
         multi = {"steps_per_graph": S, "steps": n8, "ms_per_step": 1e3 * el8 / n8, "value": n_utt * n8 / el8, "unit": "utterances/s"}
         del step8
 
-    # ---------------------------------------------------------------- the 1e-4 parity path, timed the same way (rank 0, N=1 only)
+    # ---------------------------------------------------------------- the 1e-4 parity paths, timed the same way (rank 0, N=1 only)
     fp32_path = None
     if rank == 0 and world == 1 and args.module == "cogmen" and args.dtype == "bf16" and not args.no_fp32_path and use_graph \
             and not (args.faithful_dead_encoder or args.chained_encoder):
-        # north_star's tolerance (logits within 1e-4 of the reference's fp32 CPU path) is met by --compute=f32
-        # (tests/test_gpu_cogmen.py::test_cogmen_config2_shape_parity); the headline above is the bf16 compute mode of
-        # BASELINE.json configs[1], whose deviation from the unrounded reference is bounded by
-        # tests/test_gpu_cogmen.py::test_cogmen_bf16_mode_vs_unrounded_fp32_reference_config2.  Same batch, same step, same
-        # HIP-graph replay and the same number of timed steps:
-        p32 = plugin.ParamsType().from_args(["--dataset=" + args.dataset, "--modality=" + args.modality, "--compute=f32"] + extra)
-        p32.train.batch_size = args.batch
-        tr32 = plugin.COGMENTrainer(p32, device)
-        b32 = tr32.prepare_batch(host_batch)
-        step32 = GraphedStep(lambda: tr32.train_step(b32))
-        for _ in range(args.warmup):
-            step32()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step32()
-        torch.cuda.synchronize()
-        el32 = time.perf_counter() - t0
-        fp32_path = {"dtype": "f32", "ms_per_step": 1e3 * el32 / args.steps, "value": n_utt * args.steps / el32,
-                     "unit": "utterances/s", "steps": args.steps, "warmup": args.warmup,
-                     "tolerance": "logits within 1e-4 of the fp32 oracle (tests/test_gpu_cogmen.py::test_cogmen_config2_shape_parity)",
-                     "loss": tr32.model._last_ws["stats"].cpu().tolist()[0]}
-        del step32, tr32, b32
+        # north_star's tolerance (logits within 1e-4 of the reference's fp32 CPU path) is met by the SPLIT compute modes on the
+        # same fused 5-launch step (fp32 data, products on the bf16 matrix cores from operands expanded into bf16 terms:
+        # tests/test_gpu_cogmen_split.py) and by --compute=f32 (exact-fp32 kernels, 15 launches: tests/test_gpu_cogmen.py).  The
+        # headline above is the bf16 compute mode of BASELINE.json configs[1], whose deviation from the unrounded reference is
+        # bounded by tests/test_gpu_cogmen.py::test_cogmen_bf16_mode_vs_unrounded_fp32_reference_config2.  Same batch, same step,
+        # same HIP-graph replay and the same number of timed steps:
+        def timed_path(compute, with_roofline):
+            pp = plugin.ParamsType().from_args(["--dataset=" + args.dataset, "--modality=" + args.modality, "--compute=" + compute] + extra)
+            pp.train.batch_size = args.batch
+            tr = plugin.COGMENTrainer(pp, device)
+            bb = tr.prepare_batch(host_batch)
+            st = GraphedStep(lambda: tr.train_step(bb))
+            for _ in range(args.warmup):
+                st()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                st()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out = {"dtype": compute, "ms_per_step": 1e3 * el / args.steps, "value": n_utt * args.steps / el, "unit": "utterances/s",
+                   "steps": args.steps, "warmup": args.warmup, "loss": tr.model._last_ws["stats"].cpu().tolist()[0],
+                   "launches_per_step": None}
+            if with_roofline:
+                capi.start_recording()
+                tr.train_step(bb)
+                out["launches_per_step"] = len([e for e in capi.stop_recording() if not e[0].endswith(("_ok", "_floats", "_doubles"))])
+                d = dominant_kernel("cogmen", pp, host_batch, bb, tr, args.kernel_reps)
+                if d is not None:
+                    tfs, gbs = d["flops"] / d["avg_us"] * 1e-6, d["bytes"] / d["avg_us"] * 1e-3
+                    hbm_side = d["flops"] / d["bytes"] < d["peak"] * 1e12 / (HBM_PEAK_GBS * 1e9)
+                    ptag = "%s_cogmen_b%d_%s" % (PROFILE_ROUND, args.batch, compute)
+                    tr_b, tr_src = None, None
+                    for pmc in sorted(glob.glob(os.path.join(REPO, "profiles", ptag + "_*_pmc.json"))):
+                        with open(pmc) as fh:
+                            prec = json.load(fh)
+                        if prec.get("kernel_substring", "") and prec["kernel_substring"] in d["kernel"] and prec.get("hbm_bytes_per_launch"):
+                            tr_b, tr_src = prec["hbm_bytes_per_launch"], os.path.relpath(pmc, REPO)
+                    out["roofline"] = {"bound": "hbm" if hbm_side else "mfma", "kernel": d["kernel"],
+                                       "achieved": gbs if hbm_side else tfs, "peak": HBM_PEAK_GBS if hbm_side else d["peak"],
+                                       "unit": "GB/s" if hbm_side else "TFLOP/s", "frac": gbs / HBM_PEAK_GBS if hbm_side else tfs / d["peak"],
+                                       "traffic": tr_b, "traffic_source": tr_src,
+                                       "traffic_over_algorithmic": tr_b / d["bytes"] if tr_b else None, "peak_note": d["peak_note"],
+                                       "algorithmic_flops_per_launch": d["flops"], "algorithmic_bytes_per_launch": d["bytes"],
+                                       "avg_us": d["avg_us"], "share_of_step": d["share_us"] / (out["ms_per_step"] * 1e3)}
+            del st, tr, bb
+            return out
+        fp32_path = timed_path("f32x32", True)
+        fp32_path["tolerance"] = ("logits within 1e-4, every gradient within 2e-3 of its tensor's scale of the UNROUNDED fp32 oracle "
+                                  "(tests/test_gpu_cogmen_split.py::test_cogmen_split_config2_shape_parity[f32x32], "
+                                  "test_cogmen_split_parity[*-f32x32]; measured at this shape: 2.4e-7 / 4.3e-5)")
+        fp32_path["what"] = ("fp32 feature block, fp32 activations and gradients in memory; the fused 5-launch step of the bf16 mode with "
+                             "every dense product on v_mfma_f32_16x16x32_bf16 from operands expanded into bf16 terms: three terms in the "
+                             "forward products (projection, RGCN, QKVS), two in the backward ones (dH1, dH0, weight gradients)")
+        fp32_path["other_1e-4_paths"] = {
+            "f32x2": dict(timed_path("f32x2", False), note="two terms everywhere: logits 3.6e-6; gradients 6e-5 once the oracle's backward "
+                          "uses the path's own ReLU pattern (a unit within 1e-6 of its kink sits on the other side in about every other "
+                          "batch of this size and moves a gradient entry by 3e-3 of its tensor's scale: test_cogmen_split_config2_shape_parity[f32x2])"),
+            "f32x3": dict(timed_path("f32x3", False), note="three terms everywhere: logits 2.4e-7, gradients 7.8e-6"),
+            "f32": dict(timed_path("f32", False), note="exact-fp32 kernels (v_mfma_f32_16x16x4_f32), unfused 15-launch step: the round-1..3 parity path"),
+        }
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     cpu = None
@@ -545,7 +620,7 @@ def main():
         line = {
             "metric": "utterances/sec training step, COGMEN IEMOCAP-6 atv" if args.module == "cogmen" else
             "utterances/sec training step, %s %s %s" % (args.module, args.dataset, args.modality), "value": value,
-            "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "utterances/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("COGMEN iemocap-cogmen-6 atv train step (BASELINE.json configs[1]): "

@@ -69,6 +69,15 @@ def state_dict(trainer):
 
 
 def save(trainer, path):
+    """Refuses after a bounded-wait timeout (FlatParams.check_health): the fused optimizer launch / the peer-to-peer exchange
+    give up per gradient tile, so the parameters may be a mix of updated and skipped tiles (ranks may have diverged) -- not a
+    state to resume from."""
+    flat = getattr(trainer.model, "flat", None)
+    if flat is not None:
+        if getattr(flat, "tainted", False) or int(flat.events[0].item()) or int(flat.health[0].item()):
+            from .capi import ErcGraftError
+            raise ErcGraftError("checkpoint.save: a bounded wait between cooperating workgroups timed out during this run; the "
+                                "parameters may be partially updated -- not saving (restart from the last good checkpoint)")
     torch.save(state_dict(trainer), path)
     return path
 

@@ -390,8 +390,9 @@ class COGMENModule(nn.Module):
     def check_cluster(self):
         """Raise if a bounded wait between cooperating workgroups timed out since the last call: the splits of a gradient tile
         in the weight-gradient launch with the optimizer inside (csrc/wgrad_bf16.hip), or the peer-to-peer gradient exchange
-        (csrc/optim.hip).  The affected steps' updates were skipped on the device; trainer.run calls this once per epoch."""
-        self.flat.check_health("COGMEN weight-gradient / optimizer launch")
+        (csrc/optim.hip).  These launches give up per gradient tile / chunk: the affected steps' updates are PARTIAL (and ranks may
+        have diverged) -- the run is to be treated as failed; trainer.run calls this once per epoch."""
+        self.flat.check_health("COGMEN weight-gradient / optimizer launch", partial=True)
 
     def forward(self, input_tensor, speaker_tensor, text_length, *args, label=None, **kwargs):
         if self.flat is None:

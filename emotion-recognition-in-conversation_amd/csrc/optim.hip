@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             while ((val >> 1) - ep < 0) {
                 if (++spins > p2p.spin_limit) {
                     __hip_atomic_store(p2p.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    val = 2 * ep + 1;      // give up: this rank skips (its peers time out on their own or see the bit next step)
+                    val = 2 * ep + 1;      // give up: THIS CHUNK of this rank skips.  The rank's other chunks, and the peers' copies of this
+                                           // chunk, may still update: replicas can diverge -- a timeout is fatal for the run
+                                           // (FlatParams.check_health raises, checkpoint.save refuses); it is NOT a clean skipped step
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
@@ -375,9 +377,14 @@ extern "C" int erc_p2p_alloc(int64_t bytes, void** ptr, void* handle64) {
     ERC_REQUIRE(bytes > 0 && ptr && handle64, "p2p_alloc: bad arguments");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     void* q = nullptr;
+    // UNCACHED (fine-grained) memory or nothing: the exchange relies on peers seeing sc0 sc1 stores made while the kernel runs;
+    // plain coarse-grained hipMalloc memory does not promise that across devices (stale sums, bounded-wait timeouts).  The
+    // caller falls back to the RCCL all-reduce when this fails (engine.FusedAdam.enable_p2p).
     if (hipExtMallocWithFlags(&q, (size_t)bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
-        ERC_REQUIRE(hipMalloc(&q, (size_t)bytes) == hipSuccess, "p2p_alloc: %lld bytes refused", (long long)bytes);
+        erc_set_error("p2p_alloc: the runtime refused %lld bytes of uncached device memory (no coarse-grained fallback: peers must see "
+                      "stores of a running kernel)", (long long)bytes);
+        return ERC_E_ARG;
     }
     ERC_REQUIRE(hipMemset(q, 0, (size_t)bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess, "p2p_alloc: memset failed");
     hipIpcMemHandle_t h;

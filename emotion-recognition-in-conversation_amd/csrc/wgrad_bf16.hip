@@ -623,7 +623,9 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
             if (tid == 0) {
                 int ok = 1, spins = 0;
                 while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - S * seq < 0) {
-                    if (++spins >= ad.spin_limit) {      // a split of this tile never arrived: this step's gradients are invalid
+                    if (++spins >= ad.spin_limit) {      // a split of this tile never arrived: THIS TILE is left un-updated (the other tiles of
+                                                         // the launch update, the step count advances): a partial update, fatal for the run --
+                                                         // FlatParams.check_health raises at the epoch's end, checkpoint.save refuses
                         __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok = 0;
                         break;

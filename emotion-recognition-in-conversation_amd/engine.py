@@ -110,17 +110,28 @@ class FlatParams:
         cleared (one launch, no host synchronisation)."""
         capi.health_roll(self.health, self.events)
 
-    def check_health(self, what):
+    def check_health(self, what, partial=False):
         """Host-side report (one device->host copy; the trainer calls it once per epoch): raises if any step since the
-        last call was skipped on the device, or if the word is raised right now (evaluation pass)."""
+        last call was skipped on the device, or if the word is raised right now (evaluation pass).
+        ``partial``: the module's timeouts come from the optimizer INSIDE the weight-gradient launch or from the peer-to-peer
+        exchange, which give up per gradient tile / chunk -- the parameters may then be a mix of updated and skipped tiles:
+        the buffer is marked ``tainted`` (checkpoint.save refuses, the planner keeps the two-launch form from here on)."""
         ev, live = int(self.events[0].item()), int(self.health[0].item())
         if ev or live:
             self.events.zero_()
             self.health.zero_()
+            n = ev + (1 if live else 0)
+            if partial:
+                self.tainted = True
+                raise capi.ErcGraftError("%s: a bounded wait between cooperating workgroups timed out in %d step(s) (not all of "
+                                         "them were resident at once, e.g. another process holds CUs).  This launch gives up per "
+                                         "gradient tile / chunk: tiles whose wait timed out kept their old parameters while the "
+                                         "others were updated%s.  Treat the run as failed and restart from the last checkpoint "
+                                         "(ERC_FUSE_ADAM=0 / ERC_DP_P2P=0 select the optimizer launch that skips a step as a whole)."
+                                         % (what, n, ", and ranks may have diverged" if _world_size() > 1 else ""))
             raise capi.ErcGraftError("%s: a bounded wait between cooperating workgroups timed out (not all of them were "
                                      "resident at once, e.g. another process holds CUs); %d optimizer step(s) were skipped "
-                                     "on the device%s" % (what, ev + (1 if live else 0),
-                                                          " on every rank" if _world_size() > 1 else ""))
+                                     "on the device%s" % (what, n, " on every rank" if _world_size() > 1 else ""))
 
     def g(self, name):
         return self.view(self.grad, name)
@@ -260,8 +271,10 @@ class GemmPlanner:
         if not self.deferred16:
             return
         opt = self.fused_adam
+        # (after a timeout event of the fused launch -- FlatParams.check_health sets `tainted` -- the planner keeps the two-launch
+        #  form, whose optimizer skips a step as a whole, for the rest of the run)
         fuse = opt is not None and opt.clip_norm <= 0 and opt.shadow is None and getattr(opt.flat, "p2p", None) is None and \
-            _world_size() == 1 and opt.flat.grad is self.grad
+            _world_size() == 1 and opt.flat.grad is self.grad and not getattr(opt.flat, "tainted", False)
         import ctypes
         import struct
         key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, ct, g.data_ptr() if g is not None else 0,
@@ -281,7 +294,8 @@ class GemmPlanner:
             # one 4-wavefront workgroup per CU (428 registers per lane): while every item of the launch is resident at once
             # (<= 256), as many splits as that allows; beyond, ~ERC_W2_ROWS k per item
             rows = int(os.environ.get("ERC_W2_ROWS", 1024))
-            s_max = max(1, min(32, 256 // tiles, -(-K // 64)))
+            n_cu_all = min(256, torch.cuda.get_device_properties(self.device).multi_processor_count) if torch.cuda.is_available() else 256
+            s_max = max(1, min(32, n_cu_all // tiles, -(-K // 64)))
             # a wavefront works in groups of 8 k-steps (32 k): among the split counts that fit, the smallest one with the
             # fewest groups per wavefront (K = 1982: 4 splits of 31 steps per wavefront, not 5 of 25 -- both are 4 groups)
             groups = lambda sp: -(-(-(-(-(-K // 4) // sp) // 4)) // 8)
@@ -314,7 +328,10 @@ class GemmPlanner:
                 n_tiles += tn
             # the fused optimizer needs every work item resident at once (its splits wait for each other), split counts
             # that divide a thread's 8 quads, and gradients made of whole aligned quads
-            fused = fuse and items + len(self.ranges16) <= 256 and sps <= {1, 2, 4, 8} and whole_quads
+            # (one 4-wavefront workgroup per CU: the device's CU count, not a constant, bounds what is resident; the waits also
+            #  rely on workgroups being dispatched in order, and are bounded)
+            n_cu = min(256, torch.cuda.get_device_properties(self.device).multi_processor_count) if torch.cuda.is_available() else 256
+            fused = fuse and items + len(self.ranges16) <= n_cu and sps <= {1, 2, 4, 8} and whole_quads
             if fused:     # finished gradient ranges (kind 1): one work item each
                 for r in self.ranges16:
                     raw.append(struct.pack("<QQQQQQQ14i", 0, 0, r.data_ptr(), 0, 0, 0, 0, 0, 0, 0, r.numel(), 0, 0, 0, 0, 1, 1,
@@ -503,7 +520,12 @@ class FusedAdam:
         if os.environ.get("ERC_DP_P2P", "0") != "1" or not (dist.is_available() and dist.is_initialized()) or \
                 dist.get_world_size(group) < 2 or self.clip_norm > 0 or self.flat.numel > P2PExchange.MAX_PARAMS:
             return False
-        self.flat.p2p = P2PExchange(self.flat, group)
+        try:
+            self.flat.p2p = P2PExchange(self.flat, group)
+        except P2PUnavailable as exc:      # (raised on every rank alike: the decision rides an all_gather)
+            import sys
+            print("ERC_DP_P2P=1: %s -- keeping the RCCL all-reduce" % exc, file=sys.stderr)
+            return False
         self.skip_flag = self.flat.health
         return True
 
@@ -527,8 +549,13 @@ class FusedAdam:
                        *(self.shadow if self.shadow is not None else (None, 0, 0)), skip_flag=self.skip_flag)
 
 
+class P2PUnavailable(RuntimeError):
+    """the fused gradient exchange cannot be set up on this node (every rank raises it together)"""
+
+
 class P2PExchange:
-    """ERC_DP_P2P=1: the gradient exchange of a data-parallel step fused into the optimizer launch (csrc/optim.hip, P2PArgs;
+    """ERC_DP_P2P=1 (OFF by default; UNVERIFIED ACROSS DEVICES: it has only ever run as two processes on one GPU,
+    tests/test_gpu_p2p.py -- the RCCL all-reduce stays the default until a multi-GPU run exists): the gradient exchange of a data-parallel step fused into the optimizer launch (csrc/optim.hip, P2PArgs;
     SURVEY.md 8e).  Construction is collective: every rank allocates its publish buffer and flag array, the 64-byte IPC
     handles travel through ``torch.distributed.all_gather_object`` (any backend), peers are mapped.  ``FusedAdam.step``
     then calls erc_adam_step_p2p instead of all-reduce + erc_adam_step: no RCCL call, no extra launch."""
@@ -543,10 +570,19 @@ class P2PExchange:
             raise capi.ErcGraftError("P2P gradient exchange: world <= 8 and <= %d parameters (this module: %d)" % (
                 self.MAX_PARAMS, flat.numel))
         self.n_pad = flat.numel
-        self._mine = [capi.p2p_alloc(2 * self.n_pad * 4), capi.p2p_alloc(self.world * 512 * 4)]
+        self._mine, self._peers = [], []
+        try:      # uncached (fine-grained) device memory or nothing: capi.p2p_alloc has no coarse-grained fallback
+            self._mine = [capi.p2p_alloc(2 * self.n_pad * 4), capi.p2p_alloc(self.world * 512 * 4)]
+            mine = (self._mine[0][1], self._mine[1][1])
+        except capi.ErcGraftError as exc:
+            mine = None
+            self.alloc_error = str(exc)
         handles = [None] * self.world
-        dist.all_gather_object(handles, (self._mine[0][1], self._mine[1][1]), group=group)
-        self._peers = []
+        dist.all_gather_object(handles, mine, group=group)
+        if any(h is None for h in handles):      # collective decision: one rank without the memory -> every rank keeps RCCL
+            self.close()
+            raise P2PUnavailable("rank(s) %s could not allocate uncached peer-visible memory" % [r for r, h in enumerate(handles) if h is None])
+        self.allocation = "hipDeviceMallocUncached"
         x = capi.ErcP2P()
         x.world, x.rank, x.spin_limit, x.n_pad = self.world, self.rank, int(os.environ.get("ERC_P2P_SPIN", 0)), self.n_pad
         for r in range(self.world):

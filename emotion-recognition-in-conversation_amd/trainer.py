@@ -214,17 +214,25 @@ class StepGraphs:
     def precapture(self, probe):
         """Data parallel: capture every capacity bucket NOW, in the same order on every rank.  A captured step contains the
         gradient all-reduce; a rank that captured lazily (whenever ITS batch first hit a bucket) would record a collective its
-        peers execute.  Each bucket runs one warm-up step on synthetic lengths with the health word raised -- every kernel
-        runs (workspaces, weight-gradient tables, the collective), the optimizer skips: parameters, moments, step count and
-        dropout offset stay as they are; BatchNorm's running statistics are put back -- and is then captured."""
+        peers execute.  Each bucket runs one warm-up step on synthetic lengths -- every kernel runs (workspaces, weight-gradient
+        tables, the collective) -- and is then captured.  The warm-ups are REAL steps on made-up batches (zero features, label 0;
+        the same on every rank): everything they change -- parameters, Adam moments, the optimizer's step count and dropout
+        offset, the bf16 weight shadows, BatchNorm's running statistics, the health word -- is snapshotted before and put back
+        afterwards, bit for bit, so training starts from the state it was given.  (A raised health word does not suppress the
+        update: the step's first launch rolls the word, erc_cogmen_fwd_tile.)"""
         tr = self.trainer
         flat, model = tr.model.flat, tr.model
+        opt = getattr(tr, "optim", None)
         saved = {k: v.clone() for k, v in model.state_dict().items() if "running_" in k or "num_batches" in k}
+        snap = [(t, t.clone()) for t in (getattr(flat, n, None) for n in ("data", "exp_avg", "exp_avg_sq", "grad_full")) if t is not None]
+        if opt is not None and getattr(opt, "state", None) is not None:
+            snap.append((opt.state, opt.state.clone()))
+        if getattr(flat, "p2p", None) is not None:
+            snap.append((flat.p2p.epoch, flat.p2p.epoch.clone()))
         for key, make, fill, synth in tr.all_capacity_buckets(probe):
             static = make()
             synth(static)
             ent = self.cache[key] = [static, None, None, None, fill, True, 1]
-            flat.health.fill_(capi.HEALTH_RAISED)
             self._run(ent, eager=True)
             model.dynamic_n = True
             try:
@@ -233,12 +241,17 @@ class StepGraphs:
                 model.dynamic_n = False
             ent[1], ent[2], ent[3] = g, out, getattr(model, "_last_ws", None)
             self.captures += 1
-        flat.health.zero_()
-        flat.events.zero_()
+        self._sync()
         with torch.no_grad():
+            for t, keep in snap:
+                t.copy_(keep)
             sd = model.state_dict()
             for k, v in saved.items():
                 sd[k].copy_(v)
+        flat.health.zero_()
+        flat.events.zero_()
+        if getattr(model, "shadows", None) is not None:
+            model.refresh_shadows()          # the bf16 copies follow the restored parameters
         self.maxsize = max(self.maxsize, len(self.cache) + 2)
 
     def step(self, batch, key=None, resident=False):

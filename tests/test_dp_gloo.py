@@ -217,3 +217,25 @@ def test_stepgraphs_data_parallel_control_flow():
         p.join(60)
     # 3 warm-up collectives during precapture, 6 step collectives, 3 graphs, 5 replays + 1 eager (the batch outside every bucket)
     assert res == [(0, 3, 6, 3, 5, 1), (1, 3, 6, 3, 5, 1)]
+
+
+def test_bench_launches_its_own_ranks():
+    """`bench.py --gpus N` without a launcher starts N ranks itself (torch.distributed.run children; the parent touches no
+    GPU): under --backend gloo --dry_run the line reports 2 ranks counted by an all-reduce.  With fewer visible devices than
+    N (none in this container) the real run refuses with a non-zero return code instead of printing a 1-rank line."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry_run"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["dry_run"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        res = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                             timeout=600, env=env)
+        assert res.returncode == 2 and "only" in res.stderr and not res.stdout.strip()

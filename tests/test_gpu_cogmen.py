@@ -543,13 +543,15 @@ def test_optimizer_fused_into_the_weight_gradient_launch_equals_the_separate_lau
     assert int(a[5][0]) == 4 and bool((a[6] == 4).all())          # 4 steps; every private step copy agrees
 
 
-def test_fused_optimizer_timeout_fails_the_step_and_the_next_step_recovers():
+def test_fused_optimizer_timeout_is_reported_as_a_partial_update_and_the_run_falls_back():
     """The weight-gradient launch with the optimizer inside waits (bounded) for the splits of a tile.  With every tile's arrival
     counter set back by one (no tile can ever complete) and a small bound (erc_wgrad_bf16_set_spin_limit) every wait times out:
-    the health word is raised, `check_cluster` reports the skipped step; the NEXT step's first launch (erc_cogmen_fwd_tile: the
-    health roll folded in) counts the event and clears the word, and a step with the counters and the bound restored equals the
-    same step of a trainer that never saw the timeout."""
-    from erc_amd import capi
+    the health word is raised and `check_cluster` reports a PARTIAL update (this launch gives up per tile: what does not wait --
+    BatchNorm's scale / shift records, the step count -- was updated, the tiles were not), marks the parameter buffer tainted
+    and checkpoint.save refuses.  From then on the planner keeps the two-launch form (its optimizer skips a step as a whole); the
+    NEXT step's first launch (erc_cogmen_fwd_tile: the health roll folded in) counts the event and clears the word, and -- from
+    a restored state -- equals the same step of a trainer that never saw the timeout."""
+    from erc_amd import capi, checkpoint
     from erc_amd.cogmen import COGMENTrainer
     from erc_amd.params import ERCParams
 
@@ -576,11 +578,14 @@ def test_fused_optimizer_timeout_fails_the_step_and_the_next_step_recovers():
     finally:
         capi.wgrad_bf16_set_spin_limit(0)
         ws["w16_counters"][:tiles] += 1
-    assert int(tr.model.flat.health[0].item()) == capi.HEALTH_RAISED
-    with pytest.raises(capi.ErcGraftError, match="skipped"):
-        tr.model.check_cluster()                                              # reports and clears
-    # back to the state after step 0 (the timed-out launch updated what does not wait: BatchNorm's scale / shift records)
     f, g = tr.model.flat, ref.model.flat
+    assert int(f.health[0].item()) == capi.HEALTH_RAISED
+    with pytest.raises(capi.ErcGraftError, match="gives up per gradient tile"):
+        tr.model.check_cluster()                                              # reports, clears, taints
+    assert f.tainted
+    with pytest.raises(capi.ErcGraftError, match="not saving"):
+        checkpoint.save(tr, "/tmp/never_written.pt")
+    # back to the state after step 0, as a restart from a checkpoint would (the timed-out launch updated what does not wait)
     f.data.copy_(g.data), f.exp_avg.copy_(g.exp_avg), f.exp_avg_sq.copy_(g.exp_avg_sq)
     tr.optim.state.copy_(ref.optim.state)
     tr.model.refresh_shadows()
@@ -588,8 +593,52 @@ def test_fused_optimizer_timeout_fails_the_step_and_the_next_step_recovers():
     f.health.fill_(capi.HEALTH_RAISED)                   # as the timed-out step left it
     s1, s0 = tr.train_step(b).cpu(), ref.train_step(rb).cpu()
     torch.cuda.synchronize()
+    assert not tr.model._last_ws["planner"].adam_fused       # the tainted run keeps the two-launch form
     assert int(f.events[0].item()) == 1 and int(f.health[0].item()) == 0
     assert torch.equal(s1[:3], s0[:3]) and torch.equal(f.data, g.data)
-    with pytest.raises(capi.ErcGraftError, match="skipped"):
+    with pytest.raises(capi.ErcGraftError, match="timed out"):
         tr.model.check_cluster()
     ref.model.check_cluster()                            # nothing to report
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f32x32"])
+def test_precapture_leaves_the_training_state_untouched(compute):
+    """trainer.StepGraphs.precapture (data parallel: every capacity bucket captured up front) runs one REAL warm-up step per
+    bucket on a made-up batch.  Whatever those steps change must be back afterwards, bit for bit: parameters, both Adam
+    moments, the optimizer's step count / dropout offset / per-workgroup step copies, the bf16 weight shadows, BatchNorm's
+    running statistics, the health word and its event counter.  (Round 3 relied on a raised health word to make the optimizer
+    skip the warm-ups; the step's first launch rolls that word, so up to 32 Adam steps on zero features ran silently.)"""
+    import types
+    import track_mm.cogmen as plugin
+    from erc_amd.trainer import StepGraphs
+    params = plugin.ParamsType().from_args(["--dataset=iemocap-cogmen-4", "--modality=atv", "--compute=" + compute])
+    params.train.batch_size = 8
+    tr = plugin.COGMENTrainer(params, "cuda:0")
+    tr.t_cap = 70                            # buckets of 256 and 512 nodes
+    host = cogmen_case(B=8, min_len=20, max_len=40, dims=params.dims(), seed=2, n_classes=params.n_classes)["batch"]
+    batch = tr.prepare_batch(host)
+    for _ in range(3):                       # a state worth protecting: non-zero moments, step count 3
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    fl, opt, bn = tr.model.flat, tr.optim, tr.model.gcn.bn
+    before = [t.clone() for t in (fl.data, fl.exp_avg, fl.exp_avg_sq, opt.state, tr.model.shadows.buf, bn.running_mean, bn.running_var)]
+    graphs = StepGraphs(tr)
+    graphs.precapture(batch)
+    torch.cuda.synchronize()
+    assert graphs.captures == 2
+    after = (fl.data, fl.exp_avg, fl.exp_avg_sq, opt.state, tr.model.shadows.buf, bn.running_mean, bn.running_var)
+    for name, a, b in zip(("parameters", "exp_avg", "exp_avg_sq", "optimizer state", "shadows", "running_mean", "running_var"), before, after):
+        assert torch.equal(a, b), name
+    assert int(fl.health[0]) == 0 and int(fl.events[0]) == 0
+    # and the captured graphs train: one replayed step equals the same step of a trainer that never precaptured
+    ref = plugin.COGMENTrainer(params, "cuda:0")
+    ref.t_cap = 70
+    for _ in range(3):
+        ref.train_step(batch)
+    graphs.lazy = False
+    s1 = graphs.step(batch).clone()
+    s2 = ref.train_step(batch)
+    torch.cuda.synchronize()
+    assert graphs.replays == 1
+    # (the bucket's launches are sized for its capacity: other split counts than the exact-shape step, sums in another order)
+    assert float((fl.data - ref.model.flat.data).abs().max()) < 2e-6 and torch.allclose(s1[:3], s2[:3], rtol=1e-5, atol=1e-6)

@@ -181,7 +181,9 @@ def test_dagerc_train_step_clip_adamw():
         assert float((tr.model.flat.w(n).cpu() - refp[n].detach()).abs().max()) < 2e-4, n
 
 
-@pytest.mark.parametrize("B,lens,dims,S,C", [(4, (5, 40), dict(a=100, t=100, v=512), 2, 6)])
+@pytest.mark.parametrize("B,lens,dims,S,C", [(4, (5, 40), dict(a=100, t=100, v=512), 2, 6),
+                                             # the BENCHED shape (bench.py --module dagerc: BASELINE.json configs[3]): B = 16, T = 110, D = 712
+                                             (16, (20, 110), dict(a=100, t=100, v=512), 2, 6)], ids=["b4", "benched-b16-t110"])
 def test_dagerc_bf16_feature_mode_vs_rounded_oracle(B, lens, dims, S, C):
     """``--compute=bf16`` (what bench.py --module dagerc --dtype bf16 runs): the feature block is stored in bf16; the two
     weights that multiply it (fc1.weight, the raw-feature columns of out_mlp.0.weight) are rounded to bf16 while staged.

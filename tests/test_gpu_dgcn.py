@@ -364,8 +364,10 @@ MELD = dict(a=300, t=600, v=342)      # meld-mmgcn-7 (mmbase.py:80-88)
     # context wider than a wavefront has lanes: in / out degrees up to 66 (window loops of the graph kernels take a second pass)
     dict(B=3, lens=(80, 110), dims=dict(a=10, t=14, v=12), S=2, C=6, seed=22, weights=True, context=(40, 25)),
     dict(B=3, lens=(80, 110), dims=dict(a=10, t=14, v=12), S=9, C=7, seed=23, weights=False, context=(40, 25)),
+    # the BENCHED shape (bench.py --module dgcn: BASELINE.json configs[4]): B = 32 dialogues, lengths 1-33, MELD dims, atv
+    dict(B=32, lens=(1, 33), dims=MELD, S=9, C=7, seed=31, weights=False),
 ], ids=["tiny", "meld-1242", "iemocap-712", "meld-a-300", "meld-t-600", "meld-v-342", "meld-at-900", "wide-context-s2",
-        "wide-context-s9"])
+        "wide-context-s9", "meld-benched-b32"])
 def test_dgcn_module_parity_vs_oracle(case):
     from oracle.dgcn import IEMOCAP6_WEIGHTS
     modality = case.get("modality", "atv")
@@ -410,16 +412,16 @@ def test_dgcn_train_steps_with_dropout_run():
     assert all(math.isfinite(l) for l in losses) and losses[-1] < losses[0] + 0.5
 
 
-@pytest.mark.parametrize("modality", ["atv", "a", "v"])
-def test_dgcn_bf16_feature_mode_vs_rounded_oracle(modality):
+@pytest.mark.parametrize("modality,B", [("atv", 6), ("a", 6), ("v", 6), ("atv", 32)], ids=["atv", "a", "v", "atv-benched-b32"])
+def test_dgcn_bf16_feature_mode_vs_rounded_oracle(modality, B):
     """``--compute=bf16`` (what bench.py --module dgcn --dtype bf16 runs): the feature block is stored in bf16 and the
     layer-0 input weights of the BiLSTM are rounded to bf16 while they are staged.  The oracle is fed the SAME rounded
     operands, so what is left is accumulation order plus the bf16 rounding of the gate gradients inside the
     weight_ih_l0 weight-gradient product (8 significant bits): logits within 1e-3, gradients within 2 % of their scale
     (weight_ih_l0 itself: 3 %).  Tolerances stated here are those of the MODE, not of fp32 parity (1e-4, test above)."""
     D = sum(MELD[m] for m in modality)
-    case = dict(B=6, lens=(1, 33), dims=MELD, S=9, C=7, seed=21, D=D)
-    batch = make_batch(6, MELD, n_speakers=9, n_classes=7, min_len=1, max_len=33, seed=21, force_max=True, modality=modality)
+    case = dict(B=B, lens=(1, 33), dims=MELD, S=9, C=7, seed=21, D=D)      # (B = 32: the shape bench.py --module dgcn --dtype bf16 runs)
+    batch = make_batch(B, MELD, n_speakers=9, n_classes=7, min_len=1, max_len=33, seed=21, force_max=True, modality=modality)
     ref, mine = _pair(case, compute="bf16")
     with torch.no_grad():
         for n in ("weight_ih_l0", "weight_ih_l0_reverse"):
