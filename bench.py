@@ -394,8 +394,9 @@ def main():
         # behind the last weight-gradient kernel); ERC_DP_EAGER=1 keeps the exchange and the optimizer outside the graph
         # (the round-1 structure) for comparison
         trainer.model.train()
-        if hasattr(trainer.model, "fused_optim"):
-            trainer.model.fused_optim = None      # N > 1 structure: the optimizer is its own launch behind the exchange
+        if hasattr(trainer.model, "fused_optim") and getattr(trainer.model.flat, "p2p", None) is None:
+            trainer.model.fused_optim = None      # N > 1 structure: the optimizer is its own launch behind the RCCL exchange
+        # (ERC_DP_P2P=1: the exchange happens inside the weight-gradient + optimizer launch -- the step stays 5 launches)
         cw = getattr(trainer, "class_weight", None)
         dead_encoder = getattr(trainer, "encoder", None)            # --faithful_dead_encoder
         trained_encoder = getattr(trainer.model, "enc_train", None)  # --chained_encoder
@@ -409,6 +410,9 @@ def main():
             return trainer.model.loss_and_grads(batch)
 
         def exchange_and_update():
+            pl_ = trainer.model._last_ws.get("planner") if isinstance(getattr(trainer.model, "_last_ws", None), dict) else None
+            if pl_ is not None and getattr(pl_, "adam_fused", False):
+                return                                # the weight-gradient launch exchanged the gradients and applied the update
             trainer.optim.step(grad_scale=all_reduce_grads(trainer.model.flat, always=args.rehearse_dp))
             if trained_encoder is not None:
                 trained_encoder.refresh_shadows()      # bf16 copies of the encoder weights follow the fp32 masters

@@ -58,6 +58,8 @@ _SIGS = {
     "erc_wgrad_split": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_split_adam": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp,
                                        _vp, _i64, _vp, _vp, _vp]),
+    "erc_wgrad_adam_p2p": (C.c_int, [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _vp,
+                                     _vp, _i64, _vp, _vp, _vp]),
     "erc_wgrad_bf16_set_spin_limit": (C.c_int, [_i]),
     "erc_wgrad_bf16_wide": (C.c_int, [_vp, _i, _vp, _i, _vp, _vp, _vp]),
     "erc_wgrad_bf16_slab_floats": (C.c_int64, []),
@@ -1010,9 +1012,16 @@ def wgrad_bf16(table, n_desc, item_base, n_items, slabs, counters, terms=1):
 
 
 def wgrad_bf16_adam(table, n_desc, item_base, n_items, slabs, counters, n_tiles, p, g, m, v, n, lr, b1, b2, eps, wd, decoupled,
-                    grad_scale, state, shadow_table, health, terms=1):
-    """erc_wgrad_bf16 (terms > 1: erc_wgrad_split) with the optimizer fused in (ercgraft.h)"""
+                    grad_scale, state, shadow_table, health, terms=1, p2p_desc=None):
+    """erc_wgrad_bf16 (terms > 1: erc_wgrad_split) with the optimizer fused in (ercgraft.h); p2p_desc (an ErcP2P): data
+    parallel with the gradient exchange inside the launch (erc_wgrad_adam_p2p; health = the descriptor's health word)"""
     st = shadow_table
+    if p2p_desc is not None:
+        _check(lib().erc_wgrad_adam_p2p(terms, ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), int(n_tiles), ptr(p),
+                                        ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale, ptr(state),
+                                        ptr(st.buf) if st is not None else None, st.buf.numel() if st is not None else 0,
+                                        st.tab_ptr if st is not None else None, C.addressof(p2p_desc), stream()), "erc_wgrad_adam_p2p")
+        return
     args = (ptr(table), n_desc, item_base, n_items, ptr(slabs), ptr(counters), int(n_tiles), ptr(p), ptr(g),
             ptr(m), ptr(v), n, lr, b1, b2, eps, wd, int(decoupled), grad_scale, ptr(state),
             ptr(st.buf) if st is not None else None, st.buf.numel() if st is not None else 0,

@@ -315,7 +315,8 @@ class COGMENModule(nn.Module):
         project_graph = (self.fuse_project_graph and (x.dtype == torch.float32 if split else x_bf16) and self.w1_shadow is not None
                          and self.enc_train is None
                          and speaker_tensor.dim() == (1 if desc is not None else 2) and x.is_contiguous()
-                         and N <= self.BN_FUSED_MAX_N      # beyond: many row groups per workgroup, the separate launches win (B = 512: 45 vs 54 us)
+                         and (N <= self.BN_FUSED_MAX_N or split)      # beyond: many row groups per workgroup, the separate bf16 launches win (B = 512: 45 vs 54 us;
+                                                                        #  split modes: 131 us fused vs 235 + 10 on the exact-fp32 kernels)
                          and capi.cogmen_project_graph_ok(D, F, B, D, D))
         if desc is not None and not (project_graph and self.dynamic_n):
             raise capi.ErcGraftError("COGMEN resident batches need the fused bf16 training path in capacity mode")

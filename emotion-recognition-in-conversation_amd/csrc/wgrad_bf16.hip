@@ -76,6 +76,15 @@ struct W2Adam {
     int32_t* seq;          // [512] private launch sequence numbers
     int32_t* health;       // raised when the wait for a tile's splits times out
     ShadowTab tab;
+    // data parallel, ERC_DP_P2P=1 (engine.P2PExchange; csrc/optim.hip P2PArgs): the gradient exchange INSIDE this launch -- a work
+    // item that has summed its quads over the tile's splits publishes them (write-through, system scope) at their flat gradient
+    // offsets in this rank's publish buffer, posts (epoch, health bit) to every rank's flag array, waits (bounded) for the same
+    // item of every rank and continues with the RANK-ORDERED sum: bit-identical replicas, no RCCL call, no optimizer launch.
+    int x_world, x_rank, x_spin, x_pad;
+    float* x_pub[8];
+    int32_t* x_flags[8];
+    int64_t* x_epoch;      // [512] one exchange counter per work item (private to its workgroup)
+    int64_t x_npad;
 };
 static_assert(sizeof(W2Desc) == 112, "W2Desc layout");
 
@@ -192,22 +201,101 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
             for (int t = 0; t < nt; ++t) shadow_store_desc(ad.shadow, stab.d[t], off, pv);
         }
     };
+    // ---- the exchange of one work item (see W2Adam): `publish` has stored this item's finished gradient elements into the publish
+    //      buffer at poff + their flat offsets; returns false when any rank flagged its step invalid (or a peer never arrived)
+    __shared__ int s_x_skip;
+    auto x_poff = [&]() __attribute__((always_inline)) -> int64_t { return (int64_t)((ad.x_epoch[blockIdx.x] + 1) & 1) * ad.x_npad; };
+    auto x_rendezvous = [&](const bool local_skip) __attribute__((always_inline)) -> bool {
+        const int b = blockIdx.x, nblk = gridDim.x;
+        const int ep = (int)(ad.x_epoch[b] + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's publish stores are out
+        __syncthreads();
+        if ((int)threadIdx.x < ad.x_world) {
+            int32_t *f = nullptr, *mine = nullptr;      // (selected without indexing the by-value struct dynamically)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (r == (int)threadIdx.x) f = ad.x_flags[r];
+                if (r == ad.x_rank) mine = ad.x_flags[r];
+            }
+            __hip_atomic_store(f + ad.x_rank * nblk + b, ep * 2 + (local_skip ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int32_t* w_ = mine + (int)threadIdx.x * nblk + b;
+            int val = __hip_atomic_load(w_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), spins = 0;
+            while ((val >> 1) - ep < 0) {
+                if (++spins > ad.x_spin) {      // a peer never arrived: this ITEM gives up (partial update: fatal for the run, see W2Adam)
+                    __hip_atomic_store(ad.health, ERC_HEALTH_RAISED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    val = 2 * ep + 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                val = __hip_atomic_load(w_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const unsigned long long any = __ballot((val & 1) != 0);
+            if (threadIdx.x == 0) s_x_skip = any != 0ull;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) ad.x_epoch[b] = ep;
+        return s_x_skip == 0;
+    };
+    auto x_sum4 = [&](const int64_t poff_off) __attribute__((always_inline)) -> f32x4 {      // rank-ordered sum of one published quad
+        f32x4 part[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part[r] = r < ad.x_world ? ld_sc1_x4(ad.x_pub[r] + poff_off) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]), "+v"(part[4]), "+v"(part[5]), "+v"(part[6]), "+v"(part[7])
+                     :
+                     : "memory");
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < ad.x_world) acc += part[r];
+        return acc;
+    };
+    auto x_sum1 = [&](const int64_t poff_off) __attribute__((always_inline)) -> float {
+        float acc = 0.f;
+        for (int r = 0; r < ad.x_world; ++r) {
+            const float* pb = nullptr;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q == r) pb = ad.x_pub[q];
+            acc += __hip_atomic_load(pb + poff_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return acc;
+    };
     if (ADAM && d.kind == 1) {   // plain range of finished gradients: d.C[0, M)
         if (threadIdx.x == 64) copy_tab();
         __syncthreads();
+        const int64_t base = d.C - ad.grad;
+        int64_t xoff = 0;
+        if (ad.x_world > 1) {      // (uniform) exchange the range first: every element published, then summed in rank order
+            xoff = x_poff() + base;
+            float* mypub = nullptr;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                if (r == ad.x_rank) mypub = ad.x_pub[r];
+            for (int e = (int)threadIdx.x; e < d.M; e += 256) __hip_atomic_store(mypub + xoff + e, d.C[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            adam_on = x_rendezvous(!adam_on) && adam_on;
+        }
         bump_step();
         if (adam_on) {
-            const int64_t base = d.C - ad.grad;
             for (int e = 4 * (int)threadIdx.x; e < d.M; e += 1024) {
                 if (e + 3 < d.M && ((base + e) & 3) == 0) {
                     int64_t offs[8] = {base + e};
                     float4 pn[8];
                     const bool isq[8] = {true};
-                    pn[0] = adam_quad(base + e, *(const ERC_GLOBAL f32x4*)(d.C + e), *(const ERC_GLOBAL f32x4*)(ad.data + base + e),
+                    f32x4 gq = *(const ERC_GLOBAL f32x4*)(d.C + e);
+                    if (ad.x_world > 1) {
+                        gq = x_sum4(xoff + e);
+                        *(ERC_GLOBAL f32x4*)(d.C + e) = gq;
+                    }
+                    pn[0] = adam_quad(base + e, gq, *(const ERC_GLOBAL f32x4*)(ad.data + base + e),
                                       *(const ERC_GLOBAL f32x4*)(ad.m + base + e), *(const ERC_GLOBAL f32x4*)(ad.v + base + e));
                     shadow_quads(offs, pn, 1, isq, ~0u);
                 } else {
-                    for (int t = e; t < min(e + 4, d.M); ++t) adam_one(base + t, d.C[t]);
+                    for (int t = e; t < min(e + 4, d.M); ++t) {
+                        float gv = d.C[t];
+                        if (ad.x_world > 1) d.C[t] = gv = x_sum1(xoff + t);
+                        adam_one(base + t, gv);
+                    }
                 }
             }
         }
@@ -636,8 +724,8 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
             }
             __syncthreads();
             W2_STAMP(5);
-            bump_step();                    // (every thread read the step count in front of the barriers)
-            if (!*s_flag) return;
+            if (ad.x_world <= 1) bump_step();      // (every thread read the step count in front of the barriers; with the
+            if (!*s_flag) return;                  //  gradient exchange the count moves behind it: a peer may veto the step)
             stamps = stamps_tile ? stamps_tile : stamps;
             W2_STAMP(8);
             const float* const tile_slabs = slabs + (int64_t)(d.item_base + tn * S) * W2_SLAB;
@@ -672,6 +760,28 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
                 for (int o = 1; o < 8; ++o) res[o] = z;
             }
             W2_STAMP(9);
+            float bsum = 0.f;      // bias strip element of this thread (split 0 of the tile)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) bsum += bt[jj] * (jj < S ? 1.f : 0.f);
+            if (ad.x_world > 1) {      // (uniform) the gradient exchange of this work item: its owned quads + its bias strip elements
+                const int64_t poff = x_poff();
+                float* mypub = nullptr;
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (r == ad.x_rank) mypub = ad.x_pub[r];
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    if (o < owned && valid[o] == 4) st_sc1_x4(mypub + poff + off[o], res[o]);
+                if (bdst) __hip_atomic_store(mypub + poff + boff, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                adam_on = x_rendezvous(!adam_on) && adam_on;
+                bump_step();
+                if (adam_on) {
+#pragma unroll
+                    for (int o = 0; o < 8; ++o)
+                        if (o < owned && valid[o] == 4) res[o] = x_sum4(poff + off[o]);
+                    if (bdst) bsum = x_sum1(poff + boff);
+                }
+            }
             const bool upd = adam_on;
             unsigned tmask = 0;      // shadow ranges that meet this record's gradient [cbase, cbase + rows * ldc)
             {
@@ -709,9 +819,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
                     res[o] = res[o + 1], pq[o] = pq[o + 1], mq[o] = mq[o + 1], vq[o] = vq[o + 1], off[o] = off[o + 1], valid[o] = valid[o + 1];
             }
             if (bdst) {      // bias strips: split 0 of the tile
-                float v = 0.f;
-    #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v += bt[jj] * (jj < S ? 1.f : 0.f);
+                const float v = bsum;
                 *(ERC_GLOBAL float*)bdst = v;
                 if (upd) {
                     ac.upd(bp, v, bm, bv);
@@ -910,7 +1018,7 @@ static int w2_adam_entry(int terms, const void* table, int n_desc, const int32_t
                          int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
                          float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
                          int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
-                         int32_t* health, void* stream) {
+                         int32_t* health, void* stream, const ErcP2P* x = nullptr) {
     static_assert(sizeof(ShadowTab) == sizeof(ErcShadowTab), "shadow table layout");
     ERC_REQUIRE(p && g && m && v && state && health && n > 0 && n_tiles >= 0 && n_items <= 256,
                 "wgrad_bf16_adam: bad arguments (at most 256 work items: all of them must be resident)");
@@ -920,6 +1028,16 @@ static int w2_adam_entry(int terms, const void* table, int n_desc, const int32_t
     ad.grad_scale = grad_scale, ad.data = p, ad.grad = g, ad.m = m, ad.v = v, ad.state = state, ad.skip = health, ad.health = health;
     ad.seq = counters + n_tiles;
     ad.spin_limit = g_w2_spin_limit;
+    if (x) {
+        ERC_REQUIRE(x->world >= 2 && x->world <= 8 && x->rank >= 0 && x->rank < x->world && x->epoch && x->n_pad >= n && x->n_pad % 4 == 0 &&
+                        (int32_t*)x->health == health, "wgrad_adam_p2p: bad exchange descriptor (2 <= world <= 8; health = the exchange's health word)");
+        ad.x_world = x->world, ad.x_rank = x->rank, ad.x_spin = x->spin_limit > 0 ? x->spin_limit : 4000000;
+        ad.x_epoch = (int64_t*)x->epoch, ad.x_npad = x->n_pad;
+        for (int r = 0; r < x->world; ++r) {
+            ERC_REQUIRE(x->pub[r] && x->flags[r] && ((uintptr_t)x->pub[r] & 15) == 0, "wgrad_adam_p2p: peer %d not mapped", r);
+            ad.x_pub[r] = (float*)x->pub[r], ad.x_flags[r] = (int32_t*)x->flags[r];
+        }
+    }
     if (tab_host) memcpy(&ad.tab, tab_host, sizeof(ad.tab));
     ERC_REQUIRE(ad.tab.n == 0 || shadow_base, "wgrad_bf16_adam: shadow table without a shadow buffer");
     ERC_REQUIRE(ad.tab.n >= 0 && ad.tab.n <= SHADOW_MAX, "wgrad_bf16_adam: %d shadow descriptors", ad.tab.n);
@@ -966,4 +1084,19 @@ extern "C" int erc_wgrad_split_adam(int terms, const void* table, int n_desc, co
     ERC_REQUIRE(terms == 2 || terms == 3, "wgrad_split_adam: terms = %d (2 or 3)", terms);
     return w2_adam_entry(terms, table, n_desc, item_base, n_items, slabs, counters, n_tiles, p, g, m, v, n, lr, beta1, beta2, eps,
                          weight_decay, decoupled, grad_scale, state, shadow_base, shadow_numel, tab_host, health, stream);
+}
+
+// DATA PARALLEL with the exchange inside (ERC_DP_P2P=1; ErcP2P as erc_adam_step_p2p): erc_wgrad_bf16_adam (terms = 1) /
+// erc_wgrad_split_adam (2 | 3) whose work items, having summed their quads over the tile's splits, publish them, rendezvous with
+// the same item of every rank (bounded; health bits travel with the flags) and apply the update with the RANK-ORDERED sum times
+// grad_scale (= 1 / world): the N > 1 step stays 5 launches, no RCCL call.  Every rank must launch the SAME table (same split
+// counts: same work items).  The flag arrays hold world * 512 int32 (item index < 256); x->epoch: int64 [512], zero-filled once.
+extern "C" int erc_wgrad_adam_p2p(int terms, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                                  int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                                  int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
+                                  const ErcP2P* x, void* stream) {
+    ERC_REQUIRE(x && terms >= 1 && terms <= 3, "wgrad_adam_p2p: bad arguments");
+    return w2_adam_entry(terms, table, n_desc, item_base, n_items, slabs, counters, n_tiles, p, g, m, v, n, lr, beta1, beta2, eps,
+                         weight_decay, decoupled, grad_scale, state, shadow_base, shadow_numel, tab_host, (int32_t*)x->health, stream, x);
 }

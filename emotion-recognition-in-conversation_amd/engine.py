@@ -273,8 +273,10 @@ class GemmPlanner:
         opt = self.fused_adam
         # (after a timeout event of the fused launch -- FlatParams.check_health sets `tainted` -- the planner keeps the two-launch
         #  form, whose optimizer skips a step as a whole, for the rest of the run)
-        fuse = opt is not None and opt.clip_norm <= 0 and opt.shadow is None and getattr(opt.flat, "p2p", None) is None and \
-            _world_size() == 1 and opt.flat.grad is self.grad and not getattr(opt.flat, "tainted", False)
+        # (data parallel: only with the peer-to-peer exchange, which then happens inside the launch -- erc_wgrad_adam_p2p)
+        p2p = getattr(opt.flat, "p2p", None) if opt is not None else None
+        fuse = opt is not None and opt.clip_norm <= 0 and opt.shadow is None and (p2p is not None or _world_size() == 1) and \
+            opt.flat.grad is self.grad and not getattr(opt.flat, "tainted", False)
         import ctypes
         import struct
         key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, ct, g.data_ptr() if g is not None else 0,
@@ -353,8 +355,8 @@ class GemmPlanner:
             f = opt.flat
             capi.wgrad_bf16_adam(cache["w16_table"], cache["w16_records"], cache["w16_bases"], cache["w16_items"], cache["w16_slabs"],
                                  cache["w16_counters"], cache["w16_tiles"], f.data, f.grad, f.exp_avg, f.exp_avg_sq, f.numel, opt.lr, opt.betas[0],
-                                 opt.betas[1], opt.eps, opt.weight_decay, opt.decoupled, 1.0, opt.state, opt.shadow_table,
-                                 opt.skip_flag, terms=terms)
+                                 opt.betas[1], opt.eps, opt.weight_decay, opt.decoupled, 1.0 / p2p.world if p2p is not None else 1.0,
+                                 opt.state, opt.shadow_table, opt.skip_flag, terms=terms, p2p_desc=p2p.desc if p2p is not None else None)
             self.adam_fused = True
             return
         if wide:

@@ -645,6 +645,20 @@ int erc_wgrad_split_adam(int terms, const void* table, int n_desc, const int32_t
                          int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
                          int32_t* health, void* stream);
 
+/* DATA PARALLEL with the gradient exchange INSIDE the weight-gradient + optimizer launch (ERC_DP_P2P=1; ErcP2P as
+ * erc_adam_step_p2p; the reference gets its DDP all-reduce from accelerate: lumo/trainer/trainer.py:62-64,377-384).
+ * erc_wgrad_bf16_adam (terms = 1) / erc_wgrad_split_adam (terms = 2 | 3) whose work items, having summed their quads over the
+ * tile's splits, publish them at their flat gradient offsets, post (epoch, health bit) to every rank, wait (bounded) for the
+ * same item of every rank and apply the update with the RANK-ORDERED sum times grad_scale (= 1 / world): bit-identical
+ * replicas, no RCCL call, the N > 1 step stays 5 launches.  Every rank launches the SAME table (same work items); a health
+ * bit on any rank vetoes the item's update on all.  x->health is the launch's health word; flag arrays: world * 512 int32;
+ * x->epoch: int64 [512], zero-filled once.  UNVERIFIED ACROSS DEVICES (two processes on one GPU: tests/test_gpu_p2p.py). */
+int erc_wgrad_adam_p2p(int terms, const void* table, int n_desc, const int32_t* item_base, int n_items, float* slabs,
+                       int32_t* counters, int n_tiles, float* p, float* g, float* m, float* v, int64_t n, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, int decoupled, float grad_scale,
+                       int64_t* state, void* shadow_base, int64_t shadow_numel, const ErcShadowTab* tab_host,
+                       const ErcP2P* x, void* stream);
+
 /* Health word: one device int32 that the persistent kernels with bounded polls (erc_dag_rec_*, erc_gcnii_chain_*: their
  * `health` argument; NULL = use state[0] as before) raise to ERC_HEALTH_RAISED when a poll ran into its bound, i.e. when
  * this step's results are invalid.  The value is the bit pattern of 1.0f: the host side keeps the word in the tail of the

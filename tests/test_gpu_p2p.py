@@ -80,3 +80,67 @@ def test_fused_p2p_exchange_two_processes_one_gpu():
         p.grad = (_grads(step, 0, w0.numel()) + _grads(step, 1, w0.numel())) / 2
         opt.step()
     assert float((w_a - p.detach()).abs().max()) < 2e-6
+
+
+def _trainer_worker(rank, world, port, q, compute):
+    """COGMENTrainer under ERC_DP_P2P=1: the exchange rides INSIDE the weight-gradient + optimizer launch (erc_wgrad_adam_p2p)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ERC_DP_P2P="1", ERC_P2P_SPIN="4000000",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import track_mm.cogmen as plugin
+        from tests.util_cases import cogmen_case
+        torch.cuda.set_device(0)
+        params = plugin.ParamsType().from_args(["--dataset=iemocap-cogmen-6", "--modality=atv", "--compute=" + compute, "--seed=3"])
+        params.optim.lr = 1e-3
+        tr = plugin.COGMENTrainer(params, "cuda:0")
+        tr.model.drop_p = 0.0
+        assert tr.model.flat.p2p is not None
+        w0 = tr.model.flat.data.clone()
+        grads = []
+        for step in range(3):       # every rank its own batch (data parallel), same shapes on both (same launch table)
+            b = tr.prepare_batch(cogmen_case(B=6, min_len=30, max_len=30, dims=params.dims(), seed=100 + 10 * step + rank,
+                                             n_classes=params.n_classes)["batch"])
+            tr.train_step(b)
+            torch.cuda.synchronize()
+            assert tr.model._last_ws["planner"].adam_fused
+            grads.append(tr.model.flat.grad.cpu().numpy().copy())       # the launch stores the rank-ordered SUM
+        q.put((rank, tr.model.flat.data.cpu().numpy(), int(tr.optim.state[0]), w0.cpu().numpy(), int(tr.model.flat.health[0]), grads))
+        dist.barrier()
+        tr.model.flat.p2p.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compute", ["bf16", "f32x32"])
+def test_exchange_inside_the_weight_gradient_launch_two_processes_one_gpu(compute):
+    """Two COGMEN trainers (two processes on the one GPU, ERC_DP_P2P=1) on DIFFERENT batches of the same shape: the step is the
+    single-rank 5-launch step -- the weight-gradient launch's work items exchange their summed quads with the same item of the
+    peer and apply Adam with the rank-ordered sum x 1/2.  Both replicas end bit-identical, the stored gradient is the same sum on
+    both, three steps were counted, no health event; and the parameters are what torch.optim.Adam gives for the MEAN of the two
+    ranks' gradients (the ranks' local gradients recomputed by single-process trainers on the same batches)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q, compute)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    (_, w_a, steps_a, w0, h_a, g_a), (_, w_b, steps_b, _, h_b, g_b) = res
+    assert steps_a == steps_b == 3 and h_a == 0 and h_b == 0
+    assert (w_a == w_b).all()
+    for x, y in zip(g_a, g_b):
+        assert (x == y).all()
+    # reference: the same three steps as plain Adam on half the exchanged sum
+    w0 = torch.from_numpy(w0)
+    p = torch.nn.Parameter(w0.clone())
+    opt = torch.optim.Adam([p], lr=1e-3, weight_decay=1e-8)
+    for g in g_a:
+        p.grad = torch.from_numpy(g) * 0.5
+        opt.step()
+    live = torch.from_numpy(w_a) != w0
+    assert float((torch.from_numpy(w_a) - p.detach()).abs().max()) < 2e-6 and int(live.sum()) > 1000
