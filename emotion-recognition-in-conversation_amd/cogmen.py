@@ -441,11 +441,14 @@ class COGMENModule(nn.Module):
         if self.dynamic_n and not ((w16 or wsp) and fused_head):
             raise capi.ErcGraftError("COGMEN capacity mode needs the fused bf16 / split training path (supports_capacity)")
         if fused_head:
+            # (bf16 mode: the weight-gradient launch reads the bf16 copies of H3 / Z / dZ / dlogits, nothing reads the fp32 ones: the
+            #  head does not write them -- 1.2 KB of its 2.4 KB per row; ERC_HEAD_F32_OUT=1 keeps them for inspection)
+            f32o = not w16 or os.environ.get("ERC_HEAD_F32_OUT", "0") == "1"
             head_args = (ws["H2"], F, N, F, C, fp.w("gcn.bn.weight"), fp.w("gcn.bn.bias"), ws["bn_saved"], 0.01,
                          fp.w("cls.0.weight"), fp.w("cls.0.bias"), fp.w("cls.3.weight"), fp.w("cls.3.bias"), ys,
-                         class_weight, p, self.rng_state if p > 0 else None, ws["H3"], ws["Z"], ws["logits"],
-                         ws["dlogits"], ws["dZ"], ws["dH3"], ws["bn_bwd"], fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"),
-                         ws["stats"], ws["head_ws"])
+                         class_weight, p, self.rng_state if p > 0 else None, ws["H3"] if f32o else None, ws["Z"] if f32o else None,
+                         ws["logits"], ws["dlogits"] if f32o else None, ws["dZ"] if f32o else None, ws["dH3"], ws["bn_bwd"],
+                         fp.g("gcn.bn.weight"), fp.g("gcn.bn.bias"), ws["stats"], ws["head_ws"])
             if fused and ws["bn_in_tile"]:
                 # BatchNorm's batch statistics: per-tile sums from the forward tile kernel, added up by every head workgroup
                 # ... and the head's own cross-workgroup sums (BatchNorm backward means, loss) are left to the backward tile kernel

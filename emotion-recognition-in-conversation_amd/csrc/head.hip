@@ -328,7 +328,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
             a1[kb][t] = h[t] * km;
         }
         if ((RPW == 2 ? (kb & 3) : kb) == cq && mrow < N && kv) {
-            *reinterpret_cast<f32x4*>(p.H3 + (int64_t)mrow * F + k0) = h;
+            if (p.H3) *reinterpret_cast<f32x4*>(p.H3 + (int64_t)mrow * F + k0) = h;
             if (p.H3b) *reinterpret_cast<uint2*>(p.H3b + (int64_t)mrow * p.ldb16 + k0) =
                 make_uint2((uint32_t)hf_bf(h[0]) | ((uint32_t)hf_bf(h[1]) << 16), (uint32_t)hf_bf(h[2]) | ((uint32_t)hf_bf(h[3]) << 16));
         }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
                 z *= cm[jn];
                 zreg[jn][q] = z;
                 if (row < N && 16 * nt + r < F) {
-                    p.Z[(int64_t)row * F + 16 * nt + r] = z;
+                    if (p.Z) p.Z[(int64_t)row * F + 16 * nt + r] = z;
                     if (p.Zb) p.Zb[(int64_t)row * p.ldb16 + 16 * nt + r] = hf_bf(z);
                 }
             }
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
             if (r < 8) sD[rt][4 * g + q][cr] = dq;
             if (rv && r < C) {
                 p.logits[(int64_t)row * C + r] = v;
-                p.dlogits[(int64_t)row * p.lddl + r] = dq;
+                if (p.dlogits) p.dlogits[(int64_t)row * p.lddl + r] = dq;
                 if (p.dlb) p.dlb[(int64_t)row * 8 + r] = hf_bf(dq);
             }
             if (rv && r == 0) lsum += wyq[q] * (lse - ly), hsum += ((int)am == y) ? 1.f : 0.f;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
                 for (int c = 0; c < 4; ++c) s += dhi[c] * w3[4 + c][jn];
                 const float dz = zreg[jn][q] > 0.f ? s * scale : 0.f;
                 if (row < N && 16 * nt + r < F) {
-                    p.dZ[(int64_t)row * F + 16 * nt + r] = dz;
+                    if (p.dZ) p.dZ[(int64_t)row * F + 16 * nt + r] = dz;
                     if (p.dZb) p.dZb[(int64_t)row * p.ldb16 + 16 * nt + r] = hf_bf(dz);
                 }
                 tile[(4 * g + q) * HF_ST + 16 * nt + r] = dz;
@@ -583,6 +583,334 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
     if (p.stamps && tid == 0) p.stamps[7] = __builtin_amdgcn_s_memrealtime();   // the last arriver, whichever workgroup it is
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// THROUGHPUT FORM (more than 8 192 rows: B = 512 batches).  The kernel above spreads a 16-row tile over 4-7 wavefronts that meet
+// four times in LDS: right when ONE round of workgroups is all there is (2 000 rows: the chain per wavefront sets the time),
+// wrong when there are 8 rounds -- 125 us at 33 k rows against 13 us of fp32 matrix-core time, one workgroup per CU (147
+// registers x 8 wavefronts; squeezed to 128 for two per CU it spilled: 226 us).  Here ONE WAVEFRONT takes a row tile through the
+// whole chain (its 7 column tiles in turn; the 16 x 100 dZ tile is transposed through a wavefront-private LDS area: no
+// workgroup barrier inside the loop), wavefronts loop over tiles, W0 is staged once per workgroup, and two workgroups of four
+// wavefronts share a CU: the dependent chain of one tile hides behind the other wavefronts' tiles.  Same arithmetic, same
+// outputs and records as head_fused_kernel<false, .> (the per-row math is copied instruction for instruction).
+__global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
+    __shared__ __attribute__((aligned(16))) float sW[HF_MAXF * HF_S];      // W0, row pitch HF_S
+    __shared__ __attribute__((aligned(16))) float sT[4][16 * HF_ST];       // per wavefront: the dZ tile (transposition between the products)
+    __shared__ __attribute__((aligned(16))) float sD[4][16][8];            // per wavefront: dlogits of its tile
+    float (*const sCol)[2][112] = reinterpret_cast<float (*)[2][112]>(&sT[0][0]);   // [4][2][112] column sums: in the tile area, after the loop
+    __shared__ float sLoss[4][2];                                          //   (81 280 bytes in all: two workgroups per CU)
+    __shared__ double sRed[4];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
+    const int F = p.F, C = p.C, N = p.n_dev ? min(max(*p.n_dev, 1), p.N) : p.N;
+    {   // W0 (F x F) -> LDS
+        const int nq = F * F / 4, per_row = F / 4;
+        for (int i0 = 0; i0 < nq; i0 += 5 * 256) {
+            f32x4 v[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int i = min(i0 + j * 256 + tid, nq - 1);
+                const int row = i / per_row, q = i - row * per_row;
+                v[j] = *reinterpret_cast<const f32x4*>(p.W0 + (int64_t)row * F + 4 * q);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int i = i0 + j * 256 + tid;
+                const int row = min(i, nq - 1) / per_row, q = min(i, nq - 1) - row * per_row;
+                if (i < nq) *reinterpret_cast<f32x4*>(sW + row * HF_S + 4 * q) = v[j];
+            }
+        }
+    }
+    if (p.weight) {   // cross-entropy normaliser: sum of the class weights of all rows (every workgroup computes it)
+        double wacc = 0.0;
+        for (int i0 = 0; i0 < N; i0 += 4 * 256) {
+            int y[4];
+            float wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = min(i0 + j * 256 + tid, N - 1);
+                y[j] = (int)p.labels[p.label_rows ? p.label_rows[rr] : rr];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = p.weight[y[j]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wacc += (double)wv[j] * (i0 + j * 256 + tid < N ? 1.0 : 0.0);
+        }
+        wacc = wave_sum_d(wacc);
+        if (lane == 0) sRed[w] = wacc;
+    }
+    // per-column constants (column 16 nt + r of every column tile) live in LDS and are read where they are used: held in
+    // registers across the tile loop (105 of them) the kernel spilled 210
+    __shared__ __attribute__((aligned(16))) float sPar[6][112];      // mean | rstd | gamma | beta | b0 | column mask, columns >= F clamped (mask 0)
+    __shared__ float sW3[HF_MAXC][112];
+    if (tid < 112) {
+        const int cc = min(tid, F - 1);
+        sPar[0][tid] = p.saved[cc], sPar[1][tid] = p.saved[F + cc], sPar[2][tid] = p.gamma[cc], sPar[3][tid] = p.beta[cc];
+        sPar[4][tid] = p.b0[cc], sPar[5][tid] = tid < F ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < HF_MAXC; ++c) sW3[c][tid] = (tid < F && c < C) ? p.W3[(int64_t)c * F + cc] : 0.f;
+    }
+    const int cr = r & 7;
+    const float b3c = p.b3[min(cr, C - 1)];
+    const bool cv = cr < C;
+    __syncthreads();  // sW, sRed complete
+    double wsum = (double)N;
+    if (p.weight) wsum = ((sRed[0] + sRed[1]) + sRed[2]) + sRed[3];
+    const float inv_w = (float)(1.0 / wsum);
+    const float scale = 1.f / (1.f - p.drop_p);
+    uint64_t rng_off = 0, rng_seed = 0;
+    if (p.drop_p > 0.f) rng_off = p.rng[0], rng_seed = p.rng[1];
+    float* const tile = sT[w];
+    float colA[HF_NT], colB[HF_NT];
+#pragma unroll
+    for (int nt = 0; nt < HF_NT; ++nt) colA[nt] = colB[nt] = 0.f;
+    float lsum = 0.f, hsum = 0.f;
+    const int n_tiles = (N + 15) / 16;
+#pragma unroll 1
+    for (int t_i = (int)blockIdx.x * 4 + w; t_i < n_tiles; t_i += (int)gridDim.x * 4) {
+        // (the lane coordinates go through an opaque zero once per tile: otherwise the ~300 LDS / global offsets below, all
+        //  invariant across tiles, are hoisted out of this loop and spilled -- 47 registers in scratch, reloaded inside the chain)
+        int opaque0 = 0;
+        asm volatile("" : "+v"(opaque0));
+        const int r = (lane & 15) + opaque0, g = (lane >> 4) + opaque0;
+        const int m0 = t_i * 16;
+        const int mrow = m0 + r, mrc = min(mrow, N - 1);
+        // ---- P1: A fragments of H3 = lrelu(bn(H2)); lane (r,g): row m0 + r, k = 16 kb + 4 g + t
+        float a1[HF_NT][4];
+        f32x4 xr[HF_NT];      // the tile's H2 rows: the only global operands of this phase (the BatchNorm constants come from LDS)
+#pragma unroll
+        for (int kb = 0; kb < HF_NT; ++kb) {
+            const int k0 = 16 * kb + 4 * g;
+            xr[kb] = *reinterpret_cast<const f32x4*>(p.H2 + (int64_t)mrc * p.ldh + (k0 < F ? k0 : 0));
+        }
+#pragma unroll
+        for (int kb = 0; kb < HF_NT; ++kb) {
+            const int k0 = 16 * kb + 4 * g;
+            const bool kv = k0 < F;
+            const int k0c = kv ? k0 : 0;
+            const float km = kv ? 1.f : 0.f;
+            const f32x4 x = xr[kb];
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(&sPar[0][k0c]), rs = *reinterpret_cast<const f32x4*>(&sPar[1][k0c]);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(&sPar[2][k0c]), be = *reinterpret_cast<const f32x4*>(&sPar[3][k0c]);
+            f32x4 h;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float z = (x[t] - mu[t]) * rs[t] * ga[t] + be[t];
+                h[t] = (z > 0.f ? z : z * p.slope);
+                a1[kb][t] = h[t] * km;
+            }
+            if (mrow < N && kv) {
+                if (p.H3) *reinterpret_cast<f32x4*>(p.H3 + (int64_t)mrow * F + k0) = h;
+                if (p.H3b) *reinterpret_cast<uint2*>(p.H3b + (int64_t)mrow * p.ldb16 + k0) =
+                    make_uint2((uint32_t)hf_bf(h[0]) | ((uint32_t)hf_bf(h[1]) << 16), (uint32_t)hf_bf(h[2]) | ((uint32_t)hf_bf(h[3]) << 16));
+            }
+        }
+        int ylab[4];
+        float wyq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = min(m0 + 4 * g + q, N - 1);
+            ylab[q] = (int)p.labels[p.label_rows ? p.label_rows[rr] : rr];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wyq[q] = p.weight ? p.weight[ylab[q]] : 1.f;
+        // ---- P2: Z = dropout(relu(H3 W0^T + b0)), all 7 column tiles; rows m0 + 4g + q, columns 16 nt + r
+        float zreg[HF_NT][4];
+#pragma unroll
+        for (int nt = 0; nt < HF_NT; ++nt) {
+            __builtin_amdgcn_sched_barrier(0);      // (one column tile at a time: hoisting the next tiles' 49 weight reads spills)
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < HF_NT; ++kb) {
+                const int k0 = 16 * kb + 4 * g;
+                const int k0c = k0 < F ? k0 : 0;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(sW + min(16 * nt + r, F - 1) * HF_S + k0c);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kb][t], wv[t], acc, 0, 0, 0);
+            }
+            const float b0v = sPar[4][16 * nt + r], cmv = sPar[5][16 * nt + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + 4 * g + q;
+                float z = fmaxf(acc[q] + b0v, 0.f);
+                if (p.drop_p > 0.f) {
+                    const float u = erc_uniform(rng_seed, rng_off, (uint64_t)row * (uint64_t)F + (uint64_t)(16 * nt + r));
+                    z = (u >= p.drop_p) ? z * scale : 0.f;
+                }
+                z *= cmv;
+                zreg[nt][q] = z;
+                if (row < N && 16 * nt + r < F) {
+                    if (p.Z) p.Z[(int64_t)row * F + 16 * nt + r] = z;
+                    if (p.Zb) p.Zb[(int64_t)row * p.ldb16 + 16 * nt + r] = hf_bf(z);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- P3: logits (class cr in lanes r and r + 8) and the cross entropy of rows 4g + q.  W3's columns come from LDS a class at
+        //      a time (7 registers instead of 56 across P3 / P4)
+        float mine4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < HF_MAXC; ++c) {
+            float w3c[HF_NT];
+#pragma unroll
+            for (int nt = 0; nt < HF_NT; ++nt) w3c[nt] = sW3[c][16 * nt + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float zw = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < HF_NT; ++nt) zw += zreg[nt][q] * w3c[nt];
+                const float s_ = row16_sum(zw);
+                if (c == cr) mine4[q] = s_;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = m0 + 4 * g + q;
+            const bool rv = row < N;
+            const float v = b3c + mine4[q];
+            const float mx = row8_max(cv ? v : -3.0e38f);
+            const float se = row8_sum(cv ? expf(v - mx) : 0.f);
+            const float lse = mx + logf(se);
+            const int y = ylab[q];
+            const float coef = rv ? wyq[q] * inv_w : 0.f;
+            const float dq = cv ? coef * (expf(v - lse) - (cr == y ? 1.f : 0.f)) : 0.f;
+            const float ly = row8_sum(cr == y ? v : 0.f);
+            const float am = row8_min((cv && v == mx) ? (float)cr : 99.f);
+            if (r < 8) sD[w][4 * g + q][cr] = dq;
+            if (rv && r < C) {
+                p.logits[(int64_t)row * C + r] = v;
+                if (p.dlogits) p.dlogits[(int64_t)row * p.lddl + r] = dq;
+                if (p.dlb) p.dlb[(int64_t)row * 8 + r] = hf_bf(dq);
+            }
+            if (rv && r == 0) lsum += wyq[q] * (lse - ly), hsum += ((int)am == y) ? 1.f : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- P4: dZ = (dlogits W3) * relu / dropout mask -> the wavefront's tile in LDS (written and read by this wavefront only)
+        f32x4 dlo[4], dhi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dlo[q] = *reinterpret_cast<const f32x4*>(&sD[w][4 * g + q][0]), dhi[q] = *reinterpret_cast<const f32x4*>(&sD[w][4 * g + q][4]);
+#pragma unroll
+        for (int nt = 0; nt < HF_NT; ++nt) {
+            float w3n[HF_MAXC];
+#pragma unroll
+            for (int c = 0; c < HF_MAXC; ++c) w3n[c] = sW3[c][16 * nt + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + 4 * g + q;
+                float s_ = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s_ += dlo[q][c] * w3n[c];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s_ += dhi[q][c] * w3n[4 + c];
+                const float dz = zreg[nt][q] > 0.f ? s_ * scale : 0.f;
+                if (row < N && 16 * nt + r < F) {
+                    if (p.dZ) p.dZ[(int64_t)row * F + 16 * nt + r] = dz;
+                    if (p.dZb) p.dZb[(int64_t)row * p.ldb16 + 16 * nt + r] = hf_bf(dz);
+                }
+                tile[(4 * g + q) * HF_ST + 16 * nt + r] = dz;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- P5: dH3 = dZ W0 : A fragments from the transposed tile, B[k = j][n = i] = W0[j][i] read column-wise from LDS
+        float a2[HF_NT][4];
+#pragma unroll
+        for (int kb = 0; kb < HF_NT; ++kb) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * HF_ST + 16 * kb + 4 * g);  // columns >= F hold zeros
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a2[kb][t] = v[t];
+        }
+#pragma unroll
+        for (int nt = 0; nt < HF_NT; ++nt) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < HF_NT; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int jc = min(16 * kb + 4 * g + t, F - 1);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[kb][t], sW[jc * HF_S + min(16 * nt + r, F - 1)], acc, 0, 0, 0);
+                }
+            // ---- P6: dY = dH3 * lrelu'(bn output), BatchNorm-backward column partials of this wavefront
+            float a = 0.f, b = 0.f;
+            const float mu6 = sPar[0][16 * nt + r], rs6 = sPar[1][16 * nt + r], ga6 = sPar[2][16 * nt + r], be6 = sPar[3][16 * nt + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = m0 + 4 * g + q;
+                const bool ok = row < N && 16 * nt + r < F;
+                const float x6 = p.H2[(int64_t)min(row, N - 1) * p.ldh + min(16 * nt + r, F - 1)];
+                const float xh = (x6 - mu6) * rs6;
+                const float zz = xh * ga6 + be6;
+                const float dy = ok ? acc[q] * (zz > 0.f ? 1.f : p.slope) : 0.f;
+                if (ok) p.dY[(int64_t)row * F + 16 * nt + r] = dy;
+                a += dy, b += dy * xh;
+            }
+            colA[nt] += a, colB[nt] += b;
+        }
+    }
+    // ---- workgroup record: column sums over the wavefronts' tiles (lane groups g, then wavefronts), loss, hits
+    __syncthreads();      // every wavefront is done with its tile area
+#pragma unroll
+    for (int nt = 0; nt < HF_NT; ++nt) {
+        float a = colA[nt], b = colB[nt];
+        a += __shfl_xor(a, 16, 64), a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64), b += __shfl_xor(b, 32, 64);
+        if (g == 0) sCol[w][0][16 * nt + r] = a, sCol[w][1][16 * nt + r] = b;
+    }
+    lsum = wave_sum(lsum), hsum = wave_sum(hsum);
+    if (lane == 0) sLoss[w][0] = lsum, sLoss[w][1] = hsum;
+    __syncthreads();
+    float* const rec = p.part + (int64_t)blockIdx.x * HF_PART;
+    if (tid < 112) {
+        st_sc1(rec + tid, ((sCol[0][0][tid] + sCol[1][0][tid]) + sCol[2][0][tid]) + sCol[3][0][tid]);
+        st_sc1(rec + 112 + tid, ((sCol[0][1][tid] + sCol[1][1][tid]) + sCol[2][1][tid]) + sCol[3][1][tid]);
+    } else if (tid < 114) {
+        st_sc1(rec + 224 + (tid - 112), ((sLoss[0][tid - 112] + sLoss[1][tid - 112]) + sLoss[2][tid - 112]) + sLoss[3][tid - 112]);
+    } else if (tid == 114) {
+        st_sc1(rec + 226, (float)wsum);
+    }
+    if (p.defer) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int prev = __hip_atomic_fetch_add(p.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(p.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // last arriver: column sums over the workgroups, in order, fp64 (as head_fused_kernel)
+    const int G = (int)gridDim.x;
+    const bool col = tid < F, aux = tid >= F && tid < F + 2;
+    const int o1 = col ? tid : 224 + (tid - F), o2 = col ? 112 + tid : 224 + (tid - F);
+    double s1 = 0.0, s2 = 0.0;
+    if (col || aux) {
+        for (int g0 = 0; g0 < G; g0 += 32) {
+            float t1[32], t2[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const float* q = p.part + (int64_t)min(g0 + j, G - 1) * HF_PART;
+                t1[j] = ld_sc1(q + o1), t2[j] = ld_sc1(q + o2);
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const double m = g0 + j < G ? 1.0 : 0.0;
+                s1 += (double)t1[j] * m, s2 += (double)t2[j] * m;
+            }
+        }
+    }
+    if (col) {
+        p.bn_bwd[tid] = (float)(s1 / (double)N);
+        p.bn_bwd[F + tid] = (float)(s2 / (double)N);
+        p.dbeta[tid] = (float)s1;
+        p.dgamma[tid] = (float)s2;
+    } else if (tid == F) {
+        p.stats[0] = (float)(s1 / wsum);
+        p.stats[2] = (float)wsum;
+    } else if (tid == F + 1) {
+        p.stats[1] = (float)s1;
+    }
+}
+
 // dx = gamma * rstd * (dY - mean(dY) - xhat * mean(dY * xhat)): the elementwise part of BatchNorm's backward
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int ldx, int N, int F,
                                                            const float* __restrict__ gamma, const float* __restrict__ saved,
@@ -659,13 +987,14 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     ERC_REQUIRE(lddl == 0 || lddl >= C, "head_fused: lddl = %d < C = %d", lddl, C);
     ERC_REQUIRE((!H3b && !Zb && !dZb && !dlb) || (H3b && Zb && dZb && dlb && ldb16 >= F && ldb16 % 4 == 0 && (((uintptr_t)H3b) & 7) == 0),
                 "head_fused: bf16 operand copies (all four or none, pitch %% 4 == 0)");
-    ERC_REQUIRE(H2 && gamma && beta && (saved || bn_part) && W0 && b0 && W3 && b3 && labels && H3 && Z && logits && dlogits && dZ && dY &&
-                    bn_bwd && dgamma && dbeta && stats && ws,
-                "head_fused: null pointer");
+    // (H3, Z, dZ, dlogits may be NULL when their bf16 copies are taken: the weight-gradient launch reads those, nothing reads the fp32 ones)
+    ERC_REQUIRE(H2 && gamma && beta && (saved || bn_part) && W0 && b0 && W3 && b3 && labels && logits && dY && bn_bwd && dgamma && dbeta &&
+                    stats && ws && ((H3 && Z && dZ && dlogits) || (H3b && !H3 && !Z && !dZ && !dlogits)),
+                "head_fused: null pointer (H3 / Z / dZ / dlogits: all four, or none of them next to the bf16 copies)");
     ERC_REQUIRE(n_rows > 0 && F >= 4 && F <= HF_MAXF && F % 4 == 0 && C > 0 && C <= HF_MAXC && ldh >= F && ldh % 4 == 0,
                 "head_fused: n_rows=%d F=%d C=%d ldh=%d unsupported (F <= %d, F %% 4 == 0, C <= %d)", n_rows, F, C, ldh,
                 HF_MAXF, HF_MAXC);
-    ERC_REQUIRE(al16(H2) && al16(gamma) && al16(beta) && (!saved || al16(saved)) && al16(W0) && al16(H3), "head_fused: 16-byte alignment");
+    ERC_REQUIRE(al16(H2) && al16(gamma) && al16(beta) && (!saved || al16(saved)) && al16(W0) && (!H3 || al16(H3)), "head_fused: 16-byte alignment");
     ERC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || rng_state), "head_fused: drop_p=%f", (double)drop_p);
     ERC_REQUIRE(!bn_part || (bn_tiles > 0 && saved_out && running_mean && running_var), "head_fused: BatchNorm partials operands");
     HeadP p{};
@@ -679,6 +1008,21 @@ static int head_fused_launch(const float* H2, int ldh, int n_rows, int F, int C,
     p.H3b = (unsigned short*)H3b, p.Zb = (unsigned short*)Zb, p.dZb = (unsigned short*)dZb, p.dlb = (unsigned short*)dlb, p.ldb16 = ldb16;
     p.n_dev = n_dev, p.label_rows = label_rows, p.lddl = lddl ? lddl : C;
     p.stamps = g_head_stamps;
+    static int wave_form = -1;
+    if (wave_form < 0) {
+        const char* e = getenv("ERC_HEAD_WAVE");
+        wave_form = e ? atoi(e) : 1;
+    }
+    if (!bn_part && !defer && n_rows > 8192 && wave_form) {
+        // throughput form: one wavefront per row tile, workgroups of four looping over the tiles, two per CU
+        const int tiles = erc_cdiv(n_rows, 16);
+        const int grid_w = erc_cdiv(tiles, 4) < 512 ? erc_cdiv(tiles, 4) : 512;
+        p.part = ws;
+        p.counter = reinterpret_cast<int*>(ws + (int64_t)grid_w * HF_PART);
+        hipLaunchKernelGGL(head_rows_kernel, dim3(grid_w), dim3(256), 0, (hipStream_t)stream, p);
+        ERC_LAUNCH_CHECK("head_fused (rows)");
+        return ERC_OK;
+    }
     const int rpw = erc_head_fused_rows_per_workgroup(n_rows) / 16;
     const int grid = erc_cdiv(n_rows, 16 * rpw);
     p.part = ws;

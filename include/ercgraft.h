@@ -374,7 +374,9 @@ int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C, const flo
                    const uint64_t* rng_state, float* H3, float* Z, float* logits, float* dlogits, float* dZ,
                    float* dY, float* bn_bwd, float* dgamma, float* dbeta, float* stats, float* ws, void* H3b, void* Zb,
                    void* dZb, void* dlb, int ldb16, const int32_t* n_dev, const int32_t* label_rows, int lddl, void* stream);
-/* lddl: row pitch of dlogits in floats (0 = C; the split compute modes pass 8: 16-byte rows for erc_wgrad_split, pad columns
+/* H3, Z, dZ, dlogits may be NULL when the bf16 copies (H3b, Zb, dZb, dlb) are given: the weight-gradient launch reads those, the
+ * fp32 ones are then not written (1.2 of the 2.4 KB the launch writes per row).
+ * lddl: row pitch of dlogits in floats (0 = C; the split compute modes pass 8: 16-byte rows for erc_wgrad_split, pad columns
  * are left untouched and must be finite).
  * label_rows (or NULL): the label of row i is labels[label_rows[i]] -- labels kept in a resident store (or a padded [B, T]
  * block) are read through the node -> row map instead of being compacted per batch.
