@@ -318,7 +318,14 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     const ERC_GLOBAL unsigned short* const Bg = (const ERC_GLOBAL unsigned short*)d.B;
 
     // column offsets of this lane (clamped: out-of-range columns only feed output rows / columns that are never stored)
-    const int ma = 8 * r, nb = n0 + 4 * r;
+    // output row of fragment i (0..7) of the A operand for accumulator row group rp (0..15).  bf16 operands: a lane's 16-byte load is
+    // 8 neighbouring rows (m = 8 rp + i).  fp32 operands (split modes): TWO 16-byte loads per k -- rows 4 rp .. 4 rp + 3 and
+    // 64 + 4 rp .. + 3 -- so that the 16 lanes of a row read 256 contiguous bytes per instruction (8 neighbouring rows per lane as
+    // two loads touched every cache line of the row twice: K loop 12.2 us at config 2)
+    auto mrow = [](const int rp, const int i) __attribute__((always_inline)) -> int {
+        return NT == 1 ? 8 * rp + i : (i < 4 ? 4 * rp + i : 64 + 4 * rp + (i - 4));
+    };
+    const int ma = NT == 1 ? 8 * r : 4 * r, nb = n0 + 4 * r;
     const int a_c = ma < d.M ? ma : 0;
     const int b_c = nb < d.N ? nb : 0;
     // k-steps of this wavefront: ks_begin + w + 4 s (WIDE: ks_begin + s), s < ns
@@ -449,7 +456,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
         //      cores.  
         const ERC_GLOBAL float* const Af = (const ERC_GLOBAL float*)d.A;
         const ERC_GLOBAL float* const Bf = (const ERC_GLOBAL float*)d.B;
-        const int a_c1 = ma + 4 < d.M ? ma + 4 : 0;
+        const int a_c1 = 64 + ma < d.M ? 64 + ma : 0;
         // the ring unit is a HALF group (4 k-steps: 48 operand registers); three of them -- two full 8-step groups in flight spill
         // (the expansion needs ~50 registers of its own), one leaves a single memory latency uncovered per group
         struct Half {
@@ -555,7 +562,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     #pragma unroll
             for (int i = 0; i < 8; ++i)
     #pragma unroll
-                for (int q = 0; q < 4; ++q) bred[w * 192 + 8 * (4 * g + q) + i] = bacc_a[i][q] * wsel;
+                for (int q = 0; q < 4; ++q) bred[w * 192 + mrow(4 * g + q, i)] = bacc_a[i][q] * wsel;
         }
         if (lane < 16) {
     #pragma unroll
@@ -575,11 +582,11 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
             const int il = f4 >> 8, q = (f4 >> 6) & 3, ln = f4 & 63;
             const int rp = 4 * (ln >> 4) + q;
             if (!ct) {
-                const int m = 8 * rp + 2 * h + il, n = n0 + 4 * (ln & 15);
+                const int m = mrow(rp, 2 * h + il), n = n0 + 4 * (ln & 15);
                 valid = (m < d.M && n < d.N) ? min(4, d.N - n) : 0;
                 return (int64_t)m * d.ldc + n;
             }
-            const int m = 8 * rp + 4 * il, n = n0 + 4 * (ln & 15) + h;
+            const int m = mrow(rp, 4 * il), n = n0 + 4 * (ln & 15) + h;
             valid = (m < d.M && n < d.N) ? min(4, d.M - m) : 0;
             return (int64_t)n * d.ldc + m;
         };
@@ -588,7 +595,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
             const int rp = 4 * (ln >> 4) + q;
             ERC_GLOBAL float* const Cg = (ERC_GLOBAL float*)d.C;
             if (!ct) {
-                const int m = 8 * rp + 2 * h + il, n = n0 + 4 * (ln & 15);
+                const int m = mrow(rp, 2 * h + il), n = n0 + 4 * (ln & 15);
                 if (m >= d.M || n >= d.N) return;
                 ERC_GLOBAL float* dst = Cg + (int64_t)m * d.ldc + n;
                 if (d.cvec && n + 3 < d.N) {
@@ -599,7 +606,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
                         if (n + j < d.N) dst[j] = v[j];
                 }
             } else {
-                const int m = 8 * rp + 4 * il, n = n0 + 4 * (ln & 15) + h;
+                const int m = mrow(rp, 4 * il), n = n0 + 4 * (ln & 15) + h;
                 if (m >= d.M || n >= d.N) return;
                 ERC_GLOBAL float* dst = Cg + (int64_t)n * d.ldc + m;
                 if (d.cvec && m + 3 < d.M) {
