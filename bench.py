@@ -462,7 +462,8 @@ def main():
         sb, sf, note = step_work(args.module, params, host_batch, args.dtype == "bf16")
         # the probe runs one extra (eager) training step: on one rank only when there is no collective to join
         dom = dominant_kernel(args.module, params, host_batch, batch, trainer, args.kernel_reps) if world == 1 else None
-        tag = "%s_%s_b%d_%s" % (PROFILE_ROUND, args.module, args.batch, args.dtype)
+        tag = "%s_%s_b%d_%s" % (PROFILE_ROUND, args.module, args.batch, args.dtype) if args.module == "cogmen" else \
+            "%s_%s" % (PROFILE_ROUND, args.module)      # (the other modules: one counter set per module, at its benched configuration)
         traffic, tsrc = None, None
         # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
         # command (tools/collect_profiles.sh -> tools/pmc_summary.py; gfx950 correction: read bytes = 2 x FETCH_SIZE): one
