@@ -562,7 +562,8 @@ def main():
             if with_roofline:
                 capi.start_recording()
                 tr.train_step(bb)
-                out["launches_per_step"] = len([e for e in capi.stop_recording() if not e[0].endswith(("_ok", "_floats", "_doubles"))])
+                out["launches_per_step"] = len([e for e in capi.stop_recording()
+                                                if not e[0].endswith(("_ok", "_floats", "_doubles", "_workgroup", "_split", "_stamps"))])
                 d = dominant_kernel("cogmen", pp, host_batch, bb, tr, args.kernel_reps)
                 if d is not None:
                     tfs, gbs = d["flops"] / d["avg_us"] * 1e-6, d["bytes"] / d["avg_us"] * 1e-3
