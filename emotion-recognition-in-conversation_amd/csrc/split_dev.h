@@ -8,7 +8,7 @@
 // and a product A B is the sum of the term products t_i(A) t_j(B) with i + j < NT -- the ones whose weight 2^(-8 (i + j)) is
 // above the expansion's own resolution -- accumulated in fp32 on v_mfma_f32_16x16x32_bf16, small terms first:
 //     NT = 2:  3 products, operands to 2^-17 (16 significant bits + sign of the remainder): measured on COGMEN config 2 against
-//              float64: logits 7.6e-6, gradients 6.8e-5 of a tensor's scale (tools/split_numerics.py)
+//              float64: logits 7.6e-6, gradients 6.8e-5 of a tensor's scale (tests/study_split_numerics.py)
 //     NT = 3:  6 products, operands to 2^-25: indistinguishable from fp32 arithmetic (1.8e-7 / 7.5e-6; plain fp32: 3.7e-7 / 5.4e-6)
 // No exponent-range caveat (bf16 has fp32's exponent), no loss scaling.
 #pragma once
