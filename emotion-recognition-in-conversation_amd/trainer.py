@@ -349,7 +349,13 @@ class ResidentEpochs:
             self._ahead.append((tabs[e, :, :B].sum(1).tolist(), dev[e]))
 
     def supported(self):
-        return self.trainer.resident_batch(self.store, self.cur_desc, self.B, self.T, self.N_BUCKET) is not None
+        """Can EVERY step of an epoch run from the resident store?  Probed with the smallest bucket and with the largest a batch
+        of this store can need (batch_size of its longest dialogues: above the fused path's node limit `resident_batch` returns
+        None -- found here, before the first epoch, not by a step in the middle of one)."""
+        lens = sorted((int(v) for v in self.store.lengths.tolist()), reverse=True)
+        worst = min(-(-sum(lens[:self.B]) // self.N_BUCKET) * self.N_BUCKET, self.B * self.T)
+        return all(self.trainer.resident_batch(self.store, self.cur_desc, self.B, self.T, cap) is not None
+                   for cap in sorted({self.N_BUCKET, max(worst, self.N_BUCKET)}))
 
     def _step_fn(self, batch):
         stats = self.trainer.train_step(batch)

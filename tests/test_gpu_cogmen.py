@@ -470,13 +470,14 @@ def _run_cli(args, timeout=300):
     return [l["Lall"] for l in lines if "Lall" in l], [l for l in lines if "test" in l]
 
 
-def test_training_loop_default_sampling_replays_capacity_buckets():
+@pytest.mark.parametrize("compute", ["bf16", "f32x32"])
+def test_training_loop_default_sampling_replays_capacity_buckets(compute):
     """trainer.run with the REFERENCE'S sampling (dialogues reshuffled every epoch, smaller last batch:
     lumo/trainer/trainer.py:429-442, mmbase.py:468; no --fixed_batches): batch shapes never repeat, the capacity buckets
     do -- after the first epoch almost every step is a replay of one of a handful of graphs, and the per-step losses are
     IDENTICAL to the same loop with capture switched off (same buckets, every step eager on the static buffers)."""
     args = ["--module=cogmen", "--dataset=iemocap-cogmen-6", "--epoch=3", "--n_train=44", "--n_test=6", "--train.batch_size=8",
-            "--test.batch_size=8", "--compute=bf16"]
+            "--test.batch_size=8", "--compute=" + compute]      # (f32x32: the 1e-4 parity path runs the same capacity-mode step)
     g_loss, g_ep = _run_cli(args)
     e_loss, e_ep = _run_cli(args + ["--graph_capture=False"])
     assert len(g_loss) == 18 and g_loss == e_loss
@@ -487,14 +488,15 @@ def test_training_loop_default_sampling_replays_capacity_buckets():
     assert g_ep[2]["graph_replays"] >= 10
 
 
-def test_resident_epochs_equal_the_collated_loop():
+@pytest.mark.parametrize("compute", ["bf16", "f32x32"])
+def test_resident_epochs_equal_the_collated_loop(compute):
     """``--resident``: the dialogues stay in the HBM store and a step's input is 2 B int32 (lengths | first store rows of
     the batch's dialogues) -- the projection launch reads features, speakers and labels straight from the store.  Same
     seed, same permutations, same batches as the device-collated loop (which pads every batch into a [B, T, D] block and
     copies it into the bucket's static buffers): the epoch mean losses are equal and every step after a bucket's first
     is a graph replay."""
     args = ["--module=cogmen", "--dataset=iemocap-cogmen-6", "--epoch=3", "--n_train=44", "--n_test=6", "--train.batch_size=8",
-            "--test.batch_size=8", "--compute=bf16", "--device_collate"]
+            "--test.batch_size=8", "--compute=" + compute, "--device_collate"]
     c_loss, c_ep = _run_cli(args)
     r_loss, r_ep = _run_cli(args + ["--resident"])
     assert len(c_loss) == 18 and len(r_loss) == 3
