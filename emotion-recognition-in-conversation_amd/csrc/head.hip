@@ -592,16 +592,23 @@ __global__ __launch_bounds__(512) void head_fused_kernel(const HeadP p) {
 // workgroup barrier inside the loop), wavefronts loop over tiles, W0 is staged once per workgroup, and two workgroups of four
 // wavefronts share a CU: the dependent chain of one tile hides behind the other wavefronts' tiles.  Same arithmetic, same
 // outputs and records as head_fused_kernel<false, .> (the per-row math is copied instruction for instruction).
+constexpr int HR_ST = 112;     // pitch of a wavefront's dZ tile (>= 112: 7 full column tiles are written)
 __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
     __shared__ __attribute__((aligned(16))) float sW[HF_MAXF * HF_S];      // W0, row pitch HF_S
-    __shared__ __attribute__((aligned(16))) float sT[4][16 * HF_ST];       // per wavefront: the dZ tile (transposition between the products)
+    __shared__ __attribute__((aligned(16))) float sT[4][16 * HR_ST];       // per wavefront: the dZ tile (transposition between the products)
     __shared__ __attribute__((aligned(16))) float sD[4][16][8];            // per wavefront: dlogits of its tile
     float (*const sCol)[2][112] = reinterpret_cast<float (*)[2][112]>(&sT[0][0]);   // [4][2][112] column sums: in the tile area, after the loop
-    __shared__ float sLoss[4][2];                                          //   (81 280 bytes in all: two workgroups per CU)
+    __shared__ float sLoss[4][2];                                          //   (79 240 bytes in all: two workgroups per CU -- at 81 288 the second one was not admitted)
     __shared__ double sRed[4];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
     const int F = p.F, C = p.C, N = p.n_dev ? min(max(*p.n_dev, 1), p.N) : p.N;
+    // diagnostic phase stamps (tools/head_rows_stamps.py): wavefront 0 of the middle workgroup, its first tile
+#define HR_STAMP(slot)                                                                                            \
+    do {                                                                                                          \
+        if (p.stamps && blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) p.stamps[slot] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+    HR_STAMP(0);
     {   // W0 (F x F) -> LDS
         const int nq = F * F / 4, per_row = F / 4;
         for (int i0 = 0; i0 < nq; i0 += 5 * 256) {
@@ -665,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
     for (int nt = 0; nt < HF_NT; ++nt) colA[nt] = colB[nt] = 0.f;
     float lsum = 0.f, hsum = 0.f;
     const int n_tiles = (N + 15) / 16;
+    HR_STAMP(1);
 #pragma unroll 1
     for (int t_i = (int)blockIdx.x * 4 + w; t_i < n_tiles; t_i += (int)gridDim.x * 4) {
         // (the lane coordinates go through an opaque zero once per tile: otherwise the ~300 LDS / global offsets below, all
@@ -713,6 +721,7 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) wyq[q] = p.weight ? p.weight[ylab[q]] : 1.f;
+        HR_STAMP(2);
         // ---- P2: Z = dropout(relu(H3 W0^T + b0)), all 7 column tiles; rows m0 + 4g + q, columns 16 nt + r
         float zreg[HF_NT][4];
 #pragma unroll
@@ -738,12 +747,23 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
                 }
                 z *= cmv;
                 zreg[nt][q] = z;
-                if (row < N && 16 * nt + r < F) {
-                    if (p.Z) p.Z[(int64_t)row * F + 16 * nt + r] = z;
-                    if (p.Zb) p.Zb[(int64_t)row * p.ldb16 + 16 * nt + r] = hf_bf(z);
-                }
+                tile[(4 * g + q) * HR_ST + 16 * nt + r] = z;      // (accumulator layout -> row layout through the wavefront's tile)
             }
         }
+        // Z out, row-wise: lane (r, g) holds row m0 + r, columns 16 kb + 4 g .. + 3 -- one 16-byte (fp32) / 8-byte (bf16) store per
+        // 16 columns instead of four 4- / 2-byte stores in the accumulator layout (91 narrow stores per lane and tile were what
+        // the products waited behind: vmcnt retires in order)
+#pragma unroll
+        for (int kb = 0; kb < HF_NT; ++kb) {
+            const int k0 = 16 * kb + 4 * g;
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(tile + r * HR_ST + k0);
+            if (mrow < N && k0 < F) {
+                if (p.Z) *reinterpret_cast<f32x4*>(p.Z + (int64_t)mrow * F + k0) = zv;
+                if (p.Zb) *reinterpret_cast<uint2*>(p.Zb + (int64_t)mrow * p.ldb16 + k0) =
+                    make_uint2((uint32_t)hf_bf(zv[0]) | ((uint32_t)hf_bf(zv[1]) << 16), (uint32_t)hf_bf(zv[2]) | ((uint32_t)hf_bf(zv[3]) << 16));
+            }
+        }
+        HR_STAMP(3);
         __builtin_amdgcn_sched_barrier(0);
         // ---- P3: logits (class cr in lanes r and r + 8) and the cross entropy of rows 4g + q.  W3's columns come from LDS a class at
         //      a time (7 registers instead of 56 across P3 / P4)
@@ -783,6 +803,7 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
             }
             if (rv && r == 0) lsum += wyq[q] * (lse - ly), hsum += ((int)am == y) ? 1.f : 0.f;
         }
+        HR_STAMP(4);
         __builtin_amdgcn_sched_barrier(0);
         // ---- P4: dZ = (dlogits W3) * relu / dropout mask -> the wavefront's tile in LDS (written and read by this wavefront only)
         f32x4 dlo[4], dhi[4];
@@ -802,21 +823,24 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) s_ += dhi[q][c] * w3n[4 + c];
                 const float dz = zreg[nt][q] > 0.f ? s_ * scale : 0.f;
-                if (row < N && 16 * nt + r < F) {
-                    if (p.dZ) p.dZ[(int64_t)row * F + 16 * nt + r] = dz;
-                    if (p.dZb) p.dZb[(int64_t)row * p.ldb16 + 16 * nt + r] = hf_bf(dz);
-                }
-                tile[(4 * g + q) * HF_ST + 16 * nt + r] = dz;
+                tile[(4 * g + q) * HR_ST + 16 * nt + r] = dz;
             }
         }
+        HR_STAMP(5);
         __builtin_amdgcn_sched_barrier(0);
         // ---- P5: dH3 = dZ W0 : A fragments from the transposed tile, B[k = j][n = i] = W0[j][i] read column-wise from LDS
         float a2[HF_NT][4];
 #pragma unroll
         for (int kb = 0; kb < HF_NT; ++kb) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * HF_ST + 16 * kb + 4 * g);  // columns >= F hold zeros
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + r * HR_ST + 16 * kb + 4 * g);  // columns >= F hold zeros
 #pragma unroll
             for (int t = 0; t < 4; ++t) a2[kb][t] = v[t];
+            const int k0 = 16 * kb + 4 * g;      // dZ out, row-wise (as Z above)
+            if (mrow < N && k0 < F) {
+                if (p.dZ) *reinterpret_cast<f32x4*>(p.dZ + (int64_t)mrow * F + k0) = v;
+                if (p.dZb) *reinterpret_cast<uint2*>(p.dZb + (int64_t)mrow * p.ldb16 + k0) =
+                    make_uint2((uint32_t)hf_bf(v[0]) | ((uint32_t)hf_bf(v[1]) << 16), (uint32_t)hf_bf(v[2]) | ((uint32_t)hf_bf(v[3]) << 16));
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < HF_NT; ++nt) {
@@ -840,14 +864,22 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
                 const float xh = (x6 - mu6) * rs6;
                 const float zz = xh * ga6 + be6;
                 const float dy = ok ? acc[q] * (zz > 0.f ? 1.f : p.slope) : 0.f;
-                if (ok) p.dY[(int64_t)row * F + 16 * nt + r] = dy;
+                tile[(4 * g + q) * HR_ST + 16 * nt + r] = dy;      // (the tile is free: a2 was read in front of the products)
                 a += dy, b += dy * xh;
             }
             colA[nt] += a, colB[nt] += b;
         }
+        // dY out, row-wise
+#pragma unroll
+        for (int kb = 0; kb < HF_NT; ++kb) {
+            const int k0 = 16 * kb + 4 * g;
+            if (mrow < N && k0 < F) *reinterpret_cast<f32x4*>(p.dY + (int64_t)mrow * F + k0) = *reinterpret_cast<const f32x4*>(tile + r * HR_ST + k0);
+        }
     }
+    HR_STAMP(6);
     // ---- workgroup record: column sums over the wavefronts' tiles (lane groups g, then wavefronts), loss, hits
     __syncthreads();      // every wavefront is done with its tile area
+    HR_STAMP(7);
 #pragma unroll
     for (int nt = 0; nt < HF_NT; ++nt) {
         float a = colA[nt], b = colB[nt];
@@ -870,6 +902,7 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
     if (p.defer) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    HR_STAMP(8);
     if (tid == 0) {
         const int prev = __hip_atomic_fetch_add(p.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = prev == (int)gridDim.x - 1;
@@ -911,6 +944,7 @@ __global__ __launch_bounds__(256, 2) void head_rows_kernel(const HeadP p) {
     }
 }
 
+#undef HR_STAMP
 // dx = gamma * rstd * (dY - mean(dY) - xhat * mean(dY * xhat)): the elementwise part of BatchNorm's backward
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int ldx, int N, int F,
                                                            const float* __restrict__ gamma, const float* __restrict__ saved,
