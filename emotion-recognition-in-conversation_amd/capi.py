@@ -106,6 +106,7 @@ _SIGS = {
     "erc_cogmen_bwd_tile_x": (C.c_int, [_i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _i64, _vp, _i64, _f, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "erc_head_fused_part_floats": (C.c_int, []),
+    "erc_head_rows_occupancy": (C.c_int, []),
     "erc_head_fused_rows_per_workgroup": (C.c_int, [_i]),
     "erc_clock_probe": (C.c_int, [_vp, _i, _vp]),
     "erc_grad_norm": (C.c_int, [_vp, _i64, _f, _vp, _vp, _vp]),

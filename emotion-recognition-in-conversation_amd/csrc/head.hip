@@ -1085,6 +1085,12 @@ extern "C" int erc_head_fused(const float* H2, int ldh, int n_rows, int F, int C
 }
 
 extern "C" int erc_head_fused_part_floats(void) { return HF_PART; }
+// diagnostic: resident workgroups per CU of the throughput form (head_rows_kernel), by the runtime's occupancy query
+extern "C" int erc_head_rows_occupancy(void) {
+    int n = -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, head_rows_kernel, 256, 0) != hipSuccess) return -1;
+    return n;
+}
 
 // erc_head_fused with BatchNorm's batch statistics finalised inside: bn_part [bn_tiles][2F] = the per-tile column sums
 // (sum x | sum x^2) erc_cogmen_fwd_tile leaves in bn mode 2; saved [2F] (mean | rstd) becomes an OUTPUT, the running

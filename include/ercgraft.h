@@ -399,6 +399,8 @@ int erc_head_fused_bn(const float* H2, int ldh, int n_rows, int F, int C, const 
 /* floats per workgroup record of erc_head_fused's workspace: [0,112) column sums of dY, [112,224) of dY * xhat, [224] loss
  * part, [225] hits, [226] sum of the sample weights; ceil(n_rows / erc_head_fused_rows_per_workgroup(n_rows)) records */
 int erc_head_fused_part_floats(void);
+/* diagnostic: resident workgroups per CU of the throughput form of the head (more than 8 192 rows), by the runtime's occupancy query */
+int erc_head_rows_occupancy(void);
 /* rows per workgroup (= per partial record) of erc_head_fused{,_bn} at n_rows rows: 16 up to 8 192 rows, 32 beyond
  * (ERC_HEAD_ROWS=16 / 32 forces one); the consumer of the deferred records (erc_cogmen_bwd_tile) is told
  * ceil(n_rows / this) records */
