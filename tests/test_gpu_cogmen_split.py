@@ -248,3 +248,18 @@ def test_bf16_mode_trains_like_the_parity_path_config2():
     # measured on MI355X (round 4): loss 1.827 -> 0.193 / 0.191; max |gap| 3.7e-3, mean 6.3e-4; accuracy 0.9659 / 0.9666
     assert float(gap.max()) < 1.2e-2 and float(gap.mean()) < 2e-3, (float(gap.max()), float(gap.mean()))
     assert acc_gap < 0.01, acc_gap
+
+
+@pytest.mark.parametrize("compute", ["f32x2", "f32x32"])
+def test_cogmen_split_mode_with_more_than_two_speakers(compute):
+    """The split tile kernels exist for two-speaker graphs (their compact tiles rely on a node having five non-empty relation
+    blocks).  A dataset with more speakers (MELD's 9 with COGMEN's 8 relations: ids >= 8 are ignored, as PyG's loop over
+    range(num_relations) does) keeps the unfused exact-fp32 graph kernels between the split projection and the split weight
+    gradients: same tolerances."""
+    from erc_amd.cogmen import COGMENModule
+    case = cogmen_case(B=6, min_len=4, max_len=25, dims=dict(a=12, t=20, v=16), seed=11, n_speakers=3)
+    res = run_cogmen_parity(case, compute=compute, kink_aware=(compute == "f32x2"))
+    assert res["logit_err"] < LOGIT_TOL and res["loss_err"] < 1e-5, res
+    assert res["grad_err"] < GRAD_TOL, sorted(res["grad_errs"].items(), key=lambda kv: -kv[1])[:6]
+    m = COGMENModule(case["D"], 100, 17, 3, case["n_classes"], compute=compute).finalize(DEV)
+    assert not m.fused_graph and m.shadows is not None
