@@ -68,7 +68,7 @@ def _probe_candidates(module, params, host_batch, trainer):
     N = sum(lens)
     if module == "cogmen":
         pl = trainer.model._last_ws["planner"]
-        recs = pl.deferred + pl.deferred16
+        recs = pl.flushed + pl.deferred + pl.deferred16
         fl = sum(2.0 * d[6] * d[7] * d[8] for d in recs)
         # operands of every dW = A^T B record read once + the gradient written once: K*M*sizeof(A) + K*N*sizeof(B) + M*N*4
         wg_bytes = sum(d[8] * d[6] * d[0].element_size() + d[8] * d[7] * d[2].element_size() + d[6] * d[7] * 4.0

@@ -84,6 +84,11 @@ _SIGS = {
     "erc_bn_lrelu_bwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "erc_cross_entropy": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp]),
     "erc_head_ce_stats_floats": (C.c_int64, [_i]),
+    "erc_dgcn_tail_max_rows": (C.c_int, []),
+    "erc_dgcn_tail_set_stamps": (C.c_int, [_vp]),
+    "erc_dgcn_tail_max_window": (C.c_int, []),
+    "erc_dgcn_tail_stats_floats": (C.c_int64, [_i]),
+    "erc_dgcn_tail": (C.c_int, [_vp, _i, _i64, _vp, _vp, _vp, _i] + [_vp] * 9 + [_i, _i, _f, _vp, _vp, _i] + [_vp] * 7 + [_i] + [_vp] * 4),
     "erc_head_ce": (C.c_int, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "erc_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _i64, _i64,
                                 _vp, _vp]),
@@ -1060,6 +1065,27 @@ def wgrad_slab_floats():
 
 def wgrad_max_k_per_split():
     return int(lib().erc_wgrad_max_k_per_split())
+
+
+def dgcn_tail_limits():
+    """(max rows, max window) of erc_dgcn_tail"""
+    return int(lib().erc_dgcn_tail_max_rows()), int(lib().erc_dgcn_tail_max_window())
+
+
+def dgcn_tail_set_stamps(stamps):
+    _check(lib().erc_dgcn_tail_set_stamps(ptr(stamps)), "erc_dgcn_tail_set_stamps")
+
+
+def dgcn_tail_stats_floats(n_rows):
+    return int(lib().erc_dgcn_tail_stats_floats(n_rows))
+
+
+def dgcn_tail(slabs, n_slabs, slab_stride, rgcn_bias, g, window, W_rel, b_rel, W_root, W1, b1, W2, b2, labels, weight, n_classes,
+              n_rows, drop_p, rng, Xc, ldx, Hc, AGG, Zc, logits, dlogits, dZc, dXc, lddx, dAGG, dHc, stats):
+    """DialogueGCN: RGCN slab sum .. GraphConv .. classifier .. cross entropy .. dXc, dAGG, dHc in one launch (include/ercgraft.h)"""
+    _call("erc_dgcn_tail", slabs, n_slabs, int(slab_stride), rgcn_bias, g["in_ptr"], g["in_src"], window, W_rel, b_rel, W_root, W1,
+          b1, W2, b2, labels, weight, n_classes, n_rows, float(drop_p), rng, Xc, ldx, Hc, AGG, Zc, logits, dlogits, dZc, dXc, lddx,
+          dAGG, dHc, stats)
 
 
 def head_ce_stats_floats(n_rows):

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from . import capi
-from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
+from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, SideStream, all_reduce_grads, linear_fwd, linear_wgrad, \
     matmul_wgrad_io
 from .rnn import BiLSTM2, lstm_groups
 
@@ -89,6 +89,9 @@ class DGCNModule(nn.Module):
         # basis space: aggregate + Z @ basis + x @ root as one tile launch (erc_brgcn_fwd_tile), and the node side of the
         # backward likewise (erc_brgcn_bwd_source_tile); False = the separate kernels + GEMMs (tests compare the two)
         self.fused_rgcn_fwd = True
+        # training step: the RGCN slab sum, GraphConv, the classifier, the loss and their backward down to dXc / dAGG / dHc as one
+        # launch (erc_dgcn_tail) instead of nine; False = the separate kernels (tests compare the two)
+        self.fused_tail = True
         self.drop_p = float(dropout)
         self.rnn = _SeqContext(input_size, hidden_size, dropout)
         self.edge_att = _EdgeAtt(hidden_size)
@@ -113,6 +116,7 @@ class DGCNModule(nn.Module):
         self.flat = FlatParams(self.live_groups(), device)
         self.lstm = BiLSTM2(self.flat, "rnn.rnn.", self.input_size, drop_p=self.drop_p)
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
+        self.side = SideStream()
         if self.relation_space is None:
             self.relation_space = self.R <= capi.rrgcn_max_relations()
         return self
@@ -134,7 +138,7 @@ class DGCNModule(nn.Module):
         g = dict(node_off=i32(B + 1), node_row=i32(N), node_spk=i32(N), in_ptr=i32(N + 1), in_src=i32(E),
                  in_typ=i32(E), out_ptr=i32(N + 1), out_dst=i32(E), out_typ=i32(E), out_eid=i32(E), counts=i32(2))
         ws = dict(g=g, E=E, rnn_out=f32(BT, G_DIM), Xc=f32(N, G_DIM + H1), ATT=f32(N, G_DIM), norm=f32(E),
-                  Z=f32(N, self._kb * G_DIM), Hc=f32(N, H1), AGG=f32(N, H1), Zc=f32(N, 100), logits=f32(N, C), stats=torch.zeros(max(256, capi.head_ce_stats_floats(N)), dtype=torch.float32, device=device),
+                  Z=f32(N, self._kb * G_DIM), Hc=f32(N, H1), AGG=f32(N, H1), Zc=f32(N, 100), logits=f32(N, C), stats=torch.zeros(max(256, capi.head_ce_stats_floats(N), capi.dgcn_tail_stats_floats(N)), dtype=torch.float32, device=device),
                   dlogits=f32(N, C), dZc=f32(N, 100), dXc=f32(N, G_DIM + H1), dAGG=f32(N, H1), dHc=f32(N, H1),
                   dZ=f32(N, self._kb * G_DIM), dnorm=f32(E), TT=f32(E, NB), U=f32(N, self._kb * H1),
                   basisT=f32(self._kb * H1, G_DIM), Wr=f32(self._kb * G_DIM, H1), dWr=f32(self._kb * G_DIM, H1),
@@ -158,7 +162,11 @@ class DGCNModule(nn.Module):
         N = int(label.shape[0]) if label is not None else (int(n_nodes) if n_nodes is not None else int(lens.sum().item()))
         return B, T, N
 
-    def _forward_impl(self, x, spk, lens, B, T, N, training, with_logits=True):
+    def _tail_ok(self, N):
+        max_rows, max_win = capi.dgcn_tail_limits()
+        return self.fused_tail and self.n_classes <= 8 and N <= max_rows and 0 <= self.wp <= max_win and 0 <= self.wf <= max_win
+
+    def _forward_impl(self, x, spk, lens, B, T, N, training, with_logits=True, tail=False):
         fp = self.flat
         ws = self._workspace(B, T, N, x.device)
         g, pl = ws["g"], ws["planner"]
@@ -190,6 +198,9 @@ class DGCNModule(nn.Module):
             # aggregate + basis product + root product in one tile launch (csrc/dgcn_ops.hip), partial slabs
             capi.brgcn_fwd_tile(Xc, XW, G_DIM, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB, Wz, fp.w("gcn.conv1.root"),
                                 ws["Z"], ws["rgcn_slabs"])
+            ws["tail_src"] = (ws["rgcn_slabs"], capi.brgcn_fwd_tile_slabs(), N * H1)
+            if tail:
+                return ws      # the slab sum and everything behind it: erc_dgcn_tail (loss_and_grads)
             capi.slab_reduce(ws["rgcn_slabs"], capi.brgcn_fwd_tile_slabs(), N * H1, fp.w("gcn.conv1.bias"), H1, 0, ws["Hc"],
                              N * H1)
         else:
@@ -201,6 +212,9 @@ class DGCNModule(nn.Module):
             capi.gemm_f32(ws["Z"], K1, 0, None, Wz, H1, 1, None, pl.ws[src:], H1, N, H1, K1,
                           split_k=S1, c_slab=N * H1)
             capi.gemm_f32(Xc, XW, 0, None, fp.w("gcn.conv1.root"), H1, 1, None, pl.ws[src + S1 * N * H1:], H1, N, H1, G_DIM)
+            ws["tail_src"] = (pl.ws[src:], S1 + 1, N * H1)
+            if tail:
+                return ws
             capi.slab_reduce(pl.ws[src:], S1 + 1, N * H1, fp.w("gcn.conv1.bias"), H1, 0, ws["Hc"], N * H1)
         # GraphConv: W_rel * sum_{j->i} h_j + b + W_root h_i, written next to the features
         capi.csr_sum(ws["Hc"], H1, H1, N, g["in_ptr"], g["in_src"], ws["AGG"], H1)
@@ -229,13 +243,21 @@ class DGCNModule(nn.Module):
         B, T, N = self._shape(x, lens, ys)
         training = self.training
         fused_tail = self.n_classes <= 8
-        ws = self._forward_impl(x, spk, lens, B, T, N, training, with_logits=not fused_tail)
+        tail = self._tail_ok(N)
+        ws = self._forward_impl(x, spk, lens, B, T, N, training, with_logits=not fused_tail, tail=tail)
         fp, g, pl, off = self.flat, ws["g"], ws["planner"], self.flat.offsets
         C, BT, XW = self.n_classes, B * T, G_DIM + H1
         Xc, dXc = ws["Xc"], ws["dXc"]
         p = self.drop_p if training else 0.0
         # classifier
-        if fused_tail:
+        if tail:
+            slabs, n_slabs, stride = ws["tail_src"]
+            capi.dgcn_tail(slabs, n_slabs, stride, fp.w("gcn.conv1.bias"), g, max(self.wp, self.wf),
+                           fp.w("gcn.conv2.lin_rel.weight"), fp.w("gcn.conv2.lin_rel.bias"), fp.w("gcn.conv2.lin_root.weight"),
+                           fp.w("clf.lin1.weight"), fp.w("clf.lin1.bias"), fp.w("clf.lin2.weight"), fp.w("clf.lin2.bias"), ys,
+                           class_weight, C, N, p, self.rng_state, Xc, XW, ws["Hc"], ws["AGG"], ws["Zc"], ws["logits"], ws["dlogits"],
+                           ws["dZc"], dXc, XW, ws["dAGG"], ws["dHc"], ws["stats"])
+        elif fused_tail:
             # lin2 + cross entropy + their backward through the ReLU / dropout mask in one launch (dgcn_models.py:163-170)
             capi.head_ce(ws["Zc"], 100, 100, C, N, fp.w("clf.lin2.weight"), fp.w("clf.lin2.bias"), ys, class_weight,
                          1.0 / (1.0 - p), ws["logits"], C, ws["dlogits"], C, ws["dZc"], 100, ws["stats"])
@@ -244,15 +266,18 @@ class DGCNModule(nn.Module):
             capi.gemm_f32(ws["dlogits"], C, 0, None, fp.w("clf.lin2.weight"), 100, 1, None, ws["dZc"], 100, N, 100, C,
                           act=2, aux=ws["Zc"], ldaux=100, act_scale=1.0 / (1.0 - p))
         linear_wgrad(pl, ws["dlogits"], C, ws["Zc"], 100, None, C, 100, N, off["clf.lin2.weight"], off["clf.lin2.bias"], defer=True)
-        capi.gemm_f32(ws["dZc"], 100, 0, None, fp.w("clf.lin1.weight"), XW, 1, None, dXc, XW, N, XW, 100)
+        if not tail:
+            capi.gemm_f32(ws["dZc"], 100, 0, None, fp.w("clf.lin1.weight"), XW, 1, None, dXc, XW, N, XW, 100)
         linear_wgrad(pl, ws["dZc"], 100, Xc, XW, None, 100, XW, N, off["clf.lin1.weight"], off["clf.lin1.bias"], defer=True)
         # GraphConv
         dG = dXc[:, G_DIM:]
-        capi.gemm_f32(dG, XW, 0, None, fp.w("gcn.conv2.lin_rel.weight"), H1, 1, None, ws["dAGG"], H1, N, H1, H1)
+        if not tail:
+            capi.gemm_f32(dG, XW, 0, None, fp.w("gcn.conv2.lin_rel.weight"), H1, 1, None, ws["dAGG"], H1, N, H1, H1)
         linear_wgrad(pl, dG, XW, ws["AGG"], H1, None, H1, H1, N, off["gcn.conv2.lin_rel.weight"],
                      off["gcn.conv2.lin_rel.bias"], defer=True)
         linear_wgrad(pl, dG, XW, ws["Hc"], H1, None, H1, H1, N, off["gcn.conv2.lin_root.weight"], None, defer=True)
-        capi.gemm_f32(dG, XW, 0, None, fp.w("gcn.conv2.lin_root.weight"), H1, 1, None, ws["dHc"], H1, N, H1, H1)
+        if not tail:
+            capi.gemm_f32(dG, XW, 0, None, fp.w("gcn.conv2.lin_root.weight"), H1, 1, None, ws["dHc"], H1, N, H1, H1)
         capi.csr_sum(ws["dAGG"], H1, H1, N, g["out_ptr"], g["out_dst"], ws["dHc"], H1, accumulate=1)
         # RGCNConv(basis)
         KB = self._kb
@@ -295,6 +320,11 @@ class DGCNModule(nn.Module):
         linear_wgrad(pl, ws["DATT"], G_DIM, Xc, XW, None, G_DIM, G_DIM, N, off["edge_att.weight"], None, defer=True)
         capi.gemm_f32(ws["DATT"], G_DIM, 0, None, fp.w("edge_att.weight"), G_DIM, 1, None, dXc, XW, N, G_DIM, G_DIM,
                       accumulate=1)
+        # the weight gradients of everything behind the BiLSTM (classifier, graph layers, EdgeAtt) do not wait for its backward
+        # scans, which occupy 2 B of the 256 CUs: their launch goes to a second stream (ERC_SIDE_STREAM=1)
+        if self.side.enabled:
+            with self.side.fork():
+                pl.flush_wgrads(ws, tag="_early")
         # back to the padded rows and through the BiLSTM
         if self.compact_lstm:
             self.lstm.backward(pl, dXc, XW)
@@ -303,6 +333,7 @@ class DGCNModule(nn.Module):
             capi.gather_rows(dXc, XW, g["node_row"], N, G_DIM, ws["drnn"], G_DIM, scatter=1)
             self.lstm.backward(pl, ws["drnn"], G_DIM)
         pl.reduce_into(ws, fp.grad)
+        self.side.join()
         if self.relation_space:
             capi.basis_decompose(fp.w("gcn.conv1.att"), fp.w("gcn.conv1.basis"), ws["dWr"], self.R, NB, G_DIM * H1,
                                  fp.g("gcn.conv1.basis"), fp.g("gcn.conv1.att"))

@@ -142,6 +142,22 @@ def _world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+class _Tagged:
+    """view of a workspace dict whose keys carry a suffix"""
+
+    def __init__(self, d, tag):
+        self.d, self.tag = d, tag
+
+    def get(self, k, default=None):
+        return self.d.get(k + self.tag, default)
+
+    def __getitem__(self, k):
+        return self.d[k + self.tag]
+
+    def __setitem__(self, k, v):
+        self.d[k + self.tag] = v
+
+
 class GemmPlanner:
     """Chooses split-K per GEMM and hands out slab space from one workspace."""
 
@@ -161,6 +177,7 @@ class GemmPlanner:
         self.jobs = []
         self.max_numel = 0
         self.deferred = []     # (A, lda, B, ldb, C, ldc, M, N, K, ones, bias_out): one batched launch at the end
+        self.flushed = []      # ... the records of this step that were launched already (bench.py counts their FLOPs)
         self.deferred16 = []   # bf16 compute mode: records of the bf16 weight-gradient launch (defer16)
         self.ranges16 = []     # ... and finished gradient ranges its fused optimizer has to cover (defer16_range)
         self.adam_fused = False
@@ -176,15 +193,19 @@ class GemmPlanner:
 
     WG_STEPS = 64   # k-steps (4 k each) per work item: 16 per wavefront (measured best of 48..128 on COGMEN B=32)
 
-    def flush_wgrads(self, cache):
-        """Run every deferred K-major x K-major weight-gradient product as ONE launch (erc_wgrad_table, csrc/wgrad.hip).
+    def flush_wgrads(self, cache, tag=""):
+        """Run every weight-gradient product deferred so far as ONE launch (erc_wgrad_table, csrc/wgrad.hip) and forget them.
         The descriptor table, the partial-tile slabs and the per-tile arrival counters are built on the first call
-        and reused (operands live in fixed workspace buffers)."""
+        and reused (operands live in fixed workspace buffers); ``tag`` keeps the tables of a step's several flushes apart
+        (an early flush on a side stream: DGCNModule.loss_and_grads)."""
         if not self.deferred:
             return
         import struct
+        deferred, self.deferred = self.deferred, []
+        self.flushed += deferred
+        cache = _Tagged(cache, tag)
         key = tuple((a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, g.data_ptr() if g is not None else 0, sc, mb)
-                    for a, _, b, _, c, _, M, N, K, _, _, g, sc, mb in self.deferred)
+                    for a, _, b, _, c, _, M, N, K, _, _, g, sc, mb in deferred)
         if cache.get("wgrad_key") != key:
             cap = capi.wgrad_max_k_per_split()
             raw, items, tiles, bases = [], 0, 0, []
@@ -195,9 +216,9 @@ class GemmPlanner:
                 # slots: COGMEN, DialogueGCN); with several rounds of items the per-item overhead (LDS reduce, slab, arrival)
                 # is paid per round, and longer items win (measured: MMGCN 4.68 -> 4.47 ms, DAG-ERC 3.80 -> 3.71 ms at 256)
                 n64 = sum(-(-M // 64) * -(-N // 64) * max(1, min(32, (-(-K // 4) + 32) // 64))
-                          for _, _, _, _, _, _, M, N, K, _, _, _, _, _ in self.deferred)
+                          for _, _, _, _, _, _, M, N, K, _, _, _, _, _ in deferred)
                 steps = self.WG_STEPS if n64 <= 1152 else 256
-            for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g, sc, mb in self.deferred:
+            for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g, sc, mb in deferred:
                 bf16 = b.dtype == torch.bfloat16
                 a_bf16 = a.dtype == torch.bfloat16
                 if (not a_bf16 and a.dtype != torch.float32) or c.dtype != torch.float32 or \
@@ -233,9 +254,9 @@ class GemmPlanner:
             import ctypes
             cache["wgrad_bases"] = (ctypes.c_int32 * len(bases))(*bases)
             cache["wgrad_key"] = key
-            cache["wgrad_x3"] = any(d[13] == 2 for d in self.deferred)
+            cache["wgrad_x3"] = any(d[13] == 2 for d in deferred)
         (capi.wgrad_table_x3 if cache["wgrad_x3"] else capi.wgrad_table)(
-            cache["wgrad_table"], len(self.deferred), cache["wgrad_bases"], cache["wgrad_items"], cache["wgrad_slabs"],
+            cache["wgrad_table"], len(deferred), cache["wgrad_bases"], cache["wgrad_items"], cache["wgrad_slabs"],
             cache["wgrad_counters"])
 
     # ------------------------------------------------------------------ bf16 weight gradients (csrc/wgrad_bf16.hip)

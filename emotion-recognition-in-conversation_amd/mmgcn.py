@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import capi
-from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, all_reduce_grads, linear_fwd, linear_wgrad, \
+from .engine import WorkspaceCache, FlatParams, FusedAdam, GemmPlanner, SideStream, all_reduce_grads, linear_fwd, linear_wgrad, \
     matmul_wgrad_io
 from .rnn import BiLSTM2, lstm_groups
 
@@ -127,6 +127,7 @@ class MMGCNModule(nn.Module):
         self.flat = FlatParams(self.live_groups(), device)
         self.lstm = BiLSTM2(self.flat, "lstm_l.", FD, drop_p=DROP) if "t" in self.order else None
         self.rng_state = torch.tensor([0, self._seed], dtype=torch.int64, device=device)
+        self.side = SideStream()
         return self
 
     @property
@@ -361,6 +362,11 @@ class MMGCNModule(nn.Module):
                 matmul_wgrad_io(pl, HD[l], FD, ws["DZl"][:, (l - 1) * FD:], LDS, FD, FD, R3, off[Wn], None, defer=True, scale=th)
                 matmul_wgrad_io(pl, ws["_H0"], FD, ws["DGl"][:, (l - 1) * FD:], LDS, FD, FD, R3, off[Wn] + FD * FD, None,
                                 defer=True, scale=th)
+            if self.side.enabled:
+                # nothing but the optimizer waits for the 128 weight gradients of the chain: second stream (ERC_SIDE_STREAM=1),
+                # next to the rest of the backward, whose BiLSTM scans occupy 2 B of the 256 CUs
+                with self.side.fork():
+                    pl.flush_wgrads(ws, tag="_early")
             # dA = sum_l dg_l z_l^T on the block structure (and its cross-modal entries)
             if ws["gemm_x3"]:     # the planes of a row are contiguous: one K = 64 * 200 contraction per block
                 capi.gemm_x3_grouped(ws["DGl"], LDS, ws["ZS"], LDS, ws["dADJs"], P, ws["node_off"], B, Mo, N, T, LDS,
@@ -415,6 +421,7 @@ class MMGCNModule(nn.Module):
             linear_wgrad(pl, dlin, FD, x, self.dims[m], None, FD, self.dims[m], TB, off[_LIN[m] + ".weight"],
                          off[_LIN[m] + ".bias"])
         pl.reduce_into(ws, fp.grad)
+        self.side.join()
         return ws["stats"]
 
 

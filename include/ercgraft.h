@@ -906,6 +906,26 @@ int erc_transpose_batched(const float* in, int nb, int rows, int cols, float* ou
 int erc_csr_sum(const float* x, int ldx, int F, int N, const int32_t* ptr, const int32_t* idx, float* out, int ldo,
                 int accumulate, void* stream);
 
+/* DialogueGCN's tail in ONE launch (csrc/dgcn_tail.hip): Hc = sum of the RGCN partial outputs slabs[s * slab_stride + i] + bias
+ * (models/rgcn.py:345-355), GraphConv graph_out = W_rel sum_{j->i} Hc_j + b + W_root Hc_i written to Xc[:, 200:300)
+ * (dgcn_models.py:42,46), Classifier lin1 + ReLU + inverted dropout + lin2 on [features | graph_out] (dgcn_models.py:163-170),
+ * (class-weighted) F.cross_entropy (dgcn.py:124; stats as erc_head_ce) and the backward down to dXc [N,300] and the row-local
+ * GraphConv gradients dAGG = dG W_rel, dHc = dG W_root (the scatter over the out-edges is erc_csr_sum(accumulate) afterwards).
+ * Replaces erc_slab_reduce + erc_csr_sum + 3 forward GEMMs + erc_head_ce + 3 backward GEMMs.  The in-CSR's sources of a row lie
+ * within `window` <= erc_dgcn_tail_max_window() rows of it; n_rows <= erc_dgcn_tail_max_rows(); n_classes <= 8; dropout draws
+ * erc_uniform(seed, offset, row * 100 + column) like erc_gemm_f32_stream's act 3.  stats: >= erc_dgcn_tail_stats_floats(n_rows)
+ * floats, zero-initialised once.  Exact fp32 products (v_mfma_f32_16x16x4_f32). */
+int erc_dgcn_tail_max_rows(void);
+int erc_dgcn_tail_set_stamps(uint64_t* stamps);   /* diagnostic: 16 x uint64 phase stamps (10 ns ticks) of workgroup 0; NULL = off */
+int erc_dgcn_tail_max_window(void);
+int64_t erc_dgcn_tail_stats_floats(int n_rows);
+int erc_dgcn_tail(const float* slabs, int n_slabs, int64_t slab_stride, const float* rgcn_bias, const int32_t* in_ptr,
+                  const int32_t* in_src, int window, const float* W_rel, const float* b_rel, const float* W_root,
+                  const float* W1, const float* b1, const float* W2, const float* b2, const int64_t* labels,
+                  const float* weight, int n_classes, int n_rows, float drop_p, const uint64_t* rng, float* Xc, int ldx,
+                  float* Hc, float* AGG, float* Zc, float* logits, float* dlogits, float* dZc, float* dXc, int lddx,
+                  float* dAGG, float* dHc, float* stats, void* stream);
+
 /* ------------------------------------------------------------------------
  * MMGCN (track_mm/mmgcn.py:56-123, track_mm/mmgcn_models.py:8-39,344-394,493-646).  Node rows are
  * modality-major: node (m, i) = m*N + i, i = node_off[b] + t, in the modality order [a, v, l] of

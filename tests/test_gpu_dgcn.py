@@ -336,6 +336,49 @@ def test_dgcn_fused_rgcn_equals_separate_kernels():
         assert e < 1e-3, (n, e)
 
 
+@pytest.mark.parametrize("speakers,dims,C,B,max_len,weights,drop", [
+    (9, dict(a=300, t=600, v=342), 7, 8, 33, False, 0.0),      # MELD shape, basis space (the tile launches' slabs)
+    (9, dict(a=300, t=600, v=342), 7, 32, 33, False, 0.4),     # the benched batch, dropout on (same counter-based masks)
+    (2, dict(a=100, t=100, v=512), 6, 6, 60, True, 0.0),       # two speakers: relation space (GEMM slabs), class weights
+    (2, dict(a=100, t=100, v=512), 6, 3, 17, True, 0.4),       # N not a multiple of 16, a tile that spans three dialogues
+    (2, dict(a=100, t=100, v=512), 4, 1, 1, False, 0.0),       # one utterance
+], ids=["meld-b8", "meld-b32-dropout", "iemocap-weighted", "ragged-weighted-dropout", "one-utterance"])
+def test_dgcn_fused_tail_equals_separate_kernels(speakers, dims, C, B, max_len, weights, drop, monkeypatch):
+    """erc_dgcn_tail (RGCN slab sum .. GraphConv .. classifier .. cross entropy .. dXc / dAGG / dHc in one launch) against the
+    nine launches it replaces: same module, same batch, same dropout counters."""
+    from erc_amd import capi
+    from erc_amd.dgcn import DGCNModule, IEMOCAP6_WEIGHTS
+    from tests.util_cases import poison_lds_before
+    poison_lds_before(monkeypatch, "dgcn_tail")
+    batch = to_device(make_batch(B, dims, n_speakers=speakers, n_classes=C, min_len=1, max_len=max_len, seed=43,
+                                 force_max=max_len > 1), DEV)
+    cw = torch.tensor(IEMOCAP6_WEIGHTS, dtype=torch.float32, device=DEV) if weights else None
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(8)
+        m = DGCNModule(speakers, input_size=sum(dims.values()), hidden_size=200, n_classes=C)
+        m.fused_tail = fused
+        m.finalize(DEV)
+        m.train()
+        m.drop_p, m.lstm.drop_p = drop, 0.0
+        calls = []
+        orig = capi.dgcn_tail
+        monkeypatch.setattr(capi, "dgcn_tail", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        stats = m.loss_and_grads(batch, cw).clone().cpu()
+        monkeypatch.setattr(capi, "dgcn_tail", orig)
+        assert len(calls) == (1 if fused else 0)
+        ws = m._last_ws
+        outs.append((stats, {k: ws[k].clone().cpu() for k in ("logits", "Xc", "Hc", "AGG", "Zc", "dlogits", "dZc", "dXc", "dHc")}, m))
+    (sa, a, ma), (sb, b, mb) = outs
+    assert abs(float(sa[0] - sb[0])) < 1e-5 and float(sa[1]) == float(sb[1]) and abs(float(sa[2] - sb[2])) < 1e-4 * float(sb[2])
+    assert torch.equal(a["Zc"] > 0, b["Zc"] > 0) or float(((a["Zc"] > 0) != (b["Zc"] > 0)).float().mean()) < 1e-3
+    for k in a:
+        assert rel_err(a[k], b[k]) < 2e-5, (k, rel_err(a[k], b[k]))
+    for n in ma.flat.params:
+        e = rel_err(ma.flat.g(n).cpu(), mb.flat.g(n).cpu())
+        assert e < 1e-4, (n, e)
+
+
 def _pair(case, compute="f32"):
     from oracle.dgcn import DGCNOracle
     from erc_amd.dgcn import DGCNModule

@@ -30,7 +30,7 @@ def main():
     tr.train_step(batch)
     rec = capi.stop_recording()
     torch.cuda.synchronize()
-    call = [e for e in rec if e[0] in ("erc_wgrad_bf16", "erc_wgrad_bf16_adam", "erc_wgrad_split", "erc_wgrad_split_adam")][0]
+    call = [e for e in rec if e[0] in ("erc_wgrad_bf16", "erc_wgrad_bf16_wide", "erc_wgrad_bf16_adam", "erc_wgrad_split", "erc_wgrad_split_adam")][0]
     print(call[0])
     n_items = call[1][4 if "split" in call[0] else 3]
     labels = ["first loads issued (A, gather stage, B)", "K loop", "LDS reduce + slab stores issued", "slab drained", "arrival ticket"]
