@@ -302,11 +302,8 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, g = lane >> 4;
-    // WIDE: the column-tile group is the fast index -- the workgroups that read the SAME k rows of the record's 100-wide operand are
-    // neighbours in the (XCD-remapped, see wgrad_bf16_kernel) launch order and share one XCD's L2
-    const int n_cg = WIDE ? d.n_items / d.splits : 1;
-    const int split = WIDE ? local / n_cg : local % d.splits;
-    const int tn = WIDE ? 4 * (local % n_cg) + w : local / d.splits;     // WIDE: the column tile of THIS wavefront (may be >= tiles_n)
+    const int split = local % d.splits;
+    const int tn = WIDE ? 4 * (local / d.splits) + w : local / d.splits;     // WIDE: the column tile of THIS wavefront (may be >= tiles_n)
     const int n0 = tn * 64;
     const int nks = (d.K + 3) >> 2;
     const int per = (nks + d.splits - 1) / d.splits;
@@ -914,7 +911,7 @@ __device__ __forceinline__ void w2_body(const W2Desc& d, const int local, float*
     if (!WIDE) {
         finish(tn, 1.f);
     } else {
-        const int tg = 4 * (local % n_cg);
+        const int tg = 4 * (local / d.splits);
         for (int t = 0; t < 4 && tg + t < d.tiles_n; ++t) {
             if (t) __syncthreads();        // the previous tile's readers of red / bred / s_flag are done
             finish(tg + t, w == t ? 1.f : 0.f);
@@ -933,9 +930,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const W2Desc* __restric
     __shared__ float bred[4 * 192];
     __shared__ int idx[W2_IDX_CAP];
     __shared__ int s_flag;
-    // WIDE: workgroup b runs on XCD b % 8; work item (b % 8) * (grid / 8) + b / 8 gives every XCD a contiguous range of items, so the
-    // column-tile groups of one (record, split) -- readers of the same A rows -- meet in one L2 (the grid is a multiple of 8)
-    const int L = WIDE ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int L = blockIdx.x;
     int di = 0;
 #pragma unroll
     for (int t = 1; t < W2_MAX_DESC; ++t)
@@ -995,7 +990,7 @@ static int w2_launch(int mode, const void* table, int n_desc, const int32_t* ite
         hipLaunchKernelGGL((wgrad_bf16_kernel<true, false, 1>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
                            bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
     else if (mode == 2)
-        hipLaunchKernelGGL((wgrad_bf16_kernel<false, true, 1>), dim3((n_items + 7) / 8 * 8), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
+        hipLaunchKernelGGL((wgrad_bf16_kernel<false, true, 1>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
                            bases, slabs, counters, g_w2_stamps, g_w2_stamp_item, ad);
     else
         hipLaunchKernelGGL((wgrad_bf16_kernel<false, false, 1>), dim3(n_items), dim3(256), 0, (hipStream_t)stream, (const W2Desc*)table, n_desc,
