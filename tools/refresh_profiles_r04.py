@@ -23,7 +23,7 @@ KERNELS = {
     "mmgcn": {"gcnii_chain_kernel<false": "gcnii_chain_fwd", "gcnii_chain_kernel<true": "gcnii_chain_bwd", "gemm_x3_kernel": "gemm_x3",
               "lstm_fwd_kernel": "lstm_fwd", "lstm_bwd_kernel": "lstm_bwd", "wgrad_table": "wgrad_table"},
     "dgcn": {"lstm_fwd_kernel": "lstm_fwd", "lstm_bwd_kernel": "lstm_bwd", "brgcn_fwd_tile_kernel": "brgcn_fwd_tile",
-             "brgcn_bwd_source_tile_kernel": "brgcn_bwd_source_tile", "brgcn_bwd_target_tile_kernel": "brgcn_bwd_target_tile", "wgrad_table": "wgrad_table"},
+             "brgcn_bwd_source_tile_kernel": "brgcn_bwd_source_tile", "brgcn_bwd_target_tile_kernel": "brgcn_bwd_target_tile", "wgrad_table": "wgrad_table", "dgcn_tail_kernel": "dgcn_tail"},
 }
 
 
