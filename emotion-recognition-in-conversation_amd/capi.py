@@ -123,6 +123,8 @@ _SIGS = {
     "erc_edge_att_fwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "erc_edge_att_bwd_parts": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_int64, _vp, _i, _i,
                                          _vp, _i, _vp, _vp]),
+    "erc_edge_att_bwd_fused": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_int64, _vp, _i, _i,
+                                        _vp, _i, _vp, _vp, _i, C.c_int64, _vp, _vp, _vp, _vp, _i, _vp]),
     "erc_edge_att_bwd": (C.c_int, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i,
                                    _vp, _vp]),
     "erc_brgcn_agg_fwd": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -708,6 +710,17 @@ def edge_att_bwd(x, ldx, att, lda, F, N, g, norm, dnorm, dx, lddx, accumulate_dx
                                         ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_eid"]), ptr(norm), ptr(dnorm),
                                         dn_parts, dn_stride, ptr(dx), lddx, accumulate_dx, ptr(datt), ldda, ptr(dscore),
                                         stream()), "erc_edge_att_bwd_parts")
+
+
+def edge_att_bwd_fused(x, ldx, att, lda, F, N, g, norm, dnorm, dx, lddx, accumulate_dx, datt, ldda, dscore, dn_parts=1, dn_stride=0,
+                       dx_slabs=None, n_dx_slabs=0, dx_slab_stride=0, rs_TT=None, rs_datt=None, rs_R=0):
+    """edge_att_bwd + (dx_slabs) the slab sum of erc_brgcn_bwd_source_tile into dx + (rs_TT) the relation sums d att of
+    erc_brgcn_bwd_edges_tile(datt=None), all inside the source-side launch"""
+    _check(lib().erc_edge_att_bwd_fused(ptr(x), ldx, ptr(att), lda, F, N, ptr(g["in_ptr"]), ptr(g["in_src"]),
+                                        ptr(g["out_ptr"]), ptr(g["out_dst"]), ptr(g["out_eid"]), ptr(norm), ptr(dnorm),
+                                        dn_parts, dn_stride, ptr(dx), lddx, accumulate_dx, ptr(datt), ldda, ptr(dscore),
+                                        ptr(dx_slabs), n_dx_slabs, int(dx_slab_stride), ptr(rs_TT), ptr(g["in_typ"]),
+                                        ptr(g["counts"]), ptr(rs_datt), rs_R, stream()), "erc_edge_att_bwd_fused")
 
 
 def brgcn_agg_fwd(x, ldx, F, N, g, norm, att, nb, Z):

@@ -75,6 +75,16 @@ __global__ __launch_bounds__(256) void edge_att_fwd_kernel(const float* __restri
     }
 }
 
+__device__ __forceinline__ void rel_sum_body(const int r, const float* __restrict__ TT, const int32_t* __restrict__ typ,
+                                             const int32_t* __restrict__ counts, float* __restrict__ datt);
+
+// what erc_edge_att_bwd_fused folds into the source-side launch (all optional)
+struct EdgeBwdExtra {
+    const float* dx_slabs; int n_dx_slabs; int64_t dx_slab_stride;     // dx_j += sum_s dx_slabs[s * stride + j * F + c] (the RGCN backward's partial feature gradients)
+    const float* rs_TT; const int32_t* rs_typ; const int32_t* rs_counts; float* rs_datt; int rs_R;   // rs_R extra workgroups: d att[r, :] = sum_{e: type r} TT[e, :]
+    int node_blocks;
+};
+
 // source side of the backward: ds_e = a_e (dnorm_e - sum a dnorm); dx_j = sum_e ds_e att_dst(e)
 __global__ __launch_bounds__(256) void edge_att_bwd_source_kernel(const float* __restrict__ att, int lda, int F, int N,
                                                                   const int32_t* __restrict__ out_ptr,
@@ -83,7 +93,11 @@ __global__ __launch_bounds__(256) void edge_att_bwd_source_kernel(const float* _
                                                                   const float* __restrict__ norm,
                                                                   const float* __restrict__ dnorm, float* __restrict__ dx,
                                                                   int lddx, float* __restrict__ dscore, int accumulate,
-                                                                  int dn_parts, int64_t dn_stride) {
+                                                                  int dn_parts, int64_t dn_stride, const EdgeBwdExtra ex) {
+    if ((int)blockIdx.x >= ex.node_blocks) {      // (uniform per workgroup) the relation sums of the RGCN backward ride along
+        rel_sum_body((int)blockIdx.x - ex.node_blocks, ex.rs_TT, ex.rs_typ, ex.rs_counts, ex.rs_datt);
+        return;
+    }
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j >= N) return;
     const int e0 = out_ptr[j], e1 = out_ptr[j + 1];
@@ -116,6 +130,16 @@ __global__ __launch_bounds__(256) void edge_att_bwd_source_kernel(const float* _
         }
     }
     float* d = dx + (int64_t)j * lddx;
+    if (ex.dx_slabs) {      // (uniform) partial feature gradients of erc_brgcn_bwd_source_tile, summed in slab order as erc_slab_reduce
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int sl = 0; sl < ex.n_dx_slabs; ++sl) {
+            const float* ps = ex.dx_slabs + sl * ex.dx_slab_stride + (int64_t)j * F;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) part[u] += ps[min(lane + 64 * u, F - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc.v[u] += part[u];
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
         if (lane + 64 * u < F) d[lane + 64 * u] = accumulate ? d[lane + 64 * u] + acc.v[u] : acc.v[u];
@@ -277,9 +301,9 @@ __global__ __launch_bounds__(256) void brgcn_bwd_target_kernel(const float* __re
 // thread, 120 us for E = 14 k edges; this one 1/10 of that.)
 constexpr int RS_CAP = 2048;  // matching edges kept per wavefront; more fall back to the scan-and-add path
 
-__global__ __launch_bounds__(256) void rel_sum_kernel(const float* __restrict__ TT, const int32_t* __restrict__ typ,
-                                                      const int32_t* __restrict__ counts, float* __restrict__ datt) {
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+__device__ __forceinline__ void rel_sum_body(const int r, const float* __restrict__ TT, const int32_t* __restrict__ typ,
+                                             const int32_t* __restrict__ counts, float* __restrict__ datt) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int E = counts[1];
     if (E <= 0) {
         if (tid < NB) datt[r * NB + tid] = 0.f;
@@ -334,6 +358,11 @@ __global__ __launch_bounds__(256) void rel_sum_kernel(const float* __restrict__ 
         for (int k = 0; k < 8; ++k) s += sh[k][b];
         datt[r * NB + b] = s;
     }
+}
+
+__global__ __launch_bounds__(256) void rel_sum_kernel(const float* __restrict__ TT, const int32_t* __restrict__ typ,
+                                                      const int32_t* __restrict__ counts, float* __restrict__ datt) {
+    rel_sum_body(blockIdx.x, TT, typ, counts, datt);
 }
 
 // U[j, b*O + c] = sum_{e out of j} norm_e att[type_e, b] dH[dst_e, c]   (O <= 128 output channels)
@@ -1100,6 +1129,14 @@ extern "C" int erc_edge_att_bwd_parts(const float* x, int ldx, const float* att,
                                       int64_t dn_stride, float* dx, int lddx, int accumulate_dx, float* datt, int ldda,
                                       float* dscore, void* stream);
 
+extern "C" int erc_edge_att_bwd_fused(const float* x, int ldx, const float* att, int lda, int F, int N, const int32_t* in_ptr,
+                                      const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                      const int32_t* out_eid, const float* norm, const float* dnorm, int dn_parts,
+                                      int64_t dn_stride, float* dx, int lddx, int accumulate_dx, float* datt, int ldda,
+                                      float* dscore, const float* dx_slabs, int n_dx_slabs, int64_t dx_slab_stride,
+                                      const float* rs_TT, const int32_t* rs_typ, const int32_t* rs_counts, float* rs_datt,
+                                      int rs_R, void* stream);
+
 extern "C" int erc_edge_att_bwd(const float* x, int ldx, const float* att, int lda, int F, int N, const int32_t* in_ptr,
                                 const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
                                 const int32_t* out_eid, const float* norm, const float* dnorm, float* dx, int lddx,
@@ -1117,8 +1154,30 @@ extern "C" int erc_edge_att_bwd_parts(const float* x, int ldx, const float* att,
     ERC_REQUIRE(x && att && in_ptr && in_src && out_ptr && out_dst && out_eid && norm && dnorm && dx && datt && dscore,
                 "edge_att_bwd: null pointer");
     ERC_REQUIRE(N > 0 && F > 0 && F <= 256, "edge_att_bwd: N=%d F=%d", N, F);
-    hipLaunchKernelGGL(edge_att_bwd_source_kernel, NODE_GRID(N), att, lda, F, N, out_ptr, out_dst, out_eid, norm, dnorm,
-                       dx, lddx, dscore, accumulate_dx, dn_parts, dn_stride);
+    return erc_edge_att_bwd_fused(x, ldx, att, lda, F, N, in_ptr, in_src, out_ptr, out_dst, out_eid, norm, dnorm, dn_parts, dn_stride, dx,
+                                  lddx, accumulate_dx, datt, ldda, dscore, nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int erc_edge_att_bwd_fused(const float* x, int ldx, const float* att, int lda, int F, int N, const int32_t* in_ptr,
+                                      const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                      const int32_t* out_eid, const float* norm, const float* dnorm, int dn_parts,
+                                      int64_t dn_stride, float* dx, int lddx, int accumulate_dx, float* datt, int ldda,
+                                      float* dscore, const float* dx_slabs, int n_dx_slabs, int64_t dx_slab_stride,
+                                      const float* rs_TT, const int32_t* rs_typ, const int32_t* rs_counts, float* rs_datt,
+                                      int rs_R, void* stream) {
+    ERC_REQUIRE(dn_parts >= 1 && (dn_parts == 1 || dn_stride > 0), "edge_att_bwd: dn_parts=%d", dn_parts);
+    ERC_REQUIRE(x && att && in_ptr && in_src && out_ptr && out_dst && out_eid && norm && dnorm && dx && datt && dscore,
+                "edge_att_bwd: null pointer");
+    ERC_REQUIRE(N > 0 && F > 0 && F <= 256, "edge_att_bwd: N=%d F=%d", N, F);
+    ERC_REQUIRE(!dx_slabs || (n_dx_slabs >= 1 && dx_slab_stride >= (int64_t)N * F), "edge_att_bwd_fused: %d slabs of stride %lld",
+                n_dx_slabs, (long long)dx_slab_stride);
+    ERC_REQUIRE(!rs_TT || (rs_typ && rs_counts && rs_datt && rs_R > 0), "edge_att_bwd_fused: relation sums need typ, counts, datt, R");
+    EdgeBwdExtra ex{};
+    ex.dx_slabs = dx_slabs, ex.n_dx_slabs = n_dx_slabs, ex.dx_slab_stride = dx_slab_stride;
+    ex.rs_TT = rs_TT, ex.rs_typ = rs_typ, ex.rs_counts = rs_counts, ex.rs_datt = rs_datt, ex.rs_R = rs_TT ? rs_R : 0;
+    ex.node_blocks = (N + 3) / 4;
+    hipLaunchKernelGGL(edge_att_bwd_source_kernel, dim3(ex.node_blocks + ex.rs_R), dim3(256), 0, (hipStream_t)stream, att, lda, F, N,
+                       out_ptr, out_dst, out_eid, norm, dnorm, dx, lddx, dscore, accumulate_dx, dn_parts, dn_stride, ex);
     ERC_LAUNCH_CHECK("edge_att_bwd_source");
     hipLaunchKernelGGL(edge_att_bwd_target_kernel, NODE_GRID(N), x, ldx, F, N, in_ptr, in_src, dscore, datt, ldda);
     ERC_LAUNCH_CHECK("edge_att_bwd_target");
@@ -1225,7 +1284,7 @@ extern "C" int erc_brgcn_bwd_edges_tile(const float* x, int ldx, int F, int O, i
                                         const float* norm, const float* att, int num_bases, const float* basis,
                                         const float* dH, int lddh, float* TT, float* dn_slabs, int64_t dn_stride,
                                         float* datt, void* stream) {
-    ERC_REQUIRE(x && in_ptr && in_src && in_typ && counts && norm && att && basis && dH && TT && dn_slabs && datt,
+    ERC_REQUIRE(x && in_ptr && in_src && in_typ && counts && norm && att && basis && dH && TT && dn_slabs,
                 "brgcn_bwd_edges_tile: null pointer");
     ERC_REQUIRE(num_bases == NB && F == TF && O == TO && N > 0 && R > 0 && lddh % 4 == 0 && dn_stride > 0,
                 "brgcn_bwd_edges_tile: built for %d bases, F = %d, O = %d", NB, TF, TO);
@@ -1243,8 +1302,10 @@ extern "C" int erc_brgcn_bwd_edges_tile(const float* x, int ldx, int F, int O, i
     hipLaunchKernelGGL(brgcn_bwd_target_tile_kernel, dim3(erc_cdiv(N, 16), NGRP), dim3(512), lds, (hipStream_t)stream, x, ldx, N,
                        in_ptr, in_src, in_typ, norm, att, basis, dH, lddh, TT, dn_slabs, dn_stride, g_brgcn_stamps ? g_brgcn_stamps + 8 : nullptr);
     ERC_LAUNCH_CHECK("brgcn_bwd_target_tile");
-    hipLaunchKernelGGL(rel_sum_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, TT, in_typ, counts, datt);
-    ERC_LAUNCH_CHECK("rel_sum");
+    if (datt) {      // (NULL: the caller sums TT per relation inside a later launch -- erc_edge_att_bwd_fused)
+        hipLaunchKernelGGL(rel_sum_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, TT, in_typ, counts, datt);
+        ERC_LAUNCH_CHECK("rel_sum");
+    }
     return ERC_OK;
 }
 

@@ -92,6 +92,8 @@ class DGCNModule(nn.Module):
         # training step: the RGCN slab sum, GraphConv, the classifier, the loss and their backward down to dXc / dAGG / dHc as one
         # launch (erc_dgcn_tail) instead of nine; False = the separate kernels (tests compare the two)
         self.fused_tail = True
+        # ... and the RGCN backward's slab sum into dXc + its relation sums (d att) inside EdgeAtt's backward launch
+        self.fused_edge_bwd = True
         self.drop_p = float(dropout)
         self.rnn = _SeqContext(input_size, hidden_size, dropout)
         self.edge_att = _EdgeAtt(hidden_size)
@@ -295,7 +297,7 @@ class DGCNModule(nn.Module):
                 E_cap = ws["E"]
                 capi.brgcn_bwd_edges_tile(Xc, XW, G_DIM, H1, N, self.R, g, ws["norm"], fp.w("gcn.conv1.att"), NB,
                                           fp.w("gcn.conv1.basis"), ws["dHc"], H1, ws["TT"], ws["dn_slabs"], E_cap,
-                                          fp.g("gcn.conv1.att"))
+                                          None if self.fused_edge_bwd else fp.g("gcn.conv1.att"))
                 dn_src, dn_parts, dn_stride = ws["dn_slabs"], capi.brgcn_fwd_tile_slabs(), E_cap      # summed by edge_att_bwd
             else:
                 capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.basis"), H1, 0, None, ws["dZ"], K1, N, K1, H1)
@@ -310,13 +312,21 @@ class DGCNModule(nn.Module):
             # dXc += sum_b U_b basis_b^T + dHc root^T: one tile launch + the slab sum added into dXc
             capi.brgcn_bwd_source_tile(ws["dHc"], H1, G_DIM, H1, N, g, ws["norm"], fp.w("gcn.conv1.att"), NB,
                                        fp.w("gcn.conv1.basis"), fp.w("gcn.conv1.root"), ws["rgcn_dslabs"])
-            capi.slab_reduce(ws["rgcn_dslabs"], capi.brgcn_fwd_tile_slabs(), N * G_DIM, None, G_DIM, 4, dXc, N * G_DIM, ld_out=XW)
+            if not self.fused_edge_bwd:
+                capi.slab_reduce(ws["rgcn_dslabs"], capi.brgcn_fwd_tile_slabs(), N * G_DIM, None, G_DIM, 4, dXc, N * G_DIM, ld_out=XW)
         else:
             capi.gemm_f32(ws["U"], KB * H1, 0, None, ws["basisT"], G_DIM, 1, None, dXc, XW, N, G_DIM, KB * H1, accumulate=1)
             capi.gemm_f32(ws["dHc"], H1, 0, None, fp.w("gcn.conv1.root"), H1, 0, None, dXc, XW, N, G_DIM, H1, accumulate=1)
         # EdgeAtt
-        capi.edge_att_bwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"], dn_src, dXc, XW, 1, ws["DATT"], G_DIM,
-                          ws["dscore"], dn_parts=dn_parts, dn_stride=dn_stride)
+        if self.fused_edge_bwd and self.fused_rgcn_fwd and not self.relation_space:
+            # + the slab sum of the RGCN backward's feature gradients and its relation sums (d att), inside the source-side launch
+            capi.edge_att_bwd_fused(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"], dn_src, dXc, XW, 1, ws["DATT"], G_DIM,
+                                    ws["dscore"], dn_parts=dn_parts, dn_stride=dn_stride, dx_slabs=ws["rgcn_dslabs"],
+                                    n_dx_slabs=capi.brgcn_fwd_tile_slabs(), dx_slab_stride=N * G_DIM, rs_TT=ws["TT"],
+                                    rs_datt=fp.g("gcn.conv1.att"), rs_R=self.R)
+        else:
+            capi.edge_att_bwd(Xc, XW, ws["ATT"], G_DIM, G_DIM, N, g, ws["norm"], dn_src, dXc, XW, 1, ws["DATT"], G_DIM,
+                              ws["dscore"], dn_parts=dn_parts, dn_stride=dn_stride)
         linear_wgrad(pl, ws["DATT"], G_DIM, Xc, XW, None, G_DIM, G_DIM, N, off["edge_att.weight"], None, defer=True)
         capi.gemm_f32(ws["DATT"], G_DIM, 0, None, fp.w("edge_att.weight"), G_DIM, 1, None, dXc, XW, N, G_DIM, G_DIM,
                       accumulate=1)

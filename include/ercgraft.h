@@ -839,6 +839,18 @@ int erc_edge_att_bwd_parts(const float* x, int ldx, const float* att, int lda, i
                            const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
                            const float* norm, const float* dnorm, int dn_parts, int64_t dn_stride, float* dx, int lddx,
                            int accumulate_dx, float* datt, int ldda, float* dscore, void* stream);
+/* erc_edge_att_bwd_parts with two more jobs of DialogueGCN's backward inside its source-side launch (both optional):
+ *  - dx_slabs != NULL: dx[j, c] += sum_s dx_slabs[s * dx_slab_stride + j * F + c], the partial feature gradients of
+ *    erc_brgcn_bwd_source_tile (replaces erc_slab_reduce(mode 4));
+ *  - rs_TT != NULL: rs_R extra workgroups form rs_datt[r, :30] = sum_{e: rs_typ[e] == r} rs_TT[e, :30], the relation sums
+ *    behind erc_brgcn_bwd_edges_tile called with datt = NULL (d att, models/rgcn.py:330; rs_counts[1] = #edges). */
+int erc_edge_att_bwd_fused(const float* x, int ldx, const float* att, int lda, int F, int N,
+                           const int32_t* in_ptr, const int32_t* in_src,
+                           const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_eid,
+                           const float* norm, const float* dnorm, int dn_parts, int64_t dn_stride, float* dx, int lddx,
+                           int accumulate_dx, float* datt, int ldda, float* dscore, const float* dx_slabs, int n_dx_slabs,
+                           int64_t dx_slab_stride, const float* rs_TT, const int32_t* rs_typ, const int32_t* rs_counts,
+                           float* rs_datt, int rs_R, void* stream);
 /* basis-decomposed RGCNConv with edge_norm, add aggregation (models/rgcn.py:329-355), num_bases = 30:
  *   Z[i, b*F + c] = sum_{e into i} norm_e att[type_e, b] x[src_e, c]      so that
  *   conv(x) = Z @ basis.view(30F, out) + x @ root + bias                  (two GEMMs by the caller). */

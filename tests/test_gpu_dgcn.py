@@ -358,6 +358,7 @@ def test_dgcn_fused_tail_equals_separate_kernels(speakers, dims, C, B, max_len, 
         torch.manual_seed(8)
         m = DGCNModule(speakers, input_size=sum(dims.values()), hidden_size=200, n_classes=C)
         m.fused_tail = fused
+        m.fused_edge_bwd = fused     # + the RGCN backward's slab sum and relation sums inside EdgeAtt's backward launch
         m.finalize(DEV)
         m.train()
         m.drop_p, m.lstm.drop_p = drop, 0.0
