@@ -409,19 +409,26 @@ __device__ __forceinline__ void wgrad_body(const WgDesc& d, const int local, flo
     }
 }
 
-struct WgBases {  // first work item of every descriptor, passed by value (no dependent table reads to find one's descriptor)
-    int v[WG_MAX_DESC];
+// Which descriptor a work item belongs to, passed by value (no dependent table reads to find one's descriptor).  A RUN is a
+// stretch of consecutive descriptors with the same number of work items (MMGCN: the 128 weight gradients of the GCNII chain are
+// one run), so a launch takes WG_MAX_DESC runs, not WG_MAX_DESC descriptors -- MMGCN's 133 records were five launches, each with
+// its own partly filled last round of work items.
+struct WgRuns {
+    int first_item[WG_MAX_DESC];   // first work item of the run
+    int first_desc[WG_MAX_DESC];   // its first descriptor (index into the whole table)
+    int per[WG_MAX_DESC];          // work items per descriptor
 };
 
 template <bool X3>
-__device__ __forceinline__ void wgrad_dispatch(const WgDesc* __restrict__ table, const int n_desc, const WgBases& bases,
+__device__ __forceinline__ void wgrad_dispatch(const WgDesc* __restrict__ table, const int n_runs, const WgRuns& runs,
                                                const int item_offset, float* slabs, int* counters, float* red, float* bred, int* idx,
                                                int* s_flag) {
     const int L = blockIdx.x + item_offset;
-    int di = 0;
+    int ri = 0;
 #pragma unroll
     for (int t = 1; t < WG_MAX_DESC; ++t)
-        if (t < n_desc && L >= bases.v[t]) di = t;
+        if (t < n_runs && L >= runs.first_item[t]) ri = t;
+    const int di = runs.first_desc[ri] + (L - runs.first_item[ri]) / runs.per[ri];
     const WgDesc d = table[di];
     const int local = L - d.item_base;
     if (local >= d.n_items) return;
@@ -445,7 +452,7 @@ __device__ __forceinline__ void wgrad_dispatch(const WgDesc* __restrict__ table,
 }
 
 __global__ __launch_bounds__(256, 3) void wgrad_table_kernel(const WgDesc* __restrict__ table, const int n_desc,
-                                                          const WgBases bases, const int item_offset, float* slabs,
+                                                          const WgRuns bases, const int item_offset, float* slabs,
                                                           int* counters) {
     __shared__ float red[4 * 2048];
     __shared__ float bred[4 * 64];
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_table_kernel(const WgDesc* __res
 // The same launch with the three-term bf16 split available (records with mma_bf16 == 2): its operand fragments need ~220
 // registers, i.e. two workgroups per CU instead of three.
 __global__ __launch_bounds__(256, 2) void wgrad_table_x3_kernel(const WgDesc* __restrict__ table, const int n_desc,
-                                                             const WgBases bases, const int item_offset, float* slabs,
+                                                             const WgRuns bases, const int item_offset, float* slabs,
                                                              int* counters) {
     __shared__ float red[4 * 2048];
     __shared__ float bred[4 * 64];
@@ -479,18 +486,26 @@ static int wgrad_table_launch(bool x3, const void* table, int n_desc, const int3
     for (int t = 0; t < n_desc; ++t)
         ERC_REQUIRE(item_base[t] >= 0 && item_base[t] < n_items && (t == 0 ? item_base[0] == 0 : item_base[t] > item_base[t - 1]),
                     "wgrad_table: item_base[%d] = %d", t, item_base[t]);
-    // the kernel finds a block's descriptor from by-value bases: at most WG_MAX_DESC descriptors per launch
-    for (int t0 = 0; t0 < n_desc; t0 += WG_MAX_DESC) {
-        const int nd = n_desc - t0 < WG_MAX_DESC ? n_desc - t0 : WG_MAX_DESC;
-        WgBases bases{};
-        for (int t = 0; t < nd; ++t) bases.v[t] = item_base[t0 + t];
-        const int end = t0 + nd < n_desc ? item_base[t0 + nd] : n_items;
+    // the kernel finds a work item's descriptor from by-value runs: at most WG_MAX_DESC runs per launch
+    int t = 0;
+    while (t < n_desc) {
+        WgRuns runs{};
+        int nr = 0;
+        const int first = item_base[t];
+        while (t < n_desc && nr < WG_MAX_DESC) {
+            const int per = (t + 1 < n_desc ? item_base[t + 1] : n_items) - item_base[t];
+            runs.first_item[nr] = item_base[t], runs.first_desc[nr] = t, runs.per[nr] = per;
+            ++t;
+            while (t < n_desc && (t + 1 < n_desc ? item_base[t + 1] : n_items) - item_base[t] == per) ++t;
+            ++nr;
+        }
+        const int end = t < n_desc ? item_base[t] : n_items;
         if (x3)
-            hipLaunchKernelGGL(wgrad_table_x3_kernel, dim3(end - item_base[t0]), dim3(256), 0, (hipStream_t)stream,
-                               (const WgDesc*)table + t0, nd, bases, item_base[t0], slabs, counters);
+            hipLaunchKernelGGL(wgrad_table_x3_kernel, dim3(end - first), dim3(256), 0, (hipStream_t)stream, (const WgDesc*)table, nr, runs,
+                               first, slabs, counters);
         else
-            hipLaunchKernelGGL(wgrad_table_kernel, dim3(end - item_base[t0]), dim3(256), 0, (hipStream_t)stream,
-                               (const WgDesc*)table + t0, nd, bases, item_base[t0], slabs, counters);
+            hipLaunchKernelGGL(wgrad_table_kernel, dim3(end - first), dim3(256), 0, (hipStream_t)stream, (const WgDesc*)table, nr, runs,
+                               first, slabs, counters);
         ERC_LAUNCH_CHECK("wgrad_table");
     }
     return ERC_OK;

@@ -217,7 +217,9 @@ class GemmPlanner:
                 # is paid per round, and longer items win (measured: MMGCN 4.68 -> 4.47 ms, DAG-ERC 3.80 -> 3.71 ms at 256)
                 n64 = sum(-(-M // 64) * -(-N // 64) * max(1, min(32, (-(-K // 4) + 32) // 64))
                           for _, _, _, _, _, _, M, N, K, _, _, _, _, _ in deferred)
-                steps = self.WG_STEPS if n64 <= 1152 else 256
+                # (round 4, one launch for all of MMGCN's records: 128 / 256 / 512 / 1024 steps -> 3.45 / 3.41 / 3.35 / 3.35 ms;
+                #  DAG-ERC 256 / 512 / 1024 -> 3.55 / 3.52 / 3.50 ms)
+                steps = self.WG_STEPS if n64 <= 1152 else 512
             for a, lda, b, ldb, c, ldc, M, N, K, ones, bo, g, sc, mb in deferred:
                 bf16 = b.dtype == torch.bfloat16
                 a_bf16 = a.dtype == torch.bfloat16

@@ -456,6 +456,28 @@ def test_head_ce_matches_torch(capi, C, weighted, p):
     assert abs(float(st[0]) - float(loss.detach())) < 2e-5 and int(st[1]) == int((logits.argmax(-1) == y).sum())
 
 
+def test_wgrad_table_runs_of_equal_records_and_more_than_32_runs(capi):
+    """erc_wgrad_table finds a work item's record from by-value RUNS of equally sized records (MMGCN: the 128 weight gradients of
+    the GCNII chain in one launch): 36 records of one shape followed by 40 records of 40 different sizes = 41 runs, two launches."""
+    from erc_amd.engine import GemmPlanner
+    g = torch.Generator().manual_seed(78)
+    pl = GemmPlanner(DEV, 16)
+    shapes = [(300, 40, 24)] * 36 + [(64 + 7 * i, 8 + 3 * i, 70 + i) for i in range(40)]
+    refs = []
+    for K, M, N in shapes:
+        A = torch.randn(K, M, generator=g).to(DEV)
+        Bd = torch.randn(K, N, generator=g).to(DEV)
+        Cm = torch.full((M, N), float("nan"), device=DEV)
+        pl.defer(A, M, Bd, N, Cm, N, M, N, K, 0, None)
+        refs.append((Cm, _gemm_ref(A.cpu().t(), Bd.cpu()), K))
+    cache = {}
+    pl.flush_wgrads(cache)
+    torch.cuda.synchronize()
+    assert int(cache["wgrad_counters"].abs().sum()) == 0
+    for Cm, ref, K in refs:
+        _close(Cm, ref, 3e-4 * math.sqrt(max(K, 100) / 100))
+
+
 def test_wgrad_table(capi):
     """erc_wgrad_table: several dW = A^T B[gather] products in one launch (fp32 / bf16 B, bias strips, vector and
     scalar access paths, split and unsplit K), launched twice to check that the arrival counters are left zero."""
