@@ -511,27 +511,42 @@ __global__ __launch_bounds__(CNT) void gcnii_chain_kernel(Chain p) {
     else chain_body<BWD, 2>(p, smem, b, L, nparts, m, part, RW);
 }
 
-// V_l = theta W_l[:200] + (1 - theta)(1 - alpha) I in both orientations, U_l = theta W_l[200:] + (1 - theta) alpha I
+// V_l = theta W_l[:200] + (1 - theta)(1 - alpha) I in both orientations, U_l = theta W_l[200:] + (1 - theta) alpha I.
+// One workgroup per (32 x 32 tile, layer): the two W tiles are read once with n contiguous, V / U go out directly, VT / UT through
+// an LDS transpose -- every access coalesced.  (The first version read W a second time with k contiguous -- 800-byte strides,
+// cache hits -- for the transposed outputs: 52 us for 61 MB; this one is bound by those bytes.)
+constexpr int PT = 32;                       // tile edge
+constexpr int PNT = (FD + PT - 1) / PT;      // 7 tiles per dimension
 __global__ __launch_bounds__(256) void gcnii_prep_kernel(const float* __restrict__ W, int64_t w_stride, float lamda, float alpha,
                                                          float* __restrict__ VT, float* __restrict__ V, float* __restrict__ U,
                                                          float* __restrict__ UT) {
+    __shared__ float sv[PT][PT + 1], su[PT][PT + 1];
     const int l = blockIdx.y;                 // 0-based layer
+    const int k0 = (blockIdx.x / PNT) * PT, n0 = (blockIdx.x % PNT) * PT;
     const float theta = logf(lamda / (float)(l + 1) + 1.f);
     const float* Wl = W + l * w_stride;
-    // pass 1: the outputs with n contiguous (V, U) -- coalesced reads and writes
-    for (int x = blockIdx.x * 256 + threadIdx.x; x < FD * FD; x += gridDim.x * 256) {
-        const int k = x / FD, n = x % FD;
-        const float d = k == n ? 1.f : 0.f;
-        V[((int64_t)l * FD + k) * KP + n] = theta * Wl[k * FD + n] + (1.f - theta) * (1.f - alpha) * d;
-        U[(int64_t)k * NL * FD + l * FD + n] = theta * Wl[(FD + k) * FD + n] + (1.f - theta) * alpha * d;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads, four rows each
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + ty + 8 * r, n = n0 + tx;
+        float v = 0.f, u = 0.f;
+        if (k < FD && n < FD) {
+            const float d = k == n ? 1.f : 0.f;
+            v = theta * Wl[k * FD + n] + (1.f - theta) * (1.f - alpha) * d;
+            u = theta * Wl[(FD + k) * FD + n] + (1.f - theta) * alpha * d;
+            V[((int64_t)l * FD + k) * KP + n] = v;
+            U[(int64_t)k * NL * FD + l * FD + n] = u;
+        }
+        sv[ty + 8 * r][tx] = v, su[ty + 8 * r][tx] = u;
     }
-    // pass 2: the outputs with k contiguous (VT, UT): the 320 KB of the layer are read again (strided, cache hits), the writes
-    // are coalesced (one pass with n-contiguous threads wrote VT / UT with a stride of 800 bytes: 32 -> 71 us with UT added)
-    for (int x = blockIdx.x * 256 + threadIdx.x; x < FD * FD; x += gridDim.x * 256) {
-        const int n = x / FD, k = x % FD;
-        const float d = k == n ? 1.f : 0.f;
-        VT[((int64_t)l * FD + n) * KP + k] = theta * Wl[k * FD + n] + (1.f - theta) * (1.f - alpha) * d;
-        if (UT) UT[((int64_t)l * FD + n) * FD + k] = theta * Wl[(FD + k) * FD + n] + (1.f - theta) * alpha * d;   // B operand of Call = h0 UT^T
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int n = n0 + ty + 8 * r, k = k0 + tx;
+        if (k < FD && n < FD) {
+            VT[((int64_t)l * FD + n) * KP + k] = sv[tx][ty + 8 * r];
+            if (UT) UT[((int64_t)l * FD + n) * FD + k] = su[tx][ty + 8 * r];   // B operand of Call = h0 UT^T
+        }
     }
     // the pad columns 200..207 of V / VT stay zero (zero-filled by the caller once)
 }
@@ -564,7 +579,7 @@ bool chain_ensure_lds(K kernel, int lds) {
 extern "C" int erc_gcnii_chain_prep(const float* W, int64_t w_stride, float lamda, float alpha, float* VT, float* V, float* U,
                                     float* UT, void* stream) {
     ERC_REQUIRE(W && VT && V && U && w_stride >= 2 * FD * FD, "gcnii_chain_prep: bad arguments");
-    hipLaunchKernelGGL(gcnii_prep_kernel, dim3(8, NL), dim3(256), 0, (hipStream_t)stream, W, w_stride, lamda, alpha, VT, V, U, UT);
+    hipLaunchKernelGGL(gcnii_prep_kernel, dim3(PNT * PNT, NL), dim3(256), 0, (hipStream_t)stream, W, w_stride, lamda, alpha, VT, V, U, UT);
     ERC_LAUNCH_CHECK("gcnii_chain_prep");
     return ERC_OK;
 }
