@@ -429,7 +429,20 @@ def main():
                 out = fb()
                 exchange_and_update()
                 return out
-            step = GraphedStep(whole)
+            try:
+                step = GraphedStep(whole)
+            except Exception as exc:      # (every rank runs the same capture: they fail together or not at all)
+                # an RCCL build that cannot be captured into a HIP graph: the round-1 structure -- forward + backward as a graph,
+                # the collective and the optimizer behind it eagerly -- instead of no line at all
+                sys.stderr.write("bench: capturing the whole N > 1 step failed (%s: %s); the collective runs eagerly behind the "
+                                 "captured forward + backward\n" % (type(exc).__name__, exc))
+                torch.cuda.synchronize()
+                fb_g = GraphedStep(fb)
+
+                def step():
+                    out = fb_g()
+                    exchange_and_update()
+                    return out
 
     def barrier():
         if dp:
