@@ -667,7 +667,12 @@ def main():
                                                      "test_cogmen_bf16_mode_vs_unrounded_fp32_reference_config2)")
         print(json.dumps(line))
     if dp:
-        torch.distributed.destroy_process_group()
+        # Leave without tearing the process group down: the captured step graphs hold RCCL work, and destroying the group under
+        # them aborted at interpreter exit once in a while (rc 134 AFTER the line was printed).  Every rank has printed / passed
+        # the last barrier; os._exit skips destructors and atexit hooks (the profiling runs of tools/ are single-rank).
+        sys.stdout.flush(), sys.stderr.flush()
+        barrier()
+        os._exit(0)
 
 
 if __name__ == "__main__":
