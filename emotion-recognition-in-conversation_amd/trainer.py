@@ -513,5 +513,12 @@ def run(trainer_cls, params_cls, argv=None):
         from . import checkpoint
         checkpoint.save(trainer, params.save)
     if world > 1:
+        # the captured step graphs hold RCCL work: they go before the process group does (bench.py saw an abort at interpreter
+        # exit, once in a while, with the group torn down under live graphs)
+        graphs = resident = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     return best
