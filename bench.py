@@ -273,6 +273,19 @@ WORKLOADS = {
 }
 
 
+def assert_no_skipped_steps(model, what):
+    """A number measured over steps whose update was skipped (a bounded wait of a persistent kernel ran into its bound) or only
+    partly applied is not a measurement of the step: no line, rc 4."""
+    if not hasattr(model, "check_cluster"):
+        return
+    try:
+        model.check_cluster()
+    except Exception as exc:
+        print("bench.py: %s -- %s: %s" % (what, type(exc).__name__, exc), file=sys.stderr)
+        sys.stderr.flush()
+        os._exit(4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -467,6 +480,7 @@ def main():
     else:
         total_utt, rccl_ranks = float(n_utt), 1
     stats = trainer.model._last_ws["stats"].cpu().tolist()
+    assert_no_skipped_steps(trainer.model, "timed region (%s, %s)" % (args.module, args.dtype))
 
     # ---------------------------------------------------------------- roofline: dominant kernel (HIP events) + whole step
     roof = None
@@ -542,6 +556,7 @@ def main():
         torch.cuda.synchronize()
         el8 = time.perf_counter() - t0
         n8 = max(1, args.steps // S) * S
+        assert_no_skipped_steps(trainer.model, "multi-step graph")
         multi = {"steps_per_graph": S, "steps": n8, "ms_per_step": 1e3 * el8 / n8, "value": n_utt * n8 / el8, "unit": "utterances/s"}
         del step8
 
@@ -569,6 +584,7 @@ def main():
                 st()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
+            assert_no_skipped_steps(tr.model, "timed region (cogmen, %s)" % compute)
             out = {"dtype": compute, "ms_per_step": 1e3 * el / args.steps, "value": n_utt * args.steps / el, "unit": "utterances/s",
                    "steps": args.steps, "warmup": args.warmup, "loss": tr.model._last_ws["stats"].cpu().tolist()[0],
                    "launches_per_step": None}
